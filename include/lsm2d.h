@@ -1,0 +1,194 @@
+/*
+ * lsm2d.h -- C ABI of the MI355X-native 2D scan-matching core (liblsm2d_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of rvp-group/srrg2_laser_slam_2d: the per-scan inner loop
+ * "correspondence search + plane-to-plane ICP Gauss-Newton step" that the reference runs through
+ *   - CorrespondenceFinder_<Isometry2f, PointNormal2fVectorCloud, PointNormal2fVectorCloud>
+ *     (srrg2_laser_slam_2d/src/srrg2_laser_slam_2d/registration/correspondence_finder_normal_2f.h:9-13),
+ *   - AlignerSliceProcessorLaser2D[WithSensor]  (registration/aligner_slice_processor_laser_2d.h:7-42),
+ *   - MultiAligner2D (upstream; driven as in apps/visual_test_aligner_2d.cpp:123-156).
+ * Paths below are relative to srrg2_laser_slam_2d/src/srrg2_laser_slam_2d/ unless they start
+ * with apps/ or configurations/.
+ *
+ * Conventions (apps/visual_test_aligner_2d.cpp:126,145):
+ *   - a point is the PointNormal2f payload: 4 x fp32 (x, y, nx, ny), array-of-structs on the host side;
+ *   - a pose is float[3] = (x, y, theta) = geometry2d::t2v(Isometry2f), metres / radians;
+ *   - the estimate maps MOVING into FIXED (setMovingInFixed / setLocalMapInSensor);
+ *   - H is row-major 3x3 in the right-perturbation basis X <- X * v2t(dx).
+ * Plain pointers and sizes only; no exceptions cross this boundary: every entry point returns an
+ * lsm2d_status (0 = ok, < 0 = call-level error); per-alignment outcomes go to out_status[].
+ * One lsm2d_context = one device + one HIP stream; a context is not thread-safe, different contexts
+ * may be used concurrently.  Host buffers are borrowed for the duration of a call only.
+ */
+#ifndef LSM2D_H
+#define LSM2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSM2D_VERSION 100 /* 0.1.0 */
+
+/* ---- status codes -------------------------------------------------------------------------
+ * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
+ * registration/correspondence_finder_nn_2d.cpp:11-18) and the upstream aligner status enum. */
+typedef enum {
+  LSM2D_SUCCESS                    = 0,
+  LSM2D_NOT_ENOUGH_CORRESPONDENCES = 1,  /* per-alignment */
+  LSM2D_NOT_ENOUGH_INLIERS         = 2,  /* per-alignment */
+  LSM2D_SINGULAR_H                 = 3,  /* per-alignment */
+  LSM2D_BAD_ARGUMENT               = -1,
+  LSM2D_DEVICE_ERROR               = -2, /* a HIP call failed; lsm2d_last_error() has the text */
+  LSM2D_OUT_OF_MEMORY              = -3,
+  LSM2D_CAPACITY_EXCEEDED          = -4, /* output buffer too small / canvas too large for LDS */
+  LSM2D_NO_DEVICE                  = -5
+} lsm2d_status;
+
+/* ---- parameter blocks ----------------------------------------------------------------------
+ * PointNormal2fProjectorPolar parameters as the reference sets them
+ * (apps/synthetic_scene_generator.cpp:69-75; configurations/stage_segway_double_config_MULTI.json:71-97).
+ * Camera matrix convention [[cols/(angle_max-angle_min), cols/2],[0,1]]
+ * (apps/synthetic_scene_generator.cpp:59-66, sensor_processing/raw_data_preprocessor_projective_2d.cpp:83-90). */
+typedef struct {
+  int32_t canvas_cols;
+  float   angle_min, angle_max;  /* angle_col_min / angle_col_max [rad] */
+  float   range_min, range_max;  /* [m] */
+  float   col_offset;            /* column = floor(K00*atan2(y,x) + K01 + col_offset); 0 = truncate, 0.5 = nearest */
+} lsm2d_projector;
+
+typedef enum {
+  LSM2D_FINDER_PROJECTIVE = 0, /* CorrespondenceFinderProjective2f  (registration/correspondence_finder_projective_2d.cpp:18-77) */
+  LSM2D_FINDER_NN         = 1, /* CorrespondenceFinderKDTree2D      (registration/correspondence_finder_kd_tree_2d.cpp:5-38), exact NN */
+  LSM2D_FINDER_DISTMAP    = 2  /* CorrespondenceFinderNN2D          (registration/correspondence_finder_nn_2d.cpp:54-97) */
+} lsm2d_finder;
+
+typedef enum { LSM2D_ROBUST_NONE = 0, LSM2D_ROBUST_CAUCHY = 1 } lsm2d_robustifier;
+
+/* One aligner slice = finder + factor + robustifier, i.e. one AlignerSliceProcessorLaser2D[WithSensor]
+ * (registration/aligner_slice_processor_laser_2d.h:7-42) with the config fields of MULTI.json:160-188. */
+typedef struct {
+  int32_t         finder;                  /* lsm2d_finder */
+  lsm2d_projector projector;               /* projective finder: param_projector (.h:22-26) */
+  float           point_distance;          /* projective: param_point_distance, default 0.5 (.h:16-20) */
+  float           normal_cos;              /* all finders: param_normal_cos, default 0.8 */
+  float           max_distance;            /* NN / DISTMAP: param_max_distance_m (kd .h:23, nn .h:20-24) */
+  float           resolution;              /* DISTMAP: param_resolution [m/pixel] (nn .h:25-29) */
+  int32_t         robustifier;             /* lsm2d_robustifier (RobustifierCauchy, MULTI.json:153-158) */
+  float           chi_threshold;           /* Cauchy tau */
+  int32_t         min_num_correspondences; /* slice skipped when #pairs <= this (MULTI.json:179,391,591) */
+  float           sensor_in_robot[3];      /* WithSensor variant (registration/aligner_slice_processor_laser_2d_impl.cpp:7-10); zeros = plain */
+} lsm2d_slice_params;
+
+/* MultiAligner2D parameters (MULTI.json:700-732, :602-630) + GN damping (MULTI.json:254-259). */
+typedef struct {
+  int32_t max_iterations;
+  int32_t min_num_inliers;
+  float   damping;
+} lsm2d_aligner_params;
+
+/* Optional odometry-prior cue (AlignerSliceOdom2DPrior, MULTI.json:402-422): e = t2v(Z^-1 X), information omega. */
+typedef struct {
+  float z[3];
+  float omega[9];
+} lsm2d_prior;
+
+/* Correspondence(fixed_idx, moving_idx) (registration/correspondence_finder_kd_tree_2d.cpp:25) */
+typedef struct { int32_t fixed_idx, moving_idx; } lsm2d_correspondence;
+
+/* per-iteration statistics = what aligner->iterationStats() prints (apps/visual_test_aligner_2d.cpp:156) */
+typedef struct {
+  int32_t n_correspondences, n_inliers, n_outliers;
+  float   chi_inliers, chi_outliers;
+} lsm2d_iteration_stats;
+
+typedef struct lsm2d_context  lsm2d_context;
+typedef struct lsm2d_cloudset lsm2d_cloudset;
+
+/* ---- library / context ------------------------------------------------------------------------ */
+int         lsm2d_version(void);
+const char* lsm2d_status_string(int status);
+/* text of the last HIP failure seen by this context (or by the library when ctx == NULL) */
+const char* lsm2d_last_error(const lsm2d_context* ctx);
+/* hip_stream: an existing hipStream_t to launch on (e.g. the caller's torch stream), or NULL to own one */
+int  lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out_ctx);
+void lsm2d_destroy(lsm2d_context* ctx);
+/* blocks until everything queued on the context's stream has finished */
+int  lsm2d_synchronize(lsm2d_context* ctx);
+/* device time [ms] of the hot-path kernel launches of the most recent call (HIP events on the context's stream) */
+int  lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms);
+
+/* ---- clouds: device-resident ragged sets of PointNormal2fVectorCloud ---------------------------
+ * Replace: the raw non-owning PointNormal2fVectorCloud* the reference hands to setFixed / setMoving
+ * (apps/visual_test_correspondence_finder_projective_2d.cpp:74-75).  A set holds n_clouds clouds
+ * packed back to back; offsets[n_clouds+1] delimit them (NULL when n_clouds == 1).  The local map
+ * shared by a batch is a set with ONE cloud. */
+int  lsm2d_cloudset_create(lsm2d_context* ctx, const float* points_xynn, const int32_t* offsets,
+                           int32_t n_clouds, int64_t total_points, lsm2d_cloudset** out_set);
+/* same, from points already in device memory on ctx's device (float4 per point); offsets stay host */
+int  lsm2d_cloudset_create_from_device(lsm2d_context* ctx, const void* d_points_xynn, const int32_t* offsets,
+                                       int32_t n_clouds, int64_t total_points, lsm2d_cloudset** out_set);
+void lsm2d_cloudset_destroy(lsm2d_cloudset* set);
+int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* set);
+int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* set);
+
+/* ---- a3: PointNormal2fProjectorPolar::compute -------------------------------------------------
+ * One polar z-buffer pass of cloud `cloud_index` seen through `pose` (points are mapped by pose,
+ * i.e. pose = camera_pose^-1).  Outputs (host, each canvas_cols long; any may be NULL):
+ * source index or -1, depth, transformed point (x, y, nx, ny). */
+int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* projector, const lsm2d_cloudset* cloud,
+                  int32_t cloud_index, const float pose[3], int32_t* out_source_idx, float* out_depth,
+                  float* out_transformed_xynn);
+
+/* ---- plugin interface #1: CorrespondenceFinder_::compute ---------------------------------------
+ * Replaces compute() of the three finders (registration/correspondence_finder_projective_2d.cpp:18-77,
+ * registration/correspondence_finder_kd_tree_2d.cpp:5-38, registration/correspondence_finder_nn_2d.cpp:54-97)
+ * after setFixed / setMoving / setLocalMapInSensor / setCorrespondences.  Pairs come out in the
+ * reference's order (ascending column for PROJECTIVE, ascending moving index otherwise). */
+int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_params* slice,
+                               const lsm2d_cloudset* fixed, int32_t fixed_index,
+                               const lsm2d_cloudset* moving, int32_t moving_index,
+                               const float local_map_in_sensor[3],
+                               lsm2d_correspondence* out_pairs, int32_t capacity, int32_t* out_n_pairs);
+
+/* ---- factor: SE2Plane2PlaneErrorFactor over a correspondence vector ----------------------------
+ * Replaces the per-correspondence errorAndJacobian + robustifier + H/b accumulation of the
+ * correspondence-driven factor bound at registration/aligner_slice_processor_laser_2d.h:4,8
+ * (math: octave/solver/nicp_post.m:4-26,69-90). */
+int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* slice,
+                    const lsm2d_cloudset* fixed, int32_t fixed_index,
+                    const lsm2d_cloudset* moving, int32_t moving_index,
+                    const lsm2d_correspondence* pairs, int32_t n_pairs, const float pose[3],
+                    float out_H[9], float out_b[3], lsm2d_iteration_stats* out_stats);
+
+/* ---- plugin interface #2: MultiAligner2D::compute, batched --------------------------------------
+ * Replaces aligner->setFixed / setMoving / setMovingInFixed / compute / movingInFixed /
+ * iterationStats (apps/visual_test_aligner_2d.cpp:123-156) for n_alignments independent alignments
+ * (the tracker uses 1; MultiLoopDetectorBruteForce2D's candidate loop, MULTI.json:964-986, uses many).
+ * Each alignment runs max_iterations x { every slice: finder + factor ; one 3x3 solve ; right update }
+ * entirely on the device.  Cloud selection for alignment i, slice s: fixed[s] cloud
+ * fixed_index[s*n+i] (or i when fixed_index == NULL, or 0 when the set holds one cloud); same for moving. */
+typedef struct {
+  int32_t                       n_alignments;
+  int32_t                       n_slices;
+  const lsm2d_slice_params*     slices;        /* [n_slices] */
+  const lsm2d_cloudset* const*  fixed;         /* [n_slices] */
+  const lsm2d_cloudset* const*  moving;        /* [n_slices] */
+  const int32_t*                fixed_index;   /* [n_slices][n_alignments] or NULL */
+  const int32_t*                moving_index;  /* [n_slices][n_alignments] or NULL */
+  const float*                  init_pose;     /* [n_alignments][3]  setMovingInFixed */
+  const lsm2d_prior*            prior;         /* [n_alignments] or NULL */
+} lsm2d_batch;
+
+int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params* aligner, const lsm2d_batch* batch,
+                      float* out_pose,                  /* [n][3]  movingInFixed() */
+                      float* out_H,                     /* [n][9]  information matrix = H of the last iteration; may be NULL */
+                      int32_t* out_status,              /* [n]     lsm2d_status >= 0 */
+                      int32_t* out_iterations,          /* [n]     iterations started; may be NULL */
+                      lsm2d_iteration_stats* out_stats  /* [n][max_iterations]; may be NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSM2D_H */

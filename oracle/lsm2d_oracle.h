@@ -1,0 +1,150 @@
+/*
+ * lsm2d_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY) for the 2D scan-matching hot path of
+ * rvp-group/srrg2_laser_slam_2d.
+ *
+ * PARITY UNPINNED.  The arithmetic of this path lives in un-vendored, un-pinned upstream modules
+ * (srrg2_core, srrg2_solver, srrg2_slam_interfaces; reference package.xml:14-21) that are absent from
+ * the build container, and the reference's own tests hold no golden vector for the finders, the
+ * factor or the aligner.  This file is therefore a RESTATEMENT of the
+ * reference algorithm from the in-tree sources, cited per function:
+ *
+ *   finder (projective)  srrg2_laser_slam_2d/src/srrg2_laser_slam_2d/registration/correspondence_finder_projective_2d.cpp:18-77
+ *   finder (kd-tree/NN)  .../registration/correspondence_finder_kd_tree_2d.cpp:5-38
+ *   finder (dist. map)   .../registration/correspondence_finder_nn_2d.cpp:10-97
+ *   projector convention srrg2_laser_slam_2d/apps/synthetic_scene_generator.cpp:56-88
+ *   factor / solver math srrg2_laser_slam_2d/octave/solver/nicp_post.m:4-26,69-97 (2-D restriction)
+ *   aligner loop         srrg2_laser_slam_2d/apps/visual_test_aligner_2d.cpp:102-156 (driver),
+ *                        configurations/stage_segway_double_config_MULTI.json:602-630,700-732
+ *
+ * Who may use this: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- as the
+ * checker / the timed CPU baseline, never as (part of) the shipped product path.
+ *
+ * Two instantiations of every routine: `_f` = fp32 "mirror" (same IEEE operation sequence the
+ * HIP kernels use, so index outputs agree bit-for-bit) and `_d` = fp64 "truth".
+ */
+#ifndef LSM2D_ORACLE_H
+#define LSM2D_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* PointNormal2f payload: (x, y, nx, ny) fp32 -- 4-vector confirmed at
+ * sensor_processing/raw_data_preprocessor_projective_2d.cpp:39-40 */
+typedef struct { float x, y, nx, ny; } lsmo_point;
+
+/* Correspondence(fixed_idx, moving_idx) -- ctor use at correspondence_finder_kd_tree_2d.cpp:25 */
+typedef struct { int fixed_idx, moving_idx; } lsmo_corr;
+
+/* PointNormal2fProjectorPolar parameters (synthetic_scene_generator.cpp:69-75) */
+typedef struct {
+  int   canvas_cols;
+  float angle_min, angle_max;   /* angle_col_min / angle_col_max [rad] */
+  float range_min, range_max;   /* [m] */
+  float col_offset;             /* 0 = floor(K00*theta+K01) (SURVEY App. A.3 assumption); 0.5 = round-to-nearest */
+} lsmo_projector;
+
+enum { LSMO_FINDER_PROJECTIVE = 0, LSMO_FINDER_NN = 1, LSMO_FINDER_DISTMAP = 2 };
+enum { LSMO_ROBUST_NONE = 0, LSMO_ROBUST_CAUCHY = 1 };
+enum {
+  LSMO_SUCCESS = 0,
+  LSMO_NOT_ENOUGH_CORRESPONDENCES = 1,
+  LSMO_NOT_ENOUGH_INLIERS = 2,
+  LSMO_SINGULAR_H = 3,
+  LSMO_BAD_ARGUMENT = -1
+};
+
+typedef struct {
+  int   finder;                       /* LSMO_FINDER_* */
+  lsmo_projector projector;           /* projective finder */
+  float point_distance;               /* projective: max |depth_f - depth_m|   (.h:16-20, default 0.5) */
+  float normal_cos;                   /* all finders: min n_f . n_m             (default 0.8) */
+  float max_distance;                 /* NN / distmap: max point distance [m]  (kd .h:23, nn .h:20-24) */
+  float resolution;                   /* distmap: m / pixel                     (nn .h:25-29) */
+  int   robustifier;                  /* LSMO_ROBUST_* */
+  float chi_threshold;                /* Cauchy tau (MULTI.json:153-158) */
+  int   min_num_correspondences;      /* slice skipped if #pairs <= this (MULTI.json:179) */
+  float sensor_in_robot[3];           /* WithSensor variant (aligner_slice_processor_laser_2d_impl.cpp:7-10); (0,0,0) = plain */
+} lsmo_slice_params;
+
+typedef struct {
+  int   max_iterations;               /* MULTI.json:711 (10), :613 (30); BASELINE 20 */
+  int   min_num_inliers;              /* MULTI.json:714 */
+  float damping;                      /* GN damping, MULTI.json:254-259 (0) */
+  int   has_prior;                    /* odometry-prior slice (MULTI.json:402-422): e = t2v(Z^-1 X), Omega */
+  float prior_z[3];
+  float prior_omega[9];
+} lsmo_aligner_params;
+
+typedef struct {
+  int   n_corr, n_in, n_out;
+  float chi_in, chi_out;
+} lsmo_iter_stats;
+
+/* ---- scalar helpers --------------------------------------------------------------------- */
+float lsmo_atan2f(float y, float x);     /* the fixed-polynomial atan2 both CPU and GPU evaluate */
+void  lsmo_compose_f(const float a[3], const float b[3], float out[3]);   /* v2t(a)*v2t(b) -> t2v */
+void  lsmo_inverse_f(const float a[3], float out[3]);
+void  lsmo_compose_d(const double a[3], const double b[3], double out[3]);
+void  lsmo_inverse_d(const double a[3], double out[3]);
+
+/* ---- projector: one polar z-buffer pass -------------------------------- */
+/* pose maps cloud points into the camera frame (= camera_pose^-1 of the reference projector).
+ * out_src[cols] = winning source index or -1; out_depth[cols]; out_xyn[4*cols] = transformed point. */
+int lsmo_project_f(const lsmo_projector* pr, const lsmo_point* cloud, int n, const float pose[3],
+                   int* out_src, float* out_depth, float* out_xyn);
+int lsmo_project_d(const lsmo_projector* pr, const lsmo_point* cloud, int n, const double pose[3],
+                   int* out_src, double* out_depth, double* out_xyn);
+
+/* ---- finders: return number of pairs written to out (capacity: cols resp. n_moving) ------- */
+int lsmo_find_projective_f(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                           const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
+int lsmo_find_projective_d(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                           const lsmo_point* moving, int n_moving, const double pose[3], lsmo_corr* out);
+int lsmo_find_nn_f(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                   const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
+int lsmo_find_nn_d(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                   const lsmo_point* moving, int n_moving, const double pose[3], lsmo_corr* out);
+/* O(N_f*N_m) brute force, used only to validate the grid search above */
+int lsmo_find_nn_brute_f(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                         const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
+
+/* ---- factor + robustifier: H (row-major 3x3), b, statistics ------------- */
+int lsmo_linearize_f(const lsmo_slice_params* sp, const lsmo_point* fixed, const lsmo_point* moving,
+                     const lsmo_corr* corr, int n_corr, const float pose[3],
+                     float H[9], float b[3], lsmo_iter_stats* st);
+int lsmo_linearize_d(const lsmo_slice_params* sp, const lsmo_point* fixed, const lsmo_point* moving,
+                     const lsmo_corr* corr, int n_corr, const double pose[3],
+                     double H[9], double b[3], lsmo_iter_stats* st);
+/* error and Jacobian of ONE pair (for the finite-difference test) */
+void lsmo_error_jacobian_d(const lsmo_point* f, const lsmo_point* m, const double pose[3],
+                           double e[3], double J[9]);
+
+/* ---- step: (H + damping I) dx = -b ; X <- X * v2t(dx) ------------------- */
+int lsmo_solve_update_f(const float H[9], const float b[3], float damping, float pose[3], float dx[3]);
+int lsmo_solve_update_d(const double H[9], const double b[3], double damping, double pose[3], double dx[3]);
+
+/* ---- aligner, multi-slice + optional prior ------------------------------ */
+int lsmo_align_f(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_params* sp,
+                 const lsmo_point* const* fixed, const int* n_fixed,
+                 const lsmo_point* const* moving, const int* n_moving,
+                 const float x0[3], float x_out[3], float H_out[9],
+                 lsmo_iter_stats* stats /* [max_iterations] or NULL */, int* iterations_done);
+int lsmo_align_d(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_params* sp,
+                 const lsmo_point* const* fixed, const int* n_fixed,
+                 const lsmo_point* const* moving, const int* n_moving,
+                 const double x0[3], double x_out[3], double H_out[9],
+                 lsmo_iter_stats* stats, int* iterations_done);
+
+/* batch convenience for the CPU baseline: one shared moving cloud (the map), ragged fixed clouds
+ * (scans) packed back to back with offsets[n+1]; single slice; n_threads >= 1 (pthreads). */
+int lsmo_align_batch_f(const lsmo_aligner_params* ap, const lsmo_slice_params* sp,
+                       const lsmo_point* fixed_packed, const int* fixed_offsets, int n_alignments,
+                       const lsmo_point* moving, int n_moving,
+                       const float* x0 /* [n][3] */, float* x_out /* [n][3] */, float* H_out /* [n][9] */,
+                       int* status_out, lsmo_iter_stats* last_stats /* [n] or NULL */, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

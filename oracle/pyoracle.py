@@ -1,0 +1,192 @@
+"""ctypes view of the CPU ORACLE (oracle/lsm2d_oracle.h) -- TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the oracle is a restatement of the reference algorithm (see lsm2d_oracle.h for
+the file:line map); no reference golden vector exists for this path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liblsm2d_oracle.so")
+
+FINDER_PROJECTIVE, FINDER_NN, FINDER_DISTMAP = 0, 1, 2
+ROBUST_NONE, ROBUST_CAUCHY = 0, 1
+SUCCESS, NOT_ENOUGH_CORRESPONDENCES, NOT_ENOUGH_INLIERS, SINGULAR_H, BAD_ARGUMENT = 0, 1, 2, 3, -1
+
+
+class Projector(C.Structure):
+    _fields_ = [("canvas_cols", C.c_int), ("angle_min", C.c_float), ("angle_max", C.c_float),
+                ("range_min", C.c_float), ("range_max", C.c_float), ("col_offset", C.c_float)]
+
+
+class SliceParams(C.Structure):
+    _fields_ = [("finder", C.c_int), ("projector", Projector), ("point_distance", C.c_float),
+                ("normal_cos", C.c_float), ("max_distance", C.c_float), ("resolution", C.c_float),
+                ("robustifier", C.c_int), ("chi_threshold", C.c_float),
+                ("min_num_correspondences", C.c_int), ("sensor_in_robot", C.c_float * 3)]
+
+
+class AlignerParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("min_num_inliers", C.c_int), ("damping", C.c_float),
+                ("has_prior", C.c_int), ("prior_z", C.c_float * 3), ("prior_omega", C.c_float * 9)]
+
+
+class IterStats(C.Structure):
+    _fields_ = [("n_corr", C.c_int), ("n_in", C.c_int), ("n_out", C.c_int),
+                ("chi_in", C.c_float), ("chi_out", C.c_float)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (make -C oracle)."""
+    srcs = [os.path.join(_HERE, f) for f in ("lsm2d_oracle.c", "lsm2d_oracle_impl.inc", "lsm2d_oracle.h")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.lsmo_atan2f.restype = C.c_float
+        _lib.lsmo_atan2f.argtypes = [C.c_float, C.c_float]
+    return _lib
+
+
+def slice_params(finder=FINDER_PROJECTIVE, canvas_cols=1081, angle_min=-np.pi, angle_max=np.pi, range_min=0.3,
+                 range_max=30.0, col_offset=0.0, point_distance=0.5, normal_cos=0.8, max_distance=0.5,
+                 resolution=0.05, robustifier=ROBUST_NONE, chi_threshold=0.05, min_num_correspondences=10,
+                 sensor_in_robot=(0.0, 0.0, 0.0)) -> SliceParams:
+    sp = SliceParams()
+    sp.finder = finder
+    sp.projector = Projector(canvas_cols, angle_min, angle_max, range_min, range_max, col_offset)
+    sp.point_distance, sp.normal_cos, sp.max_distance, sp.resolution = point_distance, normal_cos, max_distance, resolution
+    sp.robustifier, sp.chi_threshold, sp.min_num_correspondences = robustifier, chi_threshold, min_num_correspondences
+    sp.sensor_in_robot = (C.c_float * 3)(*sensor_in_robot)
+    return sp
+
+
+def aligner_params(max_iterations=20, min_num_inliers=10, damping=0.0, prior_z=None, prior_omega=None) -> AlignerParams:
+    ap = AlignerParams()
+    ap.max_iterations, ap.min_num_inliers, ap.damping = max_iterations, min_num_inliers, damping
+    ap.has_prior = 0 if prior_z is None else 1
+    if prior_z is not None:
+        ap.prior_z = (C.c_float * 3)(*prior_z)
+        ap.prior_omega = (C.c_float * 9)(*np.asarray(prior_omega, np.float32).ravel())
+    return ap
+
+
+def _pts(a):
+    a = np.ascontiguousarray(a, np.float32)
+    assert a.ndim == 2 and a.shape[1] == 4
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _real(double):
+    return (np.float64, "_d") if double else (np.float32, "_f")
+
+
+def atan2f(y, x):
+    y = np.asarray(y, np.float32).ravel(); x = np.asarray(x, np.float32).ravel()
+    L = lib()
+    return np.array([L.lsmo_atan2f(float(a), float(b)) for a, b in zip(y, x)], np.float32)
+
+
+def project(pr: Projector, cloud, pose, double=False):
+    dt, sfx = _real(double)
+    cloud, pc = _pts(cloud)
+    cols = pr.canvas_cols
+    src = np.empty(cols, np.int32); depth = np.empty(cols, dt); xyn = np.empty((cols, 4), dt)
+    pose = np.ascontiguousarray(pose, dt)
+    rc = getattr(lib(), "lsmo_project" + sfx)(C.byref(pr), pc, len(cloud), pose.ctypes.data_as(C.c_void_p),
+                                              src.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p),
+                                              xyn.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    return src, depth, xyn
+
+
+def find(sp: SliceParams, fixed, moving, pose, double=False, brute=False):
+    """Correspondences int32 [k, 2] = (fixed_idx, moving_idx)."""
+    dt, sfx = _real(double)
+    fixed, pf = _pts(fixed); moving, pm = _pts(moving)
+    cap = sp.projector.canvas_cols if sp.finder == FINDER_PROJECTIVE else len(moving)
+    out = np.empty((max(cap, 1), 2), np.int32)
+    pose = np.ascontiguousarray(pose, dt)
+    name = {FINDER_PROJECTIVE: "lsmo_find_projective", FINDER_NN: "lsmo_find_nn_brute" if brute else "lsmo_find_nn"}[sp.finder]
+    k = getattr(lib(), name + sfx)(C.byref(sp), pf, len(fixed), pm, len(moving), pose.ctypes.data_as(C.c_void_p),
+                                   out.ctypes.data_as(C.c_void_p))
+    assert k >= 0, k
+    return out[:k].copy()
+
+
+def linearize(sp: SliceParams, fixed, moving, corr, pose, double=False):
+    dt, sfx = _real(double)
+    fixed, pf = _pts(fixed); moving, pm = _pts(moving)
+    corr = np.ascontiguousarray(corr, np.int32)
+    H = np.empty(9, dt); b = np.empty(3, dt); st = IterStats()
+    pose = np.ascontiguousarray(pose, dt)
+    rc = getattr(lib(), "lsmo_linearize" + sfx)(C.byref(sp), pf, pm, corr.ctypes.data_as(C.c_void_p), len(corr),
+                                                pose.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
+                                                b.ctypes.data_as(C.c_void_p), C.byref(st))
+    assert rc == 0
+    return H.reshape(3, 3), b, st
+
+
+def error_jacobian(f, m, pose):
+    f = np.ascontiguousarray(f, np.float32); m = np.ascontiguousarray(m, np.float32)
+    e = np.empty(3); J = np.empty(9); pose = np.ascontiguousarray(pose, np.float64)
+    lib().lsmo_error_jacobian_d(f.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), pose.ctypes.data_as(C.c_void_p),
+                                e.ctypes.data_as(C.c_void_p), J.ctypes.data_as(C.c_void_p))
+    return e, J.reshape(3, 3)
+
+
+def solve_update(H, b, pose, damping=0.0, double=False):
+    dt, sfx = _real(double)
+    H = np.ascontiguousarray(H, dt).ravel(); b = np.ascontiguousarray(b, dt); pose = np.array(pose, dt)
+    dx = np.empty(3, dt)
+    fn = getattr(lib(), "lsmo_solve_update" + sfx)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_double if double else C.c_float, C.c_void_p, C.c_void_p]
+    rc = fn(H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), damping, pose.ctypes.data_as(C.c_void_p),
+            dx.ctypes.data_as(C.c_void_p))
+    return rc, pose, dx
+
+
+def align(ap: AlignerParams, slices, fixed, moving, x0, double=False):
+    """Multi-slice alignment. ``slices``: list of SliceParams; ``fixed``/``moving``: lists of clouds.
+    Returns dict(status, pose, H, stats[list of IterStats], iterations)."""
+    dt, sfx = _real(double)
+    n = len(slices)
+    sp = (SliceParams * n)(*slices)
+    fx = [_pts(f) for f in fixed]; mv = [_pts(m) for m in moving]
+    pf = (C.c_void_p * n)(*[p for _, p in fx]); pm = (C.c_void_p * n)(*[p for _, p in mv])
+    nf = (C.c_int * n)(*[len(a) for a, _ in fx]); nm = (C.c_int * n)(*[len(a) for a, _ in mv])
+    x0 = np.ascontiguousarray(x0, dt); xo = np.empty(3, dt); H = np.empty(9, dt)
+    stats = (IterStats * max(ap.max_iterations, 1))(); its = C.c_int(0)
+    rc = getattr(lib(), "lsmo_align" + sfx)(C.byref(ap), n, sp, pf, nf, pm, nm, x0.ctypes.data_as(C.c_void_p),
+                                            xo.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p), stats, C.byref(its))
+    return dict(status=rc, pose=xo, H=H.reshape(3, 3), stats=[stats[i] for i in range(its.value)], iterations=its.value)
+
+
+def align_batch(ap: AlignerParams, sp: SliceParams, fixed_packed, fixed_offsets, moving, x0, n_threads=1):
+    """fp32 batch over a shared moving cloud (cpu_baseline 'port').  Returns (pose [n,3], H [n,3,3], status [n], last stats)."""
+    fixed_packed, pf = _pts(fixed_packed); moving, pm = _pts(moving)
+    offs = np.ascontiguousarray(fixed_offsets, np.int32); n = len(offs) - 1
+    x0 = np.ascontiguousarray(x0, np.float32).reshape(n, 3)
+    xo = np.empty((n, 3), np.float32); H = np.empty((n, 9), np.float32); status = np.empty(n, np.int32)
+    last = (IterStats * max(n, 1))()
+    lib().lsmo_align_batch_f(C.byref(ap), C.byref(sp), pf, offs.ctypes.data_as(C.c_void_p), n, pm, len(moving),
+                             x0.ctypes.data_as(C.c_void_p), xo.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
+                             status.ctypes.data_as(C.c_void_p), last, int(n_threads))
+    return xo, H.reshape(n, 3, 3), status, [last[i] for i in range(n)]

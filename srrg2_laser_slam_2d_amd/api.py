@@ -1,0 +1,414 @@
+"""Host-side mirror of the reference's plugin surface for the scan-matching hot path, over the C ABI.
+
+Class and method names follow the reference so that tests read like its own drivers:
+
+* ``CorrespondenceFinderProjective2f`` / ``CorrespondenceFinderKDTree2D`` -- ``setFixed``, ``setMoving``,
+  ``setLocalMapInSensor``, ``compute`` (apps/visual_test_correspondence_finder_projective_2d.cpp:74-79;
+  parameters of registration/correspondence_finder_projective_2d.h:16-26, ..._kd_tree_2d.h:23-34).
+* ``AlignerSliceProcessorLaser2D`` / ``...WithSensor`` (registration/aligner_slice_processor_laser_2d.h:7-42;
+  config fields configurations/stage_segway_double_config_MULTI.json:160-188).
+* ``MultiAligner2D`` -- ``param_slice_processors``, ``setFixed``, ``setMoving``, ``setMovingInFixed``, ``compute``,
+  ``movingInFixed``, ``iterationStats`` (apps/visual_test_aligner_2d.cpp:123-156), plus ``compute_batch`` for the
+  loop-closure / relocalisation sweeps the reference runs as a sequential loop (MULTI.json:964-986).
+
+Errors: the reference throws ``std::runtime_error`` on missing inputs
+(registration/correspondence_finder_projective_2d.cpp:21-31); here that is ``RuntimeError``; device/ABI failures raise
+``Lsm2dError``.  All compute happens in the HIP library; nothing here falls back to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from ._capi import (FINDER_NN, FINDER_PROJECTIVE, ROBUST_CAUCHY, ROBUST_NONE, AlignerParams, Batch, Correspondence,
+                    IterationStats, Lsm2dError, Prior, Projector, SliceParams, check)
+
+STATUS_NAMES = {0: "Success", 1: "NotEnoughCorrespondences", 2: "NotEnoughInliers", 3: "SingularH"}
+
+
+class Context:
+    """One device + one HIP stream (lsm2d_context)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        rc = self._lib.lsm2d_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise Lsm2dError(rc, "lsm2d_create", self._lib.lsm2d_last_error(None).decode())
+        self._h = h
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self):
+        check(self._lib.lsm2d_synchronize(self._h), "lsm2d_synchronize", self._h)
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        check(self._lib.lsm2d_last_kernel_ms(self._h, C.byref(ms)), "lsm2d_last_kernel_ms", self._h)
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lsm2d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CloudSet:
+    """Device-resident ragged set of PointNormal2fVectorCloud (lsm2d_cloudset)."""
+
+    def __init__(self, ctx: Context, points, offsets=None):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        h = C.c_void_p()
+        if hasattr(points, "data_ptr"):          # a torch tensor already on ctx's device
+            if not points.is_cuda or not points.is_contiguous() or points.dtype.itemsize != 4 or points.shape[-1] != 4:
+                raise ValueError("device points must be a contiguous float32 [N, 4] tensor on the GPU")
+            total = int(points.shape[0])
+            offs = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
+            n_clouds = 1 if offs is None else len(offs) - 1
+            rc = self._lib.lsm2d_cloudset_create_from_device(
+                ctx.handle, C.c_void_p(points.data_ptr()), None if offs is None else offs.ctypes.data_as(C.c_void_p),
+                n_clouds, total, C.byref(h))
+        else:
+            pts = np.ascontiguousarray(points, np.float32)
+            if pts.ndim != 2 or pts.shape[1] != 4:
+                raise ValueError("points must be [N, 4] (x, y, nx, ny)")
+            total = len(pts)
+            offs = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
+            n_clouds = 1 if offs is None else len(offs) - 1
+            rc = self._lib.lsm2d_cloudset_create(ctx.handle, pts.ctypes.data_as(C.c_void_p),
+                                                 None if offs is None else offs.ctypes.data_as(C.c_void_p),
+                                                 n_clouds, total, C.byref(h))
+        check(rc, "lsm2d_cloudset_create", ctx.handle)
+        self._h = h
+        self.n_clouds = n_clouds
+        self.n_points = total
+        self.counts = np.array([total], np.int64) if offs is None else np.diff(offs.astype(np.int64))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lsm2d_cloudset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _as_cloudset(ctx: Context, cloud) -> CloudSet:
+    return cloud if isinstance(cloud, CloudSet) else CloudSet(ctx, cloud)
+
+
+@dataclasses.dataclass
+class PointNormal2fProjectorPolar:
+    """Parameters of the polar projector (apps/synthetic_scene_generator.cpp:69-75; MULTI.json:71-97)."""
+    param_canvas_cols: int = 721
+    param_angle_col_min: float = -math.pi
+    param_angle_col_max: float = math.pi
+    param_range_min: float = 0.3
+    param_range_max: float = 20.0
+    col_offset: float = 0.0
+
+    def struct(self) -> Projector:
+        return Projector(self.param_canvas_cols, self.param_angle_col_min, self.param_angle_col_max,
+                         self.param_range_min, self.param_range_max, self.col_offset)
+
+    def compute(self, ctx: Context, cloud, pose=(0.0, 0.0, 0.0), cloud_index: int = 0):
+        """One z-buffer pass; ``pose`` maps cloud points into the camera frame (= camera_pose^-1).
+        Returns (source_idx int32 [cols], depth float32 [cols], transformed float32 [cols, 4])."""
+        cs = _as_cloudset(ctx, cloud)
+        cols = self.param_canvas_cols
+        src = np.empty(cols, np.int32); depth = np.empty(cols, np.float32); xy = np.empty((cols, 4), np.float32)
+        pose = np.ascontiguousarray(pose, np.float32)
+        pr = self.struct()
+        check(ctx._lib.lsm2d_project(ctx.handle, C.byref(pr), cs.handle, cloud_index, pose.ctypes.data_as(C.c_void_p),
+                                     src.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p),
+                                     xy.ctypes.data_as(C.c_void_p)), "lsm2d_project", ctx.handle)
+        return src, depth, xy
+
+
+class _FinderBase:
+    finder_kind = FINDER_PROJECTIVE
+
+    def __init__(self, ctx: Context):
+        self._ctx = ctx
+        self._fixed = None
+        self._moving = None
+        self._local_map_in_sensor = np.zeros(3, np.float32)
+        self._correspondences = np.zeros((0, 2), np.int32)
+        self._fixed_index = 0
+        self._moving_index = 0
+
+    # CorrespondenceFinder_ base-class surface (registration/correspondence_finder_normal_2f.h:9-13)
+    def setFixed(self, fixed, index: int = 0):
+        self._fixed = _as_cloudset(self._ctx, fixed); self._fixed_index = index
+
+    def setMoving(self, moving, index: int = 0):
+        self._moving = _as_cloudset(self._ctx, moving); self._moving_index = index
+
+    def setLocalMapInSensor(self, pose):
+        self._local_map_in_sensor = np.ascontiguousarray(pose, np.float32).reshape(3)
+
+    def correspondences(self) -> np.ndarray:
+        return self._correspondences
+
+    def slice_params(self, **kw) -> SliceParams:
+        raise NotImplementedError
+
+    def _capacity(self) -> int:
+        raise NotImplementedError
+
+    def compute(self) -> np.ndarray:
+        if self._fixed is None:
+            raise RuntimeError(type(self).__name__ + "::compute| Missing fixed!")
+        if self._moving is None:
+            raise RuntimeError(type(self).__name__ + "::compute| Missing moving!")
+        sp = self.slice_params()
+        cap = max(self._capacity(), 1)
+        out = np.empty((cap, 2), np.int32)
+        n = C.c_int32(0)
+        lib = self._ctx._lib
+        check(lib.lsm2d_find_correspondences(self._ctx.handle, C.byref(sp), self._fixed.handle, self._fixed_index,
+                                             self._moving.handle, self._moving_index,
+                                             self._local_map_in_sensor.ctypes.data_as(C.c_void_p),
+                                             out.ctypes.data_as(C.c_void_p), cap, C.byref(n)),
+              "lsm2d_find_correspondences", self._ctx.handle)
+        self._correspondences = out[:n.value].copy()
+        return self._correspondences
+
+
+class CorrespondenceFinderProjective2f(_FinderBase):
+    """registration/correspondence_finder_projective_2d.{h,cpp}"""
+    finder_kind = FINDER_PROJECTIVE
+
+    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None,
+                 point_distance: float = 0.5, normal_cos: float = 0.8):
+        super().__init__(ctx)
+        self.param_projector = projector
+        self.param_point_distance = point_distance
+        self.param_normal_cos = normal_cos
+
+    def slice_params(self, **kw) -> SliceParams:
+        if self.param_projector is None:
+            raise RuntimeError("CorrespondenceFinderProjective2f::compute| Missing Projector")
+        return make_slice_params(finder=FINDER_PROJECTIVE, projector=self.param_projector,
+                                 point_distance=self.param_point_distance, normal_cos=self.param_normal_cos, **kw)
+
+    def _capacity(self) -> int:
+        return self.param_projector.param_canvas_cols
+
+
+class CorrespondenceFinderKDTree2D(_FinderBase):
+    """registration/correspondence_finder_kd_tree_2d.{h,cpp} (exact nearest neighbour on the device)"""
+    finder_kind = FINDER_NN
+
+    def __init__(self, ctx: Context, max_distance_m: float = 1e-2, normal_cos: float = 0.8,
+                 max_leaf_range: float = 1e-2, min_leaf_points: int = 20):
+        super().__init__(ctx)
+        self.param_max_distance_m = max_distance_m
+        self.param_normal_cos = normal_cos
+        self.param_max_leaf_range = max_leaf_range      # kept for config compatibility; the device search is a grid
+        self.param_min_leaf_points = min_leaf_points
+
+    def slice_params(self, **kw) -> SliceParams:
+        return make_slice_params(finder=FINDER_NN, projector=PointNormal2fProjectorPolar(),
+                                 max_distance=self.param_max_distance_m, normal_cos=self.param_normal_cos, **kw)
+
+    def _capacity(self) -> int:
+        return int(self._moving.counts[self._moving_index])
+
+
+def make_slice_params(finder=FINDER_PROJECTIVE, projector: Optional[PointNormal2fProjectorPolar] = None,
+                      point_distance=0.5, normal_cos=0.8, max_distance=0.5, resolution=0.05,
+                      robustifier=ROBUST_NONE, chi_threshold=0.05, min_num_correspondences=10,
+                      sensor_in_robot=(0.0, 0.0, 0.0)) -> SliceParams:
+    sp = SliceParams()
+    sp.finder = finder
+    sp.projector = (projector or PointNormal2fProjectorPolar()).struct()
+    sp.point_distance, sp.normal_cos, sp.max_distance, sp.resolution = point_distance, normal_cos, max_distance, resolution
+    sp.robustifier, sp.chi_threshold, sp.min_num_correspondences = robustifier, chi_threshold, min_num_correspondences
+    sp.sensor_in_robot = (C.c_float * 3)(*[float(v) for v in sensor_in_robot])
+    return sp
+
+
+@dataclasses.dataclass
+class RobustifierCauchy:
+    """MULTI.json:153-158"""
+    param_chi_threshold: float = 0.01
+
+
+class AlignerSliceProcessorLaser2D:
+    """registration/aligner_slice_processor_laser_2d.h:7-17 -- finder + SE2Plane2PlaneErrorFactor (+ robustifier)."""
+
+    def __init__(self, finder: _FinderBase, robustifier: Optional[RobustifierCauchy] = None,
+                 min_num_correspondences: int = 0, fixed_slice_name: str = "points", moving_slice_name: str = "points"):
+        self.param_finder = finder
+        self.param_robustifier = robustifier
+        self.param_min_num_correspondences = min_num_correspondences
+        self.param_fixed_slice_name = fixed_slice_name
+        self.param_moving_slice_name = moving_slice_name
+        self.sensor_in_robot = (0.0, 0.0, 0.0)
+
+    def slice_params(self) -> SliceParams:
+        rb = self.param_robustifier
+        return self.param_finder.slice_params(
+            robustifier=ROBUST_CAUCHY if rb else ROBUST_NONE,
+            chi_threshold=rb.param_chi_threshold if rb else 0.0,
+            min_num_correspondences=self.param_min_num_correspondences, sensor_in_robot=self.sensor_in_robot)
+
+
+class AlignerSliceProcessorLaser2DWithSensor(AlignerSliceProcessorLaser2D):
+    """registration/aligner_slice_processor_laser_2d.h:21-42: the estimate lives in the robot frame, the
+    fixed scan in the sensor frame; ``sensor_in_robot`` comes from the tf Platform in the reference
+    (apps/visual_test_aligner_2d.cpp:96-107)."""
+
+    def __init__(self, finder, sensor_in_robot=(0.0, 0.0, 0.0), **kw):
+        super().__init__(finder, **kw)
+        self.sensor_in_robot = tuple(float(v) for v in sensor_in_robot)
+
+
+@dataclasses.dataclass
+class BatchResult:
+    pose: np.ndarray          # [n, 3]  movingInFixed
+    information: np.ndarray   # [n, 3, 3]
+    status: np.ndarray        # [n]
+    iterations: np.ndarray    # [n]
+    stats: Optional[np.ndarray]  # structured [n, max_it] or None
+    kernel_ms: float
+
+    def status_names(self):
+        return [STATUS_NAMES.get(int(s), str(int(s))) for s in self.status]
+
+
+STATS_DTYPE = np.dtype([("n_correspondences", np.int32), ("n_inliers", np.int32), ("n_outliers", np.int32),
+                        ("chi_inliers", np.float32), ("chi_outliers", np.float32)])
+
+
+class MultiAligner2D:
+    """The upstream aligner as the reference drives it (apps/visual_test_aligner_2d.cpp:123-156), with the
+    whole iteration loop running on the device."""
+
+    def __init__(self, ctx: Context, max_iterations: int = 10, min_num_inliers: int = 10, damping: float = 0.0):
+        self._ctx = ctx
+        self.param_max_iterations = max_iterations
+        self.param_min_num_inliers = min_num_inliers
+        self.param_damping = damping
+        self.param_slice_processors: list[AlignerSliceProcessorLaser2D] = []
+        self._fixed = {}
+        self._moving = {}
+        self._moving_in_fixed = np.zeros(3, np.float32)
+        self._prior = None
+        self._result: Optional[BatchResult] = None
+
+    # --- single-alignment surface ---------------------------------------------------------------
+    def setFixed(self, container: dict):
+        """``container`` maps slice names to clouds (the PropertyContainer of the reference)."""
+        self._fixed = {k: _as_cloudset(self._ctx, v) for k, v in container.items()}
+
+    def setMoving(self, container: dict):
+        self._moving = {k: _as_cloudset(self._ctx, v) for k, v in container.items()}
+
+    def setMovingInFixed(self, pose):
+        self._moving_in_fixed = np.ascontiguousarray(pose, np.float32).reshape(3)
+
+    def setPrior(self, z, omega):
+        """Odometry-prior cue (AlignerSliceOdom2DPrior, MULTI.json:402-422)."""
+        self._prior = (np.asarray(z, np.float32).reshape(3), np.asarray(omega, np.float32).reshape(3, 3))
+
+    def compute(self):
+        if not self.param_slice_processors:
+            raise RuntimeError("MultiAligner2D::compute| no slice processors")
+        fixed = [self._fixed[s.param_fixed_slice_name] for s in self.param_slice_processors]
+        moving = [self._moving[s.param_moving_slice_name] for s in self.param_slice_processors]
+        prior = None if self._prior is None else [self._prior]
+        self._result = self.compute_batch(fixed, moving, self._moving_in_fixed[None, :], priors=prior, want_stats=True)
+        return self.status()
+
+    def movingInFixed(self) -> np.ndarray:
+        return self._result.pose[0]
+
+    def informationMatrix(self) -> np.ndarray:
+        return self._result.information[0]
+
+    def status(self) -> int:
+        return int(self._result.status[0])
+
+    def iterationStats(self):
+        r = self._result
+        return r.stats[0][: int(r.iterations[0])]
+
+    # --- batched surface ---------------------------------------------------------------------------
+    def compute_batch(self, fixed: Sequence[CloudSet], moving: Sequence[CloudSet], init_poses, priors=None,
+                      fixed_index=None, moving_index=None, want_stats: bool = False) -> BatchResult:
+        """``fixed[s]`` / ``moving[s]``: cloud set of slice ``s`` (one cloud = shared by the batch, else one per
+        alignment or chosen through ``*_index[s][i]``).  ``init_poses``: [n, 3]."""
+        ctx, lib = self._ctx, self._ctx._lib
+        slices = self.param_slice_processors
+        ns = len(slices)
+        x0 = np.ascontiguousarray(init_poses, np.float32).reshape(-1, 3)
+        n = len(x0)
+        sp = (SliceParams * ns)(*[s.slice_params() for s in slices])
+        fx = (C.c_void_p * ns)(*[_as_cloudset(ctx, f).handle.value for f in fixed])
+        mv = (C.c_void_p * ns)(*[_as_cloudset(ctx, m).handle.value for m in moving])
+        b = Batch()
+        b.n_alignments, b.n_slices = n, ns
+        b.slices = sp
+        b.fixed = C.cast(fx, C.POINTER(C.c_void_p)); b.moving = C.cast(mv, C.POINTER(C.c_void_p))
+        keep = []
+        if fixed_index is not None:
+            fi = np.ascontiguousarray(fixed_index, np.int32).reshape(ns, n); keep.append(fi)
+            b.fixed_index = fi.ctypes.data_as(C.POINTER(C.c_int32))
+        if moving_index is not None:
+            mi = np.ascontiguousarray(moving_index, np.int32).reshape(ns, n); keep.append(mi)
+            b.moving_index = mi.ctypes.data_as(C.POINTER(C.c_int32))
+        b.init_pose = x0.ctypes.data_as(C.POINTER(C.c_float))
+        if priors is not None:
+            pr = (Prior * n)()
+            for i, (z, om) in enumerate(priors):
+                pr[i].z = (C.c_float * 3)(*np.asarray(z, np.float32).ravel())
+                pr[i].omega = (C.c_float * 9)(*np.asarray(om, np.float32).ravel())
+            b.prior = pr
+        ap = AlignerParams(self.param_max_iterations, self.param_min_num_inliers, self.param_damping)
+        pose = np.empty((n, 3), np.float32); H = np.empty((n, 9), np.float32)
+        status = np.empty(n, np.int32); its = np.empty(n, np.int32)
+        stats = np.zeros((n, max(self.param_max_iterations, 1)), STATS_DTYPE) if want_stats else None
+        check(lib.lsm2d_align_batch(ctx.handle, C.byref(ap), C.byref(b), pose.ctypes.data_as(C.c_void_p),
+                                    H.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
+                                    its.ctypes.data_as(C.c_void_p),
+                                    stats.ctypes.data_as(C.c_void_p) if want_stats else None),
+              "lsm2d_align_batch", ctx.handle)
+        return BatchResult(pose, H.reshape(n, 3, 3), status, its, stats, ctx.last_kernel_ms() if n else 0.0)
+
+
+def linearize(ctx: Context, slice_params: SliceParams, fixed, moving, correspondences, pose,
+              fixed_index: int = 0, moving_index: int = 0):
+    """SE2Plane2PlaneErrorFactor over a correspondence vector: returns (H [3,3], b [3], IterationStats)."""
+    fx, mv = _as_cloudset(ctx, fixed), _as_cloudset(ctx, moving)
+    corr = np.ascontiguousarray(correspondences, np.int32).reshape(-1, 2)
+    pose = np.ascontiguousarray(pose, np.float32)
+    H = np.empty(9, np.float32); b = np.empty(3, np.float32); st = IterationStats()
+    check(ctx._lib.lsm2d_linearize(ctx.handle, C.byref(slice_params), fx.handle, fixed_index, mv.handle, moving_index,
+                                   corr.ctypes.data_as(C.c_void_p), len(corr), pose.ctypes.data_as(C.c_void_p),
+                                   H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(st)),
+          "lsm2d_linearize", ctx.handle)
+    return H.reshape(3, 3), b, st

@@ -1,0 +1,56 @@
+"""Build liblsm2d_hip.so (the C ABI of include/lsm2d.h) for gfx950 with hipcc, in-tree.
+
+    python -m srrg2_laser_slam_2d_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels with the tree.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "liblsm2d_hip.so")
+SOURCES = [os.path.join(CSRC, "lsm2d_capi.hip")]
+HEADERS = [os.path.join(CSRC, "lsm2d_device.h"), os.path.join(CSRC, "lsm2d_kernels.h"),
+           os.path.join(ROOT, "include", "lsm2d.h")]
+
+# -ffp-contract=off: every fused multiply-add in the kernels is explicit, so column indices and
+# z-buffer winners are reproducible bit-for-bit by an IEEE CPU (see csrc/lsm2d_device.h).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc(), *HIPCC_FLAGS, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH, *SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

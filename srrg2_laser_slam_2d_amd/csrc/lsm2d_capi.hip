@@ -1,0 +1,472 @@
+// lsm2d_capi.hip -- host side of the C ABI declared in include/lsm2d.h (liblsm2d_hip.so).
+// Owns the device buffers, packs kernel arguments, launches the gfx950 kernels of lsm2d_kernels.h on
+// the context's HIP stream.  No CPU fallback: without a usable HIP device every entry point fails.
+#include "lsm2d.h"
+
+namespace lsm2d { static constexpr int LSM2D_RUNNING = -99; }
+using lsm2d::LSM2D_RUNNING;
+#include "lsm2d_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace lsm2d;
+
+static thread_local std::string g_last_error;
+
+struct lsm2d_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool have_timing = false;
+  std::string last_error;
+  // pinned host staging + device scratch, grown on demand
+  void* h_stage = nullptr; size_t h_stage_bytes = 0;
+  void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
+  int max_dyn_lds = 0;
+};
+
+struct lsm2d_cloudset {
+  lsm2d_context* ctx = nullptr;
+  int32_t n_clouds = 0;
+  int64_t total = 0;          // logical points
+  int64_t padded_total = 0;   // device points incl. even-alignment padding
+  float2* d_xy = nullptr; float2* d_nrm = nullptr;
+  int32_t* d_start = nullptr; int32_t* d_count = nullptr;
+  std::vector<int32_t> h_start, h_count;
+};
+
+#define HIPCHK(ctx, call)                                                                           \
+  do {                                                                                              \
+    hipError_t e__ = (call);                                                                        \
+    if (e__ != hipSuccess) {                                                                        \
+      char buf__[512];                                                                              \
+      snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      g_last_error = buf__;                                                                         \
+      if (ctx) (ctx)->last_error = buf__;                                                           \
+      return e__ == hipErrorOutOfMemory ? LSM2D_OUT_OF_MEMORY : LSM2D_DEVICE_ERROR;                 \
+    }                                                                                               \
+  } while (0)
+
+static int fail(lsm2d_context* ctx, int code, const char* msg) {
+  g_last_error = msg;
+  if (ctx) ctx->last_error = msg;
+  return code;
+}
+
+extern "C" int lsm2d_version(void) { return LSM2D_VERSION; }
+
+extern "C" const char* lsm2d_status_string(int s) {
+  switch (s) {
+    case LSM2D_SUCCESS: return "Success";
+    case LSM2D_NOT_ENOUGH_CORRESPONDENCES: return "NotEnoughCorrespondences";
+    case LSM2D_NOT_ENOUGH_INLIERS: return "NotEnoughInliers";
+    case LSM2D_SINGULAR_H: return "SingularH";
+    case LSM2D_BAD_ARGUMENT: return "BadArgument";
+    case LSM2D_DEVICE_ERROR: return "DeviceError";
+    case LSM2D_OUT_OF_MEMORY: return "OutOfMemory";
+    case LSM2D_CAPACITY_EXCEEDED: return "CapacityExceeded";
+    case LSM2D_NO_DEVICE: return "NoDevice";
+    default: return "Unknown";
+  }
+}
+
+extern "C" const char* lsm2d_last_error(const lsm2d_context* ctx) {
+  return ctx ? ctx->last_error.c_str() : g_last_error.c_str();
+}
+
+extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out) {
+  if (!out) return LSM2D_BAD_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, LSM2D_NO_DEVICE, "no HIP device visible");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, LSM2D_BAD_ARGUMENT, "device_id out of range");
+  lsm2d_context* c = new (std::nothrow) lsm2d_context;
+  if (!c) return LSM2D_OUT_OF_MEMORY;
+  c->device = device_id;
+  lsm2d_context* ctx = c;
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess && hip_stream) { c->stream = (hipStream_t) hip_stream; c->owns_stream = false; }
+  else if (e == hipSuccess) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); c->owns_stream = true; }
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) { g_last_error = hipGetErrorString(e); delete c; return LSM2D_DEVICE_ERROR; }
+  // allow the big-canvas configurations to use the whole 160 KiB LDS of a CDNA4 CU
+  hipDeviceProp_t prop;
+  HIPCHK(ctx, hipGetDeviceProperties(&prop, device_id));
+  c->max_dyn_lds = (int) prop.sharedMemPerBlock;
+  (void) hipFuncSetAttribute((const void*) k_align, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipGetLastError();
+  *out = c;
+  return LSM2D_SUCCESS;
+}
+
+extern "C" void lsm2d_destroy(lsm2d_context* c) {
+  if (!c) return;
+  (void) hipSetDevice(c->device);
+  (void) hipStreamSynchronize(c->stream);
+  if (c->h_stage) (void) hipHostFree(c->h_stage);
+  if (c->d_scratch) (void) hipFree(c->d_scratch);
+  if (c->ev0) (void) hipEventDestroy(c->ev0);
+  if (c->ev1) (void) hipEventDestroy(c->ev1);
+  if (c->owns_stream && c->stream) (void) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
+  if (!ctx) return LSM2D_BAD_ARGUMENT;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LSM2D_SUCCESS;
+}
+
+extern "C" int lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms) {
+  if (!ctx || !out_ms) return LSM2D_BAD_ARGUMENT;
+  if (!ctx->have_timing) return fail(ctx, LSM2D_BAD_ARGUMENT, "no timed launch yet");
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+  HIPCHK(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+  return LSM2D_SUCCESS;
+}
+
+static int ensure_stage(lsm2d_context* ctx, size_t bytes) {
+  if (bytes <= ctx->h_stage_bytes) return LSM2D_SUCCESS;
+  if (ctx->h_stage) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipHostFree(ctx->h_stage)); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
+  size_t cap = bytes + bytes / 2 + 4096;
+  HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
+  ctx->h_stage_bytes = cap;
+  return LSM2D_SUCCESS;
+}
+static int ensure_scratch(lsm2d_context* ctx, size_t bytes) {
+  if (bytes <= ctx->d_scratch_bytes) return LSM2D_SUCCESS;
+  if (ctx->d_scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->d_scratch_bytes = 0; }
+  size_t cap = bytes + bytes / 2 + 4096;
+  HIPCHK(ctx, hipMalloc(&ctx->d_scratch, cap));
+  ctx->d_scratch_bytes = cap;
+  return LSM2D_SUCCESS;
+}
+
+// ---- cloud sets -----------------------------------------------------------------------------------
+static int cloudset_layout(lsm2d_cloudset* cs, const int32_t* offsets, int32_t n_clouds, int64_t total) {
+  cs->n_clouds = n_clouds; cs->total = total;
+  cs->h_start.resize(n_clouds); cs->h_count.resize(n_clouds);
+  int64_t p = 0;
+  for (int32_t c = 0; c < n_clouds; ++c) {
+    const int64_t b = offsets ? offsets[c] : 0, e = offsets ? offsets[c + 1] : total;
+    if (b < 0 || e < b || e > total) return LSM2D_BAD_ARGUMENT;
+    cs->h_start[c] = (int32_t) p; cs->h_count[c] = (int32_t) (e - b);
+    p += (e - b); p += (p & 1);        // every cloud starts on an even point index (16-byte aligned xy)
+    if (p > 0x7fffffff - 2) return LSM2D_CAPACITY_EXCEEDED;
+  }
+  if (offsets && (offsets[0] != 0 || offsets[n_clouds] != total)) return LSM2D_BAD_ARGUMENT;
+  cs->padded_total = p + 2;            // slack so the last lane's 16-byte load stays in bounds
+  return LSM2D_SUCCESS;
+}
+
+static int cloudset_alloc(lsm2d_context* ctx, lsm2d_cloudset* cs) {
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_xy, sizeof(float2) * (size_t) cs->padded_total));
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_nrm, sizeof(float2) * (size_t) cs->padded_total));
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_start, sizeof(int32_t) * (size_t) cs->n_clouds));
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_count, sizeof(int32_t) * (size_t) cs->n_clouds));
+  HIPCHK(ctx, hipMemsetAsync(cs->d_xy, 0, sizeof(float2) * (size_t) cs->padded_total, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(cs->d_nrm, 0, sizeof(float2) * (size_t) cs->padded_total, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(cs->d_start, cs->h_start.data(), sizeof(int32_t) * (size_t) cs->n_clouds, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(cs->d_count, cs->h_count.data(), sizeof(int32_t) * (size_t) cs->n_clouds, hipMemcpyHostToDevice, ctx->stream));
+  return LSM2D_SUCCESS;
+}
+
+static int cloudset_create_impl(lsm2d_context* ctx, const void* points, bool on_device, const int32_t* offsets,
+                                int32_t n_clouds, int64_t total, lsm2d_cloudset** out) {
+  if (!ctx || !out || n_clouds < 1 || total < 0 || (total > 0 && !points) || (n_clouds > 1 && !offsets))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "cloudset_create: bad argument");
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  lsm2d_cloudset* cs = new (std::nothrow) lsm2d_cloudset;
+  if (!cs) return LSM2D_OUT_OF_MEMORY;
+  cs->ctx = ctx;
+  int rc = cloudset_layout(cs, offsets, n_clouds, total);
+  if (rc == LSM2D_SUCCESS) rc = cloudset_alloc(ctx, cs);
+  if (rc != LSM2D_SUCCESS) { lsm2d_cloudset_destroy(cs); return rc; }
+  if (total > 0) {
+    // stage the AoS points (and the logical offsets) on the device, then split / pad with one kernel
+    const size_t pts_bytes = sizeof(float4) * (size_t) total, off_bytes = sizeof(int32_t) * (size_t) (n_clouds + 1);
+    void* d_src = nullptr; int32_t* d_off = nullptr;
+    std::vector<int32_t> one = {0, (int32_t) total};
+    const int32_t* h_off = offsets ? offsets : one.data();
+    hipError_t e = hipSuccess;
+    if (!on_device) {
+      e = hipMalloc(&d_src, pts_bytes);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_src, points, pts_bytes, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMalloc((void**) &d_off, off_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, h_off, off_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      const int block = 256;
+      long long blocks = (total + block - 1) / block; if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(k_repack_cloud, dim3((unsigned) blocks), dim3(block), 0, ctx->stream,
+                         (const float4*) (on_device ? points : d_src), d_off, cs->d_start, n_clouds, (long long) total, cs->d_xy, cs->d_nrm);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_src) (void) hipFree(d_src);
+    if (d_off) (void) hipFree(d_off);
+    if (e != hipSuccess) { lsm2d_cloudset_destroy(cs); HIPCHK(ctx, e); }
+  } else {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *out = cs;
+  return LSM2D_SUCCESS;
+}
+
+extern "C" int lsm2d_cloudset_create(lsm2d_context* ctx, const float* pts, const int32_t* offsets, int32_t n_clouds,
+                                     int64_t total, lsm2d_cloudset** out) {
+  return cloudset_create_impl(ctx, pts, false, offsets, n_clouds, total, out);
+}
+extern "C" int lsm2d_cloudset_create_from_device(lsm2d_context* ctx, const void* d_pts, const int32_t* offsets,
+                                                 int32_t n_clouds, int64_t total, lsm2d_cloudset** out) {
+  return cloudset_create_impl(ctx, d_pts, true, offsets, n_clouds, total, out);
+}
+extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
+  if (!cs) return;
+  if (cs->ctx) (void) hipSetDevice(cs->ctx->device);
+  if (cs->d_xy) (void) hipFree(cs->d_xy);
+  if (cs->d_nrm) (void) hipFree(cs->d_nrm);
+  if (cs->d_start) (void) hipFree(cs->d_start);
+  if (cs->d_count) (void) hipFree(cs->d_count);
+  delete cs;
+}
+extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
+extern "C" int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* cs) { return cs ? cs->total : 0; }
+
+// ---- parameter packing -------------------------------------------------------------------------------
+static bool make_projk(const lsm2d_projector& p, ProjK* k) {
+  if (p.canvas_cols <= 0 || !(p.angle_max > p.angle_min) || !(p.range_max >= p.range_min) || !(p.range_min >= 0.0f)) return false;
+  k->cols = p.canvas_cols;
+  k->K00 = (float) p.canvas_cols / (p.angle_max - p.angle_min);
+  k->K01 = (float) p.canvas_cols * 0.5f + p.col_offset;
+  k->rmin = p.range_min; k->rmax = p.range_max; k->colsf = (float) p.canvas_cols;
+  return true;
+}
+static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
+  CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
+  return c;
+}
+static Iso make_iso(const float pose[3]) { Iso T; T.c = cosf(pose[2]); T.s = sinf(pose[2]); T.tx = pose[0]; T.ty = pose[1]; return T; }
+static float wrap_host(float a) {
+  while (a > 3.14159274101257324f) a -= 6.28318548202514648f;
+  while (a <= -3.14159274101257324f) a += 6.28318548202514648f;
+  return a;
+}
+static void inverse_host(const float a[3], float out[3]) {   // (R,t)^-1 = (R^T, -R^T t)
+  const float c = cosf(a[2]), s = sinf(a[2]);
+  out[0] = -(fmaf(c, a[0], s * a[1]));
+  out[1] = -(fmaf(-s, a[0], c * a[1]));
+  out[2] = wrap_host(-a[2]);
+}
+static bool valid_cloud_index(const lsm2d_cloudset* cs, int32_t i) { return cs && i >= 0 && i < cs->n_clouds; }
+
+// ---- a3 ------------------------------------------------------------------------------------------------
+extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* cloud, int32_t ci,
+                             const float pose[3], int32_t* out_src, float* out_depth, float* out_xynn) {
+  if (!ctx || !pr || !pose || !valid_cloud_index(cloud, ci)) return fail(ctx, LSM2D_BAD_ARGUMENT, "project: bad argument");
+  ProjectArgs A;
+  if (!make_projk(*pr, &A.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "project: bad projector");
+  const size_t lds = sizeof(u64) * (size_t) A.proj.cols;
+  if ((int) lds > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "project: canvas does not fit LDS");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t cols = (size_t) A.proj.cols, bytes = cols * (4 + 4 + 16);
+  int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+  rc = ensure_stage(ctx, bytes); if (rc) return rc;
+  A.cloud = cloud_dev(cloud, nullptr); A.ci = ci; A.T = make_iso(pose);
+  A.out_xynn = (float4*) ctx->d_scratch;
+  A.out_src = (int32_t*) ((char*) ctx->d_scratch + cols * 16);
+  A.out_depth = (float*) ((char*) ctx->d_scratch + cols * 20);
+  hipLaunchKernelGGL(k_project_canvas, dim3(1), dim3(kFindBlock), lds, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (out_xynn) memcpy(out_xynn, ctx->h_stage, cols * 16);
+  if (out_src) memcpy(out_src, (char*) ctx->h_stage + cols * 16, cols * 4);
+  if (out_depth) memcpy(out_depth, (char*) ctx->h_stage + cols * 20, cols * 4);
+  return LSM2D_SUCCESS;
+}
+
+// ---- plugin interface #1 ---------------------------------------------------------------------------------
+extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_params* sp, const lsm2d_cloudset* fixed,
+                                          int32_t fi, const lsm2d_cloudset* moving, int32_t mi, const float pose[3],
+                                          lsm2d_correspondence* out_pairs, int32_t capacity, int32_t* out_n) {
+  if (!ctx || !sp || !pose || !out_n || !valid_cloud_index(fixed, fi) || !valid_cloud_index(moving, mi) || capacity < 0 ||
+      (capacity > 0 && !out_pairs))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad argument");
+  *out_n = 0;
+  if (sp->finder != LSM2D_FINDER_PROJECTIVE) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: finder not supported yet");
+  FindArgs A;
+  if (!make_projk(sp->projector, &A.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad projector");
+  const size_t cols = (size_t) A.proj.cols, lds = sizeof(u64) * 2 * cols;
+  if ((int) lds > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "find_correspondences: canvases do not fit LDS");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = cols * 8 + 16;
+  int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+  rc = ensure_stage(ctx, bytes); if (rc) return rc;
+  A.fixed = cloud_dev(fixed, nullptr); A.moving = cloud_dev(moving, nullptr); A.fc = fi; A.mc = mi;
+  A.point_distance = sp->point_distance; A.normal_cos = sp->normal_cos; A.T = make_iso(pose);
+  A.out_count = (int32_t*) ctx->d_scratch; A.out_pairs = (int32_t*) ((char*) ctx->d_scratch + 16);
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_find_projective, dim3(1), dim3(kFindBlock), lds, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = true;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t n = *(const int32_t*) ctx->h_stage;
+  *out_n = n;
+  if (n > capacity) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "find_correspondences: out_pairs too small");
+  memcpy(out_pairs, (char*) ctx->h_stage + 16, sizeof(lsm2d_correspondence) * (size_t) n);
+  return LSM2D_SUCCESS;
+}
+
+// ---- factor ---------------------------------------------------------------------------------------------------
+extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp, const lsm2d_cloudset* fixed, int32_t fi,
+                               const lsm2d_cloudset* moving, int32_t mi, const lsm2d_correspondence* pairs, int32_t n_pairs,
+                               const float pose[3], float out_H[9], float out_b[3], lsm2d_iteration_stats* st) {
+  if (!ctx || !sp || !pose || !out_H || !out_b || !valid_cloud_index(fixed, fi) || !valid_cloud_index(moving, mi) || n_pairs < 0 ||
+      (n_pairs > 0 && !pairs))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "linearize: bad argument");
+  for (int32_t k = 0; k < n_pairs; ++k)
+    if (pairs[k].fixed_idx < 0 || pairs[k].fixed_idx >= fixed->h_count[fi] || pairs[k].moving_idx < 0 || pairs[k].moving_idx >= moving->h_count[mi])
+      return fail(ctx, LSM2D_BAD_ARGUMENT, "linearize: correspondence index out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int blocks = (n_pairs + 255) / 256; if (blocks < 1) blocks = 1; if (blocks > 1024) blocks = 1024;
+  const size_t pair_bytes = sizeof(lsm2d_correspondence) * (size_t) n_pairs;
+  const size_t part_off = (pair_bytes + 255) & ~(size_t) 255, out_off = part_off + sizeof(float) * kAccumWords * (size_t) blocks;
+  const size_t bytes = out_off + sizeof(float) * kAccumWords;
+  int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+  rc = ensure_stage(ctx, bytes); if (rc) return rc;
+  if (n_pairs) memcpy(ctx->h_stage, pairs, pair_bytes);
+  if (n_pairs) HIPCHK(ctx, hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, pair_bytes, hipMemcpyHostToDevice, ctx->stream));
+  LinArgs A;
+  A.fixed = cloud_dev(fixed, nullptr); A.moving = cloud_dev(moving, nullptr); A.fc = fi; A.mc = mi;
+  A.pairs = (const int32_t*) ctx->d_scratch; A.n_pairs = n_pairs; A.T = make_iso(pose);
+  A.cauchy = sp->robustifier == LSM2D_ROBUST_CAUCHY; A.tau = sp->chi_threshold;
+  A.partial = (float*) ((char*) ctx->d_scratch + part_off); A.out = (float*) ((char*) ctx->d_scratch + out_off);
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_linearize_partial, dim3(blocks), dim3(256), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_linearize_final, dim3(1), dim3(64), 0, ctx->stream, (const float*) A.partial, blocks, A.out);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = true;
+  float* h = (float*) ((char*) ctx->h_stage + out_off);
+  HIPCHK(ctx, hipMemcpyAsync(h, A.out, sizeof(float) * kAccumWords, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  out_H[0] = h[0]; out_H[1] = h[1]; out_H[2] = h[2]; out_H[3] = h[1]; out_H[4] = h[3]; out_H[5] = h[4]; out_H[6] = h[2]; out_H[7] = h[4]; out_H[8] = h[5];
+  out_b[0] = h[6]; out_b[1] = h[7]; out_b[2] = h[8];
+  if (st) {
+    int32_t iv[3]; memcpy(iv, h + 11, sizeof iv);
+    st->n_inliers = iv[0]; st->n_outliers = iv[1]; st->n_correspondences = iv[2]; st->chi_inliers = h[9]; st->chi_outliers = h[10];
+  }
+  return LSM2D_SUCCESS;
+}
+
+// ---- plugin interface #2 ----------------------------------------------------------------------------------------
+extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params* ap, const lsm2d_batch* b, float* out_pose,
+                                 float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats) {
+  if (!ctx || !ap || !b || !out_pose || !out_status) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: null argument");
+  const int n = b->n_alignments, ns = b->n_slices;
+  if (n < 0 || ns < 1 || ns > kMaxSlices || ap->max_iterations < 0 || !b->slices || !b->fixed || !b->moving || (n > 0 && !b->init_pose))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad batch descriptor");
+  if (n == 0) return LSM2D_SUCCESS;
+  static_assert(sizeof(StatsDev) == sizeof(lsm2d_iteration_stats), "stats layout");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+
+  AlignArgs A; memset(&A, 0, sizeof A);
+  A.n_align = n; A.n_slices = ns; A.max_it = ap->max_iterations; A.min_inliers = ap->min_num_inliers; A.damping = ap->damping;
+  // ---- device scratch layout: [init_pose | prior | indices | out_pose | out_H | status | its | stats]
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
+  const size_t o_pose_in = take(sizeof(float) * 3 * (size_t) n);
+  const size_t o_prior = b->prior ? take(sizeof(PriorDev) * (size_t) n) : 0;
+  size_t o_fidx[kMaxSlices] = {0}, o_midx[kMaxSlices] = {0};
+  for (int s = 0; s < ns; ++s) {
+    if (b->fixed_index) o_fidx[s] = take(sizeof(int32_t) * (size_t) n);
+    if (b->moving_index) o_midx[s] = take(sizeof(int32_t) * (size_t) n);
+  }
+  const size_t in_bytes = off;
+  const size_t o_pose = take(sizeof(float) * 3 * (size_t) n), o_H = take(sizeof(float) * 9 * (size_t) n);
+  const size_t o_status = take(sizeof(int32_t) * (size_t) n), o_its = take(sizeof(int32_t) * (size_t) n);
+  const size_t o_stats = out_stats ? take(sizeof(StatsDev) * (size_t) n * (size_t) (ap->max_iterations > 0 ? ap->max_iterations : 1)) : 0;
+  const size_t total_bytes = off, out_bytes = total_bytes - o_pose;
+  int rc = ensure_scratch(ctx, total_bytes); if (rc) return rc;
+  rc = ensure_stage(ctx, total_bytes); if (rc) return rc;
+  char* hs = (char*) ctx->h_stage; char* ds = (char*) ctx->d_scratch;
+
+  // ---- slices
+  int cols_max = 0, fcan_total = 0;
+  for (int s = 0; s < ns; ++s) {
+    const lsm2d_slice_params& sp = b->slices[s];
+    SliceDev& S = A.s[s];
+    const lsm2d_cloudset* f = b->fixed[s]; const lsm2d_cloudset* m = b->moving[s];
+    if (!f || !m || f->ctx != ctx || m->ctx != ctx) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: cloud set missing or from another context");
+    if (sp.finder != LSM2D_FINDER_PROJECTIVE) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: finder not supported yet");
+    if (!make_projk(sp.projector, &S.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad projector");
+    if (!b->fixed_index && f->n_clouds != 1 && f->n_clouds != n) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: fixed set must hold 1 or n_alignments clouds");
+    if (!b->moving_index && m->n_clouds != 1 && m->n_clouds != n) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: moving set must hold 1 or n_alignments clouds");
+    const int32_t* d_fi = nullptr; const int32_t* d_mi = nullptr;
+    if (b->fixed_index) {
+      const int32_t* src = b->fixed_index + (size_t) s * n;
+      for (int i = 0; i < n; ++i) if (src[i] < 0 || src[i] >= f->n_clouds) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: fixed_index out of range");
+      memcpy(hs + o_fidx[s], src, sizeof(int32_t) * (size_t) n); d_fi = (const int32_t*) (ds + o_fidx[s]);
+    }
+    if (b->moving_index) {
+      const int32_t* src = b->moving_index + (size_t) s * n;
+      for (int i = 0; i < n; ++i) if (src[i] < 0 || src[i] >= m->n_clouds) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: moving_index out of range");
+      memcpy(hs + o_midx[s], src, sizeof(int32_t) * (size_t) n); d_mi = (const int32_t*) (ds + o_midx[s]);
+    }
+    S.fixed = cloud_dev(f, d_fi); S.moving = cloud_dev(m, d_mi);
+    S.finder = sp.finder; S.point_distance = sp.point_distance; S.normal_cos = sp.normal_cos; S.max_distance = sp.max_distance;
+    S.cauchy = sp.robustifier == LSM2D_ROBUST_CAUCHY; S.tau = sp.chi_threshold; S.min_corr = sp.min_num_correspondences;
+    if (S.cauchy && !(S.tau > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: chi_threshold must be > 0");
+    S.has_sensor = !(sp.sensor_in_robot[0] == 0.0f && sp.sensor_in_robot[1] == 0.0f && sp.sensor_in_robot[2] == 0.0f);
+    inverse_host(sp.sensor_in_robot, S.Sinv); S.cSinv = cosf(S.Sinv[2]); S.sSinv = sinf(S.Sinv[2]);
+    S.fcan_offset = fcan_total; fcan_total += S.proj.cols; if (S.proj.cols > cols_max) cols_max = S.proj.cols;
+  }
+  A.cols_max = cols_max; A.fcan_total = fcan_total;
+  const size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float) * kAccumWords * (kAlignBlock / 64);
+  if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
+
+  // ---- inputs
+  memcpy(hs + o_pose_in, b->init_pose, sizeof(float) * 3 * (size_t) n);
+  if (b->prior) {
+    PriorDev* p = (PriorDev*) (hs + o_prior);
+    for (int i = 0; i < n; ++i) {
+      inverse_host(b->prior[i].z, p[i].z_inv); p[i].cz = cosf(p[i].z_inv[2]); p[i].sz = sinf(p[i].z_inv[2]);
+      memcpy(p[i].omega, b->prior[i].omega, sizeof(float) * 9);
+    }
+    A.prior = (const PriorDev*) (ds + o_prior);
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  A.init_pose = (const float*) (ds + o_pose_in);
+  A.out_pose = (float*) (ds + o_pose); A.out_H = (float*) (ds + o_H); A.out_status = (int32_t*) (ds + o_status); A.out_its = (int32_t*) (ds + o_its);
+  A.out_stats = out_stats ? (StatsDev*) (ds + o_stats) : nullptr;
+
+  HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_align, dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = true;
+  HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out_pose, hs + o_pose, sizeof(float) * 3 * (size_t) n);
+  if (out_H) memcpy(out_H, hs + o_H, sizeof(float) * 9 * (size_t) n);
+  memcpy(out_status, hs + o_status, sizeof(int32_t) * (size_t) n);
+  if (out_its) memcpy(out_its, hs + o_its, sizeof(int32_t) * (size_t) n);
+  if (out_stats) memcpy(out_stats, hs + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) ap->max_iterations);
+  return LSM2D_SUCCESS;
+}

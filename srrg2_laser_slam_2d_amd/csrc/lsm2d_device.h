@@ -1,0 +1,223 @@
+// lsm2d_device.h -- device-side arithmetic of the scan-matching hot path (gfx950, wave64).
+//
+// Every routine here is a FIXED sequence of IEEE-754 fp32 operations (explicit fmaf, IEEE divide and
+// sqrt, no fast-math, built with -ffp-contract=off) so that column indices, z-buffer winners and
+// per-pair factor terms are reproducible bit-for-bit on a CPU; only the order of the H/b sums is
+// device-specific.  Reference semantics per routine:
+//   transform   PointNormal2f::transform<Isometry> as used at
+//               registration/correspondence_finder_kd_tree_2d.cpp:15-16
+//   projection  PointNormal2fProjectorPolar::compute as used at
+//               registration/correspondence_finder_projective_2d.cpp:40-41,47-48
+//   factor      SE2Plane2PlaneErrorFactor = 2-D restriction of octave/solver/nicp_post.m:4-26
+//   robustifier RobustifierCauchy (configurations/stage_segway_double_config_MULTI.json:153-158)
+//   step        octave/solver/nicp_post.m:92-97 (dx = -H\b ; T = T*v2t(dx))
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lsm2d {
+
+typedef unsigned long long u64;
+static constexpr u64 kEmptyCell = ~0ull;   // depth bits 0xFFFFFFFF (a NaN pattern no valid depth reaches), idx -1
+
+#define LSM2D_DEV __device__ __forceinline__
+
+struct Iso { float c, s, tx, ty; };          // R = [[c,-s],[s,c]], t = (tx,ty)
+
+// projector constants, precomputed once on the host in fp32
+struct ProjK {
+  float K00, K01;       // column = floor(K00*theta + K01)
+  float rmin, rmax;     // range gate
+  float colsf;          // (float) canvas_cols
+  int   cols;
+};
+
+LSM2D_DEV void xf_point(const Iso& T, float px, float py, float& qx, float& qy) {
+  qx = __builtin_fmaf(T.c, px, __builtin_fmaf(-T.s, py, T.tx));
+  qy = __builtin_fmaf(T.s, px, __builtin_fmaf(T.c, py, T.ty));
+}
+LSM2D_DEV void xf_normal(const Iso& T, float nx, float ny, float& ox, float& oy) {
+  ox = __builtin_fmaf(T.c, nx, (-T.s) * ny);
+  oy = __builtin_fmaf(T.s, nx, T.c * ny);
+}
+
+// atan2 as a fixed polynomial: atan(a) = a + a*s*P(s), s = a*a, a = min/max in [0,1] (IEEE divide),
+// degree-7 P (tools/fit_atan.py: max abs error 7.3e-8 rad on [0,1]), exact octant fix-ups.
+LSM2D_DEV float atan2_poly(float y, float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+  float r = 0.0f;
+  if (mx > 0.0f) {
+    const float a = mn / mx;
+    const float s = a * a;
+    float p = 2.622197615e-03f;
+    p = __builtin_fmaf(p, s, -1.513234153e-02f);
+    p = __builtin_fmaf(p, s, 4.112152755e-02f);
+    p = __builtin_fmaf(p, s, -7.366676629e-02f);
+    p = __builtin_fmaf(p, s, 1.057391763e-01f);
+    p = __builtin_fmaf(p, s, -1.418597102e-01f);
+    p = __builtin_fmaf(p, s, 1.999039650e-01f);
+    p = __builtin_fmaf(p, s, -3.333298564e-01f);
+    r = __builtin_fmaf(a * s, p, a);
+  }
+  if (ay > ax) r = 1.57079637050628662f - r;
+  if (x < 0.0f) r = 3.14159274101257324f - r;
+  return y < 0.0f ? -r : r;
+}
+
+LSM2D_DEV float wrap_angle(float a) {
+  while (a > 3.14159274101257324f) a -= 6.28318548202514648f;
+  while (a <= -3.14159274101257324f) a += 6.28318548202514648f;
+  return a;
+}
+
+// One point of the polar z-buffer.  key = (bits(depth) << 32) | index: depth >= 0 so the IEEE bit
+// pattern orders like the value, and the 64-bit unsigned min keeps the nearest point with ties going
+// to the LOWEST index == "first point wins under strict <" of the sequential reference loop.
+LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, int idx, u64* canvas) {
+  float qx, qy;
+  xf_point(T, px, py, qx, qy);
+  const float r = __builtin_sqrtf(__builtin_fmaf(qx, qx, qy * qy));
+  if (r >= P.rmin && r <= P.rmax) {
+    const float th = atan2_poly(qy, qx);
+    const float u  = __builtin_fmaf(P.K00, th, P.K01);
+    if (u >= 0.0f && u < P.colsf) {
+      const int col = (int) __builtin_floorf(u);
+      const u64 key = ((u64) __float_as_uint(r) << 32) | (u64) (uint32_t) idx;
+      // the cell only ever decreases, so a plain read that already beats us makes the atomic a no-op
+      if (key < canvas[col]) atomicMin(&canvas[col], key);
+    }
+  }
+}
+
+// Stream one cloud through the z-buffer.  xy is 16-byte aligned (cloud starts are padded to an even
+// point index by the host) so every lane loads two points with one 16-byte global_load_dwordx4.
+LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& T, const ProjK& P,
+                             u64* canvas, int tid, int nthreads) {
+  const float4* __restrict__ xy4 = reinterpret_cast<const float4*>(xy);
+  const int npairs = (n + 1) >> 1;
+  for (int j = tid; j < npairs; j += nthreads) {
+    const float4 v = xy4[j];
+    project_point(T, P, v.x, v.y, 2 * j, canvas);
+    if (2 * j + 1 < n) project_point(T, P, v.z, v.w, 2 * j + 1, canvas);
+  }
+}
+
+// ---- factor ---------------------------------------------------------------------------------
+struct Accum {      // one lane's partial sums of H (6 unique), b (3), chi and counts
+  float h00, h01, h02, h11, h12, h22, b0, b1, b2, chi_in, chi_out;
+  int n_in, n_out, n_corr;
+};
+LSM2D_DEV void accum_zero(Accum& a) {
+  a.h00 = a.h01 = a.h02 = a.h11 = a.h12 = a.h22 = a.b0 = a.b1 = a.b2 = a.chi_in = a.chi_out = 0.0f;
+  a.n_in = a.n_out = a.n_corr = 0;
+}
+
+// e = [ n_f.(q - p_f) ; n_q - n_f ],  J = [[ (R^T n_f)^T , n_f.(R J2 p_m) ], [ 0 , R J2 n_m ]]
+LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, float2 nm, bool cauchy,
+                               float tau, Accum& A) {
+  float qx, qy, nqx, nqy;
+  xf_point(T, pm.x, pm.y, qx, qy);
+  xf_normal(T, nm.x, nm.y, nqx, nqy);
+  const float dx = qx - pf.x, dy = qy - pf.y;
+  const float e0 = __builtin_fmaf(nf.x, dx, nf.y * dy);
+  const float e1 = nqx - nf.x, e2 = nqy - nf.y;
+  const float a0 = __builtin_fmaf(T.c, nf.x, T.s * nf.y);
+  const float a1 = __builtin_fmaf(-T.s, nf.x, T.c * nf.y);
+  const float a2 = __builtin_fmaf(a1, pm.x, -(a0 * pm.y));
+  const float d0 = -nqy, d1 = nqx;
+  const float chi = __builtin_fmaf(e0, e0, __builtin_fmaf(e1, e1, e2 * e2));
+  float w = 1.0f;
+  if (cauchy) {
+    const float q = chi / tau;
+    w = 1.0f / (1.0f + q);
+    if (chi < tau) { ++A.n_in; A.chi_in += chi; }
+    else { ++A.n_out; A.chi_out += tau * logf(1.0f + q); }
+  } else { ++A.n_in; A.chi_in += chi; }
+  ++A.n_corr;
+  const float dd = __builtin_fmaf(d0, d0, d1 * d1);
+  const float de = __builtin_fmaf(d0, e1, d1 * e2);
+  const float wa0 = w * a0, wa1 = w * a1, wa2 = w * a2;
+  A.h00 = __builtin_fmaf(wa0, a0, A.h00); A.h01 = __builtin_fmaf(wa0, a1, A.h01); A.h02 = __builtin_fmaf(wa0, a2, A.h02);
+  A.h11 = __builtin_fmaf(wa1, a1, A.h11); A.h12 = __builtin_fmaf(wa1, a2, A.h12);
+  A.h22 = __builtin_fmaf(wa2, a2, A.h22); A.h22 = __builtin_fmaf(w, dd, A.h22);
+  A.b0 = __builtin_fmaf(wa0, e0, A.b0); A.b1 = __builtin_fmaf(wa1, e0, A.b1);
+  A.b2 = __builtin_fmaf(wa2, e0, A.b2); A.b2 = __builtin_fmaf(w, de, A.b2);
+}
+
+// ---- wave64 / workgroup reduction: shuffle butterfly, one LDS hop, fixed order => deterministic ----
+static constexpr int kAccumWords = 14;
+
+LSM2D_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+LSM2D_DEV int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// all threads call; afterwards `red` (LDS, nwaves*kAccumWords words) holds per-wave totals.
+LSM2D_DEV void block_reduce_store(const Accum& A, float* red, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  float f[11] = {A.h00, A.h01, A.h02, A.h11, A.h12, A.h22, A.b0, A.b1, A.b2, A.chi_in, A.chi_out};
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float s = wave_sum(f[k]);
+    if (lane == 0) red[wave * kAccumWords + k] = s;
+  }
+  const int i0 = wave_sum_i(A.n_in), i1 = wave_sum_i(A.n_out), i2 = wave_sum_i(A.n_corr);
+  if (lane == 0) {
+    red[wave * kAccumWords + 11] = __int_as_float(i0);
+    red[wave * kAccumWords + 12] = __int_as_float(i1);
+    red[wave * kAccumWords + 13] = __int_as_float(i2);
+  }
+}
+// one thread: sum the per-wave totals in wave order
+LSM2D_DEV void block_reduce_gather(const float* red, int nwaves, Accum& A) {
+  accum_zero(A);
+  for (int w = 0; w < nwaves; ++w) {
+    const float* r = red + w * kAccumWords;
+    A.h00 += r[0]; A.h01 += r[1]; A.h02 += r[2]; A.h11 += r[3]; A.h12 += r[4]; A.h22 += r[5];
+    A.b0 += r[6]; A.b1 += r[7]; A.b2 += r[8]; A.chi_in += r[9]; A.chi_out += r[10];
+    A.n_in += __float_as_int(r[11]); A.n_out += __float_as_int(r[12]); A.n_corr += __float_as_int(r[13]);
+  }
+}
+
+// ---- step: (H + damping I) dx = -b in fp64 (LDL^T), X <- X * v2t(dx) ------------------------------
+// returns false on a non-positive / non-finite pivot (SingularH)
+LSM2D_DEV bool solve_update(const float H[9], const float b[3], float damping, float pose[3]) {
+  const double a00 = (double) H[0] + (double) damping, a01 = H[1], a02 = H[2];
+  const double a11 = (double) H[4] + (double) damping, a12 = H[5], a22 = (double) H[8] + (double) damping;
+  const double r0 = -(double) b[0], r1 = -(double) b[1], r2 = -(double) b[2];
+  const double d0 = a00;
+  if (!(d0 > 0) || !__builtin_isfinite(d0)) return false;
+  const double l10 = a01 / d0, l20 = a02 / d0;
+  const double d1 = a11 - l10 * a01;
+  if (!(d1 > 0) || !__builtin_isfinite(d1)) return false;
+  const double l21 = (a12 - l20 * a01) / d1;
+  const double d2 = a22 - l20 * a02 - l21 * l21 * d1;
+  if (!(d2 > 0) || !__builtin_isfinite(d2)) return false;
+  const double y0 = r0, y1 = r1 - l10 * y0, y2 = r2 - l20 * y0 - l21 * y1;
+  const double z2 = y2 / d2;
+  const double z1 = y1 / d1 - l21 * z2;
+  const double z0 = y0 / d0 - l10 * z1 - l20 * z2;
+  if (!__builtin_isfinite(z0) || !__builtin_isfinite(z1) || !__builtin_isfinite(z2)) return false;
+  const float dx = (float) z0, dy = (float) z1, dth = (float) z2;
+  const float c = cosf(pose[2]), s = sinf(pose[2]);
+  const float nx = __builtin_fmaf(c, dx, __builtin_fmaf(-s, dy, pose[0]));
+  const float ny = __builtin_fmaf(s, dx, __builtin_fmaf(c, dy, pose[1]));
+  pose[0] = nx; pose[1] = ny; pose[2] = wrap_angle(pose[2] + dth);
+  return true;
+}
+
+// v2t(a) * v2t(b) -> t2v, with cos/sin of a given (host- or device-computed)
+LSM2D_DEV void compose(float ca, float sa, const float a[3], const float b[3], float out[3]) {
+  out[0] = __builtin_fmaf(ca, b[0], __builtin_fmaf(-sa, b[1], a[0]));
+  out[1] = __builtin_fmaf(sa, b[0], __builtin_fmaf(ca, b[1], a[1]));
+  out[2] = wrap_angle(a[2] + b[2]);
+}
+
+}  // namespace lsm2d

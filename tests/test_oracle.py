@@ -1,0 +1,263 @@
+"""CPU tests of the oracle (the restated reference algorithm): known answers and invariants.
+
+The reference has no golden vector for this path -- these are the substitutes it
+lists: hand-checkable projector cases, finite-difference Jacobian, the SE(2) restriction of
+octave/solver/nicp_post.m evaluated independently (tests/golden/nicp_2d_known_answer.json), zero-noise
+convergence to the generating pose, the status logic of the aligner."""
+import json
+import math
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from srrg2_laser_slam_2d_amd import synth
+
+
+def test_atan2_polynomial_accuracy(po):
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=20000).astype(np.float32); x = rng.normal(size=20000).astype(np.float32)
+    got = po.atan2f(y, x)
+    ref = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    assert np.max(np.abs(got - ref)) < 3.5e-7
+    # axes, origin, signs
+    for (yy, xx, want) in [(0, 0, 0.0), (0, 1, 0.0), (1, 0, math.pi / 2), (0, -1, math.pi), (-1, 0, -math.pi / 2),
+                           (1, 1, math.pi / 4), (-1, -1, -3 * math.pi / 4), (1e-30, 1e30, 0.0)]:
+        assert abs(float(po.atan2f([yy], [xx])[0]) - want) < 3e-7
+
+
+def _pt(r, ang, nx=1.0, ny=0.0):
+    return [r * math.cos(ang), r * math.sin(ang), nx, ny]
+
+
+def test_projector_columns_ties_and_gates(po):
+    pr = po.Projector(360, -math.pi, math.pi, 0.5, 10.0, 0.0)      # 1 degree per column, column 180 = angle 0
+    deg = math.pi / 180
+    cloud = np.array([
+        _pt(2.0, 0.5 * deg),      # 0 -> column 180
+        _pt(1.5, 0.6 * deg),      # 1 -> column 180, nearer: wins
+        _pt(1.5, 0.7 * deg),      # 2 -> column 180, same... different float depth, see below
+        _pt(0.4, 10.5 * deg),     # 3 below range_min: dropped
+        _pt(11.0, 20.5 * deg),    # 4 above range_max: dropped
+        _pt(3.0, -90.5 * deg),    # 5 -> column 89
+        _pt(3.0, 179.5 * deg),    # 6 -> column 359
+        _pt(3.0, -179.5 * deg),   # 7 -> column 0
+    ], np.float32)
+    src, depth, xyn = po.project(pr, cloud, [0, 0, 0])
+    assert src[180] in (1, 2) and abs(depth[180] - 1.5) < 1e-6
+    assert src[190] == -1 and src[200] == -1
+    assert src[89] == 5 and src[359] == 6 and src[0] == 7
+    assert (src >= 0).sum() == 4
+    assert depth[5] == np.finfo(np.float32).max
+    # exact tie: identical points -> the first index wins (strict <)
+    tie = np.array([_pt(2.0, 30.5 * deg)] * 3, np.float32)
+    s2, _, _ = po.project(pr, tie, [0, 0, 0])
+    assert s2[210] == 0
+    # the pose maps points into the camera frame: rotate by +90 deg moves angle 0.5deg to 90.5deg
+    s3, d3, x3 = po.project(pr, cloud[:1], [0, 0, math.pi / 2])
+    assert s3[270] == 0 and abs(x3[270, 3] - 1.0) < 1e-6     # normal (1,0) -> (0,1)
+    # col_offset = 0.5 rounds to nearest
+    pr2 = po.Projector(360, -math.pi, math.pi, 0.5, 10.0, 0.5)
+    s4, _, _ = po.project(pr2, cloud[:1], [0, 0, 0])
+    assert s4[181] == 0
+
+
+def test_projective_finder_identity_and_gates(po):
+    deg = math.pi / 180
+    ang = (np.arange(-60, 60) + 0.5) * deg
+    fixed = np.stack([3 * np.cos(ang), 3 * np.sin(ang), -np.cos(ang), -np.sin(ang)], 1).astype(np.float32)
+    sp = po.slice_params(canvas_cols=360, range_min=0.3, range_max=20, point_distance=0.5, normal_cos=0.8)
+    c = po.find(sp, fixed, fixed, [0, 0, 0])
+    assert len(c) == 120 and np.array_equal(c[:, 0], c[:, 1]) and np.all(np.diff(c[:, 0]) > 0)   # ascending column
+    # depth gate: moving pushed 0.6 m away radially -> no pairs
+    far = fixed.copy(); far[:, :2] *= 3.6 / 3.0
+    assert len(po.find(sp, fixed, far, [0, 0, 0])) == 0
+    # normal gate: moving normals rotated by 45 deg (cos = 0.707 < 0.8)
+    rot = fixed.copy(); c45 = math.cos(math.pi / 4)
+    rot[:, 2] = c45 * fixed[:, 2] - c45 * fixed[:, 3]; rot[:, 3] = c45 * fixed[:, 2] + c45 * fixed[:, 3]
+    assert len(po.find(sp, fixed, rot, [0, 0, 0])) == 0
+    # empty clouds
+    assert len(po.find(sp, fixed[:0], fixed, [0, 0, 0])) == 0
+    assert len(po.find(sp, fixed, fixed[:0], [0, 0, 0])) == 0
+
+
+def test_nn_finder_grid_equals_brute_force(po):
+    rng = np.random.default_rng(1)
+    def cloud(n):
+        p = rng.uniform(-5, 5, size=(n, 2)); a = rng.uniform(-np.pi, np.pi, n)
+        return np.concatenate([p, np.cos(a)[:, None], np.sin(a)[:, None]], 1).astype(np.float32)
+    fixed, moving = cloud(3000), cloud(2000)
+    fixed[10] = fixed[11]                       # duplicate point: tie -> lowest index
+    moving[0, :2] = fixed[11, :2]
+    for md in (0.05, 0.3, 1.0):
+        sp = po.slice_params(finder=po.FINDER_NN, max_distance=md, normal_cos=-1.0)
+        g = po.find(sp, fixed, moving, [0.1, -0.2, 0.3]); b = po.find(sp, fixed, moving, [0.1, -0.2, 0.3], brute=True)
+        assert np.array_equal(g, b) and len(g) > 0
+    sp = po.slice_params(finder=po.FINDER_NN, max_distance=0.3, normal_cos=-1.0)
+    c = po.find(sp, fixed, moving, [0, 0, 0])
+    assert c[0, 1] == 0 and c[0, 0] == 10
+    # ascending moving index, normal gate prunes
+    assert np.all(np.diff(c[:, 1]) > 0)
+    sp2 = po.slice_params(finder=po.FINDER_NN, max_distance=0.3, normal_cos=0.8)
+    assert 0 < len(po.find(sp2, fixed, moving, [0, 0, 0])) < len(c)
+
+
+def test_factor_jacobian_finite_differences(po):
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        f = rng.normal(size=4); m = rng.normal(size=4)
+        f[2:] /= np.linalg.norm(f[2:]); m[2:] /= np.linalg.norm(m[2:])
+        f = f.astype(np.float32); m = m.astype(np.float32)
+        pose = rng.uniform(-1, 1, 3)
+        e, J = po.error_jacobian(f, m, pose)
+        for k in range(3):
+            d = np.zeros(3); d[k] = 1e-6
+            def at(dx):
+                c, s = math.cos(pose[2]), math.sin(pose[2])
+                p = [pose[0] + c * dx[0] - s * dx[1], pose[1] + s * dx[0] + c * dx[1], pose[2] + dx[2]]   # X * v2t(dx)
+                return po.error_jacobian(f, m, p)[0]
+            num = (at(d) - at(-d)) / 2e-6
+            assert np.allclose(num, J[:, k], atol=1e-7)
+
+
+def test_known_answer_nicp_restriction(po):
+    g = json.load(open(golden_path("nicp_2d_known_answer.json")))
+    fixed = np.array(g["fixed"], np.float32); moving = np.array(g["moving"], np.float32)
+    corr = np.array([[0, 0], [1, 1], [2, 2]], np.int32)
+    sp = po.slice_params()
+    for i in range(3):
+        e, J = po.error_jacobian(fixed[i], moving[i], g["pose"])
+        assert np.allclose(e, g["pairs"][i]["e"], atol=1e-7) and np.allclose(J, g["pairs"][i]["J"], atol=1e-7)
+    H, b, st = po.linearize(sp, fixed, moving, corr, g["pose"], double=True)
+    assert np.allclose(H, g["H"], atol=1e-6) and np.allclose(b, g["b"], atol=1e-6)
+    assert st.n_corr == 3 and st.n_in == 3 and abs(st.chi_in - g["chi"]) < 1e-6
+    Hf, bf, _ = po.linearize(sp, fixed, moving, corr, g["pose"], double=False)
+    assert np.allclose(Hf, g["H"], atol=1e-5) and np.allclose(bf, g["b"], atol=1e-5)
+    rc, pose, dx = po.solve_update(H, b, g["pose"], double=True)
+    assert rc == 0 and np.allclose(dx, g["dx"], atol=1e-5) and np.allclose(pose, g["pose_after_step"], atol=1e-5)
+    # Cauchy robustifier
+    spc = po.slice_params(robustifier=po.ROBUST_CAUCHY, chi_threshold=g["cauchy"]["tau"])
+    Hc, bc, stc = po.linearize(spc, fixed, moving, corr, g["pose"], double=True)
+    assert np.allclose(Hc, g["cauchy"]["H"], atol=1e-6) and np.allclose(bc, g["cauchy"]["b"], atol=1e-6)
+    assert stc.n_in == g["cauchy"]["n_inliers"] and stc.n_out == 3 - g["cauchy"]["n_inliers"]
+    assert abs(stc.chi_in - g["cauchy"]["chi_inliers"]) < 1e-6 and abs(stc.chi_out - g["cauchy"]["chi_outliers"]) < 1e-6
+
+
+def test_h22_b2_identity(po):
+    """the normal rows only touch H22 (+= w|n_m|^2) and b2 (= -w (R J2 n_m).n_f)."""
+    f = np.array([[1, 2, 0.6, 0.8]], np.float32); m = np.array([[1.1, 1.9, 0.8, 0.6]], np.float32)
+    pose = [0.1, 0.2, 0.3]
+    e, J = po.error_jacobian(f[0], m[0], pose)
+    c, s = math.cos(0.3), math.sin(0.3)
+    nq = np.array([c * 0.8 - s * 0.6, s * 0.8 + c * 0.6]); d = np.array([-nq[1], nq[0]])
+    assert np.allclose(J[1:, 2], d, atol=1e-6) and np.allclose(J[1:, :2], 0)
+    assert abs(d @ e[1:] - (-(d @ f[0, 2:]))) < 1e-6
+
+
+def test_solve_singular_and_damping(po):
+    H = np.diag([0.0, 1.0, 1.0]); b = np.ones(3)
+    rc, _, _ = po.solve_update(H, b, [0, 0, 0], double=True)
+    assert rc == po.SINGULAR_H
+    rc, pose, dx = po.solve_update(H, b, [0, 0, 0], damping=1.0, double=True)
+    assert rc == 0 and np.allclose(dx, [-1, -0.5, -0.5])
+    # right update: translation is rotated by the current heading; angle wraps into (-pi, pi]
+    rc, pose, dx = po.solve_update(np.eye(3), [-1.0, 0.0, -0.2], [0, 0, 3.1], double=True)
+    assert abs(pose[0] - math.cos(3.1)) < 1e-12 and abs(pose[1] - math.sin(3.1)) < 1e-12 and abs(pose[2] - (3.3 - 2 * math.pi)) < 1e-12
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_aligner_converges_to_generating_pose(po, small_workload, double):
+    wl = small_workload
+    sp = po.slice_params(); ap = po.aligner_params(20)
+    for i in range(4):
+        f = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+        r = po.align(ap, [sp], [f], [wl.map_points], wl.x0[i], double=double)
+        assert r["status"] == po.SUCCESS and r["iterations"] == 20
+        err = np.abs(r["pose"] - wl.x_true[i])
+        assert err[:2].max() < (2e-6 if double else 2e-5) and err[2] < (1e-6 if double else 1e-5)
+        assert r["stats"][-1].chi_in < 1e-6 and r["stats"][-1].n_corr > 300
+        assert np.allclose(r["H"], r["H"].T) and np.all(np.linalg.eigvalsh(r["H"]) > 0)
+
+
+def test_aligner_nn_finder_converges(po, small_workload):
+    wl = small_workload
+    sp = po.slice_params(finder=po.FINDER_NN, max_distance=0.5)
+    ap = po.aligner_params(20)
+    f = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    # role B: fixed = map, moving = scan; the estimate is then scan-in-map = inverse of x_true
+    x_true_b = synth.invert_poses(wl.x_true[:1])[0]; x0_b = synth.invert_poses(wl.x0[:1].astype(np.float64))[0]
+    r = po.align(ap, [sp], [wl.map_points], [f], x0_b, double=True)
+    assert r["status"] == po.SUCCESS
+    assert np.abs(r["pose"] - x_true_b)[:2].max() < 5e-3 and abs(r["pose"][2] - x_true_b[2]) < 2e-3
+
+
+def test_aligner_status_logic(po, small_workload):
+    wl = small_workload
+    f = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    sp = po.slice_params(); ap = po.aligner_params(20)
+    # far-off initial guess: nothing matches -> NotEnoughCorrespondences on the first iteration, pose untouched
+    r = po.align(ap, [sp], [f], [wl.map_points + np.float32([100, 100, 0, 0])], wl.x0[0])
+    assert r["status"] == po.NOT_ENOUGH_CORRESPONDENCES and r["iterations"] == 1 and np.allclose(r["pose"], wl.x0[0])
+    # min_num_inliers above what any scan can give
+    r = po.align(po.aligner_params(20, min_num_inliers=100000), [sp], [f], [wl.map_points], wl.x0[0])
+    assert r["status"] == po.NOT_ENOUGH_INLIERS
+    # a single wall: translation along it is unobservable -> H singular at heading 0
+    wall = np.stack([np.linspace(-3, 3, 400), np.full(400, 2.0), np.zeros(400), -np.ones(400)], 1).astype(np.float32)
+    r = po.align(ap, [po.slice_params(min_num_correspondences=0)], [wall], [wall], [0, 0, 0], double=True)
+    assert r["status"] == po.SINGULAR_H
+    # zero iterations: Success, pose = initial guess
+    r = po.align(po.aligner_params(0), [sp], [f], [wl.map_points], wl.x0[0])
+    assert r["status"] == po.SUCCESS and r["iterations"] == 0 and np.allclose(r["pose"], wl.x0[0])
+
+
+def test_cauchy_reduces_outlier_influence(po, small_workload):
+    wl = small_workload
+    f = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]].copy()
+    f[::7, :2] += 0.3 * f[::7, 2:]         # every 7th scan point displaced 30 cm along its normal
+    ap = po.aligner_params(20)
+    plain = po.align(ap, [po.slice_params()], [f], [wl.map_points], wl.x0[1], double=True)
+    cauchy = po.align(ap, [po.slice_params(robustifier=po.ROBUST_CAUCHY, chi_threshold=0.05)], [f], [wl.map_points], wl.x0[1], double=True)
+    e_plain = np.abs(plain["pose"] - wl.x_true[1])[:2].max(); e_cauchy = np.abs(cauchy["pose"] - wl.x_true[1])[:2].max()
+    assert e_cauchy < e_plain and cauchy["stats"][-1].n_out > 50
+
+
+def test_multi_slice_with_sensor_offsets_and_prior(po):
+    """MULTI.json:715-721: two laser slices with their own extrinsics (+ an odometry prior) share ONE pose."""
+    world = synth.make_world(5)
+    m = synth.make_map(world, 30000)
+    robot = synth.sample_poses(world, 1, seed=11)
+    S0, S1 = np.array([0.2, 0.1, 0.1]), np.array([-0.3, 0.0, math.pi])
+    scans = []
+    for S in (S0, S1):
+        sensor = synth.compose_poses(robot, S[None, :])
+        pts, offs = synth.make_scans(world, sensor, n_beams=721)
+        scans.append(pts)
+    x_true = synth.invert_poses(robot)[0]                      # map in robot frame
+    delta = np.array([[0.04, -0.03, 0.03]])
+    x0 = synth.invert_poses(synth.compose_poses(robot, delta))[0]
+    sl = [po.slice_params(canvas_cols=721, range_max=20, sensor_in_robot=tuple(S), min_num_correspondences=5,
+                          robustifier=po.ROBUST_CAUCHY if k == 0 else po.ROBUST_NONE, chi_threshold=0.01)
+          for k, S in enumerate((S0, S1))]
+    ap = po.aligner_params(10)
+    r = po.align(ap, sl, scans, [m, m], x0, double=True)
+    assert r["status"] == po.SUCCESS
+    assert np.abs(r["pose"] - x_true)[:2].max() < 1e-4 and abs(r["pose"][2] - x_true[2]) < 1e-4
+    assert r["stats"][-1].n_corr > 600        # both slices contribute
+    # a stiff prior at the initial guess holds the estimate there
+    app = po.aligner_params(10, prior_z=x0, prior_omega=np.eye(3) * 1e9)
+    rp = po.align(app, sl, scans, [m, m], x0, double=True)
+    assert np.abs(rp["pose"] - x0).max() < 1e-4
+    # one slice starved of correspondences is skipped, the other still aligns
+    sl2 = [sl[0], po.slice_params(canvas_cols=721, range_max=20, sensor_in_robot=tuple(S1), min_num_correspondences=10000)]
+    r2 = po.align(ap, sl2, scans, [m, m], x0, double=True)
+    assert r2["status"] == po.SUCCESS and np.abs(r2["pose"] - x_true)[:2].max() < 1e-3
+
+
+def test_batch_driver_matches_single_calls(po, small_workload):
+    wl = small_workload
+    sp = po.slice_params(); ap = po.aligner_params(5)
+    xo, H, status, last = po.align_batch(ap, sp, wl.scan_points, wl.scan_offsets, wl.map_points, wl.x0, n_threads=3)
+    for i in range(len(wl.x0)):
+        f = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+        r = po.align(ap, [sp], [f], [wl.map_points], wl.x0[i])
+        assert np.array_equal(r["pose"], xo[i]) and status[i] == r["status"] and last[i].n_corr == r["stats"][-1].n_corr
