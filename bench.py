@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- scan-to-map alignments/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+Workload (BASELINE.json configs[1]): a batch of 1000 synthetic 1081-beam scans against ONE 100k-point
+local map, 20 Gauss-Newton iterations per alignment, reference role assignment (fixed = scan,
+moving = map, projective finder -- SURVEY.md section 8d "role A / projective").  One step = one pass of the
+batch through lsm2d_align_batch with the clouds already resident in HBM.  With N GPUs every rank
+aligns its own 1000 scans (weak scaling) against the map broadcast from rank 0 over RCCL; there is
+no data-path collective.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes_per_alignment(n_map: int, n_scan_mean: float, bins: int, iterations: int) -> float:
+    """SURVEY.md section 8(d), role A / projective: per iteration 16*N_m (stream moving) + 48*Bins (canvas
+    key write+read, fixed-cell read, winner gather) + 64 (H, b, chi, counts); once per alignment 16*N_s."""
+    return iterations * (16.0 * n_map + 48.0 * bins + 64.0) + 16.0 * n_scan_mean
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scans", type=int, default=1000, help="alignments per GPU per step")
+    ap.add_argument("--map-points", type=int, default=100000)
+    ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--beams", type=int, default=1081)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="alignments timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from srrg2_laser_slam_2d_amd import api, distributed, synth
+
+    # ---- inputs: the shared local map comes from rank 0 (RCCL broadcast), each rank ray-casts its own scans
+    world_geom = synth.make_world(args.seed)
+    map_dev = distributed.broadcast_map(
+        synth.make_map(world_geom, args.map_points, seed=args.seed) if rank == 0 else None, args.map_points, local_rank)
+    wl = synth.make_workload(args.scans, args.map_points, seed=args.seed, n_beams=args.beams, pose_seed_offset=rank,
+                             world=world_geom, map_points=np.zeros((0, 4), np.float32))
+    ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    moving = api.CloudSet(ctx, map_dev)                       # stays in HBM, no host copy
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
+    proj = api.PointNormal2fProjectorPolar(args.beams, -np.pi, np.pi, 0.3, 30.0)
+    finder = api.CorrespondenceFinderProjective2f(ctx, proj, point_distance=0.5, normal_cos=0.8)
+    aligner = api.MultiAligner2D(ctx, max_iterations=args.iterations, min_num_inliers=10)
+    aligner.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10))
+
+    def step():
+        return aligner.compute_batch([fixed], [moving], wl.x0)
+
+    for _ in range(args.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        res = step()
+        kernel_ms.append(res.kernel_ms)          # HIP events around the k_align launch, on the launch stream
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness gate: a timing only counts if the poses are right (noise-free data -> generating pose)
+    err = np.abs(res.pose - wl.x_true)
+    ok = bool(np.all(res.status == 0) and err[:, :2].max() < 1e-4 and err[:, 2].max() < 1e-4)
+    if world > 1:
+        f = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(f, op=dist.ReduceOp.MIN); ok = bool(f.item())
+
+    if rank == 0:
+        n_total = args.scans * world * args.steps
+        bytes_per_alignment = algorithmic_bytes_per_alignment(args.map_points, float(np.diff(wl.scan_offsets).mean()),
+                                                              args.beams, args.iterations)
+        k_ms = float(np.mean(kernel_ms))
+        achieved = bytes_per_alignment * args.scans / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written from the rocprofv3 --pmc passes, see profiles/README.md
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_align_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "scan-to-map alignments/sec (1081-beam vs 100k-pt map, 20 GN iters)",
+            "value": n_total / elapsed, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d scans/GPU x %d-beam vs one %d-pt map, %d GN iters, role A (fixed=scan, moving=map), projective finder"
+                                   % (args.scans, args.beams, args.map_points, args.iterations),
+                       "alignments_per_gpu": args.scans, "map_points": args.map_points, "beams": args.beams,
+                       "iterations": args.iterations, "parallelism": "alignments sharded, map replicated (RCCL broadcast)"},
+            "parity_ok": ok, "max_pose_err_m": float(err[:, :2].max()), "max_pose_err_rad": float(err[:, 2].max()),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_align", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_alignment * args.scans},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle as po       # the checker, timed as the CPU baseline ("port")
+            ns = min(args.cpu_sample, args.scans)
+            offs = wl.scan_offsets[: ns + 1]
+            map_host = map_dev.cpu().numpy()
+            t1 = time.perf_counter()
+            xo, _, st, _ = po.align_batch(po.aligner_params(args.iterations), po.slice_params(canvas_cols=args.beams),
+                                          wl.scan_points[: offs[-1]], offs, map_host, wl.x0[:ns], n_threads=1)
+            cpu_s = time.perf_counter() - t1
+            d = np.abs(res.pose[:ns] - xo)
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "alignments/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d alignments of the same batch, CPU restatement of the reference algorithm (oracle/, gcc -O3 -march=native, fp32), %.1f s"
+                                             % (ns, cpu_s),
+                                   "max_pose_diff_gpu_vs_cpu_m": float(d[:, :2].max()), "max_pose_diff_gpu_vs_cpu_rad": float(d[:, 2].max())}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

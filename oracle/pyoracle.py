@@ -8,6 +8,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -43,13 +44,33 @@ class IterStats(C.Structure):
                 ("chi_in", C.c_float), ("chi_out", C.c_float)]
 
 
+def _host_stamp() -> str:
+    """-march=native ties the binary to this host's CPU: rebuild when the tree lands on another box."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return hashlib.sha1(line.encode()).hexdigest()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (make -C oracle)."""
     srcs = [os.path.join(_HERE, f) for f in ("lsm2d_oracle.c", "lsm2d_oracle_impl.inc", "lsm2d_oracle.h")]
+    stamp_path = os.path.join(_HERE, "_build", "host.stamp")
+    stamp = _host_stamp()
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if not stale:
+        try:
+            stale = open(stamp_path).read().strip() != stamp
+        except OSError:
+            stale = True
     if stale:
-        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+        subprocess.run(["make", "-B", "-C", _HERE], check=True, capture_output=True)
+        with open(stamp_path, "w") as fh:
+            fh.write(stamp)
     return _LIB_PATH
 
 
