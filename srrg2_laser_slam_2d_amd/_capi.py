@@ -7,6 +7,7 @@ at load time.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
 
 from . import build as _build
@@ -83,6 +84,23 @@ def library_path() -> str:
     return _build.LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm bundles its own libamdhip64.so.7; /opt/rocm has another with the SAME soname.  A
+    process must not end up with the system runtime resolved first and torch initialising on top of it
+    ("No HIP GPUs are available"), so when torch is installed its runtime is loaded before ours."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load(build_if_missing: bool = True):
     """dlopen liblsm2d_hip.so and bind every declared symbol; raises if the library is absent."""
     global _lib
@@ -93,6 +111,7 @@ def load(build_if_missing: bool = True):
         if not build_if_missing:
             raise FileNotFoundError(path)
         _build.build()
+    _preload_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
