@@ -1,0 +1,185 @@
+// lsm2d.hpp -- header-only C++ host mirror of the reference's finder / aligner surface over the C ABI
+// (include/lsm2d.h).  Same method names, argument meaning and error behaviour as the reference classes:
+//   CorrespondenceFinderProjective2f   registration/correspondence_finder_projective_2d.{h,cpp}
+//       setFixed / setMoving / setLocalMapInSensor / setCorrespondences / compute
+//       (apps/visual_test_correspondence_finder_projective_2d.cpp:74-79); throws std::runtime_error on a
+//       missing projector / fixed / moving exactly where the reference does (.cpp:21-31)
+//   MultiAligner2D                     upstream, driven as in apps/visual_test_aligner_2d.cpp:123-156
+//       param_slice_processors / setFixed / setMoving / setMovingInFixed / compute / movingInFixed /
+//       iterationStats / status
+// This header depends on nothing but the C ABI and the standard library, so it compiles with plain g++;
+// the SRRG-side adapter (adapters/srrg/) is the same code expressed with srrg2_core types.
+#pragma once
+#include <lsm2d.h>
+
+#include <array>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace lsm2d_host {
+
+struct PointNormal2f { float x, y, nx, ny; };                 // srrg2_core::PointNormal2f payload
+using PointNormal2fVectorCloud = std::vector<PointNormal2f>;
+using Correspondence = lsm2d_correspondence;                  // {fixed_idx, moving_idx}
+using CorrespondenceVector = std::vector<Correspondence>;
+using Vector3f = std::array<float, 3>;                        // geometry2d::t2v(Isometry2f) = (x, y, theta)
+
+inline void check(int rc, const char* where, const lsm2d_context* ctx = nullptr) {
+  if (rc < 0) throw std::runtime_error(std::string(where) + ": " + lsm2d_status_string(rc) + " " + lsm2d_last_error(ctx));
+}
+
+class Context {
+ public:
+  explicit Context(int device = 0, void* hip_stream = nullptr) { check(lsm2d_create(device, hip_stream, &_h), "lsm2d_create"); }
+  ~Context() { lsm2d_destroy(_h); }
+  Context(const Context&) = delete; Context& operator=(const Context&) = delete;
+  lsm2d_context* get() const { return _h; }
+  float lastKernelMs() const { float ms = 0; check(lsm2d_last_kernel_ms(_h, &ms), "lsm2d_last_kernel_ms", _h); return ms; }
+ private:
+  lsm2d_context* _h = nullptr;
+};
+
+// device-resident copy of one cloud or of a ragged batch of clouds
+class CloudSet {
+ public:
+  CloudSet(Context& ctx, const PointNormal2fVectorCloud& cloud) : _ctx(&ctx) {
+    check(lsm2d_cloudset_create(ctx.get(), cloud.empty() ? nullptr : &cloud[0].x, nullptr, 1, (int64_t) cloud.size(), &_h), "lsm2d_cloudset_create", ctx.get());
+  }
+  CloudSet(Context& ctx, const std::vector<PointNormal2fVectorCloud>& clouds) : _ctx(&ctx) {
+    std::vector<int32_t> offs(1, 0); PointNormal2fVectorCloud packed;
+    for (const auto& c : clouds) { packed.insert(packed.end(), c.begin(), c.end()); offs.push_back((int32_t) packed.size()); }
+    check(lsm2d_cloudset_create(ctx.get(), packed.empty() ? nullptr : &packed[0].x, offs.data(), (int32_t) clouds.size(), (int64_t) packed.size(), &_h),
+          "lsm2d_cloudset_create", ctx.get());
+  }
+  ~CloudSet() { lsm2d_cloudset_destroy(_h); }
+  CloudSet(const CloudSet&) = delete; CloudSet& operator=(const CloudSet&) = delete;
+  lsm2d_cloudset* get() const { return _h; }
+  int32_t numClouds() const { return lsm2d_cloudset_num_clouds(_h); }
+ private:
+  Context* _ctx; lsm2d_cloudset* _h = nullptr;
+};
+
+// PointNormal2fProjectorPolar parameters (apps/synthetic_scene_generator.cpp:69-75, MULTI.json:71-97)
+struct PointNormal2fProjectorPolar {
+  int   param_canvas_cols = 721;
+  float param_angle_col_min = -3.14159f, param_angle_col_max = 3.14159f;
+  float param_range_min = 0.3f, param_range_max = 20.f;
+  float col_offset = 0.f;
+  lsm2d_projector abi() const { return {param_canvas_cols, param_angle_col_min, param_angle_col_max, param_range_min, param_range_max, col_offset}; }
+};
+using PointNormal2fProjectorPolarPtr = std::shared_ptr<PointNormal2fProjectorPolar>;
+
+class CorrespondenceFinderProjective2f {
+ public:
+  explicit CorrespondenceFinderProjective2f(Context& ctx) : _ctx(ctx) {}
+  float param_point_distance = 0.5f;   // .h:16-20
+  float param_normal_cos = 0.8f;       // .h:21
+  PointNormal2fProjectorPolarPtr param_projector{new PointNormal2fProjectorPolar};
+
+  // the clouds are uploaded when set (the reference keeps raw pointers and a _fixed_changed_flag)
+  void setFixed(const PointNormal2fVectorCloud* fixed) { _fixed.reset(fixed ? new CloudSet(_ctx, *fixed) : nullptr); }
+  void setMoving(const PointNormal2fVectorCloud* moving) { _moving.reset(moving ? new CloudSet(_ctx, *moving) : nullptr); }
+  void setLocalMapInSensor(const Vector3f& pose) { _local_map_in_sensor = pose; }
+  void setCorrespondences(CorrespondenceVector* c) { _correspondences = c; }
+
+  lsm2d_slice_params sliceParams() const {
+    lsm2d_slice_params sp{};
+    sp.finder = LSM2D_FINDER_PROJECTIVE; sp.projector = param_projector->abi();
+    sp.point_distance = param_point_distance; sp.normal_cos = param_normal_cos;
+    return sp;
+  }
+
+  void compute() {
+    if (!param_projector) throw std::runtime_error("CorrespondenceFinderProjective2f::compute| Missing Projector");
+    if (!_fixed) throw std::runtime_error("CorrespondenceFinderProjective2f::compute| Missing fixed!");
+    if (!_moving) throw std::runtime_error("CorrespondenceFinderProjective2f::compute| Missing moving!");
+    if (!_correspondences) throw std::runtime_error("CorrespondenceFinderProjective2f::compute| Missing correspondences!");
+    const lsm2d_slice_params sp = sliceParams();
+    _correspondences->resize((size_t) sp.projector.canvas_cols);        // .cpp:49
+    int32_t k = 0;
+    check(lsm2d_find_correspondences(_ctx.get(), &sp, _fixed->get(), 0, _moving->get(), 0, _local_map_in_sensor.data(),
+                                     _correspondences->data(), (int32_t) _correspondences->size(), &k),
+          "lsm2d_find_correspondences", _ctx.get());
+    _correspondences->resize((size_t) k);                                 // .cpp:76
+  }
+ private:
+  Context& _ctx;
+  std::unique_ptr<CloudSet> _fixed, _moving;
+  Vector3f _local_map_in_sensor{{0.f, 0.f, 0.f}};
+  CorrespondenceVector* _correspondences = nullptr;
+};
+
+struct RobustifierCauchy { float param_chi_threshold = 0.01f; };     // MULTI.json:153-158
+
+// AlignerSliceProcessorLaser2D[WithSensor] (registration/aligner_slice_processor_laser_2d.h:7-42; MULTI.json:160-188)
+struct AlignerSliceProcessorLaser2D {
+  std::string param_fixed_slice_name = "points", param_moving_slice_name = "points";
+  int param_min_num_correspondences = 0;
+  std::shared_ptr<CorrespondenceFinderProjective2f> param_finder;
+  std::shared_ptr<RobustifierCauchy> param_robustifier;
+  Vector3f sensor_in_robot{{0.f, 0.f, 0.f}};                           // WithSensor: from the tf Platform
+  lsm2d_slice_params sliceParams() const {
+    if (!param_finder) throw std::runtime_error("AlignerSliceProcessorLaser2D| Missing finder");
+    lsm2d_slice_params sp = param_finder->sliceParams();
+    sp.robustifier = param_robustifier ? LSM2D_ROBUST_CAUCHY : LSM2D_ROBUST_NONE;
+    sp.chi_threshold = param_robustifier ? param_robustifier->param_chi_threshold : 0.f;
+    sp.min_num_correspondences = param_min_num_correspondences;
+    for (int i = 0; i < 3; ++i) sp.sensor_in_robot[i] = sensor_in_robot[i];
+    return sp;
+  }
+};
+using AlignerSliceProcessorLaser2DPtr = std::shared_ptr<AlignerSliceProcessorLaser2D>;
+
+class MultiAligner2D {
+ public:
+  enum Status { Success = 0, NotEnoughCorrespondences = 1, NotEnoughInliers = 2, Fail = 3 };
+  using PropertyContainer = std::map<std::string, const PointNormal2fVectorCloud*>;   // slice name -> cloud
+  explicit MultiAligner2D(Context& ctx) : _ctx(ctx) {}
+  int param_max_iterations = 10, param_min_num_inliers = 10;             // MULTI.json:711,714
+  float param_damping = 0.f;                                             // MULTI.json:254-259
+  std::vector<AlignerSliceProcessorLaser2DPtr> param_slice_processors;
+
+  void setFixed(const PropertyContainer* f) { _fixed = f; }
+  void setMoving(const PropertyContainer* m) { _moving = m; }
+  void setMovingInFixed(const Vector3f& x) { _moving_in_fixed = x; }
+  void setPrior(const Vector3f& z, const std::array<float, 9>& omega) { _has_prior = true; for (int i = 0; i < 3; ++i) _prior.z[i] = z[i]; for (int i = 0; i < 9; ++i) _prior.omega[i] = omega[i]; }
+
+  void compute() {
+    if (!_fixed || !_moving) throw std::runtime_error("MultiAligner2D::compute| fixed or moving not set");
+    const int ns = (int) param_slice_processors.size();
+    if (ns < 1) throw std::runtime_error("MultiAligner2D::compute| no slice processors");
+    std::vector<lsm2d_slice_params> sp; std::vector<std::unique_ptr<CloudSet>> own;
+    std::vector<const lsm2d_cloudset*> fx, mv;
+    for (const auto& s : param_slice_processors) {
+      sp.push_back(s->sliceParams());
+      auto fi = _fixed->find(s->param_fixed_slice_name); auto mi = _moving->find(s->param_moving_slice_name);
+      if (fi == _fixed->end() || mi == _moving->end() || !fi->second || !mi->second) throw std::runtime_error("MultiAligner2D::compute| slice cloud missing");
+      own.emplace_back(new CloudSet(_ctx, *fi->second)); fx.push_back(own.back()->get());
+      own.emplace_back(new CloudSet(_ctx, *mi->second)); mv.push_back(own.back()->get());
+    }
+    lsm2d_batch b{}; b.n_alignments = 1; b.n_slices = ns; b.slices = sp.data(); b.fixed = fx.data(); b.moving = mv.data();
+    b.init_pose = _moving_in_fixed.data(); b.prior = _has_prior ? &_prior : nullptr;
+    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, param_damping};
+    _stats.assign((size_t) (param_max_iterations > 0 ? param_max_iterations : 1), lsm2d_iteration_stats{});
+    int32_t st = 0, its = 0;
+    check(lsm2d_align_batch(_ctx.get(), &ap, &b, _moving_in_fixed.data(), _information.data(), &st, &its, _stats.data()), "lsm2d_align_batch", _ctx.get());
+    _stats.resize((size_t) its); _status = st;
+  }
+  const Vector3f& movingInFixed() const { return _moving_in_fixed; }
+  const std::array<float, 9>& informationMatrix() const { return _information; }
+  const std::vector<lsm2d_iteration_stats>& iterationStats() const { return _stats; }
+  int status() const { return _status; }
+ private:
+  Context& _ctx;
+  const PropertyContainer* _fixed = nullptr; const PropertyContainer* _moving = nullptr;
+  Vector3f _moving_in_fixed{{0.f, 0.f, 0.f}};
+  std::array<float, 9> _information{};
+  std::vector<lsm2d_iteration_stats> _stats;
+  lsm2d_prior _prior{}; bool _has_prior = false; int _status = 0;
+};
+
+}  // namespace lsm2d_host

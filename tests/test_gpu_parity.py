@@ -264,3 +264,29 @@ def test_device_resident_input(ctx, small_workload):
     pr = _projector()
     sa = pr.compute(ctx, a, wl.x0[0]); sb = pr.compute(ctx, b, wl.x0[0])
     assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+
+
+def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
+    """The header-only C++ mirror (srrg2_laser_slam_2d_amd/host/lsm2d.hpp), built with plain g++ and driven like
+    apps/visual_test_correspondence_finder_projective_2d.cpp / apps/visual_test_aligner_2d.cpp."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "host_mirror_driver")
+    lib_dir = os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "host"),
+                    os.path.join(ROOT, "tests", "cpp", "host_mirror_driver.cpp"), "-L" + lib_dir, "-llsm2d_hip", "-Wl,-rpath," + lib_dir, "-o", exe],
+                   check=True)
+    wl = small_workload
+    f = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    f.tofile(tmp_path / "fixed.bin"); wl.map_points.tofile(tmp_path / "moving.bin")
+    x0 = wl.x0[0]
+    out = subprocess.run([exe, str(tmp_path / "fixed.bin"), str(tmp_path / "moving.bin"), repr(float(x0[0])), repr(float(x0[1])), repr(float(x0[2])), "1081", "20"],
+                         check=True, capture_output=True, text=True, timeout=120).stdout
+    r = json.loads(out)
+    want = po.find(po.slice_params(), f, wl.map_points, x0)
+    assert r["threw_on_missing_inputs"] == 1
+    assert np.array_equal(np.array(r["pairs"], np.int32).reshape(-1, 2), want)
+    o = po.align(po.aligner_params(20), [po.slice_params()], [f], [wl.map_points], x0)
+    d = np.abs(np.array(r["pose"]) - o["pose"])
+    assert r["status"] == 0 and r["iterations"] == 20 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
