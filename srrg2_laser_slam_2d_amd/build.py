@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), *HIPCC_FLAGS, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH, *SOURCES]
+    extra = os.environ.get("LSM2D_EXTRA_HIPCC_FLAGS", "").split()      # tuning experiments only
+    cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH, *SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

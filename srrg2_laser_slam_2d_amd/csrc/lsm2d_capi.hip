@@ -246,12 +246,29 @@ extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return 
 extern "C" int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* cs) { return cs ? cs->total : 0; }
 
 // ---- parameter packing -------------------------------------------------------------------------------
+// Depths are compared through r2: sqrtf is correctly rounded and monotone, so
+//   rmin <= sqrtf(r2)  <=>  r2 >= r2lo,  r2lo = smallest float whose sqrtf reaches rmin   (same for rmax).
+// Ranges are clamped to [1e-15, 1e18] m so r2 stays a normal fp32 number (the oracle applies the same clamp).
+static float r2_lower_threshold(float rmin) {
+  float v = rmin * rmin;
+  while (sqrtf(v) >= rmin) v = nextafterf(v, 0.0f);
+  while (sqrtf(v) < rmin) v = nextafterf(v, INFINITY);
+  return v;
+}
+static float r2_upper_threshold(float rmax) {
+  float v = rmax * rmax;
+  while (sqrtf(v) <= rmax) v = nextafterf(v, INFINITY);
+  while (sqrtf(v) > rmax) v = nextafterf(v, 0.0f);
+  return v;
+}
 static bool make_projk(const lsm2d_projector& p, ProjK* k) {
   if (p.canvas_cols <= 0 || !(p.angle_max > p.angle_min) || !(p.range_max >= p.range_min) || !(p.range_min >= 0.0f)) return false;
   k->cols = p.canvas_cols;
   k->K00 = (float) p.canvas_cols / (p.angle_max - p.angle_min);
   k->K01 = (float) p.canvas_cols * 0.5f + p.col_offset;
-  k->rmin = p.range_min; k->rmax = p.range_max; k->colsf = (float) p.canvas_cols;
+  k->rmin = fmaxf(p.range_min, 1e-15f); k->rmax = fminf(p.range_max, 1e18f); k->colsf = (float) p.canvas_cols;
+  if (!(k->rmax >= k->rmin)) return false;
+  k->r2lo = r2_lower_threshold(k->rmin); k->r2hi = r2_upper_threshold(k->rmax);
   return true;
 }
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {

@@ -27,7 +27,8 @@ struct Iso { float c, s, tx, ty; };          // R = [[c,-s],[s,c]], t = (tx,ty)
 // projector constants, precomputed once on the host in fp32
 struct ProjK {
   float K00, K01;       // column = floor(K00*theta + K01)
-  float rmin, rmax;     // range gate
+  float rmin, rmax;     // range gate on the depth r = sqrt_rn(r2) ...
+  float r2lo, r2hi;     // ... restated on r2: rmin <= sqrt_rn(r2) <= rmax  <=>  r2lo <= r2 <= r2hi (host-proved, sqrt_rn is monotone)
   float colsf;          // (float) canvas_cols
   int   cols;
 };
@@ -71,36 +72,117 @@ LSM2D_DEV float wrap_angle(float a) {
   return a;
 }
 
+// Correctly rounded sqrt for NORMAL-range inputs (the range gate keeps r2 in [1e-30, 1e36]): the hardware
+// v_sqrt_f32 estimate (<= 1 ulp) followed by the two-sided fma residual test -- the sequence hipcc emits for
+// sqrtf() minus its denormal pre-scaling.
+LSM2D_DEV float sqrt_rn_normal(float x) {
+  const float s  = __builtin_amdgcn_sqrtf(x);
+  const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+  const float em = __builtin_fmaf(-sm, s, x), ep = __builtin_fmaf(-sp, s, x);
+  float r = em <= 0.0f ? sm : s;
+  r = ep > 0.0f ? sp : r;
+  return r;
+}
+
 // One point of the polar z-buffer.  key = (bits(depth) << 32) | index: depth >= 0 so the IEEE bit
 // pattern orders like the value, and the 64-bit unsigned min keeps the nearest point with ties going
 // to the LOWEST index == "first point wins under strict <" of the sequential reference loop.
+// The depth itself (a correctly rounded sqrt) is only formed for points that can still win their cell:
+// sqrt_rn(r2) <= d implies r2 <= d*d*(1 + 3*2^-23) in fp32, so r2 above that bound loses for certain.
 LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, int idx, u64* canvas) {
   float qx, qy;
   xf_point(T, px, py, qx, qy);
-  const float r = __builtin_sqrtf(__builtin_fmaf(qx, qx, qy * qy));
-  if (r >= P.rmin && r <= P.rmax) {
+  const float r2 = __builtin_fmaf(qx, qx, qy * qy);
+  if (r2 >= P.r2lo && r2 <= P.r2hi) {
     const float th = atan2_poly(qy, qx);
     const float u  = __builtin_fmaf(P.K00, th, P.K01);
-    if (u >= 0.0f && u < P.colsf) {
-      const int col = (int) __builtin_floorf(u);
-      const u64 key = ((u64) __float_as_uint(r) << 32) | (u64) (uint32_t) idx;
-      // the cell only ever decreases, so a plain read that already beats us makes the atomic a no-op
-      if (key < canvas[col]) atomicMin(&canvas[col], key);
+    const int col = (int) __builtin_floorf(u);            // u is finite here; negative / too large -> rejected below
+    if ((unsigned) col < (unsigned) P.cols) {
+      const u64 cur = canvas[col];
+      const float dcur = __uint_as_float((uint32_t) (cur >> 32));      // empty cell: NaN -> never rejected
+      const float bound = (dcur * dcur) * 1.00000036f;
+      if (!(r2 > bound)) {
+        const float r = sqrt_rn_normal(r2);
+        const u64 key = ((u64) __float_as_uint(r) << 32) | (u64) (uint32_t) idx;
+        // the cell only ever decreases, so a plain read that already beats us makes the atomic a no-op
+        if (key < cur) atomicMin(&canvas[col], key);
+      }
     }
   }
 }
 
+// atan2_poly for a direction that is known not to be (0,0) (the range gate guarantees r2 > 0): same operation
+// sequence, without the zero test.
+LSM2D_DEV float atan2_poly_nz(float y, float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+  const float a = mn / mx;
+  const float s = a * a;
+  float p = 2.622197615e-03f;
+  p = __builtin_fmaf(p, s, -1.513234153e-02f);
+  p = __builtin_fmaf(p, s, 4.112152755e-02f);
+  p = __builtin_fmaf(p, s, -7.366676629e-02f);
+  p = __builtin_fmaf(p, s, 1.057391763e-01f);
+  p = __builtin_fmaf(p, s, -1.418597102e-01f);
+  p = __builtin_fmaf(p, s, 1.999039650e-01f);
+  p = __builtin_fmaf(p, s, -3.333298564e-01f);
+  float r = __builtin_fmaf(a * s, p, a);
+  if (ay > ax) r = 1.57079637050628662f - r;
+  if (x < 0.0f) r = 3.14159274101257324f - r;
+  return y < 0.0f ? -r : r;
+}
+
+// Two points at once, straight-line up to the LDS phase so the two dependency chains (divide, polynomial,
+// LDS read) overlap; lanes whose point fails a gate read cell 0 and are masked out afterwards.
+LSM2D_DEV void project_pair(const Iso& T, const ProjK& P, const float4 v, int idx0, u64* canvas) {
+  float qxa, qya, qxb, qyb;
+  xf_point(T, v.x, v.y, qxa, qya);
+  xf_point(T, v.z, v.w, qxb, qyb);
+  const float r2a = __builtin_fmaf(qxa, qxa, qya * qya), r2b = __builtin_fmaf(qxb, qxb, qyb * qyb);
+  bool oka = r2a >= P.r2lo && r2a <= P.r2hi, okb = r2b >= P.r2lo && r2b <= P.r2hi;
+  if (__builtin_amdgcn_ballot_w64(oka || okb) == 0) return;          // whole wave out of range
+  const float ua = __builtin_fmaf(P.K00, atan2_poly_nz(qya, qxa), P.K01);
+  const float ub = __builtin_fmaf(P.K00, atan2_poly_nz(qyb, qxb), P.K01);
+  const int cola = (int) __builtin_floorf(ua), colb = (int) __builtin_floorf(ub);
+  oka = oka && (unsigned) cola < (unsigned) P.cols;
+  okb = okb && (unsigned) colb < (unsigned) P.cols;
+  u64* cella = canvas + (oka ? cola : 0);
+  u64* cellb = canvas + (okb ? colb : 0);
+  const u64 cura = *cella, curb = *cellb;
+  const float da = __uint_as_float((uint32_t) (cura >> 32)), db = __uint_as_float((uint32_t) (curb >> 32));
+  const bool canda = oka && !(r2a > (da * da) * 1.00000036f);
+  const bool candb = okb && !(r2b > (db * db) * 1.00000036f);
+  if (__builtin_amdgcn_ballot_w64(canda || candb) == 0) return;      // nobody in this wave can still win
+  const u64 keya = ((u64) __float_as_uint(sqrt_rn_normal(r2a)) << 32) | (u64) (uint32_t) idx0;
+  const u64 keyb = ((u64) __float_as_uint(sqrt_rn_normal(r2b)) << 32) | (u64) (uint32_t) (idx0 + 1);
+  if (canda && keya < cura) atomicMin(cella, keya);
+  if (candb && keyb < curb) atomicMin(cellb, keyb);
+}
+
 // Stream one cloud through the z-buffer.  xy is 16-byte aligned (cloud starts are padded to an even
-// point index by the host) so every lane loads two points with one 16-byte global_load_dwordx4.
-LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& T, const ProjK& P,
+// point index by the host) so every lane loads two points with one 16-byte global_load_dwordx4; the next
+// load is issued before the current pair is processed.
+LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& Tin, const ProjK& Pin,
                              u64* canvas, int tid, int nthreads) {
+  const Iso T = Tin; const ProjK P = Pin;              // registers, not kernarg re-loads inside the loop
   const float4* __restrict__ xy4 = reinterpret_cast<const float4*>(xy);
-  const int npairs = (n + 1) >> 1;
-  for (int j = tid; j < npairs; j += nthreads) {
-    const float4 v = xy4[j];
-    project_point(T, P, v.x, v.y, 2 * j, canvas);
-    if (2 * j + 1 < n) project_point(T, P, v.z, v.w, 2 * j + 1, canvas);
+  const int nfull = n >> 1;
+  int j = tid;
+  if (j < nfull) {
+    float4 v = xy4[j];
+    for (; j < nfull; j += nthreads) {
+      const int jn = j + nthreads;
+      const float4 nx = xy4[jn < nfull ? jn : j];
+#ifdef LSM2D_PROJECT_PAIR
+      project_pair(T, P, v, 2 * j, canvas);
+#else
+      project_point(T, P, v.x, v.y, 2 * j, canvas);
+      project_point(T, P, v.z, v.w, 2 * j + 1, canvas);
+#endif
+      v = nx;
+    }
   }
+  if ((n & 1) && tid == 0) { const float2 t = xy[n - 1]; project_point(T, P, t.x, t.y, n - 1, canvas); }
 }
 
 // ---- factor ---------------------------------------------------------------------------------
@@ -127,13 +209,19 @@ LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, fl
   const float a2 = __builtin_fmaf(a1, pm.x, -(a0 * pm.y));
   const float d0 = -nqy, d1 = nqx;
   const float chi = __builtin_fmaf(e0, e0, __builtin_fmaf(e1, e1, e2 * e2));
-  float w = 1.0f;
+  // branch-free bookkeeping (adding +0.0f is exact), so the sums stay in registers
+  float w = 1.0f, kern = 0.0f;
+  bool inlier = true;
   if (cauchy) {
     const float q = chi / tau;
     w = 1.0f / (1.0f + q);
-    if (chi < tau) { ++A.n_in; A.chi_in += chi; }
-    else { ++A.n_out; A.chi_out += tau * logf(1.0f + q); }
-  } else { ++A.n_in; A.chi_in += chi; }
+    inlier = chi < tau;
+    kern = tau * logf(1.0f + q);
+  }
+  A.n_in += inlier ? 1 : 0;
+  A.n_out += inlier ? 0 : 1;
+  A.chi_in += inlier ? chi : 0.0f;
+  A.chi_out += inlier ? 0.0f : kern;
   ++A.n_corr;
   const float dd = __builtin_fmaf(d0, d0, d1 * d1);
   const float de = __builtin_fmaf(d0, e1, d1 * e2);

@@ -17,7 +17,10 @@
 namespace lsm2d {
 
 static constexpr int kMaxSlices = 4;
-static constexpr int kAlignBlock = 256;
+#ifndef LSM2D_ALIGN_BLOCK
+#define LSM2D_ALIGN_BLOCK 512
+#endif
+static constexpr int kAlignBlock = LSM2D_ALIGN_BLOCK;
 static constexpr int kFindBlock = 1024;
 
 struct CloudDev {            // device view of a cloud set
@@ -73,7 +76,10 @@ LSM2D_DEV bool match_bin(u64 fk, u64 mk, const SliceDev& S, const Iso& T, const 
   return !(dot < S.normal_cos);
 }
 
-__global__ __launch_bounds__(kAlignBlock) void k_align(const AlignArgs A) {
+#ifndef LSM2D_ALIGN_MIN_WAVES
+#define LSM2D_ALIGN_MIN_WAVES 8      // waves per SIMD the register allocator must leave room for
+#endif
+__global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64* mcan = reinterpret_cast<u64*>(smem);
   u64* fcan = mcan + A.cols_max;
@@ -157,6 +163,7 @@ __global__ __launch_bounds__(kAlignBlock) void k_align(const AlignArgs A) {
       if (!s_active) { s_status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
       else {
         float H[9], b[3];
+#pragma unroll
         for (int k = 0; k < 9; ++k) H[k] = s_H[k];
         b[0] = s_b[0]; b[1] = s_b[1]; b[2] = s_b[2];
         if (A.prior) {
@@ -166,19 +173,34 @@ __global__ __launch_bounds__(kAlignBlock) void k_align(const AlignArgs A) {
           const float c = cosf(E[2]), s_ = sinf(E[2]);
           const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
           float OJ[9], Oe[3];
+#pragma unroll
           for (int r = 0; r < 3; ++r) {
             Oe[r] = 0.0f;
+#pragma unroll
             for (int k = 0; k < 3; ++k) Oe[r] += Pz.omega[3 * r + k] * E[k];
+#pragma unroll
             for (int cc = 0; cc < 3; ++cc) {
               OJ[3 * r + cc] = 0.0f;
+#pragma unroll
               for (int k = 0; k < 3; ++k) OJ[3 * r + cc] += Pz.omega[3 * r + k] * Jp[3 * k + cc];
             }
           }
+#pragma unroll
           for (int r = 0; r < 3; ++r) {
-            for (int cc = 0; cc < 3; ++cc) { float v = 0.0f; for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * OJ[3 * k + cc]; H[3 * r + cc] += v; }
-            float v = 0.0f; for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * Oe[k]; b[r] += v;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+              float v = 0.0f;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * OJ[3 * k + cc];
+              H[3 * r + cc] += v;
+            }
+            float v = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * Oe[k];
+            b[r] += v;
           }
         }
+#pragma unroll
         for (int k = 0; k < 9; ++k) s_H[k] = H[k];     // information matrix = H of the last iteration
         float X[3] = {s_pose[0], s_pose[1], s_pose[2]};
         if (!solve_update(H, b, A.damping, X)) { s_status = LSM2D_SINGULAR_H; s_done = 1; }
