@@ -32,8 +32,15 @@ struct lsm2d_context {
   int max_dyn_lds = 0;
 };
 
+struct GridCache {     // one search grid per (cloud set, max_distance), built on first use
+  float max_distance = 0.0f;
+  GridMeta* d_meta = nullptr; int32_t* d_cell_start = nullptr; int32_t* d_cursor = nullptr;
+  int32_t* d_sorted_idx = nullptr; float2* d_sorted_xy = nullptr;
+};
+
 struct lsm2d_cloudset {
   lsm2d_context* ctx = nullptr;
+  mutable std::vector<GridCache> grids;
   int32_t n_clouds = 0;
   int64_t total = 0;          // logical points
   int64_t padded_total = 0;   // device points incl. even-alignment padding
@@ -101,7 +108,9 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   hipDeviceProp_t prop;
   HIPCHK(ctx, hipGetDeviceProperties(&prop, device_id));
   c->max_dyn_lds = (int) prop.sharedMemPerBlock;
-  (void) hipFuncSetAttribute((const void*) k_align, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipGetLastError();
@@ -240,6 +249,13 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_nrm) (void) hipFree(cs->d_nrm);
   if (cs->d_start) (void) hipFree(cs->d_start);
   if (cs->d_count) (void) hipFree(cs->d_count);
+  for (auto& g : cs->grids) {
+    if (g.d_meta) (void) hipFree(g.d_meta);
+    if (g.d_cell_start) (void) hipFree(g.d_cell_start);
+    if (g.d_cursor) (void) hipFree(g.d_cursor);
+    if (g.d_sorted_idx) (void) hipFree(g.d_sorted_idx);
+    if (g.d_sorted_xy) (void) hipFree(g.d_sorted_xy);
+  }
   delete cs;
 }
 extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
@@ -273,8 +289,47 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
 }
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
+  c.grid = GridDev{nullptr, nullptr, nullptr, nullptr};
   return c;
 }
+// NN finder: uniform grid over every cloud of the (fixed) set, cached per max_distance.  Replaces
+// CorrespondenceFinderKDTree2D::reset() (registration/correspondence_finder_kd_tree_2d.cpp:31-38).
+static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_distance, GridDev* out) {
+  for (const auto& g : cs->grids)
+    if (g.max_distance == max_distance) { *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy}; return LSM2D_SUCCESS; }
+  const int nc = cs->n_clouds;
+  std::vector<int32_t> cell_base(nc), gcap(nc);
+  int64_t cells = 0;
+  for (int c = 0; c < nc; ++c) {
+    int cap = (int) ceil(3.0 * sqrt((double) cs->h_count[c]));
+    cap = cap < 16 ? 16 : (cap > 1024 ? 1024 : cap);
+    gcap[c] = cap; cell_base[c] = (int32_t) cells; cells += (int64_t) cap * cap + 1;
+    if (cells > 0x7fffffff) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "grid: too many cells");
+  }
+  GridCache g; g.max_distance = max_distance;
+  int32_t* d_base = nullptr; int32_t* d_gcap = nullptr;
+  HIPCHK(ctx, hipMalloc((void**) &g.d_meta, sizeof(GridMeta) * (size_t) nc));
+  HIPCHK(ctx, hipMalloc((void**) &g.d_cell_start, sizeof(int32_t) * (size_t) cells));
+  HIPCHK(ctx, hipMalloc((void**) &g.d_cursor, sizeof(int32_t) * (size_t) cells));
+  HIPCHK(ctx, hipMalloc((void**) &g.d_sorted_idx, sizeof(int32_t) * (size_t) cs->padded_total));
+  HIPCHK(ctx, hipMalloc((void**) &g.d_sorted_xy, sizeof(float2) * (size_t) cs->padded_total));
+  HIPCHK(ctx, hipMalloc((void**) &d_base, sizeof(int32_t) * (size_t) nc));
+  HIPCHK(ctx, hipMalloc((void**) &d_gcap, sizeof(int32_t) * (size_t) nc));
+  HIPCHK(ctx, hipMemcpyAsync(d_base, cell_base.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_gcap, gcap.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  GridBuildArgs A;
+  A.xy = cs->d_xy; A.start = cs->d_start; A.count = cs->d_count; A.n_clouds = nc; A.h_min = max_distance * 1.001f;
+  A.cell_base = d_base; A.gcap = d_gcap; A.meta = g.d_meta; A.cell_start = g.d_cell_start; A.cursor = g.d_cursor;
+  A.sorted_idx = g.d_sorted_idx; A.sorted_xy = g.d_sorted_xy;
+  hipLaunchKernelGGL(k_grid_build, dim3((unsigned) nc), dim3(1024), 0, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // host vectors above must outlive the copies
+  (void) hipFree(d_base); (void) hipFree(d_gcap);
+  cs->grids.push_back(g);
+  *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy};
+  return LSM2D_SUCCESS;
+}
+
 static Iso make_iso(const float pose[3]) { Iso T; T.c = cosf(pose[2]); T.s = sinf(pose[2]); T.tx = pose[0]; T.ty = pose[1]; return T; }
 static float wrap_host(float a) {
   while (a > 3.14159274101257324f) a -= 6.28318548202514648f;
@@ -323,6 +378,30 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
       (capacity > 0 && !out_pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad argument");
   *out_n = 0;
+  if (sp->finder == LSM2D_FINDER_NN) {
+    if (!(sp->max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: max_distance must be > 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    FindNNArgs N;
+    N.fixed = cloud_dev(fixed, nullptr); N.moving = cloud_dev(moving, nullptr); N.fc = fi; N.mc = mi;
+    int rc = ensure_grid(ctx, fixed, sp->max_distance, &N.fixed.grid); if (rc) return rc;
+    const size_t nm = (size_t) moving->h_count[mi], bytes = nm * 8 + 16;
+    rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+    rc = ensure_stage(ctx, bytes); if (rc) return rc;
+    N.max_distance = sp->max_distance; N.normal_cos = sp->normal_cos; N.T = make_iso(pose);
+    N.out_count = (int32_t*) ctx->d_scratch; N.out_pairs = (int32_t*) ((char*) ctx->d_scratch + 16);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_find_nn, dim3(1), dim3(kFindBlock), 0, ctx->stream, N);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->have_timing = true;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t n = *(const int32_t*) ctx->h_stage;
+    *out_n = n;
+    if (n > capacity) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "find_correspondences: out_pairs too small");
+    memcpy(out_pairs, (char*) ctx->h_stage + 16, sizeof(lsm2d_correspondence) * (size_t) n);
+    return LSM2D_SUCCESS;
+  }
   if (sp->finder != LSM2D_FINDER_PROJECTIVE) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: finder not supported yet");
   FindArgs A;
   if (!make_projk(sp->projector, &A.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad projector");
@@ -430,8 +509,13 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     SliceDev& S = A.s[s];
     const lsm2d_cloudset* f = b->fixed[s]; const lsm2d_cloudset* m = b->moving[s];
     if (!f || !m || f->ctx != ctx || m->ctx != ctx) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: cloud set missing or from another context");
-    if (sp.finder != LSM2D_FINDER_PROJECTIVE) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: finder not supported yet");
-    if (!make_projk(sp.projector, &S.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad projector");
+    if (sp.finder != LSM2D_FINDER_PROJECTIVE && sp.finder != LSM2D_FINDER_NN) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: finder not supported yet");
+    if (sp.finder == LSM2D_FINDER_PROJECTIVE) {
+      if (!make_projk(sp.projector, &S.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad projector");
+    } else {
+      if (!(sp.max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: max_distance must be > 0");
+      memset(&S.proj, 0, sizeof S.proj);
+    }
     if (!b->fixed_index && f->n_clouds != 1 && f->n_clouds != n) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: fixed set must hold 1 or n_alignments clouds");
     if (!b->moving_index && m->n_clouds != 1 && m->n_clouds != n) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: moving set must hold 1 or n_alignments clouds");
     const int32_t* d_fi = nullptr; const int32_t* d_mi = nullptr;
@@ -446,6 +530,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
       memcpy(hs + o_midx[s], src, sizeof(int32_t) * (size_t) n); d_mi = (const int32_t*) (ds + o_midx[s]);
     }
     S.fixed = cloud_dev(f, d_fi); S.moving = cloud_dev(m, d_mi);
+    if (sp.finder == LSM2D_FINDER_NN) { const int grc = ensure_grid(ctx, f, sp.max_distance, &S.fixed.grid); if (grc) return grc; }
     S.finder = sp.finder; S.point_distance = sp.point_distance; S.normal_cos = sp.normal_cos; S.max_distance = sp.max_distance;
     S.cauchy = sp.robustifier == LSM2D_ROBUST_CAUCHY; S.tau = sp.chi_threshold; S.min_corr = sp.min_num_correspondences;
     if (S.cauchy && !(S.tau > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: chi_threshold must be > 0");
@@ -474,7 +559,11 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
 
   HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_align, dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
+  bool has_proj = false, has_nn = false;
+  for (int s = 0; s < ns; ++s) { if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE) has_proj = true; else has_nn = true; }
+  if (has_proj && has_nn) hipLaunchKernelGGL((k_align<true, true>), dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
+  else if (has_nn) hipLaunchKernelGGL((k_align<false, true>), dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
+  else hipLaunchKernelGGL((k_align<true, false>), dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;

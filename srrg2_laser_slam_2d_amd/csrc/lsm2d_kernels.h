@@ -23,6 +23,17 @@ static constexpr int kMaxSlices = 4;
 static constexpr int kAlignBlock = LSM2D_ALIGN_BLOCK;
 static constexpr int kFindBlock = 1024;
 
+// Uniform search grid over every cloud of a set (NN finder): cells of side h >= max_distance, points
+// counting-sorted by cell.  Replaces the KDTree the reference rebuilds in reset()
+// (registration/correspondence_finder_kd_tree_2d.cpp:31-38).
+struct GridMeta { float minx, miny, inv_h, h; int32_t gw, gh, cell_base, pad; };
+struct GridDev {
+  const GridMeta* meta;        // [n_clouds]
+  const int32_t*  cell_start;  // per cloud: gw*gh+1 entries from meta.cell_base (positions relative to the cloud)
+  const int32_t*  sorted_idx;  // [padded total] original point index, cloud-relative, grouped by cell
+  const float2*   sorted_xy;   // [padded total] coordinates in the same order
+};
+
 struct CloudDev {            // device view of a cloud set
   const float2* xy;          // [padded total] coordinates
   const float2* nrm;         // [padded total] normals
@@ -30,7 +41,110 @@ struct CloudDev {            // device view of a cloud set
   const int32_t* count;      // [n_clouds] points per cloud
   const int32_t* index;      // [n_alignments] cloud chosen per alignment, or nullptr
   int32_t n_clouds;
+  GridDev grid;              // valid only when the slice uses the NN finder on this (fixed) cloud
 };
+
+// exact nearest neighbour of q among the cloud's points within sqrt(md2); ties -> lowest index
+// (SURVEY.md App. D.2).  Visits the 3x3 cells around q; h >= 1.001*max_distance makes that exhaustive.
+LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start, const int32_t* __restrict__ sidx,
+                       const float2* __restrict__ sxy, float qx, float qy, float md2) {
+  const float fx = __builtin_floorf((qx - g.minx) * g.inv_h), fy = __builtin_floorf((qy - g.miny) * g.inv_h);
+  if (!(fx >= -1.0f && fx <= (float) g.gw && fy >= -1.0f && fy <= (float) g.gh)) return -1;
+  const int cx = (int) fx, cy = (int) fy;
+  const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 > g.gw - 1 ? g.gw - 1 : cx + 1;
+  const int y0 = cy - 1 < 0 ? 0 : cy - 1, y1 = cy + 1 > g.gh - 1 ? g.gh - 1 : cy + 1;
+  int best = -1; float bd = 3.402823466e+38f;
+  if (x0 > x1) return -1;
+  for (int yy = y0; yy <= y1; ++yy) {
+    const int s = cell_start[yy * g.gw + x0], e = cell_start[yy * g.gw + x1 + 1];
+    for (int t = s; t < e; ++t) {
+      const float2 p = sxy[t];
+      const float dx = p.x - qx, dy = p.y - qy;
+      const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+      if (d2 <= md2) {
+        const int i = sidx[t];
+        if (d2 < bd || (d2 == bd && i < best)) { bd = d2; best = i; }
+      }
+    }
+  }
+  return best;
+}
+
+// One workgroup builds the grid of one cloud: bounding box -> cell size -> counting sort by cell.
+struct GridBuildArgs {
+  const float2* xy; const int32_t* start; const int32_t* count; int32_t n_clouds;
+  float h_min;                  // 1.001 * max_distance
+  const int32_t* cell_base;     // [n_clouds] host-computed: room for gcap^2 + 1 entries per cloud
+  const int32_t* gcap;          // [n_clouds] max grid dimension per cloud
+  GridMeta* meta; int32_t* cell_start; int32_t* cursor; int32_t* sorted_idx; float2* sorted_xy;
+};
+
+__global__ __launch_bounds__(1024) void k_grid_build(const GridBuildArgs A) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int n = A.count[c], base = A.start[c];
+  const float2* xy = A.xy + base;
+  __shared__ float s_min[2][16], s_max[2][16];
+  __shared__ GridMeta s_g;
+  __shared__ int s_carry, s_wtot[16];
+  // ---- bounding box
+  float mnx = 3.402823466e+38f, mny = mnx, mxx = -mnx, mxy = -mnx;
+  for (int i = tid; i < n; i += 1024) { const float2 p = xy[i]; mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x); mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y); }
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+    mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+  }
+  if ((tid & 63) == 0) { s_min[0][tid >> 6] = mnx; s_min[1][tid >> 6] = mny; s_max[0][tid >> 6] = mxx; s_max[1][tid >> 6] = mxy; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) { mnx = fminf(mnx, s_min[0][w]); mny = fminf(mny, s_min[1][w]); mxx = fmaxf(mxx, s_max[0][w]); mxy = fmaxf(mxy, s_max[1][w]); }
+    if (n == 0) { mnx = mny = 0.0f; mxx = mxy = 0.0f; }
+    const float cap = (float) A.gcap[c];
+    float h = fmaxf(A.h_min, fmaxf(mxx - mnx, mxy - mny) / cap * 1.001f);
+    if (!(h > 0.0f)) h = 1.0f;
+    GridMeta g; g.minx = mnx; g.miny = mny; g.h = h; g.inv_h = 1.0f / h;
+    int gw = (int) floorf((mxx - mnx) * g.inv_h) + 1, gh = (int) floorf((mxy - mny) * g.inv_h) + 1;
+    g.gw = gw < 1 ? 1 : (gw > A.gcap[c] ? A.gcap[c] : gw); g.gh = gh < 1 ? 1 : (gh > A.gcap[c] ? A.gcap[c] : gh);
+    g.cell_base = A.cell_base[c]; g.pad = 0;
+    s_g = g; A.meta[c] = g; s_carry = 0;
+  }
+  __syncthreads();
+  const GridMeta g = s_g;
+  const int ncell = g.gw * g.gh;
+  int32_t* cstart = A.cell_start + g.cell_base; int32_t* cur = A.cursor + g.cell_base;
+  for (int i = tid; i <= ncell; i += 1024) cur[i] = 0;
+  __syncthreads();
+  // ---- histogram
+  auto cell_of = [&](float2 p) {
+    int cx = (int) floorf((p.x - g.minx) * g.inv_h), cy = (int) floorf((p.y - g.miny) * g.inv_h);
+    cx = cx < 0 ? 0 : (cx > g.gw - 1 ? g.gw - 1 : cx); cy = cy < 0 ? 0 : (cy > g.gh - 1 ? g.gh - 1 : cy);
+    return cy * g.gw + cx;
+  };
+  for (int i = tid; i < n; i += 1024) atomicAdd(&cur[cell_of(xy[i])], 1);
+  __syncthreads();
+  // ---- exclusive scan of the counts, 1024 cells per round, carried in LDS
+  for (int c0 = 0; c0 <= ncell; c0 += 1024) {
+    const int i = c0 + tid;
+    const int v = i < ncell ? cur[i] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+    if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+    __syncthreads();
+    int before = s_carry;
+    for (int w = 0; w < (tid >> 6); ++w) before += s_wtot[w];
+    if (i <= ncell) cstart[i] = before + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = before + incl;
+    __syncthreads();
+  }
+  for (int i = tid; i < ncell; i += 1024) cur[i] = cstart[i];
+  __syncthreads();
+  // ---- scatter (order inside a cell is arbitrary; the query breaks ties by index)
+  for (int i = tid; i < n; i += 1024) {
+    const float2 p = xy[i];
+    const int pos = atomicAdd(&cur[cell_of(p)], 1);
+    A.sorted_idx[base + pos] = i; A.sorted_xy[base + pos] = p;
+  }
+}
 
 struct SliceDev {
   CloudDev fixed, moving;
@@ -79,6 +193,9 @@ LSM2D_DEV bool match_bin(u64 fk, u64 mk, const SliceDev& S, const Iso& T, const 
 #ifndef LSM2D_ALIGN_MIN_WAVES
 #define LSM2D_ALIGN_MIN_WAVES 8      // waves per SIMD the register allocator must leave room for
 #endif
+// kHasProj / kHasNN: which finders the batch's slices use -- the unused one is compiled out so the
+// projective hot loop does not carry the NN path's register pressure (and vice versa).
+template <bool kHasProj, bool kHasNN>
 __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64* mcan = reinterpret_cast<u64*>(smem);
@@ -104,6 +221,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   for (int s = 0; s < A.n_slices; ++s) {
     const SliceDev& S = A.s[s];
+    if (!kHasProj || S.finder != LSM2D_FINDER_PROJECTIVE) continue;
     const int fc = pick_cloud(S.fixed, a);
     project_cloud(S.fixed.xy + S.fixed.start[fc], S.fixed.count[fc], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
   }
@@ -123,24 +241,53 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
       s_b[0] = s_b[1] = s_b[2] = 0.0f;
       s_n_in = s_n_out = s_n_corr = s_active = 0; s_chi_in = s_chi_out = 0.0f;
     }
+    __syncthreads();       // s_iso[] is read by every lane below
     for (int s = 0; s < A.n_slices; ++s) {
       const SliceDev& S = A.s[s];
-      for (int i = tid; i < S.proj.cols; i += kAlignBlock) mcan[i] = kEmptyCell;
-      __syncthreads();
       const Iso T = s_iso[s];
-      const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
-      const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
-      // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
-      project_cloud(S.moving.xy + mbase, S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
-      __syncthreads();
       Accum acc; accum_zero(acc);
-      const u64* fcs = fcan + S.fcan_offset;
-      const float2* fn = S.fixed.nrm + fbase; const float2* mn = S.moving.nrm + mbase;
-      const float2* fp = S.fixed.xy + fbase;  const float2* mp = S.moving.xy + mbase;
-      for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
-        int fi, mi; float2 nf, nm;
-        if (match_bin(fcs[col], mcan[col], S, T, fn, mn, fi, mi, nf, nm))
-          accumulate_pair(T, fp[fi], nf, mp[mi], nm, S.cauchy != 0, S.tau, acc);
+      if (kHasProj && (!kHasNN || S.finder == LSM2D_FINDER_PROJECTIVE)) {
+        for (int i = tid; i < S.proj.cols; i += kAlignBlock) mcan[i] = kEmptyCell;
+        __syncthreads();
+        {
+          // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
+          const int mc = pick_cloud(S.moving, a);
+          project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
+        }
+        __syncthreads();
+        const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
+        const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
+        const float2* fn = S.fixed.nrm + fbase; const float2* mn = S.moving.nrm + mbase;
+        const float2* fp = S.fixed.xy + fbase;  const float2* mp = S.moving.xy + mbase;
+        const u64* fcs = fcan + S.fcan_offset;
+        for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
+          int fi, mi; float2 nf, nm;
+          if (match_bin(fcs[col], mcan[col], S, T, fn, mn, fi, mi, nf, nm))
+            accumulate_pair(T, fp[fi], nf, mp[mi], nm, S.cauchy != 0, S.tau, acc);
+        }
+      } else if (kHasNN) {
+        // NN finder fused with the factor (correspondence_finder_kd_tree_2d.cpp:12-27): every moving point is
+        // transformed, matched to its exact nearest fixed point within max_distance, normal-gated, accumulated
+        const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
+        const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
+        const float2* fn = S.fixed.nrm + fbase; const float2* mn = S.moving.nrm + mbase;
+        const float2* fp = S.fixed.xy + fbase;  const float2* mp = S.moving.xy + mbase;
+        const GridMeta g = S.fixed.grid.meta[fc];
+        const int32_t* cst = S.fixed.grid.cell_start + g.cell_base;
+        const int32_t* sidx = S.fixed.grid.sorted_idx + fbase; const float2* sxy = S.fixed.grid.sorted_xy + fbase;
+        const float md2 = S.max_distance * S.max_distance;
+        const int nm_pts = S.moving.count[mc];
+        for (int j = tid; j < nm_pts; j += kAlignBlock) {
+          const float2 pm = mp[j];
+          float qx, qy; xf_point(T, pm.x, pm.y, qx, qy);
+          const int best = nn_query(g, cst, sidx, sxy, qx, qy, md2);
+          if (best >= 0) {
+            const float2 nm = mn[j], nf = fn[best];
+            float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+            const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
+            if (!(dot < S.normal_cos)) accumulate_pair(T, fp[best], nf, pm, nm, S.cauchy != 0, S.tau, acc);
+          }
+        }
       }
       block_reduce_store(acc, red, tid);
       __syncthreads();
@@ -258,6 +405,51 @@ __global__ __launch_bounds__(kFindBlock) void k_find_projective(const FindArgs A
     int before = s_base, total = 0;
     for (int w = 0; w < kFindBlock / 64; ++w) { const int t = s_wave_tot[w]; if (w < wave) before += t; total += t; }
     if (ok) { A.out_pairs[2 * (before + prefix)] = fi; A.out_pairs[2 * (before + prefix) + 1] = mi; }
+    __syncthreads();
+    if (tid == 0) s_base += total;
+    __syncthreads();
+  }
+  if (tid == 0) *A.out_count = s_base;
+}
+
+// ---- finder-level NN: pairs in ascending moving index (correspondence_finder_kd_tree_2d.cpp:12-27) ------
+struct FindNNArgs {
+  CloudDev fixed, moving; int32_t fc, mc;
+  float max_distance, normal_cos; Iso T;
+  int32_t* out_pairs; int32_t* out_count;
+};
+
+__global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const int fbase = A.fixed.start[A.fc], mbase = A.moving.start[A.mc], n = A.moving.count[A.mc];
+  const GridMeta g = A.fixed.grid.meta[A.fc];
+  const int32_t* cst = A.fixed.grid.cell_start + g.cell_base;
+  const int32_t* sidx = A.fixed.grid.sorted_idx + fbase; const float2* sxy = A.fixed.grid.sorted_xy + fbase;
+  const float md2 = A.max_distance * A.max_distance;
+  for (int j0 = 0; j0 < n; j0 += kFindBlock) {
+    const int j = j0 + tid;
+    int best = -1; bool ok = false;
+    if (j < n) {
+      const float2 pm = A.moving.xy[mbase + j];
+      float qx, qy; xf_point(A.T, pm.x, pm.y, qx, qy);
+      best = nn_query(g, cst, sidx, sxy, qx, qy, md2);
+      if (best >= 0) {
+        const float2 nm = A.moving.nrm[mbase + j], nf = A.fixed.nrm[fbase + best];
+        float nqx, nqy; xf_normal(A.T, nm.x, nm.y, nqx, nqy);
+        ok = !(__builtin_fmaf(nqx, nf.x, nqy * nf.y) < A.normal_cos);
+      }
+    }
+    const u64 bal = __ballot(ok);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int before = s_base, total = 0;
+    for (int w = 0; w < kFindBlock / 64; ++w) { const int t = s_wave_tot[w]; if (w < wave) before += t; total += t; }
+    if (ok) { A.out_pairs[2 * (before + prefix)] = best; A.out_pairs[2 * (before + prefix) + 1] = j; }
     __syncthreads();
     if (tid == 0) s_base += total;
     __syncthreads();

@@ -290,3 +290,103 @@ def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     o = po.align(po.aligner_params(20), [po.slice_params()], [f], [wl.map_points], x0)
     d = np.abs(np.array(r["pose"]) - o["pose"])
     assert r["status"] == 0 and r["iterations"] == 20 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+
+
+# ---- NN finder (CorrespondenceFinderKDTree2D, row a4) -------------------------------------------------------
+@pytest.mark.parametrize("max_distance", [0.5, 0.05, 0.01])
+def test_nn_finder_bit_exact_both_roles(ctx, po, small_workload, max_distance):
+    wl = small_workload
+    scan = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    x = wl.x0[1] if max_distance >= 0.5 else wl.x_true[1].astype(np.float32)     # small gates need a near-true pose to match anything
+    xb = synth.invert_poses(x[None, :].astype(np.float64))[0].astype(np.float32)
+    osp = po.slice_params(finder=po.FINDER_NN, max_distance=max_distance, normal_cos=0.8)
+    for fixed, moving, pose in ((scan, wl.map_points, x), (wl.map_points, scan, xb)):     # role A (tracker wiring), role B (BASELINE wording)
+        f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=max_distance, normal_cos=0.8)
+        f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
+        got = f.compute()
+        want = po.find(osp, fixed, moving, pose)
+        assert len(want) > 50
+        assert np.array_equal(got, want)          # same pairs, ascending moving index
+
+
+def test_nn_finder_edge_cases(ctx, po):
+    rng = np.random.default_rng(5)
+    def cloud(n, lo=-5, hi=5):
+        p = rng.uniform(lo, hi, size=(n, 2)); a = rng.uniform(-np.pi, np.pi, n)
+        return np.concatenate([p, np.cos(a)[:, None], np.sin(a)[:, None]], 1).astype(np.float32)
+    fixed, moving = cloud(5000), cloud(3000, -7, 7)          # queries outside the fixed bounding box too
+    fixed[10] = fixed[11]; moving[0, :2] = fixed[11, :2]     # duplicate fixed point: tie -> lowest index
+    for md in (0.05, 0.3, 2.0):
+        f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=md, normal_cos=-1.0)
+        f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor([0.1, -0.2, 0.3])
+        got = f.compute()
+        want = po.find(po.slice_params(finder=po.FINDER_NN, max_distance=md, normal_cos=-1.0), fixed, moving, np.float32([0.1, -0.2, 0.3]), brute=True)
+        assert np.array_equal(got, want)
+    f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=-1.0)
+    f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor([0, 0, 0])
+    c = f.compute()
+    assert c[0, 1] == 0 and c[0, 0] == 10
+    # single fixed point, empty moving, all-identical fixed points
+    one = fixed[:1]
+    f.setFixed(one); f.setMoving(np.tile(one, (5, 1)))
+    assert np.array_equal(f.compute(), np.stack([np.zeros(5, np.int32), np.arange(5, dtype=np.int32)], 1))
+    f.setMoving(np.zeros((0, 4), np.float32))
+    assert len(f.compute()) == 0
+    f.setFixed(np.tile(one, (100, 1))); f.setMoving(one)
+    assert np.array_equal(f.compute(), [[0, 0]])
+
+
+def _nn_aligner(ctx, md=0.5, its=20):
+    al = api.MultiAligner2D(ctx, max_iterations=its, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=md), min_num_correspondences=10))
+    return al
+
+
+def test_aligner_nn_role_b_scan_queries_map(ctx, po):
+    """BASELINE wording: search structure over the local map, scans as queries (fixed = map, moving = scan)."""
+    wl = synth.make_workload(24, 100000, seed=6)
+    x0_b = synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32); xt_b = synth.invert_poses(wl.x_true)
+    al = _nn_aligner(ctx)
+    fixed = api.CloudSet(ctx, wl.map_points); moving = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
+    res = al.compute_batch([fixed], [moving], x0_b, want_stats=True)
+    osp = po.slice_params(finder=po.FINDER_NN, max_distance=0.5)
+    for i in range(0, 24, 4):
+        s = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+        r = po.align(po.aligner_params(20), [osp], [wl.map_points], [s], x0_b[i])
+        d = np.abs(res.pose[i] - r["pose"])
+        assert res.status[i] == r["status"] == 0 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+        assert res.stats[i]["n_correspondences"][0] == r["stats"][0].n_corr
+    # the map points are ~2 mm apart, so point-to-plane NN ICP lands within a few mm of the generating pose
+    dt = np.abs(res.pose - xt_b)
+    assert dt[:, :2].max() < 5e-3 and dt[:, 2].max() < 2e-3
+
+
+def test_aligner_nn_role_a_map_queries_scan(ctx, po):
+    """reference tracker wiring: tree over the scan, every map point is a query (up to N_m correspondences)."""
+    wl = synth.make_workload(8, 30000, seed=7)
+    al = _nn_aligner(ctx, md=0.3)
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    res = al.compute_batch([fixed], [moving], wl.x0, want_stats=True)
+    osp = po.slice_params(finder=po.FINDER_NN, max_distance=0.3)
+    for i in range(0, 8, 3):
+        s = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+        r = po.align(po.aligner_params(20), [osp], [s], [wl.map_points], wl.x0[i])
+        d = np.abs(res.pose[i] - r["pose"])
+        assert res.status[i] == r["status"] and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+        assert res.stats[i]["n_correspondences"][0] == r["stats"][0].n_corr
+
+
+def test_mixed_finders_two_slices(ctx, po, small_workload):
+    """one projective slice + one NN slice sharing the pose (exercises the k_align<true,true> instantiation)."""
+    wl = small_workload
+    s = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector()), min_num_correspondences=10))
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3), min_num_correspondences=10))
+    al.setFixed({"points": s}); al.setMoving({"points": wl.map_points}); al.setMovingInFixed(wl.x0[0])
+    assert al.compute() == 0
+    osl = [po.slice_params(), po.slice_params(finder=po.FINDER_NN, max_distance=0.3)]
+    r = po.align(po.aligner_params(10), osl, [s, s], [wl.map_points, wl.map_points], wl.x0[0])
+    d = np.abs(al.movingInFixed() - r["pose"])
+    assert r["status"] == 0 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+    assert al.iterationStats()["n_correspondences"][0] == r["stats"][0].n_corr
