@@ -318,7 +318,7 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   HIPCHK(ctx, hipMemcpyAsync(d_base, cell_base.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_gcap, gcap.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   GridBuildArgs A;
-  A.xy = cs->d_xy; A.start = cs->d_start; A.count = cs->d_count; A.n_clouds = nc; A.h_min = max_distance * 1.001f;
+  A.xy = cs->d_xy; A.start = cs->d_start; A.count = cs->d_count; A.n_clouds = nc; A.h_min = max_distance * 0.125f;
   A.cell_base = d_base; A.gcap = d_gcap; A.meta = g.d_meta; A.cell_start = g.d_cell_start; A.cursor = g.d_cursor;
   A.sorted_idx = g.d_sorted_idx; A.sorted_xy = g.d_sorted_xy;
   hipLaunchKernelGGL(k_grid_build, dim3((unsigned) nc), dim3(1024), 0, ctx->stream, A);

@@ -45,27 +45,39 @@ struct CloudDev {            // device view of a cloud set
 };
 
 // exact nearest neighbour of q among the cloud's points within sqrt(md2); ties -> lowest index
-// (SURVEY.md App. D.2).  Visits the 3x3 cells around q; h >= 1.001*max_distance makes that exhaustive.
+// (SURVEY.md App. D.2).  Cells are SMALLER than max_distance (h ~ max_distance/8): the search visits the
+// (2k+1)^2 block around q for k = 1, 2, 4, ... and stops as soon as the best distance is strictly inside the
+// block (every point outside it is farther than k*h, so it can neither win nor tie) or the block covers
+// max_distance.  Converged ICP queries finish in the first 3x3 block.
 LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start, const int32_t* __restrict__ sidx,
-                       const float2* __restrict__ sxy, float qx, float qy, float md2) {
+                       const float2* __restrict__ sxy, float qx, float qy, float md, float md2) {
   const float fx = __builtin_floorf((qx - g.minx) * g.inv_h), fy = __builtin_floorf((qy - g.miny) * g.inv_h);
-  if (!(fx >= -1.0f && fx <= (float) g.gw && fy >= -1.0f && fy <= (float) g.gh)) return -1;
-  const int cx = (int) fx, cy = (int) fy;
-  const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 > g.gw - 1 ? g.gw - 1 : cx + 1;
-  const int y0 = cy - 1 < 0 ? 0 : cy - 1, y1 = cy + 1 > g.gh - 1 ? g.gh - 1 : cy + 1;
+  const float reach = __builtin_ceilf(md * g.inv_h * 1.002f);                 // cells max_distance can span (0.2 % fp slack)
+  if (!(fx >= -reach && fx <= (float) g.gw + reach && fy >= -reach && fy <= (float) g.gh + reach)) return -1;
+  const int cx = (int) fx, cy = (int) fy, kmax = (int) reach;
   int best = -1; float bd = 3.402823466e+38f;
-  if (x0 > x1) return -1;
-  for (int yy = y0; yy <= y1; ++yy) {
-    const int s = cell_start[yy * g.gw + x0], e = cell_start[yy * g.gw + x1 + 1];
-    for (int t = s; t < e; ++t) {
-      const float2 p = sxy[t];
-      const float dx = p.x - qx, dy = p.y - qy;
-      const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-      if (d2 <= md2) {
-        const int i = sidx[t];
-        if (d2 < bd || (d2 == bd && i < best)) { bd = d2; best = i; }
+  for (int k = 1;; k *= 2) {
+    if (k > kmax) k = kmax;
+    const int x0 = cx - k < 0 ? 0 : cx - k, x1 = cx + k > g.gw - 1 ? g.gw - 1 : cx + k;
+    const int y0 = cy - k < 0 ? 0 : cy - k, y1 = cy + k > g.gh - 1 ? g.gh - 1 : cy + k;
+    if (x0 <= x1) {
+      for (int yy = y0; yy <= y1; ++yy) {
+        const int s = cell_start[yy * g.gw + x0], e = cell_start[yy * g.gw + x1 + 1];
+        for (int t = s; t < e; ++t) {
+          const float2 p = sxy[t];
+          const float dx = p.x - qx, dy = p.y - qy;
+          const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+          if (d2 <= md2) {
+            const int i = sidx[t];
+            if (d2 < bd || (d2 == bd && i < best)) { bd = d2; best = i; }
+          }
+        }
       }
     }
+    if (k >= kmax) break;
+    // q sits in cell (cx,cy): anything outside the block is at least k*h away (0.998: fp slack of the cell assignment)
+    const float inside = (float) k * g.h * 0.998f;
+    if (best >= 0 && bd < inside * inside) break;
   }
   return best;
 }
@@ -73,7 +85,7 @@ LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start
 // One workgroup builds the grid of one cloud: bounding box -> cell size -> counting sort by cell.
 struct GridBuildArgs {
   const float2* xy; const int32_t* start; const int32_t* count; int32_t n_clouds;
-  float h_min;                  // 1.001 * max_distance
+  float h_min;                  // max_distance / 8 (cells smaller than the gate; the query widens its block as needed)
   const int32_t* cell_base;     // [n_clouds] host-computed: room for gcap^2 + 1 entries per cloud
   const int32_t* gcap;          // [n_clouds] max grid dimension per cloud
   GridMeta* meta; int32_t* cell_start; int32_t* cursor; int32_t* sorted_idx; float2* sorted_xy;
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
         for (int j = tid; j < nm_pts; j += kAlignBlock) {
           const float2 pm = mp[j];
           float qx, qy; xf_point(T, pm.x, pm.y, qx, qy);
-          const int best = nn_query(g, cst, sidx, sxy, qx, qy, md2);
+          const int best = nn_query(g, cst, sidx, sxy, qx, qy, S.max_distance, md2);
           if (best >= 0) {
             const float2 nm = mn[j], nf = fn[best];
             float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
     if (j < n) {
       const float2 pm = A.moving.xy[mbase + j];
       float qx, qy; xf_point(A.T, pm.x, pm.y, qx, qy);
-      best = nn_query(g, cst, sidx, sxy, qx, qy, md2);
+      best = nn_query(g, cst, sidx, sxy, qx, qy, A.max_distance, md2);
       if (best >= 0) {
         const float2 nm = A.moving.nrm[mbase + j], nf = A.fixed.nrm[fbase + best];
         float nqx, nqy; xf_normal(A.T, nm.x, nm.y, nqx, nqy);
