@@ -71,8 +71,10 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("LSM2D_BENCH_FORCE_DIST"))   # the env var rehearses the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from srrg2_laser_slam_2d_amd import api, distributed, synth
@@ -118,7 +120,7 @@ def main() -> None:
     for _ in range(args.warmup):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -127,11 +129,11 @@ def main() -> None:
         res = step()
         kernel_ms.append(res.kernel_ms)          # HIP events around the k_align launch, on the launch stream
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -142,7 +144,7 @@ def main() -> None:
     err[:, 2] = np.abs((err[:, 2] + np.pi) % (2 * np.pi) - np.pi)
     tol_m, tol_rad = (1e-4, 1e-4) if args.finder == "projective" else (5e-3, 2e-3)
     ok = bool(np.all(res.status == 0) and err[:, :2].max() < tol_m and err[:, 2].max() < tol_rad)
-    if world > 1:
+    if use_dist:
         f = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(f, op=dist.ReduceOp.MIN); ok = bool(f.item())
 
     if rank == 0:
@@ -198,7 +200,7 @@ def main() -> None:
                                    "max_pose_diff_gpu_vs_cpu_m": float(d[:, :2].max()), "max_pose_diff_gpu_vs_cpu_rad": float(d[:, 2].max())}
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

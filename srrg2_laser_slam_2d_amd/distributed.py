@@ -24,7 +24,7 @@ def broadcast_map(map_points, n_points: int, local_rank: int = 0, src: int = 0, 
     import torch.distributed as dist
     if device is None:
         device = f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if dist.get_rank() == src:
             t = torch.from_numpy(np.ascontiguousarray(map_points, np.float32)).to(device)
         else:
