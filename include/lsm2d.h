@@ -129,6 +129,12 @@ int  lsm2d_cloudset_create(lsm2d_context* ctx, const float* points_xynn, const i
 /* same, from points already in device memory on ctx's device (float4 per point); offsets stay host */
 int  lsm2d_cloudset_create_from_device(lsm2d_context* ctx, const void* d_points_xynn, const int32_t* offsets,
                                        int32_t n_clouds, int64_t total_points, lsm2d_cloudset** out_set);
+/* a single growable cloud (count 0) with room for capacity_points: the device-resident local map / clipped scene */
+int  lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capacity_points, lsm2d_cloudset** out_set);
+/* refill an existing SINGLE-cloud set in place (no allocation); LSM2D_CAPACITY_EXCEEDED when it does not fit */
+int  lsm2d_cloudset_upload(lsm2d_cloudset* set, const float* points_xynn, int64_t n_points);
+/* copy cloud `cloud_index` back to the host as (x, y, nx, ny) rows; *out_n = its size */
+int  lsm2d_cloudset_download(const lsm2d_cloudset* set, int32_t cloud_index, float* out_points_xynn, int64_t capacity, int64_t* out_n);
 void lsm2d_cloudset_destroy(lsm2d_cloudset* set);
 int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* set);
 int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* set);
@@ -140,6 +146,24 @@ int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* set);
 int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* projector, const lsm2d_cloudset* cloud,
                   int32_t cloud_index, const float pose[3], int32_t* out_source_idx, float* out_depth,
                   float* out_transformed_xynn);
+
+/* ---- SceneClipperProjective2D::compute (mapping/scene_clipper_projective_2d.cpp:11-65, voxelize_resolution = 0
+ * as in both shipped configs, MULTI.json:673-683): what the sensor at robot_in_local_map * sensor_in_robot sees of
+ * `full_scene` -- at most one point per projector column, ascending column, expressed in the ROBOT frame.
+ * `clipped` is a reserved single-cloud set (capacity >= canvas_cols) that is overwritten and stays on the device,
+ * ready to be the aligner's moving cloud.  out_source_idx (host, canvas_cols entries) may be NULL. */
+int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* projector, const lsm2d_cloudset* full_scene,
+                     int32_t scene_index, const float robot_in_local_map[3], const float sensor_in_robot[3],
+                     lsm2d_cloudset* clipped, int32_t* out_n_points, int32_t* out_source_idx);
+
+/* ---- MergerProjective2D::compute (mapping/merger_projective_2d.cpp:9-100): folds `measurement` (cloud
+ * measurement_index, in its own sensor/robot frame) into the single-cloud reserved set `scene`, in place: per projector
+ * column seen from measurement_in_scene a measurement point is merged into (|depth difference| < merge_threshold),
+ * replaces (it lies behind) or is appended next to the scene's nearest point; measurement depths beyond
+ * 0.9*range_max are ignored.  out_counts[3] = {new, merged, replaced} (may be NULL). */
+int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* projector, lsm2d_cloudset* scene,
+                      const lsm2d_cloudset* measurement, int32_t measurement_index, const float measurement_in_scene[3],
+                      float merge_threshold, int32_t* out_scene_size, int32_t* out_counts);
 
 /* ---- plugin interface #1: CorrespondenceFinder_::compute ---------------------------------------
  * Replaces compute() of the three finders (registration/correspondence_finder_projective_2d.cpp:18-77,

@@ -136,6 +136,16 @@ int lsmo_align_d(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_p
                  const double x0[3], double x_out[3], double H_out[9],
                  lsmo_iter_stats* stats, int* iterations_done);
 
+/* ---- mapping: scene clipper and merger around the aligner ------------------------ */
+int lsmo_clip_scene_f(const lsmo_projector* pr, const lsmo_point* scene, int n_scene, const float robot_in_local_map[3],
+                      const float sensor_in_robot[3], lsmo_point* out, int* out_src);
+int lsmo_clip_scene_d(const lsmo_projector* pr, const lsmo_point* scene, int n_scene, const double robot_in_local_map[3],
+                      const double sensor_in_robot[3], lsmo_point* out, int* out_src);
+int lsmo_merge_scene_f(const lsmo_projector* pr, lsmo_point* scene, int n_scene, const lsmo_point* meas, int n_meas,
+                       const float measurement_in_scene[3], float merge_threshold, int counts[3]);
+int lsmo_merge_scene_d(const lsmo_projector* pr, lsmo_point* scene, int n_scene, const lsmo_point* meas, int n_meas,
+                       const double measurement_in_scene[3], double merge_threshold, int counts[3]);
+
 /* batch convenience for the CPU baseline: one shared moving cloud (the map), ragged fixed clouds
  * (scans) packed back to back with offsets[n+1]; single slice; n_threads >= 1 (pthreads). */
 int lsmo_align_batch_f(const lsmo_aligner_params* ap, const lsmo_slice_params* sp,

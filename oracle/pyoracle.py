@@ -211,3 +211,28 @@ def align_batch(ap: AlignerParams, sp: SliceParams, fixed_packed, fixed_offsets,
                              x0.ctypes.data_as(C.c_void_p), xo.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
                              status.ctypes.data_as(C.c_void_p), last, int(n_threads))
     return xo, H.reshape(n, 3, 3), status, [last[i] for i in range(n)]
+
+
+def clip_scene(pr: Projector, scene, robot_in_local_map, sensor_in_robot=(0.0, 0.0, 0.0), double=False):
+    """SceneClipperProjective2D::compute. Returns (clipped float32 [k,4] in the robot frame, source indices int32 [k])."""
+    dt, sfx = _real(double)
+    scene, ps = _pts(scene)
+    out = np.empty((pr.canvas_cols, 4), np.float32); src = np.empty(pr.canvas_cols, np.int32)
+    r = np.ascontiguousarray(robot_in_local_map, dt); s_ = np.ascontiguousarray(sensor_in_robot, dt)
+    k = getattr(lib(), "lsmo_clip_scene" + sfx)(C.byref(pr), ps, len(scene), r.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p),
+                                               out.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p))
+    assert k >= 0, k
+    return out[:k].copy(), src[:k].copy()
+
+
+def merge_scene(pr: Projector, scene, meas, measurement_in_scene, merge_threshold=0.2, double=False):
+    """MergerProjective2D::compute. Returns (new scene float32 [n',4], counts (new, merged, replaced))."""
+    dt, sfx = _real(double)
+    scene = np.ascontiguousarray(scene, np.float32); meas, pm = _pts(meas)
+    buf = np.zeros((len(scene) + pr.canvas_cols, 4), np.float32); buf[:len(scene)] = scene
+    m = np.ascontiguousarray(measurement_in_scene, dt); counts = (C.c_int * 3)()
+    fn = getattr(lib(), "lsmo_merge_scene" + sfx)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double if double else C.c_float, C.c_void_p]
+    n = fn(C.cast(C.byref(pr), C.c_void_p), buf.ctypes.data_as(C.c_void_p), len(scene), pm, len(meas), m.ctypes.data_as(C.c_void_p), merge_threshold, counts)
+    assert n >= 0, n
+    return buf[:n].copy(), tuple(counts)

@@ -66,10 +66,15 @@ SYMBOLS = [
     ("lsm2d_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("lsm2d_cloudset_create", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(_P)]),
     ("lsm2d_cloudset_create_from_device", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(_P)]),
+    ("lsm2d_cloudset_create_reserved", C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    ("lsm2d_cloudset_upload", C.c_int, [_P, _P, C.c_int64]),
+    ("lsm2d_cloudset_download", C.c_int, [_P, C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("lsm2d_cloudset_destroy", None, [_P]),
     ("lsm2d_cloudset_num_clouds", C.c_int32, [_P]),
     ("lsm2d_cloudset_num_points", C.c_int64, [_P]),
     ("lsm2d_project", C.c_int, [_P, C.POINTER(Projector), _P, C.c_int32, _P, _P, _P, _P]),
+    ("lsm2d_clip_scene", C.c_int, [_P, C.POINTER(Projector), _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), _P]),
+    ("lsm2d_merge_scene", C.c_int, [_P, C.POINTER(Projector), _P, _P, C.c_int32, _P, C.c_float, C.POINTER(C.c_int32), _P]),
     ("lsm2d_find_correspondences", C.c_int,
      [_P, C.POINTER(SliceParams), _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     ("lsm2d_linearize", C.c_int,

@@ -103,6 +103,32 @@ class CloudSet:
     def handle(self):
         return self._h
 
+    @classmethod
+    def reserved(cls, ctx: Context, capacity: int) -> "CloudSet":
+        """One growable device cloud (the local map a tracker keeps merging into / a clipped scene)."""
+        self = cls.__new__(cls)
+        self._ctx, self._lib = ctx, ctx._lib
+        h = C.c_void_p()
+        check(ctx._lib.lsm2d_cloudset_create_reserved(ctx.handle, int(capacity), C.byref(h)), "lsm2d_cloudset_create_reserved", ctx.handle)
+        self._h, self.n_clouds, self.n_points, self.counts, self.capacity = h, 1, 0, np.zeros(1, np.int64), int(capacity)
+        return self
+
+    def _set_count(self, n: int):
+        self.n_points = int(n); self.counts = np.array([int(n)], np.int64)
+
+    def upload(self, points):
+        """Refill this single-cloud set in place (no allocation)."""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
+        check(self._lib.lsm2d_cloudset_upload(self._h, pts.ctypes.data_as(C.c_void_p), len(pts)), "lsm2d_cloudset_upload", self._ctx.handle)
+        self._set_count(len(pts))
+
+    def download(self, cloud_index: int = 0) -> np.ndarray:
+        cap = int(self.counts[cloud_index])
+        out = np.empty((max(cap, 1), 4), np.float32); n = C.c_int64(0)
+        check(self._lib.lsm2d_cloudset_download(self._h, cloud_index, out.ctypes.data_as(C.c_void_p), cap, C.byref(n)),
+              "lsm2d_cloudset_download", self._ctx.handle)
+        return out[: n.value].copy()
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.lsm2d_cloudset_destroy(self._h)
@@ -412,3 +438,88 @@ def linearize(ctx: Context, slice_params: SliceParams, fixed, moving, correspond
                                    H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(st)),
           "lsm2d_linearize", ctx.handle)
     return H.reshape(3, 3), b, st
+
+
+class SceneClipperProjective2D:
+    """mapping/scene_clipper_projective_2d.{h,cpp} with voxelize_resolution = 0 (both shipped configs, MULTI.json:673-683):
+    keeps what the sensor sees of the local map, at most one point per projector column, in the robot frame.  The clipped
+    scene stays on the device (a reserved CloudSet) and is what the tracker hands to the aligner as ``moving``."""
+
+    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, voxelize_resolution: float = 0.0):
+        self._ctx = ctx
+        self.param_projector = projector
+        self.param_voxelize_resolution = voxelize_resolution
+        self._full_scene = None
+        self._clipped = None
+        self._robot_in_local_map = np.zeros(3, np.float32)
+        self._sensor_in_robot = np.zeros(3, np.float32)
+        self.source_indices = np.zeros(0, np.int32)
+
+    def setFullScene(self, scene):
+        self._full_scene = _as_cloudset(self._ctx, scene)
+
+    def setClippedSceneInRobot(self, clipped: CloudSet):
+        self._clipped = clipped
+
+    def setRobotInLocalMap(self, pose):
+        self._robot_in_local_map = np.ascontiguousarray(pose, np.float32).reshape(3)
+
+    def setSensorInRobot(self, pose):
+        self._sensor_in_robot = np.ascontiguousarray(pose, np.float32).reshape(3)
+
+    def compute(self) -> CloudSet:
+        if self._full_scene is None:
+            raise RuntimeError("SceneClipperProjective2D::compute| missing local OR global scene")
+        if self.param_projector is None:
+            raise RuntimeError("SceneClipperProjective2D::compute| Missing Projector")
+        if self.param_voxelize_resolution > 0:
+            raise NotImplementedError("voxelize_resolution > 0 is not on the device path (shipped configs use 0)")
+        cols = self.param_projector.param_canvas_cols
+        if self._clipped is None:
+            self._clipped = CloudSet.reserved(self._ctx, cols)
+        pr = self.param_projector.struct()
+        n = C.c_int32(0); src = np.empty(cols, np.int32)
+        check(self._ctx._lib.lsm2d_clip_scene(self._ctx.handle, C.byref(pr), self._full_scene.handle, 0,
+                                              self._robot_in_local_map.ctypes.data_as(C.c_void_p),
+                                              self._sensor_in_robot.ctypes.data_as(C.c_void_p), self._clipped.handle, C.byref(n),
+                                              src.ctypes.data_as(C.c_void_p)), "lsm2d_clip_scene", self._ctx.handle)
+        self._clipped._set_count(n.value)
+        self.source_indices = src[: n.value].copy()
+        return self._clipped
+
+
+class MergerProjective2D:
+    """mapping/merger_projective_2d.{h,cpp}: folds a measurement into the device-resident scene, in place."""
+
+    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, merge_threshold: float = 0.2):
+        self._ctx = ctx
+        self.param_projector = projector
+        self.param_merge_threshold = merge_threshold
+        self._scene = None
+        self._measurement = None
+        self._measurement_in_scene = np.zeros(3, np.float32)
+        self.counts = (0, 0, 0)      # new, merged, replaced
+
+    def setScene(self, scene: CloudSet):
+        self._scene = scene
+
+    def setMeasurement(self, measurement, index: int = 0):
+        self._measurement = _as_cloudset(self._ctx, measurement); self._measurement_index = index
+
+    def setMeasurementInScene(self, pose):
+        self._measurement_in_scene = np.ascontiguousarray(pose, np.float32).reshape(3)
+
+    def compute(self) -> int:
+        if self.param_projector is None:
+            raise RuntimeError("MergerProjective2D::compute| Missing Projector")
+        if self._scene is None or self._measurement is None:
+            raise RuntimeError("MergerProjective2D::compute| missing scene or measurement")
+        pr = self.param_projector.struct()
+        size = C.c_int32(0); counts = (C.c_int32 * 3)()
+        check(self._ctx._lib.lsm2d_merge_scene(self._ctx.handle, C.byref(pr), self._scene.handle, self._measurement.handle,
+                                               self._measurement_index, self._measurement_in_scene.ctypes.data_as(C.c_void_p),
+                                               float(self.param_merge_threshold), C.byref(size), counts),
+              "lsm2d_merge_scene", self._ctx.handle)
+        self._scene._set_count(size.value)
+        self.counts = tuple(counts)
+        return size.value

@@ -44,6 +44,7 @@ struct lsm2d_cloudset {
   int32_t n_clouds = 0;
   int64_t total = 0;          // logical points
   int64_t padded_total = 0;   // device points incl. even-alignment padding
+  int64_t capacity = 0;       // > 0: a reserved single growable cloud (lsm2d_cloudset_create_reserved)
   float2* d_xy = nullptr; float2* d_nrm = nullptr;
   int32_t* d_start = nullptr; int32_t* d_count = nullptr;
   std::vector<int32_t> h_start, h_count;
@@ -113,6 +114,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_align<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipGetLastError();
   *out = c;
   return LSM2D_SUCCESS;
@@ -145,6 +147,7 @@ extern "C" int lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms) {
   return LSM2D_SUCCESS;
 }
 
+static bool valid_cloud_index_fwd(const lsm2d_cloudset* cs, int32_t i);
 static int ensure_stage(lsm2d_context* ctx, size_t bytes) {
   if (bytes <= ctx->h_stage_bytes) return LSM2D_SUCCESS;
   if (ctx->h_stage) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipHostFree(ctx->h_stage)); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
@@ -261,6 +264,79 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
 extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
 extern "C" int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* cs) { return cs ? cs->total : 0; }
 
+static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents changed: cached NN grids are stale
+  for (auto& g : cs->grids) {
+    if (g.d_meta) (void) hipFree(g.d_meta);
+    if (g.d_cell_start) (void) hipFree(g.d_cell_start);
+    if (g.d_cursor) (void) hipFree(g.d_cursor);
+    if (g.d_sorted_idx) (void) hipFree(g.d_sorted_idx);
+    if (g.d_sorted_xy) (void) hipFree(g.d_sorted_xy);
+  }
+  cs->grids.clear();
+}
+
+extern "C" int lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capacity, lsm2d_cloudset** out) {
+  if (!ctx || !out || capacity < 1 || capacity > 0x7ffffff0) return fail(ctx, LSM2D_BAD_ARGUMENT, "cloudset_create_reserved: bad argument");
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  lsm2d_cloudset* cs = new (std::nothrow) lsm2d_cloudset;
+  if (!cs) return LSM2D_OUT_OF_MEMORY;
+  cs->ctx = ctx; cs->n_clouds = 1; cs->total = 0; cs->capacity = capacity; cs->padded_total = capacity + (capacity & 1) + 2;
+  cs->h_start.assign(1, 0); cs->h_count.assign(1, 0);
+  int rc = cloudset_alloc(ctx, cs);
+  if (rc == LSM2D_SUCCESS) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = LSM2D_DEVICE_ERROR; }
+  if (rc != LSM2D_SUCCESS) { lsm2d_cloudset_destroy(cs); return rc; }
+  *out = cs;
+  return LSM2D_SUCCESS;
+}
+
+static int set_single_count(lsm2d_context* ctx, lsm2d_cloudset* cs, int32_t n) {
+  cs->h_count[0] = n; cs->total = n;
+  HIPCHK(ctx, hipMemcpyAsync(cs->d_count, cs->h_count.data(), sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  return LSM2D_SUCCESS;
+}
+
+extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64_t n) {
+  if (!cs || !cs->ctx || cs->n_clouds != 1 || n < 0 || (n > 0 && !pts)) return fail(cs ? cs->ctx : nullptr, LSM2D_BAD_ARGUMENT, "cloudset_upload: bad argument");
+  lsm2d_context* ctx = cs->ctx;
+  const int64_t cap = cs->capacity > 0 ? cs->capacity : cs->padded_total - 2;
+  if (n > cap) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "cloudset_upload: does not fit the allocation");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  cloudset_drop_grids(cs);
+  // split on the host into the pinned staging buffer, then two plain copies (no allocation, no kernel)
+  int rc = ensure_stage(ctx, sizeof(float) * 4 * (size_t) (n > 0 ? n : 1)); if (rc) return rc;
+  float2* hxy = (float2*) ctx->h_stage; float2* hn = hxy + n;
+  for (int64_t i = 0; i < n; ++i) { hxy[i] = make_float2(pts[4 * i], pts[4 * i + 1]); hn[i] = make_float2(pts[4 * i + 2], pts[4 * i + 3]); }
+  if (n) {
+    HIPCHK(ctx, hipMemcpyAsync(cs->d_xy, hxy, sizeof(float2) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(cs->d_nrm, hn, sizeof(float2) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  rc = set_single_count(ctx, cs, (int32_t) n); if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the staging buffer is reused by the next call
+  return LSM2D_SUCCESS;
+}
+
+extern "C" int lsm2d_cloudset_download(const lsm2d_cloudset* cs, int32_t ci, float* out, int64_t capacity, int64_t* out_n) {
+  if (!cs || !cs->ctx || !out_n || !valid_cloud_index_fwd(cs, ci)) return fail(cs ? cs->ctx : nullptr, LSM2D_BAD_ARGUMENT, "cloudset_download: bad argument");
+  lsm2d_context* ctx = cs->ctx;
+  const int64_t n = cs->h_count[ci];
+  *out_n = n;
+  if (n > capacity || (n > 0 && !out)) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "cloudset_download: out buffer too small");
+  if (n == 0) return LSM2D_SUCCESS;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(float4) * (size_t) n;
+  int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+  rc = ensure_stage(ctx, bytes); if (rc) return rc;
+  const int base = cs->h_start[ci];
+  hipLaunchKernelGGL(k_pack_aos, dim3((unsigned) ((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const float2*) (cs->d_xy + base), (const float2*) (cs->d_nrm + base), (int) n, (float4*) ctx->d_scratch);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, ctx->h_stage, bytes);
+  return LSM2D_SUCCESS;
+}
+
 // ---- parameter packing -------------------------------------------------------------------------------
 // Depths are compared through r2: sqrtf is correctly rounded and monotone, so
 //   rmin <= sqrtf(r2)  <=>  r2 >= r2lo,  r2lo = smallest float whose sqrtf reaches rmin   (same for rmax).
@@ -343,6 +419,113 @@ static void inverse_host(const float a[3], float out[3]) {   // (R,t)^-1 = (R^T,
   out[2] = wrap_host(-a[2]);
 }
 static bool valid_cloud_index(const lsm2d_cloudset* cs, int32_t i) { return cs && i >= 0 && i < cs->n_clouds; }
+static bool valid_cloud_index_fwd(const lsm2d_cloudset* cs, int32_t i) { return valid_cloud_index(cs, i); }
+static void compose_host(const float a[3], const float b[3], float out[3]) {   // v2t(a) * v2t(b)
+  const float c = cosf(a[2]), s = sinf(a[2]);
+  out[0] = fmaf(c, b[0], fmaf(-s, b[1], a[0]));
+  out[1] = fmaf(s, b[0], fmaf(c, b[1], a[1]));
+  out[2] = wrap_host(a[2] + b[2]);
+}
+
+// z-buffer of one cloud spread over many workgroups into a global canvas (d_canvas: cols u64 cells)
+static int project_split(lsm2d_context* ctx, const float2* d_xy, int n, const Iso& T, const ProjK& P, u64* d_canvas) {
+  HIPCHK(ctx, hipMemsetAsync(d_canvas, 0xFF, sizeof(u64) * (size_t) P.cols, ctx->stream));
+  if (n <= 0) return LSM2D_SUCCESS;
+  ProjectSplitArgs A; A.xy = d_xy; A.n = n; A.T = T; A.proj = P; A.gcanvas = d_canvas;
+  int blocks = (n + 8191) / 8192; if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(k_project_split, dim3(blocks), dim3(512), sizeof(u64) * (size_t) P.cols, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  return LSM2D_SUCCESS;
+}
+
+// ---- SceneClipperProjective2D ------------------------------------------------------------------------------
+extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* scene, int32_t si,
+                                const float robot_in_local_map[3], const float sensor_in_robot[3], lsm2d_cloudset* clipped,
+                                int32_t* out_n, int32_t* out_src) {
+  if (!ctx || !pr || !robot_in_local_map || !sensor_in_robot || !clipped || !out_n || !valid_cloud_index(scene, si) || clipped->n_clouds != 1 ||
+      clipped == scene)
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "clip_scene: bad argument");
+  ProjK P;
+  if (!make_projk(*pr, &P)) return fail(ctx, LSM2D_BAD_ARGUMENT, "clip_scene: bad projector");
+  const int64_t cap = clipped->capacity > 0 ? clipped->capacity : clipped->padded_total - 2;
+  if (cap < P.cols) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "clip_scene: clipped set smaller than canvas_cols");
+  if ((int) (sizeof(u64) * (size_t) P.cols) > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "clip_scene: canvas does not fit LDS");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  cloudset_drop_grids(clipped);
+  const size_t cols = (size_t) P.cols, o_src = cols * 8, o_cnt = o_src + cols * 4, bytes = o_cnt + 16;
+  int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+  rc = ensure_stage(ctx, bytes); if (rc) return rc;
+  float cam[3], cam_inv[3];
+  compose_host(robot_in_local_map, sensor_in_robot, cam); inverse_host(cam, cam_inv);
+  const Iso T = make_iso(cam_inv);
+  u64* d_canvas = (u64*) ctx->d_scratch;
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  rc = project_split(ctx, scene->d_xy + scene->h_start[si], scene->h_count[si], T, P, d_canvas); if (rc) return rc;
+  ClipEmitArgs A;
+  A.gcanvas = d_canvas; A.cols = P.cols; A.xy = scene->d_xy + scene->h_start[si]; A.nrm = scene->d_nrm + scene->h_start[si];
+  A.T = T; A.S = make_iso(sensor_in_robot);
+  A.s_identity = sensor_in_robot[0] == 0.0f && sensor_in_robot[1] == 0.0f && sensor_in_robot[2] == 0.0f;
+  A.out_xy = clipped->d_xy; A.out_nrm = clipped->d_nrm; A.out_src = (int32_t*) ((char*) ctx->d_scratch + o_src);
+  A.out_count = (int32_t*) ((char*) ctx->d_scratch + o_cnt); A.out_count_dev = clipped->d_count;
+  hipLaunchKernelGGL(k_clip_emit, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = true;
+  HIPCHK(ctx, hipMemcpyAsync((char*) ctx->h_stage + o_src, (char*) ctx->d_scratch + o_src, bytes - o_src, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t n = *(const int32_t*) ((char*) ctx->h_stage + o_cnt);
+  clipped->h_count[0] = n; clipped->total = n; *out_n = n;
+  if (out_src) memcpy(out_src, (char*) ctx->h_stage + o_src, sizeof(int32_t) * (size_t) n);
+  return LSM2D_SUCCESS;
+}
+
+// ---- MergerProjective2D ----------------------------------------------------------------------------------------
+extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, lsm2d_cloudset* scene, const lsm2d_cloudset* meas,
+                                 int32_t mi, const float measurement_in_scene[3], float merge_threshold, int32_t* out_size,
+                                 int32_t* out_counts) {
+  if (!ctx || !pr || !scene || !measurement_in_scene || !out_size || !valid_cloud_index(meas, mi) || scene->n_clouds != 1 || scene == meas)
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "merge_scene: bad argument");
+  ProjK P;
+  if (!make_projk(*pr, &P)) return fail(ctx, LSM2D_BAD_ARGUMENT, "merge_scene: bad projector");
+  const int64_t cap = scene->capacity > 0 ? scene->capacity : scene->padded_total - 2;
+  const int n_scene = scene->h_count[0], n_meas = meas->h_count[mi];
+  if ((int64_t) n_scene + P.cols > cap) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "merge_scene: scene set has no room for canvas_cols more points");
+  if ((int) (sizeof(u64) * (size_t) P.cols) > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "merge_scene: canvas does not fit LDS");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  cloudset_drop_grids(scene);
+  const size_t cols = (size_t) P.cols, nm = (size_t) (n_meas > 0 ? n_meas : 1);
+  const size_t o_mcan = cols * 8, o_out = o_mcan + cols * 8, o_txy = o_out + 64, o_tn = o_txy + ((nm * 8 + 15) & ~(size_t) 15) + 16, bytes = o_tn + nm * 8 + 16;
+  int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+  rc = ensure_stage(ctx, 64); if (rc) return rc;
+  float cam_inv[3]; inverse_host(measurement_in_scene, cam_inv);
+  const Iso Tinv = make_iso(cam_inv), M = make_iso(measurement_in_scene);
+  char* ds = (char*) ctx->d_scratch;
+  u64* d_scan = (u64*) ds; u64* d_mcan = (u64*) (ds + o_mcan);
+  float2* d_txy = (float2*) (ds + o_txy); float2* d_tn = (float2*) (ds + o_tn);
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (n_meas > 0) {
+    hipLaunchKernelGGL(k_transform_cloud, dim3((unsigned) ((n_meas + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float2*) (meas->d_xy + meas->h_start[mi]), (const float2*) (meas->d_nrm + meas->h_start[mi]), n_meas, M, d_txy, d_tn);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  rc = project_split(ctx, scene->d_xy, n_scene, Tinv, P, d_scan); if (rc) return rc;
+  rc = project_split(ctx, d_txy, n_meas, Tinv, P, d_mcan); if (rc) return rc;
+  MergeArgs A;
+  A.scanvas = d_scan; A.mcanvas = d_mcan; A.cols = P.cols; A.sxy = scene->d_xy; A.snrm = scene->d_nrm; A.n_scene = n_scene;
+  A.mxy = d_txy; A.mnrm = d_tn; A.far_limit = 0.9f * pr->range_max; A.merge_threshold = merge_threshold;
+  A.out = (int32_t*) (ds + o_out); A.count_dev = scene->d_count;
+  hipLaunchKernelGGL(k_merge_apply, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = true;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ds + o_out, 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t* h = (const int32_t*) ctx->h_stage;
+  scene->h_count[0] = h[0]; scene->total = h[0]; *out_size = h[0];
+  if (out_counts) { out_counts[0] = h[1]; out_counts[1] = h[2]; out_counts[2] = h[3]; }
+  return LSM2D_SUCCESS;
+}
+
 
 // ---- a3 ------------------------------------------------------------------------------------------------
 extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* cloud, int32_t ci,

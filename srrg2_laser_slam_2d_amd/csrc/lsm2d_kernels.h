@@ -535,6 +535,154 @@ __global__ void k_linearize_final(const float* partial, int n_blocks, float* out
   out[9] = t.chi_in; out[10] = t.chi_out; out[11] = __int_as_float(t.n_in); out[12] = __int_as_float(t.n_out); out[13] = __int_as_float(t.n_corr);
 }
 
+// ---- mapping kernels around the aligner: the same polar z-buffer, spread over many
+//      workgroups for one big cloud, then an O(Bins) pass.  -----------------------------------------------
+struct ProjectSplitArgs {
+  const float2* xy; int32_t n; Iso T; ProjK proj;
+  u64* gcanvas;            // [cols], pre-filled with kEmptyCell
+};
+
+// each workgroup z-buffers a contiguous slice of the cloud in LDS, then folds its canvas into the global one
+__global__ __launch_bounds__(512) void k_project_split(const ProjectSplitArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64* can = reinterpret_cast<u64*>(smem);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < A.proj.cols; i += 512) can[i] = kEmptyCell;
+  __syncthreads();
+  const Iso T = A.T; const ProjK P = A.proj;
+  const int npairs = (A.n + 1) >> 1;
+  const int per = (npairs + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = lo + per < npairs ? lo + per : npairs;
+  const float4* xy4 = reinterpret_cast<const float4*>(A.xy);
+  for (int j = lo + tid; j < hi; j += 512) {
+    const float4 v = xy4[j];
+    project_point(T, P, v.x, v.y, 2 * j, can);
+    if (2 * j + 1 < A.n) project_point(T, P, v.z, v.w, 2 * j + 1, can);
+  }
+  __syncthreads();
+  for (int i = tid; i < P.cols; i += 512) { const u64 k = can[i]; if (k != kEmptyCell) atomicMin(&A.gcanvas[i], k); }
+}
+
+LSM2D_DEV int block_compact_offset(bool flag, int* s_wave_tot, int* s_base, int tid, int nwaves) {
+  // order-preserving position of this thread's element among the flagged ones (all threads must call)
+  const int lane = tid & 63, wave = tid >> 6;
+  const u64 bal = __ballot(flag);
+  const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave_tot[wave] = __popcll(bal);
+  __syncthreads();
+  int before = *s_base, total = 0;
+  for (int w = 0; w < nwaves; ++w) { const int t = s_wave_tot[w]; if (w < wave) before += t; total += t; }
+  __syncthreads();
+  if (tid == 0) *s_base += total;
+  __syncthreads();
+  return before + prefix;
+}
+
+// SceneClipperProjective2D::compute tail (mapping/scene_clipper_projective_2d.cpp:53-63): filled cells in ascending
+// column -> transformed point (sensor frame), then moved to the robot frame by sensor_in_robot
+struct ClipEmitArgs {
+  const u64* gcanvas; int32_t cols;
+  const float2* xy; const float2* nrm;       // full scene
+  Iso T;                                      // sensor_in_local_map^-1
+  Iso S; int32_t s_identity;                  // sensor_in_robot
+  float2* out_xy; float2* out_nrm; int32_t* out_src; int32_t* out_count_dev /* count[0] of the clipped set */; int32_t* out_count;
+};
+
+__global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A) {
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_base;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < A.cols; c0 += kFindBlock) {
+    const int col = c0 + tid;
+    const u64 k = col < A.cols ? A.gcanvas[col] : kEmptyCell;
+    const bool ok = k != kEmptyCell;
+    const int pos = block_compact_offset(ok, s_wave_tot, &s_base, tid, kFindBlock / 64);
+    if (ok) {
+      const int src = (int) (uint32_t) k;
+      const float2 p = A.xy[src], n = A.nrm[src];
+      float x, y, nx, ny;
+      xf_point(A.T, p.x, p.y, x, y); xf_normal(A.T, n.x, n.y, nx, ny);
+      if (!A.s_identity) {
+        float tx, ty, tnx, tny;
+        xf_point(A.S, x, y, tx, ty); xf_normal(A.S, nx, ny, tnx, tny);
+        x = tx; y = ty; nx = tnx; ny = tny;
+      }
+      A.out_xy[pos] = make_float2(x, y); A.out_nrm[pos] = make_float2(nx, ny);
+      if (A.out_src) A.out_src[pos] = src;
+    }
+  }
+  if (tid == 0) { *A.out_count = s_base; *A.out_count_dev = s_base; }
+}
+
+// transform a cloud (measurement -> scene frame, mapping/merger_projective_2d.cpp:22-23)
+__global__ void k_transform_cloud(const float2* __restrict__ xy, const float2* __restrict__ nrm, int n, const Iso T,
+                                  float2* __restrict__ oxy, float2* __restrict__ onrm) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float2 p = xy[i], q = nrm[i];
+    float x, y, nx, ny;
+    xf_point(T, p.x, p.y, x, y); xf_normal(T, q.x, q.y, nx, ny);
+    oxy[i] = make_float2(x, y); onrm[i] = make_float2(nx, ny);
+  }
+}
+
+// MergerProjective2D::compute column walk (mapping/merger_projective_2d.cpp:39-95)
+struct MergeArgs {
+  const u64* scanvas; const u64* mcanvas; int32_t cols;
+  float2* sxy; float2* snrm; int32_t n_scene;        // scene, updated in place and appended to
+  const float2* mxy; const float2* mnrm;             // measurement already in the scene frame
+  float far_limit, merge_threshold;
+  int32_t* out;                                       // [4]: new size, new, merged, replaced
+  int32_t* count_dev;                                 // count[0] of the scene set
+};
+
+__global__ __launch_bounds__(kFindBlock) void k_merge_apply(const MergeArgs A) {
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_base, s_new, s_merged, s_replaced;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_base = 0; s_new = s_merged = s_replaced = 0; }
+  __syncthreads();
+  for (int c0 = 0; c0 < A.cols; c0 += kFindBlock) {
+    const int col = c0 + tid;
+    bool append = false; float2 mp = make_float2(0.f, 0.f), mn = mp;
+    if (col < A.cols) {
+      const u64 mk = A.mcanvas[col], sk = A.scanvas[col];
+      const float md = __uint_as_float((uint32_t) (mk >> 32));
+      if (mk != kEmptyCell && !(md > A.far_limit)) {
+        const int mi = (int) (uint32_t) mk;
+        mp = A.mxy[mi]; mn = A.mnrm[mi];
+        if (sk == kEmptyCell) { append = true; atomicAdd(&s_new, 1); }
+        else {
+          const int si = (int) (uint32_t) sk;
+          const float dr = md - __uint_as_float((uint32_t) (sk >> 32));
+          if (__builtin_fabsf(dr) < A.merge_threshold) {
+            const float2 sp = A.sxy[si], sn = A.snrm[si];
+            const float x = (sp.x + mp.x) * 0.5f, y = (sp.y + mp.y) * 0.5f;
+            float nx = (sn.x + mn.x) * 0.5f, ny = (sn.y + mn.y) * 0.5f;
+            const float nn = __builtin_sqrtf(__builtin_fmaf(nx, nx, ny * ny));
+            if (nn > 0.0f) { nx = nx / nn; ny = ny / nn; }
+            A.sxy[si] = make_float2(x, y); A.snrm[si] = make_float2(nx, ny);
+            atomicAdd(&s_merged, 1);
+          } else if (dr > 0.0f) { A.sxy[si] = mp; A.snrm[si] = mn; atomicAdd(&s_replaced, 1); }
+          else append = true;
+        }
+      }
+    }
+    const int pos = block_compact_offset(append, s_wave_tot, &s_base, tid, kFindBlock / 64);
+    if (append) { A.sxy[A.n_scene + pos] = mp; A.snrm[A.n_scene + pos] = mn; }
+  }
+  if (tid == 0) { A.out[0] = A.n_scene + s_base; A.out[1] = s_new; A.out[2] = s_merged; A.out[3] = s_replaced; *A.count_dev = A.n_scene + s_base; }
+}
+
+// split a single device cloud back into AoS (download)
+__global__ void k_pack_aos(const float2* __restrict__ xy, const float2* __restrict__ nrm, int n, float4* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float2 p = xy[i], q = nrm[i];
+    out[i] = make_float4(p.x, p.y, q.x, q.y);
+  }
+}
+
 // ---- cloud repack: AoS float4 -> xy / normal arrays, cloud c starting at padded index pstart[c] ----
 __global__ void k_repack_cloud(const float4* __restrict__ src, const int32_t* __restrict__ offsets, const int32_t* __restrict__ pstart,
                                int n_clouds, long long total, float2* __restrict__ xy, float2* __restrict__ nrm) {

@@ -390,3 +390,98 @@ def test_mixed_finders_two_slices(ctx, po, small_workload):
     d = np.abs(al.movingInFixed() - r["pose"])
     assert r["status"] == 0 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
     assert al.iterationStats()["n_correspondences"][0] == r["stats"][0].n_corr
+
+
+# ---- mapping around the aligner (row f1): clipper, merger, device-resident local map ------------------------
+def test_scene_clipper_bit_exact(ctx, po):
+    world = synth.make_world(3)
+    m = synth.make_map(world, 60000)
+    robots = synth.sample_poses(world, 4, seed=5)
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    scene = api.CloudSet(ctx, m)
+    clipper = api.SceneClipperProjective2D(ctx, proj)
+    clipper.setFullScene(scene)
+    for robot, S in zip(robots, ([0, 0, 0], [0.2, 0.1, 0.1], [-0.3, 0.0, math.pi], [0, 0, 0])):
+        clipper.setRobotInLocalMap(robot); clipper.setSensorInRobot(S)
+        clipped = clipper.compute()
+        want, wsrc = po.clip_scene(po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0),
+                                   m, np.float32(robot), np.float32(S))
+        assert 300 < len(want) <= 721
+        assert np.array_equal(clipper.source_indices, wsrc)
+        assert np.array_equal(clipped.download(), want)
+    with pytest.raises(RuntimeError):
+        api.SceneClipperProjective2D(ctx, proj).compute()          # missing scene (scene_clipper_projective_2d.cpp:12-17)
+
+
+def test_merger_bit_exact_and_grows_in_place(ctx, po):
+    world = synth.make_world(3)
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    poses = synth.sample_poses(world, 6, seed=8)
+    scans, offs = synth.make_scans(world, poses, n_beams=721, noise_sigma=0.01, seed=3)
+    scene = api.CloudSet.reserved(ctx, 20000)
+    host_scene = scans[offs[0]:offs[1]].copy()            # first scan seeds the local map at the origin of ITS frame
+    # express everything in the frame of the first sensor pose: measurement_in_scene = T0^-1 * Ti
+    scene.upload(host_scene)
+    merger = api.MergerProjective2D(ctx, proj, merge_threshold=0.2)
+    merger.setScene(scene)
+    t0_inv = synth.invert_poses(poses[:1])
+    for i in range(1, 6):
+        meas = scans[offs[i]:offs[i + 1]]
+        mis = synth.compose_poses(t0_inv, poses[i:i + 1])[0].astype(np.float32)
+        merger.setMeasurement(meas); merger.setMeasurementInScene(mis)
+        n = merger.compute()
+        host_scene, counts = po.merge_scene(opr, host_scene, meas, mis, 0.2)
+        assert n == len(host_scene) and merger.counts == counts
+        assert np.array_equal(scene.download(), host_scene)
+    assert len(host_scene) > offs[1] - offs[0]
+    # capacity is enforced, never overrun
+    small = api.CloudSet.reserved(ctx, 800); small.upload(scans[offs[0]:offs[1]][:200])
+    merger.setScene(small)
+    with pytest.raises(api.Lsm2dError):
+        merger.compute()
+
+
+def test_tracker_step_clip_align_merge_device_resident(ctx, po):
+    """One tracker step as in apps/visual_test_tracker_2d.cpp:167-183 (clip -> align -> merge) with the local map kept
+    on the device, against the same three steps of the oracle; MULTI-like wiring: two laser slices with extrinsics."""
+    world = synth.make_world(5)
+    m = synth.make_map(world, 40000, noise_sigma=0.005, seed=1)
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    robot = synth.sample_poses(world, 1, seed=21)
+    S0, S1 = np.float32([0.2, 0.1, 0.1]), np.float32([-0.3, 0.0, math.pi])
+    scans = [synth.make_scans(world, synth.compose_poses(robot, S[None, :].astype(np.float64)), n_beams=721)[0] for S in (S0, S1)]
+    guess = synth.compose_poses(robot, np.array([[0.03, -0.02, 0.02]]))[0].astype(np.float32)      # odometry-predicted robot pose
+    # --- device pipeline
+    local_map = api.CloudSet.reserved(ctx, 60000); local_map.upload(m)
+    clipper = api.SceneClipperProjective2D(ctx, proj); clipper.setFullScene(local_map)
+    clipper.setRobotInLocalMap(guess); clipper.setSensorInRobot(S0)
+    clipped = clipper.compute()
+    al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
+        api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.9), sensor_in_robot=S0, robustifier=api.RobustifierCauchy(0.01),
+        min_num_correspondences=5, fixed_slice_name="points_0", moving_slice_name="points"))
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
+        api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.8), sensor_in_robot=S1, min_num_correspondences=5,
+        fixed_slice_name="points_1", moving_slice_name="points"))
+    al.setFixed({"points_0": scans[0], "points_1": scans[1]}); al.setMoving({"points": clipped})
+    al.setMovingInFixed([0, 0, 0])           # the clipped scene is already in the predicted robot frame
+    assert al.compute() == 0
+    # --- oracle pipeline
+    oclip, _ = po.clip_scene(opr, m, guess, S0)
+    assert np.array_equal(clipped.download(), oclip)
+    osl = [_oracle_slice(po, s.slice_params()) for s in al.param_slice_processors]
+    r = po.align(po.aligner_params(10), osl, scans, [oclip, oclip], np.zeros(3, np.float32))
+    d = np.abs(al.movingInFixed() - r["pose"])
+    assert r["status"] == 0 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+    # corrected robot pose = guess * X^-1 ; it must be close to the true robot pose
+    corrected = synth.compose_poses(guess[None, :].astype(np.float64), synth.invert_poses(al.movingInFixed()[None, :].astype(np.float64)))[0]
+    assert np.abs(corrected - robot[0])[:2].max() < 0.02 and abs(corrected[2] - robot[0][2]) < 0.01
+    # --- merge the first scan at the corrected sensor pose, in place on the device
+    sensor_in_map = synth.compose_poses(corrected[None, :], S0[None, :].astype(np.float64))[0].astype(np.float32)
+    merger = api.MergerProjective2D(ctx, proj, 0.2); merger.setScene(local_map)
+    merger.setMeasurement(scans[0]); merger.setMeasurementInScene(sensor_in_map)
+    n = merger.compute()
+    want, counts = po.merge_scene(opr, m, scans[0], sensor_in_map, 0.2)
+    assert n == len(want) and merger.counts == counts and np.array_equal(local_map.download(), want)

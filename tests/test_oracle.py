@@ -261,3 +261,34 @@ def test_batch_driver_matches_single_calls(po, small_workload):
         f = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
         r = po.align(ap, [sp], [f], [wl.map_points], wl.x0[i])
         assert np.array_equal(r["pose"], xo[i]) and status[i] == r["status"] and last[i].n_corr == r["stats"][-1].n_corr
+
+
+def test_clipper_and_merger_semantics(po):
+    """mapping/scene_clipper_projective_2d.cpp:11-65 and mapping/merger_projective_2d.cpp:9-100 restated."""
+    pr = po.Projector(360, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    deg = math.pi / 180
+    def pt(r, a, nx=-1.0, ny=0.0):
+        return [r * math.cos(a), r * math.sin(a), nx, ny]
+    scene = np.array([pt(5, 0.5 * deg), pt(7, 0.6 * deg), pt(5, 10.5 * deg), pt(25, 20.5 * deg), pt(5, 30.5 * deg)], np.float32)
+    clipped, src = po.clip_scene(pr, scene, [0, 0, 0])
+    assert list(src) == [0, 2, 4]                          # occluded point 1 and out-of-range point 3 are dropped
+    assert np.allclose(clipped, scene[[0, 2, 4]], atol=1e-6)
+    # robot rotated by 90 deg + sensor offset: clipped points come back in the ROBOT frame
+    robot = np.array([1.0, -2.0, math.pi / 2]); S = np.array([0.3, 0.1, 0.2])
+    clipped, src = po.clip_scene(pr, scene, robot, S, double=True)
+    c, s = math.cos(robot[2]), math.sin(robot[2])
+    back = np.stack([robot[0] + c * clipped[:, 0] - s * clipped[:, 1], robot[1] + s * clipped[:, 0] + c * clipped[:, 1]], 1)
+    assert np.allclose(back, scene[src, :2], atol=1e-5)
+    # merger: measurement seen from the scene origin
+    meas = np.array([pt(5.1, 0.5 * deg),      # within 0.2 of scene depth 5 -> merged
+                     pt(6.0, 10.5 * deg),     # behind the scene point (dr = +1) -> replaces it
+                     pt(3.0, 30.5 * deg),     # in front (dr = -2) -> appended
+                     pt(4.0, 50.5 * deg),     # empty column -> appended as new
+                     pt(19.0, 60.5 * deg)],   # deeper than 0.9 * range_max -> ignored
+                    np.float32)
+    new_scene, counts = po.merge_scene(pr, scene, meas, [0, 0, 0], merge_threshold=0.2)
+    assert counts == (1, 1, 1) and len(new_scene) == len(scene) + 2
+    assert np.allclose(new_scene[0, :2], (scene[0, :2] + meas[0, :2]) / 2, atol=1e-6) and abs(np.linalg.norm(new_scene[0, 2:]) - 1) < 1e-6
+    assert np.allclose(new_scene[2], meas[1], atol=1e-6)
+    assert np.allclose(new_scene[5], meas[2], atol=1e-6) and np.allclose(new_scene[6], meas[3], atol=1e-6)   # appended in ascending column
+    assert np.array_equal(new_scene[[1, 3, 4]], scene[[1, 3, 4]])
