@@ -325,6 +325,26 @@ class BatchResult:
     def status_names(self):
         return [STATUS_NAMES.get(int(s), str(int(s))) for s in self.status]
 
+    def last_stats(self) -> np.ndarray:
+        """Statistics of the last iteration each alignment started (structured [n])."""
+        if self.stats is None:
+            raise RuntimeError("compute_batch(..., want_stats=True) is needed for per-alignment statistics")
+        idx = np.clip(self.iterations - 1, 0, self.stats.shape[1] - 1)
+        return self.stats[np.arange(len(idx)), idx]
+
+    def loop_closure_accept(self, relocalize_min_inliers: int = 500, relocalize_max_chi_inliers: float = 0.1,
+                            relocalize_min_inliers_ratio: float = 0.8) -> np.ndarray:
+        """Acceptance test MultiLoopDetectorBruteForce2D applies to every candidate after relocalize_aligner
+        (configurations/stage_segway_double_config_MULTI.json:964-986): aligner succeeded, inliers >= min,
+        chi_inliers / inliers <= max, inliers / correspondences >= ratio.  The relocaliser uses the same test with
+        700 / 0.01 / 0.75 (MULTI.json:749-769).  Returns bool [n]."""
+        st = self.last_stats()
+        n_in = st["n_inliers"].astype(np.float64); n_c = np.maximum(st["n_correspondences"], 1).astype(np.float64)
+        ok = (self.status == 0) & (st["n_inliers"] >= relocalize_min_inliers)
+        ok &= st["chi_inliers"] / np.maximum(n_in, 1.0) <= relocalize_max_chi_inliers
+        ok &= n_in / n_c >= relocalize_min_inliers_ratio
+        return ok
+
 
 STATS_DTYPE = np.dtype([("n_correspondences", np.int32), ("n_inliers", np.int32), ("n_outliers", np.int32),
                         ("chi_inliers", np.float32), ("chi_outliers", np.float32)])

@@ -485,3 +485,25 @@ def test_tracker_step_clip_align_merge_device_resident(ctx, po):
     n = merger.compute()
     want, counts = po.merge_scene(opr, m, scans[0], sensor_in_map, 0.2)
     assert n == len(want) and merger.counts == counts and np.array_equal(local_map.download(), want)
+
+
+def test_loop_closure_sweep_acceptance(ctx, po):
+    """Row f3: a sweep of candidate (scan, initial guess) pairs against one submap, as MultiLoopDetectorBruteForce2D does with
+    relocalize_aligner (30 iterations, Cauchy 0.05, point_distance 1.414: MULTI.json:572-630,771-784), then the acceptance
+    test of MULTI.json:979-985.  Good guesses must be accepted, hopeless ones rejected; decisions equal the oracle's."""
+    wl = synth.make_workload(12, 60000, seed=12)
+    x0 = wl.x0.copy()
+    x0[8:] += np.float32([3.0, -2.0, 0.7])                      # candidates 8..11: wrong place
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    al = api.MultiAligner2D(ctx, max_iterations=30, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(
+        api.CorrespondenceFinderProjective2f(ctx, proj, point_distance=1.414, normal_cos=0.8), robustifier=api.RobustifierCauchy(0.05),
+        min_num_correspondences=10))
+    res = al.compute_batch([api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)], [api.CloudSet(ctx, wl.map_points)], x0, want_stats=True)
+    acc = res.loop_closure_accept(300, 0.1, 0.8)
+    osp = po.slice_params(canvas_cols=721, range_max=20.0, point_distance=1.414, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.05)
+    xo, _, status, last = po.align_batch(po.aligner_params(30), osp, wl.scan_points, wl.scan_offsets, wl.map_points, x0)
+    want = np.array([status[i] == 0 and last[i].n_in >= 300 and last[i].chi_in / max(last[i].n_in, 1) <= 0.1 and
+                     last[i].n_in / max(last[i].n_corr, 1) >= 0.8 for i in range(12)])
+    assert np.array_equal(acc, want)
+    assert acc[:8].all() and not acc[8:].any()
