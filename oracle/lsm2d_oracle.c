@@ -51,6 +51,7 @@ float lsmo_atan2f(float y, float x) {
 #define R_FABS(a) fabsf(a)
 #define R_FLOOR(a) floorf(a)
 #define R_MAX FLT_MAX
+#define R_TINY FLT_MIN
 #define R_PI LSMO_PI_F
 #define R_TWO_PI 6.28318548202514648f
 #include "lsm2d_oracle_impl.inc"
@@ -65,6 +66,7 @@ float lsmo_atan2f(float y, float x) {
 #undef R_FABS
 #undef R_FLOOR
 #undef R_MAX
+#undef R_TINY
 #undef R_PI
 #undef R_TWO_PI
 
@@ -80,6 +82,7 @@ float lsmo_atan2f(float y, float x) {
 #define R_FABS(a) fabs(a)
 #define R_FLOOR(a) floor(a)
 #define R_MAX DBL_MAX
+#define R_TINY ((double) FLT_MIN)
 #define R_PI 3.14159265358979323846
 #define R_TWO_PI 6.28318530717958647692
 #include "lsm2d_oracle_impl.inc"

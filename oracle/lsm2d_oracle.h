@@ -105,6 +105,10 @@ int lsmo_find_nn_f(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_f
                    const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
 int lsmo_find_nn_d(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
                    const lsmo_point* moving, int n_moving, const double pose[3], lsmo_corr* out);
+int lsmo_find_distmap_f(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                        const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
+int lsmo_find_distmap_d(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                        const lsmo_point* moving, int n_moving, const double pose[3], lsmo_corr* out);
 /* O(N_f*N_m) brute force, used only to validate the grid search above */
 int lsmo_find_nn_brute_f(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
                          const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);

@@ -145,7 +145,8 @@ def find(sp: SliceParams, fixed, moving, pose, double=False, brute=False):
     cap = sp.projector.canvas_cols if sp.finder == FINDER_PROJECTIVE else len(moving)
     out = np.empty((max(cap, 1), 2), np.int32)
     pose = np.ascontiguousarray(pose, dt)
-    name = {FINDER_PROJECTIVE: "lsmo_find_projective", FINDER_NN: "lsmo_find_nn_brute" if brute else "lsmo_find_nn"}[sp.finder]
+    name = {FINDER_PROJECTIVE: "lsmo_find_projective", FINDER_NN: "lsmo_find_nn_brute" if brute else "lsmo_find_nn",
+            FINDER_DISTMAP: "lsmo_find_distmap"}[sp.finder]
     k = getattr(lib(), name + sfx)(C.byref(sp), pf, len(fixed), pm, len(moving), pose.ctypes.data_as(C.c_void_p),
                                    out.ctypes.data_as(C.c_void_p))
     assert k >= 0, k

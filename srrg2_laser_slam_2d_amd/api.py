@@ -264,6 +264,29 @@ class CorrespondenceFinderKDTree2D(_FinderBase):
         return int(self._moving.counts[self._moving_index])
 
 
+class CorrespondenceFinderNN2D(_FinderBase):
+    """registration/correspondence_finder_nn_2d.{h,cpp}: distance-map finder (one grid lookup per query)."""
+    finder_kind = _capi.FINDER_DISTMAP
+
+    def __init__(self, ctx: Context, max_distance_m: float = 1.0, resolution: float = 5e-2, normal_cos: float = 0.8):
+        super().__init__(ctx)
+        self.param_max_distance_m = max_distance_m
+        self.param_resolution = resolution
+        self.param_normal_cos = normal_cos
+
+    def slice_params(self, **kw) -> SliceParams:
+        if self.param_resolution <= 0:
+            raise RuntimeError("resolution must be > 0")               # correspondence_finder_nn_2d.cpp:11-14
+        if self.param_max_distance_m < 0:
+            raise RuntimeError("please set max_distance_m > 0")        # :15-18
+        return make_slice_params(finder=_capi.FINDER_DISTMAP, projector=PointNormal2fProjectorPolar(),
+                                 max_distance=self.param_max_distance_m, resolution=self.param_resolution,
+                                 normal_cos=self.param_normal_cos, **kw)
+
+    def _capacity(self) -> int:
+        return int(self._moving.counts[self._moving_index])
+
+
 def make_slice_params(finder=FINDER_PROJECTIVE, projector: Optional[PointNormal2fProjectorPolar] = None,
                       point_distance=0.5, normal_cos=0.8, max_distance=0.5, resolution=0.05,
                       robustifier=ROBUST_NONE, chi_threshold=0.05, min_num_correspondences=10,

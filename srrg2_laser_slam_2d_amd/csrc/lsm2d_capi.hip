@@ -38,9 +38,15 @@ struct GridCache {     // one search grid per (cloud set, max_distance), built o
   int32_t* d_sorted_idx = nullptr; float2* d_sorted_xy = nullptr;
 };
 
+struct DistCache {     // one distance map per (cloud set, max_distance, resolution)
+  float max_distance = 0.0f, resolution = 0.0f;
+  DistMeta* d_meta = nullptr; int32_t* d_parent = nullptr;
+};
+
 struct lsm2d_cloudset {
   lsm2d_context* ctx = nullptr;
   mutable std::vector<GridCache> grids;
+  mutable std::vector<DistCache> dists;
   int32_t n_clouds = 0;
   int64_t total = 0;          // logical points
   int64_t padded_total = 0;   // device points incl. even-alignment padding
@@ -259,6 +265,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
     if (g.d_sorted_idx) (void) hipFree(g.d_sorted_idx);
     if (g.d_sorted_xy) (void) hipFree(g.d_sorted_xy);
   }
+  for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   delete cs;
 }
 extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
@@ -273,6 +280,8 @@ static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents 
     if (g.d_sorted_xy) (void) hipFree(g.d_sorted_xy);
   }
   cs->grids.clear();
+  for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
+  cs->dists.clear();
 }
 
 extern "C" int lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capacity, lsm2d_cloudset** out) {
@@ -366,6 +375,7 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
   c.grid = GridDev{nullptr, nullptr, nullptr, nullptr};
+  c.dist = DistDev{nullptr, nullptr};
   return c;
 }
 // NN finder: uniform grid over every cloud of the (fixed) set, cached per max_distance.  Replaces
@@ -403,6 +413,60 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   (void) hipFree(d_base); (void) hipFree(d_gcap);
   cs->grids.push_back(g);
   *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy};
+  return LSM2D_SUCCESS;
+}
+
+// Distance-map finder: CorrespondenceFinderNN2D::reset() (registration/correspondence_finder_nn_2d.cpp:10-52,84-97) for every
+// cloud of the (fixed) set, cached per (max_distance, resolution).
+static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_distance, float resolution, DistDev* out) {
+  for (const auto& d : cs->dists)
+    if (d.max_distance == max_distance && d.resolution == resolution) { *out = DistDev{d.d_meta, d.d_parent}; return LSM2D_SUCCESS; }
+  if (!(resolution > 0.0f) || max_distance < 0.0f) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap: resolution must be > 0 and max_distance >= 0");
+  const int nc = cs->n_clouds;
+  float4* d_bbox = nullptr;
+  HIPCHK(ctx, hipMalloc((void**) &d_bbox, sizeof(float4) * (size_t) nc));
+  hipLaunchKernelGGL(k_cloud_bbox, dim3((unsigned) nc), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy, (const int32_t*) cs->d_start,
+                     (const int32_t*) cs->d_count, d_bbox);
+  HIPCHK(ctx, hipGetLastError());
+  std::vector<float4> bbox((size_t) nc);
+  HIPCHK(ctx, hipMemcpyAsync(bbox.data(), d_bbox, sizeof(float4) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  (void) hipFree(d_bbox);
+  const float inv_res = 1.0f / resolution;
+  const float mds_px = max_distance * max_distance * inv_res * inv_res;
+  const int padding = (int) (sqrtf(mds_px) + 75.5f);
+  const int R = (int) floor(sqrt((double) mds_px));
+  std::vector<DistMeta> meta((size_t) nc);
+  long long total = 0; int max_rows_cols = 0;
+  for (int c = 0; c < nc; ++c) {
+    const float lx = bbox[c].x, ly = bbox[c].y, ux = bbox[c].z, uy = bbox[c].w;
+    const double rows = ceil((double) ((ux - lx) * inv_res + (float) padding)), cols = ceil((double) ((uy - ly) * inv_res + (float) padding));
+    if (!(rows >= 1 && cols >= 1) || rows * cols > 400e6) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "distmap: grid too large");
+    DistMeta& m = meta[c];
+    m.lx = lx; m.ly = ly; m.inv_res = inv_res; m.half_pad = (float) padding * 0.5f; m.rows = (int) rows; m.cols = (int) cols; m.base = total;
+    total += (long long) m.rows * m.cols;
+    if (m.rows * (long long) m.cols > max_rows_cols) max_rows_cols = (int) (m.rows * (long long) m.cols > 0x7fffffff ? 0x7fffffff : m.rows * (long long) m.cols);
+    if (total > (1ll << 33)) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "distmap: more than 8 Gi pixels in one set");
+  }
+  DistCache d; d.max_distance = max_distance; d.resolution = resolution;
+  int32_t* d_cellgoal = nullptr;
+  HIPCHK(ctx, hipMalloc((void**) &d.d_meta, sizeof(DistMeta) * (size_t) nc));
+  HIPCHK(ctx, hipMalloc((void**) &d.d_parent, sizeof(int32_t) * (size_t) total));
+  HIPCHK(ctx, hipMalloc((void**) &d_cellgoal, sizeof(int32_t) * (size_t) total));
+  HIPCHK(ctx, hipMemcpyAsync(d.d_meta, meta.data(), sizeof(DistMeta) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d_cellgoal, 0x7f, sizeof(int32_t) * (size_t) total, ctx->stream));
+  int max_pts = 1; for (int c = 0; c < nc; ++c) if (cs->h_count[c] > max_pts) max_pts = cs->h_count[c];
+  int gb = (max_pts + 255) / 256; if (gb > 1024) gb = 1024;
+  hipLaunchKernelGGL(k_distmap_goals, dim3((unsigned) gb, (unsigned) nc), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                     (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const DistMeta*) d.d_meta, d_cellgoal);
+  int fb = (max_rows_cols + 255) / 256; if (fb > 4096) fb = 4096; if (fb < 1) fb = 1;
+  hipLaunchKernelGGL(k_distmap_fill, dim3((unsigned) fb, (unsigned) nc), dim3(256), 0, ctx->stream, (const DistMeta*) d.d_meta,
+                     (const int32_t*) d_cellgoal, d.d_parent, mds_px, R);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  (void) hipFree(d_cellgoal);
+  cs->dists.push_back(d);
+  *out = DistDev{d.d_meta, d.d_parent};
   return LSM2D_SUCCESS;
 }
 
@@ -561,12 +625,14 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
       (capacity > 0 && !out_pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad argument");
   *out_n = 0;
-  if (sp->finder == LSM2D_FINDER_NN) {
-    if (!(sp->max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: max_distance must be > 0");
+  if (sp->finder == LSM2D_FINDER_NN || sp->finder == LSM2D_FINDER_DISTMAP) {
+    if (sp->finder == LSM2D_FINDER_NN && !(sp->max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: max_distance must be > 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     FindNNArgs N;
     N.fixed = cloud_dev(fixed, nullptr); N.moving = cloud_dev(moving, nullptr); N.fc = fi; N.mc = mi;
-    int rc = ensure_grid(ctx, fixed, sp->max_distance, &N.fixed.grid); if (rc) return rc;
+    N.use_distmap = sp->finder == LSM2D_FINDER_DISTMAP;
+    int rc = N.use_distmap ? ensure_distmap(ctx, fixed, sp->max_distance, sp->resolution, &N.fixed.dist) : ensure_grid(ctx, fixed, sp->max_distance, &N.fixed.grid);
+    if (rc) return rc;
     const size_t nm = (size_t) moving->h_count[mi], bytes = nm * 8 + 16;
     rc = ensure_scratch(ctx, bytes); if (rc) return rc;
     rc = ensure_stage(ctx, bytes); if (rc) return rc;
@@ -692,11 +758,12 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     SliceDev& S = A.s[s];
     const lsm2d_cloudset* f = b->fixed[s]; const lsm2d_cloudset* m = b->moving[s];
     if (!f || !m || f->ctx != ctx || m->ctx != ctx) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: cloud set missing or from another context");
-    if (sp.finder != LSM2D_FINDER_PROJECTIVE && sp.finder != LSM2D_FINDER_NN) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: finder not supported yet");
+    if (sp.finder != LSM2D_FINDER_PROJECTIVE && sp.finder != LSM2D_FINDER_NN && sp.finder != LSM2D_FINDER_DISTMAP)
+      return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: unknown finder");
     if (sp.finder == LSM2D_FINDER_PROJECTIVE) {
       if (!make_projk(sp.projector, &S.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad projector");
     } else {
-      if (!(sp.max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: max_distance must be > 0");
+      if (sp.finder == LSM2D_FINDER_NN && !(sp.max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: max_distance must be > 0");
       memset(&S.proj, 0, sizeof S.proj);
     }
     if (!b->fixed_index && f->n_clouds != 1 && f->n_clouds != n) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: fixed set must hold 1 or n_alignments clouds");
@@ -714,6 +781,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     }
     S.fixed = cloud_dev(f, d_fi); S.moving = cloud_dev(m, d_mi);
     if (sp.finder == LSM2D_FINDER_NN) { const int grc = ensure_grid(ctx, f, sp.max_distance, &S.fixed.grid); if (grc) return grc; }
+    if (sp.finder == LSM2D_FINDER_DISTMAP) { const int grc = ensure_distmap(ctx, f, sp.max_distance, sp.resolution, &S.fixed.dist); if (grc) return grc; }
     S.finder = sp.finder; S.point_distance = sp.point_distance; S.normal_cos = sp.normal_cos; S.max_distance = sp.max_distance;
     S.cauchy = sp.robustifier == LSM2D_ROBUST_CAUCHY; S.tau = sp.chi_threshold; S.min_corr = sp.min_num_correspondences;
     if (S.cauchy && !(S.tau > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: chi_threshold must be > 0");

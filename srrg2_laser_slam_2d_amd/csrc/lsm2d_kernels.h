@@ -34,6 +34,17 @@ struct GridDev {
   const float2*   sorted_xy;   // [padded total] coordinates in the same order
 };
 
+// Distance map over every cloud of a set (CorrespondenceFinderNN2D, registration/correspondence_finder_nn_2d.cpp):
+// parent[r*cols + c] = index of the nearest fixed point's pixel within max_distance, or -1.
+struct DistMeta { float lx, ly, inv_res, half_pad; int32_t rows, cols; long long base; };
+struct DistDev { const DistMeta* meta; const int32_t* parent; };
+
+LSM2D_DEV int distmap_lookup(const DistMeta& d, const int32_t* __restrict__ parent, float qx, float qy) {
+  const float gx = (qx - d.lx) * d.inv_res + d.half_pad, gy = (qy - d.ly) * d.inv_res + d.half_pad;
+  if (!(gx >= 0.0f && gy >= 0.0f && gx < (float) d.rows && gy < (float) d.cols)) return -1;
+  return parent[d.base + (long long) (int) gx * d.cols + (int) gy];
+}
+
 struct CloudDev {            // device view of a cloud set
   const float2* xy;          // [padded total] coordinates
   const float2* nrm;         // [padded total] normals
@@ -42,6 +53,7 @@ struct CloudDev {            // device view of a cloud set
   const int32_t* index;      // [n_alignments] cloud chosen per alignment, or nullptr
   int32_t n_clouds;
   GridDev grid;              // valid only when the slice uses the NN finder on this (fixed) cloud
+  DistDev dist;              // valid only when the slice uses the distance-map finder on this (fixed) cloud
 };
 
 // exact nearest neighbour of q among the cloud's points within sqrt(md2); ties -> lowest index
@@ -80,6 +92,62 @@ LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start
     if (best >= 0 && bd < inside * inside) break;
   }
   return best;
+}
+
+// bounding box per cloud as CorrespondenceFinderNN2D::_adjustSize computes it (correspondence_finder_nn_2d.cpp:28-43):
+// upper bounds start at the smallest positive float (the reference's numeric_limits<float>::min()).
+__global__ __launch_bounds__(256) void k_cloud_bbox(const float2* __restrict__ xy, const int32_t* __restrict__ start,
+                                                    const int32_t* __restrict__ count, float4* __restrict__ out) {
+  const int c = blockIdx.x, tid = threadIdx.x, n = count[c];
+  const float2* p = xy + start[c];
+  __shared__ float s[4][4];
+  float lx = 3.402823466e+38f, ly = lx, ux = 1.175494351e-38f, uy = ux;
+  for (int i = tid; i < n; i += 256) { const float2 v = p[i]; lx = fminf(lx, v.x); ly = fminf(ly, v.y); ux = fmaxf(ux, v.x); uy = fmaxf(uy, v.y); }
+  for (int o = 32; o > 0; o >>= 1) {
+    lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64));
+    ux = fmaxf(ux, __shfl_xor(ux, o, 64)); uy = fmaxf(uy, __shfl_xor(uy, o, 64));
+  }
+  if ((tid & 63) == 0) { s[0][tid >> 6] = lx; s[1][tid >> 6] = ly; s[2][tid >> 6] = ux; s[3][tid >> 6] = uy; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) { lx = fminf(lx, s[0][w]); ly = fminf(ly, s[1][w]); ux = fmaxf(ux, s[2][w]); uy = fmaxf(uy, s[3][w]); }
+    if (n == 0) { lx = 0.0f; ly = 0.0f; }
+    out[c] = make_float4(lx, ly, ux, uy);
+  }
+}
+
+// lowest goal index per pixel (goals sharing a pixel are equidistant from every pixel, so only the lowest can win)
+__global__ void k_distmap_goals(const float2* __restrict__ xy, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
+                                const DistMeta* __restrict__ meta, int32_t* __restrict__ cellgoal) {
+  const int c = blockIdx.y; const DistMeta d = meta[c];
+  const float2* p = xy + start[c];
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < count[c]; f += gridDim.x * blockDim.x) {
+    const float gx = (p[f].x - d.lx) * d.inv_res + d.half_pad, gy = (p[f].y - d.ly) * d.inv_res + d.half_pad;
+    if (!(gx >= 0.0f && gy >= 0.0f && gx < (float) d.rows && gy < (float) d.cols)) continue;
+    atomicMin(&cellgoal[d.base + (long long) (int) gx * d.cols + (int) gy], f);
+  }
+}
+
+// every pixel: nearest goal pixel within mds_px (squared integer pixel distance), ties -> lowest goal index
+__global__ __launch_bounds__(256) void k_distmap_fill(const DistMeta* __restrict__ meta, const int32_t* __restrict__ cellgoal,
+                                                      int32_t* __restrict__ parent, float mds_px, int R) {
+  const int c = blockIdx.y; const DistMeta d = meta[c];
+  const long long npx = (long long) d.rows * d.cols;
+  for (long long k = blockIdx.x * 256ll + threadIdx.x; k < npx; k += (long long) gridDim.x * 256) {
+    const int r = (int) (k / d.cols), cc = (int) (k % d.cols);
+    int best = -1, bd = 0x7fffffff;
+    for (int dr = -R; dr <= R; ++dr) {
+      const int rr = r + dr; if (rr < 0 || rr >= d.rows) continue;
+      for (int dc = -R; dc <= R; ++dc) {
+        const int c2 = cc + dc; if (c2 < 0 || c2 >= d.cols) continue;
+        const int d2 = dr * dr + dc * dc;
+        if ((float) d2 > mds_px) continue;
+        const int g = cellgoal[d.base + (long long) rr * d.cols + c2];
+        if (g != 0x7f7f7f7f && (d2 < bd || (d2 == bd && g < best))) { bd = d2; best = g; }
+      }
+    }
+    parent[d.base + k] = best;
+  }
 }
 
 // One workgroup builds the grid of one cloud: bounding box -> cell size -> counting sort by cell.
@@ -284,15 +352,21 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
         const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
         const float2* fn = S.fixed.nrm + fbase; const float2* mn = S.moving.nrm + mbase;
         const float2* fp = S.fixed.xy + fbase;  const float2* mp = S.moving.xy + mbase;
-        const GridMeta g = S.fixed.grid.meta[fc];
-        const int32_t* cst = S.fixed.grid.cell_start + g.cell_base;
-        const int32_t* sidx = S.fixed.grid.sorted_idx + fbase; const float2* sxy = S.fixed.grid.sorted_xy + fbase;
+        const bool use_grid = S.finder == LSM2D_FINDER_NN;
+        GridMeta g; DistMeta dm;
+        const int32_t* cst = nullptr; const int32_t* sidx = nullptr; const float2* sxy = nullptr;
+        if (use_grid) {
+          g = S.fixed.grid.meta[fc]; cst = S.fixed.grid.cell_start + g.cell_base;
+          sidx = S.fixed.grid.sorted_idx + fbase; sxy = S.fixed.grid.sorted_xy + fbase;
+        } else {
+          dm = S.fixed.dist.meta[fc];       // distance-map finder: one lookup per query (correspondence_finder_nn_2d.cpp:63-80)
+        }
         const float md2 = S.max_distance * S.max_distance;
         const int nm_pts = S.moving.count[mc];
         for (int j = tid; j < nm_pts; j += kAlignBlock) {
           const float2 pm = mp[j];
           float qx, qy; xf_point(T, pm.x, pm.y, qx, qy);
-          const int best = nn_query(g, cst, sidx, sxy, qx, qy, S.max_distance, md2);
+          const int best = use_grid ? nn_query(g, cst, sidx, sxy, qx, qy, S.max_distance, md2) : distmap_lookup(dm, S.fixed.dist.parent, qx, qy);
           if (best >= 0) {
             const float2 nm = mn[j], nf = fn[best];
             float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
@@ -426,7 +500,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_projective(const FindArgs A
 
 // ---- finder-level NN: pairs in ascending moving index (correspondence_finder_kd_tree_2d.cpp:12-27) ------
 struct FindNNArgs {
-  CloudDev fixed, moving; int32_t fc, mc;
+  CloudDev fixed, moving; int32_t fc, mc; int32_t use_distmap;
   float max_distance, normal_cos; Iso T;
   int32_t* out_pairs; int32_t* out_count;
 };
@@ -438,9 +512,13 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
   if (tid == 0) s_base = 0;
   __syncthreads();
   const int fbase = A.fixed.start[A.fc], mbase = A.moving.start[A.mc], n = A.moving.count[A.mc];
-  const GridMeta g = A.fixed.grid.meta[A.fc];
-  const int32_t* cst = A.fixed.grid.cell_start + g.cell_base;
-  const int32_t* sidx = A.fixed.grid.sorted_idx + fbase; const float2* sxy = A.fixed.grid.sorted_xy + fbase;
+  GridMeta g; DistMeta dm;
+  const int32_t* cst = nullptr; const int32_t* sidx = nullptr; const float2* sxy = nullptr;
+  if (A.use_distmap) dm = A.fixed.dist.meta[A.fc];
+  else {
+    g = A.fixed.grid.meta[A.fc]; cst = A.fixed.grid.cell_start + g.cell_base;
+    sidx = A.fixed.grid.sorted_idx + fbase; sxy = A.fixed.grid.sorted_xy + fbase;
+  }
   const float md2 = A.max_distance * A.max_distance;
   for (int j0 = 0; j0 < n; j0 += kFindBlock) {
     const int j = j0 + tid;
@@ -448,7 +526,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
     if (j < n) {
       const float2 pm = A.moving.xy[mbase + j];
       float qx, qy; xf_point(A.T, pm.x, pm.y, qx, qy);
-      best = nn_query(g, cst, sidx, sxy, qx, qy, A.max_distance, md2);
+      best = A.use_distmap ? distmap_lookup(dm, A.fixed.dist.parent, qx, qy) : nn_query(g, cst, sidx, sxy, qx, qy, A.max_distance, md2);
       if (best >= 0) {
         const float2 nm = A.moving.nrm[mbase + j], nf = A.fixed.nrm[fbase + best];
         float nqx, nqy; xf_normal(A.T, nm.x, nm.y, nqx, nqy);

@@ -507,3 +507,34 @@ def test_loop_closure_sweep_acceptance(ctx, po):
                      last[i].n_in / max(last[i].n_corr, 1) >= 0.8 for i in range(12)])
     assert np.array_equal(acc, want)
     assert acc[:8].all() and not acc[8:].any()
+
+
+# ---- distance-map finder (CorrespondenceFinderNN2D, row a5 / f4) ----------------------------------------------
+def test_distmap_finder_bit_exact_and_aligner(ctx, po, small_workload):
+    wl = small_workload
+    scan = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    for md, res in ((1.0, 0.05), (0.3, 0.1)):
+        osp = po.slice_params(finder=po.FINDER_DISTMAP, max_distance=md, resolution=res)
+        for fixed, moving, pose in ((scan, wl.map_points, wl.x0[1]),
+                                    (wl.map_points, scan, synth.invert_poses(wl.x0[1:2].astype(np.float64))[0].astype(np.float32))):
+            f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=md, resolution=res)
+            f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
+            got = f.compute()
+            want = po.find(osp, fixed, moving, pose)
+            assert len(want) > 100 and np.array_equal(got, want)
+    # all-negative coordinates exercise the reference's bounding-box quirk (upper bound initialised to +FLT_MIN)
+    neg = scan.copy(); neg[:, :2] -= np.float32([60, 60])
+    f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=0.5, resolution=0.1)
+    f.setFixed(neg); f.setMoving(neg[::3]); f.setLocalMapInSensor([0.01, 0.0, 0.0])
+    assert np.array_equal(f.compute(), po.find(po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.1), neg, neg[::3], np.float32([0.01, 0, 0])))
+    with pytest.raises(RuntimeError):
+        api.CorrespondenceFinderNN2D(ctx, resolution=0.0).slice_params()
+    # aligner with the distance-map finder (role A), vs oracle
+    al = api.MultiAligner2D(ctx, max_iterations=20, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderNN2D(ctx, 1.0, 0.05), min_num_correspondences=10))
+    al.setFixed({"points": scan}); al.setMoving({"points": wl.map_points}); al.setMovingInFixed(wl.x0[1])
+    assert al.compute() == 0
+    r = po.align(po.aligner_params(20), [po.slice_params(finder=po.FINDER_DISTMAP, max_distance=1.0, resolution=0.05)], [scan], [wl.map_points], wl.x0[1])
+    d = np.abs(al.movingInFixed() - r["pose"])
+    assert r["status"] == 0 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+    assert al.iterationStats()["n_correspondences"][0] == r["stats"][0].n_corr
