@@ -115,9 +115,8 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   hipDeviceProp_t prop;
   HIPCHK(ctx, hipGetDeviceProperties(&prop, device_id));
   c->max_dyn_lds = (int) prop.sharedMemPerBlock;
-  (void) hipFuncSetAttribute((const void*) k_align<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-  (void) hipFuncSetAttribute((const void*) k_align<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
-  (void) hipFuncSetAttribute((const void*) k_align<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -810,11 +809,15 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
 
   HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  bool has_proj = false, has_nn = false;
-  for (int s = 0; s < ns; ++s) { if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE) has_proj = true; else has_nn = true; }
-  if (has_proj && has_nn) hipLaunchKernelGGL((k_align<true, true>), dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
-  else if (has_nn) hipLaunchKernelGGL((k_align<false, true>), dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
-  else hipLaunchKernelGGL((k_align<true, false>), dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
+  bool has_proj = false, has_nn = false, has_dist = false;
+  for (int s = 0; s < ns; ++s) {
+    if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE) has_proj = true; else if (A.s[s].finder == LSM2D_FINDER_NN) has_nn = true; else has_dist = true;
+  }
+  const dim3 grid((unsigned) n), block(kAlignBlock);
+  if (has_proj && !has_nn && !has_dist) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
+  else if (!has_proj && has_nn && !has_dist) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
+  else if (!has_proj && !has_nn && has_dist) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
+  else hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;

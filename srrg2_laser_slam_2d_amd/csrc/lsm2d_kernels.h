@@ -275,7 +275,8 @@ LSM2D_DEV bool match_bin(u64 fk, u64 mk, const SliceDev& S, const Iso& T, const 
 #endif
 // kHasProj / kHasNN: which finders the batch's slices use -- the unused one is compiled out so the
 // projective hot loop does not carry the NN path's register pressure (and vice versa).
-template <bool kHasProj, bool kHasNN>
+// kHasDist: a slice uses the distance-map finder (compiled out otherwise so the NN search keeps its registers).
+template <bool kHasProj, bool kHasNN, bool kHasDist>
 __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64* mcan = reinterpret_cast<u64*>(smem);
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
       const SliceDev& S = A.s[s];
       const Iso T = s_iso[s];
       Accum acc; accum_zero(acc);
-      if (kHasProj && (!kHasNN || S.finder == LSM2D_FINDER_PROJECTIVE)) {
+      if (kHasProj && ((!kHasNN && !kHasDist) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
         for (int i = tid; i < S.proj.cols; i += kAlignBlock) mcan[i] = kEmptyCell;
         __syncthreads();
         {
@@ -345,14 +346,14 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
           if (match_bin(fcs[col], mcan[col], S, T, fn, mn, fi, mi, nf, nm))
             accumulate_pair(T, fp[fi], nf, mp[mi], nm, S.cauchy != 0, S.tau, acc);
         }
-      } else if (kHasNN) {
+      } else if (kHasNN || kHasDist) {
         // NN finder fused with the factor (correspondence_finder_kd_tree_2d.cpp:12-27): every moving point is
         // transformed, matched to its exact nearest fixed point within max_distance, normal-gated, accumulated
         const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
         const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
         const float2* fn = S.fixed.nrm + fbase; const float2* mn = S.moving.nrm + mbase;
         const float2* fp = S.fixed.xy + fbase;  const float2* mp = S.moving.xy + mbase;
-        const bool use_grid = S.finder == LSM2D_FINDER_NN;
+        const bool use_grid = kHasNN && (!kHasDist || S.finder == LSM2D_FINDER_NN);
         GridMeta g; DistMeta dm;
         const int32_t* cst = nullptr; const int32_t* sidx = nullptr; const float2* sxy = nullptr;
         if (use_grid) {
