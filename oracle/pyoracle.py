@@ -80,7 +80,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        override = os.environ.get("LSM2D_ORACLE_LIB")      # e.g. the -fsanitize build from `make -C oracle asan`
+        _lib = C.CDLL(override if override else build())
         _lib.lsmo_atan2f.restype = C.c_float
         _lib.lsmo_atan2f.argtypes = [C.c_float, C.c_float]
     return _lib
