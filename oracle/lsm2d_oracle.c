@@ -36,7 +36,7 @@ float lsmo_atan2f(float y, float x) {
   }
   if (ay > ax) r = LSMO_HALF_PI_F - r;
   if (x < 0.0f) r = LSMO_PI_F - r;
-  return y < 0.0f ? -r : r;
+  return copysignf(r, y);      /* atan2(-0, x<0) = -pi, as libm */
 }
 
 /* ---- fp32 mirror --------------------------------------------------------------------------- */

@@ -42,14 +42,35 @@ LSM2D_DEV void xf_normal(const Iso& T, float nx, float ny, float& ox, float& oy)
   oy = __builtin_fmaf(T.s, nx, T.c * ny);
 }
 
+// IEEE-754 correctly rounded n/d for 0 <= n <= d, d a normal number in [2^-100, 2^100] and n either 0 or
+// >= 2^-100 * d: the reciprocal-refinement sequence hipcc emits for '/', without the v_div_scale / v_div_fixup
+// range handling those inputs never need.  Anything outside that range takes the compiler's full divide.
+LSM2D_DEV float div_rn_unit(float n, float d) {
+  if (__builtin_expect(n != 0.0f && n < 1e-12f, 0)) return n / d;      // quotient could be subnormal: full IEEE path
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e0, r0, r0);
+  const float q0 = n * r1;
+  const float e1 = __builtin_fmaf(-d, q0, n);
+  const float q1 = __builtin_fmaf(e1, r1, q0);
+  const float e2 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(e2, r1, q1);
+}
+
 // atan2 as a fixed polynomial: atan(a) = a + a*s*P(s), s = a*a, a = min/max in [0,1] (IEEE divide),
-// degree-7 P (tools/fit_atan.py: max abs error 7.3e-8 rad on [0,1]), exact octant fix-ups.
-LSM2D_DEV float atan2_poly(float y, float x) {
+// degree-7 P (tools/fit_atan.py: max abs error 7.3e-8 rad on [0,1]), exact octant fix-ups, sign of y copied
+// onto the result (so atan2(-0, x<0) = -pi like libm).  kUnitDiv: the caller guarantees max(|x|,|y|) in
+// [1e-15, 1e18] (the projector's range gate), which lets the divide skip its range handling.
+template <bool kUnitDiv>
+LSM2D_DEV float atan2_poly_t(float y, float x) {
   const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-  const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+  float mx, mn;
+  // |.| folded into the operands (plain fmaxf/fminf would first canonicalise both inputs: 2 extra VALU ops)
+  asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
+  asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
   float r = 0.0f;
-  if (mx > 0.0f) {
-    const float a = mn / mx;
+  if (kUnitDiv || mx > 0.0f) {
+    const float a = kUnitDiv ? div_rn_unit(mn, mx) : mn / mx;
     const float s = a * a;
     float p = 2.622197615e-03f;
     p = __builtin_fmaf(p, s, -1.513234153e-02f);
@@ -63,8 +84,9 @@ LSM2D_DEV float atan2_poly(float y, float x) {
   }
   if (ay > ax) r = 1.57079637050628662f - r;
   if (x < 0.0f) r = 3.14159274101257324f - r;
-  return y < 0.0f ? -r : r;
+  return __builtin_copysignf(r, y);
 }
+LSM2D_DEV float atan2_poly(float y, float x) { return atan2_poly_t<false>(y, x); }
 
 LSM2D_DEV float wrap_angle(float a) {
   while (a > 3.14159274101257324f) a -= 6.28318548202514648f;
@@ -94,7 +116,7 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
   xf_point(T, px, py, qx, qy);
   const float r2 = __builtin_fmaf(qx, qx, qy * qy);
   if (r2 >= P.r2lo && r2 <= P.r2hi) {
-    const float th = atan2_poly(qy, qx);
+    const float th = atan2_poly_t<true>(qy, qx);          // r2 in [1e-30, 1e36] => max(|qx|,|qy|) in [7e-16, 1e18]
     const float u  = __builtin_fmaf(P.K00, th, P.K01);
     const int col = (int) __builtin_floorf(u);            // u is finite here; negative / too large -> rejected below
     if ((unsigned) col < (unsigned) P.cols) {
@@ -111,54 +133,6 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
   }
 }
 
-// atan2_poly for a direction that is known not to be (0,0) (the range gate guarantees r2 > 0): same operation
-// sequence, without the zero test.
-LSM2D_DEV float atan2_poly_nz(float y, float x) {
-  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-  const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
-  const float a = mn / mx;
-  const float s = a * a;
-  float p = 2.622197615e-03f;
-  p = __builtin_fmaf(p, s, -1.513234153e-02f);
-  p = __builtin_fmaf(p, s, 4.112152755e-02f);
-  p = __builtin_fmaf(p, s, -7.366676629e-02f);
-  p = __builtin_fmaf(p, s, 1.057391763e-01f);
-  p = __builtin_fmaf(p, s, -1.418597102e-01f);
-  p = __builtin_fmaf(p, s, 1.999039650e-01f);
-  p = __builtin_fmaf(p, s, -3.333298564e-01f);
-  float r = __builtin_fmaf(a * s, p, a);
-  if (ay > ax) r = 1.57079637050628662f - r;
-  if (x < 0.0f) r = 3.14159274101257324f - r;
-  return y < 0.0f ? -r : r;
-}
-
-// Two points at once, straight-line up to the LDS phase so the two dependency chains (divide, polynomial,
-// LDS read) overlap; lanes whose point fails a gate read cell 0 and are masked out afterwards.
-LSM2D_DEV void project_pair(const Iso& T, const ProjK& P, const float4 v, int idx0, u64* canvas) {
-  float qxa, qya, qxb, qyb;
-  xf_point(T, v.x, v.y, qxa, qya);
-  xf_point(T, v.z, v.w, qxb, qyb);
-  const float r2a = __builtin_fmaf(qxa, qxa, qya * qya), r2b = __builtin_fmaf(qxb, qxb, qyb * qyb);
-  bool oka = r2a >= P.r2lo && r2a <= P.r2hi, okb = r2b >= P.r2lo && r2b <= P.r2hi;
-  if (__builtin_amdgcn_ballot_w64(oka || okb) == 0) return;          // whole wave out of range
-  const float ua = __builtin_fmaf(P.K00, atan2_poly_nz(qya, qxa), P.K01);
-  const float ub = __builtin_fmaf(P.K00, atan2_poly_nz(qyb, qxb), P.K01);
-  const int cola = (int) __builtin_floorf(ua), colb = (int) __builtin_floorf(ub);
-  oka = oka && (unsigned) cola < (unsigned) P.cols;
-  okb = okb && (unsigned) colb < (unsigned) P.cols;
-  u64* cella = canvas + (oka ? cola : 0);
-  u64* cellb = canvas + (okb ? colb : 0);
-  const u64 cura = *cella, curb = *cellb;
-  const float da = __uint_as_float((uint32_t) (cura >> 32)), db = __uint_as_float((uint32_t) (curb >> 32));
-  const bool canda = oka && !(r2a > (da * da) * 1.00000036f);
-  const bool candb = okb && !(r2b > (db * db) * 1.00000036f);
-  if (__builtin_amdgcn_ballot_w64(canda || candb) == 0) return;      // nobody in this wave can still win
-  const u64 keya = ((u64) __float_as_uint(sqrt_rn_normal(r2a)) << 32) | (u64) (uint32_t) idx0;
-  const u64 keyb = ((u64) __float_as_uint(sqrt_rn_normal(r2b)) << 32) | (u64) (uint32_t) (idx0 + 1);
-  if (canda && keya < cura) atomicMin(cella, keya);
-  if (candb && keyb < curb) atomicMin(cellb, keyb);
-}
-
 // Stream one cloud through the z-buffer.  xy is 16-byte aligned (cloud starts are padded to an even
 // point index by the host) so every lane loads two points with one 16-byte global_load_dwordx4; the next
 // load is issued before the current pair is processed.
@@ -173,12 +147,8 @@ LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& Ti
     for (; j < nfull; j += nthreads) {
       const int jn = j + nthreads;
       const float4 nx = xy4[jn < nfull ? jn : j];
-#ifdef LSM2D_PROJECT_PAIR
-      project_pair(T, P, v, 2 * j, canvas);
-#else
-      project_point(T, P, v.x, v.y, 2 * j, canvas);
-      project_point(T, P, v.z, v.w, 2 * j + 1, canvas);
-#endif
+      project_point(T, P, v.x, v.y, 2 * j, canvas);      // (a fused two-point block was measured 50 % slower: the second
+      project_point(T, P, v.z, v.w, 2 * j + 1, canvas);  //  point must see the first one's LDS update -- DESIGN.md section 5)
       v = nx;
     }
   }

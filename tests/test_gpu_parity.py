@@ -538,3 +538,21 @@ def test_distmap_finder_bit_exact_and_aligner(ctx, po, small_workload):
     d = np.abs(al.movingInFixed() - r["pose"])
     assert r["status"] == 0 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
     assert al.iterationStats()["n_correspondences"][0] == r["stats"][0].n_corr
+
+
+def test_projection_arithmetic_exhaustive_random(ctx, po):
+    """Stress the fixed-operation-sequence contract (hand-written divide, polynomial atan2, filtered sqrt): 3 million random
+    points, all magnitudes and octants, 16 384 columns -- any single column or depth mismatch changes a winner."""
+    rng = np.random.default_rng(123)
+    n = 3_000_000
+    r = np.exp(rng.uniform(np.log(0.05), np.log(60.0), n)); a = rng.uniform(-np.pi, np.pi, n)
+    pts = np.stack([r * np.cos(a), r * np.sin(a), np.cos(a), np.sin(a)], 1).astype(np.float32)
+    pts[:1000, 1] = 0.0; pts[1000:2000, 0] = 0.0; pts[2000:2100, :2] = 0.0           # axes and the origin
+    pts[2100:2200, 1] = np.float32(1e-30) * pts[2100:2200, 0]                         # subnormal quotients
+    pts[2200:2300, 1] = -0.0
+    for cols, pose, off in ((16384, [0.0, 0.0, 0.0], 0.0), (16384, [0.3, -0.2, 1.1], 0.0), (4096, [-5.0, 7.0, -2.9], 0.5)):
+        pr = api.PointNormal2fProjectorPolar(cols, -math.pi, math.pi, 0.1, 50.0, off)
+        src, depth, xyn = pr.compute(ctx, pts, np.float32(pose))
+        osrc, odepth, oxyn = po.project(po.Projector(cols, -math.pi, math.pi, 0.1, 50.0, off), pts, np.float32(pose))
+        assert (osrc >= 0).sum() > 0.9 * cols
+        assert np.array_equal(src, osrc) and np.array_equal(depth, odepth)
