@@ -147,8 +147,10 @@ LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& Ti
     for (; j < nfull; j += nthreads) {
       const int jn = j + nthreads;
       const float4 nx = xy4[jn < nfull ? jn : j];
-      project_point(T, P, v.x, v.y, 2 * j, canvas);      // (a fused two-point block was measured 50 % slower: the second
-      project_point(T, P, v.z, v.w, 2 * j + 1, canvas);  //  point must see the first one's LDS update -- DESIGN.md section 5)
+      // two fused-pair variants were measured and dropped: both LDS reads up front 50 % slower
+      // (the second point must see the first one's update), straight-line arithmetic + sequential LDS phases 3 % slower
+      project_point(T, P, v.x, v.y, 2 * j, canvas);
+      project_point(T, P, v.z, v.w, 2 * j + 1, canvas);
       v = nx;
     }
   }

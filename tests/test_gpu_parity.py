@@ -556,3 +556,60 @@ def test_projection_arithmetic_exhaustive_random(ctx, po):
         osrc, odepth, oxyn = po.project(po.Projector(cols, -math.pi, math.pi, 0.1, 50.0, off), pts, np.float32(pose))
         assert (osrc >= 0).sum() > 0.9 * cols
         assert np.array_equal(src, osrc) and np.array_equal(depth, odepth)
+
+
+def test_abi_error_paths_and_limits(ctx, small_workload):
+    """Call-level errors come back as negative codes (never exceptions / crashes across the ABI); limits are enforced."""
+    import ctypes as C
+    from srrg2_laser_slam_2d_amd import _capi
+    lib = ctx._lib
+    wl = small_workload
+    m = api.CloudSet(ctx, wl.map_points); s = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
+    # projector validation
+    for bad in (api.PointNormal2fProjectorPolar(0), api.PointNormal2fProjectorPolar(721, 1.0, -1.0), api.PointNormal2fProjectorPolar(721, -3.14, 3.14, 5.0, 1.0)):
+        with pytest.raises(api.Lsm2dError) as ei:
+            bad.compute(ctx, m)
+        assert ei.value.code == _capi.BAD_ARGUMENT
+    # a canvas that cannot fit the 160 KiB LDS of a CU
+    with pytest.raises(api.Lsm2dError) as ei:
+        api.PointNormal2fProjectorPolar(40000).compute(ctx, m)
+    assert ei.value.code == _capi.CAPACITY_EXCEEDED
+    # the largest canvas that does fit still works (and matches a smaller run on the columns they share a boundary with)
+    src, depth, _ = api.PointNormal2fProjectorPolar(16000, -math.pi, math.pi, 0.3, 30.0).compute(ctx, m, wl.x0[0])
+    assert (src >= 0).sum() > 1000
+    # cloud index out of range, unknown finder, cloud sets of another size than the batch
+    f = api.CorrespondenceFinderProjective2f(ctx, _projector())
+    f.setFixed(s, 99); f.setMoving(m); f.setLocalMapInSensor([0, 0, 0])
+    with pytest.raises(api.Lsm2dError):
+        f.compute()
+    al = _aligner(ctx)
+    with pytest.raises(api.Lsm2dError):
+        al.compute_batch([s], [m], wl.x0[:3])                  # 6 clouds, 3 alignments, no index array
+    with pytest.raises(api.Lsm2dError):
+        al.compute_batch([s], [m], wl.x0, fixed_index=np.full((1, len(wl.x0)), 77, np.int32))
+    sp = api.make_slice_params(finder=7)
+    n = C.c_int32(0); out = np.zeros((10, 2), np.int32)
+    rc = lib.lsm2d_find_correspondences(ctx.handle, C.byref(sp), s.handle, 0, m.handle, 0, np.zeros(3, np.float32).ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p), 10, C.byref(n))
+    assert rc == _capi.BAD_ARGUMENT and b"finder" in lib.lsm2d_last_error(ctx.handle)
+    # output capacity too small: the count is still reported
+    sp = api.make_slice_params(projector=_projector())
+    rc = lib.lsm2d_find_correspondences(ctx.handle, C.byref(sp), s.handle, 0, m.handle, 0, wl.x0[0].ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p), 10, C.byref(n))
+    assert rc == _capi.CAPACITY_EXCEEDED and n.value > 10
+    # null handles
+    assert lib.lsm2d_synchronize(None) == _capi.BAD_ARGUMENT
+    assert lib.lsm2d_cloudset_num_points(None) == 0
+    # empty batch is a no-op
+    r = al.compute_batch([s], [m], np.zeros((0, 3), np.float32))
+    assert len(r.pose) == 0
+    # more than 4 slices is rejected
+    al5 = api.MultiAligner2D(ctx)
+    for _ in range(5):
+        al5.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector())))
+    with pytest.raises(api.Lsm2dError):
+        al5.compute_batch([m] * 5, [m] * 5, np.zeros((1, 3), np.float32))
+    # Cauchy with a non-positive threshold
+    alc = _aligner(ctx, robustifier=api.RobustifierCauchy(0.0))
+    with pytest.raises(api.Lsm2dError):
+        alc.compute_batch([s], [m], wl.x0)
