@@ -113,6 +113,111 @@ class CorrespondenceFinderProjective2f {
   CorrespondenceVector* _correspondences = nullptr;
 };
 
+// CorrespondenceFinderKDTree2D (registration/correspondence_finder_kd_tree_2d.{h,cpp}) and CorrespondenceFinderNN2D
+// (registration/correspondence_finder_nn_2d.{h,cpp}): same surface, different lsm2d_finder.
+class CorrespondenceFinderPointQuery {
+ public:
+  CorrespondenceFinderPointQuery(Context& ctx, int finder) : _ctx(ctx), _finder(finder) {}
+  float param_max_distance_m = 1e-2f;   // kd .h:23 (nn .h:20-24 defaults to 1)
+  float param_resolution = 5e-2f;       // nn .h:25-29
+  float param_normal_cos = 0.8f;
+  void setFixed(const PointNormal2fVectorCloud* fixed) { _fixed.reset(fixed ? new CloudSet(_ctx, *fixed) : nullptr); }
+  void setMoving(const PointNormal2fVectorCloud* moving) { _moving.reset(moving ? new CloudSet(_ctx, *moving) : nullptr); _n_moving = moving ? moving->size() : 0; }
+  void setLocalMapInSensor(const Vector3f& pose) { _local_map_in_sensor = pose; }
+  void setCorrespondences(CorrespondenceVector* c) { _correspondences = c; }
+  lsm2d_slice_params sliceParams() const {
+    lsm2d_slice_params sp{};
+    sp.finder = _finder; sp.projector = PointNormal2fProjectorPolar().abi();
+    sp.max_distance = param_max_distance_m; sp.resolution = param_resolution; sp.normal_cos = param_normal_cos;
+    return sp;
+  }
+  void compute() {
+    if (_finder == LSM2D_FINDER_DISTMAP && !(param_resolution > 0.f)) throw std::runtime_error("resolution must be > 0");      // nn .cpp:11-14
+    if (!_fixed || !_moving || !_correspondences) throw std::runtime_error("CorrespondenceFinder::compute| missing fixed, moving or correspondences");
+    const lsm2d_slice_params sp = sliceParams();
+    _correspondences->resize(_n_moving);                                   // kd .cpp:10, nn .cpp:60
+    int32_t k = 0;
+    check(lsm2d_find_correspondences(_ctx.get(), &sp, _fixed->get(), 0, _moving->get(), 0, _local_map_in_sensor.data(),
+                                     _correspondences->data(), (int32_t) _correspondences->size(), &k),
+          "lsm2d_find_correspondences", _ctx.get());
+    _correspondences->resize((size_t) k);
+  }
+ private:
+  Context& _ctx; int _finder;
+  std::unique_ptr<CloudSet> _fixed, _moving; size_t _n_moving = 0;
+  Vector3f _local_map_in_sensor{{0.f, 0.f, 0.f}};
+  CorrespondenceVector* _correspondences = nullptr;
+};
+struct CorrespondenceFinderKDTree2D : CorrespondenceFinderPointQuery {
+  explicit CorrespondenceFinderKDTree2D(Context& ctx) : CorrespondenceFinderPointQuery(ctx, LSM2D_FINDER_NN) {}
+};
+struct CorrespondenceFinderNN2D : CorrespondenceFinderPointQuery {
+  explicit CorrespondenceFinderNN2D(Context& ctx) : CorrespondenceFinderPointQuery(ctx, LSM2D_FINDER_DISTMAP) { param_max_distance_m = 1.f; }
+};
+
+// a single growable device cloud: the tracker's local map / the clipped scene
+class ReservedCloud {
+ public:
+  ReservedCloud(Context& ctx, int64_t capacity) : _ctx(ctx) { check(lsm2d_cloudset_create_reserved(ctx.get(), capacity, &_h), "lsm2d_cloudset_create_reserved", ctx.get()); }
+  ~ReservedCloud() { lsm2d_cloudset_destroy(_h); }
+  ReservedCloud(const ReservedCloud&) = delete; ReservedCloud& operator=(const ReservedCloud&) = delete;
+  lsm2d_cloudset* get() const { return _h; }
+  void upload(const PointNormal2fVectorCloud& c) { check(lsm2d_cloudset_upload(_h, c.empty() ? nullptr : &c[0].x, (int64_t) c.size()), "lsm2d_cloudset_upload", _ctx.get()); }
+  PointNormal2fVectorCloud download() const {
+    PointNormal2fVectorCloud c((size_t) lsm2d_cloudset_num_points(_h)); int64_t n = 0;
+    check(lsm2d_cloudset_download(_h, 0, c.empty() ? nullptr : &c[0].x, (int64_t) c.size(), &n), "lsm2d_cloudset_download", _ctx.get());
+    c.resize((size_t) n); return c;
+  }
+  int64_t size() const { return lsm2d_cloudset_num_points(_h); }
+ private:
+  Context& _ctx; lsm2d_cloudset* _h = nullptr;
+};
+
+// SceneClipperProjective2D (mapping/scene_clipper_projective_2d.{h,cpp}), voxelize_resolution = 0
+class SceneClipperProjective2D {
+ public:
+  explicit SceneClipperProjective2D(Context& ctx) : _ctx(ctx) {}
+  PointNormal2fProjectorPolarPtr param_projector{new PointNormal2fProjectorPolar};
+  void setFullScene(const ReservedCloud* scene) { _scene = scene; }
+  void setClippedSceneInRobot(ReservedCloud* clipped) { _clipped = clipped; }
+  void setRobotInLocalMap(const Vector3f& p) { _robot_in_local_map = p; }
+  void setSensorInRobot(const Vector3f& p) { _sensor_in_robot = p; }
+  int compute() {
+    if (!_scene || !_clipped) throw std::runtime_error("SceneClipperProjective2D::compute| missing local OR global scene");     // .cpp:12-17
+    if (!param_projector) throw std::runtime_error("SceneClipperProjective2D::compute| Missing Projector");                     // .cpp:19-21
+    const lsm2d_projector pr = param_projector->abi(); int32_t n = 0;
+    check(lsm2d_clip_scene(_ctx.get(), &pr, _scene->get(), 0, _robot_in_local_map.data(), _sensor_in_robot.data(), _clipped->get(), &n, nullptr),
+          "lsm2d_clip_scene", _ctx.get());
+    return n;
+  }
+ private:
+  Context& _ctx; const ReservedCloud* _scene = nullptr; ReservedCloud* _clipped = nullptr;
+  Vector3f _robot_in_local_map{{0.f, 0.f, 0.f}}, _sensor_in_robot{{0.f, 0.f, 0.f}};
+};
+
+// MergerProjective2D (mapping/merger_projective_2d.{h,cpp})
+class MergerProjective2D {
+ public:
+  explicit MergerProjective2D(Context& ctx) : _ctx(ctx) {}
+  float param_merge_threshold = 0.2f;                                      // .h:12-16
+  PointNormal2fProjectorPolarPtr param_projector{new PointNormal2fProjectorPolar};
+  void setScene(ReservedCloud* scene) { _scene = scene; }
+  void setMeasurement(const PointNormal2fVectorCloud* m) { _measurement.reset(m ? new CloudSet(_ctx, *m) : nullptr); }
+  void setMeasurementInScene(const Vector3f& p) { _measurement_in_scene = p; }
+  int compute() {
+    if (!param_projector) throw std::runtime_error("MergerProjective2D::compute| Missing Projector");                            // .cpp:10-12
+    if (!_scene || !_measurement) throw std::runtime_error("MergerProjective2D::compute| missing scene or measurement");
+    const lsm2d_projector pr = param_projector->abi(); int32_t size = 0;
+    check(lsm2d_merge_scene(_ctx.get(), &pr, _scene->get(), _measurement->get(), 0, _measurement_in_scene.data(), param_merge_threshold, &size, counts.data()),
+          "lsm2d_merge_scene", _ctx.get());
+    return size;
+  }
+  std::array<int32_t, 3> counts{{0, 0, 0}};                                // new, merged, replaced
+ private:
+  Context& _ctx; ReservedCloud* _scene = nullptr; std::unique_ptr<CloudSet> _measurement;
+  Vector3f _measurement_in_scene{{0.f, 0.f, 0.f}};
+};
+
 struct RobustifierCauchy { float param_chi_threshold = 0.01f; };     // MULTI.json:153-158
 
 // AlignerSliceProcessorLaser2D[WithSensor] (registration/aligner_slice_processor_laser_2d.h:7-42; MULTI.json:160-188)

@@ -8,6 +8,11 @@
 
 using namespace lsm2d_host;
 
+static Vector3f x_inv(const Vector3f& a) {     // (R,t)^-1 in (x, y, theta) form: the sensor pose in the map for pose = map-in-sensor
+  const float c = cosf(a[2]), s = sinf(a[2]);
+  return Vector3f{{-(c * a[0] + s * a[1]), -(-s * a[0] + c * a[1]), -a[2]}};
+}
+
 static PointNormal2fVectorCloud read_cloud(const char* path) {
   FILE* f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
   fseek(f, 0, SEEK_END); long n = ftell(f) / (long) sizeof(PointNormal2f); fseek(f, 0, SEEK_SET);
@@ -44,7 +49,29 @@ int main(int argc, char** argv) {
     aligner.setFixed(&fixed_props); aligner.setMoving(&moving_props); aligner.setMovingInFixed(pose);
     aligner.compute();
 
-    printf("{\"threw_on_missing_inputs\": %d, \"n_pairs\": %zu, \"pairs\": [", threw, correspondences.size());
+    // the other two finders and the mapping steps, through their reference-named classes
+    CorrespondenceVector nn_pairs, dm_pairs;
+    { CorrespondenceFinderKDTree2D kd(ctx); kd.param_max_distance_m = 0.3f;
+      kd.setFixed(&fixed); kd.setMoving(&moving); kd.setLocalMapInSensor(pose); kd.setCorrespondences(&nn_pairs); kd.compute(); }
+    { CorrespondenceFinderNN2D dm(ctx); dm.param_max_distance_m = 0.5f; dm.param_resolution = 0.1f;
+      dm.setFixed(&fixed); dm.setMoving(&moving); dm.setLocalMapInSensor(pose); dm.setCorrespondences(&dm_pairs); dm.compute(); }
+    ReservedCloud scene(ctx, (int64_t) moving.size() + 4096), clipped(ctx, cols);
+    scene.upload(moving);
+    SceneClipperProjective2D clipper(ctx);
+    clipper.param_projector->param_canvas_cols = cols; clipper.param_projector->param_range_max = 30.f;
+    clipper.param_projector->param_angle_col_min = -(float) M_PI; clipper.param_projector->param_angle_col_max = (float) M_PI;
+    clipper.setFullScene(&scene); clipper.setClippedSceneInRobot(&clipped);
+    Vector3f robot{{-x_inv(pose)[0], -x_inv(pose)[1], -pose[2]}};
+    clipper.setRobotInLocalMap(x_inv(pose));
+    const int n_clipped = clipper.compute();
+    MergerProjective2D merger(ctx);
+    *merger.param_projector = *clipper.param_projector;
+    merger.setScene(&scene); merger.setMeasurement(&fixed); merger.setMeasurementInScene(x_inv(pose));
+    const int merged_size = merger.compute();
+    (void) robot;
+
+    printf("{\"threw_on_missing_inputs\": %d, \"n_nn\": %zu, \"n_distmap\": %zu, \"n_clipped\": %d, \"merged_size\": %d, \"merge_counts\": [%d,%d,%d], \"n_pairs\": %zu, \"pairs\": [",
+           threw, nn_pairs.size(), dm_pairs.size(), n_clipped, merged_size, merger.counts[0], merger.counts[1], merger.counts[2], correspondences.size());
     for (size_t i = 0; i < correspondences.size(); ++i) printf("%s[%d,%d]", i ? "," : "", correspondences[i].fixed_idx, correspondences[i].moving_idx);
     const Vector3f& x = aligner.movingInFixed();
     printf("], \"status\": %d, \"pose\": [%.9g, %.9g, %.9g], \"iterations\": %zu, \"last_n_corr\": %d}\n", aligner.status(), x[0], x[1], x[2],

@@ -290,6 +290,16 @@ def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     o = po.align(po.aligner_params(20), [po.slice_params()], [f], [wl.map_points], x0)
     d = np.abs(np.array(r["pose"]) - o["pose"])
     assert r["status"] == 0 and r["iterations"] == 20 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+    # the other finders and the mapping classes of the C++ mirror give the oracle's counts on the same inputs
+    assert r["n_nn"] == len(po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.3), f, wl.map_points, x0))
+    assert r["n_distmap"] == len(po.find(po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.1), f, wl.map_points, x0))
+    xi = synth.invert_poses(x0[None, :].astype(np.float64))[0]
+    c, s_ = math.cos(float(x0[2])), math.sin(float(x0[2]))
+    sensor_in_map = np.float32([-(np.float32(c) * x0[0] + np.float32(s_) * x0[1]), -(-np.float32(s_) * x0[0] + np.float32(c) * x0[1]), -x0[2]])
+    opr = po.Projector(1081, -math.pi, math.pi, 0.3, 30.0, 0.0)
+    oclip, _ = po.clip_scene(opr, wl.map_points, sensor_in_map)
+    omerge, ocounts = po.merge_scene(opr, wl.map_points, f, sensor_in_map, 0.2)
+    assert abs(r["n_clipped"] - len(oclip)) <= 2 and abs(r["merged_size"] - len(omerge)) <= 2     # host-side inverse differs in the last bit
 
 
 # ---- NN finder (CorrespondenceFinderKDTree2D, row a4) -------------------------------------------------------
