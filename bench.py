@@ -193,11 +193,19 @@ def main() -> None:
                     r = po.align(po.aligner_params(args.iterations), [osp], [map_host], [wl.scan_points[offs[i]:offs[i + 1]]], x0[i])
                     xo[i] = r["pose"]
             cpu_s = time.perf_counter() - t1
+            all_cores = None
+            if args.role == "A" and ns >= 64:       # BASELINE.md section 3, second row: one alignment per host thread
+                nt = max(1, len(os.sched_getaffinity(0)))
+                t2 = time.perf_counter()
+                po.align_batch(po.aligner_params(args.iterations), osp, wl.scan_points[: offs[-1]], offs, map_host, x0[:ns], n_threads=nt)
+                all_cores = {"value": ns / (time.perf_counter() - t2), "cores": nt}
             d = np.abs(res.pose[:ns] - xo)
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "alignments/s", "cores": 1, "kind": "port",
                                    "sample": "first %d alignments of the same batch, CPU restatement of the reference algorithm (oracle/, gcc -O3 -march=native, fp32), %.1f s"
                                              % (ns, cpu_s),
                                    "max_pose_diff_gpu_vs_cpu_m": float(d[:, :2].max()), "max_pose_diff_gpu_vs_cpu_rad": float(d[:, 2].max())}
+            if all_cores:
+                out["cpu_baseline"]["all_cores"] = all_cores
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_dist:
