@@ -138,6 +138,8 @@ int  lsm2d_cloudset_download(const lsm2d_cloudset* set, int32_t cloud_index, flo
 void lsm2d_cloudset_destroy(lsm2d_cloudset* set);
 int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* set);
 int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* set);
+/* points in cloud `cloud_index` (-1 when out of range) */
+int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* set, int32_t cloud_index);
 
 /* ---- a3: PointNormal2fProjectorPolar::compute -------------------------------------------------
  * One polar z-buffer pass of cloud `cloud_index` seen through `pose` (points are mapped by pose,
@@ -146,6 +148,23 @@ int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* set);
 int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* projector, const lsm2d_cloudset* cloud,
                   int32_t cloud_index, const float pose[3], int32_t* out_source_idx, float* out_depth,
                   float* out_transformed_xynn);
+
+/* ---- RawDataPreprocessorProjective2D::compute, batched (sensor_processing/raw_data_preprocessor_projective_2d.cpp:13-51,
+ * :77-104): ranges of n_scans LaserMessages -> one cloud set of n_scans PointNormal2fVectorClouds that never leaves the
+ * device (ready to be the aligner's `fixed`).  Per scan: polar unprojection with the reference's sensor matrix
+ * [[n/(angle_max-angle_min), n/2]], sliding-window normals (NormalComputator1DSlidingWindow: normal_point_distance,
+ * normal_min_points; MULTI.json:845-853), voxelisation at voxelize_resolution (.h:41-45; <= 0 keeps every valid point).
+ * n_beams <= 2048.  The upstream pieces are not in the reference tree: semantics as restated in oracle/lsm2d_oracle.c F2.1-F2.3. */
+typedef struct {
+  int32_t n_beams;
+  float   angle_min, angle_max;    /* LaserMessage angle_min / angle_max [rad] */
+  float   range_min, range_max;    /* max(message, param) / min(message, param), .cpp:83-84 */
+  float   normal_point_distance;
+  int32_t normal_min_points;
+  float   voxelize_resolution;
+} lsm2d_preprocessor;
+int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges /* host [n_scans][n_beams] */,
+                           int32_t n_scans, lsm2d_cloudset** out_set);
 
 /* ---- SceneClipperProjective2D::compute (mapping/scene_clipper_projective_2d.cpp:11-65, voxelize_resolution = 0
  * as in both shipped configs, MULTI.json:673-683): what the sensor at robot_in_local_map * sensor_in_robot sees of

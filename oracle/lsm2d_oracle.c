@@ -97,6 +97,96 @@ void lsmo_error_jacobian_d(const lsmo_point* f, const lsmo_point* m, const doubl
   J[6] = 0; J[7] = 0; J[8] = d[1];
 }
 
+/* ---- RawDataPreprocessorProjective2D (fp32 only: it is the producer of fp32 clouds) --------------------------
+ * Assumptions about the un-vendored upstream pieces (each is what the in-tree call site constrains, nothing more):
+ * F2.1 unprojector: beam c is valid iff range_min <= range <= range_max; its bearing is (c - n/2) * sensor_res with
+ *      sensor_res = (angle_max - angle_min) / n -- the inverse of the sensor matrix [[1/sensor_res, n/2]] the
+ *      reference installs (.cpp:87-90: the centre column, not angle_min, anchors the bearings); point =
+ *      range * (cos, sin); valid points are appended in beam order (back_insert_iterator, .cpp:29-30).
+ * F2.2 sliding-window normals: the window of point i grows from i to both sides over consecutive points while
+ *      |p_j - p_i|^2 <= normal_point_distance^2; fewer than normal_min_points points -> the point is dropped;
+ *      otherwise normal = eigenvector of the smallest eigenvalue of the window scatter matrix (closed form
+ *      below), flipped to face the sensor (n . p <= 0).
+ * F2.3 voxelize(res, res, 1, 1) (.cpp:38-41): key = floor of each of (x/res, y/res, nx, ny); points with the same key
+ *      are averaged (normal re-normalised); voxels come out in ascending lexicographic key order. */
+typedef struct { long long key; int idx; } lsmo_vox;
+static int lsmo_vox_cmp(const void* a, const void* b) {
+  const lsmo_vox* x = (const lsmo_vox*) a; const lsmo_vox* y = (const lsmo_vox*) b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx - y->idx;
+}
+/* voxel key packed in 64 bits: (kx+2^15) | (ky+2^15) | (knx+1) | (kny+1); returns -1 when out of the packable range */
+static long long lsmo_vox_key(float x, float y, float nx, float ny, float inv_res) {
+  const float kx = floorf(x * inv_res), ky = floorf(y * inv_res), knx = floorf(nx), kny = floorf(ny);
+  if (!(kx >= -32768.0f && kx < 32768.0f && ky >= -32768.0f && ky < 32768.0f && knx >= -1.0f && knx <= 1.0f && kny >= -1.0f && kny <= 1.0f)) return -1;
+  return ((long long) ((int) kx + 32768) << 20) | ((long long) ((int) ky + 32768) << 4) | ((long long) ((int) knx + 1) << 2) | (long long) ((int) kny + 1);
+}
+
+int lsmo_preprocess_scan_f(const lsmo_preprocessor* pp, const float* ranges, lsmo_point* out) {
+  const int n = pp->n_beams;
+  if (n <= 0 || !(pp->angle_max > pp->angle_min)) return LSMO_BAD_ARGUMENT;
+  const float sensor_res = (pp->angle_max - pp->angle_min) / (float) n, k01 = (float) n * 0.5f;
+  float* px = (float*) malloc(sizeof(float) * 2 * (size_t) n); float* py = px + n;
+  int m = 0;
+  for (int c = 0; c < n; ++c) {                                   /* F2.1 */
+    const float r = ranges[c];
+    if (!(r >= pp->range_min && r <= pp->range_max)) continue;
+    const float a = ((float) c - k01) * sensor_res;
+    px[m] = r * cosf(a); py[m] = r * sinf(a); ++m;
+  }
+  const float d2max = pp->normal_point_distance * pp->normal_point_distance;
+  int k = 0;                                                      /* F2.2, compacting in place (k <= i) */
+  float* ox = (float*) malloc(sizeof(float) * 4 * (size_t) (n > 0 ? n : 1)); float* oy = ox + n; float* onx = oy + n; float* ony = onx + n;
+  for (int i = 0; i < m; ++i) {
+    int lo = i, hi = i;
+    while (lo > 0) { const float dx = px[lo - 1] - px[i], dy = py[lo - 1] - py[i]; if (!(fmaf(dx, dx, dy * dy) <= d2max)) break; --lo; }
+    while (hi < m - 1) { const float dx = px[hi + 1] - px[i], dy = py[hi + 1] - py[i]; if (!(fmaf(dx, dx, dy * dy) <= d2max)) break; ++hi; }
+    const int cnt = hi - lo + 1;
+    if (cnt < pp->normal_min_points) continue;
+    float sx = 0.0f, sy = 0.0f;
+    for (int j = lo; j <= hi; ++j) { sx += px[j]; sy += py[j]; }
+    const float inv = 1.0f / (float) cnt, mx = sx * inv, my = sy * inv;
+    float sxx = 0.0f, sxy = 0.0f, syy = 0.0f;
+    for (int j = lo; j <= hi; ++j) { const float dx = px[j] - mx, dy = py[j] - my; sxx = fmaf(dx, dx, sxx); sxy = fmaf(dx, dy, sxy); syy = fmaf(dy, dy, syy); }
+    const float tr = sxx + syy, df = sxx - syy;
+    const float disc = sqrtf(fmaf(df, df, 4.0f * (sxy * sxy)));
+    const float lmin = 0.5f * (tr - disc);
+    float v1x = sxy, v1y = lmin - sxx, v2x = lmin - syy, v2y = sxy;
+    const float n1 = fmaf(v1x, v1x, v1y * v1y), n2 = fmaf(v2x, v2x, v2y * v2y);
+    float vx = v1x, vy = v1y, nn = n1;
+    if (n2 > n1) { vx = v2x; vy = v2y; nn = n2; }
+    if (!(nn > 0.0f)) continue;                                   /* isotropic window: no direction */
+    const float s = sqrtf(nn);
+    vx = vx / s; vy = vy / s;
+    if (fmaf(vx, px[i], vy * py[i]) > 0.0f) { vx = -vx; vy = -vy; }
+    ox[k] = px[i]; oy[k] = py[i]; onx[k] = vx; ony[k] = vy; ++k;
+  }
+  int n_out = 0;
+  if (!(pp->voxelize_resolution > 0.0f)) {
+    for (int i = 0; i < k; ++i) { out[i].x = ox[i]; out[i].y = oy[i]; out[i].nx = onx[i]; out[i].ny = ony[i]; }
+    n_out = k;
+  } else {                                                        /* F2.3 */
+    const float inv_res = 1.0f / pp->voxelize_resolution;
+    lsmo_vox* vx = (lsmo_vox*) malloc(sizeof(lsmo_vox) * (size_t) (k > 0 ? k : 1));
+    int nv = 0;
+    for (int i = 0; i < k; ++i) { const long long key = lsmo_vox_key(ox[i], oy[i], onx[i], ony[i], inv_res); if (key >= 0) { vx[nv].key = key; vx[nv].idx = i; ++nv; } }
+    qsort(vx, (size_t) nv, sizeof(lsmo_vox), lsmo_vox_cmp);
+    for (int b = 0; b < nv;) {
+      int e = b; float ax = 0.0f, ay = 0.0f, anx = 0.0f, any_ = 0.0f;
+      while (e < nv && vx[e].key == vx[b].key) { const int i = vx[e].idx; ax += ox[i]; ay += oy[i]; anx += onx[i]; any_ += ony[i]; ++e; }
+      const float inv = 1.0f / (float) (e - b);
+      ax *= inv; ay *= inv; anx *= inv; any_ *= inv;
+      const float nn = sqrtf(fmaf(anx, anx, any_ * any_));
+      if (nn > 0.0f) { anx = anx / nn; any_ = any_ / nn; }
+      out[n_out].x = ax; out[n_out].y = ay; out[n_out].nx = anx; out[n_out].ny = any_; ++n_out;
+      b = e;
+    }
+    free(vx);
+  }
+  free(px); free(ox);
+  return n_out;
+}
+
 /* ---- batch driver (cpu_baseline): static block partition over pthreads ---------------------- */
 typedef struct {
   const lsmo_aligner_params* ap; const lsmo_slice_params* sp;

@@ -140,6 +140,24 @@ int lsmo_align_d(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_p
                  const double x0[3], double x_out[3], double H_out[9],
                  lsmo_iter_stats* stats, int* iterations_done);
 
+/* ---- sensor processing: RawDataPreprocessorProjective2D ----------------------------
+ * sensor_processing/raw_data_preprocessor_projective_2d.cpp:13-51 (compute) and :77-104 (_processLaserMessage).
+ * The three upstream pieces it chains -- PointNormal2fUnprojectorPolar::compute<WithNormals>,
+ * NormalComputator1DSlidingWindow::computeNormals, PointCloud::voxelize -- are NOT in the tree; their restatement
+ * here rests on the assumptions F2.1-F2.3 listed in lsm2d_oracle.c.  Pinned by the one value the reference's own
+ * test holds: the `Synthetic` fixture (tests/fixtures.hpp:8-53) must yield exactly 100 points
+ * (tests/test_measurement_adaptor.cpp:36). */
+typedef struct {
+  int   n_beams;
+  float angle_min, angle_max;          /* LaserMessage angle_min / angle_max */
+  float range_min, range_max;          /* max(msg, param) / min(msg, param), .cpp:83-84 */
+  float normal_point_distance;         /* NormalComputator1DSlidingWindow (MULTI.json:845-853: 0.3) */
+  int   normal_min_points;             /* (5) */
+  float voxelize_resolution;           /* .h:41-45 default 0.02; <= 0: keep every valid point */
+} lsmo_preprocessor;
+/* out: capacity n_beams points; returns the number of points (>= 0) */
+int lsmo_preprocess_scan_f(const lsmo_preprocessor* pp, const float* ranges, lsmo_point* out);
+
 /* ---- mapping: scene clipper and merger around the aligner ------------------------ */
 int lsmo_clip_scene_f(const lsmo_projector* pr, const lsmo_point* scene, int n_scene, const float robot_in_local_map[3],
                       const float sensor_in_robot[3], lsmo_point* out, int* out_src);

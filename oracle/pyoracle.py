@@ -238,3 +238,18 @@ def merge_scene(pr: Projector, scene, meas, measurement_in_scene, merge_threshol
     n = fn(C.cast(C.byref(pr), C.c_void_p), buf.ctypes.data_as(C.c_void_p), len(scene), pm, len(meas), m.ctypes.data_as(C.c_void_p), merge_threshold, counts)
     assert n >= 0, n
     return buf[:n].copy(), tuple(counts)
+
+
+class Preprocessor(C.Structure):
+    _fields_ = [("n_beams", C.c_int), ("angle_min", C.c_float), ("angle_max", C.c_float), ("range_min", C.c_float),
+                ("range_max", C.c_float), ("normal_point_distance", C.c_float), ("normal_min_points", C.c_int),
+                ("voxelize_resolution", C.c_float)]
+
+
+def preprocess_scan(pp: Preprocessor, ranges) -> np.ndarray:
+    """RawDataPreprocessorProjective2D::compute for one LaserMessage. Returns float32 [k, 4]."""
+    r = np.ascontiguousarray(ranges, np.float32); assert len(r) == pp.n_beams
+    out = np.empty((max(pp.n_beams, 1), 4), np.float32)
+    k = lib().lsmo_preprocess_scan_f(C.byref(pp), r.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert k >= 0, k
+    return out[:k].copy()

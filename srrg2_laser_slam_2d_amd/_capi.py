@@ -47,6 +47,12 @@ class IterationStats(C.Structure):
                 ("chi_inliers", C.c_float), ("chi_outliers", C.c_float)]
 
 
+class Preprocessor(C.Structure):
+    _fields_ = [("n_beams", C.c_int32), ("angle_min", C.c_float), ("angle_max", C.c_float), ("range_min", C.c_float),
+                ("range_max", C.c_float), ("normal_point_distance", C.c_float), ("normal_min_points", C.c_int32),
+                ("voxelize_resolution", C.c_float)]
+
+
 class Batch(C.Structure):
     _fields_ = [("n_alignments", C.c_int32), ("n_slices", C.c_int32), ("slices", C.POINTER(SliceParams)),
                 ("fixed", C.POINTER(C.c_void_p)), ("moving", C.POINTER(C.c_void_p)),
@@ -72,7 +78,9 @@ SYMBOLS = [
     ("lsm2d_cloudset_destroy", None, [_P]),
     ("lsm2d_cloudset_num_clouds", C.c_int32, [_P]),
     ("lsm2d_cloudset_num_points", C.c_int64, [_P]),
+    ("lsm2d_cloudset_cloud_size", C.c_int64, [_P, C.c_int32]),
     ("lsm2d_project", C.c_int, [_P, C.POINTER(Projector), _P, C.c_int32, _P, _P, _P, _P]),
+    ("lsm2d_preprocess_scans", C.c_int, [_P, C.POINTER(Preprocessor), _P, C.c_int32, C.POINTER(_P)]),
     ("lsm2d_clip_scene", C.c_int, [_P, C.POINTER(Projector), _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), _P]),
     ("lsm2d_merge_scene", C.c_int, [_P, C.POINTER(Projector), _P, _P, C.c_int32, _P, C.c_float, C.POINTER(C.c_int32), _P]),
     ("lsm2d_find_correspondences", C.c_int,

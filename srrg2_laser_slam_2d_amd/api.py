@@ -566,3 +566,46 @@ class MergerProjective2D:
         self._scene._set_count(size.value)
         self.counts = tuple(counts)
         return size.value
+
+
+class RawDataPreprocessorProjective2D:
+    """sensor_processing/raw_data_preprocessor_projective_2d.{h,cpp}: LaserMessage ranges -> PointNormal2fVectorCloud
+    (polar unprojection, sliding-window normals, voxelisation), batched over scans; the clouds stay on the device."""
+
+    def __init__(self, ctx: Context, range_min: float = 0.0, range_max: float = 1000.0, voxelize_resolution: float = 0.02,
+                 normal_point_distance: float = 0.3, normal_min_points: int = 5):
+        self._ctx = ctx
+        self.param_range_min = range_min                    # .h:39
+        self.param_range_max = range_max                    # .h:40
+        self.param_voxelize_resolution = voxelize_resolution  # .h:41-45
+        self.param_normal_point_distance = normal_point_distance   # NormalComputator1DSlidingWindow (MULTI.json:845-853)
+        self.param_normal_min_points = normal_min_points
+        self._msg = None
+        self._meas: Optional[CloudSet] = None
+
+    def setRawData(self, ranges, angle_min: float, angle_max: float, range_min: float = 0.0, range_max: float = float("inf")) -> bool:
+        """One LaserMessage (ranges [n_beams]) or a batch of them ([n_scans, n_beams]) with the message's own limits."""
+        r = np.ascontiguousarray(ranges, np.float32)
+        if r.ndim == 1:
+            r = r[None, :]
+        if r.ndim != 2 or r.shape[1] < 1:
+            raise RuntimeError("RawDataPreprocessorProjective2D::setMeasurement|measurement is not set")     # .cpp:54-57
+        self._msg = (r, float(angle_min), float(angle_max), float(range_min), float(range_max))
+        return True
+
+    def compute(self) -> CloudSet:
+        if self._msg is None:
+            raise RuntimeError("RawDataPreprocessorProjective2D::compute| no raw data")
+        r, a0, a1, m_rmin, m_rmax = self._msg
+        pp = _capi.Preprocessor(r.shape[1], a0, a1, max(m_rmin, self.param_range_min), min(m_rmax, self.param_range_max),   # .cpp:83-84
+                                self.param_normal_point_distance, self.param_normal_min_points, self.param_voxelize_resolution)
+        h = C.c_void_p()
+        check(self._ctx._lib.lsm2d_preprocess_scans(self._ctx.handle, C.byref(pp), r.ctypes.data_as(C.c_void_p), r.shape[0], C.byref(h)),
+              "lsm2d_preprocess_scans", self._ctx.handle)
+        cs = CloudSet.__new__(CloudSet)
+        cs._ctx, cs._lib, cs._h = self._ctx, self._ctx._lib, h
+        cs.n_clouds = r.shape[0]
+        cs.n_points = int(self._ctx._lib.lsm2d_cloudset_num_points(h))
+        cs.counts = np.array([self._ctx._lib.lsm2d_cloudset_cloud_size(h, i) for i in range(r.shape[0])], np.int64)
+        self._meas = cs
+        return cs

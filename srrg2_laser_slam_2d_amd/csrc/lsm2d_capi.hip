@@ -269,6 +269,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
 }
 extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
 extern "C" int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* cs) { return cs ? cs->total : 0; }
+extern "C" int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* cs, int32_t i) { return (cs && i >= 0 && i < cs->n_clouds) ? cs->h_count[i] : -1; }
 
 static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents changed: cached NN grids are stale
   for (auto& g : cs->grids) {
@@ -498,6 +499,53 @@ static int project_split(lsm2d_context* ctx, const float2* d_xy, int n, const Is
   int blocks = (n + 8191) / 8192; if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(k_project_split, dim3(blocks), dim3(512), sizeof(u64) * (size_t) P.cols, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
+  return LSM2D_SUCCESS;
+}
+
+// ---- RawDataPreprocessorProjective2D, batched -------------------------------------------------------------------
+extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* pp, const float* ranges, int32_t n_scans,
+                                      lsm2d_cloudset** out) {
+  if (!ctx || !pp || !out || n_scans < 1 || !ranges) return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scans: bad argument");
+  *out = nullptr;
+  const int nb = pp->n_beams;
+  if (nb < 1 || nb > kPrepMaxBeams) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "preprocess_scans: n_beams must be in [1, 2048]");
+  if (!(pp->angle_max > pp->angle_min) || pp->normal_min_points < 1 || !(pp->normal_point_distance >= 0.0f))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scans: bad parameters");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int stride = nb + (nb & 1);
+  if ((int64_t) stride * n_scans > 0x7ffffff0) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "preprocess_scans: too many points");
+  lsm2d_cloudset* cs = new (std::nothrow) lsm2d_cloudset;
+  if (!cs) return LSM2D_OUT_OF_MEMORY;
+  cs->ctx = ctx; cs->n_clouds = n_scans; cs->padded_total = (int64_t) stride * n_scans + 2;
+  cs->h_start.resize(n_scans); cs->h_count.assign(n_scans, 0);
+  for (int c = 0; c < n_scans; ++c) cs->h_start[c] = c * stride;
+  int rc = cloudset_alloc(ctx, cs);
+  if (rc != LSM2D_SUCCESS) { lsm2d_cloudset_destroy(cs); return rc; }
+  // beam directions with the host libm (the oracle does the same): angle = (c - n/2) * sensor_res
+  const size_t rbytes = sizeof(float) * (size_t) nb * (size_t) n_scans, dbytes = sizeof(float2) * (size_t) nb;
+  const size_t o_dir = (rbytes + 255) & ~(size_t) 255;
+  rc = ensure_scratch(ctx, o_dir + dbytes); if (rc) { lsm2d_cloudset_destroy(cs); return rc; }
+  rc = ensure_stage(ctx, o_dir + dbytes); if (rc) { lsm2d_cloudset_destroy(cs); return rc; }
+  memcpy(ctx->h_stage, ranges, rbytes);
+  float2* hd = (float2*) ((char*) ctx->h_stage + o_dir);
+  const float sensor_res = (pp->angle_max - pp->angle_min) / (float) nb, k01 = (float) nb * 0.5f;
+  for (int c = 0; c < nb; ++c) { const float a = ((float) c - k01) * sensor_res; hd[c] = make_float2(cosf(a), sinf(a)); }
+  PrepArgs A;
+  A.ranges = (const float*) ctx->d_scratch; A.beam_dir = (const float2*) ((char*) ctx->d_scratch + o_dir);
+  A.n_beams = nb; A.stride = stride; A.rmin = pp->range_min; A.rmax = pp->range_max;
+  A.d2max = pp->normal_point_distance * pp->normal_point_distance; A.min_points = pp->normal_min_points;
+  A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
+  A.out_xy = cs->d_xy; A.out_nrm = cs->d_nrm; A.out_count = cs->d_count;
+  hipError_t e = hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, o_dir + dbytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev0, ctx->stream);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, ctx->stream, A); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(cs->h_count.data(), cs->d_count, sizeof(int32_t) * (size_t) n_scans, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { lsm2d_cloudset_destroy(cs); HIPCHK(ctx, e); }
+  ctx->have_timing = true;
+  cs->total = 0; for (int c = 0; c < n_scans; ++c) cs->total += cs->h_count[c];
+  *out = cs;
   return LSM2D_SUCCESS;
 }
 

@@ -762,6 +762,133 @@ __global__ void k_pack_aos(const float2* __restrict__ xy, const float2* __restri
   }
 }
 
+// ---- RawDataPreprocessorProjective2D (row f2): one workgroup per scan, everything in LDS -----------------------
+static constexpr int kPrepBlock = 256;
+static constexpr int kPrepMaxBeams = 2048;
+struct PrepArgs {
+  const float* ranges; const float2* beam_dir;      // [n_scans][n_beams]; (cos, sin) per beam, host-computed
+  int32_t n_beams, stride;                           // stride: points reserved per output cloud (even)
+  float rmin, rmax, d2max; int32_t min_points; float inv_res;   // inv_res <= 0: no voxelisation
+  float2* out_xy; float2* out_nrm; int32_t* out_count;
+};
+
+__global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs A) {
+  __shared__ float2 s_p[kPrepMaxBeams];      // unprojected points, beam order
+  __shared__ float2 s_q[kPrepMaxBeams];      // points that got a normal
+  __shared__ float2 s_n[kPrepMaxBeams];      // their normals
+  __shared__ u64 s_key[kPrepMaxBeams];       // (voxel key << 16) | index, bitonic-sorted
+  __shared__ int s_wave_tot[kPrepBlock / 64];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, scan = blockIdx.x, nb = A.n_beams;
+  const float* rg = A.ranges + (size_t) scan * nb;
+  float2* oxy = A.out_xy + (size_t) scan * A.stride; float2* onr = A.out_nrm + (size_t) scan * A.stride;
+  // ---- F2.1 unprojection, valid beams compacted in beam order
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < nb; c0 += kPrepBlock) {
+    const int c = c0 + tid;
+    float r = 0.0f; bool ok = false;
+    if (c < nb) { r = rg[c]; ok = r >= A.rmin && r <= A.rmax; }
+    const int pos = block_compact_offset(ok, s_wave_tot, &s_base, tid, kPrepBlock / 64);
+    if (ok) { const float2 d = A.beam_dir[c]; s_p[pos] = make_float2(r * d.x, r * d.y); }
+  }
+  const int m = s_base;
+  __syncthreads();
+  // ---- F2.2 sliding-window normals
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < m; i0 += kPrepBlock) {
+    const int i = i0 + tid;
+    bool ok = false; float vx = 0.0f, vy = 0.0f; float2 pi = make_float2(0.0f, 0.0f);
+    if (i < m) {
+      pi = s_p[i];
+      int lo = i, hi = i;
+      while (lo > 0) { const float dx = s_p[lo - 1].x - pi.x, dy = s_p[lo - 1].y - pi.y; if (!(__builtin_fmaf(dx, dx, dy * dy) <= A.d2max)) break; --lo; }
+      while (hi < m - 1) { const float dx = s_p[hi + 1].x - pi.x, dy = s_p[hi + 1].y - pi.y; if (!(__builtin_fmaf(dx, dx, dy * dy) <= A.d2max)) break; ++hi; }
+      const int cnt = hi - lo + 1;
+      if (cnt >= A.min_points) {
+        float sx = 0.0f, sy = 0.0f;
+        for (int j = lo; j <= hi; ++j) { sx += s_p[j].x; sy += s_p[j].y; }
+        const float inv = 1.0f / (float) cnt, mx = sx * inv, my = sy * inv;
+        float sxx = 0.0f, sxy = 0.0f, syy = 0.0f;
+        for (int j = lo; j <= hi; ++j) {
+          const float dx = s_p[j].x - mx, dy = s_p[j].y - my;
+          sxx = __builtin_fmaf(dx, dx, sxx); sxy = __builtin_fmaf(dx, dy, sxy); syy = __builtin_fmaf(dy, dy, syy);
+        }
+        const float tr = sxx + syy, df = sxx - syy;
+        const float disc = __builtin_sqrtf(__builtin_fmaf(df, df, 4.0f * (sxy * sxy)));
+        const float lmin = 0.5f * (tr - disc);
+        const float v1x = sxy, v1y = lmin - sxx, v2x = lmin - syy, v2y = sxy;
+        const float n1 = __builtin_fmaf(v1x, v1x, v1y * v1y), n2 = __builtin_fmaf(v2x, v2x, v2y * v2y);
+        float nn = n1; vx = v1x; vy = v1y;
+        if (n2 > n1) { vx = v2x; vy = v2y; nn = n2; }
+        if (nn > 0.0f) {
+          const float s = __builtin_sqrtf(nn);
+          vx = vx / s; vy = vy / s;
+          if (__builtin_fmaf(vx, pi.x, vy * pi.y) > 0.0f) { vx = -vx; vy = -vy; }
+          ok = true;
+        }
+      }
+    }
+    const int pos = block_compact_offset(ok, s_wave_tot, &s_base, tid, kPrepBlock / 64);
+    if (ok) { s_q[pos] = pi; s_n[pos] = make_float2(vx, vy); }
+  }
+  const int k = s_base;
+  __syncthreads();
+  if (!(A.inv_res > 0.0f)) {                       // no voxelisation: every valid point, beam order
+    for (int i = tid; i < k; i += kPrepBlock) { oxy[i] = s_q[i]; onr[i] = s_n[i]; }
+    if (tid == 0) A.out_count[scan] = k;
+    return;
+  }
+  // ---- F2.3 voxelisation: sort (key, index), average equal-key runs, ascending key order
+  int np2 = 1; while (np2 < k) np2 <<= 1;
+  for (int i = tid; i < np2; i += kPrepBlock) {
+    u64 key = ~0ull;
+    if (i < k) {
+      const float kx = __builtin_floorf(s_q[i].x * A.inv_res), ky = __builtin_floorf(s_q[i].y * A.inv_res);
+      const float knx = __builtin_floorf(s_n[i].x), kny = __builtin_floorf(s_n[i].y);
+      if (kx >= -32768.0f && kx < 32768.0f && ky >= -32768.0f && ky < 32768.0f && knx >= -1.0f && knx <= 1.0f && kny >= -1.0f && kny <= 1.0f) {
+        const u64 v = ((u64) ((int) kx + 32768) << 20) | ((u64) ((int) ky + 32768) << 4) | ((u64) ((int) knx + 1) << 2) | (u64) ((int) kny + 1);
+        key = (v << 16) | (u64) i;
+      }
+    }
+    s_key[i] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= np2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (np2 >> 1); t += kPrepBlock) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const u64 a = s_key[lo], b = s_key[hi];
+        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < np2; t0 += kPrepBlock) {
+    const int t = t0 + tid;
+    bool head = false; u64 key = ~0ull;
+    if (t < np2) { key = s_key[t]; head = key != ~0ull && (t == 0 || (s_key[t - 1] >> 16) != (key >> 16)); }
+    const int pos = block_compact_offset(head, s_wave_tot, &s_base, tid, kPrepBlock / 64);
+    if (head) {
+      float ax = 0.0f, ay = 0.0f, anx = 0.0f, any_ = 0.0f; int cnt = 0;
+      for (int e = t; e < np2 && (s_key[e] >> 16) == (key >> 16); ++e) {
+        const int i = (int) (s_key[e] & 0xFFFFull);
+        ax += s_q[i].x; ay += s_q[i].y; anx += s_n[i].x; any_ += s_n[i].y; ++cnt;
+      }
+      const float inv = 1.0f / (float) cnt;
+      ax *= inv; ay *= inv; anx *= inv; any_ *= inv;
+      const float nn = __builtin_sqrtf(__builtin_fmaf(anx, anx, any_ * any_));
+      if (nn > 0.0f) { anx = anx / nn; any_ = any_ / nn; }
+      oxy[pos] = make_float2(ax, ay); onr[pos] = make_float2(anx, any_);
+    }
+  }
+  if (tid == 0) A.out_count[scan] = s_base;
+}
+
 // ---- cloud repack: AoS float4 -> xy / normal arrays, cloud c starting at padded index pstart[c] ----
 __global__ void k_repack_cloud(const float4* __restrict__ src, const int32_t* __restrict__ offsets, const int32_t* __restrict__ pstart,
                                int n_clouds, long long total, float2* __restrict__ xy, float2* __restrict__ nrm) {

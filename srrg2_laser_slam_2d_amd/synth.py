@@ -168,6 +168,34 @@ def scan_angles(n_beams: int = 1081, fov_deg: float = 270.0) -> np.ndarray:
     return np.deg2rad(-fov_deg / 2 + np.arange(n_beams) * (fov_deg / (n_beams - 1)))
 
 
+def make_scan_ranges(world: World, poses: np.ndarray, n_beams: int = 1081, angle_min: float = -0.75 * np.pi,
+                     angle_max: float = 0.75 * np.pi, noise_sigma: float = 0.0, seed: int = 0, chunk: int = 64) -> np.ndarray:
+    """Raw LaserMessage-style ranges float32 [n, n_beams] for the preprocessor: beam c looks along
+    (c - n_beams/2) * (angle_max - angle_min) / n_beams (the bearing convention of the reference's sensor matrix,
+    sensor_processing/raw_data_preprocessor_projective_2d.cpp:87-90); no hit -> +inf."""
+    res = (angle_max - angle_min) / n_beams
+    ang = (np.arange(n_beams) - n_beams / 2.0) * res
+    a, d = world.a, world.b - world.a
+    out = np.empty((len(poses), n_beams), np.float32)
+    st = Stream(seed, salt=12)
+    for lo in range(0, len(poses), chunk):
+        P = poses[lo:lo + chunk]
+        th = P[:, 2:3] + ang[None, :]
+        dx, dy = np.cos(th), np.sin(th)
+        ox, oy = P[:, 0, None, None], P[:, 1, None, None]
+        den = dx[..., None] * d[None, None, :, 1] - dy[..., None] * d[None, None, :, 0]
+        ex, ey = a[None, None, :, 0] - ox, a[None, None, :, 1] - oy
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (ex * d[None, None, :, 1] - ey * d[None, None, :, 0]) / den
+            u = (ex * dy[..., None] - ey * dx[..., None]) / den
+        hit = (np.abs(den) > 1e-12) & (t > 0) & (u >= 0) & (u <= 1)
+        r = np.min(np.where(hit, t, np.inf), axis=2)
+        if noise_sigma > 0:
+            r = r + noise_sigma * st.normal(r.size).reshape(r.shape)
+        out[lo:lo + chunk] = r
+    return out
+
+
 def make_scans(world: World, poses: np.ndarray, n_beams: int = 1081, fov_deg: float = 270.0,
                range_min: float = 0.1, range_max: float = 30.0, noise_sigma: float = 0.0, seed: int = 0,
                chunk: int = 64):

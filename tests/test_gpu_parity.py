@@ -623,3 +623,49 @@ def test_abi_error_paths_and_limits(ctx, small_workload):
     alc = _aligner(ctx, robustifier=api.RobustifierCauchy(0.0))
     with pytest.raises(api.Lsm2dError):
         alc.compute_batch([s], [m], wl.x0)
+
+
+# ---- RawDataPreprocessorProjective2D (row f2) --------------------------------------------------------------------
+def test_preprocessor_reference_fixture_on_gpu(ctx):
+    """tests/test_measurement_adaptor.cpp:10-39 on the device path: the Synthetic fixture gives exactly 100 points."""
+    n = int(np.float32(1.0 - (-1.0)) / np.float32(0.02))
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.0, range_max=1000.0, voxelize_resolution=0.01)
+    assert pre.setRawData(np.ones(n, np.float32), angle_min=-1.0, angle_max=1.0, range_min=0.0, range_max=1000.0)
+    meas = pre.compute()
+    assert meas.counts[0] == 100 and len(meas.download(0)) == 100
+
+
+def test_preprocessor_bit_exact_batch_and_feeds_aligner(ctx, po):
+    world = synth.make_world(2)
+    poses = synth.sample_poses(world, 24, seed=4)
+    a0, a1 = -2.34747, 2.35619                                       # laser_0 of MULTI.json:103-132 (asymmetric field of view)
+    ranges = synth.make_scan_ranges(world, poses, n_beams=721, angle_min=a0, angle_max=a1, noise_sigma=0.005, seed=1)
+    ranges[3, 100:140] = np.inf; ranges[5, :] = 0.01                  # a gap; a scan with every beam below range_min
+    for vox, npd in ((0.02, 0.3), (0.0, 0.2), (0.1, 0.3)):
+        pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=20.0, voxelize_resolution=vox, normal_point_distance=npd)
+        pre.setRawData(ranges, a0, a1, 0.0, 30.0)
+        meas = pre.compute()
+        pp = po.Preprocessor(721, a0, a1, 0.3, 20.0, npd, 5, vox)
+        for i in range(len(poses)):
+            want = po.preprocess_scan(pp, ranges[i])
+            assert meas.counts[i] == len(want)
+            assert np.array_equal(meas.download(i), want)
+        assert meas.counts[5] == 0 and meas.counts.max() > 300
+    # ranges in -> pose out, everything on the device: the preprocessed clouds are the aligner's fixed set
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+    clean = synth.make_scan_ranges(world, poses, n_beams=721, angle_min=a0, angle_max=a1)
+    pre.setRawData(clean, a0, a1, 0.0, 30.0)
+    fixed = pre.compute()
+    m = synth.make_map(world, 60000)
+    x_true, x0 = synth.initial_guesses(poses, seed=9)
+    al = api.MultiAligner2D(ctx, max_iterations=20, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(
+        api.CorrespondenceFinderProjective2f(ctx, api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)), min_num_correspondences=10))
+    res = al.compute_batch([fixed], [api.CloudSet(ctx, m)], x0.astype(np.float32))
+    err = np.abs(res.pose - x_true)
+    assert np.all(res.status == 0) and err[:, :2].max() < 3e-2 and err[:, 2].max() < 1e-2      # PCA normals on 2 cm voxels (corners!), not analytic ones
+    # the same clouds through the oracle aligner give the same poses
+    for i in (0, 7, 19):
+        r = po.align(po.aligner_params(20), [po.slice_params(canvas_cols=721, range_max=20.0)], [fixed.download(i)], [m], x0[i].astype(np.float32))
+        d = np.abs(res.pose[i] - r["pose"])
+        assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD

@@ -292,3 +292,28 @@ def test_clipper_and_merger_semantics(po):
     assert np.allclose(new_scene[2], meas[1], atol=1e-6)
     assert np.allclose(new_scene[5], meas[2], atol=1e-6) and np.allclose(new_scene[6], meas[3], atol=1e-6)   # appended in ascending column
     assert np.array_equal(new_scene[[1, 3, 4]], scene[[1, 3, 4]])
+
+
+def test_preprocessor_reference_fixture_and_semantics(po):
+    """Row f2.  The one value the reference's own tests pin on this path: the `Synthetic` fixture (tests/fixtures.hpp:8-53:
+    (1 - -1)/0.02 beams, every range 1 m, range limits [0, 1000], voxelize 0.01) must give exactly 100 points
+    (tests/test_measurement_adaptor.cpp:36)."""
+    n = int(np.float32(1.0 - (-1.0)) / np.float32(0.02))
+    pp = po.Preprocessor(n, -1.0, 1.0, 0.0, 1000.0, 0.3, 5, 0.01)
+    pts = po.preprocess_scan(pp, np.ones(n, np.float32))
+    assert len(pts) == 100
+    assert np.allclose(np.hypot(pts[:, 0], pts[:, 1]), 1.0, atol=1e-6)                  # on the unit circle
+    assert np.all(np.sum(pts[:, :2] * pts[:, 2:], 1) < -0.98)                            # normals face the sensor
+    assert np.allclose(np.hypot(pts[:, 2], pts[:, 3]), 1.0, atol=1e-6)
+    # bearings follow the sensor matrix [[1/res, n/2]]: beam c looks along (c - n/2) * res
+    raw = po.preprocess_scan(po.Preprocessor(n, -1.0, 1.0, 0.0, 1000.0, 0.3, 5, 0.0), np.ones(n, np.float32))
+    ang = np.arctan2(raw[:, 1], raw[:, 0])
+    assert np.allclose(ang, (np.arange(n) - n / 2) * (2.0 / n), atol=1e-6)
+    # range gates, too few neighbours, voxel merging
+    r = np.ones(n, np.float32); r[10] = 2000.0; r[20:23] = -1.0
+    assert len(po.preprocess_scan(po.Preprocessor(n, -1.0, 1.0, 0.0, 1000.0, 0.3, 5, 0.0), r)) == n - 4
+    assert len(po.preprocess_scan(po.Preprocessor(n, -1.0, 1.0, 0.0, 1000.0, 0.01, 5, 0.0), np.ones(n, np.float32))) == 0     # 2 cm spacing, 1 cm window
+    coarse = po.preprocess_scan(po.Preprocessor(n, -1.0, 1.0, 0.0, 1000.0, 0.3, 5, 0.1), np.ones(n, np.float32))
+    assert 15 < len(coarse) < 40
+    key = np.floor(coarse[:, 0] / np.float32(0.1)) * 1e6 + np.floor(coarse[:, 1] / np.float32(0.1))
+    assert np.all(np.diff(key) > 0)                                                      # ascending voxel order, one point per voxel
