@@ -47,6 +47,8 @@ struct lsm2d_cloudset {
   lsm2d_context* ctx = nullptr;
   mutable std::vector<GridCache> grids;
   mutable std::vector<DistCache> dists;
+  // lane-chunked copy of xy for k_align's streaming pass (built on first use, dropped when the contents change)
+  mutable float4* d_lane_xy = nullptr; mutable long long* d_lane_start = nullptr; mutable int32_t* d_lane_T = nullptr;
   int32_t n_clouds = 0;
   int64_t total = 0;          // logical points
   int64_t padded_total = 0;   // device points incl. even-alignment padding
@@ -265,6 +267,9 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
     if (g.d_sorted_xy) (void) hipFree(g.d_sorted_xy);
   }
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
+  if (cs->d_lane_xy) (void) hipFree(cs->d_lane_xy);
+  if (cs->d_lane_start) (void) hipFree(cs->d_lane_start);
+  if (cs->d_lane_T) (void) hipFree(cs->d_lane_T);
   delete cs;
 }
 extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
@@ -280,6 +285,9 @@ static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents 
     if (g.d_sorted_xy) (void) hipFree(g.d_sorted_xy);
   }
   cs->grids.clear();
+  if (cs->d_lane_xy) { (void) hipFree(cs->d_lane_xy); cs->d_lane_xy = nullptr; }
+  if (cs->d_lane_start) { (void) hipFree(cs->d_lane_start); cs->d_lane_start = nullptr; }
+  if (cs->d_lane_T) { (void) hipFree(cs->d_lane_T); cs->d_lane_T = nullptr; }
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   cs->dists.clear();
 }
@@ -374,6 +382,7 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
 }
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
+  c.lane_xy = cs->d_lane_xy; c.lane_start = cs->d_lane_start; c.lane_T = cs->d_lane_T;
   c.grid = GridDev{nullptr, nullptr, nullptr, nullptr};
   c.dist = DistDev{nullptr, nullptr};
   return c;
@@ -413,6 +422,35 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   (void) hipFree(d_base); (void) hipFree(d_gcap);
   cs->grids.push_back(g);
   *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy};
+  return LSM2D_SUCCESS;
+}
+
+// lane-chunked copy of every cloud for k_align's projective streaming pass (project_cloud_lanes in lsm2d_device.h)
+static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
+  if (cs->d_lane_xy) return LSM2D_SUCCESS;
+  const int nc = cs->n_clouds;
+  std::vector<long long> lstart((size_t) nc); std::vector<int32_t> lT((size_t) nc);
+  long long slots = 0; int maxT = 1;
+  for (int c = 0; c < nc; ++c) {
+    const long long npairs = ((long long) cs->h_count[c] + 1) / 2;
+    const int T = (int) ((npairs + kAlignBlock - 1) / kAlignBlock);
+    lstart[c] = slots; lT[c] = T; slots += (long long) T * kAlignBlock; if (T > maxT) maxT = T;
+  }
+  if (slots == 0) slots = 1;
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_xy, sizeof(float4) * (size_t) slots));
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_start, sizeof(long long) * (size_t) nc));
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_T, sizeof(int32_t) * (size_t) nc));
+  HIPCHK(ctx, hipMemcpyAsync(cs->d_lane_start, lstart.data(), sizeof(long long) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(cs->d_lane_T, lT.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  long long per = (long long) maxT * kAlignBlock; int gx = (int) ((per + 255) / 256); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
+  for (int c0 = 0; c0 < nc; c0 += 32768) {         // gridDim.y is limited to 65535
+    const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
+    hipLaunchKernelGGL(k_lane_layout, dim3((unsigned) gx, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const long long*) cs->d_lane_start,
+                       (const int32_t*) cs->d_lane_T, (int) kAlignBlock, cs->d_lane_xy, c0);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));        // the host vectors above back the async copies
   return LSM2D_SUCCESS;
 }
 
@@ -457,11 +495,17 @@ static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float ma
   HIPCHK(ctx, hipMemsetAsync(d_cellgoal, 0x7f, sizeof(int32_t) * (size_t) total, ctx->stream));
   int max_pts = 1; for (int c = 0; c < nc; ++c) if (cs->h_count[c] > max_pts) max_pts = cs->h_count[c];
   int gb = (max_pts + 255) / 256; if (gb > 1024) gb = 1024;
-  hipLaunchKernelGGL(k_distmap_goals, dim3((unsigned) gb, (unsigned) nc), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
-                     (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const DistMeta*) d.d_meta, d_cellgoal);
   int fb = (max_rows_cols + 255) / 256; if (fb > 4096) fb = 4096; if (fb < 1) fb = 1;
-  hipLaunchKernelGGL(k_distmap_fill, dim3((unsigned) fb, (unsigned) nc), dim3(256), 0, ctx->stream, (const DistMeta*) d.d_meta,
-                     (const int32_t*) d_cellgoal, d.d_parent, mds_px, R);
+  for (int c0 = 0; c0 < nc; c0 += 32768) {         // gridDim.y is limited to 65535
+    const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
+    hipLaunchKernelGGL(k_distmap_goals, dim3((unsigned) gb, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const DistMeta*) d.d_meta, d_cellgoal, c0);
+  }
+  for (int c0 = 0; c0 < nc; c0 += 32768) {
+    const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
+    hipLaunchKernelGGL(k_distmap_fill, dim3((unsigned) fb, (unsigned) ny), dim3(256), 0, ctx->stream, (const DistMeta*) d.d_meta,
+                       (const int32_t*) d_cellgoal, d.d_parent, mds_px, R, c0);
+  }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   (void) hipFree(d_cellgoal);
@@ -826,6 +870,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
       for (int i = 0; i < n; ++i) if (src[i] < 0 || src[i] >= m->n_clouds) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: moving_index out of range");
       memcpy(hs + o_midx[s], src, sizeof(int32_t) * (size_t) n); d_mi = (const int32_t*) (ds + o_midx[s]);
     }
+    if (sp.finder == LSM2D_FINDER_PROJECTIVE) { const int lrc = ensure_lane_layout(ctx, m); if (lrc) return lrc; }
     S.fixed = cloud_dev(f, d_fi); S.moving = cloud_dev(m, d_mi);
     if (sp.finder == LSM2D_FINDER_NN) { const int grc = ensure_grid(ctx, f, sp.max_distance, &S.fixed.grid); if (grc) return grc; }
     if (sp.finder == LSM2D_FINDER_DISTMAP) { const int grc = ensure_distmap(ctx, f, sp.max_distance, sp.resolution, &S.fixed.dist); if (grc) return grc; }

@@ -157,6 +157,28 @@ LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& Ti
   if ((n & 1) && tid == 0) { const float2 t = xy[n - 1]; project_point(T, P, t.x, t.y, n - 1, canvas); }
 }
 
+// The same pass over a LANE-CHUNKED copy of the cloud (k_lane_layout): thread g owns the contiguous pairs
+// [g*T, (g+1)*T) and the copy is stored step-major (slot t*nthreads + g), so every load is still one coalesced
+// 16-byte access per lane -- but the 64 lanes of a wave now sit T pairs apart along the map.  Two effects on the
+// LDS z-buffer: lanes of one wave-instruction almost never hit the same cell (the same-address serialisation of
+// ds_min_u64 was ~1/3 of the kernel with neighbouring points in neighbouring lanes), and each lane walks its own
+// stretch of wall, so the plain-read filter sees the lane's previous update and only true improvements reach the
+// atomic.  Padding slots hold +inf and fail the range gate.
+LSM2D_DEV void project_cloud_lanes(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin,
+                                   u64* canvas, int tid, int nthreads) {
+  const Iso T = Tin; const ProjK P = Pin;
+  if (T_steps <= 0) return;
+  const int base = tid * T_steps;
+  float4 v = lane_xy[tid];
+  for (int t = 0; t < T_steps; ++t) {
+    const int tn = t + 1 < T_steps ? t + 1 : t;
+    const float4 nx = lane_xy[(size_t) tn * nthreads + tid];
+    project_point(T, P, v.x, v.y, 2 * (base + t), canvas);
+    project_point(T, P, v.z, v.w, 2 * (base + t) + 1, canvas);
+    v = nx;
+  }
+}
+
 // ---- factor ---------------------------------------------------------------------------------
 struct Accum {      // one lane's partial sums of H (6 unique), b (3), chi and counts
   float h00, h01, h02, h11, h12, h22, b0, b1, b2, chi_in, chi_out;

@@ -52,6 +52,9 @@ struct CloudDev {            // device view of a cloud set
   const int32_t* count;      // [n_clouds] points per cloud
   const int32_t* index;      // [n_alignments] cloud chosen per alignment, or nullptr
   int32_t n_clouds;
+  const float4* lane_xy;     // lane-chunked copy of xy for the k_align streaming pass (see project_cloud_lanes), or nullptr
+  const long long* lane_start; // [n_clouds] first float4 slot of each cloud in lane_xy
+  const int32_t* lane_T;     // [n_clouds] steps per thread
   GridDev grid;              // valid only when the slice uses the NN finder on this (fixed) cloud
   DistDev dist;              // valid only when the slice uses the distance-map finder on this (fixed) cloud
 };
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(256) void k_cloud_bbox(const float2* __restrict__ x
 
 // lowest goal index per pixel (goals sharing a pixel are equidistant from every pixel, so only the lowest can win)
 __global__ void k_distmap_goals(const float2* __restrict__ xy, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
-                                const DistMeta* __restrict__ meta, int32_t* __restrict__ cellgoal) {
-  const int c = blockIdx.y; const DistMeta d = meta[c];
+                                const DistMeta* __restrict__ meta, int32_t* __restrict__ cellgoal, int cloud0) {
+  const int c = cloud0 + blockIdx.y; const DistMeta d = meta[c];
   const float2* p = xy + start[c];
   for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < count[c]; f += gridDim.x * blockDim.x) {
     const float gx = (p[f].x - d.lx) * d.inv_res + d.half_pad, gy = (p[f].y - d.ly) * d.inv_res + d.half_pad;
@@ -130,8 +133,8 @@ __global__ void k_distmap_goals(const float2* __restrict__ xy, const int32_t* __
 
 // every pixel: nearest goal pixel within mds_px (squared integer pixel distance), ties -> lowest goal index
 __global__ __launch_bounds__(256) void k_distmap_fill(const DistMeta* __restrict__ meta, const int32_t* __restrict__ cellgoal,
-                                                      int32_t* __restrict__ parent, float mds_px, int R) {
-  const int c = blockIdx.y; const DistMeta d = meta[c];
+                                                      int32_t* __restrict__ parent, float mds_px, int R, int cloud0) {
+  const int c = cloud0 + blockIdx.y; const DistMeta d = meta[c];
   const long long npx = (long long) d.rows * d.cols;
   for (long long k = blockIdx.x * 256ll + threadIdx.x; k < npx; k += (long long) gridDim.x * 256) {
     const int r = (int) (k / d.cols), cc = (int) (k % d.cols);
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
         {
           // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
           const int mc = pick_cloud(S.moving, a);
-          project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
+          project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
         }
         __syncthreads();
         const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
@@ -887,6 +890,26 @@ __global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs 
     }
   }
   if (tid == 0) A.out_count[scan] = s_base;
+}
+
+// ---- lane-chunked copy of every cloud of a set for k_align's streaming pass (project_cloud_lanes) -------------
+// slot t*nthreads + g of cloud c  <-  pair g*T_c + t of the cloud (two points), +inf where the cloud has ended
+__global__ void k_lane_layout(const float2* __restrict__ xy, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
+                              const long long* __restrict__ lane_start, const int32_t* __restrict__ lane_T, int nthreads,
+                              float4* __restrict__ out, int cloud0) {
+  const int c = cloud0 + blockIdx.y, n = count[c], T = lane_T[c];
+  const float2* p = xy + start[c];
+  float4* o = out + lane_start[c];
+  const long long slots = (long long) T * nthreads;
+  const float inf = __builtin_huge_valf();
+  for (long long m = blockIdx.x * (long long) blockDim.x + threadIdx.x; m < slots; m += (long long) gridDim.x * blockDim.x) {
+    const int t = (int) (m / nthreads), g = (int) (m % nthreads);
+    const long long pair = (long long) g * T + t;
+    float4 v = make_float4(inf, inf, inf, inf);
+    if (2 * pair < n) { const float2 a = p[2 * pair]; v.x = a.x; v.y = a.y; }
+    if (2 * pair + 1 < n) { const float2 b = p[2 * pair + 1]; v.z = b.x; v.w = b.y; }
+    o[m] = v;
+  }
 }
 
 // ---- cloud repack: AoS float4 -> xy / normal arrays, cloud c starting at padded index pstart[c] ----
