@@ -53,7 +53,7 @@ def main() -> None:
     ap.add_argument("--map-points", type=int, default=100000)
     ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--beams", type=int, default=1081)
-    ap.add_argument("--cpu-sample", type=int, default=256, help="alignments timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="alignments timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--role", choices=["A", "B"], default="A", help="A: fixed=scan, moving=map (reference tracker wiring); B: fixed=map, moving=scan")

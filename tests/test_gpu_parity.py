@@ -669,3 +669,42 @@ def test_preprocessor_bit_exact_batch_and_feeds_aligner(ctx, po):
         r = po.align(po.aligner_params(20), [po.slice_params(canvas_cols=721, range_max=20.0)], [fixed.download(i)], [m], x0[i].astype(np.float32))
         d = np.abs(res.pose[i] - r["pose"])
         assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+
+
+def test_maximum_sizes_against_oracle(ctx, po):
+    """BASELINE configs[4] scale in a unit test: a 1M-point local map (oracle: ~0.2 s per alignment), plus the widest
+    scan the preprocessor takes (2048 beams) and a ragged batch with single-point and odd-sized clouds."""
+    world = synth.make_world(0)
+    m = synth.make_map(world, 1_000_000)
+    poses = synth.sample_poses(world, 3, seed=17)
+    scans, offs = synth.make_scans(world, poses)
+    x_true, x0 = synth.initial_guesses(poses, seed=17)
+    al = _aligner(ctx)
+    res = al.compute_batch([api.CloudSet(ctx, scans, offs)], [api.CloudSet(ctx, m)], x0.astype(np.float32), want_stats=True)
+    xo, _, status, last = po.align_batch(po.aligner_params(20), po.slice_params(), scans, offs, m, x0.astype(np.float32), n_threads=3)
+    d = np.abs(res.pose - xo)
+    assert np.array_equal(res.status, status) and d[:, :2].max() < POSE_TOL_M and d[:, 2].max() < POSE_TOL_RAD
+    assert [int(s) for s in res.last_stats()["n_correspondences"]] == [l.n_corr for l in last]
+    assert np.abs(res.pose - x_true)[:, :2].max() < POSE_TOL_M
+    # finder level on the 1M map: bit-exact pairs
+    f = api.CorrespondenceFinderProjective2f(ctx, _projector())
+    f.setFixed(scans[offs[0]:offs[1]]); f.setMoving(m); f.setLocalMapInSensor(x0[0].astype(np.float32))
+    assert np.array_equal(f.compute(), po.find(po.slice_params(), scans[offs[0]:offs[1]], m, x0[0].astype(np.float32)))
+    # widest scan of the preprocessor
+    rng = synth.make_scan_ranges(world, poses, n_beams=2048, angle_min=-math.pi, angle_max=math.pi)
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=30.0, voxelize_resolution=0.02)
+    pre.setRawData(rng, -math.pi, math.pi)
+    meas = pre.compute()
+    pp = po.Preprocessor(2048, -math.pi, math.pi, 0.3, 30.0, 0.3, 5, 0.02)
+    for i in range(3):
+        assert np.array_equal(meas.download(i), po.preprocess_scan(pp, rng[i]))
+    with pytest.raises(api.Lsm2dError):
+        pre.setRawData(np.ones((1, 2049), np.float32), -1.0, 1.0); pre.compute()
+    # ragged set: clouds of 1, 2, 3, 1081 and 0 points (odd sizes exercise the even-aligned starts)
+    c = scans[offs[0]:offs[1]]
+    ragged = np.concatenate([c[:1], c[:2], c[:3], c, c[:0]], 0); roffs = np.array([0, 1, 3, 6, 6 + len(c), 6 + len(c)], np.int32)
+    rs = api.CloudSet(ctx, ragged, roffs)
+    for i, want in enumerate((c[:1], c[:2], c[:3], c, c[:0])):
+        assert np.array_equal(rs.download(i), want)
+    r5 = al.compute_batch([rs], [api.CloudSet(ctx, m)], np.tile(x0[0].astype(np.float32), (5, 1)))
+    assert list(r5.status) == [1, 1, 1, 0, 1] and np.array_equal(r5.pose[3], res.pose[0])

@@ -77,6 +77,8 @@ def main():
     local_map.upload(host_map)
     est_gpu = traj[0].copy(); est_cpu = traj[0].copy()
     t_gpu = t_cpu = 0.0; gpu_kernel_ms = 0.0
+    phase = {"clip": 0.0, "upload_scans": 0.0, "align": 0.0, "merge": 0.0}
+    scan_sets = [api.CloudSet.reserved(ctx, 1024), api.CloudSet.reserved(ctx, 1024)]     # reused every step: no allocation per scan
     max_dp = max_dth = 0.0; err_truth = []
     for k in range(1, args.steps + 1):
         a0, a1 = sc0[of0[k]:of0[k + 1]], sc1[of1[k]:of1[k + 1]]
@@ -88,15 +90,20 @@ def main():
         guess = synth.compose_poses(est_gpu[None, :], odo[None, :])[0].astype(np.float32)
         clipper.setRobotInLocalMap(guess); clipper.setSensorInRobot(S0)
         clipped = clipper.compute()
-        al.setFixed({"points_0": a0, "points_1": a1}); al.setMoving({"points": clipped}); al.setMovingInFixed([0, 0, 0])
+        t1 = time.perf_counter(); phase["clip"] += t1 - t
+        scan_sets[0].upload(a0); scan_sets[1].upload(a1)
+        t2 = time.perf_counter(); phase["upload_scans"] += t2 - t1
+        al.setFixed({"points_0": scan_sets[0], "points_1": scan_sets[1]}); al.setMoving({"points": clipped}); al.setMovingInFixed([0, 0, 0])
         al.setPrior([0, 0, 0], omega)
         status = al.compute(); gpu_kernel_ms += al._result.kernel_ms
         x_gpu = al.movingInFixed().astype(np.float64)
         est_gpu = synth.compose_poses(guess[None, :].astype(np.float64), synth.invert_poses(x_gpu[None, :]))[0]
-        for meas, S in ((a0, S0), (a1, S1)):
-            merger.setMeasurement(meas); merger.setMeasurementInScene(synth.compose_poses(est_gpu[None, :], S[None, :].astype(np.float64))[0])
+        t3 = time.perf_counter(); phase["align"] += t3 - t2
+        for sset, S in ((scan_sets[0], S0), (scan_sets[1], S1)):
+            merger.setMeasurement(sset); merger.setMeasurementInScene(synth.compose_poses(est_gpu[None, :], S[None, :].astype(np.float64))[0])
             merger.compute()
-        t_gpu += time.perf_counter() - t
+        t4 = time.perf_counter(); phase["merge"] += t4 - t3
+        t_gpu += t4 - t
         # ---- CPU oracle: the same calls
         t = time.perf_counter()
         guess_c = synth.compose_poses(est_cpu[None, :], odo[None, :])[0].astype(np.float32)
@@ -112,6 +119,7 @@ def main():
         assert status == r["status"], (k, status, r["status"])
     out = {"mode": "chained" if args.chained else "lockstep (GPU state reset to the CPU state before every step)",
            "config": "configs[2]: synthetic MULTI-parameter replay (721 cols, 10 its, 2 laser slices + odometry prior, clip+merge)",
+           "gpu_phase_ms_per_step": {k: 1e3 * v / args.steps for k, v in phase.items()},
            "steps": args.steps, "gpu_ms_per_step_wall": 1e3 * t_gpu / args.steps, "gpu_align_kernel_ms_per_step": gpu_kernel_ms / args.steps,
            "cpu_oracle_ms_per_step_wall": 1e3 * t_cpu / args.steps, "max_pose_diff_gpu_vs_cpu_m": float(max_dp), "max_pose_diff_gpu_vs_cpu_rad": float(max_dth),
            "final_map_points_gpu": int(local_map.n_points), "final_map_points_cpu": int(len(host_map)),
