@@ -429,6 +429,9 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
 static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
   if (cs->d_lane_xy) return LSM2D_SUCCESS;
   const int nc = cs->n_clouds;
+  bool any_big = false;                       // every cloud <= one pair per thread: the plain layout already is lane-chunked
+  for (int c = 0; c < nc; ++c) if (((long long) cs->h_count[c] + 1) / 2 > kAlignBlock) { any_big = true; break; }
+  if (!any_big) return LSM2D_SUCCESS;
   std::vector<long long> lstart((size_t) nc); std::vector<int32_t> lT((size_t) nc);
   long long slots = 0; int maxT = 1;
   for (int c = 0; c < nc; ++c) {
