@@ -116,6 +116,10 @@ int  lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out_ctx);
 void lsm2d_destroy(lsm2d_context* ctx);
 /* blocks until everything queued on the context's stream has finished */
 int  lsm2d_synchronize(lsm2d_context* ctx);
+/* tuning / test knobs.  "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align),
+ * 2 = always the split path (k_split_project + k_split_finish per iteration; projective slices only).  The two paths
+ * return bit-identical results; the split path is for a handful of alignments against a large cloud. */
+int  lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value);
 /* device time [ms] of the hot-path kernel launches of the most recent call (HIP events on the context's stream) */
 int  lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms);
 

@@ -50,6 +50,10 @@ class Context:
     def synchronize(self):
         check(self._lib.lsm2d_synchronize(self._h), "lsm2d_synchronize", self._h)
 
+    def set_option(self, key: str, value: int):
+        """e.g. ``set_option("align_path", 2)``: 0 automatic, 1 one workgroup per alignment, 2 split over many workgroups."""
+        check(self._lib.lsm2d_set_option(self._h, key.encode(), int(value)), "lsm2d_set_option", self._h)
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         check(self._lib.lsm2d_last_kernel_ms(self._h, C.byref(ms)), "lsm2d_last_kernel_ms", self._h)
@@ -437,8 +441,10 @@ class MultiAligner2D:
         x0 = np.ascontiguousarray(init_poses, np.float32).reshape(-1, 3)
         n = len(x0)
         sp = (SliceParams * ns)(*[s.slice_params() for s in slices])
-        fx = (C.c_void_p * ns)(*[_as_cloudset(ctx, f).handle.value for f in fixed])
-        mv = (C.c_void_p * ns)(*[_as_cloudset(ctx, m).handle.value for m in moving])
+        fixed_sets = [_as_cloudset(ctx, f) for f in fixed]          # keep host-array uploads alive for the duration of the call
+        moving_sets = [_as_cloudset(ctx, m) for m in moving]
+        fx = (C.c_void_p * ns)(*[f.handle.value for f in fixed_sets])
+        mv = (C.c_void_p * ns)(*[m.handle.value for m in moving_sets])
         b = Batch()
         b.n_alignments, b.n_slices = n, ns
         b.slices = sp

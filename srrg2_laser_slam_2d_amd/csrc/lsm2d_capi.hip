@@ -29,7 +29,10 @@ struct lsm2d_context {
   // pinned host staging + device scratch, grown on demand
   void* h_stage = nullptr; size_t h_stage_bytes = 0;
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
+  void* d_split = nullptr; size_t d_split_bytes = 0;      // workspace of the split aligner path
   int max_dyn_lds = 0;
+  int align_path = 0;          // 0 auto, 1 fused, 2 split
+  int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1 or 2)
 };
 
 struct GridCache {     // one search grid per (cloud set, max_distance), built on first use
@@ -122,6 +125,8 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_split_project<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_split_project<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipGetLastError();
   *out = c;
   return LSM2D_SUCCESS;
@@ -133,6 +138,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   (void) hipStreamSynchronize(c->stream);
   if (c->h_stage) (void) hipHostFree(c->h_stage);
   if (c->d_scratch) (void) hipFree(c->d_scratch);
+  if (c->d_split) (void) hipFree(c->d_split);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
   if (c->ev1) (void) hipEventDestroy(c->ev1);
   if (c->owns_stream && c->stream) (void) hipStreamDestroy(c->stream);
@@ -144,6 +150,12 @@ extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return LSM2D_SUCCESS;
+}
+
+extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return LSM2D_BAD_ARGUMENT;
+  if (!strcmp(key, "align_path")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1 or 2"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
+  return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
 
 extern "C" int lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms) {
@@ -904,16 +916,62 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   A.out_stats = out_stats ? (StatsDev*) (ds + o_stats) : nullptr;
 
   HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   bool has_proj = false, has_nn = false, has_dist = false;
+  int max_moving = 0;
   for (int s = 0; s < ns; ++s) {
     if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE) has_proj = true; else if (A.s[s].finder == LSM2D_FINDER_NN) has_nn = true; else has_dist = true;
+    const lsm2d_cloudset* m = b->moving[s];
+    for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] > max_moving) max_moving = m->h_count[c];
   }
-  const dim3 grid((unsigned) n), block(kAlignBlock);
-  if (has_proj && !has_nn && !has_dist) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
-  else if (!has_proj && has_nn && !has_dist) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
-  else if (!has_proj && !has_nn && has_dist) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
-  else hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
+  // few alignments against a big cloud: spread each alignment over many workgroups (projective slices only)
+  const bool split_ok = has_proj && !has_nn && !has_dist && ap->max_iterations > 0 && n <= 32768;
+  // measured (tools/small_batch_bench.py, profiles/r01/small_batch.jsonl): the split path costs ~0.33 ms of launches per
+  // alignment call and wins whenever one workgroup per alignment would leave most of the chip idle for long enough
+  const bool use_split = split_ok && (ctx->align_path == 2 ||
+                                      (ctx->align_path == 0 && n <= 192 && (long long) max_moving * ap->max_iterations >= 400000));
+  ctx->last_align_path = use_split ? 2 : 1;
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (use_split) {
+    // workspace: global canvases + running pose / flags, grown on demand and kept by the context
+    const size_t can_bytes = sizeof(u64) * 2 * (size_t) fcan_total * (size_t) n;
+    const size_t w_pose = (can_bytes + 255) & ~(size_t) 255, w_done = w_pose + (((sizeof(float) * 3 * (size_t) n) + 255) & ~(size_t) 255);
+    const size_t w_H = w_done + (((sizeof(int32_t) * (size_t) n) + 255) & ~(size_t) 255), w_last = w_H + (((sizeof(float) * 9 * (size_t) n) + 255) & ~(size_t) 255);
+    const size_t w_total = w_last + sizeof(StatsDev) * (size_t) n;
+    if (w_total > ctx->d_split_bytes) {
+      if (ctx->d_split) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_split)); ctx->d_split = nullptr; ctx->d_split_bytes = 0; }
+      HIPCHK(ctx, hipMalloc(&ctx->d_split, w_total + w_total / 2));
+      ctx->d_split_bytes = w_total + w_total / 2;
+    }
+    char* w = (char*) ctx->d_split;
+    SplitArgs SA; SA.A = A;
+    SA.gcan = (u64*) w; SA.pose = (float*) (w + w_pose); SA.done = (int32_t*) (w + w_done); SA.H_last = (float*) (w + w_H); SA.last = (StatsDev*) (w + w_last);
+    HIPCHK(ctx, hipMemsetAsync(SA.gcan, 0xFF, can_bytes, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(SA.done, 0, sizeof(int32_t) * (size_t) n, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(SA.pose, A.init_pose, sizeof(float) * 3 * (size_t) n, hipMemcpyDeviceToDevice, ctx->stream));
+    int max_fixed = 0;
+    for (int s = 0; s < ns; ++s) { const lsm2d_cloudset* f = b->fixed[s]; for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > max_fixed) max_fixed = f->h_count[c]; }
+    auto chunks_for = [&](int max_points) {
+      int c = (max_points / 2 + 2047) / 2048;                 // >= 4 pairs per thread and chunk
+      const int budget = 2048 / (n * ns) > 1 ? 2048 / (n * ns) : 1;
+      if (c > budget) c = budget;
+      return c < 1 ? 1 : c;
+    };
+    const size_t clds = sizeof(u64) * (size_t) cols_max;
+    SA.it = 0;
+    hipLaunchKernelGGL((k_split_project<true>), dim3((unsigned) chunks_for(max_fixed), (unsigned) n, (unsigned) ns), dim3(512), clds, ctx->stream, SA);
+    const int mchunks = chunks_for(max_moving);
+    for (int it = 0; it < ap->max_iterations; ++it) {
+      SA.it = it;
+      hipLaunchKernelGGL((k_split_project<false>), dim3((unsigned) mchunks, (unsigned) n, (unsigned) ns), dim3(512), clds, ctx->stream, SA);
+      hipLaunchKernelGGL(k_split_finish, dim3((unsigned) n), dim3(kAlignBlock), 0, ctx->stream, SA);
+    }
+  } else {
+    const dim3 grid((unsigned) n), block(kAlignBlock);
+    if (has_proj && !has_nn && !has_dist) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
+    else if (!has_proj && has_nn && !has_dist) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
+    else if (!has_proj && !has_nn && has_dist) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
+    else hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
+  }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;

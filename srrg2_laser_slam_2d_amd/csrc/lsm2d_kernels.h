@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   float* red = reinterpret_cast<float*>(fcan + A.fcan_total);     // [nwaves][kAccumWords]
   __shared__ float s_pose[3];
   __shared__ Iso   s_iso[kMaxSlices];
-  __shared__ float s_H[9], s_b[3];
+  __shared__ float s_H[9], s_Hs[9], s_b[3];      // s_H: information matrix (H of the last solved iteration); s_Hs: this iteration's sum
   __shared__ int   s_n_in, s_n_out, s_n_corr, s_active, s_done, s_status;
   __shared__ float s_chi_in, s_chi_out;
 
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
         if (A.s[s].has_sensor) compose(A.s[s].cSinv, A.s[s].sSinv, A.s[s].Sinv, s_pose, Xe);
         s_iso[s].c = cosf(Xe[2]); s_iso[s].s = sinf(Xe[2]); s_iso[s].tx = Xe[0]; s_iso[s].ty = Xe[1];
       }
-      for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
+      for (int k = 0; k < 9; ++k) s_Hs[k] = 0.0f;
       s_b[0] = s_b[1] = s_b[2] = 0.0f;
       s_n_in = s_n_out = s_n_corr = s_active = 0; s_chi_in = s_chi_out = 0.0f;
     }
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
         s_n_corr += t.n_corr;
         if (t.n_corr > S.min_corr) {   // slices with #pairs <= min_num_correspondences are skipped
           ++s_active;
-          s_H[0] += t.h00; s_H[1] += t.h01; s_H[2] += t.h02; s_H[3] += t.h01; s_H[4] += t.h11; s_H[5] += t.h12;
-          s_H[6] += t.h02; s_H[7] += t.h12; s_H[8] += t.h22;
+          s_Hs[0] += t.h00; s_Hs[1] += t.h01; s_Hs[2] += t.h02; s_Hs[3] += t.h01; s_Hs[4] += t.h11; s_Hs[5] += t.h12;
+          s_Hs[6] += t.h02; s_Hs[7] += t.h12; s_Hs[8] += t.h22;
           s_b[0] += t.b0; s_b[1] += t.b1; s_b[2] += t.b2;
           s_n_in += t.n_in; s_n_out += t.n_out; s_chi_in += t.chi_in; s_chi_out += t.chi_out;
         }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
       else {
         float H[9], b[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) H[k] = s_H[k];
+        for (int k = 0; k < 9; ++k) H[k] = s_Hs[k];
         b[0] = s_b[0]; b[1] = s_b[1]; b[2] = s_b[2];
         if (A.prior) {
           // SE2 prior: e = t2v(Z^-1 X), J = blkdiag(R_e, 1) for the right perturbation
@@ -456,6 +456,170 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
     A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
     if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = s_H[k];
     if (A.out_its) A.out_its[a] = it;
+  }
+}
+
+// ---- split path: the same alignment spread over many workgroups -------------------------------------------------
+// For a handful of alignments against a big cloud one workgroup per alignment leaves the chip empty, so each iteration
+// becomes two launches: k_split_project z-buffers slices of the cloud in LDS and folds them into a global canvas
+// (atomicMin u64 is order independent), k_split_finish does the bin walk, the reduction (same thread <-> column mapping,
+// same order as k_align, hence bit-identical sums), the 3x3 solve and the pose update.  Projective slices only.
+struct SplitArgs {
+  AlignArgs A;
+  u64* gcan;             // [n_align][2 * fcan_total]: fixed canvases then moving canvases, pre-filled with kEmptyCell
+  float* pose;           // [n_align][3] current estimate
+  int32_t* done;         // [n_align] 0 = running
+  float* H_last;         // [n_align][9]
+  StatsDev* last;        // [n_align]
+  int32_t it;            // iteration this launch belongs to
+};
+
+LSM2D_DEV Iso slice_iso(const SliceDev& S, const float pose[3]) {
+  float Xe[3] = {pose[0], pose[1], pose[2]};
+  if (S.has_sensor) compose(S.cSinv, S.sSinv, S.Sinv, pose, Xe);
+  Iso T; T.c = cosf(Xe[2]); T.s = sinf(Xe[2]); T.tx = Xe[0]; T.ty = Xe[1];
+  return T;
+}
+
+template <bool kFixed>
+__global__ __launch_bounds__(512) void k_split_project(const SplitArgs S) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64* can = reinterpret_cast<u64*>(smem);
+  __shared__ Iso s_T;
+  const int a = blockIdx.y, sl = blockIdx.z, tid = threadIdx.x;
+  if (S.done[a]) return;
+  const SliceDev& SL = S.A.s[sl];
+  const CloudDev& C = kFixed ? SL.fixed : SL.moving;
+  const int ci = pick_cloud(C, a), n = C.count[ci];
+  const int npairs = (n + 1) >> 1;
+  const int per = (npairs + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = lo + per < npairs ? lo + per : npairs;
+  if (lo >= hi) return;
+  if (tid == 0) {
+    if (kFixed) { s_T.c = 1.0f; s_T.s = 0.0f; s_T.tx = 0.0f; s_T.ty = 0.0f; }
+    else { const float p[3] = {S.pose[3 * a], S.pose[3 * a + 1], S.pose[3 * a + 2]}; s_T = slice_iso(SL, p); }
+  }
+  const ProjK P = SL.proj;
+  for (int i = tid; i < P.cols; i += 512) can[i] = kEmptyCell;
+  __syncthreads();
+  const Iso T = s_T;
+  const float4* xy4 = reinterpret_cast<const float4*>(C.xy + C.start[ci]);
+  for (int j = lo + tid; j < hi; j += 512) {
+    const float4 v = xy4[j];
+    project_point(T, P, v.x, v.y, 2 * j, can);
+    if (2 * j + 1 < n) project_point(T, P, v.z, v.w, 2 * j + 1, can);
+  }
+  __syncthreads();
+  u64* g = S.gcan + (size_t) a * 2 * S.A.fcan_total + (kFixed ? 0 : S.A.fcan_total) + SL.fcan_offset;
+  for (int i = tid; i < P.cols; i += 512) { const u64 k = can[i]; if (k != kEmptyCell) atomicMin(&g[i], k); }
+}
+
+__global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S) {
+  const AlignArgs& A = S.A;
+  __shared__ float red[(kAlignBlock / 64) * kAccumWords];
+  __shared__ Iso s_iso[kMaxSlices];
+  __shared__ float s_H[9], s_b[3], s_chi_in, s_chi_out;
+  __shared__ int s_n_in, s_n_out, s_n_corr, s_active;
+  const int a = blockIdx.x, tid = threadIdx.x;
+  constexpr int nwaves = kAlignBlock / 64;
+  if (S.done[a]) return;
+  float pose[3] = {S.pose[3 * a], S.pose[3 * a + 1], S.pose[3 * a + 2]};
+  if (tid == 0) {
+    for (int s = 0; s < A.n_slices; ++s) s_iso[s] = slice_iso(A.s[s], pose);
+    for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
+    s_b[0] = s_b[1] = s_b[2] = 0.0f;
+    s_n_in = s_n_out = s_n_corr = s_active = 0; s_chi_in = s_chi_out = 0.0f;
+  }
+  __syncthreads();
+  u64* gF = S.gcan + (size_t) a * 2 * A.fcan_total; u64* gM = gF + A.fcan_total;
+  for (int s = 0; s < A.n_slices; ++s) {
+    const SliceDev& SL = A.s[s];
+    const Iso T = s_iso[s];
+    const int fc = pick_cloud(SL.fixed, a), mc = pick_cloud(SL.moving, a);
+    const int mbase = SL.moving.start[mc], fbase = SL.fixed.start[fc];
+    const float2* fn = SL.fixed.nrm + fbase; const float2* mn = SL.moving.nrm + mbase;
+    const float2* fp = SL.fixed.xy + fbase;  const float2* mp = SL.moving.xy + mbase;
+    Accum acc; accum_zero(acc);
+    for (int col = tid; col < SL.proj.cols; col += kAlignBlock) {
+      const u64 mk = gM[SL.fcan_offset + col];
+      gM[SL.fcan_offset + col] = kEmptyCell;                  // ready for the next iteration's projection
+      int fi, mi; float2 nf, nm;
+      if (match_bin(gF[SL.fcan_offset + col], mk, SL, T, fn, mn, fi, mi, nf, nm))
+        accumulate_pair(T, fp[fi], nf, mp[mi], nm, SL.cauchy != 0, SL.tau, acc);
+    }
+    block_reduce_store(acc, red, tid);
+    __syncthreads();
+    if (tid == 0) {
+      Accum t; block_reduce_gather(red, nwaves, t);
+      s_n_corr += t.n_corr;
+      if (t.n_corr > SL.min_corr) {
+        ++s_active;
+        s_H[0] += t.h00; s_H[1] += t.h01; s_H[2] += t.h02; s_H[3] += t.h01; s_H[4] += t.h11; s_H[5] += t.h12;
+        s_H[6] += t.h02; s_H[7] += t.h12; s_H[8] += t.h22;
+        s_b[0] += t.b0; s_b[1] += t.b1; s_b[2] += t.b2;
+        s_n_in += t.n_in; s_n_out += t.n_out; s_chi_in += t.chi_in; s_chi_out += t.chi_out;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    StatsDev last; last.n_corr = s_n_corr; last.n_in = s_n_in; last.n_out = s_n_out; last.chi_in = s_chi_in; last.chi_out = s_chi_out;
+    if (A.out_stats) A.out_stats[(size_t) a * A.max_it + S.it] = last;
+    int status = LSM2D_RUNNING;
+    float H[9];
+    for (int k = 0; k < 9; ++k) H[k] = S.it == 0 ? 0.0f : S.H_last[9 * a + k];
+    if (!s_active) status = LSM2D_NOT_ENOUGH_CORRESPONDENCES;
+    else {
+      float b[3] = {s_b[0], s_b[1], s_b[2]};
+#pragma unroll
+      for (int k = 0; k < 9; ++k) H[k] = s_H[k];
+      if (A.prior) {
+        const PriorDev& Pz = A.prior[a];
+        float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, pose, E);
+        const float c = cosf(E[2]), s_ = sinf(E[2]);
+        const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
+        float OJ[9], Oe[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          Oe[r] = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Oe[r] += Pz.omega[3 * r + k] * E[k];
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            OJ[3 * r + cc] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) OJ[3 * r + cc] += Pz.omega[3 * r + k] * Jp[3 * k + cc];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            float v = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * OJ[3 * k + cc];
+            H[3 * r + cc] += v;
+          }
+          float v = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * Oe[k];
+          b[r] += v;
+        }
+      }
+      if (!solve_update(H, b, A.damping, pose)) status = LSM2D_SINGULAR_H;
+      else { S.pose[3 * a] = pose[0]; S.pose[3 * a + 1] = pose[1]; S.pose[3 * a + 2] = pose[2]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S.H_last[9 * a + k] = H[k];
+    const bool last_it = S.it == A.max_it - 1;
+    if (status == LSM2D_RUNNING && last_it) status = last.n_in < A.min_inliers ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
+    if (status != LSM2D_RUNNING) {
+      S.done[a] = 1;
+      A.out_status[a] = status;
+      A.out_pose[3 * a] = pose[0]; A.out_pose[3 * a + 1] = pose[1]; A.out_pose[3 * a + 2] = pose[2];
+      if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = H[k];
+      if (A.out_its) A.out_its[a] = S.it + 1;
+    }
   }
 }
 

@@ -708,3 +708,52 @@ def test_maximum_sizes_against_oracle(ctx, po):
         assert np.array_equal(rs.download(i), want)
     r5 = al.compute_batch([rs], [api.CloudSet(ctx, m)], np.tile(x0[0].astype(np.float32), (5, 1)))
     assert list(r5.status) == [1, 1, 1, 0, 1] and np.array_equal(r5.pose[3], res.pose[0])
+
+
+def test_split_path_is_bit_identical_to_fused_path(ctx, po):
+    """The many-workgroups-per-alignment path (k_split_project + k_split_finish) against the one-workgroup path (k_align):
+    same z-buffer winners (u64 min is order independent), same reduction order -> bitwise equal poses, H, statistics."""
+    wl = synth.make_workload(5, 200000, seed=21)
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    x0 = wl.x0.copy(); x0[3] += np.float32([70, 70, 0])                     # one hopeless candidate: NotEnoughCorrespondences
+    def run(path, al, *args, **kw):
+        ctx.set_option("align_path", path)
+        try:
+            return al.compute_batch(*args, **kw)
+        finally:
+            ctx.set_option("align_path", 0)
+    al = _aligner(ctx)
+    a = run(1, al, [fixed], [moving], x0, want_stats=True); b = run(2, al, [fixed], [moving], x0, want_stats=True)
+    for k in ("pose", "information", "status", "iterations"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    for i in range(5):
+        assert np.array_equal(a.stats[i][: a.iterations[i]], b.stats[i][: b.iterations[i]])
+    assert a.status[3] == 1 and a.iterations[3] == 1 and np.all(a.status[[0, 1, 2, 4]] == 0)
+    # automatic choice: a single alignment against a big map takes the split path and matches the oracle
+    c = al.compute_batch([api.CloudSet(ctx, wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]])], [moving], x0[:1])
+    assert np.array_equal(c.pose[0], a.pose[0])
+    r = po.align(po.aligner_params(20), [po.slice_params()], [wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]], [wl.map_points], x0[0])
+    d = np.abs(c.pose[0] - r["pose"]); assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+    # NotEnoughInliers and SingularH through the split path
+    al2 = _aligner(ctx); al2.param_min_num_inliers = 100000
+    assert np.all(run(2, al2, [fixed], [moving], wl.x0).status == 2)
+    wall = np.stack([np.linspace(-3, 3, 400), np.full(400, 2.0), np.zeros(400), -np.ones(400)], 1).astype(np.float32)
+    al3 = _aligner(ctx, 360); al3.param_slice_processors[0].param_min_num_correspondences = 0
+    assert run(2, al3, [wall], [wall], np.zeros((1, 3), np.float32)).status[0] == 3
+    # multi-slice with extrinsics, Cauchy and prior
+    world = synth.make_world(5); m = synth.make_map(world, 80000)
+    robot = synth.sample_poses(world, 2, seed=11)
+    S0, S1 = np.array([0.2, 0.1, 0.1]), np.array([-0.3, 0.0, math.pi])
+    sc = [synth.make_scans(world, synth.compose_poses(robot, np.tile(S, (2, 1))), n_beams=721) for S in (S0, S1)]
+    xg = synth.invert_poses(synth.compose_poses(robot, np.tile([[0.04, -0.03, 0.03]], (2, 1)))).astype(np.float32)
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    alm = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
+    alm.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.9), sensor_in_robot=S0,
+                                                                                 robustifier=api.RobustifierCauchy(0.01), min_num_correspondences=5))
+    alm.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.8), sensor_in_robot=S1,
+                                                                                 min_num_correspondences=5))
+    fx = [api.CloudSet(ctx, p, o) for p, o in sc]; mv = [api.CloudSet(ctx, m)] * 2
+    pri = [(xg[i], np.eye(3, dtype=np.float32) * 20.0) for i in range(2)]
+    f1 = run(1, alm, fx, mv, xg, priors=pri, want_stats=True); f2 = run(2, alm, fx, mv, xg, priors=pri, want_stats=True)
+    assert np.array_equal(f1.pose, f2.pose) and np.array_equal(f1.information, f2.information) and np.array_equal(f1.stats, f2.stats)
+    assert np.all(f1.status == 0)
