@@ -743,6 +743,7 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
     rc = ensure_scratch(ctx, bytes); if (rc) return rc;
     rc = ensure_stage(ctx, bytes); if (rc) return rc;
     N.max_distance = sp->max_distance; N.normal_cos = sp->normal_cos; N.T = make_iso(pose);
+    N.nn_group = fixed->h_count[fi] >= 4 * (int64_t) moving->h_count[mi] ? kNNGroup : 1;     // dense fixed cloud: cooperative search
     N.out_count = (int32_t*) ctx->d_scratch; N.out_pairs = (int32_t*) ((char*) ctx->d_scratch + 16);
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_find_nn, dim3(1), dim3(kFindBlock), 0, ctx->stream, N);
@@ -889,6 +890,12 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     S.fixed = cloud_dev(f, d_fi); S.moving = cloud_dev(m, d_mi);
     if (sp.finder == LSM2D_FINDER_NN) { const int grc = ensure_grid(ctx, f, sp.max_distance, &S.fixed.grid); if (grc) return grc; }
     if (sp.finder == LSM2D_FINDER_DISTMAP) { const int grc = ensure_distmap(ctx, f, sp.max_distance, sp.resolution, &S.fixed.dist); if (grc) return grc; }
+    {   // cooperative NN search pays when the fixed cloud is much denser than the queries (map as fixed, scans as queries)
+      int64_t mf = 0, mm = 1;
+      for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > mf) mf = f->h_count[c];
+      for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] > mm) mm = m->h_count[c];
+      S.nn_group = mf >= 4 * mm ? kNNGroup : 1;
+    }
     S.finder = sp.finder; S.point_distance = sp.point_distance; S.normal_cos = sp.normal_cos; S.max_distance = sp.max_distance;
     S.cauchy = sp.robustifier == LSM2D_ROBUST_CAUCHY; S.tau = sp.chi_threshold; S.min_corr = sp.min_num_correspondences;
     if (S.cauchy && !(S.tau > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: chi_threshold must be > 0");

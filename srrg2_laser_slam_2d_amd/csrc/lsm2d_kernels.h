@@ -14,6 +14,8 @@
 #pragma once
 #include "lsm2d_device.h"
 
+#include <type_traits>
+
 namespace lsm2d {
 
 static constexpr int kMaxSlices = 4;
@@ -64,8 +66,16 @@ struct CloudDev {            // device view of a cloud set
 // (2k+1)^2 block around q for k = 1, 2, 4, ... and stops as soon as the best distance is strictly inside the
 // block (every point outside it is farther than k*h, so it can neither win nor tie) or the block covers
 // max_distance.  Converged ICP queries finish in the first 3x3 block.
+static constexpr int kNNGroup = 8;      // lanes that cooperate on one query: they read 8 consecutive candidates = one 64-byte line
+
+template <int group>
 LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start, const int32_t* __restrict__ sidx,
-                       const float2* __restrict__ sxy, float qx, float qy, float md, float md2) {
+                       const float2* __restrict__ sxy, float qx, float qy, float md, float md2, int sub) {
+  // group == kNNGroup: every lane of a group of kNNGroup consecutive lanes calls this with the SAME query and its own
+  // `sub` in [0, kNNGroup) (dense fixed clouds: a scan point has ~100 map points in its 3x3 block); group == 1: one lane per
+  // query (sparse fixed clouds, where most queries find an empty block).  Candidates are strided over the group (coalesced loads instead of 64 private streams per wave),
+  // the group's (d2, index) minimum is combined with three xor-shuffles per block level, so control flow is uniform
+  // inside a group and every lane returns the same answer.
   const float fx = __builtin_floorf((qx - g.minx) * g.inv_h), fy = __builtin_floorf((qy - g.miny) * g.inv_h);
   const float reach = __builtin_ceilf(md * g.inv_h * 1.002f);                 // cells max_distance can span (0.2 % fp slack)
   if (!(fx >= -reach && fx <= (float) g.gw + reach && fy >= -reach && fy <= (float) g.gh + reach)) return -1;
@@ -78,7 +88,7 @@ LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start
     if (x0 <= x1) {
       for (int yy = y0; yy <= y1; ++yy) {
         const int s = cell_start[yy * g.gw + x0], e = cell_start[yy * g.gw + x1 + 1];
-        for (int t = s; t < e; ++t) {
+        for (int t = s + sub; t < e; t += group) {
           const float2 p = sxy[t];
           const float dx = p.x - qx, dy = p.y - qy;
           const float d2 = __builtin_fmaf(dx, dx, dy * dy);
@@ -88,6 +98,12 @@ LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start
           }
         }
       }
+    }
+    if (group > 1)
+#pragma unroll
+    for (int o = 1; o < kNNGroup; o <<= 1) {                     // lexicographic (d2, index) minimum over the group
+      const float od = __shfl_xor(bd, o, 64); const int oi = __shfl_xor(best, o, 64);
+      if (oi >= 0 && (best < 0 || od < bd || (od == bd && oi < best))) { bd = od; best = oi; }
     }
     if (k >= kmax) break;
     // q sits in cell (cx,cy): anything outside the block is at least k*h away (0.998: fp slack of the cell assignment)
@@ -234,6 +250,7 @@ struct SliceDev {
   int32_t finder;
   ProjK   proj;
   float   point_distance, normal_cos, max_distance;
+  int32_t nn_group;          // lanes per NN query: kNNGroup (dense fixed cloud) or 1
   int32_t cauchy;
   float   tau;
   int32_t min_corr;
@@ -369,17 +386,29 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
         }
         const float md2 = S.max_distance * S.max_distance;
         const int nm_pts = S.moving.count[mc];
-        for (int j = tid; j < nm_pts; j += kAlignBlock) {
-          const float2 pm = mp[j];
-          float qx, qy; xf_point(T, pm.x, pm.y, qx, qy);
-          const int best = use_grid ? nn_query(g, cst, sidx, sxy, qx, qy, S.max_distance, md2) : distmap_lookup(dm, S.fixed.dist.parent, qx, qy);
-          if (best >= 0) {
-            const float2 nm = mn[j], nf = fn[best];
-            float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
-            const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
-            if (!(dot < S.normal_cos)) accumulate_pair(T, fp[best], nf, pm, nm, S.cauchy != 0, S.tau, acc);
+        // the grid search is cooperative on dense fixed clouds (kNNGroup lanes per query); the distance map is one lookup
+        auto query_loop = [&](auto group_tag) {
+          constexpr int group = decltype(group_tag)::value;
+          const int sub = tid & (group - 1);
+          constexpr int per_step = kAlignBlock / group;
+          for (int j0 = 0; j0 < nm_pts; j0 += per_step) {
+            const int j = j0 + tid / group;
+            const bool live = j < nm_pts;                    // whole groups are live or not: the shuffles inside stay uniform
+            const float2 pm = live ? mp[j] : make_float2(0.0f, 0.0f);
+            float qx, qy; xf_point(T, pm.x, pm.y, qx, qy);
+            int best = -1;
+            if (use_grid) { if (live) best = nn_query<group>(g, cst, sidx, sxy, qx, qy, S.max_distance, md2, sub); }
+            else if (live) best = distmap_lookup(dm, S.fixed.dist.parent, qx, qy);
+            if (best >= 0 && sub == 0) {                     // one lane per query accumulates
+              const float2 nm = mn[j], nf = fn[best];
+              float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+              const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
+              if (!(dot < S.normal_cos)) accumulate_pair(T, fp[best], nf, pm, nm, S.cauchy != 0, S.tau, acc);
+            }
           }
-        }
+        };
+        if (use_grid && S.nn_group == kNNGroup) query_loop(std::integral_constant<int, kNNGroup>{});
+        else query_loop(std::integral_constant<int, 1>{});
       }
       block_reduce_store(acc, red, tid);
       __syncthreads();
@@ -671,7 +700,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_projective(const FindArgs A
 // ---- finder-level NN: pairs in ascending moving index (correspondence_finder_kd_tree_2d.cpp:12-27) ------
 struct FindNNArgs {
   CloudDev fixed, moving; int32_t fc, mc; int32_t use_distmap;
-  float max_distance, normal_cos; Iso T;
+  float max_distance, normal_cos; Iso T; int32_t nn_group;
   int32_t* out_pairs; int32_t* out_count;
 };
 
@@ -690,19 +719,26 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
     sidx = A.fixed.grid.sorted_idx + fbase; sxy = A.fixed.grid.sorted_xy + fbase;
   }
   const float md2 = A.max_distance * A.max_distance;
-  for (int j0 = 0; j0 < n; j0 += kFindBlock) {
-    const int j = j0 + tid;
+  const int group = A.use_distmap ? 1 : A.nn_group, sub = tid & (group - 1);
+  const int per_step = kFindBlock / group;
+  auto query = [&](float qx, float qy) {
+    return group == kNNGroup ? nn_query<kNNGroup>(g, cst, sidx, sxy, qx, qy, A.max_distance, md2, sub)
+                             : nn_query<1>(g, cst, sidx, sxy, qx, qy, A.max_distance, md2, sub);
+  };
+  for (int j0 = 0; j0 < n; j0 += per_step) {
+    const int j = j0 + tid / group;
     int best = -1; bool ok = false;
     if (j < n) {
       const float2 pm = A.moving.xy[mbase + j];
       float qx, qy; xf_point(A.T, pm.x, pm.y, qx, qy);
-      best = A.use_distmap ? distmap_lookup(dm, A.fixed.dist.parent, qx, qy) : nn_query(g, cst, sidx, sxy, qx, qy, A.max_distance, md2);
-      if (best >= 0) {
+      best = A.use_distmap ? distmap_lookup(dm, A.fixed.dist.parent, qx, qy) : query(qx, qy);
+      if (best >= 0 && sub == 0) {
         const float2 nm = A.moving.nrm[mbase + j], nf = A.fixed.nrm[fbase + best];
         float nqx, nqy; xf_normal(A.T, nm.x, nm.y, nqx, nqy);
         ok = !(__builtin_fmaf(nqx, nf.x, nqy * nf.y) < A.normal_cos);
       }
     }
+    // lanes are in ascending query order (tid / group), so the ballot compaction keeps ascending moving index
     const u64 bal = __ballot(ok);
     const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) s_wave_tot[wave] = __popcll(bal);
