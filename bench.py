@@ -175,6 +175,8 @@ def main() -> None:
             "parity_ok": ok, "max_pose_err_m": float(err[:, :2].max()), "max_pose_err_rad": float(err[:, 2].max()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_align", "kernel_ms": k_ms,
+                         "note": "achieved = SURVEY.md 8(d) algorithmic bytes / launch time; the map (<= 8 MB of xy) is L2 / Infinity-Cache "
+                                 "resident, so achieved can exceed the HBM peak: the measured limiter is VALU issue (DESIGN.md section 5)",
                          "algorithmic_bytes_per_launch": bytes_per_alignment * args.scans},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -317,3 +317,21 @@ def test_preprocessor_reference_fixture_and_semantics(po):
     assert 15 < len(coarse) < 40
     key = np.floor(coarse[:, 0] / np.float32(0.1)) * 1e6 + np.floor(coarse[:, 1] / np.float32(0.1))
     assert np.all(np.diff(key) > 0)                                                      # ascending voxel order, one point per voxel
+
+
+def test_oracle_regression_vectors(po):
+    """tests/golden/oracle_regression.json freezes the restated algorithm on small seeded inputs (oracle-generated, NOT
+    reference outputs).  Counts may move by a pair or two across libm versions (cosf/sinf of the pose), poses may not."""
+    g = json.load(open(golden_path("oracle_regression.json")))
+    wl = synth.make_workload(3, 8000, seed=42, n_beams=361)
+    sps = {"projective": po.slice_params(canvas_cols=361), "nn": po.slice_params(finder=po.FINDER_NN, max_distance=0.3),
+           "distmap": po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.1)}
+    for c in g["cases"]:
+        i = c["index"]; scan = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+        for name, sp in sps.items():
+            want = c[name]
+            pairs = po.find(sp, scan, wl.map_points, wl.x0[i])
+            assert abs(len(pairs) - want["n_pairs"]) <= 2
+            r = po.align(po.aligner_params(10), [sp], [scan], [wl.map_points], wl.x0[i].astype(np.float64), double=True)
+            assert r["status"] == want["status"] and np.allclose(r["pose"], want["pose_after_10_its_fp64"], atol=1e-6)
+            assert abs(r["stats"][0].n_corr - want["n_corr_first"]) <= 2 and abs(r["stats"][0].chi_in - want["chi_first"]) <= 1e-3 * max(want["chi_first"], 1.0)
