@@ -757,3 +757,70 @@ def test_split_path_is_bit_identical_to_fused_path(ctx, po):
     f1 = run(1, alm, fx, mv, xg, priors=pri, want_stats=True); f2 = run(2, alm, fx, mv, xg, priors=pri, want_stats=True)
     assert np.array_equal(f1.pose, f2.pose) and np.array_equal(f1.information, f2.information) and np.array_equal(f1.stats, f2.stats)
     assert np.all(f1.status == 0)
+
+
+def test_randomised_parameters_finder_and_aligner(ctx, po):
+    """Fuzz the bit-exact contract over the parameter space the ABI accepts: asymmetric fields of view, odd canvas sizes,
+    column rounding, tight and wide gates, all three finders, Cauchy on/off, sensor extrinsics -- finder pairs must equal
+    the oracle's exactly, aligner poses within the north_star tolerance whenever the oracle succeeds."""
+    rng = np.random.default_rng(2024)
+    world = synth.make_world(9)
+    maps = {n: synth.make_map(world, n, noise_sigma=0.003, seed=n) for n in (3000, 20000)}
+    poses = synth.sample_poses(world, 12, seed=3)
+    checked_pairs = checked_poses = 0
+    for trial in range(36):
+        n_map = (3000, 20000)[trial % 2]
+        m = maps[n_map]
+        beams = int(rng.integers(90, 1200))
+        scan, _ = synth.make_scans(world, poses[trial % 12:trial % 12 + 1], n_beams=beams, fov_deg=float(rng.uniform(90, 300)))
+        x_true, x0 = synth.initial_guesses(poses[trial % 12:trial % 12 + 1], seed=trial, scale=float(rng.uniform(0.0, 0.08)))
+        x0 = x0[0].astype(np.float32)
+        finder = trial % 3
+        a0 = float(rng.uniform(-math.pi, -0.5)); a1 = float(rng.uniform(0.5, math.pi))
+        cols = int(rng.integers(64, 2000)); off = float(rng.choice([0.0, 0.5]))
+        rmin = float(rng.uniform(0.0, 1.0)); rmax = float(rng.uniform(5.0, 40.0))
+        pd = float(rng.uniform(0.05, 1.5)); nc = float(rng.uniform(0.3, 0.95)); md = float(rng.uniform(0.02, 0.8)); res = float(rng.uniform(0.03, 0.2))
+        cauchy = bool(trial % 4 == 1); tau = float(rng.uniform(0.005, 0.1)); mc = int(rng.integers(0, 30))
+        S = (0.0, 0.0, 0.0) if trial % 5 else (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-1, 1)))
+        proj = api.PointNormal2fProjectorPolar(cols, a0, a1, rmin, rmax, off)
+        if finder == 0:
+            f = api.CorrespondenceFinderProjective2f(ctx, proj, pd, nc)
+            osp = po.slice_params(canvas_cols=cols, angle_min=a0, angle_max=a1, range_min=rmin, range_max=rmax, col_offset=off, point_distance=pd, normal_cos=nc)
+        elif finder == 1:
+            f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=md, normal_cos=nc)
+            osp = po.slice_params(finder=po.FINDER_NN, max_distance=md, normal_cos=nc)
+        else:
+            f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=md, resolution=res, normal_cos=nc)
+            osp = po.slice_params(finder=po.FINDER_DISTMAP, max_distance=md, resolution=res, normal_cos=nc)
+        f.setFixed(scan); f.setMoving(m); f.setLocalMapInSensor(x0)
+        got = f.compute(); want = po.find(osp, scan, m, x0)
+        assert np.array_equal(got, want), (trial, finder, len(got), len(want))
+        checked_pairs += len(want)
+        # aligner with the same finder
+        osp.robustifier = po.ROBUST_CAUCHY if cauchy else po.ROBUST_NONE; osp.chi_threshold = tau; osp.min_num_correspondences = mc
+        osp.sensor_in_robot = (po.C.c_float * 3)(*S)
+        if any(S):
+            slicep = api.AlignerSliceProcessorLaser2DWithSensor(f, sensor_in_robot=S, robustifier=api.RobustifierCauchy(tau) if cauchy else None, min_num_correspondences=mc)
+        else:
+            slicep = api.AlignerSliceProcessorLaser2D(f, robustifier=api.RobustifierCauchy(tau) if cauchy else None, min_num_correspondences=mc)
+        its = int(rng.integers(1, 15))
+        al = api.MultiAligner2D(ctx, max_iterations=its, min_num_inliers=int(rng.integers(0, 50)))
+        al.param_slice_processors.append(slicep)
+        res_g = al.compute_batch([scan], [m], x0[None, :], want_stats=True)
+        r = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers), [osp], [scan], [m], x0)
+        rd = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers), [osp], [scan], [m], x0.astype(np.float64), double=True)
+        assert res_g.stats[0]["n_correspondences"][0] == r["stats"][0].n_corr          # first iteration: same pose, same pairs -- always
+        # degenerate geometry (one wall in view: H singular to rounding) has no well-defined outcome -- the fp32 and fp64 oracles
+        # themselves part ways there -- so status and pose are compared on well-posed trials only
+        ev = np.linalg.eigvalsh(rd["H"]) if np.all(np.isfinite(rd["H"])) else np.zeros(3)
+        well_posed = r["status"] == rd["status"] and r["iterations"] == rd["iterations"] and ev[0] > 1e-5 * max(ev[2], 1e-30)
+        if not well_posed:
+            continue
+        assert res_g.status[0] == r["status"], (trial, res_g.status[0], r["status"])
+        assert res_g.iterations[0] == r["iterations"]
+        d = np.abs(res_g.pose[0] - r["pose"]); d[2] = abs((d[2] + math.pi) % (2 * math.pi) - math.pi)
+        if r["status"] == 0:
+            # ICP on a few hundred noisy pairs amplifies fp32 summation-order noise; the bar stays the north_star tolerance
+            assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD, (trial, finder, d)
+            checked_poses += 1
+    assert checked_pairs > 5000 and checked_poses >= 12
