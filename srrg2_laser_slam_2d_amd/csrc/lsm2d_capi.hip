@@ -73,6 +73,13 @@ struct lsm2d_cloudset {
     }                                                                                               \
   } while (0)
 
+// scope guard for device temporaries: every early return (HIPCHK) releases them
+struct DevTmp {
+  void* p = nullptr;
+  ~DevTmp() { if (p) (void) hipFree(p); }
+  void* release() { void* q = p; p = nullptr; return q; }
+};
+
 static int fail(lsm2d_context* ctx, int code, const char* msg) {
   g_last_error = msg;
   if (ctx) ctx->last_error = msg;
@@ -414,14 +421,17 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
     if (cells > 0x7fffffff) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "grid: too many cells");
   }
   GridCache g; g.max_distance = max_distance;
-  int32_t* d_base = nullptr; int32_t* d_gcap = nullptr;
-  HIPCHK(ctx, hipMalloc((void**) &g.d_meta, sizeof(GridMeta) * (size_t) nc));
-  HIPCHK(ctx, hipMalloc((void**) &g.d_cell_start, sizeof(int32_t) * (size_t) cells));
-  HIPCHK(ctx, hipMalloc((void**) &g.d_cursor, sizeof(int32_t) * (size_t) cells));
-  HIPCHK(ctx, hipMalloc((void**) &g.d_sorted_idx, sizeof(int32_t) * (size_t) cs->padded_total));
-  HIPCHK(ctx, hipMalloc((void**) &g.d_sorted_xy, sizeof(float2) * (size_t) cs->padded_total));
-  HIPCHK(ctx, hipMalloc((void**) &d_base, sizeof(int32_t) * (size_t) nc));
-  HIPCHK(ctx, hipMalloc((void**) &d_gcap, sizeof(int32_t) * (size_t) nc));
+  DevTmp t_meta, t_start, t_cursor, t_sidx, t_sxy, t_base, t_gcap;
+  HIPCHK(ctx, hipMalloc(&t_meta.p, sizeof(GridMeta) * (size_t) nc));
+  HIPCHK(ctx, hipMalloc(&t_start.p, sizeof(int32_t) * (size_t) cells));
+  HIPCHK(ctx, hipMalloc(&t_cursor.p, sizeof(int32_t) * (size_t) cells));
+  HIPCHK(ctx, hipMalloc(&t_sidx.p, sizeof(int32_t) * (size_t) cs->padded_total));
+  HIPCHK(ctx, hipMalloc(&t_sxy.p, sizeof(float2) * (size_t) cs->padded_total));
+  HIPCHK(ctx, hipMalloc(&t_base.p, sizeof(int32_t) * (size_t) nc));
+  HIPCHK(ctx, hipMalloc(&t_gcap.p, sizeof(int32_t) * (size_t) nc));
+  g.d_meta = (GridMeta*) t_meta.p; g.d_cell_start = (int32_t*) t_start.p; g.d_cursor = (int32_t*) t_cursor.p;
+  g.d_sorted_idx = (int32_t*) t_sidx.p; g.d_sorted_xy = (float2*) t_sxy.p;
+  int32_t* d_base = (int32_t*) t_base.p; int32_t* d_gcap = (int32_t*) t_gcap.p;
   HIPCHK(ctx, hipMemcpyAsync(d_base, cell_base.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_gcap, gcap.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   GridBuildArgs A;
@@ -431,7 +441,7 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   hipLaunchKernelGGL(k_grid_build, dim3((unsigned) nc), dim3(1024), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // host vectors above must outlive the copies
-  (void) hipFree(d_base); (void) hipFree(d_gcap);
+  t_meta.release(); t_start.release(); t_cursor.release(); t_sidx.release(); t_sxy.release();   // owned by the cache from here on
   cs->grids.push_back(g);
   *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy};
   return LSM2D_SUCCESS;
@@ -476,15 +486,15 @@ static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float ma
     if (d.max_distance == max_distance && d.resolution == resolution) { *out = DistDev{d.d_meta, d.d_parent}; return LSM2D_SUCCESS; }
   if (!(resolution > 0.0f) || max_distance < 0.0f) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap: resolution must be > 0 and max_distance >= 0");
   const int nc = cs->n_clouds;
-  float4* d_bbox = nullptr;
-  HIPCHK(ctx, hipMalloc((void**) &d_bbox, sizeof(float4) * (size_t) nc));
+  DevTmp t_bbox;
+  HIPCHK(ctx, hipMalloc(&t_bbox.p, sizeof(float4) * (size_t) nc));
+  float4* d_bbox = (float4*) t_bbox.p;
   hipLaunchKernelGGL(k_cloud_bbox, dim3((unsigned) nc), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy, (const int32_t*) cs->d_start,
                      (const int32_t*) cs->d_count, d_bbox);
   HIPCHK(ctx, hipGetLastError());
   std::vector<float4> bbox((size_t) nc);
   HIPCHK(ctx, hipMemcpyAsync(bbox.data(), d_bbox, sizeof(float4) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  (void) hipFree(d_bbox);
   const float inv_res = 1.0f / resolution;
   const float mds_px = max_distance * max_distance * inv_res * inv_res;
   const int padding = (int) (sqrtf(mds_px) + 75.5f);
@@ -502,10 +512,12 @@ static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float ma
     if (total > (1ll << 33)) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "distmap: more than 8 Gi pixels in one set");
   }
   DistCache d; d.max_distance = max_distance; d.resolution = resolution;
-  int32_t* d_cellgoal = nullptr;
-  HIPCHK(ctx, hipMalloc((void**) &d.d_meta, sizeof(DistMeta) * (size_t) nc));
-  HIPCHK(ctx, hipMalloc((void**) &d.d_parent, sizeof(int32_t) * (size_t) total));
-  HIPCHK(ctx, hipMalloc((void**) &d_cellgoal, sizeof(int32_t) * (size_t) total));
+  DevTmp t_dmeta, t_parent, t_goal;
+  HIPCHK(ctx, hipMalloc(&t_dmeta.p, sizeof(DistMeta) * (size_t) nc));
+  HIPCHK(ctx, hipMalloc(&t_parent.p, sizeof(int32_t) * (size_t) total));
+  HIPCHK(ctx, hipMalloc(&t_goal.p, sizeof(int32_t) * (size_t) total));
+  d.d_meta = (DistMeta*) t_dmeta.p; d.d_parent = (int32_t*) t_parent.p;
+  int32_t* d_cellgoal = (int32_t*) t_goal.p;
   HIPCHK(ctx, hipMemcpyAsync(d.d_meta, meta.data(), sizeof(DistMeta) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(d_cellgoal, 0x7f, sizeof(int32_t) * (size_t) total, ctx->stream));
   int max_pts = 1; for (int c = 0; c < nc; ++c) if (cs->h_count[c] > max_pts) max_pts = cs->h_count[c];
@@ -523,7 +535,7 @@ static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float ma
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  (void) hipFree(d_cellgoal);
+  t_dmeta.release(); t_parent.release();          // owned by the cache from here on (t_goal is freed by its guard)
   cs->dists.push_back(d);
   *out = DistDev{d.d_meta, d.d_parent};
   return LSM2D_SUCCESS;
