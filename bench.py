@@ -59,6 +59,9 @@ def main() -> None:
     ap.add_argument("--role", choices=["A", "B"], default="A", help="A: fixed=scan, moving=map (reference tracker wiring); B: fixed=map, moving=scan")
     ap.add_argument("--finder", choices=["projective", "nn"], default="projective")
     ap.add_argument("--max-distance", type=float, default=0.5, help="NN finder gate [m]")
+    ap.add_argument("--total-candidates", type=int, default=0,
+                    help="BASELINE configs[3]: a fixed sweep of this many candidate alignments sharded over the ranks (strong scaling); "
+                         "overrides --scans with this rank's share and gathers the poses on every rank at the end")
     ap.add_argument("--unique-scans", type=int, default=0, help="ray-cast only this many scans; candidates reuse them through an index array (loop-closure sweep)")
     args = ap.parse_args()
 
@@ -78,6 +81,11 @@ def main() -> None:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from srrg2_laser_slam_2d_amd import api, distributed, synth
+
+    strong = args.total_candidates > 0
+    if strong:
+        lo, hi = distributed.shard_range(args.total_candidates, rank, world)
+        args.scans = hi - lo
 
     # ---- inputs: the shared local map comes from rank 0 (RCCL broadcast), each rank ray-casts its own scans
     world_geom = synth.make_world(args.seed)
@@ -132,6 +140,12 @@ def main() -> None:
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    if strong and use_dist:          # the sweep's consumer wants every candidate's pose: one all_gather of 12 B per candidate
+        counts = [distributed.shard_range(args.total_candidates, r, world) for r in range(world)]
+        pad = max(h - l for l, h in counts)
+        mine = np.zeros((pad, 3), np.float32); mine[: len(res.pose)] = res.pose
+        allp = distributed.gather_results(mine)
+        assert allp.shape == (pad * world, 3)
     elapsed = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -148,7 +162,7 @@ def main() -> None:
         f = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(f, op=dist.ReduceOp.MIN); ok = bool(f.item())
 
     if rank == 0:
-        n_total = args.scans * world * args.steps
+        n_total = (args.total_candidates if strong else args.scans * world) * args.steps
         bytes_per_alignment = algorithmic_bytes_per_alignment(args.role, args.finder, args.map_points,
                                                               float(np.diff(wl.scan_offsets).mean()), args.beams, args.iterations)
         k_ms = float(np.mean(kernel_ms))
@@ -164,7 +178,7 @@ def main() -> None:
         out = {
             "metric": "scan-to-map alignments/sec (1081-beam vs 100k-pt map, 20 GN iters)",
             "value": n_total / elapsed, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s%d scans/GPU x %d-beam vs one %d-pt map, %d GN iters, role %s (%s), %s finder"
                                    % ("configs[1]: " if default_cfg else "", args.scans, args.beams, args.map_points, args.iterations, args.role,
