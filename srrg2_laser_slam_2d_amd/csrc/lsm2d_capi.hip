@@ -916,7 +916,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     S.fcan_offset = fcan_total; fcan_total += S.proj.cols; if (S.proj.cols > cols_max) cols_max = S.proj.cols;
   }
   A.cols_max = cols_max; A.fcan_total = fcan_total;
-  const size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float) * kAccumWords * (kAlignBlock / 64);
+  const size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float4) * (size_t) fcan_total +
+                     sizeof(float) * kAccumWords * (kAlignBlock / 64);      // moving canvas, fixed canvases, fixed winners, reduction
   if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
 
   // ---- inputs

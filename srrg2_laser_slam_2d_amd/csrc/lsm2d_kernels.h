@@ -301,7 +301,8 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   extern __shared__ __align__(16) unsigned char smem[];
   u64* mcan = reinterpret_cast<u64*>(smem);
   u64* fcan = mcan + A.cols_max;
-  float* red = reinterpret_cast<float*>(fcan + A.fcan_total);     // [nwaves][kAccumWords]
+  float4* fwin = reinterpret_cast<float4*>(fcan + A.fcan_total);  // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
+  float* red = reinterpret_cast<float*>(fwin + A.fcan_total);     // [nwaves][kAccumWords]
   __shared__ float s_pose[3];
   __shared__ Iso   s_iso[kMaxSlices];
   __shared__ float s_H[9], s_Hs[9], s_b[3];      // s_H: information matrix (H of the last solved iteration); s_Hs: this iteration's sum
@@ -313,10 +314,24 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
 
   // ---- prologue: fixed canvases, camera at identity (correspondence_finder_projective_2d.cpp:37-44)
   for (int i = tid; i < A.fcan_total; i += kAlignBlock) fcan[i] = kEmptyCell;
+  for (int i = tid; i < A.cols_max; i += kAlignBlock) mcan[i] = kEmptyCell;      // afterwards the bin walk resets what it reads
+  // per-iteration set-up by lane 0: X_eff = S^-1 X per slice (AlignerSliceProcessorLaser2DWithSensor), cos/sin once per
+  // slice, zeroed sums.  Done here for iteration 0 and at the end of every solve for the next one (no extra barrier).
+  auto begin_iteration = [&]() {
+    for (int s = 0; s < A.n_slices; ++s) {
+      float Xe[3] = {s_pose[0], s_pose[1], s_pose[2]};
+      if (A.s[s].has_sensor) compose(A.s[s].cSinv, A.s[s].sSinv, A.s[s].Sinv, s_pose, Xe);
+      s_iso[s].c = cosf(Xe[2]); s_iso[s].s = sinf(Xe[2]); s_iso[s].tx = Xe[0]; s_iso[s].ty = Xe[1];
+    }
+    for (int k = 0; k < 9; ++k) s_Hs[k] = 0.0f;
+    s_b[0] = s_b[1] = s_b[2] = 0.0f;
+    s_n_in = s_n_out = s_n_corr = s_active = 0; s_chi_in = s_chi_out = 0.0f;
+  };
   if (tid == 0) {
     s_pose[0] = A.init_pose[3 * a + 0]; s_pose[1] = A.init_pose[3 * a + 1]; s_pose[2] = A.init_pose[3 * a + 2];
     s_done = 0; s_status = LSM2D_RUNNING;
     for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
+    begin_iteration();
   }
   __syncthreads();
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
@@ -327,29 +342,29 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
     project_cloud(S.fixed.xy + S.fixed.start[fc], S.fixed.count[fc], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
   }
   __syncthreads();
+  for (int s = 0; s < A.n_slices; ++s) {      // cache the fixed winners' payload next to their keys
+    const SliceDev& S = A.s[s];
+    if (!kHasProj || S.finder != LSM2D_FINDER_PROJECTIVE) continue;
+    const int fbase = S.fixed.start[pick_cloud(S.fixed, a)];
+    for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
+      const u64 k = fcan[S.fcan_offset + col];
+      if (k != kEmptyCell) {
+        const int fi = (int) (uint32_t) k;
+        const float2 p = S.fixed.xy[fbase + fi], n = S.fixed.nrm[fbase + fi];
+        fwin[S.fcan_offset + col] = make_float4(p.x, p.y, n.x, n.y);
+      }
+    }
+  }
+  __syncthreads();
 
   int it = 0;
   StatsDev last = {0, 0, 0, 0.0f, 0.0f};
   for (; it < A.max_it; ++it) {
-    if (tid == 0) {
-      // X_eff = S^-1 X per slice (AlignerSliceProcessorLaser2DWithSensor), then cos/sin once per slice
-      for (int s = 0; s < A.n_slices; ++s) {
-        float Xe[3] = {s_pose[0], s_pose[1], s_pose[2]};
-        if (A.s[s].has_sensor) compose(A.s[s].cSinv, A.s[s].sSinv, A.s[s].Sinv, s_pose, Xe);
-        s_iso[s].c = cosf(Xe[2]); s_iso[s].s = sinf(Xe[2]); s_iso[s].tx = Xe[0]; s_iso[s].ty = Xe[1];
-      }
-      for (int k = 0; k < 9; ++k) s_Hs[k] = 0.0f;
-      s_b[0] = s_b[1] = s_b[2] = 0.0f;
-      s_n_in = s_n_out = s_n_corr = s_active = 0; s_chi_in = s_chi_out = 0.0f;
-    }
-    __syncthreads();       // s_iso[] is read by every lane below
     for (int s = 0; s < A.n_slices; ++s) {
       const SliceDev& S = A.s[s];
       const Iso T = s_iso[s];
       Accum acc; accum_zero(acc);
       if (kHasProj && ((!kHasNN && !kHasDist) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
-        for (int i = tid; i < S.proj.cols; i += kAlignBlock) mcan[i] = kEmptyCell;
-        __syncthreads();
         {
           // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
           const int mc = pick_cloud(S.moving, a);
@@ -358,15 +373,23 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
           else project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
         }
         __syncthreads();
-        const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
-        const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
-        const float2* fn = S.fixed.nrm + fbase; const float2* mn = S.moving.nrm + mbase;
-        const float2* fp = S.fixed.xy + fbase;  const float2* mp = S.moving.xy + mbase;
-        const u64* fcs = fcan + S.fcan_offset;
+        // bin walk (correspondence_finder_projective_2d.cpp:55-74): the fixed side comes from LDS, the two gathers of the
+        // moving winner are issued together, and every cell read is reset for the next projection
+        const int mbase = S.moving.start[pick_cloud(S.moving, a)];
+        const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
+        const u64* fcs = fcan + S.fcan_offset; const float4* fws = fwin + S.fcan_offset;
         for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
-          int fi, mi; float2 nf, nm;
-          if (match_bin(fcs[col], mcan[col], S, T, fn, mn, fi, mi, nf, nm))
-            accumulate_pair(T, fp[fi], nf, mp[mi], nm, S.cauchy != 0, S.tau, acc);
+          const u64 fk = fcs[col], mk = mcan[col];
+          mcan[col] = kEmptyCell;
+          if (mk == kEmptyCell || fk == kEmptyCell) continue;
+          const float fd = __uint_as_float((uint32_t) (fk >> 32)), md = __uint_as_float((uint32_t) (mk >> 32));
+          if (__builtin_fabsf(fd - md) > S.point_distance) continue;
+          const int mi = (int) (uint32_t) mk;
+          const float2 nm = mn[mi], pm = mp[mi];
+          const float4 f = fws[col];
+          float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+          if (__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos) continue;
+          accumulate_pair(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, S.cauchy != 0, S.tau, acc);
         }
       } else if (kHasNN || kHasDist) {
         // NN finder fused with the factor (correspondence_finder_kd_tree_2d.cpp:12-27): every moving point is
@@ -423,7 +446,10 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
           s_n_in += t.n_in; s_n_out += t.n_out; s_chi_in += t.chi_in; s_chi_out += t.chi_out;
         }
       }
-      __syncthreads();
+      // pure projective kernels need no barrier here: the other waves go on to the next slice's projection (the cells it
+      // writes were reset by the bin walk) and touch `red` again only after the barrier that follows it, which lane 0
+      // joins once it is done with the partials.  The point-query branches write `red` without such a barrier in between.
+      if (kHasNN || kHasDist) __syncthreads();
     }
     if (tid == 0) {
       last.n_corr = s_n_corr; last.n_in = s_n_in; last.n_out = s_n_out; last.chi_in = s_chi_in; last.chi_out = s_chi_out;
@@ -474,6 +500,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
         if (!solve_update(H, b, A.damping, X)) { s_status = LSM2D_SINGULAR_H; s_done = 1; }
         else { s_pose[0] = X[0]; s_pose[1] = X[1]; s_pose[2] = X[2]; }
       }
+      if (!s_done) begin_iteration();        // next iteration's transforms and zeroed sums, under the same barrier
     }
     __syncthreads();
     if (s_done) { ++it; break; }
