@@ -232,14 +232,22 @@ LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, fl
 // ---- wave64 / workgroup reduction: shuffle butterfly, one LDS hop, fixed order => deterministic ----
 static constexpr int kAccumWords = 14;
 
-LSM2D_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave64 sum with DPP row operations (no LDS traffic): inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then
+// lane 15 -> lanes 16..31 / lane 47 -> lanes 48..63 (row_bcast:15, row_mask 0xA) and lane 31 -> lanes 32..63 (row_bcast:31,
+// row_mask 0xC).  The total ends up in LANE 63.  Lanes without a source keep the identity 0.  Six v_add with DPP operands
+// per value; the ds_bpermute-based __shfl_xor butterfly this replaces cost 2.4 us for the 14 sums of one slice-iteration.
+LSM2D_DEV float wave_sum63(float v) {
+#define LSM2D_DPP_ADD_F(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
+  LSM2D_DPP_ADD_F(0x111, 0xF); LSM2D_DPP_ADD_F(0x112, 0xF); LSM2D_DPP_ADD_F(0x114, 0xF); LSM2D_DPP_ADD_F(0x118, 0xF);
+  LSM2D_DPP_ADD_F(0x142, 0xA); LSM2D_DPP_ADD_F(0x143, 0xC);
+#undef LSM2D_DPP_ADD_F
   return v;
 }
-LSM2D_DEV int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+LSM2D_DEV int wave_sum63_i(int v) {
+#define LSM2D_DPP_ADD_I(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xF, false)
+  LSM2D_DPP_ADD_I(0x111, 0xF); LSM2D_DPP_ADD_I(0x112, 0xF); LSM2D_DPP_ADD_I(0x114, 0xF); LSM2D_DPP_ADD_I(0x118, 0xF);
+  LSM2D_DPP_ADD_I(0x142, 0xA); LSM2D_DPP_ADD_I(0x143, 0xC);
+#undef LSM2D_DPP_ADD_I
   return v;
 }
 
@@ -249,11 +257,11 @@ LSM2D_DEV void block_reduce_store(const Accum& A, float* red, int tid) {
   float f[11] = {A.h00, A.h01, A.h02, A.h11, A.h12, A.h22, A.b0, A.b1, A.b2, A.chi_in, A.chi_out};
 #pragma unroll
   for (int k = 0; k < 11; ++k) {
-    const float s = wave_sum(f[k]);
-    if (lane == 0) red[wave * kAccumWords + k] = s;
+    const float s = wave_sum63(f[k]);
+    if (lane == 63) red[wave * kAccumWords + k] = s;
   }
-  const int i0 = wave_sum_i(A.n_in), i1 = wave_sum_i(A.n_out), i2 = wave_sum_i(A.n_corr);
-  if (lane == 0) {
+  const int i0 = wave_sum63_i(A.n_in), i1 = wave_sum63_i(A.n_out), i2 = wave_sum63_i(A.n_corr);
+  if (lane == 63) {
     red[wave * kAccumWords + 11] = __int_as_float(i0);
     red[wave * kAccumWords + 12] = __int_as_float(i1);
     red[wave * kAccumWords + 13] = __int_as_float(i2);
