@@ -278,6 +278,20 @@ LSM2D_DEV void block_reduce_gather(const float* red, int nwaves, Accum& A) {
   }
 }
 
+// the same totals for lane 0 of wave 0, gathered in parallel: lanes 0..13 each add one quantity over the waves (same wave
+// order, hence the same bits as block_reduce_gather), lane 0 collects them with v_readlane.  Call from every lane of wave 0.
+LSM2D_DEV void block_reduce_gather_wave0(const float* red, int nwaves, int lane, Accum& A) {
+  float v = 0.0f; int vi = 0;
+  if (lane < 11) { for (int w = 0; w < nwaves; ++w) v += red[w * kAccumWords + lane]; }
+  else if (lane < kAccumWords) { for (int w = 0; w < nwaves; ++w) vi += __float_as_int(red[w * kAccumWords + lane]); }
+  const int b = __float_as_int(v);
+#define LSM2D_RL_F(k) __int_as_float(__builtin_amdgcn_readlane(b, k))
+  A.h00 = LSM2D_RL_F(0); A.h01 = LSM2D_RL_F(1); A.h02 = LSM2D_RL_F(2); A.h11 = LSM2D_RL_F(3); A.h12 = LSM2D_RL_F(4); A.h22 = LSM2D_RL_F(5);
+  A.b0 = LSM2D_RL_F(6); A.b1 = LSM2D_RL_F(7); A.b2 = LSM2D_RL_F(8); A.chi_in = LSM2D_RL_F(9); A.chi_out = LSM2D_RL_F(10);
+#undef LSM2D_RL_F
+  A.n_in = __builtin_amdgcn_readlane(vi, 11); A.n_out = __builtin_amdgcn_readlane(vi, 12); A.n_corr = __builtin_amdgcn_readlane(vi, 13);
+}
+
 // ---- step: (H + damping I) dx = -b in fp64 (LDL^T), X <- X * v2t(dx) ------------------------------
 // returns false on a non-positive / non-finite pivot (SingularH)
 LSM2D_DEV bool solve_update(const float H[9], const float b[3], float damping, float pose[3]) {

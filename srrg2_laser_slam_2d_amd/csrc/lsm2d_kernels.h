@@ -435,8 +435,9 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
       }
       block_reduce_store(acc, red, tid);
       __syncthreads();
+      Accum t;
+      if (tid < 64) block_reduce_gather_wave0(red, nwaves, tid, t);
       if (tid == 0) {
-        Accum t; block_reduce_gather(red, nwaves, t);
         s_n_corr += t.n_corr;
         if (t.n_corr > S.min_corr) {   // slices with #pairs <= min_num_correspondences are skipped
           ++s_active;
@@ -605,8 +606,9 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
     }
     block_reduce_store(acc, red, tid);
     __syncthreads();
+    Accum t;
+    if (tid < 64) block_reduce_gather_wave0(red, nwaves, tid, t);
     if (tid == 0) {
-      Accum t; block_reduce_gather(red, nwaves, t);
       s_n_corr += t.n_corr;
       if (t.n_corr > SL.min_corr) {
         ++s_active;
