@@ -132,6 +132,8 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_clip_small, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_merge_small, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_split_project<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_split_project<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipGetLastError();
@@ -642,14 +644,20 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   const Iso T = make_iso(cam_inv);
   u64* d_canvas = (u64*) ctx->d_scratch;
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  rc = project_split(ctx, scene->d_xy + scene->h_start[si], scene->h_count[si], T, P, d_canvas); if (rc) return rc;
+  const bool small = scene->h_count[si] <= 32768;            // one workgroup, LDS canvas, one launch
+  if (!small) { rc = project_split(ctx, scene->d_xy + scene->h_start[si], scene->h_count[si], T, P, d_canvas); if (rc) return rc; }
   ClipEmitArgs A;
   A.gcanvas = d_canvas; A.cols = P.cols; A.xy = scene->d_xy + scene->h_start[si]; A.nrm = scene->d_nrm + scene->h_start[si];
   A.T = T; A.S = make_iso(sensor_in_robot);
   A.s_identity = sensor_in_robot[0] == 0.0f && sensor_in_robot[1] == 0.0f && sensor_in_robot[2] == 0.0f;
   A.out_xy = clipped->d_xy; A.out_nrm = clipped->d_nrm; A.out_src = (int32_t*) ((char*) ctx->d_scratch + o_src);
   A.out_count = (int32_t*) ((char*) ctx->d_scratch + o_cnt); A.out_count_dev = clipped->d_count;
-  hipLaunchKernelGGL(k_clip_emit, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
+  if (small) {
+    ClipSmallArgs CS; CS.xy = A.xy; CS.nrm = A.nrm; CS.n = scene->h_count[si]; CS.proj = P; CS.emit = A;
+    hipLaunchKernelGGL(k_clip_small, dim3(1), dim3(kFindBlock), sizeof(u64) * (size_t) P.cols, ctx->stream, CS);
+  } else {
+    hipLaunchKernelGGL(k_clip_emit, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
+  }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;
@@ -685,6 +693,17 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   u64* d_scan = (u64*) ds; u64* d_mcan = (u64*) (ds + o_mcan);
   float2* d_txy = (float2*) (ds + o_txy); float2* d_tn = (float2*) (ds + o_tn);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  const bool small = n_scene <= 32768 && n_meas <= 32768 && (int) (sizeof(u64) * 2 * (size_t) P.cols) <= ctx->max_dyn_lds;
+  if (small) {                                               // one workgroup does the transform, both z-buffers and the column walk
+    MergeSmallArgs MS;
+    MS.m.scanvas = nullptr; MS.m.mcanvas = nullptr; MS.m.cols = P.cols; MS.m.sxy = scene->d_xy; MS.m.snrm = scene->d_nrm; MS.m.n_scene = n_scene;
+    MS.m.mxy = meas->d_xy + meas->h_start[mi]; MS.m.mnrm = meas->d_nrm + meas->h_start[mi];
+    MS.m.far_limit = 0.9f * pr->range_max; MS.m.merge_threshold = merge_threshold;
+    MS.m.out = (int32_t*) (ds + o_out); MS.m.count_dev = scene->d_count;
+    MS.proj = P; MS.Tinv = Tinv; MS.M = M; MS.n_meas = n_meas;
+    hipLaunchKernelGGL(k_merge_small, dim3(1), dim3(kFindBlock), sizeof(u64) * 2 * (size_t) P.cols, ctx->stream, MS);
+    HIPCHK(ctx, hipGetLastError());
+  } else {
   if (n_meas > 0) {
     hipLaunchKernelGGL(k_transform_cloud, dim3((unsigned) ((n_meas + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const float2*) (meas->d_xy + meas->h_start[mi]), (const float2*) (meas->d_nrm + meas->h_start[mi]), n_meas, M, d_txy, d_tn);
@@ -698,6 +717,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   A.out = (int32_t*) (ds + o_out); A.count_dev = scene->d_count;
   hipLaunchKernelGGL(k_merge_apply, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
+  }
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ds + o_out, 16, hipMemcpyDeviceToHost, ctx->stream));

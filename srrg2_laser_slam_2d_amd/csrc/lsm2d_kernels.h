@@ -901,17 +901,18 @@ struct ClipEmitArgs {
   float2* out_xy; float2* out_nrm; int32_t* out_src; int32_t* out_count_dev /* count[0] of the clipped set */; int32_t* out_count;
 };
 
-__global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A) {
-  __shared__ int s_wave_tot[kFindBlock / 64];
-  __shared__ int s_base;
-  const int tid = threadIdx.x;
-  if (tid == 0) s_base = 0;
-  __syncthreads();
+__global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A);
+
+// small scenes (the tracker's local map between key frames): clipper and merger as ONE workgroup-resident kernel each --
+// z-buffers in LDS, no global canvas, no memsets, one launch instead of three resp. six
+struct ClipSmallArgs { const float2* xy; const float2* nrm; int32_t n; ProjK proj; ClipEmitArgs emit; };
+
+LSM2D_DEV void clip_emit_body(const ClipEmitArgs& A, const u64* canvas, int* s_wave_tot, int* s_base, int tid) {
   for (int c0 = 0; c0 < A.cols; c0 += kFindBlock) {
     const int col = c0 + tid;
-    const u64 k = col < A.cols ? A.gcanvas[col] : kEmptyCell;
+    const u64 k = col < A.cols ? canvas[col] : kEmptyCell;
     const bool ok = k != kEmptyCell;
-    const int pos = block_compact_offset(ok, s_wave_tot, &s_base, tid, kFindBlock / 64);
+    const int pos = block_compact_offset(ok, s_wave_tot, s_base, tid, kFindBlock / 64);
     if (ok) {
       const int src = (int) (uint32_t) k;
       const float2 p = A.xy[src], n = A.nrm[src];
@@ -926,7 +927,29 @@ __global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A) 
       if (A.out_src) A.out_src[pos] = src;
     }
   }
-  if (tid == 0) { *A.out_count = s_base; *A.out_count_dev = s_base; }
+  if (tid == 0) { *A.out_count = *s_base; *A.out_count_dev = *s_base; }
+}
+
+__global__ __launch_bounds__(kFindBlock) void k_clip_small(const ClipSmallArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64* can = reinterpret_cast<u64*>(smem);
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_base;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < A.proj.cols; i += kFindBlock) can[i] = kEmptyCell;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  project_cloud(A.xy, A.n, A.emit.T, A.proj, can, tid, kFindBlock);
+  __syncthreads();
+  clip_emit_body(A.emit, can, s_wave_tot, &s_base, tid);
+}
+
+__global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A) {
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  clip_emit_body(A, A.gcanvas, s_wave_tot, &s_base, threadIdx.x);
 }
 
 // transform a cloud (measurement -> scene frame, mapping/merger_projective_2d.cpp:22-23)
@@ -950,22 +973,25 @@ struct MergeArgs {
   int32_t* count_dev;                                 // count[0] of the scene set
 };
 
-__global__ __launch_bounds__(kFindBlock) void k_merge_apply(const MergeArgs A) {
-  __shared__ int s_wave_tot[kFindBlock / 64];
-  __shared__ int s_base, s_new, s_merged, s_replaced;
-  const int tid = threadIdx.x;
-  if (tid == 0) { s_base = 0; s_new = s_merged = s_replaced = 0; }
-  __syncthreads();
+// mkT: when non-null the measurement is still in its own frame and is moved by *mkT on the fly (fused small-scene kernel);
+// the transform is the same operation sequence as k_transform_cloud, so both forms give the same bits
+LSM2D_DEV void merge_apply_body(const MergeArgs& A, const u64* scanvas, const u64* mcanvas, const Iso* mkT, int* s_wave_tot, int* s_cnt, int tid) {
+  // s_cnt: [0] appended, [1] new, [2] merged, [3] replaced
   for (int c0 = 0; c0 < A.cols; c0 += kFindBlock) {
     const int col = c0 + tid;
     bool append = false; float2 mp = make_float2(0.f, 0.f), mn = mp;
     if (col < A.cols) {
-      const u64 mk = A.mcanvas[col], sk = A.scanvas[col];
+      const u64 mk = mcanvas[col], sk = scanvas[col];
       const float md = __uint_as_float((uint32_t) (mk >> 32));
       if (mk != kEmptyCell && !(md > A.far_limit)) {
         const int mi = (int) (uint32_t) mk;
         mp = A.mxy[mi]; mn = A.mnrm[mi];
-        if (sk == kEmptyCell) { append = true; atomicAdd(&s_new, 1); }
+        if (mkT) {
+          float x, y, nx, ny;
+          xf_point(*mkT, mp.x, mp.y, x, y); xf_normal(*mkT, mn.x, mn.y, nx, ny);
+          mp = make_float2(x, y); mn = make_float2(nx, ny);
+        }
+        if (sk == kEmptyCell) { append = true; atomicAdd(&s_cnt[1], 1); }
         else {
           const int si = (int) (uint32_t) sk;
           const float dr = md - __uint_as_float((uint32_t) (sk >> 32));
@@ -976,16 +1002,47 @@ __global__ __launch_bounds__(kFindBlock) void k_merge_apply(const MergeArgs A) {
             const float nn = __builtin_sqrtf(__builtin_fmaf(nx, nx, ny * ny));
             if (nn > 0.0f) { nx = nx / nn; ny = ny / nn; }
             A.sxy[si] = make_float2(x, y); A.snrm[si] = make_float2(nx, ny);
-            atomicAdd(&s_merged, 1);
-          } else if (dr > 0.0f) { A.sxy[si] = mp; A.snrm[si] = mn; atomicAdd(&s_replaced, 1); }
+            atomicAdd(&s_cnt[2], 1);
+          } else if (dr > 0.0f) { A.sxy[si] = mp; A.snrm[si] = mn; atomicAdd(&s_cnt[3], 1); }
           else append = true;
         }
       }
     }
-    const int pos = block_compact_offset(append, s_wave_tot, &s_base, tid, kFindBlock / 64);
+    const int pos = block_compact_offset(append, s_wave_tot, &s_cnt[0], tid, kFindBlock / 64);
     if (append) { A.sxy[A.n_scene + pos] = mp; A.snrm[A.n_scene + pos] = mn; }
   }
-  if (tid == 0) { A.out[0] = A.n_scene + s_base; A.out[1] = s_new; A.out[2] = s_merged; A.out[3] = s_replaced; *A.count_dev = A.n_scene + s_base; }
+  if (tid == 0) { A.out[0] = A.n_scene + s_cnt[0]; A.out[1] = s_cnt[1]; A.out[2] = s_cnt[2]; A.out[3] = s_cnt[3]; *A.count_dev = A.n_scene + s_cnt[0]; }
+}
+
+__global__ __launch_bounds__(kFindBlock) void k_merge_apply(const MergeArgs A) {
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_cnt[4];
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  merge_apply_body(A, A.scanvas, A.mcanvas, nullptr, s_wave_tot, s_cnt, threadIdx.x);
+}
+
+// small scene: transform + both projections + column walk in one workgroup (mxy / mnrm hold the measurement in ITS frame)
+struct MergeSmallArgs { MergeArgs m; ProjK proj; Iso Tinv, M; int32_t n_meas; };
+
+__global__ __launch_bounds__(kFindBlock) void k_merge_small(const MergeSmallArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64* scan = reinterpret_cast<u64*>(smem);
+  u64* mcan = scan + A.proj.cols;
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_cnt[4];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < A.proj.cols; i += kFindBlock) { scan[i] = kEmptyCell; mcan[i] = kEmptyCell; }
+  if (tid < 4) s_cnt[tid] = 0;
+  __syncthreads();
+  project_cloud(A.m.sxy, A.m.n_scene, A.Tinv, A.proj, scan, tid, kFindBlock);
+  for (int i = tid; i < A.n_meas; i += kFindBlock) {             // measurement -> scene frame -> camera frame
+    const float2 p = A.m.mxy[i];
+    float x, y; xf_point(A.M, p.x, p.y, x, y);
+    project_point(A.Tinv, A.proj, x, y, i, mcan);
+  }
+  __syncthreads();
+  merge_apply_body(A.m, scan, mcan, &A.M, s_wave_tot, s_cnt, tid);
 }
 
 // split a single device cloud back into AoS (download)

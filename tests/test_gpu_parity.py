@@ -824,3 +824,28 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
             assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD, (trial, finder, d)
             checked_poses += 1
     assert checked_pairs > 5000 and checked_poses >= 12
+
+
+def test_clipper_and_merger_small_and_large_scene_paths(ctx, po):
+    """Both implementations of the mapping steps -- one workgroup with LDS canvases (scenes <= 32768 points) and the
+    many-workgroup split projection -- against the oracle, bit for bit."""
+    world = synth.make_world(4)
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    robot = synth.sample_poses(world, 1, seed=6)[0]
+    S = np.float32([0.2, -0.1, 0.3])
+    sensor = synth.compose_poses(robot[None, :], S[None, :].astype(np.float64))
+    scan, _ = synth.make_scans(world, sensor, n_beams=721, noise_sigma=0.01, seed=2)
+    for n_scene in (5000, 32768, 32769, 90000):
+        m = synth.make_map(world, n_scene, noise_sigma=0.004, seed=n_scene)
+        scene = api.CloudSet.reserved(ctx, n_scene + 2000); scene.upload(m)
+        clipper = api.SceneClipperProjective2D(ctx, proj); clipper.setFullScene(scene)
+        clipper.setRobotInLocalMap(robot); clipper.setSensorInRobot(S)
+        clipped = clipper.compute()
+        want, wsrc = po.clip_scene(opr, m, np.float32(robot), S)
+        assert np.array_equal(clipper.source_indices, wsrc) and np.array_equal(clipped.download(), want)
+        merger = api.MergerProjective2D(ctx, proj, 0.2); merger.setScene(scene)
+        merger.setMeasurement(scan); merger.setMeasurementInScene(np.float32(sensor[0]))
+        n = merger.compute()
+        wm, counts = po.merge_scene(opr, m, scan, np.float32(sensor[0]), 0.2)
+        assert n == len(wm) and merger.counts == counts and np.array_equal(scene.download(), wm)
