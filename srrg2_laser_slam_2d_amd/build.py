@@ -21,7 +21,9 @@ HEADERS = [os.path.join(CSRC, "lsm2d_device.h"), os.path.join(CSRC, "lsm2d_kerne
 
 # -ffp-contract=off: every fused multiply-add in the kernels is explicit, so column indices and
 # z-buffer winners are reproducible bit-for-bit by an IEEE CPU (see csrc/lsm2d_device.h).
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+# -fno-slp-vectorize: the SLP pass pairs scalar fp32 operations into v_pk_*_f32, which issue slower than the two scalar
+# instructions they replace on gfx950 (measured: DESIGN.md section 5).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-Wall", "-Wno-unused-function"]
 
 

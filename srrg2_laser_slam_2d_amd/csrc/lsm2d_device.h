@@ -42,19 +42,21 @@ LSM2D_DEV void xf_normal(const Iso& T, float nx, float ny, float& ox, float& oy)
   oy = __builtin_fmaf(T.s, nx, T.c * ny);
 }
 
-// IEEE-754 correctly rounded n/d for 0 <= n <= d, d a normal number in [2^-100, 2^100] and n either 0 or
-// >= 2^-100 * d: the reciprocal-refinement sequence hipcc emits for '/', without the v_div_scale / v_div_fixup
-// range handling those inputs never need.  Anything outside that range takes the compiler's full divide.
+// IEEE-754 correctly rounded n/d for 0 <= n <= d, d a normal number in [2^-100, 2^100] and n >= 1e-12: v_rcp_f32, one
+// refinement of the reciprocal and ONE residual correction of the quotient (Markstein's sequence; the compiler's '/' spends two
+// more operations on a second correction plus v_div_scale / v_div_fixup range handling these inputs never need).  Every step
+// scales exactly with powers of two inside that range, so exactness is a property of the (mantissa of n, mantissa of d) pair
+// alone: tools/fp_exact_check.hip compares this function with '/' on ALL 2^46 pairs on the MI355X -- 0 mismatches
+// (profiles/r01/fp_exact_full.log; the cheaper sequences it also tries fail 2.7e4 / 4.7e4 times).  n < 1e-12 (a quotient that could
+// be subnormal, and n == 0) takes the compiler's full divide.
 LSM2D_DEV float div_rn_unit(float n, float d) {
-  if (__builtin_expect(n != 0.0f && n < 1e-12f, 0)) return n / d;      // quotient could be subnormal: full IEEE path
+  if (__builtin_expect(n < 1e-12f, 0)) return n / d;
   const float r0 = __builtin_amdgcn_rcpf(d);
   const float e0 = __builtin_fmaf(-d, r0, 1.0f);
   const float r1 = __builtin_fmaf(e0, r0, r0);
   const float q0 = n * r1;
   const float e1 = __builtin_fmaf(-d, q0, n);
-  const float q1 = __builtin_fmaf(e1, r1, q0);
-  const float e2 = __builtin_fmaf(-d, q1, n);
-  return __builtin_fmaf(e2, r1, q1);
+  return __builtin_fmaf(e1, r1, q0);
 }
 
 // atan2 as a fixed polynomial: atan(a) = a + a*s*P(s), s = a*a, a = min/max in [0,1] (IEEE divide),
@@ -94,23 +96,20 @@ LSM2D_DEV float wrap_angle(float a) {
   return a;
 }
 
-// Correctly rounded sqrt for NORMAL-range inputs (the range gate keeps r2 in [1e-30, 1e36]): the hardware
-// v_sqrt_f32 estimate (<= 1 ulp) followed by the two-sided fma residual test -- the sequence hipcc emits for
-// sqrtf() minus its denormal pre-scaling.
+// Correctly rounded sqrt for inputs in [1e-30, 1e36] (the range gate's r2): v_rsq_f32, s0 = x*y, one residual correction
+// s0 + (x - s0*s0) * (y/2).  tools/fp_exact_check.hip compares it with sqrtf on every fp32 bit pattern of that interval
+// (1.84e9 inputs) on the MI355X: 0 mismatches (profiles/r01/fp_exact_full.log).  Six issue slots instead of the eleven of
+// v_sqrt_f32 + the two-sided residual test hipcc emits for sqrtf().
 LSM2D_DEV float sqrt_rn_normal(float x) {
-  const float s  = __builtin_amdgcn_sqrtf(x);
-  const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
-  const float em = __builtin_fmaf(-sm, s, x), ep = __builtin_fmaf(-sp, s, x);
-  float r = em <= 0.0f ? sm : s;
-  r = ep > 0.0f ? sp : r;
-  return r;
+  const float y  = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y, h = 0.5f * y;
+  const float e  = __builtin_fmaf(-s0, s0, x);
+  return __builtin_fmaf(e, h, s0);
 }
 
 // One point of the polar z-buffer.  key = (bits(depth) << 32) | index: depth >= 0 so the IEEE bit
 // pattern orders like the value, and the 64-bit unsigned min keeps the nearest point with ties going
 // to the LOWEST index == "first point wins under strict <" of the sequential reference loop.
-// The depth itself (a correctly rounded sqrt) is only formed for points that can still win their cell:
-// sqrt_rn(r2) <= d implies r2 <= d*d*(1 + 3*2^-23) in fp32, so r2 above that bound loses for certain.
 LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, int idx, u64* canvas) {
   float qx, qy;
   xf_point(T, px, py, qx, qy);
@@ -118,17 +117,15 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
   if (r2 >= P.r2lo && r2 <= P.r2hi) {
     const float th = atan2_poly_t<true>(qy, qx);          // r2 in [1e-30, 1e36] => max(|qx|,|qy|) in [7e-16, 1e18]
     const float u  = __builtin_fmaf(P.K00, th, P.K01);
-    const int col = (int) __builtin_floorf(u);            // u is finite here; negative / too large -> rejected below
+    int col;                                               // floor + convert in one instruction (u is finite here;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col) : "v"(u));  // negative / too large -> rejected below)
     if ((unsigned) col < (unsigned) P.cols) {
       const u64 cur = canvas[col];
-      const float dcur = __uint_as_float((uint32_t) (cur >> 32));      // empty cell: NaN -> never rejected
-      const float bound = (dcur * dcur) * 1.00000036f;
-      if (!(r2 > bound)) {
-        const float r = sqrt_rn_normal(r2);
-        const u64 key = ((u64) __float_as_uint(r) << 32) | (u64) (uint32_t) idx;
-        // the cell only ever decreases, so a plain read that already beats us makes the atomic a no-op
-        if (key < cur) atomicMin(&canvas[col], key);
-      }
+      // the depth does not depend on the cell: its six operations run under the LDS read's latency
+      const float r = sqrt_rn_normal(r2);
+      const u64 key = ((u64) __float_as_uint(r) << 32) | (u64) (uint32_t) idx;
+      // the cell only ever decreases, so a plain read that already beats us makes the atomic a no-op
+      if (key < cur) atomicMin(&canvas[col], key);
     }
   }
 }
@@ -168,7 +165,8 @@ LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& Ti
 // the wave executes the LDS block anyway and only pays for the extra bookkeeping.)
 LSM2D_DEV void project_cloud_lanes(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin,
                                    u64* canvas, int tid, int nthreads) {
-  const Iso T = Tin; const ProjK P = Pin;
+  const Iso T = Tin; ProjK P = Pin;
+  asm volatile("" : "+v"(P.K01));        // keep K01 in a VGPR: fma(K00, th, K01) may read only one SGPR, the compiler would v_mov it per point
   if (T_steps <= 0) return;
   const int base = tid * T_steps;
   float4 v = lane_xy[tid];

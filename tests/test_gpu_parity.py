@@ -302,6 +302,26 @@ def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     assert abs(r["n_clipped"] - len(oclip)) <= 2 and abs(r["merged_size"] - len(omerge)) <= 2     # host-side inverse differs in the last bit
 
 
+def test_short_divide_and_sqrt_sequences_are_correctly_rounded(tmp_path):
+    """csrc/lsm2d_device.h replaces '/' and sqrtf() by shorter v_rcp / v_rsq sequences; the oracle uses the plain IEEE
+    operations, so columns and depths are bit-exact only if those sequences round correctly for EVERY admissible input.
+    tools/fp_exact_check.hip proves it on the card: every fp32 in the range gate's [1e-30, 1e36] for the sqrt, and here a
+    stride of 2^15 divisor mantissas x all 2^23 numerator mantissas (2.7e11 pairs) for the divide -- the full 2^46 sweep
+    (50 s of GPU) is profiles/r01/fp_exact_full.log.  The checker must also still catch the sequences known to be inexact."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "fp_exact_check")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize",
+                    "-I" + os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                    "-o", exe, os.path.join(ROOT, "tools", "fp_exact_check.hip")], check=True, timeout=300)
+    r = subprocess.run([exe, "32768"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = {ln.split()[0]: ln for ln in r.stdout.splitlines() if ln.startswith("  ")}
+    assert "mismatches vs sqrtf: 0 " in lines["sqrt_rn_normal"] and "mismatches vs n/d: 0 " in lines["div_rn_unit"]
+    assert "mismatches vs n/d: 0 " not in lines["S3(raw"]           # the check has teeth: the 3-operation divide IS inexact
+
+
 # ---- NN finder (CorrespondenceFinderKDTree2D, row a4) -------------------------------------------------------
 @pytest.mark.parametrize("max_distance", [0.5, 0.05, 0.01])
 def test_nn_finder_bit_exact_both_roles(ctx, po, small_workload, max_distance):
