@@ -110,6 +110,7 @@ LSM2D_DEV float sqrt_rn_normal(float x) {
 // One point of the polar z-buffer.  key = (bits(depth) << 32) | index: depth >= 0 so the IEEE bit
 // pattern orders like the value, and the 64-bit unsigned min keeps the nearest point with ties going
 // to the LOWEST index == "first point wins under strict <" of the sequential reference loop.
+template <bool kReadFirst = true>
 LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, int idx, u64* canvas) {
   float qx, qy;
   xf_point(T, px, py, qx, qy);
@@ -120,12 +121,17 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
     int col;                                               // floor + convert in one instruction (u is finite here;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col) : "v"(u));  // negative / too large -> rejected below)
     if ((unsigned) col < (unsigned) P.cols) {
-      const u64 cur = canvas[col];
       // the depth does not depend on the cell: its six operations run under the LDS read's latency
       const float r = sqrt_rn_normal(r2);
       const u64 key = ((u64) __float_as_uint(r) << 32) | (u64) (uint32_t) idx;
-      // the cell only ever decreases, so a plain read that already beats us makes the atomic a no-op
-      if (key < cur) atomicMin(&canvas[col], key);
+      if (kReadFirst) {
+        // the cell only ever decreases, so a plain read that already beats us makes the atomic a no-op: neighbouring lanes
+        // holding neighbouring points hit the SAME cell, where reads broadcast and atomics serialise
+        const u64 cur = canvas[col];
+        if (key < cur) atomicMin(&canvas[col], key);
+      } else {
+        atomicMin(&canvas[col], key);      // lane-chunked streams: lanes rarely share a cell, and a no-return atomic needs no wait
+      }
     }
   }
 }
@@ -173,8 +179,8 @@ LSM2D_DEV void project_cloud_lanes(const float4* __restrict__ lane_xy, int T_ste
   for (int t = 0; t < T_steps; ++t) {
     const int tn = t + 1 < T_steps ? t + 1 : t;
     const float4 nx = lane_xy[(size_t) tn * nthreads + tid];
-    project_point(T, P, v.x, v.y, 2 * (base + t), canvas);
-    project_point(T, P, v.z, v.w, 2 * (base + t) + 1, canvas);
+    project_point<false>(T, P, v.x, v.y, 2 * (base + t), canvas);
+    project_point<false>(T, P, v.z, v.w, 2 * (base + t) + 1, canvas);
     v = nx;
   }
 }
