@@ -456,6 +456,9 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
   bool any_big = false;                       // every cloud <= one pair per thread: the plain layout already is lane-chunked
   for (int c = 0; c < nc; ++c) if (((long long) cs->h_count[c] + 1) / 2 > kAlignBlock) { any_big = true; break; }
   if (!any_big) return LSM2D_SUCCESS;
+  // project_cloud_lanes walks a cloud's rows with a 32-bit scalar byte offset: a cloud beyond 2^31 bytes of slots
+  // (> 2.6e8 points) keeps the plain layout and project_cloud
+  for (int c = 0; c < nc; ++c) if ((((long long) cs->h_count[c] + 1) / 2 + kAlignBlock) * (long long) sizeof(float4) >= (1ll << 31)) return LSM2D_SUCCESS;
   std::vector<long long> lstart((size_t) nc); std::vector<int32_t> lT((size_t) nc);
   long long slots = 0; int maxT = 1;
   for (int c = 0; c < nc; ++c) {

@@ -66,10 +66,10 @@ LSM2D_DEV float div_rn_unit(float n, float d) {
 template <bool kUnitDiv>
 LSM2D_DEV float atan2_poly_t(float y, float x) {
   const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-  float mx, mn;
-  // |.| folded into the operands (plain fmaxf/fminf would first canonicalise both inputs: 2 extra VALU ops)
-  asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
-  asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
+  // one compare serves the operand order AND the octant fix-up below (selects with |.| folded in; equal magnitudes give the
+  // same two values either way)
+  const bool swap = ay > ax;
+  const float mx = swap ? ay : ax, mn = swap ? ax : ay;
   float r = 0.0f;
   if (kUnitDiv || mx > 0.0f) {
     const float a = kUnitDiv ? div_rn_unit(mn, mx) : mn / mx;
@@ -84,7 +84,7 @@ LSM2D_DEV float atan2_poly_t(float y, float x) {
     p = __builtin_fmaf(p, s, -3.333298564e-01f);
     r = __builtin_fmaf(a * s, p, a);
   }
-  if (ay > ax) r = 1.57079637050628662f - r;
+  if (swap) r = 1.57079637050628662f - r;
   if (x < 0.0f) r = 3.14159274101257324f - r;
   return __builtin_copysignf(r, y);
 }
@@ -162,26 +162,47 @@ LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& Ti
 
 // The same pass over a LANE-CHUNKED copy of the cloud (k_lane_layout): thread g owns the contiguous pairs
 // [g*T, (g+1)*T) and the copy is stored step-major (slot t*nthreads + g), so every load is still one coalesced
-// 16-byte access per lane -- but the 64 lanes of a wave now sit T pairs apart along the map.  Two effects on the
-// LDS z-buffer: lanes of one wave-instruction almost never hit the same cell (the same-address serialisation of
-// ds_min_u64 was ~1/3 of the kernel with neighbouring points in neighbouring lanes), and each lane walks its own
-// stretch of wall, so the plain-read filter sees the lane's previous update and only true improvements reach the
-// atomic.  Padding slots hold +inf and fail the range gate.  (A per-lane register cache of the last cell's bound, which
-// would skip ~90 % of the LDS reads, was measured 5 % SLOWER: with decorrelated lanes some lane always needs the read, so
-// the wave executes the LDS block anyway and only pays for the extra bookkeeping.)
+// 16-byte access per lane -- but the 64 lanes of a wave now sit T pairs apart along the map, so lanes of one
+// wave-instruction almost never hit the same cell: the same-address serialisation of ds_min_u64 (~1/3 of the kernel with
+// neighbouring points in neighbouring lanes) is gone, and with it the reason to read a cell before updating it -- the
+// update is one fire-and-forget LDS atomic and the stream never waits on the LDS.  Padding slots hold +inf and fail the
+// range gate.
 LSM2D_DEV void project_cloud_lanes(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin,
                                    u64* canvas, int tid, int nthreads) {
   const Iso T = Tin; ProjK P = Pin;
   asm volatile("" : "+v"(P.K01));        // keep K01 in a VGPR: fma(K00, th, K01) may read only one SGPR, the compiler would v_mov it per point
   if (T_steps <= 0) return;
   const int base = tid * T_steps;
-  float4 v = lane_xy[tid];
-  for (int t = 0; t < T_steps; ++t) {
-    const int tn = t + 1 < T_steps ? t + 1 : t;
-    const float4 nx = lane_xy[(size_t) tn * nthreads + tid];
-    project_point<false>(T, P, v.x, v.y, 2 * (base + t), canvas);
-    project_point<false>(T, P, v.z, v.w, 2 * (base + t) + 1, canvas);
-    v = nx;
+  // Buffer addressing: the cloud's base sits in a 4-SGPR resource, the lane adds a constant byte offset (voffset) and the row
+  // advances in the scalar offset -- the load address costs no vector instruction.  Two steps per trip with the two load
+  // buffers swapping roles, so no register copies either; each load has one whole pair of points of cover.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long pb = reinterpret_cast<unsigned long long>(lane_xy);       // wave-uniform, but it reached us through a
+  const unsigned pb_hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (pb >> 32));       // vector load: say so.  (The builtin returns
+  const unsigned pb_lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) pb);     // int: widen through unsigned, no sign extension)
+  float4* ubase = reinterpret_cast<float4*>(((unsigned long long) pb_hi << 32) | (unsigned long long) pb_lo);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, (short) 0, 0x7fffffff, 0x00020000);
+  const int lane_off = tid * (int) sizeof(float4), row_bytes = nthreads * (int) sizeof(float4);
+  int row = 0;                                           // < 2^31: ensure_lane_layout() keeps larger clouds off this path
+  auto load = [&](int r) {
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, r, 0);
+    return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+  };
+  int idx = 2 * base, t = 0;
+  float4 va = load(row);
+  for (; t + 2 <= T_steps; t += 2) {
+    const float4 vb = load(row + row_bytes);
+    project_point<false>(T, P, va.x, va.y, idx, canvas);
+    project_point<false>(T, P, va.z, va.w, idx + 1, canvas);
+    if (t + 2 < T_steps) row += 2 * row_bytes;            // else: a harmless re-read of the current row, never used
+    va = load(row);
+    project_point<false>(T, P, vb.x, vb.y, idx + 2, canvas);
+    project_point<false>(T, P, vb.z, vb.w, idx + 3, canvas);
+    idx += 4;
+  }
+  if (t < T_steps) {
+    project_point<false>(T, P, va.x, va.y, idx, canvas);
+    project_point<false>(T, P, va.z, va.w, idx + 1, canvas);
   }
 }
 
