@@ -417,8 +417,11 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   std::vector<int32_t> cell_base(nc), gcap(nc);
   int64_t cells = 0;
   for (int c = 0; c < nc; ++c) {
-    int cap = (int) ceil(3.0 * sqrt((double) cs->h_count[c]));
-    cap = cap < 16 ? 16 : (cap > 1024 ? 1024 : cap);
+    // cells per side: ~3 sqrt(n) for scan-sized clouds (their queries mostly find empty blocks; finer cells only add block
+    // levels), ~6 sqrt(n) for map-sized ones (dense walls: the 3x3 block of a converged query holds 3x fewer candidates).
+    // Measured on configs[1], role B: 3 sqrt(n) 3.12 ms, 6 sqrt(n) 2.95 ms, 12 sqrt(n) 3.24 ms (cell table out of L2).
+    int cap = (int) ceil((cs->h_count[c] >= 16384 ? 6.0 : 3.0) * sqrt((double) cs->h_count[c]));
+    cap = cap < 16 ? 16 : (cap > 2048 ? 2048 : cap);
     gcap[c] = cap; cell_base[c] = (int32_t) cells; cells += (int64_t) cap * cap + 1;
     if (cells > 0x7fffffff) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "grid: too many cells");
   }
@@ -437,7 +440,7 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   HIPCHK(ctx, hipMemcpyAsync(d_base, cell_base.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_gcap, gcap.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   GridBuildArgs A;
-  A.xy = cs->d_xy; A.start = cs->d_start; A.count = cs->d_count; A.n_clouds = nc; A.h_min = max_distance * 0.125f;
+  A.xy = cs->d_xy; A.start = cs->d_start; A.count = cs->d_count; A.n_clouds = nc; A.h_min = max_distance * 0.015625f;
   A.cell_base = d_base; A.gcap = d_gcap; A.meta = g.d_meta; A.cell_start = g.d_cell_start; A.cursor = g.d_cursor;
   A.sorted_idx = g.d_sorted_idx; A.sorted_xy = g.d_sorted_xy;
   hipLaunchKernelGGL(k_grid_build, dim3((unsigned) nc), dim3(1024), 0, ctx->stream, A);

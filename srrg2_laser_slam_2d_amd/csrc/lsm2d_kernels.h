@@ -62,7 +62,7 @@ struct CloudDev {            // device view of a cloud set
 };
 
 // exact nearest neighbour of q among the cloud's points within sqrt(md2); ties -> lowest index
-// (SURVEY.md App. D.2).  Cells are SMALLER than max_distance (h ~ max_distance/8): the search visits the
+// (SURVEY.md App. D.2).  Cells are SMALLER than max_distance (h >= max_distance/64, see ensure_grid): the search visits the
 // (2k+1)^2 block around q for k = 1, 2, 4, ... and stops as soon as the best distance is strictly inside the
 // block (every point outside it is farther than k*h, so it can neither win nor tie) or the block covers
 // max_distance.  Converged ICP queries finish in the first 3x3 block.
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_distmap_fill(const DistMeta* __restrict
 // One workgroup builds the grid of one cloud: bounding box -> cell size -> counting sort by cell.
 struct GridBuildArgs {
   const float2* xy; const int32_t* start; const int32_t* count; int32_t n_clouds;
-  float h_min;                  // max_distance / 8 (cells smaller than the gate; the query widens its block as needed)
+  float h_min;                  // max_distance / 64 (cells smaller than the gate; the query widens its block as needed)
   const int32_t* cell_base;     // [n_clouds] host-computed: room for gcap^2 + 1 entries per cloud
   const int32_t* gcap;          // [n_clouds] max grid dimension per cloud
   GridMeta* meta; int32_t* cell_start; int32_t* cursor; int32_t* sorted_idx; float2* sorted_xy;

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Every BASELINE.json configuration that is a bench.py line, one JSON line each -> gpurun_out/<tag>/bench_modes.jsonl
+# usage on the GPU box: bash tools/bench_modes.sh <tag>
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; tag=${1:-round}; O=$R/gpurun_out/$tag; mkdir -p $O; cd $R
+: > $O/bench_modes.jsonl
+run() { timeout -k 10 400 python bench.py "$@" 2>> $O/bench_modes.err | tail -1 >> $O/bench_modes.jsonl; echo "mode [$*] rc=$?"; }
+run                                                                  # configs[1], role A / projective (the headline line)
+run --role B --finder nn --cpu-sample 200                            # configs[1], role B / NN
+run --role A --finder nn --max-distance 0.3 --cpu-sample 100 --steps 5      # configs[1], role A / NN
+run --map-points 1000000 --cpu-sample 100 --steps 5                  # configs[4]
+run --scans 65536 --unique-scans 2048 --steps 3 --warmup 1 --cpu-sample 1000      # configs[3], one GPU's view
+run --scans 1 --map-points 10000 --steps 200 --warmup 20 --cpu-sample 1          # configs[0]
+python - <<PY
+import json
+for l in open("$O/bench_modes.jsonl"):
+    d = json.loads(l); c = d.get("cpu_baseline") or {}
+    print("%-110s | %9.0f /s | kernel %8.3f ms | cpu %s | ok=%s" % (d["config"]["workload"][:110], d["value"], d["roofline"]["kernel_ms"], c.get("value"), d["parity_ok"]))
+PY
