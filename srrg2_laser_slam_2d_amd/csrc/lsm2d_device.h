@@ -96,9 +96,9 @@ LSM2D_DEV float wrap_angle(float a) {
   return a;
 }
 
-// Correctly rounded sqrt for inputs in [1e-30, 1e36] (the range gate's r2): v_rsq_f32, s0 = x*y, one residual correction
+// Correctly rounded sqrt for inputs in [1e-30, FLT_MAX] (the range gate's r2 and beyond): v_rsq_f32, s0 = x*y, one residual correction
 // s0 + (x - s0*s0) * (y/2).  tools/fp_exact_check.hip compares it with sqrtf on every fp32 bit pattern of that interval
-// (1.84e9 inputs) on the MI355X: 0 mismatches (profiles/r01/fp_exact_full.log).  Six issue slots instead of the eleven of
+// (1.88e9 inputs) on the MI355X: 0 mismatches (profiles/r01/fp_exact_full.log).  Six issue slots instead of the eleven of
 // v_sqrt_f32 + the two-sided residual test hipcc emits for sqrtf().
 LSM2D_DEV float sqrt_rn_normal(float x) {
   const float y  = __builtin_amdgcn_rsqf(x);

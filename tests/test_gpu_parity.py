@@ -218,13 +218,15 @@ def test_multi_slice_sensor_offsets_and_prior(ctx, po):
     S0, S1 = np.array([0.2, 0.1, 0.1]), np.array([-0.3, 0.0, math.pi])
     scans = [synth.make_scans(world, synth.compose_poses(robot, S[None, :]), n_beams=721)[0] for S in (S0, S1)]
     x0 = synth.invert_poses(synth.compose_poses(robot, np.array([[0.04, -0.03, 0.03]])))[0].astype(np.float32)
+    # two different projectors (columns AND range gate): the slices share one moving canvas inside the kernel
     proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    proj1 = api.PointNormal2fProjectorPolar(541, -math.pi, math.pi, 0.5, 9.0)
     al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
     al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
         api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.9), sensor_in_robot=S0, robustifier=api.RobustifierCauchy(0.01),
         min_num_correspondences=5, fixed_slice_name="points_0", moving_slice_name="points"))
     al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
-        api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.8), sensor_in_robot=S1, min_num_correspondences=5,
+        api.CorrespondenceFinderProjective2f(ctx, proj1, 0.5, 0.8), sensor_in_robot=S1, min_num_correspondences=5,
         fixed_slice_name="points_1", moving_slice_name="points"))
     al.setFixed({"points_0": scans[0], "points_1": scans[1]}); al.setMoving({"points": m}); al.setMovingInFixed(x0)
     osl = [_oracle_slice(po, s.slice_params()) for s in al.param_slice_processors]

@@ -5,7 +5,8 @@
 //
 //   division  n/d, 0 < n <= d: every step scales exactly with powers of two (no subnormals inside the gate), so all
 //             2^23 x 2^23 mantissa pairs cover every admissible input; n = 1.m_n (or half of it when m_n > m_d).
-//   sqrt      every fp32 bit pattern in [1e-30, 1e36].
+//   sqrt      every fp32 bit pattern in [1e-30, FLT_MAX] (the gate's r2 lies in [1e-30, 1e36]; the lane-chunked stream also
+//             forms depths of points beyond range_max, which only have to stay above it).
 //
 // Column 0 of each table is the PRODUCTION function (lsm2d::div_rn_unit / lsm2d::sqrt_rn_normal, included from
 // csrc/lsm2d_device.h); the others are the longer sequence it replaced and the shorter ones that turn out not to be exact.
@@ -113,7 +114,7 @@ int main(int argc, char** argv) {
 
   // ---- sqrt
   CK(hipMemset(d_rep, 0, sizeof(Report)));
-  float flo = 1e-30f, fhi = 1e36f; uint32_t lo, hi; memcpy(&lo, &flo, 4); memcpy(&hi, &fhi, 4);
+  float flo = 1e-30f, fhi = 3.402823466e+38f; uint32_t lo, hi; memcpy(&lo, &flo, 4); memcpy(&hi, &fhi, 4);
   hipLaunchKernelGGL(k_sqrt, dim3(8192), dim3(256), 0, 0, lo, hi, d_rep);
   CK(hipDeviceSynchronize());
   CK(hipMemcpy(&h, d_rep, sizeof(h), hipMemcpyDeviceToHost));
