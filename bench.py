@@ -167,12 +167,17 @@ def main() -> None:
                                                               float(np.diff(wl.scan_offsets).mean()), args.beams, args.iterations)
         k_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_alignment * args.scans / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = None; valu = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written from the rocprofv3 --pmc passes, see profiles/README.md
         default_cfg = (args.role, args.finder, args.scans, args.map_points, args.iterations, args.beams) == ("A", "projective", 1000, 100000, 20, 1081)
         if os.path.exists(tpath) and default_cfg:
             try:
-                traffic = json.load(open(tpath)).get("k_align_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_align_hbm_bytes_per_launch")
+                vi = tj.get("k_align_valu_insts_per_launch")      # SQ_INSTS_VALU of the same launch: the limiter that matters here
+                if vi:
+                    visits = args.scans * args.iterations * (args.map_points + float(np.diff(wl.scan_offsets).mean())) / 64.0
+                    valu = {"insts_per_launch": vi, "insts_per_point_visit": vi / visits, "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
             except Exception:
                 traffic = None
         out = {
@@ -188,7 +193,7 @@ def main() -> None:
                        "iterations": args.iterations, "parallelism": "alignments sharded, map replicated (RCCL broadcast)"},
             "parity_ok": ok, "max_pose_err_m": float(err[:, :2].max()), "max_pose_err_rad": float(err[:, 2].max()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_align", "kernel_ms": k_ms,
+                         "traffic": traffic, "valu": valu, "kernel": "k_align", "kernel_ms": k_ms,
                          "note": "achieved = SURVEY.md 8(d) algorithmic bytes / launch time; the map (<= 8 MB of xy) is L2 / Infinity-Cache "
                                  "resident, so achieved can exceed the HBM peak: the measured limiter is VALU issue (DESIGN.md section 5)",
                          "algorithmic_bytes_per_launch": bytes_per_alignment * args.scans},
