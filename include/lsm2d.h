@@ -135,14 +135,16 @@ int  lsm2d_cloudset_create_from_device(lsm2d_context* ctx, const void* d_points_
                                        int32_t n_clouds, int64_t total_points, lsm2d_cloudset** out_set);
 /* a single growable cloud (count 0) with room for capacity_points: the device-resident local map / clipped scene */
 int  lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capacity_points, lsm2d_cloudset** out_set);
-/* refill an existing SINGLE-cloud set in place (no allocation); LSM2D_CAPACITY_EXCEEDED when it does not fit */
+/* refill an existing SINGLE-cloud set in place (no allocation); LSM2D_CAPACITY_EXCEEDED when it does not fit.  The points are
+ * copied into the set's pinned staging buffer before the call returns and travel asynchronously on the context's stream. */
 int  lsm2d_cloudset_upload(lsm2d_cloudset* set, const float* points_xynn, int64_t n_points);
 /* copy cloud `cloud_index` back to the host as (x, y, nx, ny) rows; *out_n = its size */
 int  lsm2d_cloudset_download(const lsm2d_cloudset* set, int32_t cloud_index, float* out_points_xynn, int64_t capacity, int64_t* out_n);
 void lsm2d_cloudset_destroy(lsm2d_cloudset* set);
 int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* set);
 int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* set);
-/* points in cloud `cloud_index` (-1 when out of range) */
+/* points in cloud `cloud_index` (-1 when out of range).  After an asynchronous lsm2d_clip_scene / lsm2d_merge_scene the size
+ * of the set they wrote is known to the device only; the size queries (and lsm2d_cloudset_download) then wait for the stream. */
 int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* set, int32_t cloud_index);
 
 /* ---- a3: PointNormal2fProjectorPolar::compute -------------------------------------------------
@@ -174,7 +176,10 @@ int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params,
  * as in both shipped configs, MULTI.json:673-683): what the sensor at robot_in_local_map * sensor_in_robot sees of
  * `full_scene` -- at most one point per projector column, ascending column, expressed in the ROBOT frame.
  * `clipped` is a reserved single-cloud set (capacity >= canvas_cols) that is overwritten and stays on the device,
- * ready to be the aligner's moving cloud.  out_source_idx (host, canvas_cols entries) may be NULL. */
+ * ready to be the aligner's moving cloud.  out_source_idx (host, canvas_cols entries) may be NULL.
+ * out_n_points == NULL (then out_source_idx must be NULL too): ASYNCHRONOUS -- the call only queues the work on the context's
+ * stream and nothing is copied back; lsm2d_align_batch (projective slices), lsm2d_merge_scene and another lsm2d_clip_scene accept
+ * the sets as they are, so a tracker step (clip -> upload -> align -> merge) synchronises once, for the aligner's pose. */
 int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* projector, const lsm2d_cloudset* full_scene,
                      int32_t scene_index, const float robot_in_local_map[3], const float sensor_in_robot[3],
                      lsm2d_cloudset* clipped, int32_t* out_n_points, int32_t* out_source_idx);
@@ -183,7 +188,8 @@ int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* projector, const
  * measurement_index, in its own sensor/robot frame) into the single-cloud reserved set `scene`, in place: per projector
  * column seen from measurement_in_scene a measurement point is merged into (|depth difference| < merge_threshold),
  * replaces (it lies behind) or is appended next to the scene's nearest point; measurement depths beyond
- * 0.9*range_max are ignored.  out_counts[3] = {new, merged, replaced} (may be NULL). */
+ * 0.9*range_max are ignored.  out_counts[3] = {new, merged, replaced} (may be NULL).
+ * out_scene_size == NULL (then out_counts must be NULL too): ASYNCHRONOUS, see lsm2d_clip_scene. */
 int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* projector, lsm2d_cloudset* scene,
                       const lsm2d_cloudset* measurement, int32_t measurement_index, const float measurement_in_scene[3],
                       float merge_threshold, int32_t* out_scene_size, int32_t* out_counts);

@@ -117,11 +117,43 @@ class CloudSet:
         self._h, self.n_clouds, self.n_points, self.counts, self.capacity = h, 1, 0, np.zeros(1, np.int64), int(capacity)
         return self
 
+    # n_points / counts of a reserved set can be "known to the device only" after an asynchronous clip / merge
+    # (SceneClipperProjective2D / MergerProjective2D with asynchronous=True): reading them then asks the library, which
+    # synchronises once.
+    @property
+    def n_points(self) -> int:
+        self._resolve()
+        return self._n_points
+
+    @n_points.setter
+    def n_points(self, v):
+        self._n_points = int(v)
+
+    @property
+    def counts(self) -> np.ndarray:
+        self._resolve()
+        return self._counts
+
+    @counts.setter
+    def counts(self, v):
+        self._counts = v
+
+    def _resolve(self):
+        if getattr(self, "_pending", False):
+            n = int(self._lib.lsm2d_cloudset_cloud_size(self._h, 0))
+            self._pending = False
+            self._n_points = n; self._counts = np.array([n], np.int64)
+
     def _set_count(self, n: int):
-        self.n_points = int(n); self.counts = np.array([int(n)], np.int64)
+        self._pending = False
+        self._n_points = int(n); self._counts = np.array([int(n)], np.int64)
+
+    def _set_pending(self):
+        self._pending = True
 
     def upload(self, points):
-        """Refill this single-cloud set in place (no allocation)."""
+        """Refill this single-cloud set in place (no allocation, no wait for the stream: the points are copied into the
+        set's pinned staging buffer before the call returns)."""
         pts = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
         check(self._lib.lsm2d_cloudset_upload(self._h, pts.ctypes.data_as(C.c_void_p), len(pts)), "lsm2d_cloudset_upload", self._ctx.handle)
         self._set_count(len(pts))
@@ -494,10 +526,14 @@ class SceneClipperProjective2D:
     keeps what the sensor sees of the local map, at most one point per projector column, in the robot frame.  The clipped
     scene stays on the device (a reserved CloudSet) and is what the tracker hands to the aligner as ``moving``."""
 
-    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, voxelize_resolution: float = 0.0):
+    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, voxelize_resolution: float = 0.0,
+                 asynchronous: bool = False):
         self._ctx = ctx
         self.param_projector = projector
         self.param_voxelize_resolution = voxelize_resolution
+        # asynchronous: compute() only queues the work -- nothing is copied back (source_indices stays empty) and the clipped
+        # set's size is fetched when somebody reads it; the aligner and the merger take such a set as it is
+        self.asynchronous = asynchronous
         self._full_scene = None
         self._clipped = None
         self._robot_in_local_map = np.zeros(3, np.float32)
@@ -527,6 +563,14 @@ class SceneClipperProjective2D:
         if self._clipped is None:
             self._clipped = CloudSet.reserved(self._ctx, cols)
         pr = self.param_projector.struct()
+        if self.asynchronous:
+            check(self._ctx._lib.lsm2d_clip_scene(self._ctx.handle, C.byref(pr), self._full_scene.handle, 0,
+                                                  self._robot_in_local_map.ctypes.data_as(C.c_void_p),
+                                                  self._sensor_in_robot.ctypes.data_as(C.c_void_p), self._clipped.handle, None, None),
+                  "lsm2d_clip_scene", self._ctx.handle)
+            self._clipped._set_pending()
+            self.source_indices = np.zeros(0, np.int32)
+            return self._clipped
         n = C.c_int32(0); src = np.empty(cols, np.int32)
         check(self._ctx._lib.lsm2d_clip_scene(self._ctx.handle, C.byref(pr), self._full_scene.handle, 0,
                                               self._robot_in_local_map.ctypes.data_as(C.c_void_p),
@@ -540,10 +584,12 @@ class SceneClipperProjective2D:
 class MergerProjective2D:
     """mapping/merger_projective_2d.{h,cpp}: folds a measurement into the device-resident scene, in place."""
 
-    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, merge_threshold: float = 0.2):
+    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, merge_threshold: float = 0.2,
+                 asynchronous: bool = False):
         self._ctx = ctx
         self.param_projector = projector
         self.param_merge_threshold = merge_threshold
+        self.asynchronous = asynchronous      # compute() only queues the merge; the scene's new size is fetched when it is read
         self._scene = None
         self._measurement = None
         self._measurement_in_scene = np.zeros(3, np.float32)
@@ -564,6 +610,14 @@ class MergerProjective2D:
         if self._scene is None or self._measurement is None:
             raise RuntimeError("MergerProjective2D::compute| missing scene or measurement")
         pr = self.param_projector.struct()
+        if self.asynchronous:
+            check(self._ctx._lib.lsm2d_merge_scene(self._ctx.handle, C.byref(pr), self._scene.handle, self._measurement.handle,
+                                                   self._measurement_index, self._measurement_in_scene.ctypes.data_as(C.c_void_p),
+                                                   float(self.param_merge_threshold), None, None),
+                  "lsm2d_merge_scene", self._ctx.handle)
+            self._scene._set_pending()
+            self.counts = (0, 0, 0)
+            return -1
         size = C.c_int32(0); counts = (C.c_int32 * 3)()
         check(self._ctx._lib.lsm2d_merge_scene(self._ctx.handle, C.byref(pr), self._scene.handle, self._measurement.handle,
                                                self._measurement_index, self._measurement_in_scene.ctypes.data_as(C.c_void_p),

@@ -53,12 +53,17 @@ struct lsm2d_cloudset {
   // lane-chunked copy of xy for k_align's streaming pass (built on first use, dropped when the contents change)
   mutable float4* d_lane_xy = nullptr; mutable long long* d_lane_start = nullptr; mutable int32_t* d_lane_T = nullptr;
   int32_t n_clouds = 0;
-  int64_t total = 0;          // logical points
+  mutable int64_t total = 0;  // logical points
   int64_t padded_total = 0;   // device points incl. even-alignment padding
   int64_t capacity = 0;       // > 0: a reserved single growable cloud (lsm2d_cloudset_create_reserved)
   float2* d_xy = nullptr; float2* d_nrm = nullptr;
   int32_t* d_start = nullptr; int32_t* d_count = nullptr;
-  std::vector<int32_t> h_start, h_count;
+  std::vector<int32_t> h_start; mutable std::vector<int32_t> h_count;
+  // Asynchronous clip / merge leave the size of a reserved set known to the device only: h_count[0] is then an UPPER BOUND
+  // and count_pending is set; kernels read d_count, and whatever needs the exact number calls resolve_count() (one sync).
+  mutable bool count_pending = false;
+  // per-set pinned staging for lsm2d_cloudset_upload, so an upload does not have to wait for the stream
+  void* h_upload = nullptr; size_t h_upload_bytes = 0; hipEvent_t ev_upload = nullptr;
 };
 
 #define HIPCHK(ctx, call)                                                                           \
@@ -291,11 +296,25 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_lane_xy) (void) hipFree(cs->d_lane_xy);
   if (cs->d_lane_start) (void) hipFree(cs->d_lane_start);
   if (cs->d_lane_T) (void) hipFree(cs->d_lane_T);
+  if (cs->ev_upload) { (void) hipEventSynchronize(cs->ev_upload); (void) hipEventDestroy(cs->ev_upload); }
+  if (cs->h_upload) (void) hipHostFree(cs->h_upload);
   delete cs;
 }
+static int resolve_count(const lsm2d_cloudset* cs) {
+  if (!cs || !cs->count_pending) return LSM2D_SUCCESS;
+  lsm2d_context* ctx = cs->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t n = 0;
+  HIPCHK(ctx, hipMemcpy(&n, cs->d_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+  cs->h_count[0] = n; cs->total = n; cs->count_pending = false;
+  return LSM2D_SUCCESS;
+}
 extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
-extern "C" int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* cs) { return cs ? cs->total : 0; }
-extern "C" int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* cs, int32_t i) { return (cs && i >= 0 && i < cs->n_clouds) ? cs->h_count[i] : -1; }
+extern "C" int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* cs) { return (cs && resolve_count(cs) == LSM2D_SUCCESS) ? cs->total : 0; }
+extern "C" int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* cs, int32_t i) {
+  return (cs && i >= 0 && i < cs->n_clouds && resolve_count(cs) == LSM2D_SUCCESS) ? cs->h_count[i] : -1;
+}
 
 static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents changed: cached NN grids are stale
   for (auto& g : cs->grids) {
@@ -341,22 +360,36 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
   if (n > cap) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "cloudset_upload: does not fit the allocation");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   cloudset_drop_grids(cs);
-  // split on the host into the pinned staging buffer, then two plain copies (no allocation, no kernel)
-  int rc = ensure_stage(ctx, sizeof(float) * 4 * (size_t) (n > 0 ? n : 1)); if (rc) return rc;
-  float2* hxy = (float2*) ctx->h_stage; float2* hn = hxy + n;
+  // split on the host into the set's own pinned staging buffer, then two plain async copies: no allocation, no kernel and no
+  // wait for the stream -- only for this set's PREVIOUS upload (an event), whose source the buffer still is until it ran
+  const size_t need = sizeof(float) * 4 * (size_t) (n > 0 ? n : 1) + 16;
+  if (cs->ev_upload) HIPCHK(ctx, hipEventSynchronize(cs->ev_upload));
+  else HIPCHK(ctx, hipEventCreateWithFlags(&cs->ev_upload, hipEventDisableTiming));
+  if (need > cs->h_upload_bytes) {
+    if (cs->h_upload) { HIPCHK(ctx, hipHostFree(cs->h_upload)); cs->h_upload = nullptr; cs->h_upload_bytes = 0; }
+    const size_t want = cs->capacity > 0 ? sizeof(float) * 4 * (size_t) cs->capacity + 16 : need;
+    HIPCHK(ctx, hipHostMalloc(&cs->h_upload, want > need ? want : need, hipHostMallocDefault));
+    cs->h_upload_bytes = want > need ? want : need;
+  }
+  float2* hxy = (float2*) cs->h_upload; float2* hn = hxy + n;
   for (int64_t i = 0; i < n; ++i) { hxy[i] = make_float2(pts[4 * i], pts[4 * i + 1]); hn[i] = make_float2(pts[4 * i + 2], pts[4 * i + 3]); }
   if (n) {
     HIPCHK(ctx, hipMemcpyAsync(cs->d_xy, hxy, sizeof(float2) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(cs->d_nrm, hn, sizeof(float2) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
   }
-  rc = set_single_count(ctx, cs, (int32_t) n); if (rc) return rc;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the staging buffer is reused by the next call
+  cs->count_pending = false;
+  // the count travels in the same staging buffer (h_count may be rewritten by the host before the copy runs)
+  int32_t* hcnt = (int32_t*) ((char*) cs->h_upload + cs->h_upload_bytes - sizeof(int32_t));
+  cs->h_count[0] = (int32_t) n; cs->total = n; *hcnt = (int32_t) n;
+  HIPCHK(ctx, hipMemcpyAsync(cs->d_count, hcnt, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(cs->ev_upload, ctx->stream));
   return LSM2D_SUCCESS;
 }
 
 extern "C" int lsm2d_cloudset_download(const lsm2d_cloudset* cs, int32_t ci, float* out, int64_t capacity, int64_t* out_n) {
   if (!cs || !cs->ctx || !out_n || !valid_cloud_index_fwd(cs, ci)) return fail(cs ? cs->ctx : nullptr, LSM2D_BAD_ARGUMENT, "cloudset_download: bad argument");
   lsm2d_context* ctx = cs->ctx;
+  { const int rc0 = resolve_count(cs); if (rc0) return rc0; }
   const int64_t n = cs->h_count[ci];
   *out_n = n;
   if (n > capacity || (n > 0 && !out)) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "cloudset_download: out buffer too small");
@@ -454,7 +487,7 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
 
 // lane-chunked copy of every cloud for k_align's projective streaming pass (project_cloud_lanes in lsm2d_device.h)
 static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
-  if (cs->d_lane_xy) return LSM2D_SUCCESS;
+  if (cs->d_lane_xy || cs->count_pending) return LSM2D_SUCCESS;     // a size-pending set is a clipped scene: small, and building needs a sync
   const int nc = cs->n_clouds;
   bool any_big = false;                       // every cloud <= one pair per thread: the plain layout already is lane-chunked
   for (int c = 0; c < nc; ++c) if (((long long) cs->h_count[c] + 1) / 2 > kAlignBlock) { any_big = true; break; }
@@ -632,9 +665,11 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
 extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* scene, int32_t si,
                                 const float robot_in_local_map[3], const float sensor_in_robot[3], lsm2d_cloudset* clipped,
                                 int32_t* out_n, int32_t* out_src) {
-  if (!ctx || !pr || !robot_in_local_map || !sensor_in_robot || !clipped || !out_n || !valid_cloud_index(scene, si) || clipped->n_clouds != 1 ||
-      clipped == scene)
+  if (!ctx || !pr || !robot_in_local_map || !sensor_in_robot || !clipped || !valid_cloud_index(scene, si) || clipped->n_clouds != 1 ||
+      clipped == scene || (!out_n && out_src))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "clip_scene: bad argument");
+  // out_n == NULL: asynchronous -- nothing comes back, the clipped set's size stays on the device until somebody asks
+  if (scene->count_pending && scene->h_count[si] > 32768) { const int rc0 = resolve_count(scene); if (rc0) return rc0; }
   ProjK P;
   if (!make_projk(*pr, &P)) return fail(ctx, LSM2D_BAD_ARGUMENT, "clip_scene: bad projector");
   const int64_t cap = clipped->capacity > 0 ? clipped->capacity : clipped->padded_total - 2;
@@ -659,7 +694,7 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   A.out_xy = clipped->d_xy; A.out_nrm = clipped->d_nrm; A.out_src = (int32_t*) ((char*) ctx->d_scratch + o_src);
   A.out_count = (int32_t*) ((char*) ctx->d_scratch + o_cnt); A.out_count_dev = clipped->d_count;
   if (small) {
-    ClipSmallArgs CS; CS.xy = A.xy; CS.nrm = A.nrm; CS.n = scene->h_count[si]; CS.proj = P; CS.emit = A;
+    ClipSmallArgs CS; CS.xy = A.xy; CS.nrm = A.nrm; CS.n = scene->h_count[si]; CS.n_dev = scene->count_pending ? scene->d_count : nullptr; CS.proj = P; CS.emit = A;
     hipLaunchKernelGGL(k_clip_small, dim3(1), dim3(kFindBlock), sizeof(u64) * (size_t) P.cols, ctx->stream, CS);
   } else {
     hipLaunchKernelGGL(k_clip_emit, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
@@ -667,10 +702,14 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;
+  if (!out_n) {                               // at most one point per column
+    clipped->h_count[0] = P.cols; clipped->total = P.cols; clipped->count_pending = true;
+    return LSM2D_SUCCESS;
+  }
   HIPCHK(ctx, hipMemcpyAsync((char*) ctx->h_stage + o_src, (char*) ctx->d_scratch + o_src, bytes - o_src, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const int32_t n = *(const int32_t*) ((char*) ctx->h_stage + o_cnt);
-  clipped->h_count[0] = n; clipped->total = n; *out_n = n;
+  clipped->h_count[0] = n; clipped->total = n; clipped->count_pending = false; *out_n = n;
   if (out_src) memcpy(out_src, (char*) ctx->h_stage + o_src, sizeof(int32_t) * (size_t) n);
   return LSM2D_SUCCESS;
 }
@@ -679,11 +718,19 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
 extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, lsm2d_cloudset* scene, const lsm2d_cloudset* meas,
                                  int32_t mi, const float measurement_in_scene[3], float merge_threshold, int32_t* out_size,
                                  int32_t* out_counts) {
-  if (!ctx || !pr || !scene || !measurement_in_scene || !out_size || !valid_cloud_index(meas, mi) || scene->n_clouds != 1 || scene == meas)
+  if (!ctx || !pr || !scene || !measurement_in_scene || !valid_cloud_index(meas, mi) || scene->n_clouds != 1 || scene == meas || (!out_size && out_counts))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "merge_scene: bad argument");
   ProjK P;
   if (!make_projk(*pr, &P)) return fail(ctx, LSM2D_BAD_ARGUMENT, "merge_scene: bad projector");
   const int64_t cap = scene->capacity > 0 ? scene->capacity : scene->padded_total - 2;
+  // out_size == NULL: asynchronous.  Sizes only the device knows are upper bounds here; when a bound no longer settles a
+  // decision (room left, single-workgroup path) it is replaced by the real number (one synchronisation)
+  if (scene->count_pending && ((int64_t) scene->h_count[0] + P.cols > cap || scene->h_count[0] > 32768)) { const int rc0 = resolve_count(scene); if (rc0) return rc0; }
+  if (meas->count_pending && meas->h_count[mi] > 32768) { const int rc0 = resolve_count(meas); if (rc0) return rc0; }
+  if ((int) (sizeof(u64) * 2 * (size_t) P.cols) > ctx->max_dyn_lds) {       // multi-launch path: it takes the sizes by value
+    int rc0 = resolve_count(scene); if (rc0) return rc0;
+    rc0 = resolve_count(meas); if (rc0) return rc0;
+  }
   const int n_scene = scene->h_count[0], n_meas = meas->h_count[mi];
   if ((int64_t) n_scene + P.cols > cap) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "merge_scene: scene set has no room for canvas_cols more points");
   if ((int) (sizeof(u64) * (size_t) P.cols) > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "merge_scene: canvas does not fit LDS");
@@ -707,6 +754,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
     MS.m.far_limit = 0.9f * pr->range_max; MS.m.merge_threshold = merge_threshold;
     MS.m.out = (int32_t*) (ds + o_out); MS.m.count_dev = scene->d_count;
     MS.proj = P; MS.Tinv = Tinv; MS.M = M; MS.n_meas = n_meas;
+    MS.n_scene_dev = scene->count_pending ? scene->d_count : nullptr; MS.n_meas_dev = meas->count_pending ? meas->d_count + mi : nullptr;
     hipLaunchKernelGGL(k_merge_small, dim3(1), dim3(kFindBlock), sizeof(u64) * 2 * (size_t) P.cols, ctx->stream, MS);
     HIPCHK(ctx, hipGetLastError());
   } else {
@@ -726,10 +774,14 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;
+  if (!out_size) {                            // a merge appends at most one point per column
+    scene->h_count[0] = n_scene + P.cols; scene->total = scene->h_count[0]; scene->count_pending = true;
+    return LSM2D_SUCCESS;
+  }
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ds + o_out, 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const int32_t* h = (const int32_t*) ctx->h_stage;
-  scene->h_count[0] = h[0]; scene->total = h[0]; *out_size = h[0];
+  scene->h_count[0] = h[0]; scene->total = h[0]; scene->count_pending = false; *out_size = h[0];
   if (out_counts) { out_counts[0] = h[1]; out_counts[1] = h[2]; out_counts[2] = h[3]; }
   return LSM2D_SUCCESS;
 }
@@ -739,6 +791,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
 extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* cloud, int32_t ci,
                              const float pose[3], int32_t* out_src, float* out_depth, float* out_xynn) {
   if (!ctx || !pr || !pose || !valid_cloud_index(cloud, ci)) return fail(ctx, LSM2D_BAD_ARGUMENT, "project: bad argument");
+  { const int rc0 = resolve_count(cloud); if (rc0) return rc0; }
   ProjectArgs A;
   if (!make_projk(*pr, &A.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "project: bad projector");
   const size_t lds = sizeof(u64) * (size_t) A.proj.cols;
@@ -768,6 +821,7 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
   if (!ctx || !sp || !pose || !out_n || !valid_cloud_index(fixed, fi) || !valid_cloud_index(moving, mi) || capacity < 0 ||
       (capacity > 0 && !out_pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad argument");
+  { int rc0 = resolve_count(fixed); if (rc0) return rc0; rc0 = resolve_count(moving); if (rc0) return rc0; }
   *out_n = 0;
   if (sp->finder == LSM2D_FINDER_NN || sp->finder == LSM2D_FINDER_DISTMAP) {
     if (sp->finder == LSM2D_FINDER_NN && !(sp->max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: max_distance must be > 0");
@@ -829,6 +883,7 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   if (!ctx || !sp || !pose || !out_H || !out_b || !valid_cloud_index(fixed, fi) || !valid_cloud_index(moving, mi) || n_pairs < 0 ||
       (n_pairs > 0 && !pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "linearize: bad argument");
+  { int rc0 = resolve_count(fixed); if (rc0) return rc0; rc0 = resolve_count(moving); if (rc0) return rc0; }
   for (int32_t k = 0; k < n_pairs; ++k)
     if (pairs[k].fixed_idx < 0 || pairs[k].fixed_idx >= fixed->h_count[fi] || pairs[k].moving_idx < 0 || pairs[k].moving_idx >= moving->h_count[mi])
       return fail(ctx, LSM2D_BAD_ARGUMENT, "linearize: correspondence index out of range");
@@ -903,6 +958,9 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     SliceDev& S = A.s[s];
     const lsm2d_cloudset* f = b->fixed[s]; const lsm2d_cloudset* m = b->moving[s];
     if (!f || !m || f->ctx != ctx || m->ctx != ctx) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: cloud set missing or from another context");
+    // sizes that only the device knows yet (asynchronous clip / merge) are fine for the projective finder -- the kernels read the
+    // device-side counts and the host needs upper bounds only; the search structures of the other finders need the numbers
+    if (sp.finder != LSM2D_FINDER_PROJECTIVE) { int rc0 = resolve_count(f); if (rc0) return rc0; rc0 = resolve_count(m); if (rc0) return rc0; }
     if (sp.finder != LSM2D_FINDER_PROJECTIVE && sp.finder != LSM2D_FINDER_NN && sp.finder != LSM2D_FINDER_DISTMAP)
       return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: unknown finder");
     if (sp.finder == LSM2D_FINDER_PROJECTIVE) {

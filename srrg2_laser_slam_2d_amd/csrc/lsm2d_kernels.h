@@ -905,7 +905,8 @@ __global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A);
 
 // small scenes (the tracker's local map between key frames): clipper and merger as ONE workgroup-resident kernel each --
 // z-buffers in LDS, no global canvas, no memsets, one launch instead of three resp. six
-struct ClipSmallArgs { const float2* xy; const float2* nrm; int32_t n; ProjK proj; ClipEmitArgs emit; };
+// n_dev: when non-null the scene's size is only known on the device (its set was last written by an asynchronous clip / merge)
+struct ClipSmallArgs { const float2* xy; const float2* nrm; int32_t n; const int32_t* n_dev; ProjK proj; ClipEmitArgs emit; };
 
 LSM2D_DEV void clip_emit_body(const ClipEmitArgs& A, const u64* canvas, int* s_wave_tot, int* s_base, int tid) {
   for (int c0 = 0; c0 < A.cols; c0 += kFindBlock) {
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(kFindBlock) void k_clip_small(const ClipSmallArgs A
   for (int i = tid; i < A.proj.cols; i += kFindBlock) can[i] = kEmptyCell;
   if (tid == 0) s_base = 0;
   __syncthreads();
-  project_cloud(A.xy, A.n, A.emit.T, A.proj, can, tid, kFindBlock);
+  project_cloud(A.xy, A.n_dev ? *A.n_dev : A.n, A.emit.T, A.proj, can, tid, kFindBlock);
   __syncthreads();
   clip_emit_body(A.emit, can, s_wave_tot, &s_base, tid);
 }
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(kFindBlock) void k_merge_apply(const MergeArgs A) {
 }
 
 // small scene: transform + both projections + column walk in one workgroup (mxy / mnrm hold the measurement in ITS frame)
-struct MergeSmallArgs { MergeArgs m; ProjK proj; Iso Tinv, M; int32_t n_meas; };
+struct MergeSmallArgs { MergeArgs m; ProjK proj; Iso Tinv, M; int32_t n_meas; const int32_t* n_scene_dev; const int32_t* n_meas_dev; };   // *_dev: see ClipSmallArgs
 
 __global__ __launch_bounds__(kFindBlock) void k_merge_small(const MergeSmallArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1035,14 +1036,17 @@ __global__ __launch_bounds__(kFindBlock) void k_merge_small(const MergeSmallArgs
   for (int i = tid; i < A.proj.cols; i += kFindBlock) { scan[i] = kEmptyCell; mcan[i] = kEmptyCell; }
   if (tid < 4) s_cnt[tid] = 0;
   __syncthreads();
-  project_cloud(A.m.sxy, A.m.n_scene, A.Tinv, A.proj, scan, tid, kFindBlock);
-  for (int i = tid; i < A.n_meas; i += kFindBlock) {             // measurement -> scene frame -> camera frame
-    const float2 p = A.m.mxy[i];
+  MergeArgs m = A.m;
+  if (A.n_scene_dev) m.n_scene = *A.n_scene_dev;
+  const int n_meas = A.n_meas_dev ? *A.n_meas_dev : A.n_meas;
+  project_cloud(m.sxy, m.n_scene, A.Tinv, A.proj, scan, tid, kFindBlock);
+  for (int i = tid; i < n_meas; i += kFindBlock) {               // measurement -> scene frame -> camera frame
+    const float2 p = m.mxy[i];
     float x, y; xf_point(A.M, p.x, p.y, x, y);
     project_point(A.Tinv, A.proj, x, y, i, mcan);
   }
   __syncthreads();
-  merge_apply_body(A.m, scan, mcan, &A.M, s_wave_tot, s_cnt, tid);
+  merge_apply_body(m, scan, mcan, &A.M, s_wave_tot, s_cnt, tid);
 }
 
 // split a single device cloud back into AoS (download)

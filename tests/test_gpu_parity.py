@@ -519,6 +519,72 @@ def test_tracker_step_clip_align_merge_device_resident(ctx, po):
     assert n == len(want) and merger.counts == counts and np.array_equal(local_map.download(), want)
 
 
+def test_asynchronous_tracker_chain_equals_synchronous(ctx, po):
+    """clip -> upload scans -> align -> merge x2 for several scans, once with every call synchronous and once with the clipper
+    and the merger asynchronous (sizes known to the device only, one host synchronisation per step: the aligner's pose).
+    Poses and the final local map must be IDENTICAL, and the map must equal the oracle's chain."""
+    world = synth.make_world(3)
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    S = [np.float32([0.2, 0.1, 0.1]), np.float32([-0.3, 0.0, math.pi])]
+    robots = synth.sample_poses(world, 1, seed=5)
+    traj = [robots[0]]
+    for k in range(5):
+        traj.append(synth.compose_poses(traj[-1][None, :], np.array([[0.05, 0.01, 0.02]]))[0])
+    scans = [[synth.make_scans(world, synth.compose_poses(np.array([t]), s[None, :].astype(np.float64)), n_beams=721, noise_sigma=0.005, seed=17 + k)[0]
+              for s in S] for k, t in enumerate(traj)]
+
+    def run(asynchronous):
+        local_map = api.CloudSet.reserved(ctx, 40000); local_map.upload(np.zeros((0, 4), np.float32))
+        clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=asynchronous); clipper.setFullScene(local_map)
+        merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=asynchronous); merger.setScene(local_map)
+        sets = [api.CloudSet.reserved(ctx, 1024), api.CloudSet.reserved(ctx, 1024)]
+        al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
+        for i, s in enumerate(S):
+            al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
+                api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.8), sensor_in_robot=s, min_num_correspondences=5,
+                fixed_slice_name="points_%d" % i, moving_slice_name="points"))
+        est = traj[0].copy(); poses = []
+        for i, s in enumerate(S):            # start: both scans merged at the true pose
+            sets[i].upload(scans[0][i]); merger.setMeasurement(sets[i])
+            merger.setMeasurementInScene(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0]); merger.compute()
+        for k in range(1, len(traj)):
+            guess = synth.compose_poses(est[None, :], np.array([[0.04, 0.0, 0.03]]))[0].astype(np.float32)
+            clipper.setRobotInLocalMap(guess); clipper.setSensorInRobot(S[0])
+            clipped = clipper.compute()
+            for i in range(2):
+                sets[i].upload(scans[k][i])
+            al.setFixed({"points_0": sets[0], "points_1": sets[1]}); al.setMoving({"points": clipped}); al.setMovingInFixed([0, 0, 0])
+            assert al.compute() == 0
+            x = al.movingInFixed().astype(np.float64)
+            est = synth.compose_poses(guess[None, :].astype(np.float64), synth.invert_poses(x[None, :]))[0]
+            poses.append(est.copy())
+            for i, s in enumerate(S):
+                merger.setMeasurement(sets[i]); merger.setMeasurementInScene(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0])
+                merger.compute()
+        return np.array(poses), local_map.download(), local_map.n_points
+
+    p_sync, m_sync, n_sync = run(False)
+    p_async, m_async, n_async = run(True)
+    assert n_sync == n_async == len(m_sync) and n_sync > 400
+    assert np.array_equal(p_sync, p_async) and np.array_equal(m_sync, m_async)
+    assert np.abs(p_sync - np.array(traj[1:]))[:, :2].max() < 0.03
+    # the same chain on the oracle (its poses feed its own merges; the GPU's differ by ~1e-7, so compare sizes and geometry)
+    host_map = np.zeros((0, 4), np.float32); est = traj[0].copy()
+    for i, s in enumerate(S):
+        host_map, _ = po.merge_scene(opr, host_map, scans[0][i], np.float32(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0]), 0.2)
+    osl = [po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.8, min_num_correspondences=5, sensor_in_robot=tuple(s)) for s in S]
+    for k in range(1, len(traj)):
+        guess = synth.compose_poses(est[None, :], np.array([[0.04, 0.0, 0.03]]))[0].astype(np.float32)
+        oclip, _ = po.clip_scene(opr, host_map, guess, S[0])
+        r = po.align(po.aligner_params(10), osl, scans[k], [oclip, oclip], np.zeros(3, np.float32))
+        est = synth.compose_poses(guess[None, :].astype(np.float64), synth.invert_poses(r["pose"][None, :].astype(np.float64)))[0]
+        assert np.abs(est - p_sync[k - 1])[:2].max() < 1e-4
+        for i, s in enumerate(S):
+            host_map, _ = po.merge_scene(opr, host_map, scans[k][i], np.float32(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0]), 0.2)
+    assert abs(len(host_map) - n_sync) <= 0.02 * n_sync
+
+
 def test_loop_closure_sweep_acceptance(ctx, po):
     """Row f3: a sweep of candidate (scan, initial guess) pairs against one submap, as MultiLoopDetectorBruteForce2D does with
     relocalize_aligner (30 iterations, Cauchy 0.05, point_distance 1.414: MULTI.json:572-630,771-784), then the acceptance

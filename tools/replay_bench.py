@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--scan-noise", type=float, default=0.01)
+    ap.add_argument("--sync-calls", action="store_true",
+                    help="every clip / merge call waits for its result (5 host synchronisations per step); default: the clipper and the "
+                         "merger only queue their work and the step synchronises once, for the aligner's pose")
     ap.add_argument("--chained", action="store_true",
                     help="let the GPU pipeline run on its own state for the whole trajectory (reports drift); default is lockstep: "
                          "before every step the GPU state is reset to the CPU state, so differences are per-step")
@@ -55,8 +58,8 @@ def main():
     opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
     ctx = api.Context(0)
     local_map = api.CloudSet.reserved(ctx, 400000)
-    clipper = api.SceneClipperProjective2D(ctx, proj); clipper.setFullScene(local_map)
-    merger = api.MergerProjective2D(ctx, proj, 0.2); merger.setScene(local_map)
+    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=not args.sync_calls); clipper.setFullScene(local_map)
+    merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=not args.sync_calls); merger.setScene(local_map)
     al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
     al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
         api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.9), sensor_in_robot=S0, robustifier=api.RobustifierCauchy(0.01),
@@ -118,6 +121,7 @@ def main():
         err_truth.append(np.abs(est_gpu - traj[k])[:2].max())
         assert status == r["status"], (k, status, r["status"])
     out = {"mode": "chained" if args.chained else "lockstep (GPU state reset to the CPU state before every step)",
+           "calls": "synchronous" if args.sync_calls else "asynchronous clip / upload / merge, one synchronisation per step",
            "config": "configs[2]: synthetic MULTI-parameter replay (721 cols, 10 its, 2 laser slices + odometry prior, clip+merge)",
            "gpu_phase_ms_per_step": {k: 1e3 * v / args.steps for k, v in phase.items()},
            "steps": args.steps, "gpu_ms_per_step_wall": 1e3 * t_gpu / args.steps, "gpu_align_kernel_ms_per_step": gpu_kernel_ms / args.steps,
