@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Tracker-step latency through the C ABI alone: builds tools/cpp/track_step_bench.cpp with g++ against liblsm2d_hip.so, feeds
+it one synthetic scene (MULTI.json parameters, as tools/replay_bench.py) and prints its JSON lines (synchronous and
+asynchronous calls) plus the CPU oracle's time for the same step.
+    python tools/track_step_bench.py [--steps 2000]"""
+import argparse, json, math, os, subprocess, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from srrg2_laser_slam_2d_amd import synth
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=2000); args = ap.parse_args()
+    from oracle import pyoracle as po          # the checker: builds the reference local map and times the CPU step
+    world = synth.make_world(5)
+    S = [np.float32([0.2, 0.1, 0.1]), np.float32([-0.3, 0.0, math.pi])]
+    opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    traj = [synth.sample_poses(world, 1, seed=21)[0]]
+    for k in range(12):
+        traj.append(synth.compose_poses(traj[-1][None, :], np.array([[0.05, 0.0, 0.02]]))[0])
+    host_map = np.zeros((0, 4), np.float32)
+    for k, t in enumerate(traj[:-1]):          # a local map as the tracker has it between key frames
+        for s in S:
+            sc = synth.make_scans(world, synth.compose_poses(np.array([t]), s[None, :].astype(np.float64)), n_beams=721, noise_sigma=0.01, seed=3 + k)[0]
+            host_map, _ = po.merge_scene(opr, host_map, sc, np.float32(synth.compose_poses(t[None, :], s[None, :].astype(np.float64))[0]), 0.2)
+    scans = [synth.make_scans(world, synth.compose_poses(np.array([traj[-1]]), s[None, :].astype(np.float64)), n_beams=721, noise_sigma=0.01, seed=99)[0] for s in S]
+    guess = synth.compose_poses(traj[-1][None, :], np.array([[0.03, -0.02, 0.02]]))[0]
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "track_step_bench"); lib = os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "lib")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cpp", "track_step_bench.cpp"),
+                        "-L" + lib, "-llsm2d_hip", "-Wl,-rpath," + lib, "-o", exe], check=True)
+        host_map.tofile(os.path.join(d, "map.bin")); scans[0].tofile(os.path.join(d, "s0.bin")); scans[1].tofile(os.path.join(d, "s1.bin"))
+        out = {"local_map_points": int(len(host_map)), "scan_points": [int(len(s)) for s in scans]}
+        for mode in (0, 1):
+            r = subprocess.run([exe, os.path.join(d, "map.bin"), os.path.join(d, "s0.bin"), os.path.join(d, "s1.bin"),
+                                repr(float(guess[0])), repr(float(guess[1])), repr(float(guess[2])), str(args.steps), str(mode)],
+                               check=True, capture_output=True, text=True, timeout=300)
+            out["c_abi_async" if mode else "c_abi_sync"] = json.loads(r.stdout.strip().splitlines()[-1])
+    # the same step on the CPU oracle
+    osl = [po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.9, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.01, min_num_correspondences=5, sensor_in_robot=tuple(S[0])),
+           po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.8, min_num_correspondences=5, sensor_in_robot=tuple(S[1]))]
+    omega = np.diag([100.0, 100.0, 100.0]).astype(np.float32)
+    reps = 200; t0 = time.perf_counter()
+    for _ in range(reps):
+        g32 = guess.astype(np.float32)
+        oclip, _ = po.clip_scene(opr, host_map, g32, S[0])
+        r = po.align(po.aligner_params(10, prior_z=[0, 0, 0], prior_omega=omega), osl, scans, [oclip, oclip], np.zeros(3, np.float32))
+        est = synth.compose_poses(guess[None, :], synth.invert_poses(r["pose"][None, :].astype(np.float64)))[0]
+        hm = host_map
+        for sc, s in zip(scans, S):
+            hm, _ = po.merge_scene(opr, hm, sc, np.float32(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0]), 0.2)
+    out["cpu_oracle_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / reps
+    out["pose_diff_gpu_vs_cpu"] = [float(abs(a - b)) for a, b in zip(out["c_abi_async"]["est_on_fresh_map"], est)]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
