@@ -713,6 +713,46 @@ def test_abi_error_paths_and_limits(ctx, small_workload):
         alc.compute_batch([s], [m], wl.x0)
 
 
+def test_pending_sizes_are_resolved_where_the_host_needs_them(ctx, po):
+    """Asynchronous clip / merge leave sizes on the device.  Every consumer must still be right: a point-query finder on a
+    size-pending set (its grid needs the number), a download, a merge whose size BOUND no longer fits the capacity although the
+    real size does, many asynchronous merges in a row (bound >> real size), and the host buffer of an upload reused at once."""
+    world = synth.make_world(4)
+    proj = api.PointNormal2fProjectorPolar(361, -math.pi, math.pi, 0.3, 20.0)
+    opr = po.Projector(361, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    pose = synth.sample_poses(world, 1, seed=3)[0]
+    scan = synth.make_scans(world, pose[None, :], n_beams=361, noise_sigma=0.004, seed=8)[0]
+    # upload: the caller may overwrite its buffer right after the call
+    buf = scan.copy()
+    meas = api.CloudSet.reserved(ctx, 512); meas.upload(buf); buf[:] = 7.0
+    assert np.array_equal(meas.download(), scan)
+    # capacity just above what 40 merges of the SAME scan need (they mostly merge into existing points), far below 40 * cols
+    local_map = api.CloudSet.reserved(ctx, 3 * 361); local_map.upload(np.zeros((0, 4), np.float32))
+    merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=True); merger.setScene(local_map); merger.setMeasurement(meas)
+    merger.setMeasurementInScene(pose.astype(np.float32))
+    host_map = np.zeros((0, 4), np.float32)
+    for _ in range(40):
+        assert merger.compute() == -1
+        host_map, _ = po.merge_scene(opr, host_map, scan, pose.astype(np.float32), 0.2)
+    assert local_map.n_points == len(host_map) and np.array_equal(local_map.download(), host_map)
+    # asynchronous clip, then consumers that need the exact size
+    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True); clipper.setFullScene(local_map)
+    clipper.setRobotInLocalMap(pose.astype(np.float32)); clipper.setSensorInRobot([0, 0, 0])
+    clipped = clipper.compute()
+    oclip, _ = po.clip_scene(opr, host_map, pose.astype(np.float32), np.zeros(3, np.float32))
+    kd = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=0.8)
+    kd.setFixed(clipped); kd.setMoving(meas); kd.setLocalMapInSensor([0, 0, 0])         # fixed = the size-pending clipped set
+    pairs = kd.compute()
+    want = po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.3), oclip, scan, np.zeros(3, np.float32))
+    assert np.array_equal(pairs, want) and len(pairs) > 100
+    assert clipped.n_points == len(oclip) and np.array_equal(clipped.download(), oclip)
+    # a second asynchronous clip straight from a size-pending scene (merge -> clip without any size query in between)
+    merger.compute(); host_map, _ = po.merge_scene(opr, host_map, scan, pose.astype(np.float32), 0.2)
+    clipped = clipper.compute()
+    oclip, _ = po.clip_scene(opr, host_map, pose.astype(np.float32), np.zeros(3, np.float32))
+    assert np.array_equal(clipped.download(), oclip)
+
+
 # ---- RawDataPreprocessorProjective2D (row f2) --------------------------------------------------------------------
 def test_preprocessor_reference_fixture_on_gpu(ctx):
     """tests/test_measurement_adaptor.cpp:10-39 on the device path: the Synthetic fixture gives exactly 100 points."""
