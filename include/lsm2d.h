@@ -171,6 +171,11 @@ typedef struct {
 } lsm2d_preprocessor;
 int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges /* host [n_scans][n_beams] */,
                            int32_t n_scans, lsm2d_cloudset** out_set);
+/* The live tracker's form of the same operation: ONE scan into an existing reserved single-cloud set (capacity >= n_beams) --
+ * no allocation, nothing waits: the ranges are staged in the set's pinned buffer, the cloud's size stays on the device until
+ * somebody asks (see lsm2d_clip_scene).  Same kernel, same bits as lsm2d_preprocess_scans with n_scans = 1. */
+int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges /* host [n_beams] */,
+                               lsm2d_cloudset* out_reserved_set);
 
 /* ---- SceneClipperProjective2D::compute (mapping/scene_clipper_projective_2d.cpp:11-65, voxelize_resolution = 0
  * as in both shipped configs, MULTI.json:673-683): what the sensor at robot_in_local_map * sensor_in_robot sees of

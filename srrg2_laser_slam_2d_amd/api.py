@@ -669,3 +669,19 @@ class RawDataPreprocessorProjective2D:
         cs.counts = np.array([self._ctx._lib.lsm2d_cloudset_cloud_size(h, i) for i in range(r.shape[0])], np.int64)
         self._meas = cs
         return cs
+
+    def compute_into(self, out: CloudSet) -> CloudSet:
+        """The live tracker's form: the ONE scan set with setRawData goes into the reserved set ``out`` -- no allocation,
+        nothing waits; the cloud's size stays on the device until it is read (lsm2d_preprocess_scan_into)."""
+        if self._msg is None:
+            raise RuntimeError("RawDataPreprocessorProjective2D::compute| no raw data")
+        r, a0, a1, m_rmin, m_rmax = self._msg
+        if r.shape[0] != 1:
+            raise ValueError("compute_into takes one scan")
+        pp = _capi.Preprocessor(r.shape[1], a0, a1, max(m_rmin, self.param_range_min), min(m_rmax, self.param_range_max),
+                                self.param_normal_point_distance, self.param_normal_min_points, self.param_voxelize_resolution)
+        check(self._ctx._lib.lsm2d_preprocess_scan_into(self._ctx.handle, C.byref(pp), r.ctypes.data_as(C.c_void_p), out.handle),
+              "lsm2d_preprocess_scan_into", self._ctx.handle)
+        out._set_pending()
+        self._meas = out
+        return out

@@ -30,6 +30,8 @@ struct lsm2d_context {
   void* h_stage = nullptr; size_t h_stage_bytes = 0;
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_split = nullptr; size_t d_split_bytes = 0;      // workspace of the split aligner path
+  struct BeamDirs { int n_beams; float angle_min, angle_max; float2* d_dir; };
+  std::vector<BeamDirs> beam_dirs;                        // (cos, sin) per beam of the sensors seen so far (lsm2d_preprocess_scan_into)
   int max_dyn_lds = 0;
   int align_path = 0;          // 0 auto, 1 fused, 2 split
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1 or 2)
@@ -153,6 +155,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->h_stage) (void) hipHostFree(c->h_stage);
   if (c->d_scratch) (void) hipFree(c->d_scratch);
   if (c->d_split) (void) hipFree(c->d_split);
+  for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
   if (c->ev1) (void) hipEventDestroy(c->ev1);
   if (c->owns_stream && c->stream) (void) hipStreamDestroy(c->stream);
@@ -353,6 +356,20 @@ static int set_single_count(lsm2d_context* ctx, lsm2d_cloudset* cs, int32_t n) {
   return LSM2D_SUCCESS;
 }
 
+// the set's own pinned staging buffer, free to be overwritten: waits for the set's previous staged transfer only
+static int acquire_upload_stage(lsm2d_cloudset* cs, size_t need) {
+  lsm2d_context* ctx = cs->ctx;
+  if (cs->ev_upload) HIPCHK(ctx, hipEventSynchronize(cs->ev_upload));
+  else HIPCHK(ctx, hipEventCreateWithFlags(&cs->ev_upload, hipEventDisableTiming));
+  if (need > cs->h_upload_bytes) {
+    if (cs->h_upload) { HIPCHK(ctx, hipHostFree(cs->h_upload)); cs->h_upload = nullptr; cs->h_upload_bytes = 0; }
+    const size_t want = cs->capacity > 0 ? sizeof(float) * 4 * (size_t) cs->capacity + 16 : need;
+    HIPCHK(ctx, hipHostMalloc(&cs->h_upload, want > need ? want : need, hipHostMallocDefault));
+    cs->h_upload_bytes = want > need ? want : need;
+  }
+  return LSM2D_SUCCESS;
+}
+
 extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64_t n) {
   if (!cs || !cs->ctx || cs->n_clouds != 1 || n < 0 || (n > 0 && !pts)) return fail(cs ? cs->ctx : nullptr, LSM2D_BAD_ARGUMENT, "cloudset_upload: bad argument");
   lsm2d_context* ctx = cs->ctx;
@@ -362,15 +379,7 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
   cloudset_drop_grids(cs);
   // split on the host into the set's own pinned staging buffer, then two plain async copies: no allocation, no kernel and no
   // wait for the stream -- only for this set's PREVIOUS upload (an event), whose source the buffer still is until it ran
-  const size_t need = sizeof(float) * 4 * (size_t) (n > 0 ? n : 1) + 16;
-  if (cs->ev_upload) HIPCHK(ctx, hipEventSynchronize(cs->ev_upload));
-  else HIPCHK(ctx, hipEventCreateWithFlags(&cs->ev_upload, hipEventDisableTiming));
-  if (need > cs->h_upload_bytes) {
-    if (cs->h_upload) { HIPCHK(ctx, hipHostFree(cs->h_upload)); cs->h_upload = nullptr; cs->h_upload_bytes = 0; }
-    const size_t want = cs->capacity > 0 ? sizeof(float) * 4 * (size_t) cs->capacity + 16 : need;
-    HIPCHK(ctx, hipHostMalloc(&cs->h_upload, want > need ? want : need, hipHostMallocDefault));
-    cs->h_upload_bytes = want > need ? want : need;
-  }
+  { const int rc0 = acquire_upload_stage(cs, sizeof(float) * 4 * (size_t) (n > 0 ? n : 1) + 16); if (rc0) return rc0; }
   float2* hxy = (float2*) cs->h_upload; float2* hn = hxy + n;
   for (int64_t i = 0; i < n; ++i) { hxy[i] = make_float2(pts[4 * i], pts[4 * i + 1]); hn[i] = make_float2(pts[4 * i + 2], pts[4 * i + 3]); }
   if (n) {
@@ -658,6 +667,51 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   ctx->have_timing = true;
   cs->total = 0; for (int c = 0; c < n_scans; ++c) cs->total += cs->h_count[c];
   *out = cs;
+  return LSM2D_SUCCESS;
+}
+
+// the live tracker's form: ONE scan into an existing reserved set, no allocation, no wait (size pending on the device)
+extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_preprocessor* pp, const float* ranges, lsm2d_cloudset* out) {
+  if (!ctx || !pp || !ranges || !out || out->ctx != ctx || out->n_clouds != 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scan_into: bad argument");
+  const int nb = pp->n_beams;
+  if (nb < 1 || nb > kPrepMaxBeams) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "preprocess_scan_into: n_beams must be in [1, 2048]");
+  if (!(pp->angle_max > pp->angle_min) || pp->normal_min_points < 1 || !(pp->normal_point_distance >= 0.0f))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scan_into: bad parameters");
+  const int64_t cap = out->capacity > 0 ? out->capacity : out->padded_total - 2;
+  if (cap < nb) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "preprocess_scan_into: the set must have room for n_beams points");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  cloudset_drop_grids(out);
+  // beam directions with the host libm (the oracle does the same), once per sensor geometry
+  const float2* d_dir = nullptr;
+  for (const auto& bd : ctx->beam_dirs) if (bd.n_beams == nb && bd.angle_min == pp->angle_min && bd.angle_max == pp->angle_max) d_dir = bd.d_dir;
+  if (!d_dir) {
+    std::vector<float2> hd((size_t) nb);
+    const float sensor_res = (pp->angle_max - pp->angle_min) / (float) nb, k01 = (float) nb * 0.5f;
+    for (int c = 0; c < nb; ++c) { const float a = ((float) c - k01) * sensor_res; hd[c] = make_float2(cosf(a), sinf(a)); }
+    float2* d = nullptr;
+    HIPCHK(ctx, hipMalloc((void**) &d, sizeof(float2) * (size_t) nb));
+    hipError_t e = hipMemcpy(d, hd.data(), sizeof(float2) * (size_t) nb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void) hipFree(d); HIPCHK(ctx, e); }
+    ctx->beam_dirs.push_back({nb, pp->angle_min, pp->angle_max, d}); d_dir = d;
+  }
+  const size_t rbytes = sizeof(float) * (size_t) nb;
+  int rc = ensure_scratch(ctx, rbytes); if (rc) return rc;
+  rc = acquire_upload_stage(out, rbytes + 16); if (rc) return rc;
+  memcpy(out->h_upload, ranges, rbytes);
+  PrepArgs A;
+  A.ranges = (const float*) ctx->d_scratch; A.beam_dir = d_dir;
+  A.n_beams = nb; A.stride = nb + (nb & 1); A.rmin = pp->range_min; A.rmax = pp->range_max;
+  A.d2max = pp->normal_point_distance * pp->normal_point_distance; A.min_points = pp->normal_min_points;
+  A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
+  A.out_xy = out->d_xy; A.out_nrm = out->d_nrm; A.out_count = out->d_count;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_scratch, out->h_upload, rbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(out->ev_upload, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_preprocess_scans, dim3(1), dim3(kPrepBlock), 0, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = true;
+  out->h_count[0] = nb; out->total = nb; out->count_pending = true;          // at most one point per beam
   return LSM2D_SUCCESS;
 }
 

@@ -799,6 +799,58 @@ def test_preprocessor_bit_exact_batch_and_feeds_aligner(ctx, po):
         assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
 
 
+def test_ranges_in_pose_out_tracker_step_without_host_round_trips(ctx, po):
+    """Row f2's point: raw ranges in, pose out, one synchronisation.  Two LaserMessages are preprocessed INTO reserved sets
+    (lsm2d_preprocess_scan_into: same bits as the batched call), the local map is clipped, the aligner runs on the three
+    size-pending sets, both measurements are merged -- every call but the aligner asynchronous.  Checked against the same
+    chain on the oracle."""
+    world = synth.make_world(6)
+    a0, a1 = -2.34747, 2.35619
+    S = [np.float32([0.2, 0.1, 0.1]), np.float32([-0.3, 0.0, math.pi])]
+    robot = synth.sample_poses(world, 1, seed=12)[0]
+    sensors = [synth.compose_poses(robot[None, :], s[None, :].astype(np.float64)) for s in S]
+    ranges = [synth.make_scan_ranges(world, sp, n_beams=721, angle_min=a0, angle_max=a1, noise_sigma=0.004, seed=40 + i)[0] for i, sp in enumerate(sensors)]
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    m = synth.make_map(world, 20000, noise_sigma=0.004, seed=2)
+    guess = synth.compose_poses(robot[None, :], np.array([[0.03, -0.02, 0.02]]))[0].astype(np.float32)
+    # --- device
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+    sets = [api.CloudSet.reserved(ctx, 1024), api.CloudSet.reserved(ctx, 1024)]
+    for i in range(2):
+        pre.setRawData(ranges[i], a0, a1, 0.0, 30.0); pre.compute_into(sets[i])
+    local_map = api.CloudSet.reserved(ctx, 30000); local_map.upload(m)
+    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True); clipper.setFullScene(local_map)
+    clipper.setRobotInLocalMap(guess); clipper.setSensorInRobot(S[0])
+    clipped = clipper.compute()
+    al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
+    for i, s in enumerate(S):
+        al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
+            api.CorrespondenceFinderProjective2f(ctx, proj, 0.5, 0.8), sensor_in_robot=s, min_num_correspondences=5,
+            fixed_slice_name="points_%d" % i, moving_slice_name="points"))
+    al.setFixed({"points_0": sets[0], "points_1": sets[1]}); al.setMoving({"points": clipped}); al.setMovingInFixed([0, 0, 0])
+    assert al.compute() == 0
+    est = synth.compose_poses(guess[None, :].astype(np.float64), synth.invert_poses(al.movingInFixed()[None, :].astype(np.float64)))[0]
+    merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=True); merger.setScene(local_map)
+    for i, s in enumerate(S):
+        merger.setMeasurement(sets[i]); merger.setMeasurementInScene(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0]); merger.compute()
+    # --- oracle
+    pp = po.Preprocessor(721, a0, a1, 0.3, 20.0, 0.3, 5, 0.02)
+    meas = [po.preprocess_scan(pp, r) for r in ranges]
+    for i in range(2):
+        assert np.array_equal(sets[i].download(), meas[i]) and len(meas[i]) > 200
+    oclip, _ = po.clip_scene(opr, m, guess, S[0])
+    osl = [po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.8, min_num_correspondences=5, sensor_in_robot=tuple(s)) for s in S]
+    r = po.align(po.aligner_params(10), osl, meas, [oclip, oclip], np.zeros(3, np.float32))
+    d = np.abs(al.movingInFixed() - r["pose"])
+    assert r["status"] == 0 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+    assert np.abs(est - robot)[:2].max() < 0.03
+    host_map = m
+    for i, s in enumerate(S):       # merged at the DEVICE's estimate so that the maps can be compared bit for bit
+        host_map, _ = po.merge_scene(opr, host_map, meas[i], np.float32(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0]), 0.2)
+    assert local_map.n_points == len(host_map) and np.array_equal(local_map.download(), host_map)
+
+
 def test_maximum_sizes_against_oracle(ctx, po):
     """BASELINE configs[4] scale in a unit test: a 1M-point local map (oracle: ~0.2 s per alignment), plus the widest
     scan the preprocessor takes (2048 beams) and a ragged batch with single-point and odd-sized clouds."""
