@@ -1058,7 +1058,7 @@ __global__ void k_pack_aos(const float2* __restrict__ xy, const float2* __restri
 }
 
 // ---- RawDataPreprocessorProjective2D (row f2): one workgroup per scan, everything in LDS -----------------------
-static constexpr int kPrepBlock = 256;
+static constexpr int kPrepBlock = 1024;     // one beam per thread for the window walks; one compare-exchange per thread in the sort
 static constexpr int kPrepMaxBeams = 2048;
 struct PrepArgs {
   const float* ranges; const float2* beam_dir;      // [n_scans][n_beams]; (cos, sin) per beam, host-computed
@@ -1150,17 +1150,26 @@ __global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs 
     s_key[i] = key;
   }
   __syncthreads();
+  // bitonic network, one compare-exchange per thread and step (np2 / 2 <= kPrepBlock).  Pair t touches elements inside the
+  // aligned 128-element block of its wave whenever stride <= 64, so those steps need no workgroup barrier -- LDS operations
+  // of one wave complete in order -- only the compiler must keep them in order (wavefront fence).  6 of the 55 steps of a
+  // 1024-key sort cross waves.
+  static_assert(kPrepMaxBeams / 2 <= kPrepBlock, "one compare-exchange per thread");
   for (int size = 2; size <= np2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (np2 >> 1); t += kPrepBlock) {
+      const int t = tid;
+      if (t < (np2 >> 1)) {
         const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
         const bool up = (lo & size) == 0;
         const u64 a = s_key[lo], b = s_key[hi];
         if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
       }
-      __syncthreads();
+      // the next step's stride is stride / 2, or `size` when this was the last step of its stage
+      if (stride > 64 || (stride == 1 && size > 64)) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     }
   }
+  __syncthreads();
   if (tid == 0) s_base = 0;
   __syncthreads();
   for (int t0 = 0; t0 < np2; t0 += kPrepBlock) {

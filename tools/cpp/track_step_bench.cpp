@@ -1,5 +1,6 @@
 // Latency of one tracker step through the C ABI alone (no Python in the loop): what an SRRG-side C++ adapter pays.
-//   track_step_bench map.bin scan0.bin scan1.bin gx gy gth steps async(0|1)
+//   track_step_bench map.bin scan0.bin scan1.bin gx gy gth steps mode [ranges0.bin ranges1.bin amin amax]
+//   mode 0: every call synchronous; 1: asynchronous clip / upload / merge; 2: as 1, but raw ranges in (preprocessed on the device)
 // Every step: clip the device-resident local map around the guess, upload the two scans, align (2 laser slices with their
 // extrinsics + odometry prior, 10 iterations, 721 columns: the MULTI.json parameters), compose the corrected pose on the host,
 // merge both scans.  The map is re-uploaded every `reset` steps so it stays the size a local map between key frames has.
@@ -32,7 +33,14 @@ int main(int argc, char** argv) {
   if (argc < 9) { fprintf(stderr, "usage: %s map.bin scan0.bin scan1.bin gx gy gth steps async\n", argv[0]); return 2; }
   const std::vector<float> map = read_bin(argv[1]), s0 = read_bin(argv[2]), s1 = read_bin(argv[3]);
   const double guess[3] = {atof(argv[4]), atof(argv[5]), atof(argv[6])};
-  const int steps = atoi(argv[7]); const bool async = atoi(argv[8]) != 0;
+  const int steps = atoi(argv[7]), mode = atoi(argv[8]); const bool async = mode != 0;
+  std::vector<float> r0, r1; lsm2d_preprocessor pp; memset(&pp, 0, sizeof pp);
+  if (mode == 2) {
+    if (argc < 13) { fprintf(stderr, "mode 2 needs ranges0.bin ranges1.bin amin amax\n"); return 2; }
+    r0 = read_bin(argv[9]); r1 = read_bin(argv[10]);
+    pp.n_beams = (int32_t) r0.size(); pp.angle_min = (float) atof(argv[11]); pp.angle_max = (float) atof(argv[12]);
+    pp.range_min = 0.3f; pp.range_max = 20.0f; pp.normal_point_distance = 0.3f; pp.normal_min_points = 5; pp.voxelize_resolution = 0.02f;
+  }
   lsm2d_context* ctx = nullptr;
   CK(lsm2d_create(0, nullptr, &ctx));
   lsm2d_cloudset *local_map, *clipped, *m0, *m1;
@@ -62,7 +70,8 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     int32_t n_clip = 0, n_map = 0;
     CK(lsm2d_clip_scene(ctx, &pr, local_map, 0, g32, S0, clipped, async ? nullptr : &n_clip, nullptr));
-    CK(lsm2d_cloudset_upload(m0, s0.data(), (int64_t) (s0.size() / 4))); CK(lsm2d_cloudset_upload(m1, s1.data(), (int64_t) (s1.size() / 4)));
+    if (mode == 2) { CK(lsm2d_preprocess_scan_into(ctx, &pp, r0.data(), m0)); CK(lsm2d_preprocess_scan_into(ctx, &pp, r1.data(), m1)); }
+    else { CK(lsm2d_cloudset_upload(m0, s0.data(), (int64_t) (s0.size() / 4))); CK(lsm2d_cloudset_upload(m1, s1.data(), (int64_t) (s1.size() / 4))); }
     float x[3];
     CK(lsm2d_align_batch(ctx, &ap, &b, x, nullptr, &status, nullptr, nullptr));
     if (k >= 0) { lsm2d_last_kernel_ms(ctx, &ms_kernel); kernel_sum += ms_kernel; }
@@ -77,8 +86,8 @@ int main(int argc, char** argv) {
     if (k >= 0) total += t1 - t0;
   }
   CK(lsm2d_synchronize(ctx));
-  printf("{\"steps\": %d, \"asynchronous\": %s, \"ms_per_step_wall\": %.5f, \"align_kernel_ms_per_step\": %.5f, \"status\": %d, \"map_points\": %lld, \"est_on_fresh_map\": [%.9f, %.9f, %.9f]}\n",
-         steps, async ? "true" : "false", 1e3 * total.count() / steps, kernel_sum / steps, status, (long long) lsm2d_cloudset_num_points(local_map), est_fresh[0], est_fresh[1], est_fresh[2]);
+  printf("{\"steps\": %d, \"mode\": %d, \"asynchronous\": %s, \"ms_per_step_wall\": %.5f, \"align_kernel_ms_per_step\": %.5f, \"status\": %d, \"map_points\": %lld, \"est_on_fresh_map\": [%.9f, %.9f, %.9f]}\n",
+         steps, mode, async ? "true" : "false", 1e3 * total.count() / steps, kernel_sum / steps, status, (long long) lsm2d_cloudset_num_points(local_map), est_fresh[0], est_fresh[1], est_fresh[2]);
   lsm2d_cloudset_destroy(m0); lsm2d_cloudset_destroy(m1); lsm2d_cloudset_destroy(clipped); lsm2d_cloudset_destroy(local_map);
   lsm2d_destroy(ctx);
   return 0;

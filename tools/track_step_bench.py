@@ -23,7 +23,12 @@ def main():
         for s in S:
             sc = synth.make_scans(world, synth.compose_poses(np.array([t]), s[None, :].astype(np.float64)), n_beams=721, noise_sigma=0.01, seed=3 + k)[0]
             host_map, _ = po.merge_scene(opr, host_map, sc, np.float32(synth.compose_poses(t[None, :], s[None, :].astype(np.float64))[0]), 0.2)
-    scans = [synth.make_scans(world, synth.compose_poses(np.array([traj[-1]]), s[None, :].astype(np.float64)), n_beams=721, noise_sigma=0.01, seed=99)[0] for s in S]
+    # the step's two LaserMessages as raw ranges; the "points in" modes get them preprocessed by the oracle (bit-identical to the device)
+    a0, a1 = -2.34747, 2.35619
+    ranges = [synth.make_scan_ranges(world, synth.compose_poses(np.array([traj[-1]]), s[None, :].astype(np.float64)), n_beams=721, angle_min=a0, angle_max=a1,
+                                     noise_sigma=0.01, seed=99 + i)[0] for i, s in enumerate(S)]
+    pp = po.Preprocessor(721, a0, a1, 0.3, 20.0, 0.3, 5, 0.02)
+    scans = [po.preprocess_scan(pp, r) for r in ranges]
     guess = synth.compose_poses(traj[-1][None, :], np.array([[0.03, -0.02, 0.02]]))[0]
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "track_step_bench"); lib = os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "lib")
@@ -31,16 +36,22 @@ def main():
                         "-L" + lib, "-llsm2d_hip", "-Wl,-rpath," + lib, "-o", exe], check=True)
         host_map.tofile(os.path.join(d, "map.bin")); scans[0].tofile(os.path.join(d, "s0.bin")); scans[1].tofile(os.path.join(d, "s1.bin"))
         out = {"local_map_points": int(len(host_map)), "scan_points": [int(len(s)) for s in scans]}
-        for mode in (0, 1):
+        ranges[0].tofile(os.path.join(d, "r0.bin")); ranges[1].tofile(os.path.join(d, "r1.bin"))
+        for mode, key in ((0, "c_abi_sync"), (1, "c_abi_async"), (2, "c_abi_async_ranges_in")):
             r = subprocess.run([exe, os.path.join(d, "map.bin"), os.path.join(d, "s0.bin"), os.path.join(d, "s1.bin"),
-                                repr(float(guess[0])), repr(float(guess[1])), repr(float(guess[2])), str(args.steps), str(mode)],
+                                repr(float(guess[0])), repr(float(guess[1])), repr(float(guess[2])), str(args.steps), str(mode),
+                                os.path.join(d, "r0.bin"), os.path.join(d, "r1.bin"), repr(a0), repr(a1)],
                                check=True, capture_output=True, text=True, timeout=300)
-            out["c_abi_async" if mode else "c_abi_sync"] = json.loads(r.stdout.strip().splitlines()[-1])
+            out[key] = json.loads(r.stdout.strip().splitlines()[-1])
     # the same step on the CPU oracle
     osl = [po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.9, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.01, min_num_correspondences=5, sensor_in_robot=tuple(S[0])),
            po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.8, min_num_correspondences=5, sensor_in_robot=tuple(S[1]))]
     omega = np.diag([100.0, 100.0, 100.0]).astype(np.float32)
     reps = 200; t0 = time.perf_counter()
+    for _ in range(reps):
+        _ = [po.preprocess_scan(pp, r) for r in ranges]
+    out["cpu_oracle_preprocess_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
     for _ in range(reps):
         g32 = guess.astype(np.float32)
         oclip, _ = po.clip_scene(opr, host_map, g32, S[0])
@@ -49,7 +60,7 @@ def main():
         hm = host_map
         for sc, s in zip(scans, S):
             hm, _ = po.merge_scene(opr, hm, sc, np.float32(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0]), 0.2)
-    out["cpu_oracle_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / reps
+    out["cpu_oracle_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / reps        # points in; add the preprocess line for ranges in
     out["pose_diff_gpu_vs_cpu"] = [float(abs(a - b)) for a, b in zip(out["c_abi_async"]["est_on_fresh_map"], est)]
     print(json.dumps(out))
 
