@@ -211,6 +211,32 @@ def test_aligner_cloud_index_selection(ctx, small_workload):
     assert np.array_equal(res.pose, base.pose[perm])
 
 
+def test_ragged_moving_clouds_through_the_lane_chunked_stream(ctx, po, small_workload):
+    """k_align streams a moving cloud from its lane-chunked copy in steps of one pair per thread, two steps per trip.  A set
+    mixing every step count that matters (0, 1, 2, 3 and more, odd and even sizes, exactly / just over a multiple of 512
+    pairs) goes through one launch, each cloud chosen by an index array; status, iteration count and pose equal the oracle's
+    for every cloud, and the correspondence counts of the first iteration are equal (bit-exact z-buffers)."""
+    wl = small_workload
+    rng = np.random.default_rng(5)
+    sizes = [0, 1, 2, 7, 1023, 1024, 1025, 2047, 2048, 2049, 3071, 3073, 4096, 4099, 5121, 12001]
+    perm = rng.permutation(len(wl.map_points))
+    clouds = [wl.map_points[np.sort(perm[:k])] for k in sizes]          # subsets of the map, in map order
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    moving = api.CloudSet(ctx, np.concatenate(clouds, 0), offs)
+    scan = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    al = _aligner(ctx, its=8)
+    n = len(sizes)
+    x0 = np.repeat(wl.x0[:1], n, 0)
+    res = al.compute_batch([api.CloudSet(ctx, scan)], [moving], x0, moving_index=np.arange(n, dtype=np.int32)[None, :], want_stats=True)
+    for i, c in enumerate(clouds):
+        r = po.align(po.aligner_params(8), [po.slice_params()], [scan], [c], wl.x0[0])
+        assert res.status[i] == r["status"] and res.iterations[i] == r["iterations"], (sizes[i], res.status[i], r["status"])
+        assert res.stats[i]["n_correspondences"][0] == r["stats"][0].n_corr, sizes[i]
+        d = np.abs(res.pose[i] - r["pose"])
+        assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD, (sizes[i], d)
+    assert (res.status == 0).sum() >= 8 and (res.status == 1).sum() >= 3
+
+
 def test_multi_slice_sensor_offsets_and_prior(ctx, po):
     world = synth.make_world(5)
     m = synth.make_map(world, 30000)
