@@ -85,19 +85,20 @@ LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start
     if (k > kmax) k = kmax;
     const int x0 = cx - k < 0 ? 0 : cx - k, x1 = cx + k > g.gw - 1 ? g.gw - 1 : cx + k;
     const int y0 = cy - k < 0 ? 0 : cy - k, y1 = cy + k > g.gh - 1 ? g.gh - 1 : cy + k;
-    if (x0 <= x1) {
-      for (int yy = y0; yy <= y1; ++yy) {
-        const int s = cell_start[yy * g.gw + x0], e = cell_start[yy * g.gw + x1 + 1];
+    if (x0 <= x1 && y0 <= y1) {
+      // a candidate's original index is only needed when it improves on or ties with the best so far (ties -> lowest index)
+      auto scan_row = [&](int s, int e) {
         for (int t = s + sub; t < e; t += group) {
           const float2 p = sxy[t];
           const float dx = p.x - qx, dy = p.y - qy;
           const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-          if (d2 <= md2) {
+          if (d2 <= md2 && d2 <= bd) {
             const int i = sidx[t];
-            if (d2 < bd || (d2 == bd && i < best)) { bd = d2; best = i; }
+            if (d2 < bd || i < best || best < 0) { bd = d2; best = i; }
           }
         }
-      }
+      };
+      for (int yy = y0; yy <= y1; ++yy) scan_row(cell_start[yy * g.gw + x0], cell_start[yy * g.gw + x1 + 1]);
     }
     if (group > 1)
 #pragma unroll
