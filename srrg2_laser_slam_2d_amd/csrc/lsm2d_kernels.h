@@ -66,7 +66,8 @@ struct CloudDev {            // device view of a cloud set
 // (2k+1)^2 block around q for k = 1, 2, 4, ... and stops as soon as the best distance is strictly inside the
 // block (every point outside it is farther than k*h, so it can neither win nor tie) or the block covers
 // max_distance.  Converged ICP queries finish in the first 3x3 block.
-static constexpr int kNNGroup = 8;      // lanes that cooperate on one query: they read 8 consecutive candidates = one 64-byte line
+static constexpr int kNNGroup = 4;      // lanes that cooperate on one query on a dense fixed cloud: they read 4 consecutive candidates (32 bytes);
+                                        // measured on configs[1] role B with ~13 points per cell: 2 lanes 2.81 ms, 4 lanes 2.48, 8 lanes 2.76, 16 lanes 3.92
 
 template <int group>
 LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start, const int32_t* __restrict__ sidx,
