@@ -1054,8 +1054,18 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     S.fcan_offset = fcan_total; fcan_total += S.proj.cols; if (S.proj.cols > cols_max) cols_max = S.proj.cols;
   }
   A.cols_max = cols_max; A.fcan_total = fcan_total;
-  const size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float4) * (size_t) fcan_total +
-                     sizeof(float) * kAccumWords * (kAlignBlock / 64);      // moving canvas, fixed canvases, fixed winners, reduction
+  size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float4) * (size_t) fcan_total +
+               sizeof(float) * kAccumWords * (kAlignBlock / 64);      // moving canvas, fixed canvases, fixed winners, reduction
+  // one NN slice whose fixed clouds are scan-sized (one lane per query): stage each cloud's search tables in LDS.  Budget 38 KB
+  // per workgroup keeps four workgroups on a CU; bigger clouds / grids search in global memory as before.
+  A.nn_lds_points = 0; A.nn_lds_cells = 0;
+  if (ns == 1 && b->slices[0].finder == LSM2D_FINDER_NN && A.s[0].nn_group == 1) {
+    const lsm2d_cloudset* f = b->fixed[0];
+    int mf = 0; for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > mf) mf = f->h_count[c];
+    int cap = (int) ceil((mf >= 16384 ? 6.0 : 3.0) * sqrt((double) (mf > 0 ? mf : 1))); cap = cap < 16 ? 16 : cap;      // ensure_grid's rule
+    const size_t need = sizeof(float2) * (size_t) mf + sizeof(uint16_t) * ((size_t) cap * cap + 4) + sizeof(uint16_t) * ((size_t) mf + 2);
+    if (mf > 0 && mf <= 65535 && need <= 38 * 1024 - lds) { A.nn_lds_points = mf; A.nn_lds_cells = cap * cap + 1; lds += need + 16; }
+  }
   if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
 
   // ---- inputs

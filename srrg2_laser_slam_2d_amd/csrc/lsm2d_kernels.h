@@ -69,8 +69,9 @@ struct CloudDev {            // device view of a cloud set
 static constexpr int kNNGroup = 4;      // lanes that cooperate on one query on a dense fixed cloud: they read 4 consecutive candidates (32 bytes);
                                         // measured on configs[1] role B with ~13 points per cell: 2 lanes 2.81 ms, 4 lanes 2.48, 8 lanes 2.76, 16 lanes 3.92
 
-template <int group>
-LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start, const int32_t* __restrict__ sidx,
+// CellT / IdxT: int32_t for the tables in global memory, uint16_t for a scan-sized cloud's tables staged in LDS (k_align)
+template <int group, typename CellT = int32_t, typename IdxT = int32_t>
+LSM2D_DEV int nn_query(const GridMeta& g, const CellT* __restrict__ cell_start, const IdxT* __restrict__ sidx,
                        const float2* __restrict__ sxy, float qx, float qy, float md, float md2, int sub) {
   // group == kNNGroup: every lane of a group of kNNGroup consecutive lanes calls this with the SAME query and its own
   // `sub` in [0, kNNGroup) (dense fixed clouds: a scan point has ~100 map points in its 3x3 block); group == 1: one lane per
@@ -94,12 +95,12 @@ LSM2D_DEV int nn_query(const GridMeta& g, const int32_t* __restrict__ cell_start
           const float dx = p.x - qx, dy = p.y - qy;
           const float d2 = __builtin_fmaf(dx, dx, dy * dy);
           if (d2 <= md2 && d2 <= bd) {
-            const int i = sidx[t];
+            const int i = (int) sidx[t];
             if (d2 < bd || i < best || best < 0) { bd = d2; best = i; }
           }
         }
       };
-      for (int yy = y0; yy <= y1; ++yy) scan_row(cell_start[yy * g.gw + x0], cell_start[yy * g.gw + x1 + 1]);
+      for (int yy = y0; yy <= y1; ++yy) scan_row((int) cell_start[yy * g.gw + x0], (int) cell_start[yy * g.gw + x1 + 1]);
     }
     if (group > 1)
 #pragma unroll
@@ -268,6 +269,7 @@ struct AlignArgs {
   int32_t n_align, n_slices, max_it, min_inliers;
   float   damping;
   int32_t cols_max, fcan_total;
+  int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
   const float* init_pose;
   const PriorDev* prior;
   float* out_pose; float* out_H; int32_t* out_status; int32_t* out_its; StatsDev* out_stats;
@@ -305,6 +307,11 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   u64* fcan = mcan + A.cols_max;
   float4* fwin = reinterpret_cast<float4*>(fcan + A.fcan_total);  // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
   float* red = reinterpret_cast<float*>(fwin + A.fcan_total);     // [nwaves][kAccumWords]
+  // NN finder over a scan-sized fixed cloud (the tracker wiring: tree over the scan, every map point a query): the cloud's search
+  // tables live in LDS for the whole alignment -- 20 iterations x N_m queries then touch global memory only for the query stream
+  float2* l_sxy = reinterpret_cast<float2*>(red + (kAlignBlock / 64) * kAccumWords);
+  uint16_t* l_cst = reinterpret_cast<uint16_t*>(l_sxy + A.nn_lds_points);
+  uint16_t* l_sidx = l_cst + ((A.nn_lds_cells + 2) & ~1);
   __shared__ float s_pose[3];
   __shared__ Iso   s_iso[kMaxSlices];
   __shared__ float s_H[9], s_Hs[9], s_b[3];      // s_H: information matrix (H of the last solved iteration); s_Hs: this iteration's sum
@@ -336,6 +343,20 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
     begin_iteration();
   }
   __syncthreads();
+  bool nn_lds = false;
+  if (kHasNN && A.nn_lds_points > 0) {
+    const SliceDev& S = A.s[0];
+    const int fc = pick_cloud(S.fixed, a), nf = S.fixed.count[fc];
+    const GridMeta g0 = S.fixed.grid.meta[fc];
+    const int ncell = g0.gw * g0.gh;
+    nn_lds = nf <= A.nn_lds_points && ncell + 1 <= A.nn_lds_cells;     // workgroup-uniform; else this alignment searches in global memory
+    if (nn_lds) {
+      const int32_t* cst = S.fixed.grid.cell_start + g0.cell_base;
+      const int fbase = S.fixed.start[fc];
+      for (int i = tid; i <= ncell; i += kAlignBlock) l_cst[i] = (uint16_t) cst[i];
+      for (int i = tid; i < nf; i += kAlignBlock) { l_sxy[i] = S.fixed.grid.sorted_xy[fbase + i]; l_sidx[i] = (uint16_t) S.fixed.grid.sorted_idx[fbase + i]; }
+    }
+  }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   for (int s = 0; s < A.n_slices; ++s) {
     const SliceDev& S = A.s[s];
@@ -422,7 +443,10 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
             const float2 pm = live ? mp[j] : make_float2(0.0f, 0.0f);
             float qx, qy; xf_point(T, pm.x, pm.y, qx, qy);
             int best = -1;
-            if (use_grid) { if (live) best = nn_query<group>(g, cst, sidx, sxy, qx, qy, S.max_distance, md2, sub); }
+            if (use_grid) {
+              if (live) best = (group == 1 && nn_lds) ? nn_query<1, uint16_t, uint16_t>(g, l_cst, l_sidx, l_sxy, qx, qy, S.max_distance, md2, 0)
+                                                      : nn_query<group>(g, cst, sidx, sxy, qx, qy, S.max_distance, md2, sub);
+            }
             else if (live) best = distmap_lookup(dm, S.fixed.dist.parent, qx, qy);
             if (best >= 0 && sub == 0) {                     // one lane per query accumulates
               const float2 nm = mn[j], nf = fn[best];
