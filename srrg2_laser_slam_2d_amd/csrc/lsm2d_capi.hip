@@ -1057,7 +1057,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float4) * (size_t) fcan_total +
                sizeof(float) * kAccumWords * (kAlignBlock / 64);      // moving canvas, fixed canvases, fixed winners, reduction
   // one NN slice whose fixed clouds are scan-sized (one lane per query): stage each cloud's search tables in LDS.  Budget 38 KB
-  // per workgroup keeps four workgroups on a CU; bigger clouds / grids search in global memory as before.
+  // per workgroup keeps four workgroups on a CU; bigger clouds / grids search in global memory as before.  (Measured on configs[1]
+  // role A: 3 sqrt(n) cells per side in 38 KB 9.6 ms; 4 sqrt(n) in 50 KB -- three workgroups per CU -- 12.2; 2 sqrt(n) 12.3.)
   A.nn_lds_points = 0; A.nn_lds_cells = 0;
   if (ns == 1 && b->slices[0].finder == LSM2D_FINDER_NN && A.s[0].nn_group == 1) {
     const lsm2d_cloudset* f = b->fixed[0];
