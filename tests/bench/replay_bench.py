@@ -6,7 +6,7 @@ their own extrinsics (laser_0: Cauchy 0.01, normal_cos 0.9; laser_1: no robustif
 10 iterations, clipper before / merger after the aligner, local map kept on the device.
 
 Every step runs the SAME three calls on both sides (clip -> align -> merge); the CPU side is the oracle (checker).
-    python tools/replay_bench.py [--steps 200]
+    python tests/bench/replay_bench.py [--steps 200]
 """
 import argparse
 import json
@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

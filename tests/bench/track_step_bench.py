@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Tracker-step latency through the C ABI alone: builds tools/cpp/track_step_bench.cpp with g++ against liblsm2d_hip.so, feeds
-it one synthetic scene (MULTI.json parameters, as tools/replay_bench.py) and prints its JSON lines (synchronous and
+"""Tracker-step latency through the C ABI alone: builds tests/cpp/track_step_bench.cpp with g++ against liblsm2d_hip.so, feeds
+it one synthetic scene (MULTI.json parameters, as tests/bench/replay_bench.py) and prints its JSON lines (synchronous and
 asynchronous calls) plus the CPU oracle's time for the same step.
-    python tools/track_step_bench.py [--steps 2000]"""
+    python tests/bench/track_step_bench.py [--steps 2000]"""
 import argparse, json, math, os, subprocess, sys, tempfile, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from srrg2_laser_slam_2d_amd import synth
 
 
@@ -32,7 +32,7 @@ def main():
     guess = synth.compose_poses(traj[-1][None, :], np.array([[0.03, -0.02, 0.02]]))[0]
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "track_step_bench"); lib = os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "lib")
-        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cpp", "track_step_bench.cpp"),
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "track_step_bench.cpp"),
                         "-L" + lib, "-llsm2d_hip", "-Wl,-rpath," + lib, "-o", exe], check=True)
         host_map.tofile(os.path.join(d, "map.bin")); scans[0].tofile(os.path.join(d, "s0.bin")); scans[1].tofile(os.path.join(d, "s1.bin"))
         out = {"local_map_points": int(len(host_map)), "scan_points": [int(len(s)) for s in scans]}
