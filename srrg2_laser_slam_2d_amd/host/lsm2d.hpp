@@ -185,11 +185,14 @@ class SceneClipperProjective2D {
   int compute() {
     if (!_scene || !_clipped) throw std::runtime_error("SceneClipperProjective2D::compute| missing local OR global scene");     // .cpp:12-17
     if (!param_projector) throw std::runtime_error("SceneClipperProjective2D::compute| Missing Projector");                     // .cpp:19-21
-    const lsm2d_projector pr = param_projector->abi(); int32_t n = 0;
-    check(lsm2d_clip_scene(_ctx.get(), &pr, _scene->get(), 0, _robot_in_local_map.data(), _sensor_in_robot.data(), _clipped->get(), &n, nullptr),
+    const lsm2d_projector pr = param_projector->abi(); int32_t n = -1;
+    // asynchronous: the call only queues the work; the clipped set's size stays on the device until somebody asks (returns -1)
+    check(lsm2d_clip_scene(_ctx.get(), &pr, _scene->get(), 0, _robot_in_local_map.data(), _sensor_in_robot.data(), _clipped->get(),
+                           asynchronous ? nullptr : &n, nullptr),
           "lsm2d_clip_scene", _ctx.get());
     return n;
   }
+  bool asynchronous = false;
  private:
   Context& _ctx; const ReservedCloud* _scene = nullptr; ReservedCloud* _clipped = nullptr;
   Vector3f _robot_in_local_map{{0.f, 0.f, 0.f}}, _sensor_in_robot{{0.f, 0.f, 0.f}};
@@ -202,19 +205,24 @@ class MergerProjective2D {
   float param_merge_threshold = 0.2f;                                      // .h:12-16
   PointNormal2fProjectorPolarPtr param_projector{new PointNormal2fProjectorPolar};
   void setScene(ReservedCloud* scene) { _scene = scene; }
-  void setMeasurement(const PointNormal2fVectorCloud* m) { _measurement.reset(m ? new CloudSet(_ctx, *m) : nullptr); }
+  void setMeasurement(const PointNormal2fVectorCloud* m) { _measurement.reset(m ? new CloudSet(_ctx, *m) : nullptr); _device_measurement = nullptr; }
+  void setMeasurement(const ReservedCloud* m) { _measurement.reset(); _device_measurement = m; }     // a measurement that already lives on the device
   void setMeasurementInScene(const Vector3f& p) { _measurement_in_scene = p; }
   int compute() {
     if (!param_projector) throw std::runtime_error("MergerProjective2D::compute| Missing Projector");                            // .cpp:10-12
-    if (!_scene || !_measurement) throw std::runtime_error("MergerProjective2D::compute| missing scene or measurement");
-    const lsm2d_projector pr = param_projector->abi(); int32_t size = 0;
-    check(lsm2d_merge_scene(_ctx.get(), &pr, _scene->get(), _measurement->get(), 0, _measurement_in_scene.data(), param_merge_threshold, &size, counts.data()),
+    const lsm2d_cloudset* meas = _device_measurement ? _device_measurement->get() : (_measurement ? _measurement->get() : nullptr);
+    if (!_scene || !meas) throw std::runtime_error("MergerProjective2D::compute| missing scene or measurement");
+    const lsm2d_projector pr = param_projector->abi(); int32_t size = -1;
+    // asynchronous: queue only; the scene's new size (and the counts) stay on the device (returns -1)
+    check(lsm2d_merge_scene(_ctx.get(), &pr, _scene->get(), meas, 0, _measurement_in_scene.data(), param_merge_threshold,
+                            asynchronous ? nullptr : &size, asynchronous ? nullptr : counts.data()),
           "lsm2d_merge_scene", _ctx.get());
     return size;
   }
+  bool asynchronous = false;
   std::array<int32_t, 3> counts{{0, 0, 0}};                                // new, merged, replaced
  private:
-  Context& _ctx; ReservedCloud* _scene = nullptr; std::unique_ptr<CloudSet> _measurement;
+  Context& _ctx; ReservedCloud* _scene = nullptr; std::unique_ptr<CloudSet> _measurement; const ReservedCloud* _device_measurement = nullptr;
   Vector3f _measurement_in_scene{{0.f, 0.f, 0.f}};
 };
 
