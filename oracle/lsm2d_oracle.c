@@ -39,13 +39,35 @@ float lsmo_atan2f(float y, float x) {
   return copysignf(r, y);      /* atan2(-0, x<0) = -pi, as libm */
 }
 
+/* cos / sin of a pose angle as a FIXED operation sequence, for the same reason as atan2: the rotation of a pose must have the
+ * same bits on the CPU and on the GPU, and the two libms (glibc, ROCm's ocml) differ in the last place now and then -- one
+ * flipped bit in a rotation moves a point across a column edge of the z-buffer about once in 300 alignments.
+ * k = rint(x * 2/pi); r = x - k*pi/2 in two fma steps; degree-2 polynomials in r^2 on [-pi/4, pi/4] (tools/fit_sincos.py:
+ * max abs error 9.3e-8 for |x| <= 3000 rad, i.e. about 1 ulp of a value near 1); quadrant by k mod 4.  Stands in for the
+ * cos/sin Eigen's Rotation2D calls upstream. */
+void lsmo_sincosf(float x, float* sn, float* cs) {
+  const float kf = rintf(x * 6.3661974669e-01f);
+  float r = fmaf(-kf, 1.5707963705e+00f, x);
+  r = fmaf(-kf, -4.3711388287e-08f, r);
+  const float z = r * r;
+  float ps = -1.9495635934e-04f; ps = fmaf(ps, z, 8.3319786936e-03f); ps = fmaf(ps, z, -1.6666650772e-01f);
+  const float s = fmaf(r * z, ps, r);
+  float pc = 2.4438450055e-05f; pc = fmaf(pc, z, -1.3887367677e-03f); pc = fmaf(pc, z, 4.1666645557e-02f);
+  const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  const int q = (int) kf & 3;
+  *sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+  *cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+}
+static float lsmo_cosf_fixed(float a) { float s, c; lsmo_sincosf(a, &s, &c); return c; }
+static float lsmo_sinf_fixed(float a) { float s, c; lsmo_sincosf(a, &s, &c); return s; }
+
 /* ---- fp32 mirror --------------------------------------------------------------------------- */
 #define REAL float
 #define SFX(n) n##_f
 #define R_FMA(a, b, c) fmaf((a), (b), (c))
 #define R_SQRT(a) sqrtf(a)
-#define R_COS(a) cosf(a)
-#define R_SIN(a) sinf(a)
+#define R_COS(a) lsmo_cosf_fixed(a)
+#define R_SIN(a) lsmo_sinf_fixed(a)
 #define R_ATAN2(y, x) lsmo_atan2f((y), (x))
 #define R_LOG(a) logf(a)
 #define R_FABS(a) fabsf(a)

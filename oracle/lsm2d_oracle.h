@@ -83,6 +83,7 @@ typedef struct {
 
 /* ---- scalar helpers --------------------------------------------------------------------- */
 float lsmo_atan2f(float y, float x);     /* the fixed-polynomial atan2 both CPU and GPU evaluate */
+void  lsmo_sincosf(float x, float* sn, float* cs);     /* the fixed-sequence sin / cos of a pose angle both CPU and GPU evaluate */
 void  lsmo_compose_f(const float a[3], const float b[3], float out[3]);   /* v2t(a)*v2t(b) -> t2v */
 void  lsmo_inverse_f(const float a[3], float out[3]);
 void  lsmo_compose_d(const double a[3], const double b[3], double out[3]);

@@ -84,7 +84,18 @@ def lib():
         _lib = C.CDLL(override if override else build())
         _lib.lsmo_atan2f.restype = C.c_float
         _lib.lsmo_atan2f.argtypes = [C.c_float, C.c_float]
+        _lib.lsmo_sincosf.restype = None
+        _lib.lsmo_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     return _lib
+
+
+def sincos(x):
+    """(sin, cos) float32 arrays through the oracle's fixed-sequence lsmo_sincosf."""
+    x = np.atleast_1d(np.asarray(x, np.float32)); L = lib()
+    s = np.empty_like(x); c = np.empty_like(x); a, b = C.c_float(), C.c_float()
+    for i, v in enumerate(x):
+        L.lsmo_sincosf(float(v), C.byref(a), C.byref(b)); s[i], c[i] = a.value, b.value
+    return s, c
 
 
 def slice_params(finder=FINDER_PROJECTIVE, canvas_cols=1081, angle_min=-np.pi, angle_max=np.pi, range_min=0.3,

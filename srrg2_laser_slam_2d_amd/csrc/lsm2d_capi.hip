@@ -591,14 +591,14 @@ static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float ma
   return LSM2D_SUCCESS;
 }
 
-static Iso make_iso(const float pose[3]) { Iso T; T.c = cosf(pose[2]); T.s = sinf(pose[2]); T.tx = pose[0]; T.ty = pose[1]; return T; }
+static Iso make_iso(const float pose[3]) { Iso T; sincos_fixed(pose[2], T.s, T.c); T.tx = pose[0]; T.ty = pose[1]; return T; }
 static float wrap_host(float a) {
   while (a > 3.14159274101257324f) a -= 6.28318548202514648f;
   while (a <= -3.14159274101257324f) a += 6.28318548202514648f;
   return a;
 }
 static void inverse_host(const float a[3], float out[3]) {   // (R,t)^-1 = (R^T, -R^T t)
-  const float c = cosf(a[2]), s = sinf(a[2]);
+  float s, c; sincos_fixed(a[2], s, c);
   out[0] = -(fmaf(c, a[0], s * a[1]));
   out[1] = -(fmaf(-s, a[0], c * a[1]));
   out[2] = wrap_host(-a[2]);
@@ -606,7 +606,7 @@ static void inverse_host(const float a[3], float out[3]) {   // (R,t)^-1 = (R^T,
 static bool valid_cloud_index(const lsm2d_cloudset* cs, int32_t i) { return cs && i >= 0 && i < cs->n_clouds; }
 static bool valid_cloud_index_fwd(const lsm2d_cloudset* cs, int32_t i) { return valid_cloud_index(cs, i); }
 static void compose_host(const float a[3], const float b[3], float out[3]) {   // v2t(a) * v2t(b)
-  const float c = cosf(a[2]), s = sinf(a[2]);
+  float s, c; sincos_fixed(a[2], s, c);
   out[0] = fmaf(c, b[0], fmaf(-s, b[1], a[0]));
   out[1] = fmaf(s, b[0], fmaf(c, b[1], a[1]));
   out[2] = wrap_host(a[2] + b[2]);
@@ -1050,7 +1050,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     S.cauchy = sp.robustifier == LSM2D_ROBUST_CAUCHY; S.tau = sp.chi_threshold; S.min_corr = sp.min_num_correspondences;
     if (S.cauchy && !(S.tau > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: chi_threshold must be > 0");
     S.has_sensor = !(sp.sensor_in_robot[0] == 0.0f && sp.sensor_in_robot[1] == 0.0f && sp.sensor_in_robot[2] == 0.0f);
-    inverse_host(sp.sensor_in_robot, S.Sinv); S.cSinv = cosf(S.Sinv[2]); S.sSinv = sinf(S.Sinv[2]);
+    inverse_host(sp.sensor_in_robot, S.Sinv); sincos_fixed(S.Sinv[2], S.sSinv, S.cSinv);
     S.fcan_offset = fcan_total; fcan_total += S.proj.cols; if (S.proj.cols > cols_max) cols_max = S.proj.cols;
   }
   A.cols_max = cols_max; A.fcan_total = fcan_total;
@@ -1074,7 +1074,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   if (b->prior) {
     PriorDev* p = (PriorDev*) (hs + o_prior);
     for (int i = 0; i < n; ++i) {
-      inverse_host(b->prior[i].z, p[i].z_inv); p[i].cz = cosf(p[i].z_inv[2]); p[i].sz = sinf(p[i].z_inv[2]);
+      inverse_host(b->prior[i].z, p[i].z_inv); sincos_fixed(p[i].z_inv[2], p[i].sz, p[i].cz);
       memcpy(p[i].omega, b->prior[i].omega, sizeof(float) * 9);
     }
     A.prior = (const PriorDev*) (ds + o_prior);

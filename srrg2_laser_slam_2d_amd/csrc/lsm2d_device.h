@@ -21,6 +21,7 @@ typedef unsigned long long u64;
 static constexpr u64 kEmptyCell = ~0ull;   // depth bits 0xFFFFFFFF (a NaN pattern no valid depth reaches), idx -1
 
 #define LSM2D_DEV __device__ __forceinline__
+#define LSM2D_HD  __host__ __device__ inline
 
 struct Iso { float c, s, tx, ty; };          // R = [[c,-s],[s,c]], t = (tx,ty)
 
@@ -32,6 +33,23 @@ struct ProjK {
   float colsf;          // (float) canvas_cols
   int   cols;
 };
+
+// cos / sin of a pose angle as a fixed operation sequence (the CPU restatement evaluates the same sequence, operation for operation; coefficients from
+// tools/fit_sincos.py, max abs error 9.3e-8): host code, kernels and the CPU oracle give a rotation the same bits -- glibc's and
+// ocml's cosf / sinf differ in the last place now and then, and one such bit moves a point across a z-buffer column edge.
+LSM2D_HD void sincos_fixed(float x, float& sn, float& cs) {
+  const float kf = __builtin_rintf(x * 6.3661974669e-01f);
+  float r = __builtin_fmaf(-kf, 1.5707963705e+00f, x);
+  r = __builtin_fmaf(-kf, -4.3711388287e-08f, r);
+  const float z = r * r;
+  float ps = -1.9495635934e-04f; ps = __builtin_fmaf(ps, z, 8.3319786936e-03f); ps = __builtin_fmaf(ps, z, -1.6666650772e-01f);
+  const float s = __builtin_fmaf(r * z, ps, r);
+  float pc = 2.4438450055e-05f; pc = __builtin_fmaf(pc, z, -1.3887367677e-03f); pc = __builtin_fmaf(pc, z, 4.1666645557e-02f);
+  const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+  const int q = (int) kf & 3;
+  sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+  cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+}
 
 LSM2D_DEV void xf_point(const Iso& T, float px, float py, float& qx, float& qy) {
   qx = __builtin_fmaf(T.c, px, __builtin_fmaf(-T.s, py, T.tx));
@@ -337,7 +355,7 @@ LSM2D_DEV bool solve_update(const float H[9], const float b[3], float damping, f
   const double z0 = y0 / d0 - l10 * z1 - l20 * z2;
   if (!__builtin_isfinite(z0) || !__builtin_isfinite(z1) || !__builtin_isfinite(z2)) return false;
   const float dx = (float) z0, dy = (float) z1, dth = (float) z2;
-  const float c = cosf(pose[2]), s = sinf(pose[2]);
+  float s, c; sincos_fixed(pose[2], s, c);
   const float nx = __builtin_fmaf(c, dx, __builtin_fmaf(-s, dy, pose[0]));
   const float ny = __builtin_fmaf(s, dx, __builtin_fmaf(c, dy, pose[1]));
   pose[0] = nx; pose[1] = ny; pose[2] = wrap_angle(pose[2] + dth);

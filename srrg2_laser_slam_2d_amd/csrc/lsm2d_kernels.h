@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
     for (int s = 0; s < A.n_slices; ++s) {
       float Xe[3] = {s_pose[0], s_pose[1], s_pose[2]};
       if (A.s[s].has_sensor) compose(A.s[s].cSinv, A.s[s].sSinv, A.s[s].Sinv, s_pose, Xe);
-      s_iso[s].c = cosf(Xe[2]); s_iso[s].s = sinf(Xe[2]); s_iso[s].tx = Xe[0]; s_iso[s].ty = Xe[1];
+      sincos_fixed(Xe[2], s_iso[s].s, s_iso[s].c); s_iso[s].tx = Xe[0]; s_iso[s].ty = Xe[1];
     }
     for (int k = 0; k < 9; ++k) s_Hs[k] = 0.0f;
     s_b[0] = s_b[1] = s_b[2] = 0.0f;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
           // SE2 prior: e = t2v(Z^-1 X), J = blkdiag(R_e, 1) for the right perturbation
           const PriorDev& Pz = A.prior[a];
           float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, s_pose, E);
-          const float c = cosf(E[2]), s_ = sinf(E[2]);
+          float c, s_; sincos_fixed(E[2], s_, c);
           const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
           float OJ[9], Oe[3];
 #pragma unroll
@@ -560,7 +560,7 @@ struct SplitArgs {
 LSM2D_DEV Iso slice_iso(const SliceDev& S, const float pose[3]) {
   float Xe[3] = {pose[0], pose[1], pose[2]};
   if (S.has_sensor) compose(S.cSinv, S.sSinv, S.Sinv, pose, Xe);
-  Iso T; T.c = cosf(Xe[2]); T.s = sinf(Xe[2]); T.tx = Xe[0]; T.ty = Xe[1];
+  Iso T; sincos_fixed(Xe[2], T.s, T.c); T.tx = Xe[0]; T.ty = Xe[1];
   return T;
 }
 
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
       if (A.prior) {
         const PriorDev& Pz = A.prior[a];
         float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, pose, E);
-        const float c = cosf(E[2]), s_ = sinf(E[2]);
+        float c, s_; sincos_fixed(E[2], s_, c);
         const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
         float OJ[9], Oe[3];
 #pragma unroll

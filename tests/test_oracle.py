@@ -335,3 +335,17 @@ def test_oracle_regression_vectors(po):
             r = po.align(po.aligner_params(10), [sp], [scan], [wl.map_points], wl.x0[i].astype(np.float64), double=True)
             assert r["status"] == want["status"] and np.allclose(r["pose"], want["pose_after_10_its_fp64"], atol=1e-6)
             assert abs(r["stats"][0].n_corr - want["n_corr_first"]) <= 2 and abs(r["stats"][0].chi_in - want["chi_first"]) <= 1e-3 * max(want["chi_first"], 1.0)
+
+
+def test_fixed_sincos_accuracy_and_quadrants(po):
+    """lsmo_sincosf replaces libm's cosf / sinf for pose rotations (same operation sequence on the GPU): within 1.2e-7 of
+    float64 sin / cos over the angles poses take, exact at 0, right signs in every quadrant, odd / even symmetry."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-7, 7, 20000), np.linspace(-math.pi, math.pi, 4001), [0.0, math.pi / 2, -math.pi / 2, math.pi, 100.0, -2500.0]]).astype(np.float32)
+    s, c = po.sincos(x)
+    assert np.abs(s.astype(np.float64) - np.sin(x.astype(np.float64))).max() < 1.2e-7
+    assert np.abs(c.astype(np.float64) - np.cos(x.astype(np.float64))).max() < 1.2e-7
+    s0, c0 = po.sincos([0.0]); assert s0[0] == 0.0 and c0[0] == 1.0
+    sp, cp = po.sincos(x); sm, cm = po.sincos(-x)
+    assert np.array_equal(sm, -sp) and np.array_equal(cm, cp)
+    assert np.abs(s * s + c * c - 1.0).max() < 3e-7

@@ -5,6 +5,7 @@
 //
 //   division  n/d, 0 < n <= d: every step scales exactly with powers of two (no subnormals inside the gate), so all
 //             2^23 x 2^23 mantissa pairs cover every admissible input; n = 1.m_n (or half of it when m_n > m_d).
+//   sincos    device vs host evaluation of the fixed sin / cos sequence (bitwise) on 6.5e6 arguments, and its error vs libm.
 //   sqrt      every fp32 bit pattern in [1e-30, FLT_MAX] (the gate's r2 lies in [1e-30, 1e36]; the lane-chunked stream also
 //             forms depths of points beyond range_max, which only have to stay above it).
 //
@@ -21,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <vector>
 
 #define NVAR 4
 struct Report { unsigned long long fails[NVAR]; uint32_t first_n[NVAR], first_d[NVAR]; };
@@ -105,11 +108,18 @@ __global__ void k_sqrt(uint32_t lo, uint32_t hi, Report* rep) {
     if (bad[k]) { if (atomicAdd(&rep->fails[k], bad[k]) == 0) rep->first_n[k] = firstx[k]; }
 }
 
+__global__ void k_sincos(const float* x, float2* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+    float s, c; lsm2d::sincos_fixed(x[i], s, c);
+    out[i] = make_float2(s, c);
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 
 int main(int argc, char** argv) {
   const uint32_t rows = argc > 1 ? (uint32_t) strtoul(argv[1], nullptr, 0) : (1u << 23);
-  Report* d_rep; Report h;
+  Report* d_rep; Report h; unsigned long long sincos_fails = 0;
   CK(hipMalloc(&d_rep, sizeof(Report)));
 
   // ---- sqrt
@@ -123,6 +133,33 @@ int main(int argc, char** argv) {
   for (int k = 0; k < NVAR; ++k) printf("  %-20s mismatches vs sqrtf: %llu  first x=0x%08x\n", sn[k], h.fails[k], h.first_n[k]);
   const unsigned long long sqrt_prod_fails = h.fails[0];
   fflush(stdout);
+
+  // ---- sincos_fixed: the kernels' rotation of a pose must have the bits the host code (and the CPU oracle, which evaluates the
+  // same fmaf sequence) gives it.  Every 97th fp32 bit pattern with |x| in [2^-20, 64]: ~6.5e6 arguments of either sign.
+  {
+    std::vector<float> xs;
+    float a = 9.5367431640625e-07f, b = 64.0f; uint32_t ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
+    for (uint32_t u = ua; u <= ub; u += 97) { float v; memcpy(&v, &u, 4); xs.push_back(v); xs.push_back(-v); }
+    const size_t n = xs.size();
+    float* d_x; float2* d_sc;
+    CK(hipMalloc(&d_x, n * sizeof(float))); CK(hipMalloc(&d_sc, n * sizeof(float2)));
+    CK(hipMemcpy(d_x, xs.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_sincos, dim3(4096), dim3(256), 0, 0, d_x, d_sc, n);
+    CK(hipDeviceSynchronize());
+    std::vector<float2> sc(n);
+    CK(hipMemcpy(sc.data(), d_sc, n * sizeof(float2), hipMemcpyDeviceToHost));
+    unsigned long long bad = 0; double worst = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+      float s, c; lsm2d::sincos_fixed(xs[i], s, c);
+      if (memcmp(&s, &sc[i].x, 4) || memcmp(&c, &sc[i].y, 4)) ++bad;
+      const double es = fabs((double) s - sin((double) xs[i])), ec = fabs((double) c - cos((double) xs[i]));
+      if (es > worst) worst = es; if (ec > worst) worst = ec;
+    }
+    printf("sincos: %zu arguments, |x| in [2^-20, 64]\n  %-20s device vs host bit mismatches: %llu  max abs error vs libm (double): %.3e\n", n, "sincos_fixed", bad, worst);
+    sincos_fails = bad + (worst > 1.5e-7 ? 1 : 0);
+    CK(hipFree(d_x)); CK(hipFree(d_sc));
+    fflush(stdout);
+  }
 
   // ---- division: rows of m_d, every m_n
   CK(hipMemset(d_rep, 0, sizeof(Report)));
@@ -146,5 +183,5 @@ int main(int argc, char** argv) {
   printf("division: %.4e (n,d) mantissa pairs\n", (double) pairs);
   for (int k = 0; k < NVAR; ++k) printf("  %-20s mismatches vs n/d: %llu  first n=0x%08x d=0x%08x\n", dn[k], h.fails[k], h.first_n[k], h.first_d[k]);
   CK(hipFree(d_rep));
-  return (h.fails[0] || sqrt_prod_fails) ? 1 : 0;
+  return (h.fails[0] || sqrt_prod_fails || sincos_fails) ? 1 : 0;
 }
