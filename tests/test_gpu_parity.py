@@ -1083,3 +1083,56 @@ def test_clipper_and_merger_small_and_large_scene_paths(ctx, po):
         n = merger.compute()
         wm, counts = po.merge_scene(opr, m, scan, np.float32(sensor[0]), 0.2)
         assert n == len(wm) and merger.counts == counts and np.array_equal(scene.download(), wm)
+
+
+def test_randomised_mapping_and_preprocessing(ctx, po):
+    """Fuzz the mapping side of the path over the parameters the ABI accepts -- projector geometry, sensor extrinsics, merge
+    threshold, scene sizes on both sides of the one-workgroup limit, synchronous and asynchronous calls, preprocessor windows and
+    voxel sizes -- bit for bit against the oracle.  LSM2D_FUZZ_TRIALS / LSM2D_FUZZ_SEED soak it."""
+    import os
+    n_trials = int(os.environ.get("LSM2D_FUZZ_TRIALS", "24")); rng = np.random.default_rng(int(os.environ.get("LSM2D_FUZZ_SEED", "77")))
+    world = synth.make_world(8)
+    maps = {n: synth.make_map(world, n, noise_sigma=0.004, seed=n + 1) for n in (700, 6000, 40000)}
+    poses = synth.sample_poses(world, 10, seed=13)
+    clipped_pts = merged_pts = prep_pts = 0
+    for trial in range(n_trials):
+        cols = int(rng.integers(90, 1500)); a0 = float(rng.uniform(-math.pi, -0.6)); a1 = float(rng.uniform(0.6, math.pi))
+        rmin = float(rng.uniform(0.0, 0.8)); rmax = float(rng.uniform(6.0, 35.0)); off = float(rng.choice([0.0, 0.5]))
+        S = np.float32([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(-3, 3)]) if trial % 3 else np.zeros(3, np.float32)
+        thr = float(rng.uniform(0.02, 0.5)); n_scene = (700, 6000, 40000)[trial % 3]; asynchronous = bool(trial % 2)
+        robot = poses[trial % 10] + np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2)])
+        beams = int(rng.integers(64, 1400)); fov = float(rng.uniform(1.0, 3.1))
+        vox = float(rng.choice([0.0, 0.02, 0.05, 0.2])); npd = float(rng.uniform(0.05, 0.6)); nmin = int(rng.integers(2, 9))
+        m = maps[n_scene]
+        proj = api.PointNormal2fProjectorPolar(cols, a0, a1, rmin, rmax, off); opr = po.Projector(cols, a0, a1, rmin, rmax, off)
+        # preprocessor: raw ranges -> measurement (into a reserved set on odd trials)
+        sensor = synth.compose_poses(robot[None, :], S[None, :].astype(np.float64))
+        ranges = synth.make_scan_ranges(world, sensor, n_beams=beams, angle_min=-fov / 2, angle_max=fov / 2, noise_sigma=0.005, seed=trial)[0]
+        pre = api.RawDataPreprocessorProjective2D(ctx, range_min=rmin, range_max=rmax, voxelize_resolution=vox, normal_point_distance=npd, normal_min_points=nmin)
+        pre.setRawData(ranges, -fov / 2, fov / 2, 0.0, 40.0)
+        meas_set = pre.compute_into(api.CloudSet.reserved(ctx, 2048)) if asynchronous else pre.compute()
+        want_meas = po.preprocess_scan(po.Preprocessor(beams, -fov / 2, fov / 2, rmin, rmax, npd, nmin, vox), ranges)
+        assert np.array_equal(meas_set.download(0), want_meas), ("preprocess", trial)
+        prep_pts += len(want_meas)
+        # clipper
+        scene = api.CloudSet.reserved(ctx, n_scene + 4 * cols); scene.upload(m)
+        clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=asynchronous); clipper.setFullScene(scene)
+        clipper.setRobotInLocalMap(np.float32(robot)); clipper.setSensorInRobot(S)
+        clipped = clipper.compute()
+        want_clip, want_src = po.clip_scene(opr, m, np.float32(robot), S)
+        assert np.array_equal(clipped.download(), want_clip), ("clip", trial)
+        if not asynchronous:
+            assert np.array_equal(clipper.source_indices, want_src)
+        clipped_pts += len(want_clip)
+        # merger: the measurement twice (the second pass mostly merges into what the first one added)
+        merger = api.MergerProjective2D(ctx, proj, thr, asynchronous=asynchronous); merger.setScene(scene); merger.setMeasurement(meas_set)
+        mis = np.float32(sensor[0]); host = m
+        for _ in range(2):
+            merger.setMeasurementInScene(mis); n = merger.compute()
+            host, counts = po.merge_scene(opr, host, want_meas, mis, thr)
+            if not asynchronous:
+                assert n == len(host) and merger.counts == counts, ("merge", trial)
+        assert scene.n_points == len(host) and np.array_equal(scene.download(), host), ("merge", trial)
+        merged_pts += len(host)
+    print("mapping fuzz: %d trials, %d clipped / %d merged / %d preprocessed points bit-exact" % (n_trials, clipped_pts, merged_pts, prep_pts))
+    assert clipped_pts > 1000 and prep_pts > 1000
