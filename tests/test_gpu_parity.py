@@ -31,6 +31,20 @@ def _oracle_slice(po, sp):
                            sensor_in_robot=tuple(sp.sensor_in_robot))
 
 
+def _same_correspondence_sets(gpu_stats, oracle_stats, iterations):
+    """Did the device and the fp32 oracle use the SAME pairs in every iteration?  Equal counts are necessary, not sufficient: an
+    ICP on z-buffer correspondences often ends in a limit cycle where a pair or two flip every iteration, and two runs whose poses
+    differ in their last bits can settle on different cycles with equal counts.  Equal sets give chi^2 sums that agree to fp32
+    summation noise (<= ~1e-4 relative); one exchanged pair shows up at the 1e-3 level."""
+    for k in range(iterations):
+        g, o = gpu_stats[k], oracle_stats[k]
+        if int(g["n_correspondences"]) != o.n_corr or int(g["n_inliers"]) != o.n_in:
+            return False
+        if abs(float(g["chi_inliers"]) - o.chi_in) > 3e-4 * abs(o.chi_in) + 1e-9:
+            return False
+    return True
+
+
 def _projector(cols=1081, rmin=0.3, rmax=30.0, off=0.0):
     return api.PointNormal2fProjectorPolar(cols, -math.pi, math.pi, rmin, rmax, off)
 
@@ -1048,7 +1062,7 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
             tol_m, tol_rad = max(POSE_TOL_M, 4.0 * dd[:2].max()), max(POSE_TOL_RAD, 4.0 * dd[2])
             # ... or the correspondence SETS part ways: after a solve the poses differ in their last bits (tree vs sequential sums),
             # a point next to a column edge changes its cell, and with a few hundred pairs two of them move the optimum by > 1e-4
-            same_sets = res_g.stats[0]["n_correspondences"][:r["iterations"]].tolist() == [st.n_corr for st in r["stats"]]
+            same_sets = _same_correspondence_sets(res_g.stats[0], r["stats"], r["iterations"])
             if not same_sets:
                 tol_m, tol_rad = max(tol_m, 1e-3), max(tol_rad, 1e-3)
             assert d[:2].max() < tol_m and d[2] < tol_rad, (trial, finder, d, dd)
@@ -1056,7 +1070,7 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
             checked_poses += 1
     if only >= 0:
         return
-    assert checked_pairs > 5000 and checked_poses >= 12 and soft <= max(2, checked_poses // 8)
+    assert checked_pairs > 5000 and checked_poses >= 12 and soft <= max(3, checked_poses // 3)
     print("fuzz: %d trials, %d pairs bit-exact, %d poses checked (%d against a widened bar)" % (n_trials, checked_pairs, checked_poses, soft))
 
 
@@ -1136,3 +1150,76 @@ def test_randomised_mapping_and_preprocessing(ctx, po):
         merged_pts += len(host)
     print("mapping fuzz: %d trials, %d clipped / %d merged / %d preprocessed points bit-exact" % (n_trials, clipped_pts, merged_pts, prep_pts))
     assert clipped_pts > 1000 and prep_pts > 1000
+
+
+def test_randomised_aligner_structure(ctx, po):
+    """Fuzz the aligner's STRUCTURE: 1-3 projective slices with their own projectors and extrinsics, Cauchy on some, an odometry
+    prior on some, batches of 1-5 alignments choosing their scans through an index array, 1-12 iterations.  The split path must
+    give the fused path's bits; against the oracle the first iteration has the same correspondence count and the final pose is
+    within the north_star tolerance (widened only where the fp32 and fp64 oracles themselves disagree or the sets part ways)."""
+    import os
+    n_trials = int(os.environ.get("LSM2D_FUZZ_TRIALS", "12")); rng = np.random.default_rng(int(os.environ.get("LSM2D_FUZZ_SEED", "5")))
+    world = synth.make_world(7)
+    maps = {n: synth.make_map(world, n, noise_sigma=0.003, seed=n + 3) for n in (4000, 30000)}
+    poses = synth.sample_poses(world, 8, seed=17)
+    checked = soft = 0
+    for trial in range(n_trials):
+        ns = int(rng.integers(1, 4)); nb = int(rng.integers(1, 6)); its = int(rng.integers(1, 13)); m = maps[(4000, 30000)[trial % 2]]
+        use_prior = bool(trial % 3 == 0)
+        robots = poses[rng.integers(0, 8, nb)]
+        guess = synth.compose_poses(robots, rng.uniform(-0.04, 0.04, (nb, 3)))
+        x0 = synth.invert_poses(guess).astype(np.float32)
+        al = api.MultiAligner2D(ctx, max_iterations=its, min_num_inliers=int(rng.integers(0, 30)))
+        fixed_sets, oslices, scans_per_slice = [], [], []
+        for s in range(ns):
+            cols = int(rng.integers(200, 1300)); rmax = float(rng.uniform(8.0, 30.0)); ncos = float(rng.uniform(0.5, 0.9)); pd = float(rng.uniform(0.2, 1.0))
+            S = np.float32([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(-3, 3)]) if (trial + s) % 2 else np.zeros(3, np.float32)
+            cauchy = bool((trial + s) % 3 == 1); tau = float(rng.uniform(0.005, 0.05)); mc = int(rng.integers(0, 20))
+            proj = api.PointNormal2fProjectorPolar(cols, -math.pi, math.pi, 0.3, rmax)
+            f = api.CorrespondenceFinderProjective2f(ctx, proj, pd, ncos)
+            rob = api.RobustifierCauchy(tau) if cauchy else None
+            sl = (api.AlignerSliceProcessorLaser2DWithSensor(f, sensor_in_robot=S, robustifier=rob, min_num_correspondences=mc) if S.any()
+                  else api.AlignerSliceProcessorLaser2D(f, robustifier=rob, min_num_correspondences=mc))
+            al.param_slice_processors.append(sl)
+            pts, offs = synth.make_scans(world, synth.compose_poses(robots, np.tile(S[None, :].astype(np.float64), (nb, 1))), n_beams=int(rng.integers(300, 1100)),
+                                         noise_sigma=0.003, seed=trial * 7 + s)
+            fixed_sets.append(api.CloudSet(ctx, pts, offs)); scans_per_slice.append((pts, offs))
+            oslices.append(_oracle_slice(po, sl.slice_params()))
+        pri = [(np.zeros(3, np.float32) + x0[i], np.diag(rng.uniform(5.0, 80.0, 3)).astype(np.float32)) for i in range(nb)] if use_prior else None
+        mv = [api.CloudSet(ctx, m)] * ns
+
+        def run(path):
+            ctx.set_option("align_path", path)
+            try:
+                return al.compute_batch(fixed_sets, mv, x0, priors=pri, want_stats=True)
+            finally:
+                ctx.set_option("align_path", 0)
+        a, b = run(1), run(2)
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.information, b.information) and np.array_equal(a.status, b.status), ("split != fused", trial)
+        for i in range(nb):
+            sc = [p[o[i]:o[i + 1]] for p, o in scans_per_slice]
+            kw = dict(prior_z=pri[i][0], prior_omega=pri[i][1]) if use_prior else {}
+            r = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, **kw), oslices, sc, [m] * ns, x0[i])
+            rd = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, **kw), oslices, sc, [m] * ns, x0[i].astype(np.float64), double=True)
+            assert a.stats[i]["n_correspondences"][0] == r["stats"][0].n_corr, ("first iteration", trial, i)
+            dd = np.abs(r["pose"].astype(np.float64) - rd["pose"]); dd[2] = abs((dd[2] + math.pi) % (2 * math.pi) - math.pi)
+            if not (r["status"] == rd["status"] == 0 and r["iterations"] == rd["iterations"] and dd[:2].max() < 1e-3 and dd[2] < 1e-3):
+                continue
+            assert a.status[i] == 0 and a.iterations[i] == r["iterations"], (trial, i, a.status[i])
+            same_sets = _same_correspondence_sets(a.stats[i], r["stats"], r["iterations"])
+            tol = max(POSE_TOL_M, 4.0 * dd.max(), 0.0 if same_sets else 1e-3)
+            d = np.abs(a.pose[i] - r["pose"]); d[2] = abs((d[2] + math.pi) % (2 * math.pi) - math.pi)
+            if d.max() >= tol and os.environ.get("LSM2D_FUZZ_VERBOSE"):
+                print("trial", trial, "alignment", i, dict(ns=ns, nb=nb, its=its, prior=use_prior, n_map=len(m)))
+                for sl_ in al.param_slice_processors:
+                    sp_ = sl_.slice_params(); print("  slice cols", sp_.projector.canvas_cols, "rmax", sp_.projector.range_max, "pd", sp_.point_distance, "nc", sp_.normal_cos,
+                                                    "rob", sp_.robustifier, sp_.chi_threshold, "mc", sp_.min_num_correspondences, "S", list(sp_.sensor_in_robot))
+                for k_ in range(r["iterations"]):
+                    g_ = a.stats[i][k_]; o_ = r["stats"][k_]; t_ = rd["stats"][k_]
+                    print("  it %d gpu n=%d in=%d chi=%.7g | f32 n=%d in=%d chi=%.7g | f64 n=%d in=%d chi=%.7g" % (k_, g_["n_correspondences"], g_["n_inliers"], g_["chi_inliers"],
+                          o_.n_corr, o_.n_in, o_.chi_in, t_.n_corr, t_.n_in, t_.chi_in))
+                print("  pose gpu", a.pose[i].tolist(), "f32", r["pose"].tolist(), "f64", rd["pose"].tolist())
+            assert d.max() < tol, (trial, i, d, dd, same_sets)
+            checked += 1; soft += int(tol > POSE_TOL_M)
+    print("structure fuzz: %d trials, %d alignments checked (%d against a widened bar), split == fused in all" % (n_trials, checked, soft))
+    assert checked >= n_trials // 2
