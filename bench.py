@@ -227,10 +227,21 @@ def main() -> None:
                 po.align_batch(po.aligner_params(args.iterations), osp, wl.scan_points[: offs[-1]], offs, map_host, x0[:ns], n_threads=nt)
                 all_cores = {"value": ns / (time.perf_counter() - t2), "cores": nt}
             d = np.abs(res.pose[:ns] - xo)
+            # the same checker summing in the kernels' order must reproduce the device BIT FOR BIT (a handful of alignments)
+            nbit = min(16, ns); bit_equal = 0
+            if args.role == "A":
+                for i in range(nbit):
+                    rt = po.align(po.aligner_params(args.iterations, device_order=True), [osp], [wl.scan_points[offs[i]:offs[i + 1]]], [map_host], x0[i])
+                    bit_equal += int(np.array_equal(res.pose[i], rt["pose"]) and np.array_equal(res.information[i], rt["H"]))
+            else:
+                for i in range(nbit):
+                    rt = po.align(po.aligner_params(args.iterations, device_order=True), [osp], [map_host], [wl.scan_points[offs[i]:offs[i + 1]]], x0[i])
+                    bit_equal += int(np.array_equal(res.pose[i], rt["pose"]) and np.array_equal(res.information[i], rt["H"]))
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "alignments/s", "cores": 1, "kind": "port",
                                    "sample": "first %d alignments of the same batch, CPU restatement of the reference algorithm (oracle/, gcc -O3 -march=native, fp32), %.1f s"
                                              % (ns, cpu_s),
-                                   "max_pose_diff_gpu_vs_cpu_m": float(d[:, :2].max()), "max_pose_diff_gpu_vs_cpu_rad": float(d[:, 2].max())}
+                                   "max_pose_diff_gpu_vs_cpu_m": float(d[:, :2].max()), "max_pose_diff_gpu_vs_cpu_rad": float(d[:, 2].max()),
+                                   "bit_identical_to_device_order_port": "%d of %d alignments (pose and information matrix)" % (bit_equal, nbit)}
             if all_cores:
                 out["cpu_baseline"]["all_cores"] = all_cores
         print(json.dumps(out), flush=True)

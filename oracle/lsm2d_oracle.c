@@ -63,6 +63,7 @@ static float lsmo_sinf_fixed(float a) { float s, c; lsmo_sincosf(a, &s, &c); ret
 
 /* ---- fp32 mirror --------------------------------------------------------------------------- */
 #define REAL float
+#define LSMO_FLOAT_PASS 1
 #define SFX(n) n##_f
 #define R_FMA(a, b, c) fmaf((a), (b), (c))
 #define R_SQRT(a) sqrtf(a)
@@ -78,6 +79,7 @@ static float lsmo_sinf_fixed(float a) { float s, c; lsmo_sincosf(a, &s, &c); ret
 #define R_TWO_PI 6.28318548202514648f
 #include "lsm2d_oracle_impl.inc"
 #undef REAL
+#undef LSMO_FLOAT_PASS
 #undef SFX
 #undef R_FMA
 #undef R_SQRT

@@ -74,6 +74,14 @@ typedef struct {
   int   has_prior;                    /* odometry-prior slice (MULTI.json:402-422): e = t2v(Z^-1 X), Omega */
   float prior_z[3];
   float prior_omega[9];
+  int   device_order;                 /* fp32 mirror only.  0: H, b and the statistics are summed pair after pair, as the reference's
+                                         solver does.  1: they are summed in the ORDER THE HIP KERNELS USE (the pair of column c /
+                                         moving point j goes to thread c mod 512 / j mod 512, threads sum their pairs in turn, a wave's
+                                         64 partial sums are combined by the DPP scan tree of wave_sum63, the 8 wave totals in wave
+                                         order) -- every other operation already is the same sequence on both sides, so with this
+                                         switch the mirror reproduces the device's poses, H and statistics BIT FOR BIT through all
+                                         iterations (chi_out excepted: it goes through the two libms' logf).  The two orders are
+                                         equally valid fp32 evaluations of the same sums. */
 } lsmo_aligner_params;
 
 typedef struct {

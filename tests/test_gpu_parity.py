@@ -45,6 +45,20 @@ def _same_correspondence_sets(gpu_stats, oracle_stats, iterations):
     return True
 
 
+def _assert_bitwise_equal_to_device_order_oracle(res, i, rt, tag):
+    """The fp32 oracle with lsmo_aligner_params.device_order = 1 sums in the kernels' order: everything must be equal BITWISE --
+    status, iteration count, pose, information matrix, and every iteration's counts and inlier chi^2 (chi_out goes through logf
+    of two different libms and is left out)."""
+    assert int(res.status[i]) == rt["status"] and int(res.iterations[i]) == rt["iterations"], (tag, res.status[i], rt["status"], res.iterations[i], rt["iterations"])
+    assert np.array_equal(res.pose[i], rt["pose"]), (tag, "pose", res.pose[i].tolist(), rt["pose"].tolist())
+    assert np.array_equal(res.information[i], rt["H"]), (tag, "H", res.information[i].tolist(), rt["H"].tolist())
+    if res.stats is not None:
+        for k in range(rt["iterations"]):
+            g, o = res.stats[i][k], rt["stats"][k]
+            assert (int(g["n_correspondences"]), int(g["n_inliers"]), int(g["n_outliers"])) == (o.n_corr, o.n_in, o.n_out), (tag, "counts", k)
+            assert np.float32(g["chi_inliers"]) == np.float32(o.chi_in), (tag, "chi_in", k, float(g["chi_inliers"]), o.chi_in)
+
+
 def _projector(cols=1081, rmin=0.3, rmax=30.0, off=0.0):
     return api.PointNormal2fProjectorPolar(cols, -math.pi, math.pi, rmin, rmax, off)
 
@@ -1034,6 +1048,9 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
         res_g = al.compute_batch([scan], [m], x0[None, :], want_stats=True)
         r = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers), [osp], [scan], [m], x0)
         rd = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers), [osp], [scan], [m], x0.astype(np.float64), double=True)
+        rt = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, device_order=True), [osp], [scan], [m], x0)
+        if only < 0:
+            _assert_bitwise_equal_to_device_order_oracle(res_g, 0, rt, ("trial=%d" % trial, finder))       # EVERY trial, well-posed or not
         if only >= 0:
             print("trial", trial, dict(finder=finder, n_map=n_map, beams=beams, cols=cols, off=off, a0=a0, a1=a1, rmin=rmin, rmax=rmax, pd=pd, nc=nc, md=md, res=res,
                                        cauchy=cauchy, tau=tau, mc=mc, S=S, its=its, min_inl=min_inl, x0=x0.tolist()))
@@ -1201,6 +1218,8 @@ def test_randomised_aligner_structure(ctx, po):
             kw = dict(prior_z=pri[i][0], prior_omega=pri[i][1]) if use_prior else {}
             r = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, **kw), oslices, sc, [m] * ns, x0[i])
             rd = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, **kw), oslices, sc, [m] * ns, x0[i].astype(np.float64), double=True)
+            rt = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, device_order=True, **kw), oslices, sc, [m] * ns, x0[i])
+            _assert_bitwise_equal_to_device_order_oracle(a, i, rt, ("trial=%d" % trial, i))
             assert a.stats[i]["n_correspondences"][0] == r["stats"][0].n_corr, ("first iteration", trial, i)
             dd = np.abs(r["pose"].astype(np.float64) - rd["pose"]); dd[2] = abs((dd[2] + math.pi) % (2 * math.pi) - math.pi)
             if not (r["status"] == rd["status"] == 0 and r["iterations"] == rd["iterations"] and dd[:2].max() < 1e-3 and dd[2] < 1e-3):
