@@ -349,3 +349,25 @@ def test_fixed_sincos_accuracy_and_quadrants(po):
     sp, cp = po.sincos(x); sm, cm = po.sincos(-x)
     assert np.array_equal(sm, -sp) and np.array_equal(cm, cp)
     assert np.abs(s * s + c * c - 1.0).max() < 3e-7
+
+
+def test_device_order_summation_is_the_same_sum(po):
+    """lsmo_aligner_params.device_order re-associates the per-pair sums (thread = column mod 512, DPP scan tree, waves in order) and
+    changes nothing else: first-iteration statistics are identical up to fp32 summation noise, poses agree to ~1e-5, for every
+    finder, with Cauchy and with a prior."""
+    wl = synth.make_workload(3, 20000, seed=4)
+    scans = [wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]] for i in range(3)]
+    cases = [po.slice_params(), po.slice_params(robustifier=po.ROBUST_CAUCHY, chi_threshold=0.02),
+             po.slice_params(finder=po.FINDER_NN, max_distance=0.3), po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.1)]
+    for sp in cases:
+        for i in range(3):
+            kw = dict(prior_z=wl.x0[i], prior_omega=np.eye(3) * 10.0) if i == 2 else {}
+            a = po.align(po.aligner_params(10, **kw), [sp], [scans[i]], [wl.map_points], wl.x0[i])
+            b = po.align(po.aligner_params(10, device_order=True, **kw), [sp], [scans[i]], [wl.map_points], wl.x0[i])
+            assert a["status"] == b["status"] == 0 and a["iterations"] == b["iterations"]
+            sa, sb = a["stats"][0], b["stats"][0]
+            assert (sa.n_corr, sa.n_in, sa.n_out) == (sb.n_corr, sb.n_in, sb.n_out)
+            assert abs(sa.chi_in - sb.chi_in) <= 2e-5 * abs(sa.chi_in) + 1e-9
+            d = np.abs(a["pose"] - b["pose"])
+            assert d.max() < 2e-5, (sp.finder, i, d)
+            assert np.abs(a["H"] - b["H"]).max() <= 2e-4 * np.abs(a["H"]).max()
