@@ -129,6 +129,12 @@ int lsmo_linearize_f(const lsmo_slice_params* sp, const lsmo_point* fixed, const
 int lsmo_linearize_d(const lsmo_slice_params* sp, const lsmo_point* fixed, const lsmo_point* moving,
                      const lsmo_corr* corr, int n_corr, const double pose[3],
                      double H[9], double b[3], lsmo_iter_stats* st);
+/* the same sums in the order a HIP launch of `threads` threads in workgroups of `block` forms them (see lsmo_aligner_params.device_order
+ * and lsm2d_oracle_impl.inc): pair k -> thread (slot ? slot[k] : k) mod threads.  lsm2d_linearize: block 256, threads = 256 *
+ * min(1024, ceil(n / 256)); the aligner kernels: block = threads = 512, slot = column / moving index. */
+int lsmo_linearize_device_order_f(const lsmo_slice_params* sp, const lsmo_point* fixed, const lsmo_point* moving,
+                                  const lsmo_corr* corr, const int* slot, int n_corr, const float pose[3], int threads, int block,
+                                  float H[9], float b[3], lsmo_iter_stats* st);
 /* error and Jacobian of ONE pair (for the finite-difference test) */
 void lsmo_error_jacobian_d(const lsmo_point* f, const lsmo_point* m, const double pose[3],
                            double e[3], double J[9]);

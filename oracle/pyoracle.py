@@ -180,6 +180,19 @@ def linearize(sp: SliceParams, fixed, moving, corr, pose, double=False):
     return H.reshape(3, 3), b, st
 
 
+def linearize_device_order(sp: SliceParams, fixed, moving, corr, pose):
+    """H, b, stats summed in the order lsm2d_linearize's launch forms them (workgroups of 256, one thread per pair up to 1024 groups)."""
+    fixed, pf = _pts(fixed); moving, pm = _pts(moving)
+    corr = np.ascontiguousarray(corr, np.int32)
+    H = np.empty(9, np.float32); b = np.empty(3, np.float32); st = IterStats()
+    pose = np.ascontiguousarray(pose, np.float32)
+    blocks = min(1024, max(1, (len(corr) + 255) // 256))
+    rc = lib().lsmo_linearize_device_order_f(C.byref(sp), pf, pm, corr.ctypes.data_as(C.c_void_p), None, len(corr), pose.ctypes.data_as(C.c_void_p),
+                                             256 * blocks, 256, H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(st))
+    assert rc == 0
+    return H.reshape(3, 3), b, st
+
+
 def error_jacobian(f, m, pose):
     f = np.ascontiguousarray(f, np.float32); m = np.ascontiguousarray(m, np.float32)
     e = np.empty(3); J = np.empty(9); pose = np.ascontiguousarray(pose, np.float64)

@@ -138,6 +138,16 @@ def test_factor_known_answer_and_parity(ctx, po, small_workload):
         assert st.n_correspondences == len(corr) and st.n_inliers == ost.n_in and st.n_outliers == ost.n_out
         assert abs(st.chi_inliers - ost.chi_in) <= 2e-5 * max(ost.chi_in, 1.0)
         assert abs(st.chi_outliers - ost.chi_out) <= 2e-5 * max(ost.chi_out, 1.0)
+        # ... and BITWISE against the fp32 oracle summing in this launch's order (a few hundred pairs: two workgroups of 256)
+        tH, tb, tst = po.linearize_device_order(po.slice_params(robustifier=robust, chi_threshold=0.05), f, wl.map_points, corr, wl.x0[0])
+        assert np.array_equal(H, tH) and np.array_equal(b, tb) and np.float32(st.chi_inliers) == np.float32(tst.chi_in)
+    # the NN finder's thousands of pairs: many workgroups, the launch's two-level order
+    osp = po.slice_params(finder=po.FINDER_NN, max_distance=0.3)
+    corr = po.find(osp, f, wl.map_points, wl.x0[0])
+    assert len(corr) > 3000
+    H, b, st = api.linearize(ctx, api.make_slice_params(), f, wl.map_points, corr, wl.x0[0])
+    tH, tb, tst = po.linearize_device_order(po.slice_params(), f, wl.map_points, corr, wl.x0[0])
+    assert np.array_equal(H, tH) and np.array_equal(b, tb) and np.float32(st.chi_inliers) == np.float32(tst.chi_in) and st.n_correspondences == len(corr)
     # empty correspondence vector
     H, b, st = api.linearize(ctx, sp, f, wl.map_points, np.zeros((0, 2), np.int32), wl.x0[0])
     assert np.all(H == 0) and np.all(b == 0) and st.n_correspondences == 0
