@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--sync-calls", action="store_true",
                     help="every clip / merge call waits for its result (5 host synchronisations per step); default: the clipper and the "
                          "merger only queue their work and the step synchronises once, for the aligner's pose")
+    ap.add_argument("--sequential-oracle", action="store_true",
+                    help="the CPU side sums H, b pair after pair (the reference's order: poses then agree to ~1e-7 per step); default: it "
+                         "sums in the kernels' order (lsmo_aligner_params.device_order), and the two pipelines must stay BIT-IDENTICAL")
     ap.add_argument("--chained", action="store_true",
                     help="let the GPU pipeline run on its own state for the whole trajectory (reports drift); default is lockstep: "
                          "before every step the GPU state is reset to the CPU state, so differences are per-step")
@@ -111,7 +114,7 @@ def main():
         t = time.perf_counter()
         guess_c = synth.compose_poses(est_cpu[None, :], odo[None, :])[0].astype(np.float32)
         oclip, _ = po.clip_scene(opr, host_map, guess_c, S0)
-        r = po.align(po.aligner_params(10, prior_z=[0, 0, 0], prior_omega=omega), osl, [a0, a1], [oclip, oclip], np.zeros(3, np.float32))
+        r = po.align(po.aligner_params(10, prior_z=[0, 0, 0], prior_omega=omega, device_order=not args.sequential_oracle), osl, [a0, a1], [oclip, oclip], np.zeros(3, np.float32))
         est_cpu = synth.compose_poses(guess_c[None, :].astype(np.float64), synth.invert_poses(r["pose"][None, :].astype(np.float64)))[0]
         for meas, S in ((a0, S0), (a1, S1)):
             host_map, _ = po.merge_scene(opr, host_map, meas, np.float32(synth.compose_poses(est_cpu[None, :], S[None, :].astype(np.float64))[0]), 0.2)
@@ -126,7 +129,9 @@ def main():
            "gpu_phase_ms_per_step": {k: 1e3 * v / args.steps for k, v in phase.items()},
            "steps": args.steps, "gpu_ms_per_step_wall": 1e3 * t_gpu / args.steps, "gpu_align_kernel_ms_per_step": gpu_kernel_ms / args.steps,
            "cpu_oracle_ms_per_step_wall": 1e3 * t_cpu / args.steps, "max_pose_diff_gpu_vs_cpu_m": float(max_dp), "max_pose_diff_gpu_vs_cpu_rad": float(max_dth),
+           "oracle_summation": "sequential (reference order)" if args.sequential_oracle else "device order",
            "final_map_points_gpu": int(local_map.n_points), "final_map_points_cpu": int(len(host_map)),
+           "final_maps_bit_identical": bool(np.array_equal(local_map.download(), host_map)),
            "max_abs_translation_error_vs_truth_m": float(max(err_truth)), "final_translation_error_vs_truth_m": float(err_truth[-1])}
     print(json.dumps(out))
 
