@@ -58,6 +58,23 @@ void lsmo_sincosf(float x, float* sn, float* cs) {
   *sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
   *cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
 }
+/* log of a positive normal number as a FIXED operation sequence (the Cauchy kernel's statistic chi_out = tau * log(1 + chi/tau) was
+ * the last libm call on the path): x = m * 2^e with m in [sqrt(1/2), sqrt(2)), f = m - 1, log x = e*ln2 + f - f^2/2 + f^3 P(f);
+ * degree-7 P from tools/fit_log.py, max relative error 1.3e-7. */
+float lsmo_logf_fixed(float x) {
+  unsigned int bits; memcpy(&bits, &x, 4);
+  int e = (int) (bits >> 23) - 127;
+  unsigned int mb = (bits & 0x7FFFFFu) | 0x3F800000u;
+  float m; memcpy(&m, &mb, 4);
+  if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+  const float f = m - 1.0f, z = f * f;
+  float p = -7.6311752200e-02f;
+  p = fmaf(p, f, 1.2854909897e-01f); p = fmaf(p, f, -1.3207894564e-01f); p = fmaf(p, f, 1.4190009236e-01f);
+  p = fmaf(p, f, -1.6616521776e-01f); p = fmaf(p, f, 2.0001615584e-01f); p = fmaf(p, f, -2.5001060963e-01f);
+  p = fmaf(p, f, 3.3333328366e-01f);
+  const float r = fmaf(z * f, p, fmaf(-0.5f, z, f));
+  return fmaf((float) e, 6.9314718246e-01f, r);
+}
 static float lsmo_cosf_fixed(float a) { float s, c; lsmo_sincosf(a, &s, &c); return c; }
 static float lsmo_sinf_fixed(float a) { float s, c; lsmo_sincosf(a, &s, &c); return s; }
 
@@ -70,7 +87,7 @@ static float lsmo_sinf_fixed(float a) { float s, c; lsmo_sincosf(a, &s, &c); ret
 #define R_COS(a) lsmo_cosf_fixed(a)
 #define R_SIN(a) lsmo_sinf_fixed(a)
 #define R_ATAN2(y, x) lsmo_atan2f((y), (x))
-#define R_LOG(a) logf(a)
+#define R_LOG(a) lsmo_logf_fixed(a)
 #define R_FABS(a) fabsf(a)
 #define R_FLOOR(a) floorf(a)
 #define R_MAX FLT_MAX

@@ -80,7 +80,7 @@ typedef struct {
                                          64 partial sums are combined by the DPP scan tree of wave_sum63, the 8 wave totals in wave
                                          order) -- every other operation already is the same sequence on both sides, so with this
                                          switch the mirror reproduces the device's poses, H and statistics BIT FOR BIT through all
-                                         iterations (chi_out excepted: it goes through the two libms' logf).  The two orders are
+                                         iterations.  The two orders are
                                          equally valid fp32 evaluations of the same sums. */
 } lsmo_aligner_params;
 
@@ -91,6 +91,7 @@ typedef struct {
 
 /* ---- scalar helpers --------------------------------------------------------------------- */
 float lsmo_atan2f(float y, float x);     /* the fixed-polynomial atan2 both CPU and GPU evaluate */
+float lsmo_logf_fixed(float x);             /* the fixed-sequence log of the Cauchy kernel statistic (x > 0, normal) */
 void  lsmo_sincosf(float x, float* sn, float* cs);     /* the fixed-sequence sin / cos of a pose angle both CPU and GPU evaluate */
 void  lsmo_compose_f(const float a[3], const float b[3], float out[3]);   /* v2t(a)*v2t(b) -> t2v */
 void  lsmo_inverse_f(const float a[3], float out[3]);

@@ -84,9 +84,17 @@ def lib():
         _lib = C.CDLL(override if override else build())
         _lib.lsmo_atan2f.restype = C.c_float
         _lib.lsmo_atan2f.argtypes = [C.c_float, C.c_float]
+        _lib.lsmo_logf_fixed.restype = C.c_float
+        _lib.lsmo_logf_fixed.argtypes = [C.c_float]
         _lib.lsmo_sincosf.restype = None
         _lib.lsmo_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     return _lib
+
+
+def log_fixed(x):
+    """float32 array through the oracle's fixed-sequence lsmo_logf_fixed."""
+    x = np.atleast_1d(np.asarray(x, np.float32)); L = lib()
+    return np.array([L.lsmo_logf_fixed(float(v)) for v in x], np.float32)
 
 
 def sincos(x):

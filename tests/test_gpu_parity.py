@@ -47,8 +47,7 @@ def _same_correspondence_sets(gpu_stats, oracle_stats, iterations):
 
 def _assert_bitwise_equal_to_device_order_oracle(res, i, rt, tag):
     """The fp32 oracle with lsmo_aligner_params.device_order = 1 sums in the kernels' order: everything must be equal BITWISE --
-    status, iteration count, pose, information matrix, and every iteration's counts and inlier chi^2 (chi_out goes through logf
-    of two different libms and is left out)."""
+    status, iteration count, pose, information matrix, and every iteration's counts and chi^2 sums (inliers and kernelised outliers)."""
     assert int(res.status[i]) == rt["status"] and int(res.iterations[i]) == rt["iterations"], (tag, res.status[i], rt["status"], res.iterations[i], rt["iterations"])
     assert np.array_equal(res.pose[i], rt["pose"]), (tag, "pose", res.pose[i].tolist(), rt["pose"].tolist())
     assert np.array_equal(res.information[i], rt["H"]), (tag, "H", res.information[i].tolist(), rt["H"].tolist())
@@ -57,6 +56,7 @@ def _assert_bitwise_equal_to_device_order_oracle(res, i, rt, tag):
             g, o = res.stats[i][k], rt["stats"][k]
             assert (int(g["n_correspondences"]), int(g["n_inliers"]), int(g["n_outliers"])) == (o.n_corr, o.n_in, o.n_out), (tag, "counts", k)
             assert np.float32(g["chi_inliers"]) == np.float32(o.chi_in), (tag, "chi_in", k, float(g["chi_inliers"]), o.chi_in)
+            assert np.float32(g["chi_outliers"]) == np.float32(o.chi_out), (tag, "chi_out", k, float(g["chi_outliers"]), o.chi_out)
 
 
 def _projector(cols=1081, rmin=0.3, rmax=30.0, off=0.0):

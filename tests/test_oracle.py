@@ -371,3 +371,12 @@ def test_device_order_summation_is_the_same_sum(po):
             d = np.abs(a["pose"] - b["pose"])
             assert d.max() < 2e-5, (sp.finder, i, d)
             assert np.abs(a["H"] - b["H"]).max() <= 2e-4 * np.abs(a["H"]).max()
+
+
+def test_fixed_log_accuracy(po):
+    """lsmo_logf_fixed replaces libm's logf in the Cauchy kernel statistic (same operation sequence on the GPU)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(1.0, 8.0, 20000), np.exp(rng.uniform(0.0, 60.0, 20000)), [1.0, 2.0, 1.4142135, 1.4142137]]).astype(np.float32)
+    got = po.log_fixed(x).astype(np.float64); ref = np.log(x.astype(np.float64))
+    assert (np.abs(got - ref) / np.maximum(ref, 0.1)).max() < 2e-7
+    assert po.log_fixed([1.0])[0] == 0.0
