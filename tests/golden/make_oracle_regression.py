@@ -30,6 +30,14 @@ def main():
                          ("distmap", po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.1))):
             pairs = po.find(sp, scan, wl.map_points, wl.x0[i])
             r = po.align(po.aligner_params(10), [sp], [scan], [wl.map_points], wl.x0[i].astype(np.float64), double=True)
+            # the fp32 mirror is a fixed sequence of IEEE operations (no libm since the fixed sin / cos / log): its results are the same
+            # BITS on every host, in both summation orders
+            f32 = {}
+            for tag, dev in (("sequential", False), ("device_order", True)):
+                rf = po.align(po.aligner_params(10, device_order=dev), [sp], [scan], [wl.map_points], wl.x0[i])
+                f32[tag] = {"pose_hex": [float(v).hex() for v in rf["pose"]], "status": int(rf["status"]),
+                            "n_corr": [int(st.n_corr) for st in rf["stats"]], "chi_in_hex": [float(st.chi_in).hex() for st in rf["stats"]]}
+            c[name + "_fp32"] = f32
             c[name] = {"n_pairs": int(len(pairs)), "pairs_checksum": int((pairs.astype(np.int64) * np.array([1000003, 7919])).sum() % (2 ** 31)),
                        "pose_after_10_its_fp64": [float(v) for v in r["pose"]], "status": int(r["status"]),
                        "n_corr_first": int(r["stats"][0].n_corr), "n_corr_last": int(r["stats"][-1].n_corr), "chi_first": float(r["stats"][0].chi_in)}

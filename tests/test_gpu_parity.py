@@ -1252,3 +1252,26 @@ def test_randomised_aligner_structure(ctx, po):
             checked += 1; soft += int(tol > POSE_TOL_M)
     print("structure fuzz: %d trials, %d alignments checked (%d against a widened bar), split == fused in all" % (n_trials, checked, soft))
     assert checked >= n_trials // 2
+
+
+def test_gpu_reproduces_the_frozen_golden_bits(ctx):
+    """tests/golden/oracle_regression.json holds the fp32 mirror's poses and per-iteration statistics in the kernels' summation order,
+    frozen as hex floats (generated on the CPU by tests/golden/make_oracle_regression.py).  The device must give exactly those bits --
+    no oracle call in this test: committed data against the HIP path."""
+    g = json.load(open(golden_path("oracle_regression.json")))
+    wl = synth.make_workload(3, 8000, seed=42, n_beams=361)
+    finders = {"projective": lambda: api.CorrespondenceFinderProjective2f(ctx, api.PointNormal2fProjectorPolar(361, -math.pi, math.pi, 0.3, 30.0)),
+               "nn": lambda: api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=0.8),
+               "distmap": lambda: api.CorrespondenceFinderNN2D(ctx, max_distance_m=0.5, resolution=0.1, normal_cos=0.8)}
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    for name, mk in finders.items():
+        al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
+        al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(mk(), min_num_correspondences=10))
+        res = al.compute_batch([fixed], [moving], wl.x0, want_stats=True)
+        for c in g["cases"]:
+            i = c["index"]; w = c[name + "_fp32"]["device_order"]
+            assert int(res.status[i]) == w["status"], (name, i)
+            assert [float(v).hex() for v in res.pose[i]] == w["pose_hex"], (name, i, res.pose[i].tolist())
+            k = len(w["n_corr"])
+            assert res.stats[i]["n_correspondences"][:k].tolist() == w["n_corr"]
+            assert [float(v).hex() for v in res.stats[i]["chi_inliers"][:k]] == w["chi_in_hex"]
