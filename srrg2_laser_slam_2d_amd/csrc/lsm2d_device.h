@@ -53,7 +53,9 @@ LSM2D_HD void sincos_fixed(float x, float& sn, float& cs) {
 
 // log of a positive normal number as a fixed operation sequence (the Cauchy kernel's statistic tau * log(1 + chi/tau) was the last
 // libm call on the path; the CPU restatement evaluates the same sequence; tools/fit_log.py, max relative error 1.3e-7)
-LSM2D_DEV float log_fixed(float x) {
+// NOT inlined: a real call keeps its temporaries out of the register allocation of the loops around accumulate_pair (measured:
+// k_align 2.09 -> 2.03 ms projective, 2.75 -> 2.58 ms NN role B against the inlined form); only Cauchy slices ever take the call
+__device__ __noinline__ float log_fixed(float x) {
   const uint32_t bits = __float_as_uint(x);
   int e = (int) (bits >> 23) - 127;
   float m = __uint_as_float((bits & 0x7FFFFFu) | 0x3F800000u);
