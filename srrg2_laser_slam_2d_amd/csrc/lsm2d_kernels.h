@@ -297,6 +297,42 @@ LSM2D_DEV bool match_bin(u64 fk, u64 mk, const SliceDev& S, const Iso& T, const 
 #ifndef LSM2D_ALIGN_MIN_WAVES
 #define LSM2D_ALIGN_MIN_WAVES 8      // waves per SIMD the register allocator must leave room for
 #endif
+// SE2 odometry prior (AlignerSliceOdom2DPrior, MULTI.json:402-422): e = t2v(Z^-1 X), J = blkdiag(R_e, 1) for the right perturbation;
+// adds J^T Omega J to H and J^T Omega e to b.  One definition for k_align and the split path: the same operation order in both.
+// A real call: rarely taken, and out of the register allocation of the loops.
+__device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) {
+  float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, pose, E);
+  float c, s_; sincos_fixed(E[2], s_, c);
+  const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
+  float OJ[9], Oe[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Oe[r] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Oe[r] += Pz.omega[3 * r + k] * E[k];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      OJ[3 * r + cc] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) OJ[3 * r + cc] += Pz.omega[3 * r + k] * Jp[3 * k + cc];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      float v = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * OJ[3 * k + cc];
+      H[3 * r + cc] += v;
+    }
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * Oe[k];
+    b[r] += v;
+  }
+}
+
 // kHasProj / kHasNN: which finders the batch's slices use -- the unused one is compiled out so the
 // projective hot loop does not carry the NN path's register pressure (and vice versa).
 // kHasDist: a slice uses the distance-map finder (compiled out otherwise so the NN search keeps its registers).
@@ -487,40 +523,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
 #pragma unroll
         for (int k = 0; k < 9; ++k) H[k] = s_Hs[k];
         b[0] = s_b[0]; b[1] = s_b[1]; b[2] = s_b[2];
-        if (A.prior) {
-          // SE2 prior: e = t2v(Z^-1 X), J = blkdiag(R_e, 1) for the right perturbation
-          const PriorDev& Pz = A.prior[a];
-          float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, s_pose, E);
-          float c, s_; sincos_fixed(E[2], s_, c);
-          const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
-          float OJ[9], Oe[3];
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            Oe[r] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) Oe[r] += Pz.omega[3 * r + k] * E[k];
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-              OJ[3 * r + cc] = 0.0f;
-#pragma unroll
-              for (int k = 0; k < 3; ++k) OJ[3 * r + cc] += Pz.omega[3 * r + k] * Jp[3 * k + cc];
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-              float v = 0.0f;
-#pragma unroll
-              for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * OJ[3 * k + cc];
-              H[3 * r + cc] += v;
-            }
-            float v = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * Oe[k];
-            b[r] += v;
-          }
-        }
+        if (A.prior) add_prior(A.prior[a], s_pose, H, b);
 #pragma unroll
         for (int k = 0; k < 9; ++k) s_H[k] = H[k];     // information matrix = H of the last iteration
         float X[3] = {s_pose[0], s_pose[1], s_pose[2]};
@@ -657,39 +660,7 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
       float b[3] = {s_b[0], s_b[1], s_b[2]};
 #pragma unroll
       for (int k = 0; k < 9; ++k) H[k] = s_H[k];
-      if (A.prior) {
-        const PriorDev& Pz = A.prior[a];
-        float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, pose, E);
-        float c, s_; sincos_fixed(E[2], s_, c);
-        const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
-        float OJ[9], Oe[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          Oe[r] = 0.0f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) Oe[r] += Pz.omega[3 * r + k] * E[k];
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) {
-            OJ[3 * r + cc] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) OJ[3 * r + cc] += Pz.omega[3 * r + k] * Jp[3 * k + cc];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) {
-            float v = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * OJ[3 * k + cc];
-            H[3 * r + cc] += v;
-          }
-          float v = 0.0f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * Oe[k];
-          b[r] += v;
-        }
-      }
+      if (A.prior) add_prior(A.prior[a], pose, H, b);
       if (!solve_update(H, b, A.damping, pose)) status = LSM2D_SINGULAR_H;
       else { S.pose[3 * a] = pose[0]; S.pose[3 * a + 1] = pose[1]; S.pose[3 * a + 2] = pose[2]; }
     }
