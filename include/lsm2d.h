@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 100 /* 0.1.0 */
+#define LSM2D_VERSION 110 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
