@@ -192,6 +192,10 @@ def test_aligner_batch_matches_oracle_and_truth(ctx, po):
     # bitwise reproducible run to run (z-buffer min and fixed-order reductions are order independent)
     res2 = al.compute_batch([fixed], [moving], wl.x0)
     assert np.array_equal(res.pose, res2.pose) and np.array_equal(res.information, res2.information)
+    # and bit-identical to the fp32 oracle summing in the kernels' order: full size (100k-point map, 20 iterations), every 6th alignment
+    for i in range(0, 48, 6):
+        rt = po.align(po.aligner_params(20, device_order=True), [po.slice_params()], [wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]], [wl.map_points], wl.x0[i])
+        _assert_bitwise_equal_to_device_order_oracle(res, i, rt, ("batch", i))
 
 
 def test_aligner_noisy_data_and_cauchy(ctx, po):
@@ -205,6 +209,10 @@ def test_aligner_noisy_data_and_cauchy(ctx, po):
         assert np.array_equal(res.status, status)
         d = np.abs(res.pose - xo)
         assert d[:, :2].max() < POSE_TOL_M and d[:, 2].max() < POSE_TOL_RAD
+        for i in range(0, 16, 3):           # noisy data, Cauchy: still the mirror's bits in the kernels' summation order
+            osp_t = po.slice_params(robustifier=po.ROBUST_CAUCHY if rb else po.ROBUST_NONE, chi_threshold=0.05)
+            rt = po.align(po.aligner_params(20, device_order=True), [osp_t], [wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]], [wl.map_points], wl.x0[i])
+            _assert_bitwise_equal_to_device_order_oracle(res, i, rt, ("noisy", bool(rb), i))
 
 
 def test_aligner_status_codes_and_ragged_inputs(ctx, po, small_workload):
