@@ -253,7 +253,7 @@ struct SliceDev {
   int32_t finder;
   ProjK   proj;
   float   point_distance, normal_cos, max_distance;
-  int32_t nn_group;          // lanes per NN query: kNNGroup (dense fixed cloud) or 1
+  int32_t nn_group;          // host hint (largest fixed vs largest moving cloud of the sets): 1 = scan-sized fixed clouds, worth staging their tables in LDS
   int32_t cauchy;
   float   tau;
   int32_t min_corr;
@@ -492,7 +492,11 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
             }
           }
         };
-        if (use_grid && S.nn_group == kNNGroup) query_loop(std::integral_constant<int, kNNGroup>{});
+        // cooperative search (kNNGroup lanes per query) when THIS alignment's fixed cloud is at least four times its moving one --
+        // decided per alignment from the device-side counts, so ragged batches get the right loop for each cloud (the oracle's
+        // device-order mode applies the same rule)
+        const bool coop = use_grid && (long long) S.fixed.count[fc] >= 4ll * nm_pts;
+        if (coop) query_loop(std::integral_constant<int, kNNGroup>{});
         else query_loop(std::integral_constant<int, 1>{});
       }
       block_reduce_store(acc, red, tid);

@@ -1283,3 +1283,24 @@ def test_gpu_reproduces_the_frozen_golden_bits(ctx):
             k = len(w["n_corr"])
             assert res.stats[i]["n_correspondences"][:k].tolist() == w["n_corr"]
             assert [float(v).hex() for v in res.stats[i]["chi_inliers"][:k]] == w["chi_in_hex"]
+
+
+def test_nn_cooperative_search_is_chosen_per_alignment(ctx, po, small_workload):
+    """A ragged NN batch: alignment 0 searches a fixed cloud more than four times its moving one (four lanes per query), alignment 1 a
+    fixed cloud smaller than that (one lane per query).  The loop is picked per alignment from the device-side counts; both must
+    carry the device-order mirror's bits (the mirror applies the same rule), i.e. the summation order follows the loop actually run."""
+    wl = small_workload
+    scan0 = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]; scan1 = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    big = wl.map_points; small = wl.map_points[::12]                      # ~30000 vs ~2500 fixed points; the scans have ~1000
+    assert len(big) >= 4 * len(scan0) and len(small) < 4 * len(scan1)
+    fixed = api.CloudSet(ctx, np.concatenate([big, small], 0), np.array([0, len(big), len(big) + len(small)], np.int32))
+    moving = api.CloudSet(ctx, np.concatenate([scan0, scan1], 0), np.array([0, len(scan0), len(scan0) + len(scan1)], np.int32))
+    x0 = synth.invert_poses(wl.x0[:2].astype(np.float64)).astype(np.float32)       # scan-in-map estimates
+    al = api.MultiAligner2D(ctx, max_iterations=12, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.4, normal_cos=0.8), min_num_correspondences=10))
+    res = al.compute_batch([fixed], [moving], x0, want_stats=True)
+    osp = po.slice_params(finder=po.FINDER_NN, max_distance=0.4)
+    for i, (f, m) in enumerate(((big, scan0), (small, scan1))):
+        rt = po.align(po.aligner_params(12, device_order=True), [osp], [f], [m], x0[i])
+        _assert_bitwise_equal_to_device_order_oracle(res, i, rt, ("ragged nn", i))
+    assert res.status[0] == 0
