@@ -377,20 +377,33 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
   if (n > cap) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "cloudset_upload: does not fit the allocation");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   cloudset_drop_grids(cs);
-  // split on the host into the set's own pinned staging buffer, then two plain async copies: no allocation, no kernel and no
-  // wait for the stream -- only for this set's PREVIOUS upload (an event), whose source the buffer still is until it ran
+  // no allocation and no wait for the stream -- only for this set's PREVIOUS upload (an event), whose source the staging buffer
+  // still is until it ran
   { const int rc0 = acquire_upload_stage(cs, sizeof(float) * 4 * (size_t) (n > 0 ? n : 1) + 16); if (rc0) return rc0; }
-  float2* hxy = (float2*) cs->h_upload; float2* hn = hxy + n;
-  for (int64_t i = 0; i < n; ++i) { hxy[i] = make_float2(pts[4 * i], pts[4 * i + 1]); hn[i] = make_float2(pts[4 * i + 2], pts[4 * i + 3]); }
-  if (n) {
-    HIPCHK(ctx, hipMemcpyAsync(cs->d_xy, hxy, sizeof(float2) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(cs->d_nrm, hn, sizeof(float2) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
-  }
   cs->count_pending = false;
-  // the count travels in the same staging buffer (h_count may be rewritten by the host before the copy runs)
-  int32_t* hcnt = (int32_t*) ((char*) cs->h_upload + cs->h_upload_bytes - sizeof(int32_t));
-  cs->h_count[0] = (int32_t) n; cs->total = n; *hcnt = (int32_t) n;
-  HIPCHK(ctx, hipMemcpyAsync(cs->d_count, hcnt, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  cs->h_count[0] = (int32_t) n; cs->total = n;
+  if (n <= 16384) {
+    // scan-sized: the points go into the pinned buffer as they are and ONE small kernel reads them over the bus, splits them into
+    // the coordinate / normal arrays and sets the count (three host-to-device copies cost three times the API and launch overhead)
+    if (n) memcpy(cs->h_upload, pts, sizeof(float) * 4 * (size_t) n);
+    void* dev_view = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer(&dev_view, cs->h_upload, 0));
+    hipLaunchKernelGGL(k_upload_unpack, dim3((unsigned) (n > 4096 ? 16 : (n + 255) / 256 > 0 ? (n + 255) / 256 : 1)), dim3(256), 0, ctx->stream,
+                       (const float4*) dev_view, (int) n, cs->d_xy, cs->d_nrm, cs->d_count);
+    HIPCHK(ctx, hipGetLastError());
+  } else {
+    // split on the host, then plain async copies
+    float2* hxy = (float2*) cs->h_upload; float2* hn = hxy + n;
+    for (int64_t i = 0; i < n; ++i) { hxy[i] = make_float2(pts[4 * i], pts[4 * i + 1]); hn[i] = make_float2(pts[4 * i + 2], pts[4 * i + 3]); }
+    if (n) {
+      HIPCHK(ctx, hipMemcpyAsync(cs->d_xy, hxy, sizeof(float2) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(cs->d_nrm, hn, sizeof(float2) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    // the count travels in the same staging buffer (h_count may be rewritten by the host before the copy runs)
+    int32_t* hcnt = (int32_t*) ((char*) cs->h_upload + cs->h_upload_bytes - sizeof(int32_t));
+    *hcnt = (int32_t) n;
+    HIPCHK(ctx, hipMemcpyAsync(cs->d_count, hcnt, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  }
   HIPCHK(ctx, hipEventRecord(cs->ev_upload, ctx->stream));
   return LSM2D_SUCCESS;
 }

@@ -1214,6 +1214,17 @@ __global__ void k_lane_layout(const float2* __restrict__ xy, const int32_t* __re
   }
 }
 
+// ---- refill of a small single-cloud set straight from its pinned staging buffer (lsm2d_cloudset_upload): the kernel reads the
+//      host's AoS points over the bus and writes the split arrays and the count -- one launch instead of three copies ----
+__global__ __launch_bounds__(256) void k_upload_unpack(const float4* __restrict__ host_aos, int n, float2* __restrict__ xy, float2* __restrict__ nrm,
+                                                       int32_t* __restrict__ count) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 v = host_aos[i];
+    xy[i] = make_float2(v.x, v.y); nrm[i] = make_float2(v.z, v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = n;
+}
+
 // ---- cloud repack: AoS float4 -> xy / normal arrays, cloud c starting at padded index pstart[c] ----
 __global__ void k_repack_cloud(const float4* __restrict__ src, const int32_t* __restrict__ offsets, const int32_t* __restrict__ pstart,
                                int n_clouds, long long total, float2* __restrict__ xy, float2* __restrict__ nrm) {
