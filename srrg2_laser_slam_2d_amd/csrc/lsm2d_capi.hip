@@ -708,21 +708,21 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
     ctx->beam_dirs.push_back({nb, pp->angle_min, pp->angle_max, d}); d_dir = d;
   }
   const size_t rbytes = sizeof(float) * (size_t) nb;
-  int rc = ensure_scratch(ctx, rbytes); if (rc) return rc;
-  rc = acquire_upload_stage(out, rbytes + 16); if (rc) return rc;
+  int rc = acquire_upload_stage(out, rbytes + 16); if (rc) return rc;
   memcpy(out->h_upload, ranges, rbytes);
+  void* dev_view = nullptr;                    // the kernel reads the ranges straight from the pinned buffer: no copy, no extra launch
+  HIPCHK(ctx, hipHostGetDevicePointer(&dev_view, out->h_upload, 0));
   PrepArgs A;
-  A.ranges = (const float*) ctx->d_scratch; A.beam_dir = d_dir;
+  A.ranges = (const float*) dev_view; A.beam_dir = d_dir;
   A.n_beams = nb; A.stride = nb + (nb & 1); A.rmin = pp->range_min; A.rmax = pp->range_max;
   A.d2max = pp->normal_point_distance * pp->normal_point_distance; A.min_points = pp->normal_min_points;
   A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
   A.out_xy = out->d_xy; A.out_nrm = out->d_nrm; A.out_count = out->d_count;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_scratch, out->h_upload, rbytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipEventRecord(out->ev_upload, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_preprocess_scans, dim3(1), dim3(kPrepBlock), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(out->ev_upload, ctx->stream));        // the staging buffer is free again once the kernel has run
   ctx->have_timing = true;
   out->h_count[0] = nb; out->total = nb; out->count_pending = true;          // at most one point per beam
   return LSM2D_SUCCESS;
