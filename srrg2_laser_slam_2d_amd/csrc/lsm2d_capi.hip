@@ -1018,6 +1018,26 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   rc = ensure_stage(ctx, total_bytes); if (rc) return rc;
   char* hs = (char*) ctx->h_stage; char* ds = (char*) ctx->d_scratch;
 
+  // ---- which path: few alignments against a big cloud are spread over many workgroups each (projective slices only)
+  bool has_proj = false, has_nn = false, has_dist = false;
+  int max_moving = 0;
+  for (int s = 0; s < ns; ++s) {
+    const int fd = b->slices[s].finder;
+    if (fd == LSM2D_FINDER_PROJECTIVE) has_proj = true; else if (fd == LSM2D_FINDER_NN) has_nn = true; else has_dist = true;
+    const lsm2d_cloudset* m = b->moving[s];
+    if (m) for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] > max_moving) max_moving = m->h_count[c];
+  }
+  const bool split_ok = has_proj && !has_nn && !has_dist && ap->max_iterations > 0 && n <= 32768;
+  // measured (tools/small_batch_bench.py, profiles/r01/small_batch*.jsonl): the split path costs two launches per iteration per
+  // alignment call and wins whenever one workgroup per alignment would leave most of the chip idle for long enough
+  const bool use_split = split_ok && (ctx->align_path == 2 ||
+                                      (ctx->align_path == 0 && n <= 192 && (long long) max_moving * ap->max_iterations >= 400000));
+  // A handful of alignments in one launch (the live tracker: one): the kernel reads its few hundred bytes of arguments from, and
+  // writes its results to, the PINNED staging buffer directly -- no host-to-device copy, no memset, no device-to-host copy, i.e.
+  // three small transfers and their launch latencies off the critical path of the call.
+  const bool zero_copy = !use_split && n <= 256;
+  if (zero_copy) { void* v = nullptr; HIPCHK(ctx, hipHostGetDevicePointer(&v, ctx->h_stage, 0)); ds = (char*) v; }
+
   // ---- slices
   int cols_max = 0, fcan_total = 0;
   for (int s = 0; s < ns; ++s) {
@@ -1092,25 +1112,13 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     }
     A.prior = (const PriorDev*) (ds + o_prior);
   }
-  HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   A.init_pose = (const float*) (ds + o_pose_in);
   A.out_pose = (float*) (ds + o_pose); A.out_H = (float*) (ds + o_H); A.out_status = (int32_t*) (ds + o_status); A.out_its = (int32_t*) (ds + o_its);
   A.out_stats = out_stats ? (StatsDev*) (ds + o_stats) : nullptr;
 
-  HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
-  bool has_proj = false, has_nn = false, has_dist = false;
-  int max_moving = 0;
-  for (int s = 0; s < ns; ++s) {
-    if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE) has_proj = true; else if (A.s[s].finder == LSM2D_FINDER_NN) has_nn = true; else has_dist = true;
-    const lsm2d_cloudset* m = b->moving[s];
-    for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] > max_moving) max_moving = m->h_count[c];
-  }
-  // few alignments against a big cloud: spread each alignment over many workgroups (projective slices only)
-  const bool split_ok = has_proj && !has_nn && !has_dist && ap->max_iterations > 0 && n <= 32768;
-  // measured (tools/small_batch_bench.py, profiles/r01/small_batch.jsonl): the split path costs ~0.33 ms of launches per
-  // alignment call and wins whenever one workgroup per alignment would leave most of the chip idle for long enough
-  const bool use_split = split_ok && (ctx->align_path == 2 ||
-                                      (ctx->align_path == 0 && n <= 192 && (long long) max_moving * ap->max_iterations >= 400000));
+  if (zero_copy) memset(hs + o_pose, 0, out_bytes);
+  else HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
   ctx->last_align_path = use_split ? 2 : 1;
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   if (use_split) {
@@ -1157,7 +1165,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;
-  HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(out_pose, hs + o_pose, sizeof(float) * 3 * (size_t) n);
   if (out_H) memcpy(out_H, hs + o_H, sizeof(float) * 9 * (size_t) n);
