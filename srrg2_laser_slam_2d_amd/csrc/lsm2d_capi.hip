@@ -192,6 +192,14 @@ static int ensure_stage(lsm2d_context* ctx, size_t bytes) {
   ctx->h_stage_bytes = cap;
   return LSM2D_SUCCESS;
 }
+// device-side address of the pinned staging buffer: kernels with small outputs write them there directly (no device-to-host copy)
+static int stage_device_view(lsm2d_context* ctx, char** out) {
+  void* v = nullptr;
+  HIPCHK(ctx, hipHostGetDevicePointer(&v, ctx->h_stage, 0));
+  *out = (char*) v;
+  return LSM2D_SUCCESS;
+}
+
 static int ensure_scratch(lsm2d_context* ctx, size_t bytes) {
   if (bytes <= ctx->d_scratch_bytes) return LSM2D_SUCCESS;
   if (ctx->d_scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->d_scratch_bytes = 0; }
@@ -868,12 +876,12 @@ extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, cons
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
   rc = ensure_stage(ctx, bytes); if (rc) return rc;
   A.cloud = cloud_dev(cloud, nullptr); A.ci = ci; A.T = make_iso(pose);
-  A.out_xynn = (float4*) ctx->d_scratch;
-  A.out_src = (int32_t*) ((char*) ctx->d_scratch + cols * 16);
-  A.out_depth = (float*) ((char*) ctx->d_scratch + cols * 20);
+  char* dv = nullptr; rc = stage_device_view(ctx, &dv); if (rc) return rc;       // the canvas rows go straight to pinned host memory
+  A.out_xynn = (float4*) dv;
+  A.out_src = (int32_t*) (dv + cols * 16);
+  A.out_depth = (float*) (dv + cols * 20);
   hipLaunchKernelGGL(k_project_canvas, dim3(1), dim3(kFindBlock), lds, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (out_xynn) memcpy(out_xynn, ctx->h_stage, cols * 16);
   if (out_src) memcpy(out_src, (char*) ctx->h_stage + cols * 16, cols * 4);
@@ -903,13 +911,16 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
     rc = ensure_stage(ctx, bytes); if (rc) return rc;
     N.max_distance = sp->max_distance; N.normal_cos = sp->normal_cos; N.T = make_iso(pose);
     N.nn_group = fixed->h_count[fi] >= 4 * (int64_t) moving->h_count[mi] ? kNNGroup : 1;     // dense fixed cloud: cooperative search
-    N.out_count = (int32_t*) ctx->d_scratch; N.out_pairs = (int32_t*) ((char*) ctx->d_scratch + 16);
+    const bool direct = bytes <= (1u << 16);             // up to 8k pairs: written straight to pinned host memory
+    char* dv = (char*) ctx->d_scratch;
+    if (direct) { rc = stage_device_view(ctx, &dv); if (rc) return rc; }
+    N.out_count = (int32_t*) dv; N.out_pairs = (int32_t*) (dv + 16);
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_find_nn, dim3(1), dim3(kFindBlock), 0, ctx->stream, N);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->have_timing = true;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (!direct) HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t n = *(const int32_t*) ctx->h_stage;
     *out_n = n;
@@ -928,13 +939,13 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
   rc = ensure_stage(ctx, bytes); if (rc) return rc;
   A.fixed = cloud_dev(fixed, nullptr); A.moving = cloud_dev(moving, nullptr); A.fc = fi; A.mc = mi;
   A.point_distance = sp->point_distance; A.normal_cos = sp->normal_cos; A.T = make_iso(pose);
-  A.out_count = (int32_t*) ctx->d_scratch; A.out_pairs = (int32_t*) ((char*) ctx->d_scratch + 16);
+  char* dv = nullptr; rc = stage_device_view(ctx, &dv); if (rc) return rc;       // <= one pair per column: written straight to pinned host memory
+  A.out_count = (int32_t*) dv; A.out_pairs = (int32_t*) (dv + 16);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_find_projective, dim3(1), dim3(kFindBlock), lds, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const int32_t n = *(const int32_t*) ctx->h_stage;
   *out_n = n;
