@@ -973,12 +973,16 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
   rc = ensure_stage(ctx, bytes); if (rc) return rc;
   if (n_pairs) memcpy(ctx->h_stage, pairs, pair_bytes);
-  if (n_pairs) HIPCHK(ctx, hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, pair_bytes, hipMemcpyHostToDevice, ctx->stream));
+  // up to 8k pairs (a canvas worth): the kernels read the pairs from, and write the sums to, the pinned staging buffer directly
+  const bool direct = n_pairs <= 8192;
+  char* dv = (char*) ctx->d_scratch;
+  if (direct) { rc = stage_device_view(ctx, &dv); if (rc) return rc; }
+  else if (n_pairs) HIPCHK(ctx, hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, pair_bytes, hipMemcpyHostToDevice, ctx->stream));
   LinArgs A;
   A.fixed = cloud_dev(fixed, nullptr); A.moving = cloud_dev(moving, nullptr); A.fc = fi; A.mc = mi;
-  A.pairs = (const int32_t*) ctx->d_scratch; A.n_pairs = n_pairs; A.T = make_iso(pose);
+  A.pairs = (const int32_t*) dv; A.n_pairs = n_pairs; A.T = make_iso(pose);
   A.cauchy = sp->robustifier == LSM2D_ROBUST_CAUCHY; A.tau = sp->chi_threshold;
-  A.partial = (float*) ((char*) ctx->d_scratch + part_off); A.out = (float*) ((char*) ctx->d_scratch + out_off);
+  A.partial = (float*) ((char*) ctx->d_scratch + part_off); A.out = (float*) (dv + out_off);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_linearize_partial, dim3(blocks), dim3(256), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_linearize_final, dim3(1), dim3(64), 0, ctx->stream, (const float*) A.partial, blocks, A.out);
@@ -986,7 +990,7 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = true;
   float* h = (float*) ((char*) ctx->h_stage + out_off);
-  HIPCHK(ctx, hipMemcpyAsync(h, A.out, sizeof(float) * kAccumWords, hipMemcpyDeviceToHost, ctx->stream));
+  if (!direct) HIPCHK(ctx, hipMemcpyAsync(h, A.out, sizeof(float) * kAccumWords, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   out_H[0] = h[0]; out_H[1] = h[1]; out_H[2] = h[2]; out_H[3] = h[1]; out_H[4] = h[3]; out_H[5] = h[4]; out_H[6] = h[2]; out_H[7] = h[4]; out_H[8] = h[5];
   out_b[0] = h[6]; out_b[1] = h[7]; out_b[2] = h[8];
