@@ -766,8 +766,11 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   A.gcanvas = d_canvas; A.cols = P.cols; A.xy = scene->d_xy + scene->h_start[si]; A.nrm = scene->d_nrm + scene->h_start[si];
   A.T = T; A.S = make_iso(sensor_in_robot);
   A.s_identity = sensor_in_robot[0] == 0.0f && sensor_in_robot[1] == 0.0f && sensor_in_robot[2] == 0.0f;
-  A.out_xy = clipped->d_xy; A.out_nrm = clipped->d_nrm; A.out_src = (int32_t*) ((char*) ctx->d_scratch + o_src);
-  A.out_count = (int32_t*) ((char*) ctx->d_scratch + o_cnt); A.out_count_dev = clipped->d_count;
+  // synchronous form: source indices and the count go straight to the pinned staging buffer (no device-to-host copy)
+  char* dvo = (char*) ctx->d_scratch;
+  if (out_n) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; }
+  A.out_xy = clipped->d_xy; A.out_nrm = clipped->d_nrm; A.out_src = (int32_t*) (dvo + o_src);
+  A.out_count = (int32_t*) (dvo + o_cnt); A.out_count_dev = clipped->d_count;
   if (small) {
     ClipSmallArgs CS; CS.xy = A.xy; CS.nrm = A.nrm; CS.n = scene->h_count[si]; CS.n_dev = scene->count_pending ? scene->d_count : nullptr; CS.proj = P; CS.emit = A;
     hipLaunchKernelGGL(k_clip_small, dim3(1), dim3(kFindBlock), sizeof(u64) * (size_t) P.cols, ctx->stream, CS);
@@ -781,7 +784,6 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
     clipped->h_count[0] = P.cols; clipped->total = P.cols; clipped->count_pending = true;
     return LSM2D_SUCCESS;
   }
-  HIPCHK(ctx, hipMemcpyAsync((char*) ctx->h_stage + o_src, (char*) ctx->d_scratch + o_src, bytes - o_src, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const int32_t n = *(const int32_t*) ((char*) ctx->h_stage + o_cnt);
   clipped->h_count[0] = n; clipped->total = n; clipped->count_pending = false; *out_n = n;
@@ -814,10 +816,12 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   const size_t cols = (size_t) P.cols, nm = (size_t) (n_meas > 0 ? n_meas : 1);
   const size_t o_mcan = cols * 8, o_out = o_mcan + cols * 8, o_txy = o_out + 64, o_tn = o_txy + ((nm * 8 + 15) & ~(size_t) 15) + 16, bytes = o_tn + nm * 8 + 16;
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
-  rc = ensure_stage(ctx, 64); if (rc) return rc;
+  rc = ensure_stage(ctx, o_out + 64); if (rc) return rc;
   float cam_inv[3]; inverse_host(measurement_in_scene, cam_inv);
   const Iso Tinv = make_iso(cam_inv), M = make_iso(measurement_in_scene);
   char* ds = (char*) ctx->d_scratch;
+  char* dvo = ds;                                  // synchronous form: the four counters go straight to the pinned staging buffer
+  if (out_size) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; }
   u64* d_scan = (u64*) ds; u64* d_mcan = (u64*) (ds + o_mcan);
   float2* d_txy = (float2*) (ds + o_txy); float2* d_tn = (float2*) (ds + o_tn);
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -827,7 +831,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
     MS.m.scanvas = nullptr; MS.m.mcanvas = nullptr; MS.m.cols = P.cols; MS.m.sxy = scene->d_xy; MS.m.snrm = scene->d_nrm; MS.m.n_scene = n_scene;
     MS.m.mxy = meas->d_xy + meas->h_start[mi]; MS.m.mnrm = meas->d_nrm + meas->h_start[mi];
     MS.m.far_limit = 0.9f * pr->range_max; MS.m.merge_threshold = merge_threshold;
-    MS.m.out = (int32_t*) (ds + o_out); MS.m.count_dev = scene->d_count;
+    MS.m.out = (int32_t*) (dvo + o_out); MS.m.count_dev = scene->d_count;
     MS.proj = P; MS.Tinv = Tinv; MS.M = M; MS.n_meas = n_meas;
     MS.n_scene_dev = scene->count_pending ? scene->d_count : nullptr; MS.n_meas_dev = meas->count_pending ? meas->d_count + mi : nullptr;
     hipLaunchKernelGGL(k_merge_small, dim3(1), dim3(kFindBlock), sizeof(u64) * 2 * (size_t) P.cols, ctx->stream, MS);
@@ -843,7 +847,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   MergeArgs A;
   A.scanvas = d_scan; A.mcanvas = d_mcan; A.cols = P.cols; A.sxy = scene->d_xy; A.snrm = scene->d_nrm; A.n_scene = n_scene;
   A.mxy = d_txy; A.mnrm = d_tn; A.far_limit = 0.9f * pr->range_max; A.merge_threshold = merge_threshold;
-  A.out = (int32_t*) (ds + o_out); A.count_dev = scene->d_count;
+  A.out = (int32_t*) (dvo + o_out); A.count_dev = scene->d_count;
   hipLaunchKernelGGL(k_merge_apply, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   }
@@ -853,9 +857,8 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
     scene->h_count[0] = n_scene + P.cols; scene->total = scene->h_count[0]; scene->count_pending = true;
     return LSM2D_SUCCESS;
   }
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ds + o_out, 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  const int32_t* h = (const int32_t*) ctx->h_stage;
+  const int32_t* h = (const int32_t*) ((char*) ctx->h_stage + o_out);
   scene->h_count[0] = h[0]; scene->total = h[0]; scene->count_pending = false; *out_size = h[0];
   if (out_counts) { out_counts[0] = h[1]; out_counts[1] = h[2]; out_counts[2] = h[3]; }
   return LSM2D_SUCCESS;
