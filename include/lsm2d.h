@@ -118,9 +118,13 @@ void lsm2d_destroy(lsm2d_context* ctx);
 int  lsm2d_synchronize(lsm2d_context* ctx);
 /* tuning / test knobs.  "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align),
  * 2 = always the split path (k_split_project + k_split_finish per iteration; projective slices only).  The two paths
- * return bit-identical results; the split path is for a handful of alignments against a large cloud. */
+ * return bit-identical results; the split path is for a handful of alignments against a large cloud.
+ * "kernel_timing": 1 records HIP events around the hot-path launches so that lsm2d_last_kernel_ms can report them; 0 (default)
+ * does not -- the two timed events per operation cost a latency-critical caller such as the live tracker ~20 % of its step --
+ * and lsm2d_last_kernel_ms returns LSM2D_BAD_ARGUMENT. */
 int  lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value);
-/* device time [ms] of the hot-path kernel launches of the most recent call (HIP events on the context's stream) */
+/* device time [ms] of the hot-path kernel launches of the most recent call (HIP events on the context's stream);
+ * needs lsm2d_set_option(ctx, "kernel_timing", 1) */
 int  lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms);
 
 /* ---- clouds: device-resident ragged sets of PointNormal2fVectorCloud ---------------------------

@@ -34,7 +34,10 @@ STATUS_NAMES = {0: "Success", 1: "NotEnoughCorrespondences", 2: "NotEnoughInlier
 class Context:
     """One device + one HIP stream (lsm2d_context)."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, kernel_timing: bool = True):
+        """kernel_timing: record HIP events around the hot-path launches so that ``last_kernel_ms()`` / ``BatchResult.kernel_ms``
+        work (what the tests and bench.py want; the library's own default is off: the events cost a latency-critical caller
+        ~20 % of a tracker step)."""
         self._lib = _capi.load()
         h = C.c_void_p()
         rc = self._lib.lsm2d_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
@@ -42,6 +45,9 @@ class Context:
             raise Lsm2dError(rc, "lsm2d_create", self._lib.lsm2d_last_error(None).decode())
         self._h = h
         self.device = device
+        self.kernel_timing = bool(kernel_timing)
+        if kernel_timing:
+            check(self._lib.lsm2d_set_option(self._h, b"kernel_timing", 1), "lsm2d_set_option", self._h)
 
     @property
     def handle(self):
@@ -52,6 +58,8 @@ class Context:
 
     def set_option(self, key: str, value: int):
         """e.g. ``set_option("align_path", 2)``: 0 automatic, 1 one workgroup per alignment, 2 split over many workgroups."""
+        if key == "kernel_timing":
+            self.kernel_timing = bool(value)
         check(self._lib.lsm2d_set_option(self._h, key.encode(), int(value)), "lsm2d_set_option", self._h)
 
     def last_kernel_ms(self) -> float:
@@ -504,7 +512,7 @@ class MultiAligner2D:
                                     its.ctypes.data_as(C.c_void_p),
                                     stats.ctypes.data_as(C.c_void_p) if want_stats else None),
               "lsm2d_align_batch", ctx.handle)
-        return BatchResult(pose, H.reshape(n, 3, 3), status, its, stats, ctx.last_kernel_ms() if n else 0.0)
+        return BatchResult(pose, H.reshape(n, 3, 3), status, its, stats, ctx.last_kernel_ms() if (n and ctx.kernel_timing) else 0.0)
 
 
 def linearize(ctx: Context, slice_params: SliceParams, fixed, moving, correspondences, pose,

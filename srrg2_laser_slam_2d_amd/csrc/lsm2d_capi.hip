@@ -34,6 +34,8 @@ struct lsm2d_context {
   std::vector<BeamDirs> beam_dirs;                        // (cos, sin) per beam of the sensors seen so far (lsm2d_preprocess_scan_into)
   int max_dyn_lds = 0;
   int align_path = 0;          // 0 auto, 1 fused, 2 split
+  bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
+                               // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1 or 2)
 };
 
@@ -171,6 +173,7 @@ extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
 
 extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return LSM2D_BAD_ARGUMENT;
+  if (!strcmp(key, "kernel_timing")) { ctx->kernel_timing = value != 0; if (!ctx->kernel_timing) ctx->have_timing = false; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1 or 2"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
@@ -679,13 +682,13 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
   A.out_xy = cs->d_xy; A.out_nrm = cs->d_nrm; A.out_count = cs->d_count;
   hipError_t e = hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, o_dir + dbytes, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipEventRecord(ctx->ev0, ctx->stream);
+  if (e == hipSuccess && ctx->kernel_timing) e = hipEventRecord(ctx->ev0, ctx->stream);
   if (e == hipSuccess) { hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, ctx->stream, A); e = hipGetLastError(); }
-  if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+  if (e == hipSuccess && ctx->kernel_timing) e = hipEventRecord(ctx->ev1, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(cs->h_count.data(), cs->d_count, sizeof(int32_t) * (size_t) n_scans, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { lsm2d_cloudset_destroy(cs); HIPCHK(ctx, e); }
-  ctx->have_timing = true;
+  ctx->have_timing = ctx->kernel_timing;
   cs->total = 0; for (int c = 0; c < n_scans; ++c) cs->total += cs->h_count[c];
   *out = cs;
   return LSM2D_SUCCESS;
@@ -726,12 +729,12 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
   A.d2max = pp->normal_point_distance * pp->normal_point_distance; A.min_points = pp->normal_min_points;
   A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
   A.out_xy = out->d_xy; A.out_nrm = out->d_nrm; A.out_count = out->d_count;
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_preprocess_scans, dim3(1), dim3(kPrepBlock), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(ctx, hipEventRecord(out->ev_upload, ctx->stream));        // the staging buffer is free again once the kernel has run
-  ctx->have_timing = true;
+  ctx->have_timing = ctx->kernel_timing;
   out->h_count[0] = nb; out->total = nb; out->count_pending = true;          // at most one point per beam
   return LSM2D_SUCCESS;
 }
@@ -759,7 +762,7 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   compose_host(robot_in_local_map, sensor_in_robot, cam); inverse_host(cam, cam_inv);
   const Iso T = make_iso(cam_inv);
   u64* d_canvas = (u64*) ctx->d_scratch;
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const bool small = scene->h_count[si] <= 32768;            // one workgroup, LDS canvas, one launch
   if (!small) { rc = project_split(ctx, scene->d_xy + scene->h_start[si], scene->h_count[si], T, P, d_canvas); if (rc) return rc; }
   ClipEmitArgs A;
@@ -778,8 +781,8 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
     hipLaunchKernelGGL(k_clip_emit, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
   }
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = true;
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = ctx->kernel_timing;
   if (!out_n) {                               // at most one point per column
     clipped->h_count[0] = P.cols; clipped->total = P.cols; clipped->count_pending = true;
     return LSM2D_SUCCESS;
@@ -824,7 +827,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   if (out_size) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; }
   u64* d_scan = (u64*) ds; u64* d_mcan = (u64*) (ds + o_mcan);
   float2* d_txy = (float2*) (ds + o_txy); float2* d_tn = (float2*) (ds + o_tn);
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const bool small = n_scene <= 32768 && n_meas <= 32768 && (int) (sizeof(u64) * 2 * (size_t) P.cols) <= ctx->max_dyn_lds;
   if (small) {                                               // one workgroup does the transform, both z-buffers and the column walk
     MergeSmallArgs MS;
@@ -851,8 +854,8 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   hipLaunchKernelGGL(k_merge_apply, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   }
-  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = true;
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = ctx->kernel_timing;
   if (!out_size) {                            // a merge appends at most one point per column
     scene->h_count[0] = n_scene + P.cols; scene->total = scene->h_count[0]; scene->count_pending = true;
     return LSM2D_SUCCESS;
@@ -918,11 +921,11 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
     char* dv = (char*) ctx->d_scratch;
     if (direct) { rc = stage_device_view(ctx, &dv); if (rc) return rc; }
     N.out_count = (int32_t*) dv; N.out_pairs = (int32_t*) (dv + 16);
-    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_find_nn, dim3(1), dim3(kFindBlock), 0, ctx->stream, N);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->have_timing = true;
+    if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->have_timing = ctx->kernel_timing;
     if (!direct) HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t n = *(const int32_t*) ctx->h_stage;
@@ -944,11 +947,11 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
   A.point_distance = sp->point_distance; A.normal_cos = sp->normal_cos; A.T = make_iso(pose);
   char* dv = nullptr; rc = stage_device_view(ctx, &dv); if (rc) return rc;       // <= one pair per column: written straight to pinned host memory
   A.out_count = (int32_t*) dv; A.out_pairs = (int32_t*) (dv + 16);
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_find_projective, dim3(1), dim3(kFindBlock), lds, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = true;
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = ctx->kernel_timing;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const int32_t n = *(const int32_t*) ctx->h_stage;
   *out_n = n;
@@ -986,12 +989,12 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   A.pairs = (const int32_t*) dv; A.n_pairs = n_pairs; A.T = make_iso(pose);
   A.cauchy = sp->robustifier == LSM2D_ROBUST_CAUCHY; A.tau = sp->chi_threshold;
   A.partial = (float*) ((char*) ctx->d_scratch + part_off); A.out = (float*) (dv + out_off);
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_linearize_partial, dim3(blocks), dim3(256), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_linearize_final, dim3(1), dim3(64), 0, ctx->stream, (const float*) A.partial, blocks, A.out);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = true;
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = ctx->kernel_timing;
   float* h = (float*) ((char*) ctx->h_stage + out_off);
   if (!direct) HIPCHK(ctx, hipMemcpyAsync(h, A.out, sizeof(float) * kAccumWords, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1138,7 +1141,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   if (zero_copy) memset(hs + o_pose, 0, out_bytes);
   else HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
   ctx->last_align_path = use_split ? 2 : 1;
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   if (use_split) {
     // workspace: global canvases + running pose / flags, grown on demand and kept by the context
     const size_t can_bytes = sizeof(u64) * 2 * (size_t) fcan_total * (size_t) n;
@@ -1181,8 +1184,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     else hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
   }
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = true;
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = ctx->kernel_timing;
   if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(out_pose, hs + o_pose, sizeof(float) * 3 * (size_t) n);

@@ -38,6 +38,7 @@ class Context {
   ~Context() { lsm2d_destroy(_h); }
   Context(const Context&) = delete; Context& operator=(const Context&) = delete;
   lsm2d_context* get() const { return _h; }
+  void setKernelTiming(bool on) { check(lsm2d_set_option(_h, "kernel_timing", on ? 1 : 0), "lsm2d_set_option", _h); }   // needed before lastKernelMs()
   float lastKernelMs() const { float ms = 0; check(lsm2d_last_kernel_ms(_h, &ms), "lsm2d_last_kernel_ms", _h); return ms; }
  private:
   lsm2d_context* _h = nullptr;

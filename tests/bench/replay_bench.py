@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--sequential-oracle", action="store_true",
                     help="the CPU side sums H, b pair after pair (the reference's order: poses then agree to ~1e-7 per step); default: it "
                          "sums in the kernels' order (lsmo_aligner_params.device_order), and the two pipelines must stay BIT-IDENTICAL")
+    ap.add_argument("--kernel-timing", action="store_true",
+                    help="record HIP events around every launch to report the aligner's kernel time (costs ~30 us per step; default off)")
     ap.add_argument("--chained", action="store_true",
                     help="let the GPU pipeline run on its own state for the whole trajectory (reports drift); default is lockstep: "
                          "before every step the GPU state is reset to the CPU state, so differences are per-step")
@@ -59,7 +61,7 @@ def main():
 
     proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
     opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
-    ctx = api.Context(0)
+    ctx = api.Context(0, kernel_timing=args.kernel_timing)
     local_map = api.CloudSet.reserved(ctx, 400000)
     clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=not args.sync_calls); clipper.setFullScene(local_map)
     merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=not args.sync_calls); merger.setScene(local_map)

@@ -43,6 +43,8 @@ int main(int argc, char** argv) {
   }
   lsm2d_context* ctx = nullptr;
   CK(lsm2d_create(0, nullptr, &ctx));
+  const bool timing = getenv("LSM2D_TSB_TIMING") != nullptr;        // kernel events cost ~30 us per step: off unless asked for
+  if (timing) CK(lsm2d_set_option(ctx, "kernel_timing", 1));
   lsm2d_cloudset *local_map, *clipped, *m0, *m1;
   CK(lsm2d_cloudset_create_reserved(ctx, 60000, &local_map));
   CK(lsm2d_cloudset_create_reserved(ctx, 721, &clipped));
@@ -74,7 +76,7 @@ int main(int argc, char** argv) {
     else { CK(lsm2d_cloudset_upload(m0, s0.data(), (int64_t) (s0.size() / 4))); CK(lsm2d_cloudset_upload(m1, s1.data(), (int64_t) (s1.size() / 4))); }
     float x[3];
     CK(lsm2d_align_batch(ctx, &ap, &b, x, nullptr, &status, nullptr, nullptr));
-    if (k >= 0) { lsm2d_last_kernel_ms(ctx, &ms_kernel); kernel_sum += ms_kernel; }
+    if (k >= 0 && timing) { lsm2d_last_kernel_ms(ctx, &ms_kernel); kernel_sum += ms_kernel; }
     const double xd[3] = {x[0], x[1], x[2]}; double xi[3]; inverse(xd, xi); compose(guess, xi, est);
     if ((k + 20) % reset == 0) memcpy(est_fresh, est, sizeof est);      // the step right after a map reset: comparable with the oracle
     for (int i = 0; i < 2; ++i) {
