@@ -784,6 +784,21 @@ def test_abi_error_paths_and_limits(ctx, small_workload):
     alc = _aligner(ctx, robustifier=api.RobustifierCauchy(0.0))
     with pytest.raises(api.Lsm2dError):
         alc.compute_batch([s], [m], wl.x0)
+    # kernel timing is opt-in at the ABI: a context without it gives the same results and refuses lsm2d_last_kernel_ms
+    quiet = api.Context(0, kernel_timing=False)
+    try:
+        alq = _aligner(quiet)
+        rq = alq.compute_batch([api.CloudSet(quiet, wl.scan_points, wl.scan_offsets)], [api.CloudSet(quiet, wl.map_points)], wl.x0)
+        rt_ = al.compute_batch([s], [m], wl.x0)
+        assert np.array_equal(rq.pose, rt_.pose) and rq.kernel_ms == 0.0 and rt_.kernel_ms > 0.0
+        with pytest.raises(api.Lsm2dError) as ei:
+            quiet.last_kernel_ms()
+        assert ei.value.code == _capi.BAD_ARGUMENT
+        quiet.set_option("kernel_timing", 1)
+        alq.compute_batch([api.CloudSet(quiet, wl.scan_points, wl.scan_offsets)], [api.CloudSet(quiet, wl.map_points)], wl.x0)
+        assert quiet.last_kernel_ms() > 0.0
+    finally:
+        quiet.close()
 
 
 def test_pending_sizes_are_resolved_where_the_host_needs_them(ctx, po):
