@@ -33,11 +33,20 @@ struct lsm2d_context {
   struct BeamDirs { int n_beams; float angle_min, angle_max; float2* d_dir; };
   std::vector<BeamDirs> beam_dirs;                        // (cos, sin) per beam of the sensors seen so far (lsm2d_preprocess_scan_into)
   int max_dyn_lds = 0;
+  unsigned long long sync_epoch = 1;   // bumped by every stream_sync()
   int align_path = 0;          // 0 auto, 1 fused, 2 split
   bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1 or 2)
 };
+
+// every wait for the context's stream goes through here: the epoch lets a set know that a transfer it queued from its pinned
+// staging buffer has certainly run (some wait happened since) without an event of its own
+static hipError_t stream_sync(lsm2d_context* ctx) {
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  ++ctx->sync_epoch;
+  return e;
+}
 
 struct GridCache {     // one search grid per (cloud set, max_distance), built on first use
   float max_distance = 0.0f;
@@ -67,7 +76,8 @@ struct lsm2d_cloudset {
   // and count_pending is set; kernels read d_count, and whatever needs the exact number calls resolve_count() (one sync).
   mutable bool count_pending = false;
   // per-set pinned staging for lsm2d_cloudset_upload, so an upload does not have to wait for the stream
-  void* h_upload = nullptr; size_t h_upload_bytes = 0; hipEvent_t ev_upload = nullptr;
+  void* h_upload = nullptr; size_t h_upload_bytes = 0;
+  unsigned long long staged_epoch = 0;       // ctx->sync_epoch when the last transfer out of h_upload was queued (0: none pending)
 };
 
 #define HIPCHK(ctx, call)                                                                           \
@@ -153,7 +163,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
 extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
-  (void) hipStreamSynchronize(c->stream);
+  (void) hipStreamSynchronize(c->stream); ++c->sync_epoch;
   if (c->h_stage) (void) hipHostFree(c->h_stage);
   if (c->d_scratch) (void) hipFree(c->d_scratch);
   if (c->d_split) (void) hipFree(c->d_split);
@@ -167,7 +177,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
 extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
   if (!ctx) return LSM2D_BAD_ARGUMENT;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   return LSM2D_SUCCESS;
 }
 
@@ -189,7 +199,7 @@ extern "C" int lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms) {
 static bool valid_cloud_index_fwd(const lsm2d_cloudset* cs, int32_t i);
 static int ensure_stage(lsm2d_context* ctx, size_t bytes) {
   if (bytes <= ctx->h_stage_bytes) return LSM2D_SUCCESS;
-  if (ctx->h_stage) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipHostFree(ctx->h_stage)); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
+  if (ctx->h_stage) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipHostFree(ctx->h_stage)); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
   size_t cap = bytes + bytes / 2 + 4096;
   HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
   ctx->h_stage_bytes = cap;
@@ -205,7 +215,7 @@ static int stage_device_view(lsm2d_context* ctx, char** out) {
 
 static int ensure_scratch(lsm2d_context* ctx, size_t bytes) {
   if (bytes <= ctx->d_scratch_bytes) return LSM2D_SUCCESS;
-  if (ctx->d_scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->d_scratch_bytes = 0; }
+  if (ctx->d_scratch) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->d_scratch_bytes = 0; }
   size_t cap = bytes + bytes / 2 + 4096;
   HIPCHK(ctx, hipMalloc(&ctx->d_scratch, cap));
   ctx->d_scratch_bytes = cap;
@@ -273,12 +283,12 @@ static int cloudset_create_impl(lsm2d_context* ctx, const void* points, bool on_
                          (const float4*) (on_device ? points : d_src), d_off, cs->d_start, n_clouds, (long long) total, cs->d_xy, cs->d_nrm);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stream_sync(ctx);
     if (d_src) (void) hipFree(d_src);
     if (d_off) (void) hipFree(d_off);
     if (e != hipSuccess) { lsm2d_cloudset_destroy(cs); HIPCHK(ctx, e); }
   } else {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_sync(ctx));
   }
   *out = cs;
   return LSM2D_SUCCESS;
@@ -310,7 +320,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_lane_xy) (void) hipFree(cs->d_lane_xy);
   if (cs->d_lane_start) (void) hipFree(cs->d_lane_start);
   if (cs->d_lane_T) (void) hipFree(cs->d_lane_T);
-  if (cs->ev_upload) { (void) hipEventSynchronize(cs->ev_upload); (void) hipEventDestroy(cs->ev_upload); }
+  if (cs->ctx && cs->staged_epoch == cs->ctx->sync_epoch) (void) stream_sync(cs->ctx);      // a staged transfer may still be reading h_upload
   if (cs->h_upload) (void) hipHostFree(cs->h_upload);
   delete cs;
 }
@@ -318,7 +328,7 @@ static int resolve_count(const lsm2d_cloudset* cs) {
   if (!cs || !cs->count_pending) return LSM2D_SUCCESS;
   lsm2d_context* ctx = cs->ctx;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   int32_t n = 0;
   HIPCHK(ctx, hipMemcpy(&n, cs->d_count, sizeof(int32_t), hipMemcpyDeviceToHost));
   cs->h_count[0] = n; cs->total = n; cs->count_pending = false;
@@ -355,7 +365,7 @@ extern "C" int lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capaci
   cs->ctx = ctx; cs->n_clouds = 1; cs->total = 0; cs->capacity = capacity; cs->padded_total = capacity + (capacity & 1) + 2;
   cs->h_start.assign(1, 0); cs->h_count.assign(1, 0);
   int rc = cloudset_alloc(ctx, cs);
-  if (rc == LSM2D_SUCCESS) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = LSM2D_DEVICE_ERROR; }
+  if (rc == LSM2D_SUCCESS) { hipError_t e = stream_sync(ctx); if (e != hipSuccess) rc = LSM2D_DEVICE_ERROR; }
   if (rc != LSM2D_SUCCESS) { lsm2d_cloudset_destroy(cs); return rc; }
   *out = cs;
   return LSM2D_SUCCESS;
@@ -370,8 +380,9 @@ static int set_single_count(lsm2d_context* ctx, lsm2d_cloudset* cs, int32_t n) {
 // the set's own pinned staging buffer, free to be overwritten: waits for the set's previous staged transfer only
 static int acquire_upload_stage(lsm2d_cloudset* cs, size_t need) {
   lsm2d_context* ctx = cs->ctx;
-  if (cs->ev_upload) HIPCHK(ctx, hipEventSynchronize(cs->ev_upload));
-  else HIPCHK(ctx, hipEventCreateWithFlags(&cs->ev_upload, hipEventDisableTiming));
+  // free to overwrite once the stream has been waited for since the last staged transfer was queued (the aligner call in between
+  // does that); two uploads to the same set back to back wait here
+  if (cs->staged_epoch == ctx->sync_epoch) HIPCHK(ctx, stream_sync(ctx));
   if (need > cs->h_upload_bytes) {
     if (cs->h_upload) { HIPCHK(ctx, hipHostFree(cs->h_upload)); cs->h_upload = nullptr; cs->h_upload_bytes = 0; }
     const size_t want = cs->capacity > 0 ? sizeof(float) * 4 * (size_t) cs->capacity + 16 : need;
@@ -415,7 +426,7 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
     *hcnt = (int32_t) n;
     HIPCHK(ctx, hipMemcpyAsync(cs->d_count, hcnt, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   }
-  HIPCHK(ctx, hipEventRecord(cs->ev_upload, ctx->stream));
+  cs->staged_epoch = ctx->sync_epoch;
   return LSM2D_SUCCESS;
 }
 
@@ -436,7 +447,7 @@ extern "C" int lsm2d_cloudset_download(const lsm2d_cloudset* cs, int32_t ci, flo
                      (const float2*) (cs->d_xy + base), (const float2*) (cs->d_nrm + base), (int) n, (float4*) ctx->d_scratch);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   memcpy(out, ctx->h_stage, bytes);
   return LSM2D_SUCCESS;
 }
@@ -511,7 +522,7 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   A.sorted_idx = g.d_sorted_idx; A.sorted_xy = g.d_sorted_xy;
   hipLaunchKernelGGL(k_grid_build, dim3((unsigned) nc), dim3(1024), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // host vectors above must outlive the copies
+  HIPCHK(ctx, stream_sync(ctx));      // host vectors above must outlive the copies
   t_meta.release(); t_start.release(); t_cursor.release(); t_sidx.release(); t_sxy.release();   // owned by the cache from here on
   cs->grids.push_back(g);
   *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy};
@@ -549,7 +560,7 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
                        (const int32_t*) cs->d_lane_T, (int) kAlignBlock, cs->d_lane_xy, c0);
   }
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));        // the host vectors above back the async copies
+  HIPCHK(ctx, stream_sync(ctx));        // the host vectors above back the async copies
   return LSM2D_SUCCESS;
 }
 
@@ -568,7 +579,7 @@ static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float ma
   HIPCHK(ctx, hipGetLastError());
   std::vector<float4> bbox((size_t) nc);
   HIPCHK(ctx, hipMemcpyAsync(bbox.data(), d_bbox, sizeof(float4) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   const float inv_res = 1.0f / resolution;
   const float mds_px = max_distance * max_distance * inv_res * inv_res;
   const int padding = (int) (sqrtf(mds_px) + 75.5f);
@@ -608,7 +619,7 @@ static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float ma
                        (const int32_t*) d_cellgoal, d.d_parent, mds_px, R, c0);
   }
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   t_dmeta.release(); t_parent.release();          // owned by the cache from here on (t_goal is freed by its guard)
   cs->dists.push_back(d);
   *out = DistDev{d.d_meta, d.d_parent};
@@ -686,7 +697,7 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   if (e == hipSuccess) { hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, ctx->stream, A); e = hipGetLastError(); }
   if (e == hipSuccess && ctx->kernel_timing) e = hipEventRecord(ctx->ev1, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(cs->h_count.data(), cs->d_count, sizeof(int32_t) * (size_t) n_scans, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = stream_sync(ctx);
   if (e != hipSuccess) { lsm2d_cloudset_destroy(cs); HIPCHK(ctx, e); }
   ctx->have_timing = ctx->kernel_timing;
   cs->total = 0; for (int c = 0; c < n_scans; ++c) cs->total += cs->h_count[c];
@@ -733,7 +744,7 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
   hipLaunchKernelGGL(k_preprocess_scans, dim3(1), dim3(kPrepBlock), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIPCHK(ctx, hipEventRecord(out->ev_upload, ctx->stream));        // the staging buffer is free again once the kernel has run
+  out->staged_epoch = ctx->sync_epoch;                    // the staging buffer is free again once the kernel has run
   ctx->have_timing = ctx->kernel_timing;
   out->h_count[0] = nb; out->total = nb; out->count_pending = true;          // at most one point per beam
   return LSM2D_SUCCESS;
@@ -787,7 +798,7 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
     clipped->h_count[0] = P.cols; clipped->total = P.cols; clipped->count_pending = true;
     return LSM2D_SUCCESS;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   const int32_t n = *(const int32_t*) ((char*) ctx->h_stage + o_cnt);
   clipped->h_count[0] = n; clipped->total = n; clipped->count_pending = false; *out_n = n;
   if (out_src) memcpy(out_src, (char*) ctx->h_stage + o_src, sizeof(int32_t) * (size_t) n);
@@ -860,7 +871,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
     scene->h_count[0] = n_scene + P.cols; scene->total = scene->h_count[0]; scene->count_pending = true;
     return LSM2D_SUCCESS;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   const int32_t* h = (const int32_t*) ((char*) ctx->h_stage + o_out);
   scene->h_count[0] = h[0]; scene->total = h[0]; scene->count_pending = false; *out_size = h[0];
   if (out_counts) { out_counts[0] = h[1]; out_counts[1] = h[2]; out_counts[2] = h[3]; }
@@ -888,7 +899,7 @@ extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, cons
   A.out_depth = (float*) (dv + cols * 20);
   hipLaunchKernelGGL(k_project_canvas, dim3(1), dim3(kFindBlock), lds, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   if (out_xynn) memcpy(out_xynn, ctx->h_stage, cols * 16);
   if (out_src) memcpy(out_src, (char*) ctx->h_stage + cols * 16, cols * 4);
   if (out_depth) memcpy(out_depth, (char*) ctx->h_stage + cols * 20, cols * 4);
@@ -927,7 +938,7 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
     if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->have_timing = ctx->kernel_timing;
     if (!direct) HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_sync(ctx));
     const int32_t n = *(const int32_t*) ctx->h_stage;
     *out_n = n;
     if (n > capacity) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "find_correspondences: out_pairs too small");
@@ -952,7 +963,7 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
   HIPCHK(ctx, hipGetLastError());
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = ctx->kernel_timing;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   const int32_t n = *(const int32_t*) ctx->h_stage;
   *out_n = n;
   if (n > capacity) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "find_correspondences: out_pairs too small");
@@ -997,7 +1008,7 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   ctx->have_timing = ctx->kernel_timing;
   float* h = (float*) ((char*) ctx->h_stage + out_off);
   if (!direct) HIPCHK(ctx, hipMemcpyAsync(h, A.out, sizeof(float) * kAccumWords, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   out_H[0] = h[0]; out_H[1] = h[1]; out_H[2] = h[2]; out_H[3] = h[1]; out_H[4] = h[3]; out_H[5] = h[4]; out_H[6] = h[2]; out_H[7] = h[4]; out_H[8] = h[5];
   out_b[0] = h[6]; out_b[1] = h[7]; out_b[2] = h[8];
   if (st) {
@@ -1149,7 +1160,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     const size_t w_H = w_done + (((sizeof(int32_t) * (size_t) n) + 255) & ~(size_t) 255), w_last = w_H + (((sizeof(float) * 9 * (size_t) n) + 255) & ~(size_t) 255);
     const size_t w_total = w_last + sizeof(StatsDev) * (size_t) n;
     if (w_total > ctx->d_split_bytes) {
-      if (ctx->d_split) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_split)); ctx->d_split = nullptr; ctx->d_split_bytes = 0; }
+      if (ctx->d_split) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipFree(ctx->d_split)); ctx->d_split = nullptr; ctx->d_split_bytes = 0; }
       HIPCHK(ctx, hipMalloc(&ctx->d_split, w_total + w_total / 2));
       ctx->d_split_bytes = w_total + w_total / 2;
     }
@@ -1187,7 +1198,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = ctx->kernel_timing;
   if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
   memcpy(out_pose, hs + o_pose, sizeof(float) * 3 * (size_t) n);
   if (out_H) memcpy(out_H, hs + o_H, sizeof(float) * 9 * (size_t) n);
   memcpy(out_status, hs + o_status, sizeof(int32_t) * (size_t) n);
