@@ -27,7 +27,7 @@ struct lsm2d_context {
   bool have_timing = false;
   std::string last_error;
   // pinned host staging + device scratch, grown on demand
-  void* h_stage = nullptr; size_t h_stage_bytes = 0;
+  void* h_stage = nullptr; size_t h_stage_bytes = 0; void* h_stage_dev = nullptr;
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_split = nullptr; size_t d_split_bytes = 0;      // workspace of the split aligner path
   struct BeamDirs { int n_beams; float angle_min, angle_max; float2* d_dir; };
@@ -76,7 +76,7 @@ struct lsm2d_cloudset {
   // and count_pending is set; kernels read d_count, and whatever needs the exact number calls resolve_count() (one sync).
   mutable bool count_pending = false;
   // per-set pinned staging for lsm2d_cloudset_upload, so an upload does not have to wait for the stream
-  void* h_upload = nullptr; size_t h_upload_bytes = 0;
+  void* h_upload = nullptr; size_t h_upload_bytes = 0; void* h_upload_dev = nullptr;
   unsigned long long staged_epoch = 0;       // ctx->sync_epoch when the last transfer out of h_upload was queued (0: none pending)
 };
 
@@ -202,14 +202,13 @@ static int ensure_stage(lsm2d_context* ctx, size_t bytes) {
   if (ctx->h_stage) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipHostFree(ctx->h_stage)); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
   size_t cap = bytes + bytes / 2 + 4096;
   HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostGetDevicePointer(&ctx->h_stage_dev, ctx->h_stage, 0));      // looked up once: kernels read / write the buffer directly
   ctx->h_stage_bytes = cap;
   return LSM2D_SUCCESS;
 }
 // device-side address of the pinned staging buffer: kernels with small outputs write them there directly (no device-to-host copy)
 static int stage_device_view(lsm2d_context* ctx, char** out) {
-  void* v = nullptr;
-  HIPCHK(ctx, hipHostGetDevicePointer(&v, ctx->h_stage, 0));
-  *out = (char*) v;
+  *out = (char*) ctx->h_stage_dev;
   return LSM2D_SUCCESS;
 }
 
@@ -387,6 +386,7 @@ static int acquire_upload_stage(lsm2d_cloudset* cs, size_t need) {
     if (cs->h_upload) { HIPCHK(ctx, hipHostFree(cs->h_upload)); cs->h_upload = nullptr; cs->h_upload_bytes = 0; }
     const size_t want = cs->capacity > 0 ? sizeof(float) * 4 * (size_t) cs->capacity + 16 : need;
     HIPCHK(ctx, hipHostMalloc(&cs->h_upload, want > need ? want : need, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostGetDevicePointer(&cs->h_upload_dev, cs->h_upload, 0));
     cs->h_upload_bytes = want > need ? want : need;
   }
   return LSM2D_SUCCESS;
@@ -408,8 +408,7 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
     // scan-sized: the points go into the pinned buffer as they are and ONE small kernel reads them over the bus, splits them into
     // the coordinate / normal arrays and sets the count (three host-to-device copies cost three times the API and launch overhead)
     if (n) memcpy(cs->h_upload, pts, sizeof(float) * 4 * (size_t) n);
-    void* dev_view = nullptr;
-    HIPCHK(ctx, hipHostGetDevicePointer(&dev_view, cs->h_upload, 0));
+    void* dev_view = cs->h_upload_dev;
     hipLaunchKernelGGL(k_upload_unpack, dim3((unsigned) (n > 4096 ? 16 : (n + 255) / 256 > 0 ? (n + 255) / 256 : 1)), dim3(256), 0, ctx->stream,
                        (const float4*) dev_view, (int) n, cs->d_xy, cs->d_nrm, cs->d_count);
     HIPCHK(ctx, hipGetLastError());
@@ -732,8 +731,7 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
   const size_t rbytes = sizeof(float) * (size_t) nb;
   int rc = acquire_upload_stage(out, rbytes + 16); if (rc) return rc;
   memcpy(out->h_upload, ranges, rbytes);
-  void* dev_view = nullptr;                    // the kernel reads the ranges straight from the pinned buffer: no copy, no extra launch
-  HIPCHK(ctx, hipHostGetDevicePointer(&dev_view, out->h_upload, 0));
+  void* dev_view = out->h_upload_dev;          // the kernel reads the ranges straight from the pinned buffer: no copy, no extra launch
   PrepArgs A;
   A.ranges = (const float*) dev_view; A.beam_dir = d_dir;
   A.n_beams = nb; A.stride = nb + (nb & 1); A.rmin = pp->range_min; A.rmax = pp->range_max;
@@ -1068,7 +1066,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   // writes its results to, the PINNED staging buffer directly -- no host-to-device copy, no memset, no device-to-host copy, i.e.
   // three small transfers and their launch latencies off the critical path of the call.
   const bool zero_copy = !use_split && n <= 256;
-  if (zero_copy) { void* v = nullptr; HIPCHK(ctx, hipHostGetDevicePointer(&v, ctx->h_stage, 0)); ds = (char*) v; }
+  if (zero_copy) ds = (char*) ctx->h_stage_dev;
 
   // ---- slices
   int cols_max = 0, fcan_total = 0;
