@@ -1142,6 +1142,10 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     }
     A.prior = (const PriorDev*) (ds + o_prior);
   }
+  // one alignment (the live tracker's call): start pose and prior ride in the kernel arguments, so the kernel's prologue does not
+  // wait for a read of host memory
+  A.inline_n1 = n == 1 && !use_split;
+  if (A.inline_n1) { memcpy(A.pose1, b->init_pose, sizeof A.pose1); if (b->prior) memcpy(&A.prior1, hs + o_prior, sizeof A.prior1); }
   if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   A.init_pose = (const float*) (ds + o_pose_in);
   A.out_pose = (float*) (ds + o_pose); A.out_H = (float*) (ds + o_H); A.out_status = (int32_t*) (ds + o_status); A.out_its = (int32_t*) (ds + o_its);

@@ -272,6 +272,9 @@ struct AlignArgs {
   int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
   const float* init_pose;
   const PriorDev* prior;
+  int32_t  inline_n1;                       // 1: a single alignment whose start pose / prior travel in the kernel arguments (pose1, prior1)
+  float    pose1[3];
+  PriorDev prior1;
   float* out_pose; float* out_H; int32_t* out_status; int32_t* out_its; StatsDev* out_stats;
   SliceDev s[kMaxSlices];
 };
@@ -353,9 +356,13 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   __shared__ float s_H[9], s_Hs[9], s_b[3];      // s_H: information matrix (H of the last solved iteration); s_Hs: this iteration's sum
   __shared__ int   s_n_in, s_n_out, s_n_corr, s_active, s_done, s_status;
   __shared__ float s_chi_in, s_chi_out;
+  __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   const int a = blockIdx.x, tid = threadIdx.x;
   constexpr int nwaves = kAlignBlock / 64;
+  constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
+  if (A.prior && tid >= 64 && tid < 64 + kPriorWords)
+    ((float*) &s_prior)[tid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[tid - 64] : ((const float*) (A.prior + a))[tid - 64];
 
   // ---- prologue: fixed canvases, camera at identity (correspondence_finder_projective_2d.cpp:37-44)
   for (int i = tid; i < A.fcan_total; i += kAlignBlock) fcan[i] = kEmptyCell;
@@ -373,7 +380,8 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
     s_n_in = s_n_out = s_n_corr = s_active = 0; s_chi_in = s_chi_out = 0.0f;
   };
   if (tid == 0) {
-    s_pose[0] = A.init_pose[3 * a + 0]; s_pose[1] = A.init_pose[3 * a + 1]; s_pose[2] = A.init_pose[3 * a + 2];
+    if (A.inline_n1) { s_pose[0] = A.pose1[0]; s_pose[1] = A.pose1[1]; s_pose[2] = A.pose1[2]; }
+    else { s_pose[0] = A.init_pose[3 * a + 0]; s_pose[1] = A.init_pose[3 * a + 1]; s_pose[2] = A.init_pose[3 * a + 2]; }
     s_done = 0; s_status = LSM2D_RUNNING;
     for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
     begin_iteration();
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
 #pragma unroll
         for (int k = 0; k < 9; ++k) H[k] = s_Hs[k];
         b[0] = s_b[0]; b[1] = s_b[1]; b[2] = s_b[2];
-        if (A.prior) add_prior(A.prior[a], s_pose, H, b);
+        if (A.prior) add_prior(s_prior, s_pose, H, b);
 #pragma unroll
         for (int k = 0; k < 9; ++k) s_H[k] = H[k];     // information matrix = H of the last iteration
         float X[3] = {s_pose[0], s_pose[1], s_pose[2]};
