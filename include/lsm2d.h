@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 110 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload */
+#define LSM2D_VERSION 111 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
+                             0.1.11: + lsm2d_get_option, align_path 3 */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -117,12 +118,16 @@ void lsm2d_destroy(lsm2d_context* ctx);
 /* blocks until everything queued on the context's stream has finished */
 int  lsm2d_synchronize(lsm2d_context* ctx);
 /* tuning / test knobs.  "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align),
- * 2 = always the split path (k_split_project + k_split_finish per iteration; projective slices only).  The two paths
- * return bit-identical results; the split path is for a handful of alignments against a large cloud.
+ * 2 = always the split path (k_split_project + k_split_finish per iteration; projective slices only), 3 = the slice-pair
+ * kernel whenever the batch has exactly two projective slices (k_align_pair: both slices' passes side by side in one
+ * 1024-thread workgroup; automatic for <= 256 alignments).  All paths return bit-identical results; the split path is for a
+ * handful of alignments against a large cloud, the slice pair for the live tracker's two-scanner aligner.
  * "kernel_timing": 1 records HIP events around the hot-path launches so that lsm2d_last_kernel_ms can report them; 0 (default)
  * does not -- the two timed events per operation cost a latency-critical caller such as the live tracker ~20 % of its step --
  * and lsm2d_last_kernel_ms returns LSM2D_BAD_ARGUMENT. */
 int  lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value);
+/* reads a knob back; also "last_align_path": what the most recent lsm2d_align_batch ran (1 k_align, 2 split, 3 slice pair) */
+int  lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* out_value);
 /* device time [ms] of the hot-path kernel launches of the most recent call (HIP events on the context's stream);
  * needs lsm2d_set_option(ctx, "kernel_timing", 1) */
 int  lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms);

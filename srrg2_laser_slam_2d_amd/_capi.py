@@ -70,6 +70,7 @@ SYMBOLS = [
     ("lsm2d_destroy", None, [_P]),
     ("lsm2d_synchronize", C.c_int, [_P]),
     ("lsm2d_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("lsm2d_get_option", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     ("lsm2d_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("lsm2d_cloudset_create", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(_P)]),
     ("lsm2d_cloudset_create_from_device", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(_P)]),

@@ -57,10 +57,17 @@ class Context:
         check(self._lib.lsm2d_synchronize(self._h), "lsm2d_synchronize", self._h)
 
     def set_option(self, key: str, value: int):
-        """e.g. ``set_option("align_path", 2)``: 0 automatic, 1 one workgroup per alignment, 2 split over many workgroups."""
+        """e.g. ``set_option("align_path", 2)``: 0 automatic, 1 one workgroup per alignment, 2 split over many workgroups,
+        3 two projective slices side by side in one workgroup."""
         if key == "kernel_timing":
             self.kernel_timing = bool(value)
         check(self._lib.lsm2d_set_option(self._h, key.encode(), int(value)), "lsm2d_set_option", self._h)
+
+    def get_option(self, key: str) -> int:
+        """Reads a knob back; ``"last_align_path"`` tells which kernels the latest ``align_batch`` ran (1, 2 or 3)."""
+        v = C.c_int64()
+        check(self._lib.lsm2d_get_option(self._h, key.encode(), C.byref(v)), "lsm2d_get_option", self._h)
+        return int(v.value)
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

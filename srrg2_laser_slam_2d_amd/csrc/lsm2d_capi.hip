@@ -34,10 +34,10 @@ struct lsm2d_context {
   std::vector<BeamDirs> beam_dirs;                        // (cos, sin) per beam of the sensors seen so far (lsm2d_preprocess_scan_into)
   int max_dyn_lds = 0;
   unsigned long long sync_epoch = 1;   // bumped by every stream_sync()
-  int align_path = 0;          // 0 auto, 1 fused, 2 split
+  int align_path = 0;          // 0 auto, 1 fused, 2 split, 3 slice pair
   bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
-  int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1 or 2)
+  int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1, 2 or 3)
 };
 
 // every wait for the context's stream goes through here: the epoch lets a set know that a transfer it queued from its pinned
@@ -148,6 +148,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   c->max_dyn_lds = (int) prop.sharedMemPerBlock;
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -184,7 +185,15 @@ extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
 extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return LSM2D_BAD_ARGUMENT;
   if (!strcmp(key, "kernel_timing")) { ctx->kernel_timing = value != 0; if (!ctx->kernel_timing) ctx->have_timing = false; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "align_path")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1 or 2"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "align_path")) { if (value < 0 || value > 3) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1, 2 or 3"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
+  return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
+}
+
+extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* out_value) {
+  if (!ctx || !key || !out_value) return LSM2D_BAD_ARGUMENT;
+  if (!strcmp(key, "kernel_timing")) { *out_value = ctx->kernel_timing ? 1 : 0; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "align_path")) { *out_value = ctx->align_path; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "last_align_path")) { *out_value = ctx->last_align_path; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
 
@@ -1131,6 +1140,11 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     if (mf > 0 && mf <= 65535 && need <= 38 * 1024 - lds) { A.nn_lds_points = mf; A.nn_lds_cells = cap * cap + 1; lds += need + 16; }
   }
   if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
+  // two projective slices and too few alignments to fill the chip (the live tracker: front + rear scanner, one alignment): the
+  // slices' passes run side by side in one 1024-thread workgroup (k_align_pair; bit-identical sums) instead of one after the other
+  const size_t lds_pair = lds + sizeof(u64) * (size_t) cols_max + sizeof(float) * kAccumWords * (kAlignBlock / 64);
+  const bool use_pair = !use_split && ctx->align_path != 1 && ns == 2 && has_proj && !has_nn && !has_dist && (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0 &&
+                        (int) lds_pair + 512 <= ctx->max_dyn_lds;
 
   // ---- inputs
   memcpy(hs + o_pose_in, b->init_pose, sizeof(float) * 3 * (size_t) n);
@@ -1153,7 +1167,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
 
   if (zero_copy) memset(hs + o_pose, 0, out_bytes);
   else HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
-  ctx->last_align_path = use_split ? 2 : 1;
+  ctx->last_align_path = use_split ? 2 : (use_pair ? 3 : 1);
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   if (use_split) {
     // workspace: global canvases + running pose / flags, grown on demand and kept by the context
@@ -1191,7 +1205,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     }
   } else {
     const dim3 grid((unsigned) n), block(kAlignBlock);
-    if (has_proj && !has_nn && !has_dist) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
+    if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3(kPairBlock), lds_pair, ctx->stream, A);
+    else if (has_proj && !has_nn && !has_dist) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && has_nn && !has_dist) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && !has_nn && has_dist) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
     else hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders

@@ -297,6 +297,12 @@ LSM2D_DEV bool match_bin(u64 fk, u64 mk, const SliceDev& S, const Iso& T, const 
   return !(dot < S.normal_cos);
 }
 
+LSM2D_DEV Iso slice_iso(const SliceDev& S, const float pose[3]) {      // X_eff = S^-1 X (AlignerSliceProcessorLaser2DWithSensor) as rotation + translation
+  float Xe[3] = {pose[0], pose[1], pose[2]};
+  if (S.has_sensor) compose(S.cSinv, S.sSinv, S.Sinv, pose, Xe);
+  Iso T; sincos_fixed(Xe[2], T.s, T.c); T.tx = Xe[0]; T.ty = Xe[1];
+  return T;
+}
 #ifndef LSM2D_ALIGN_MIN_WAVES
 #define LSM2D_ALIGN_MIN_WAVES 8      // waves per SIMD the register allocator must leave room for
 #endif
@@ -557,6 +563,153 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   }
 }
 
+// ---- two projective slices side by side -------------------------------------------------------------------------
+// The live tracker's aligner has two laser slices (front and rear scanner, MULTI.json:396-401) and runs one alignment at a
+// time: with one workgroup per alignment the chip is empty and the call is a chain of latencies, so the two slices' passes
+// run next to each other instead of one after the other.  1024 threads: waves 0-7 own slice 0, waves 8-15 slice 1, every
+// thread keeps the role it has in k_align (thread = tid mod 512 of its slice), the per-wave sums are gathered in the same wave
+// order and the two slice totals are added in slice order -- the sums, hence the poses, have k_align's bits.
+static constexpr int kPairBlock = 2 * kAlignBlock;
+LSM2D_DEV void block_reduce_gather_pair(const float* red0, const float* red1, int nwaves, int lane, Accum& A0, Accum& A1) {
+  const int q = lane & 15;
+  const float* red = (lane & 16) ? red1 : red0;
+  float v = 0.0f; int vi = 0;
+  if (lane < 32) {
+    if (q < 11) { for (int w = 0; w < nwaves; ++w) v += red[w * kAccumWords + q]; }
+    else if (q < kAccumWords) { for (int w = 0; w < nwaves; ++w) vi += __float_as_int(red[w * kAccumWords + q]); }
+  }
+  const int b = __float_as_int(v);
+#define LSM2D_RL_F(k) __int_as_float(__builtin_amdgcn_readlane(b, k))
+  A0.h00 = LSM2D_RL_F(0); A0.h01 = LSM2D_RL_F(1); A0.h02 = LSM2D_RL_F(2); A0.h11 = LSM2D_RL_F(3); A0.h12 = LSM2D_RL_F(4); A0.h22 = LSM2D_RL_F(5);
+  A0.b0 = LSM2D_RL_F(6); A0.b1 = LSM2D_RL_F(7); A0.b2 = LSM2D_RL_F(8); A0.chi_in = LSM2D_RL_F(9); A0.chi_out = LSM2D_RL_F(10);
+  A1.h00 = LSM2D_RL_F(16); A1.h01 = LSM2D_RL_F(17); A1.h02 = LSM2D_RL_F(18); A1.h11 = LSM2D_RL_F(19); A1.h12 = LSM2D_RL_F(20); A1.h22 = LSM2D_RL_F(21);
+  A1.b0 = LSM2D_RL_F(22); A1.b1 = LSM2D_RL_F(23); A1.b2 = LSM2D_RL_F(24); A1.chi_in = LSM2D_RL_F(25); A1.chi_out = LSM2D_RL_F(26);
+#undef LSM2D_RL_F
+  A0.n_in = __builtin_amdgcn_readlane(vi, 11); A0.n_out = __builtin_amdgcn_readlane(vi, 12); A0.n_corr = __builtin_amdgcn_readlane(vi, 13);
+  A1.n_in = __builtin_amdgcn_readlane(vi, 27); A1.n_out = __builtin_amdgcn_readlane(vi, 28); A1.n_corr = __builtin_amdgcn_readlane(vi, 29);
+}
+
+__global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64* mcan2 = reinterpret_cast<u64*>(smem);                       // [2][cols_max]: one moving canvas per slice
+  u64* fcan = mcan2 + 2 * A.cols_max;
+  float4* fwin = reinterpret_cast<float4*>(fcan + A.fcan_total);
+  float* red2 = reinterpret_cast<float*>(fwin + A.fcan_total);     // [2][nwaves][kAccumWords]
+  __shared__ float s_pose[3];
+  __shared__ Iso   s_iso[2];
+  __shared__ float s_H[9];
+  __shared__ int   s_done, s_status;
+  __shared__ PriorDev s_prior;
+
+  constexpr int nwaves = kAlignBlock / 64;
+  const int a = blockIdx.x, gtid = threadIdx.x;
+  const int half = __builtin_amdgcn_readfirstlane(gtid >> 9);      // wave-uniform: the slice this wave works for
+  const int tid = gtid & (kAlignBlock - 1);
+  u64* mcan = mcan2 + half * A.cols_max;
+  float* red = red2 + half * nwaves * kAccumWords;
+  constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
+  if (A.prior && gtid >= 64 && gtid < 64 + kPriorWords)
+    ((float*) &s_prior)[gtid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[gtid - 64] : ((const float*) (A.prior + a))[gtid - 64];
+  for (int i = gtid; i < A.fcan_total; i += kPairBlock) fcan[i] = kEmptyCell;
+  for (int i = gtid; i < 2 * A.cols_max; i += kPairBlock) mcan2[i] = kEmptyCell;
+  auto begin_iteration = [&]() {
+    for (int s = 0; s < 2; ++s) s_iso[s] = slice_iso(A.s[s], s_pose);
+  };
+  if (gtid == 0) {
+    if (A.inline_n1) { s_pose[0] = A.pose1[0]; s_pose[1] = A.pose1[1]; s_pose[2] = A.pose1[2]; }
+    else { s_pose[0] = A.init_pose[3 * a + 0]; s_pose[1] = A.init_pose[3 * a + 1]; s_pose[2] = A.init_pose[3 * a + 2]; }
+    s_done = 0; s_status = LSM2D_RUNNING;
+    for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
+    begin_iteration();
+  }
+  __syncthreads();
+  const SliceDev& S = A.s[half];
+  const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
+  const int fbase = S.fixed.start[pick_cloud(S.fixed, a)];
+  project_cloud(S.fixed.xy + fbase, S.fixed.count[pick_cloud(S.fixed, a)], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
+  __syncthreads();
+  for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
+    const u64 k = fcan[S.fcan_offset + col];
+    if (k != kEmptyCell) {
+      const int fi = (int) (uint32_t) k;
+      const float2 p = S.fixed.xy[fbase + fi], n = S.fixed.nrm[fbase + fi];
+      fwin[S.fcan_offset + col] = make_float4(p.x, p.y, n.x, n.y);
+    }
+  }
+  __syncthreads();
+
+  const int mc = pick_cloud(S.moving, a);
+  const int mbase = S.moving.start[mc];
+  const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
+  const u64* fcs = fcan + S.fcan_offset; const float4* fws = fwin + S.fcan_offset;
+  int it = 0;
+  StatsDev last = {0, 0, 0, 0.0f, 0.0f};
+  for (; it < A.max_it; ++it) {
+    const Iso T = s_iso[half];
+    Accum acc; accum_zero(acc);
+    if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
+    else project_cloud(mp, S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
+    __syncthreads();
+    for (int col = tid; col < S.proj.cols; col += kAlignBlock) {      // k_align's bin walk, same thread <-> column mapping
+      const u64 fk = fcs[col], mk = mcan[col];
+      mcan[col] = kEmptyCell;
+      if (mk == kEmptyCell || fk == kEmptyCell) continue;
+      const float fd = __uint_as_float((uint32_t) (fk >> 32)), md = __uint_as_float((uint32_t) (mk >> 32));
+      if (__builtin_fabsf(fd - md) > S.point_distance) continue;
+      const int mi = (int) (uint32_t) mk;
+      const float2 nm = mn[mi], pm = mp[mi];
+      const float4 f = fws[col];
+      float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+      if (__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos) continue;
+      accumulate_pair(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, S.cauchy != 0, S.tau, acc);
+    }
+    block_reduce_store(acc, red, tid);
+    __syncthreads();
+    if (gtid < 64) {
+      Accum t[2];
+      block_reduce_gather_pair(red2, red2 + nwaves * kAccumWords, nwaves, gtid, t[0], t[1]);
+      if (gtid == 0) {
+        // k_align's per-slice accumulation (zeroed sums, then slice 0, then slice 1) and its solve step, in its order
+        float Hs[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, bs[3] = {0.0f, 0.0f, 0.0f};
+        int n_in = 0, n_out = 0, n_corr = 0, active = 0; float chi_in = 0.0f, chi_out = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          n_corr += t[s].n_corr;
+          if (t[s].n_corr > A.s[s].min_corr) {
+            ++active;
+            Hs[0] += t[s].h00; Hs[1] += t[s].h01; Hs[2] += t[s].h02; Hs[3] += t[s].h01; Hs[4] += t[s].h11; Hs[5] += t[s].h12;
+            Hs[6] += t[s].h02; Hs[7] += t[s].h12; Hs[8] += t[s].h22;
+            bs[0] += t[s].b0; bs[1] += t[s].b1; bs[2] += t[s].b2;
+            n_in += t[s].n_in; n_out += t[s].n_out; chi_in += t[s].chi_in; chi_out += t[s].chi_out;
+          }
+        }
+        last.n_corr = n_corr; last.n_in = n_in; last.n_out = n_out; last.chi_in = chi_in; last.chi_out = chi_out;
+        if (A.out_stats) A.out_stats[(size_t) a * A.max_it + it] = last;
+        if (!active) { s_status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
+        else {
+          if (A.prior) add_prior(s_prior, s_pose, Hs, bs);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) s_H[k] = Hs[k];
+          float X[3] = {s_pose[0], s_pose[1], s_pose[2]};
+          if (!solve_update(Hs, bs, A.damping, X)) { s_status = LSM2D_SINGULAR_H; s_done = 1; }
+          else { s_pose[0] = X[0]; s_pose[1] = X[1]; s_pose[2] = X[2]; }
+        }
+        if (!s_done) begin_iteration();
+      }
+    }
+    __syncthreads();
+    if (s_done) { ++it; break; }
+  }
+  if (gtid == 0) {
+    int st = s_status;
+    if (st == LSM2D_RUNNING) st = (A.max_it > 0 && last.n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
+    A.out_status[a] = st;
+    A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
+    if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = s_H[k];
+    if (A.out_its) A.out_its[a] = it;
+  }
+}
+
 // ---- split path: the same alignment spread over many workgroups -------------------------------------------------
 // For a handful of alignments against a big cloud one workgroup per alignment leaves the chip empty, so each iteration
 // becomes two launches: k_split_project z-buffers slices of the cloud in LDS and folds them into a global canvas
@@ -572,12 +725,6 @@ struct SplitArgs {
   int32_t it;            // iteration this launch belongs to
 };
 
-LSM2D_DEV Iso slice_iso(const SliceDev& S, const float pose[3]) {
-  float Xe[3] = {pose[0], pose[1], pose[2]};
-  if (S.has_sensor) compose(S.cSinv, S.sSinv, S.Sinv, pose, Xe);
-  Iso T; sincos_fixed(Xe[2], T.s, T.c); T.tx = Xe[0]; T.ty = Xe[1];
-  return T;
-}
 
 template <bool kFixed>
 __global__ __launch_bounds__(512) void k_split_project(const SplitArgs S) {

@@ -1027,6 +1027,73 @@ def test_split_path_is_bit_identical_to_fused_path(ctx, po):
     assert np.all(f1.status == 0)
 
 
+def test_slice_pair_kernel_is_bit_identical_to_one_slice_after_the_other(ctx, po):
+    """Two projective slices side by side in one 1024-thread workgroup (k_align_pair, the live tracker's two-scanner aligner)
+    against k_align running them one after the other: same thread <-> pair mapping per slice, same gather order, slice totals
+    added in slice order -> bitwise equal poses, information matrices, statistics, statuses."""
+    def run(path, al, *args, **kw):
+        ctx.set_option("align_path", path)
+        try:
+            r = al.compute_batch(*args, **kw)
+            return r, ctx.get_option("last_align_path")
+        finally:
+            ctx.set_option("align_path", 0)
+    def same(a, b):
+        for k in ("pose", "information", "status", "iterations"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), k
+        for i in range(len(a.status)):
+            assert np.array_equal(a.stats[i][: a.iterations[i]], b.stats[i][: b.iterations[i]]), i
+    world = synth.make_world(5)
+    S0, S1 = np.array([0.2, 0.1, 0.1]), np.array([-0.3, 0.0, math.pi])
+    proj0 = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    proj1 = api.PointNormal2fProjectorPolar(541, -math.pi, math.pi, 0.5, 9.0)       # other columns AND range gate: one canvas per slice
+    def aligner(min_inliers=10, min_corr=5):
+        al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=min_inliers)
+        al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
+            api.CorrespondenceFinderProjective2f(ctx, proj0, 0.5, 0.9), sensor_in_robot=S0, robustifier=api.RobustifierCauchy(0.01), min_num_correspondences=min_corr))
+        al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
+            api.CorrespondenceFinderProjective2f(ctx, proj1, 0.5, 0.8), sensor_in_robot=S1, min_num_correspondences=min_corr))
+        return al
+    for n_map, n in ((900, 1), (30000, 3), (30000, 300)):      # a clipped-scene sized map (no lane-chunked copy), a streamed one, a big batch (forced)
+        m = synth.make_map(world, n_map)
+        robot = synth.sample_poses(world, n, seed=11)
+        sc = [synth.make_scans(world, synth.compose_poses(robot, np.tile(S, (n, 1))), n_beams=721) for S in (S0, S1)]
+        xg = synth.invert_poses(synth.compose_poses(robot, np.tile([[0.04, -0.03, 0.03]], (n, 1)))).astype(np.float32)
+        if n >= 3:
+            xg[1] += np.float32([70, 70, 0])                   # a hopeless candidate: NotEnoughCorrespondences after one iteration
+        fx = [api.CloudSet(ctx, p, o) for p, o in sc]; mv = [api.CloudSet(ctx, m)] * 2
+        for pri in (None, [(xg[i], np.eye(3, dtype=np.float32) * 20.0) for i in range(n)]):
+            al = aligner()
+            (f1, p1), (f3, p3) = run(1, al, fx, mv, xg, priors=pri, want_stats=True), run(3, al, fx, mv, xg, priors=pri, want_stats=True)
+            assert p1 == 1 and p3 == 3
+            same(f1, f3)
+            assert (n_map < 30000 or f1.status[0] == 0) and (n < 3 or (f1.status[1] == 1 and f1.iterations[1] == 1))
+            fa, pa = run(0, al, fx, mv, xg, priors=pri, want_stats=True)
+            assert pa == (3 if n <= 256 else 1)
+            same(f1, fa)
+        # the oracle in the kernels' summation order gives the same bits (first alignment, with the prior)
+        osl = [_oracle_slice(po, sp.slice_params()) for sp in al.param_slice_processors]
+        r = po.align(po.aligner_params(10, prior_z=xg[0], prior_omega=np.eye(3, dtype=np.float32) * 20.0, device_order=True), osl,
+                     [sc[0][0][sc[0][1][0]:sc[0][1][1]], sc[1][0][sc[1][1][0]:sc[1][1][1]]], [m, m], xg[0])
+        _assert_bitwise_equal_to_device_order_oracle(f3, 0, r, ("pair", n_map, n))
+        # NotEnoughInliers; one slice below min_num_correspondences (skipped), both below (NotEnoughCorrespondences)
+        al2 = aligner(min_inliers=100000)
+        (g1, _), (g3, q3) = run(1, al2, fx, mv, xg, want_stats=True), run(3, al2, fx, mv, xg, want_stats=True)
+        assert q3 == 3 and g3.status[0] in (1, 2)
+        same(g1, g3)
+        al3 = aligner(min_corr=400)                             # the 541-column slice never has that many pairs
+        (h1, _), (h3, _) = run(1, al3, fx, mv, xg, want_stats=True), run(3, al3, fx, mv, xg, want_stats=True)
+        same(h1, h3)
+        al4 = aligner(min_corr=5000)
+        (k1, _), (k3, _) = run(1, al4, fx, mv, xg, want_stats=True), run(3, al4, fx, mv, xg, want_stats=True)
+        assert np.all(k3.status == 1)
+        same(k1, k3)
+    # not two projective slices: the option falls back to the ordinary kernel
+    wl = synth.make_workload(2, 5000, seed=3)
+    r1, p = run(3, _aligner(ctx), [api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)], [api.CloudSet(ctx, wl.map_points)], wl.x0)
+    assert p == 1 and np.all(r1.status == 0)
+
+
 def test_randomised_parameters_finder_and_aligner(ctx, po):
     """Fuzz the bit-exact contract over the parameter space the ABI accepts: asymmetric fields of view, odd canvas sizes,
     column rounding, tight and wide gates, all three finders, Cauchy on/off, sensor extrinsics -- finder pairs must equal
