@@ -53,9 +53,7 @@ LSM2D_HD void sincos_fixed(float x, float& sn, float& cs) {
 
 // log of a positive normal number as a fixed operation sequence (the Cauchy kernel's statistic tau * log(1 + chi/tau) was the last
 // libm call on the path; the CPU restatement evaluates the same sequence; tools/fit_log.py, max relative error 1.3e-7)
-// NOT inlined: a real call keeps its temporaries out of the register allocation of the loops around accumulate_pair (measured:
-// k_align 2.09 -> 2.03 ms projective, 2.75 -> 2.58 ms NN role B against the inlined form); only Cauchy slices ever take the call
-__device__ __noinline__ float log_fixed(float x) {
+LSM2D_HD float log_fixed_inline(float x) {
   const uint32_t bits = __float_as_uint(x);
   int e = (int) (bits >> 23) - 127;
   float m = __uint_as_float((bits & 0x7FFFFFu) | 0x3F800000u);
@@ -68,6 +66,10 @@ __device__ __noinline__ float log_fixed(float x) {
   const float r = __builtin_fmaf(z * f, p, __builtin_fmaf(-0.5f, z, f));
   return __builtin_fmaf((float) e, 6.9314718246e-01f, r);
 }
+// NOT inlined in the throughput kernels: a real call keeps its temporaries out of the register allocation of the loops around
+// accumulate_pair (measured: k_align 2.09 -> 2.03 ms projective, 2.75 -> 2.58 ms NN role B against the inlined form); only
+// Cauchy slices ever take the call.  The latency kernel (k_align_pair, registers to spare) inlines it.
+__device__ __noinline__ float log_fixed(float x) { return log_fixed_inline(x); }
 
 LSM2D_DEV void xf_point(const Iso& T, float px, float py, float& qx, float& qy) {
   qx = __builtin_fmaf(T.c, px, __builtin_fmaf(-T.s, py, T.tx));
@@ -253,6 +255,7 @@ LSM2D_DEV void accum_zero(Accum& a) {
 }
 
 // e = [ n_f.(q - p_f) ; n_q - n_f ],  J = [[ (R^T n_f)^T , n_f.(R J2 p_m) ], [ 0 , R J2 n_m ]]
+template <bool kInlineLog = false>
 LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, float2 nm, bool cauchy,
                                float tau, Accum& A) {
   float qx, qy, nqx, nqy;
@@ -273,7 +276,7 @@ LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, fl
     const float q = chi / tau;
     w = 1.0f / (1.0f + q);
     inlier = chi < tau;
-    kern = tau * log_fixed(1.0f + q);
+    kern = tau * (kInlineLog ? log_fixed_inline(1.0f + q) : log_fixed(1.0f + q));
   }
   A.n_in += inlier ? 1 : 0;
   A.n_out += inlier ? 0 : 1;

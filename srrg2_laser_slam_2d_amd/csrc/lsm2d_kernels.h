@@ -308,8 +308,7 @@ LSM2D_DEV Iso slice_iso(const SliceDev& S, const float pose[3]) {      // X_eff 
 #endif
 // SE2 odometry prior (AlignerSliceOdom2DPrior, MULTI.json:402-422): e = t2v(Z^-1 X), J = blkdiag(R_e, 1) for the right perturbation;
 // adds J^T Omega J to H and J^T Omega e to b.  One definition for k_align and the split path: the same operation order in both.
-// A real call: rarely taken, and out of the register allocation of the loops.
-__device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) {
+LSM2D_DEV void add_prior_inline(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) {
   float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, pose, E);
   float c, s_; sincos_fixed(E[2], s_, c);
   const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
@@ -341,6 +340,8 @@ __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], 
     b[r] += v;
   }
 }
+// k_align (64 VGPRs) and the split path call it: rarely taken, and out of the register allocation of their loops
+__device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) { add_prior_inline(Pz, pose, H, b); }
 
 // kHasProj / kHasNN: which finders the batch's slices use -- the unused one is compiled out so the
 // projective hot loop does not carry the NN path's register pressure (and vice versa).
@@ -595,14 +596,20 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   u64* fcan = mcan2 + 2 * A.cols_max;
   float4* fwin = reinterpret_cast<float4*>(fcan + A.fcan_total);
   float* red2 = reinterpret_cast<float*>(fwin + A.fcan_total);     // [2][nwaves][kAccumWords]
-  __shared__ float s_pose[3];
   __shared__ Iso   s_iso[2];
-  __shared__ float s_H[9];
-  __shared__ int   s_done, s_status;
+  __shared__ int   s_done;
+  float pose[3] = {0.0f, 0.0f, 0.0f}, Hlast[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // thread 0's: estimate and information matrix stay in registers
+  int status = LSM2D_RUNNING;
   __shared__ PriorDev s_prior;
 
   constexpr int nwaves = kAlignBlock / 64;
   const int a = blockIdx.x, gtid = threadIdx.x;
+#ifdef LSM2D_PHASE_CLOCKS      // debug build: where one alignment's time goes (10 ns ticks), printed by thread 0
+  unsigned long long pc_t = __builtin_amdgcn_s_memrealtime(), pc_acc[6] = {0, 0, 0, 0, 0, 0};
+#define LSM2D_PC(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); pc_acc[k] += n_ - pc_t; pc_t = n_; } while (0)
+#else
+#define LSM2D_PC(k) do { } while (0)
+#endif
   const int half = __builtin_amdgcn_readfirstlane(gtid >> 9);      // wave-uniform: the slice this wave works for
   const int tid = gtid & (kAlignBlock - 1);
   u64* mcan = mcan2 + half * A.cols_max;
@@ -613,13 +620,12 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   for (int i = gtid; i < A.fcan_total; i += kPairBlock) fcan[i] = kEmptyCell;
   for (int i = gtid; i < 2 * A.cols_max; i += kPairBlock) mcan2[i] = kEmptyCell;
   auto begin_iteration = [&]() {
-    for (int s = 0; s < 2; ++s) s_iso[s] = slice_iso(A.s[s], s_pose);
+    for (int s = 0; s < 2; ++s) s_iso[s] = slice_iso(A.s[s], pose);
   };
   if (gtid == 0) {
-    if (A.inline_n1) { s_pose[0] = A.pose1[0]; s_pose[1] = A.pose1[1]; s_pose[2] = A.pose1[2]; }
-    else { s_pose[0] = A.init_pose[3 * a + 0]; s_pose[1] = A.init_pose[3 * a + 1]; s_pose[2] = A.init_pose[3 * a + 2]; }
-    s_done = 0; s_status = LSM2D_RUNNING;
-    for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
+    if (A.inline_n1) { pose[0] = A.pose1[0]; pose[1] = A.pose1[1]; pose[2] = A.pose1[2]; }
+    else { pose[0] = A.init_pose[3 * a + 0]; pose[1] = A.init_pose[3 * a + 1]; pose[2] = A.init_pose[3 * a + 2]; }
+    s_done = 0;
     begin_iteration();
   }
   __syncthreads();
@@ -637,37 +643,73 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
     }
   }
   __syncthreads();
+  LSM2D_PC(0);
 
   const int mc = pick_cloud(S.moving, a);
   const int mbase = S.moving.start[mc];
   const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
   const u64* fcs = fcan + S.fcan_offset; const float4* fws = fwin + S.fcan_offset;
+  // a moving cloud of at most one pair of points per thread (the tracker's clipped scene: one point per column) is read once and
+  // kept in registers for all iterations
+  const int m_count = S.moving.count[mc];
+  const bool m_in_regs = !S.moving.lane_xy && m_count <= 2 * kAlignBlock;
+  float4 m_pair = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float2 m_tail = make_float2(0.0f, 0.0f);
+  if (m_in_regs) {
+    if (tid < (m_count >> 1)) m_pair = reinterpret_cast<const float4*>(mp)[tid];
+    if ((m_count & 1) && tid == 0) m_tail = mp[m_count - 1];
+  }
   int it = 0;
   StatsDev last = {0, 0, 0, 0.0f, 0.0f};
   for (; it < A.max_it; ++it) {
     const Iso T = s_iso[half];
     Accum acc; accum_zero(acc);
     if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
-    else project_cloud(mp, S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
+    else if (m_in_regs) {         // the same points every iteration: no load, no wait
+      if (tid < (m_count >> 1)) { project_point(T, S.proj, m_pair.x, m_pair.y, 2 * tid, mcan); project_point(T, S.proj, m_pair.z, m_pair.w, 2 * tid + 1, mcan); }
+      if ((m_count & 1) && tid == 0) project_point(T, S.proj, m_tail.x, m_tail.y, m_count - 1, mcan);
+    }
+    else project_cloud(mp, m_count, T, S.proj, mcan, tid, kAlignBlock);
     __syncthreads();
-    for (int col = tid; col < S.proj.cols; col += kAlignBlock) {      // k_align's bin walk, same thread <-> column mapping
-      const u64 fk = fcs[col], mk = mcan[col];
+    LSM2D_PC(1);
+    // k_align's bin walk, same thread <-> column mapping and order (col, then col + 512, ...), two columns per trip: both
+    // columns' gathers of the moving winner are in flight together
+    for (int col = tid; col < S.proj.cols; col += 2 * kAlignBlock) {
+      const int col1 = col + kAlignBlock;
+      const bool in1 = col1 < S.proj.cols;
+      const u64 fk0 = fcs[col], mk0 = mcan[col];
+      const u64 fk1 = in1 ? fcs[col1] : kEmptyCell, mk1 = in1 ? mcan[col1] : kEmptyCell;
       mcan[col] = kEmptyCell;
-      if (mk == kEmptyCell || fk == kEmptyCell) continue;
-      const float fd = __uint_as_float((uint32_t) (fk >> 32)), md = __uint_as_float((uint32_t) (mk >> 32));
-      if (__builtin_fabsf(fd - md) > S.point_distance) continue;
-      const int mi = (int) (uint32_t) mk;
-      const float2 nm = mn[mi], pm = mp[mi];
-      const float4 f = fws[col];
-      float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
-      if (__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos) continue;
-      accumulate_pair(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, S.cauchy != 0, S.tau, acc);
+      if (in1) mcan[col1] = kEmptyCell;
+      auto depth_gate = [&](u64 fk, u64 mk) {
+        if (mk == kEmptyCell || fk == kEmptyCell) return false;
+        const float fd = __uint_as_float((uint32_t) (fk >> 32)), md = __uint_as_float((uint32_t) (mk >> 32));
+        return !(__builtin_fabsf(fd - md) > S.point_distance);
+      };
+      const bool g0 = depth_gate(fk0, mk0), g1 = depth_gate(fk1, mk1);
+      const int mi0 = g0 ? (int) (uint32_t) mk0 : 0, mi1 = g1 ? (int) (uint32_t) mk1 : 0;
+      float2 nm0, pm0, nm1, pm1;
+      if (g0) { nm0 = mn[mi0]; pm0 = mp[mi0]; }
+      if (g1) { nm1 = mn[mi1]; pm1 = mp[mi1]; }
+      if (g0) {
+        const float4 f = fws[col];
+        float nqx, nqy; xf_normal(T, nm0.x, nm0.y, nqx, nqy);
+        if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos))
+          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm0, nm0, S.cauchy != 0, S.tau, acc);
+      }
+      if (g1) {
+        const float4 f = fws[col1];
+        float nqx, nqy; xf_normal(T, nm1.x, nm1.y, nqx, nqy);
+        if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos))
+          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm1, nm1, S.cauchy != 0, S.tau, acc);
+      }
     }
     block_reduce_store(acc, red, tid);
     __syncthreads();
+    LSM2D_PC(2);
     if (gtid < 64) {
       Accum t[2];
       block_reduce_gather_pair(red2, red2 + nwaves * kAccumWords, nwaves, gtid, t[0], t[1]);
+      LSM2D_PC(3);
       if (gtid == 0) {
         // k_align's per-slice accumulation (zeroed sums, then slice 0, then slice 1) and its solve step, in its order
         float Hs[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, bs[3] = {0.0f, 0.0f, 0.0f};
@@ -685,27 +727,34 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
         }
         last.n_corr = n_corr; last.n_in = n_in; last.n_out = n_out; last.chi_in = chi_in; last.chi_out = chi_out;
         if (A.out_stats) A.out_stats[(size_t) a * A.max_it + it] = last;
-        if (!active) { s_status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
+        if (!active) { status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
         else {
-          if (A.prior) add_prior(s_prior, s_pose, Hs, bs);
+          if (A.prior) add_prior_inline(s_prior, pose, Hs, bs);      // inlined: no round trip through scratch on the serial path
 #pragma unroll
-          for (int k = 0; k < 9; ++k) s_H[k] = Hs[k];
-          float X[3] = {s_pose[0], s_pose[1], s_pose[2]};
-          if (!solve_update(Hs, bs, A.damping, X)) { s_status = LSM2D_SINGULAR_H; s_done = 1; }
-          else { s_pose[0] = X[0]; s_pose[1] = X[1]; s_pose[2] = X[2]; }
+          for (int k = 0; k < 9; ++k) Hlast[k] = Hs[k];
+          float X[3] = {pose[0], pose[1], pose[2]};
+          if (!solve_update(Hs, bs, A.damping, X)) { status = LSM2D_SINGULAR_H; s_done = 1; }
+          else { pose[0] = X[0]; pose[1] = X[1]; pose[2] = X[2]; }
         }
         if (!s_done) begin_iteration();
       }
     }
+    LSM2D_PC(4);
     __syncthreads();
+    LSM2D_PC(5);
     if (s_done) { ++it; break; }
   }
+#ifdef LSM2D_PHASE_CLOCKS
+  if (gtid == 0 && a == 0) printf("k_align_pair ticks(10ns): prologue %llu project %llu walk+reduce %llu gather %llu solve %llu barrier %llu its %d\n",
+                                  pc_acc[0], pc_acc[1], pc_acc[2], pc_acc[3], pc_acc[4], pc_acc[5], it);
+#endif
+#undef LSM2D_PC
   if (gtid == 0) {
-    int st = s_status;
+    int st = status;
     if (st == LSM2D_RUNNING) st = (A.max_it > 0 && last.n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
     A.out_status[a] = st;
-    A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
-    if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = s_H[k];
+    A.out_pose[3 * a + 0] = pose[0]; A.out_pose[3 * a + 1] = pose[1]; A.out_pose[3 * a + 2] = pose[2];
+    if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = Hlast[k];
     if (A.out_its) A.out_its[a] = it;
   }
 }

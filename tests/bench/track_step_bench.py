@@ -42,6 +42,8 @@ def main():
                                 repr(float(guess[0])), repr(float(guess[1])), repr(float(guess[2])), str(args.steps), str(mode),
                                 os.path.join(d, "r0.bin"), os.path.join(d, "r1.bin"), repr(a0), repr(a1)],
                                check=True, capture_output=True, text=True, timeout=300)
+            if os.environ.get("LSM2D_TSB_DUMP"):          # debug builds (-DLSM2D_PHASE_CLOCKS) print from the kernel
+                sys.stderr.write(r.stdout)
             out[key] = json.loads(r.stdout.strip().splitlines()[-1])
     # the same step on the CPU oracle
     osl = [po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.9, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.01, min_num_correspondences=5, sensor_in_robot=tuple(S[0])),
