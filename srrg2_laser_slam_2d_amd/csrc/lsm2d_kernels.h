@@ -630,6 +630,18 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   }
   __syncthreads();
   const SliceDev& S = A.s[half];
+  const int mc = pick_cloud(S.moving, a);
+  const int mbase = S.moving.start[mc];
+  const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
+  // a moving cloud of at most one pair of points per thread (the tracker's clipped scene: one point per column) is read once and
+  // kept in registers for all iterations (loaded here, ahead of the fixed cloud's passes: the two dependent loads overlap them)
+  const int m_count = S.moving.count[mc];
+  const bool m_in_regs = !S.moving.lane_xy && m_count <= 2 * kAlignBlock;
+  float4 m_pair = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float2 m_tail = make_float2(0.0f, 0.0f);
+  if (m_in_regs) {
+    if (tid < (m_count >> 1)) m_pair = reinterpret_cast<const float4*>(mp)[tid];
+    if ((m_count & 1) && tid == 0) m_tail = mp[m_count - 1];
+  }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   const int fbase = S.fixed.start[pick_cloud(S.fixed, a)];
   project_cloud(S.fixed.xy + fbase, S.fixed.count[pick_cloud(S.fixed, a)], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
@@ -645,19 +657,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   __syncthreads();
   LSM2D_PC(0);
 
-  const int mc = pick_cloud(S.moving, a);
-  const int mbase = S.moving.start[mc];
-  const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
   const u64* fcs = fcan + S.fcan_offset; const float4* fws = fwin + S.fcan_offset;
-  // a moving cloud of at most one pair of points per thread (the tracker's clipped scene: one point per column) is read once and
-  // kept in registers for all iterations
-  const int m_count = S.moving.count[mc];
-  const bool m_in_regs = !S.moving.lane_xy && m_count <= 2 * kAlignBlock;
-  float4 m_pair = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float2 m_tail = make_float2(0.0f, 0.0f);
-  if (m_in_regs) {
-    if (tid < (m_count >> 1)) m_pair = reinterpret_cast<const float4*>(mp)[tid];
-    if ((m_count & 1) && tid == 0) m_tail = mp[m_count - 1];
-  }
   int it = 0;
   StatsDev last = {0, 0, 0, 0.0f, 0.0f};
   for (; it < A.max_it; ++it) {
