@@ -39,6 +39,9 @@ class Context {
   Context(const Context&) = delete; Context& operator=(const Context&) = delete;
   lsm2d_context* get() const { return _h; }
   void setKernelTiming(bool on) { check(lsm2d_set_option(_h, "kernel_timing", on ? 1 : 0), "lsm2d_set_option", _h); }   // needed before lastKernelMs()
+  // "align_path": 0 automatic, 1 k_align, 2 split over many workgroups, 3 two projective slices side by side (include/lsm2d.h)
+  void setOption(const char* key, int64_t value) { check(lsm2d_set_option(_h, key, value), "lsm2d_set_option", _h); }
+  int64_t getOption(const char* key) const { int64_t v = 0; check(lsm2d_get_option(_h, key, &v), "lsm2d_get_option", _h); return v; }
   float lastKernelMs() const { float ms = 0; check(lsm2d_last_kernel_ms(_h, &ms), "lsm2d_last_kernel_ms", _h); return ms; }
  private:
   lsm2d_context* _h = nullptr;
