@@ -1279,7 +1279,7 @@ def test_randomised_aligner_structure(ctx, po):
     world = synth.make_world(7)
     maps = {n: synth.make_map(world, n, noise_sigma=0.003, seed=n + 3) for n in (4000, 30000)}
     poses = synth.sample_poses(world, 8, seed=17)
-    checked = soft = 0
+    checked = soft = paired = 0
     for trial in range(n_trials):
         ns = int(rng.integers(1, 4)); nb = int(rng.integers(1, 6)); its = int(rng.integers(1, 13)); m = maps[(4000, 30000)[trial % 2]]
         use_prior = bool(trial % 3 == 0)
@@ -1323,6 +1323,14 @@ def test_randomised_aligner_structure(ctx, po):
         if all_projective:                # the split path takes projective slices only
             b = run(2)
             assert np.array_equal(a.pose, b.pose) and np.array_equal(a.information, b.information) and np.array_equal(a.status, b.status), ("split != fused", trial)
+            if ns == 2:                   # two projective slices side by side in one workgroup (k_align_pair): the same bits, statistics included
+                c = run(3)
+                assert ctx.get_option("last_align_path") == 3
+                assert np.array_equal(a.pose, c.pose) and np.array_equal(a.information, c.information) and np.array_equal(a.status, c.status) and \
+                    np.array_equal(a.iterations, c.iterations), ("pair != fused", trial)
+                for i in range(nb):
+                    assert np.array_equal(a.stats[i][: a.iterations[i]], c.stats[i][: c.iterations[i]]), ("pair != fused, statistics", trial, i)
+                paired += 1
         for i in range(nb):
             sc = [p[o[i]:o[i + 1]] for p, o in scans_per_slice]
             kw = dict(prior_z=pri[i][0], prior_omega=pri[i][1]) if use_prior else {}
@@ -1350,7 +1358,8 @@ def test_randomised_aligner_structure(ctx, po):
                 print("  pose gpu", a.pose[i].tolist(), "f32", r["pose"].tolist(), "f64", rd["pose"].tolist())
             assert d.max() < tol, (trial, i, d, dd, same_sets)
             checked += 1; soft += int(tol > POSE_TOL_M)
-    print("structure fuzz: %d trials, %d alignments checked (%d against a widened bar), split == fused in all" % (n_trials, checked, soft))
+    print("structure fuzz: %d trials, %d alignments checked (%d against a widened bar), split == fused in all, slice pair == fused in all %d two-slice trials"
+          % (n_trials, checked, soft, paired))
     assert checked >= n_trials // 2
 
 
