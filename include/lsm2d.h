@@ -145,7 +145,9 @@ int  lsm2d_cloudset_create_from_device(lsm2d_context* ctx, const void* d_points_
 /* a single growable cloud (count 0) with room for capacity_points: the device-resident local map / clipped scene */
 int  lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capacity_points, lsm2d_cloudset** out_set);
 /* refill an existing SINGLE-cloud set in place (no allocation); LSM2D_CAPACITY_EXCEEDED when it does not fit.  The points are
- * copied into the set's pinned staging buffer before the call returns and travel asynchronously on the context's stream. */
+ * copied into the set's pinned staging buffer before the call returns and travel asynchronously on the context's stream:
+ * for scan-sized sets (<= 16 384 points) whoever reads the set first queues their unpacking, and a single-alignment projective
+ * lsm2d_align_batch unpacks its fixed sets inside the aligner kernel -- the live tracker's scans cost no launch of their own. */
 int  lsm2d_cloudset_upload(lsm2d_cloudset* set, const float* points_xynn, int64_t n_points);
 /* copy cloud `cloud_index` back to the host as (x, y, nx, ny) rows; *out_n = its size */
 int  lsm2d_cloudset_download(const lsm2d_cloudset* set, int32_t cloud_index, float* out_points_xynn, int64_t capacity, int64_t* out_n);

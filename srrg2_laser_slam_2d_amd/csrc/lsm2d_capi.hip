@@ -77,7 +77,10 @@ struct lsm2d_cloudset {
   mutable bool count_pending = false;
   // per-set pinned staging for lsm2d_cloudset_upload, so an upload does not have to wait for the stream
   void* h_upload = nullptr; size_t h_upload_bytes = 0; void* h_upload_dev = nullptr;
-  unsigned long long staged_epoch = 0;       // ctx->sync_epoch when the last transfer out of h_upload was queued (0: none pending)
+  mutable unsigned long long staged_epoch = 0;       // ctx->sync_epoch when the last transfer out of h_upload was queued (0: none pending)
+  // lsm2d_cloudset_upload of a scan-sized set only fills h_upload: the unpacking into d_xy / d_nrm / d_count is queued by the first
+  // consumer (flush_upload) -- or done by the aligner kernel itself in its prologue (single-alignment calls: one launch less per scan)
+  mutable bool unpack_pending = false;
 };
 
 #define HIPCHK(ctx, call)                                                                           \
@@ -342,6 +345,18 @@ static int resolve_count(const lsm2d_cloudset* cs) {
   cs->h_count[0] = n; cs->total = n; cs->count_pending = false;
   return LSM2D_SUCCESS;
 }
+// queues the unpacking of a set whose latest upload still sits in its pinned buffer; every reader of the device arrays calls it
+static int flush_upload(const lsm2d_cloudset* cs) {
+  if (!cs || !cs->unpack_pending) return LSM2D_SUCCESS;
+  lsm2d_context* ctx = cs->ctx;
+  const int n = cs->h_count[0];
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_upload_unpack, dim3((unsigned) (n > 4096 ? 16 : (n + 255) / 256 > 0 ? (n + 255) / 256 : 1)), dim3(256), 0, ctx->stream,
+                     (const float4*) cs->h_upload_dev, n, cs->d_xy, cs->d_nrm, cs->d_count);
+  HIPCHK(ctx, hipGetLastError());
+  cs->unpack_pending = false; cs->staged_epoch = ctx->sync_epoch;
+  return LSM2D_SUCCESS;
+}
 extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
 extern "C" int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* cs) { return (cs && resolve_count(cs) == LSM2D_SUCCESS) ? cs->total : 0; }
 extern "C" int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* cs, int32_t i) {
@@ -416,12 +431,12 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
   if (n <= 16384) {
     // scan-sized: the points go into the pinned buffer as they are and ONE small kernel reads them over the bus, splits them into
     // the coordinate / normal arrays and sets the count (three host-to-device copies cost three times the API and launch overhead)
+    // -- queued by the set's first reader (flush_upload), or done by the aligner kernel itself
     if (n) memcpy(cs->h_upload, pts, sizeof(float) * 4 * (size_t) n);
-    void* dev_view = cs->h_upload_dev;
-    hipLaunchKernelGGL(k_upload_unpack, dim3((unsigned) (n > 4096 ? 16 : (n + 255) / 256 > 0 ? (n + 255) / 256 : 1)), dim3(256), 0, ctx->stream,
-                       (const float4*) dev_view, (int) n, cs->d_xy, cs->d_nrm, cs->d_count);
-    HIPCHK(ctx, hipGetLastError());
+    cs->unpack_pending = true;
+    return LSM2D_SUCCESS;
   } else {
+    cs->unpack_pending = false;
     // split on the host, then plain async copies
     float2* hxy = (float2*) cs->h_upload; float2* hn = hxy + n;
     for (int64_t i = 0; i < n; ++i) { hxy[i] = make_float2(pts[4 * i], pts[4 * i + 1]); hn[i] = make_float2(pts[4 * i + 2], pts[4 * i + 3]); }
@@ -441,7 +456,7 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
 extern "C" int lsm2d_cloudset_download(const lsm2d_cloudset* cs, int32_t ci, float* out, int64_t capacity, int64_t* out_n) {
   if (!cs || !cs->ctx || !out_n || !valid_cloud_index_fwd(cs, ci)) return fail(cs ? cs->ctx : nullptr, LSM2D_BAD_ARGUMENT, "cloudset_download: bad argument");
   lsm2d_context* ctx = cs->ctx;
-  { const int rc0 = resolve_count(cs); if (rc0) return rc0; }
+  { int rc0 = resolve_count(cs); if (rc0) return rc0; rc0 = flush_upload(cs); if (rc0) return rc0; }
   const int64_t n = cs->h_count[ci];
   *out_n = n;
   if (n > capacity || (n > 0 && !out)) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "cloudset_download: out buffer too small");
@@ -738,6 +753,7 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
     ctx->beam_dirs.push_back({nb, pp->angle_min, pp->angle_max, d}); d_dir = d;
   }
   const size_t rbytes = sizeof(float) * (size_t) nb;
+  out->unpack_pending = false;                  // an upload nobody read is simply replaced
   int rc = acquire_upload_stage(out, rbytes + 16); if (rc) return rc;
   memcpy(out->h_upload, ranges, rbytes);
   void* dev_view = out->h_upload_dev;          // the kernel reads the ranges straight from the pinned buffer: no copy, no extra launch
@@ -773,6 +789,8 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   if ((int) (sizeof(u64) * (size_t) P.cols) > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "clip_scene: canvas does not fit LDS");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   cloudset_drop_grids(clipped);
+  { const int rc0 = flush_upload(scene); if (rc0) return rc0; }
+  clipped->unpack_pending = false;              // whatever was uploaded into the output set is replaced
   const size_t cols = (size_t) P.cols, o_src = cols * 8, o_cnt = o_src + cols * 4, bytes = o_cnt + 16;
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
   rc = ensure_stage(ctx, bytes); if (rc) return rc;
@@ -834,6 +852,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   if ((int) (sizeof(u64) * (size_t) P.cols) > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "merge_scene: canvas does not fit LDS");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   cloudset_drop_grids(scene);
+  { int rc0 = flush_upload(scene); if (rc0) return rc0; rc0 = flush_upload(meas); if (rc0) return rc0; }
   const size_t cols = (size_t) P.cols, nm = (size_t) (n_meas > 0 ? n_meas : 1);
   const size_t o_mcan = cols * 8, o_out = o_mcan + cols * 8, o_txy = o_out + 64, o_tn = o_txy + ((nm * 8 + 15) & ~(size_t) 15) + 16, bytes = o_tn + nm * 8 + 16;
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
@@ -890,7 +909,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
 extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* cloud, int32_t ci,
                              const float pose[3], int32_t* out_src, float* out_depth, float* out_xynn) {
   if (!ctx || !pr || !pose || !valid_cloud_index(cloud, ci)) return fail(ctx, LSM2D_BAD_ARGUMENT, "project: bad argument");
-  { const int rc0 = resolve_count(cloud); if (rc0) return rc0; }
+  { int rc0 = resolve_count(cloud); if (rc0) return rc0; rc0 = flush_upload(cloud); if (rc0) return rc0; }
   ProjectArgs A;
   if (!make_projk(*pr, &A.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "project: bad projector");
   const size_t lds = sizeof(u64) * (size_t) A.proj.cols;
@@ -921,6 +940,7 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
       (capacity > 0 && !out_pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad argument");
   { int rc0 = resolve_count(fixed); if (rc0) return rc0; rc0 = resolve_count(moving); if (rc0) return rc0; }
+  { int rc0 = flush_upload(fixed); if (rc0) return rc0; rc0 = flush_upload(moving); if (rc0) return rc0; }
   *out_n = 0;
   if (sp->finder == LSM2D_FINDER_NN || sp->finder == LSM2D_FINDER_DISTMAP) {
     if (sp->finder == LSM2D_FINDER_NN && !(sp->max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: max_distance must be > 0");
@@ -986,6 +1006,7 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
       (n_pairs > 0 && !pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "linearize: bad argument");
   { int rc0 = resolve_count(fixed); if (rc0) return rc0; rc0 = resolve_count(moving); if (rc0) return rc0; }
+  { int rc0 = flush_upload(fixed); if (rc0) return rc0; rc0 = flush_upload(moving); if (rc0) return rc0; }
   for (int32_t k = 0; k < n_pairs; ++k)
     if (pairs[k].fixed_idx < 0 || pairs[k].fixed_idx >= fixed->h_count[fi] || pairs[k].moving_idx < 0 || pairs[k].moving_idx >= moving->h_count[mi])
       return fail(ctx, LSM2D_BAD_ARGUMENT, "linearize: correspondence index out of range");
@@ -1108,8 +1129,14 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
       for (int i = 0; i < n; ++i) if (src[i] < 0 || src[i] >= m->n_clouds) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: moving_index out of range");
       memcpy(hs + o_midx[s], src, sizeof(int32_t) * (size_t) n); d_mi = (const int32_t*) (ds + o_midx[s]);
     }
+    // a fixed set whose upload still sits in its pinned buffer: single-alignment projective calls unpack it in the kernel's prologue
+    // (decided once the kernel is known, below); every other reader gets it unpacked by a launch of its own, here
+    const bool defer_unpack = f->unpack_pending && n == 1 && !use_split && has_proj && !has_nn && !has_dist && f != m;
+    if (!defer_unpack) { const int urc = flush_upload(f); if (urc) return urc; }
+    { const int urc = flush_upload(m); if (urc) return urc; }
     if (sp.finder == LSM2D_FINDER_PROJECTIVE) { const int lrc = ensure_lane_layout(ctx, m); if (lrc) return lrc; }
     S.fixed = cloud_dev(f, d_fi); S.moving = cloud_dev(m, d_mi);
+    S.unpack_src = defer_unpack ? (const float4*) f->h_upload_dev : nullptr; S.unpack_n = defer_unpack ? f->h_count[0] : 0;
     if (sp.finder == LSM2D_FINDER_NN) { const int grc = ensure_grid(ctx, f, sp.max_distance, &S.fixed.grid); if (grc) return grc; }
     if (sp.finder == LSM2D_FINDER_DISTMAP) { const int grc = ensure_distmap(ctx, f, sp.max_distance, sp.resolution, &S.fixed.dist); if (grc) return grc; }
     {   // cooperative NN search pays when the fixed cloud is much denser than the queries (map as fixed, scans as queries)
@@ -1212,6 +1239,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     else hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
   }
   HIPCHK(ctx, hipGetLastError());
+  for (int s = 0; s < ns; ++s)                  // sets the kernel's prologue unpacks (SliceDev::unpack_src)
+    if (A.s[s].unpack_src) { b->fixed[s]->unpack_pending = false; b->fixed[s]->staged_epoch = ctx->sync_epoch; }
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = ctx->kernel_timing;
   if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -260,6 +260,11 @@ struct SliceDev {
   int32_t has_sensor;        // X_eff = S^-1 * X
   float   Sinv[3], cSinv, sSinv;
   int32_t fcan_offset;       // start of this slice's fixed canvas, in cells
+  // single-alignment calls whose fixed set still sits in its pinned upload buffer (lsm2d_cloudset_upload defers the unpacking):
+  // the kernel's prologue reads the host's AoS points over the bus itself, writes the set's arrays and count (later consumers
+  // find them there) and goes on -- no separate k_upload_unpack launch in front of the alignment
+  const float4* unpack_src;  // device view of the pinned AoS points, or nullptr
+  int32_t unpack_n;
 };
 
 struct PriorDev { float z_inv[3], cz, sz, omega[9]; };   // Z^-1 and cos/sin of its angle, host-computed
@@ -302,6 +307,15 @@ LSM2D_DEV Iso slice_iso(const SliceDev& S, const float pose[3]) {      // X_eff 
   if (S.has_sensor) compose(S.cSinv, S.sSinv, S.Sinv, pose, Xe);
   Iso T; sincos_fixed(Xe[2], T.s, T.c); T.tx = Xe[0]; T.ty = Xe[1];
   return T;
+}
+// prologue of the single-alignment kernels: unpack the slices' freshly uploaded fixed sets (see SliceDev::unpack_src)
+LSM2D_DEV void unpack_fixed_set(const SliceDev& S, int tid, int nthreads) {
+  float2* xy = const_cast<float2*>(S.fixed.xy); float2* nrm = const_cast<float2*>(S.fixed.nrm);
+  for (int i = tid; i < S.unpack_n; i += nthreads) {
+    const float4 v = S.unpack_src[i];
+    xy[i] = make_float2(v.x, v.y); nrm[i] = make_float2(v.z, v.w);
+  }
+  if (tid == 0) *const_cast<int32_t*>(S.fixed.count) = S.unpack_n;
 }
 #ifndef LSM2D_ALIGN_MIN_WAVES
 #define LSM2D_ALIGN_MIN_WAVES 8      // waves per SIMD the register allocator must leave room for
@@ -371,6 +385,8 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   if (A.prior && tid >= 64 && tid < 64 + kPriorWords)
     ((float*) &s_prior)[tid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[tid - 64] : ((const float*) (A.prior + a))[tid - 64];
 
+  if (kHasProj && !kHasNN && !kHasDist && A.inline_n1)
+    for (int s = 0; s < A.n_slices; ++s) if (A.s[s].unpack_src) unpack_fixed_set(A.s[s], tid, kAlignBlock);      // visible after the barrier below
   // ---- prologue: fixed canvases, camera at identity (correspondence_finder_projective_2d.cpp:37-44)
   for (int i = tid; i < A.fcan_total; i += kAlignBlock) fcan[i] = kEmptyCell;
   for (int i = tid; i < A.cols_max; i += kAlignBlock) mcan[i] = kEmptyCell;      // afterwards the bin walk resets what it reads
@@ -413,7 +429,8 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
     const SliceDev& S = A.s[s];
     if (!kHasProj || S.finder != LSM2D_FINDER_PROJECTIVE) continue;
     const int fc = pick_cloud(S.fixed, a);
-    project_cloud(S.fixed.xy + S.fixed.start[fc], S.fixed.count[fc], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
+    // (a set unpacked by this launch: its size comes with the arguments -- the scalar cache may not have seen the count written above)
+    project_cloud(S.fixed.xy + S.fixed.start[fc], (A.inline_n1 && S.unpack_src) ? S.unpack_n : S.fixed.count[fc], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
   }
   __syncthreads();
   for (int s = 0; s < A.n_slices; ++s) {      // cache the fixed winners' payload next to their keys
@@ -617,6 +634,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
   if (A.prior && gtid >= 64 && gtid < 64 + kPriorWords)
     ((float*) &s_prior)[gtid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[gtid - 64] : ((const float*) (A.prior + a))[gtid - 64];
+  if (A.inline_n1 && A.s[half].unpack_src) unpack_fixed_set(A.s[half], tid, kAlignBlock);      // visible after the barrier below
   for (int i = gtid; i < A.fcan_total; i += kPairBlock) fcan[i] = kEmptyCell;
   for (int i = gtid; i < 2 * A.cols_max; i += kPairBlock) mcan2[i] = kEmptyCell;
   auto begin_iteration = [&]() {
@@ -644,7 +662,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   const int fbase = S.fixed.start[pick_cloud(S.fixed, a)];
-  project_cloud(S.fixed.xy + fbase, S.fixed.count[pick_cloud(S.fixed, a)], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
+  project_cloud(S.fixed.xy + fbase, (A.inline_n1 && S.unpack_src) ? S.unpack_n : S.fixed.count[pick_cloud(S.fixed, a)], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
   __syncthreads();
   for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
     const u64 k = fcan[S.fcan_offset + col];

@@ -1094,6 +1094,72 @@ def test_slice_pair_kernel_is_bit_identical_to_one_slice_after_the_other(ctx, po
     assert p == 1 and np.all(r1.status == 0)
 
 
+def test_deferred_upload_is_unpacked_by_whoever_reads_the_set_first(ctx, po, small_workload):
+    """lsm2d_cloudset_upload of a scan-sized set only fills the set's pinned buffer; the unpacking is queued by the first reader, or
+    done by the aligner kernel in its prologue (single-alignment projective calls: k_align and k_align_pair).  Every reader must see
+    the uploaded points, the kernels that unpack must leave them behind for later readers, and results must be those of a set
+    created in one go."""
+    wl = small_workload
+    sc = [wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]] for i in range(3)]
+    m = api.CloudSet(ctx, wl.map_points)
+    # (1) plain readers: download, size, replaced uploads
+    r = api.CloudSet.reserved(ctx, 2048)
+    r.upload(sc[0]); assert r.n_points == len(sc[0]) and np.array_equal(r.download(), sc[0])
+    r.upload(sc[1]); r.upload(sc[2]); assert np.array_equal(r.download(), sc[2])           # the unread upload is simply replaced
+    r.upload(sc[0][:0]); assert r.n_points == 0 and len(r.download()) == 0
+    # (2) finder, projector, factor
+    f = api.CorrespondenceFinderProjective2f(ctx, _projector(361), 0.5, 0.8)
+    r.upload(sc[1]); f.setFixed(r); f.setMoving(m); f.setLocalMapInSensor(wl.x0[1]); a = f.compute()
+    f.setFixed(api.CloudSet(ctx, sc[1])); b = f.compute()
+    assert len(a) > 50 and np.array_equal(a, b)
+    r.upload(sc[2]); src, depth, _ = _projector(361).compute(ctx, r, np.zeros(3, np.float32))
+    src2, depth2, _ = _projector(361).compute(ctx, sc[2], np.zeros(3, np.float32))
+    assert np.array_equal(src, src2) and np.array_equal(depth, depth2)
+    # (3) one alignment, one slice: k_align unpacks in its prologue and leaves the set behind
+    al = _aligner(ctx, 361)
+    for path in (0, 1, 2):                                     # automatic, one workgroup, split (the split path gets a launch of its own)
+        r.upload(sc[0])
+        ctx.set_option("align_path", path)
+        try:
+            g = al.compute_batch([r], [m], wl.x0[:1], want_stats=True)
+        finally:
+            ctx.set_option("align_path", 0)
+        h = al.compute_batch([api.CloudSet(ctx, sc[0])], [m], wl.x0[:1], want_stats=True)
+        assert g.status[0] == 0 and np.array_equal(g.pose, h.pose) and np.array_equal(g.information, h.information) and np.array_equal(g.stats, h.stats), path
+        assert r.n_points == len(sc[0]) and np.array_equal(r.download(), sc[0]), path
+    # (4) one alignment, two slices (k_align_pair), each with its own freshly uploaded scan; then the same set in both slices
+    r2 = api.CloudSet.reserved(ctx, 2048)
+    al2 = api.MultiAligner2D(ctx, max_iterations=8, min_num_inliers=10)
+    for nc in (0.8, 0.7):
+        al2.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector(361), 0.5, nc), min_num_correspondences=5))
+    for same in (False, True):
+        r.upload(sc[0]); r2.upload(sc[0] if same else sc[0][::2].copy())
+        fx = [r, r] if same else [r, r2]
+        g = al2.compute_batch(fx, [m, m], wl.x0[:1], want_stats=True)
+        assert ctx.get_option("last_align_path") == 3
+        ref = [api.CloudSet(ctx, sc[0]), api.CloudSet(ctx, sc[0] if same else sc[0][::2].copy())]
+        h = al2.compute_batch(ref, [m, m], wl.x0[:1], want_stats=True)
+        assert g.status[0] == 0 and np.array_equal(g.pose, h.pose) and np.array_equal(g.information, h.information) and np.array_equal(g.stats, h.stats), same
+        assert np.array_equal(r.download(), sc[0]) and (same or np.array_equal(r2.download(), sc[0][::2]))
+    # (5) more than one alignment, or another finder: the set is unpacked by a launch in front
+    r.upload(sc[1])
+    g = al.compute_batch([r], [m], np.stack([wl.x0[1], wl.x0[1]]))
+    h = al.compute_batch([api.CloudSet(ctx, sc[1])], [m], np.stack([wl.x0[1], wl.x0[1]]))
+    assert np.array_equal(g.pose, h.pose) and np.all(g.status == 0)
+    aln = api.MultiAligner2D(ctx, max_iterations=5, min_num_inliers=10)
+    aln.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=0.8), min_num_correspondences=5))
+    r.upload(sc[2])
+    g = aln.compute_batch([r], [m], wl.x0[2:3]); h = aln.compute_batch([api.CloudSet(ctx, sc[2])], [m], wl.x0[2:3])
+    assert np.array_equal(g.pose, h.pose) and g.status[0] == 0
+    # (6) the merger reads an uploaded measurement; the clipper replaces an uploaded output set
+    scene = api.CloudSet.reserved(ctx, 20000); scene.upload(wl.map_points[:3000])
+    pose = synth.invert_poses(wl.x_true[:1])[0].astype(np.float32)
+    mg = api.MergerProjective2D(ctx, _projector(361), merge_threshold=0.2)
+    r.upload(sc[0]); mg.setScene(scene); mg.setMeasurement(r); mg.setMeasurementInScene(pose); mg.compute()
+    omap, _ = po.merge_scene(po.Projector(361, -math.pi, math.pi, 0.3, 30.0, 0.0), wl.map_points[:3000], sc[0], pose, 0.2)
+    assert np.array_equal(scene.download(), omap)
+
+
 def test_randomised_parameters_finder_and_aligner(ctx, po):
     """Fuzz the bit-exact contract over the parameter space the ABI accepts: asymmetric fields of view, odd canvas sizes,
     column rounding, tight and wide gates, all three finders, Cauchy on/off, sensor extrinsics -- finder pairs must equal
