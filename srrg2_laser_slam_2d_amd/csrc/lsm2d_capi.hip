@@ -13,6 +13,7 @@ using lsm2d::LSM2D_RUNNING;
 
 #include <new>
 #include <string>
+#include <chrono>
 #include <vector>
 
 using namespace lsm2d;
@@ -46,6 +47,26 @@ static hipError_t stream_sync(lsm2d_context* ctx) {
   const hipError_t e = hipStreamSynchronize(ctx->stream);
   ++ctx->sync_epoch;
   return e;
+}
+
+// The aligner kernels write their results straight to pinned host memory when a call carries few alignments, each alignment's
+// status word last and behind a system-scope release.  Polling those words gets the pose to the caller a few microseconds earlier
+// than waking up from hipStreamSynchronize -- the live tracker's next launches (the merger) are waiting for exactly that.  The
+// stream is in-order, so once the last alignment has reported, everything queued before the launch has run as well: the epoch
+// moves as for a stream wait.  A launch that does not report within the spin budget falls back to the real wait (which also
+// surfaces a device error).
+static constexpr int32_t kStatusNotWritten = -1;
+static hipError_t wait_for_statuses(lsm2d_context* ctx, const int32_t* st, int n) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n; ++i) {
+    unsigned spins = 0;
+    while (__atomic_load_n(&st[i], __ATOMIC_ACQUIRE) == kStatusNotWritten) {
+      __builtin_ia32_pause();
+      if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return stream_sync(ctx);
+    }
+  }
+  ++ctx->sync_epoch;
+  return hipSuccess;
 }
 
 struct GridCache {     // one search grid per (cloud set, max_distance), built on first use
@@ -1192,7 +1213,11 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   A.out_pose = (float*) (ds + o_pose); A.out_H = (float*) (ds + o_H); A.out_status = (int32_t*) (ds + o_status); A.out_its = (int32_t*) (ds + o_its);
   A.out_stats = out_stats ? (StatsDev*) (ds + o_stats) : nullptr;
 
-  if (zero_copy) memset(hs + o_pose, 0, out_bytes);
+  if (zero_copy) {
+    memset(hs + o_pose, 0, out_bytes);
+    int32_t* st = (int32_t*) (hs + o_status);
+    for (int i = 0; i < n; ++i) st[i] = kStatusNotWritten;          // the kernels write an alignment's status last (release, system scope)
+  }
   else HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
   ctx->last_align_path = use_split ? 2 : (use_pair ? 3 : 1);
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -1244,7 +1269,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = ctx->kernel_timing;
   if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, stream_sync(ctx));
+  if (zero_copy) HIPCHK(ctx, wait_for_statuses(ctx, (const int32_t*) (hs + o_status), n));
+  else HIPCHK(ctx, stream_sync(ctx));
   memcpy(out_pose, hs + o_pose, sizeof(float) * 3 * (size_t) n);
   if (out_H) memcpy(out_H, hs + o_H, sizeof(float) * 9 * (size_t) n);
   memcpy(out_status, hs + o_status, sizeof(int32_t) * (size_t) n);

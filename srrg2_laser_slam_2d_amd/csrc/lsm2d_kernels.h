@@ -574,10 +574,13 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   if (tid == 0) {
     int st = s_status;
     if (st == LSM2D_RUNNING) st = (A.max_it > 0 && last.n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
-    A.out_status[a] = st;
     A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
     if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = s_H[k];
     if (A.out_its) A.out_its[a] = it;
+    // the status goes last, behind a system-scope release: with results written straight to pinned host memory the host polls
+    // this word instead of waiting for the stream (lsm2d_align_batch), and whoever sees it sees everything above
+    __threadfence_system();
+    __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -770,10 +773,11 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   if (gtid == 0) {
     int st = status;
     if (st == LSM2D_RUNNING) st = (A.max_it > 0 && last.n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
-    A.out_status[a] = st;
     A.out_pose[3 * a + 0] = pose[0]; A.out_pose[3 * a + 1] = pose[1]; A.out_pose[3 * a + 2] = pose[2];
     if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = Hlast[k];
     if (A.out_its) A.out_its[a] = it;
+    __threadfence_system();                    // status last: the host may be polling it (see k_align)
+    __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
