@@ -828,9 +828,9 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   A.s_identity = sensor_in_robot[0] == 0.0f && sensor_in_robot[1] == 0.0f && sensor_in_robot[2] == 0.0f;
   // synchronous form: source indices and the count go straight to the pinned staging buffer (no device-to-host copy)
   char* dvo = (char*) ctx->d_scratch;
-  if (out_n) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; }
+  if (out_n) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; *(int32_t*) ((char*) ctx->h_stage + o_cnt) = kStatusNotWritten; }
   A.out_xy = clipped->d_xy; A.out_nrm = clipped->d_nrm; A.out_src = (int32_t*) (dvo + o_src);
-  A.out_count = (int32_t*) (dvo + o_cnt); A.out_count_dev = clipped->d_count;
+  A.out_count = (int32_t*) (dvo + o_cnt); A.out_count_dev = clipped->d_count; A.host_polls = out_n != nullptr;
   if (small) {
     ClipSmallArgs CS; CS.xy = A.xy; CS.nrm = A.nrm; CS.n = scene->h_count[si]; CS.n_dev = scene->count_pending ? scene->d_count : nullptr; CS.proj = P; CS.emit = A;
     hipLaunchKernelGGL(k_clip_small, dim3(1), dim3(kFindBlock), sizeof(u64) * (size_t) P.cols, ctx->stream, CS);
@@ -844,7 +844,7 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
     clipped->h_count[0] = P.cols; clipped->total = P.cols; clipped->count_pending = true;
     return LSM2D_SUCCESS;
   }
-  HIPCHK(ctx, stream_sync(ctx));
+  HIPCHK(ctx, wait_for_statuses(ctx, (const int32_t*) ((char*) ctx->h_stage + o_cnt), 1));      // the kernel writes the count last
   const int32_t n = *(const int32_t*) ((char*) ctx->h_stage + o_cnt);
   clipped->h_count[0] = n; clipped->total = n; clipped->count_pending = false; *out_n = n;
   if (out_src) memcpy(out_src, (char*) ctx->h_stage + o_src, sizeof(int32_t) * (size_t) n);
@@ -882,7 +882,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   const Iso Tinv = make_iso(cam_inv), M = make_iso(measurement_in_scene);
   char* ds = (char*) ctx->d_scratch;
   char* dvo = ds;                                  // synchronous form: the four counters go straight to the pinned staging buffer
-  if (out_size) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; }
+  if (out_size) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; *(int32_t*) ((char*) ctx->h_stage + o_out) = kStatusNotWritten; }
   u64* d_scan = (u64*) ds; u64* d_mcan = (u64*) (ds + o_mcan);
   float2* d_txy = (float2*) (ds + o_txy); float2* d_tn = (float2*) (ds + o_tn);
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -892,7 +892,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
     MS.m.scanvas = nullptr; MS.m.mcanvas = nullptr; MS.m.cols = P.cols; MS.m.sxy = scene->d_xy; MS.m.snrm = scene->d_nrm; MS.m.n_scene = n_scene;
     MS.m.mxy = meas->d_xy + meas->h_start[mi]; MS.m.mnrm = meas->d_nrm + meas->h_start[mi];
     MS.m.far_limit = 0.9f * pr->range_max; MS.m.merge_threshold = merge_threshold;
-    MS.m.out = (int32_t*) (dvo + o_out); MS.m.count_dev = scene->d_count;
+    MS.m.out = (int32_t*) (dvo + o_out); MS.m.count_dev = scene->d_count; MS.m.host_polls = out_size != nullptr;
     MS.proj = P; MS.Tinv = Tinv; MS.M = M; MS.n_meas = n_meas;
     MS.n_scene_dev = scene->count_pending ? scene->d_count : nullptr; MS.n_meas_dev = meas->count_pending ? meas->d_count + mi : nullptr;
     hipLaunchKernelGGL(k_merge_small, dim3(1), dim3(kFindBlock), sizeof(u64) * 2 * (size_t) P.cols, ctx->stream, MS);
@@ -908,7 +908,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   MergeArgs A;
   A.scanvas = d_scan; A.mcanvas = d_mcan; A.cols = P.cols; A.sxy = scene->d_xy; A.snrm = scene->d_nrm; A.n_scene = n_scene;
   A.mxy = d_txy; A.mnrm = d_tn; A.far_limit = 0.9f * pr->range_max; A.merge_threshold = merge_threshold;
-  A.out = (int32_t*) (dvo + o_out); A.count_dev = scene->d_count;
+  A.out = (int32_t*) (dvo + o_out); A.count_dev = scene->d_count; A.host_polls = out_size != nullptr;
   hipLaunchKernelGGL(k_merge_apply, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   }
@@ -918,7 +918,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
     scene->h_count[0] = n_scene + P.cols; scene->total = scene->h_count[0]; scene->count_pending = true;
     return LSM2D_SUCCESS;
   }
-  HIPCHK(ctx, stream_sync(ctx));
+  HIPCHK(ctx, wait_for_statuses(ctx, (const int32_t*) ((char*) ctx->h_stage + o_out), 1));      // the kernel writes the new size last
   const int32_t* h = (const int32_t*) ((char*) ctx->h_stage + o_out);
   scene->h_count[0] = h[0]; scene->total = h[0]; scene->count_pending = false; *out_size = h[0];
   if (out_counts) { out_counts[0] = h[1]; out_counts[1] = h[2]; out_counts[2] = h[3]; }
@@ -1213,6 +1213,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   A.out_pose = (float*) (ds + o_pose); A.out_H = (float*) (ds + o_H); A.out_status = (int32_t*) (ds + o_status); A.out_its = (int32_t*) (ds + o_its);
   A.out_stats = out_stats ? (StatsDev*) (ds + o_stats) : nullptr;
 
+  A.host_polls = zero_copy;
   if (zero_copy) {
     memset(hs + o_pose, 0, out_bytes);
     int32_t* st = (int32_t*) (hs + o_status);

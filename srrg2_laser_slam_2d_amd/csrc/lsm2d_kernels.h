@@ -277,6 +277,7 @@ struct AlignArgs {
   int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
   const float* init_pose;
   const PriorDev* prior;
+  int32_t  host_polls;                      // results go to pinned host memory and the host polls the status words: release them to the system
   int32_t  inline_n1;                       // 1: a single alignment whose start pose / prior travel in the kernel arguments (pose1, prior1)
   float    pose1[3];
   PriorDev prior1;
@@ -579,8 +580,8 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
     if (A.out_its) A.out_its[a] = it;
     // the status goes last, behind a system-scope release: with results written straight to pinned host memory the host polls
     // this word instead of waiting for the stream (lsm2d_align_batch), and whoever sees it sees everything above
-    __threadfence_system();
-    __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    else A.out_status[a] = st;
   }
 }
 
@@ -776,8 +777,8 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
     A.out_pose[3 * a + 0] = pose[0]; A.out_pose[3 * a + 1] = pose[1]; A.out_pose[3 * a + 2] = pose[2];
     if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = Hlast[k];
     if (A.out_its) A.out_its[a] = it;
-    __threadfence_system();                    // status last: the host may be polling it (see k_align)
-    __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }    // status last (see k_align)
+    else A.out_status[a] = st;
   }
 }
 
@@ -1126,6 +1127,7 @@ struct ClipEmitArgs {
   Iso T;                                      // sensor_in_local_map^-1
   Iso S; int32_t s_identity;                  // sensor_in_robot
   float2* out_xy; float2* out_nrm; int32_t* out_src; int32_t* out_count_dev /* count[0] of the clipped set */; int32_t* out_count;
+  int32_t host_polls;                          // out_src / out_count are pinned host memory and the host polls out_count: write it last, released to the system
 };
 
 __global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A);
@@ -1155,7 +1157,11 @@ LSM2D_DEV void clip_emit_body(const ClipEmitArgs& A, const u64* canvas, int* s_w
       if (A.out_src) A.out_src[pos] = src;
     }
   }
-  if (tid == 0) { *A.out_count = *s_base; *A.out_count_dev = *s_base; }
+  if (A.host_polls) {      // the count goes last, behind every thread's system-scope release of its rows: the synchronous form's host side polls it
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) { *A.out_count_dev = *s_base; __hip_atomic_store(A.out_count, *s_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  } else if (tid == 0) { *A.out_count = *s_base; *A.out_count_dev = *s_base; }
 }
 
 __global__ __launch_bounds__(kFindBlock) void k_clip_small(const ClipSmallArgs A) {
@@ -1199,6 +1205,7 @@ struct MergeArgs {
   float far_limit, merge_threshold;
   int32_t* out;                                       // [4]: new size, new, merged, replaced
   int32_t* count_dev;                                 // count[0] of the scene set
+  int32_t host_polls;                                 // out is pinned host memory and the host polls out[0]: write it last, released to the system
 };
 
 // mkT: when non-null the measurement is still in its own frame and is moved by *mkT on the fly (fused small-scene kernel);
@@ -1239,7 +1246,11 @@ LSM2D_DEV void merge_apply_body(const MergeArgs& A, const u64* scanvas, const u6
     const int pos = block_compact_offset(append, s_wave_tot, &s_cnt[0], tid, kFindBlock / 64);
     if (append) { A.sxy[A.n_scene + pos] = mp; A.snrm[A.n_scene + pos] = mn; }
   }
-  if (tid == 0) { A.out[0] = A.n_scene + s_cnt[0]; A.out[1] = s_cnt[1]; A.out[2] = s_cnt[2]; A.out[3] = s_cnt[3]; *A.count_dev = A.n_scene + s_cnt[0]; }
+  if (tid == 0) {      // the new size goes last; the synchronous form's host side polls it in pinned memory: released to the system then
+    A.out[1] = s_cnt[1]; A.out[2] = s_cnt[2]; A.out[3] = s_cnt[3]; *A.count_dev = A.n_scene + s_cnt[0];
+    if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out[0], A.n_scene + s_cnt[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    else A.out[0] = A.n_scene + s_cnt[0];
+  }
 }
 
 __global__ __launch_bounds__(kFindBlock) void k_merge_apply(const MergeArgs A) {
