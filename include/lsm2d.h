@@ -184,7 +184,9 @@ int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params,
                            int32_t n_scans, lsm2d_cloudset** out_set);
 /* The live tracker's form of the same operation: ONE scan into an existing reserved single-cloud set (capacity >= n_beams) --
  * no allocation, nothing waits: the ranges are staged in the set's pinned buffer, the cloud's size stays on the device until
- * somebody asks (see lsm2d_clip_scene).  Same kernel, same bits as lsm2d_preprocess_scans with n_scans = 1. */
+ * somebody asks (see lsm2d_clip_scene).  Same kernel, same bits as lsm2d_preprocess_scans with n_scans = 1.  Unless kernel timing is
+ * on, the launch itself is queued by the set's first reader, and an lsm2d_align_batch that reads several such sets (front and rear
+ * scanner) queues them as one launch, one workgroup per scan. */
 int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges /* host [n_beams] */,
                                lsm2d_cloudset* out_reserved_set);
 

@@ -18,6 +18,7 @@ Errors: the reference throws ``std::runtime_error`` on missing inputs
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import dataclasses
 import math
 from typing import Optional, Sequence
@@ -44,6 +45,7 @@ class Context:
         if rc != 0:
             raise Lsm2dError(rc, "lsm2d_create", self._lib.lsm2d_last_error(None).decode())
         self._h = h
+        self._sets = weakref.WeakSet()      # the cloud sets living on this context: close() destroys them first (a set outliving its context would touch freed memory)
         self.device = device
         self.kernel_timing = bool(kernel_timing)
         if kernel_timing:
@@ -76,6 +78,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for cs in list(getattr(self, "_sets", ())):
+                cs.close()
             self._lib.lsm2d_destroy(self._h)
             self._h = None
 
@@ -114,6 +118,7 @@ class CloudSet:
                                                  n_clouds, total, C.byref(h))
         check(rc, "lsm2d_cloudset_create", ctx.handle)
         self._h = h
+        ctx._sets.add(self)
         self.n_clouds = n_clouds
         self.n_points = total
         self.counts = np.array([total], np.int64) if offs is None else np.diff(offs.astype(np.int64))
@@ -130,6 +135,7 @@ class CloudSet:
         h = C.c_void_p()
         check(ctx._lib.lsm2d_cloudset_create_reserved(ctx.handle, int(capacity), C.byref(h)), "lsm2d_cloudset_create_reserved", ctx.handle)
         self._h, self.n_clouds, self.n_points, self.counts, self.capacity = h, 1, 0, np.zeros(1, np.int64), int(capacity)
+        ctx._sets.add(self)
         return self
 
     # n_points / counts of a reserved set can be "known to the device only" after an asynchronous clip / merge
@@ -679,6 +685,7 @@ class RawDataPreprocessorProjective2D:
               "lsm2d_preprocess_scans", self._ctx.handle)
         cs = CloudSet.__new__(CloudSet)
         cs._ctx, cs._lib, cs._h = self._ctx, self._ctx._lib, h
+        self._ctx._sets.add(cs)
         cs.n_clouds = r.shape[0]
         cs.n_points = int(self._ctx._lib.lsm2d_cloudset_num_points(h))
         cs.counts = np.array([self._ctx._lib.lsm2d_cloudset_cloud_size(h, i) for i in range(r.shape[0])], np.int64)

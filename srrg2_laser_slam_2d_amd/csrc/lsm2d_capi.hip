@@ -102,6 +102,10 @@ struct lsm2d_cloudset {
   // lsm2d_cloudset_upload of a scan-sized set only fills h_upload: the unpacking into d_xy / d_nrm / d_count is queued by the first
   // consumer (flush_upload) -- or done by the aligner kernel itself in its prologue (single-alignment calls: one launch less per scan)
   mutable bool unpack_pending = false;
+  // lsm2d_preprocess_scan_into likewise only stages the ranges (unless kernel timing is on): the preprocessing launch is queued by the
+  // first reader -- an aligner call that reads several such sets queues them as ONE launch, one workgroup per scan (k_preprocess_multi)
+  mutable bool prep_pending = false;
+  mutable PrepArgs prep_args;
 };
 
 #define HIPCHK(ctx, call)                                                                           \
@@ -356,8 +360,10 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->h_upload) (void) hipHostFree(cs->h_upload);
   delete cs;
 }
+static int flush_upload(const lsm2d_cloudset* cs);
 static int resolve_count(const lsm2d_cloudset* cs) {
   if (!cs || !cs->count_pending) return LSM2D_SUCCESS;
+  { const int rc0 = flush_upload(cs); if (rc0) return rc0; }      // a preprocessing launch still pending: its result is the count asked for
   lsm2d_context* ctx = cs->ctx;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, stream_sync(ctx));
@@ -368,6 +374,14 @@ static int resolve_count(const lsm2d_cloudset* cs) {
 }
 // queues the unpacking of a set whose latest upload still sits in its pinned buffer; every reader of the device arrays calls it
 static int flush_upload(const lsm2d_cloudset* cs) {
+  if (cs && cs->prep_pending) {
+    lsm2d_context* ctx = cs->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_preprocess_scans, dim3(1), dim3(kPrepBlock), 0, ctx->stream, cs->prep_args);
+    HIPCHK(ctx, hipGetLastError());
+    cs->prep_pending = false; cs->staged_epoch = ctx->sync_epoch;
+    return LSM2D_SUCCESS;
+  }
   if (!cs || !cs->unpack_pending) return LSM2D_SUCCESS;
   lsm2d_context* ctx = cs->ctx;
   const int n = cs->h_count[0];
@@ -376,6 +390,28 @@ static int flush_upload(const lsm2d_cloudset* cs) {
                      (const float4*) cs->h_upload_dev, n, cs->d_xy, cs->d_nrm, cs->d_count);
   HIPCHK(ctx, hipGetLastError());
   cs->unpack_pending = false; cs->staged_epoch = ctx->sync_epoch;
+  return LSM2D_SUCCESS;
+}
+// the sets an aligner call reads: pending preprocessing launches go out together, one workgroup per scan
+static int flush_preprocessing_together(lsm2d_context* ctx, const lsm2d_cloudset* const* sets, int n_sets) {
+  const lsm2d_cloudset* todo[kPrepMulti]; int nt = 0;
+  for (int i = 0; i < n_sets; ++i) {
+    const lsm2d_cloudset* cs = sets[i];
+    if (!cs || !cs->prep_pending) continue;
+    bool seen = false; for (int k = 0; k < nt; ++k) seen = seen || todo[k] == cs;
+    if (seen) continue;
+    if (nt == kPrepMulti) { const int rc = flush_upload(cs); if (rc) return rc; continue; }
+    todo[nt++] = cs;
+  }
+  if (nt == 0) return LSM2D_SUCCESS;
+  if (nt == 1) return flush_upload(todo[0]);
+  PrepMultiArgs M;
+  for (int k = 0; k < nt; ++k) M.a[k] = todo[k]->prep_args;
+  for (int k = nt; k < kPrepMulti; ++k) M.a[k] = todo[0]->prep_args;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_preprocess_multi, dim3((unsigned) nt), dim3(kPrepBlock), 0, ctx->stream, M);
+  HIPCHK(ctx, hipGetLastError());
+  for (int k = 0; k < nt; ++k) { todo[k]->prep_pending = false; todo[k]->staged_epoch = ctx->sync_epoch; }
   return LSM2D_SUCCESS;
 }
 extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return cs ? cs->n_clouds : 0; }
@@ -447,7 +483,7 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
   // no allocation and no wait for the stream -- only for this set's PREVIOUS upload (an event), whose source the staging buffer
   // still is until it ran
   { const int rc0 = acquire_upload_stage(cs, sizeof(float) * 4 * (size_t) (n > 0 ? n : 1) + 16); if (rc0) return rc0; }
-  cs->count_pending = false;
+  cs->count_pending = false; cs->prep_pending = false;
   cs->h_count[0] = (int32_t) n; cs->total = n;
   if (n <= 16384) {
     // scan-sized: the points go into the pinned buffer as they are and ONE small kernel reads them over the bus, splits them into
@@ -784,13 +820,18 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
   A.d2max = pp->normal_point_distance * pp->normal_point_distance; A.min_points = pp->normal_min_points;
   A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
   A.out_xy = out->d_xy; A.out_nrm = out->d_nrm; A.out_count = out->d_count;
-  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  out->h_count[0] = nb; out->total = nb; out->count_pending = true;          // at most one point per beam
+  if (!ctx->kernel_timing) {                    // the launch is queued by the set's first reader (flush_upload / flush_preprocessing_together)
+    out->prep_pending = true; out->prep_args = A;
+    return LSM2D_SUCCESS;
+  }
+  out->prep_pending = false;
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_preprocess_scans, dim3(1), dim3(kPrepBlock), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
-  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   out->staged_epoch = ctx->sync_epoch;                    // the staging buffer is free again once the kernel has run
-  ctx->have_timing = ctx->kernel_timing;
-  out->h_count[0] = nb; out->total = nb; out->count_pending = true;          // at most one point per beam
+  ctx->have_timing = true;
   return LSM2D_SUCCESS;
 }
 
@@ -811,7 +852,7 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   HIPCHK(ctx, hipSetDevice(ctx->device));
   cloudset_drop_grids(clipped);
   { const int rc0 = flush_upload(scene); if (rc0) return rc0; }
-  clipped->unpack_pending = false;              // whatever was uploaded into the output set is replaced
+  clipped->unpack_pending = false; clipped->prep_pending = false;      // whatever was staged for the output set is replaced
   const size_t cols = (size_t) P.cols, o_src = cols * 8, o_cnt = o_src + cols * 4, bytes = o_cnt + 16;
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
   rc = ensure_stage(ctx, bytes); if (rc) return rc;
@@ -1120,6 +1161,11 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   if (zero_copy) ds = (char*) ctx->h_stage_dev;
 
   // ---- slices
+  {   // scans whose preprocessing is still pending (lsm2d_preprocess_scan_into): one launch for all of them
+    const lsm2d_cloudset* rd[2 * kMaxSlices]; int nr = 0;
+    for (int s = 0; s < ns; ++s) { rd[nr++] = b->fixed[s]; rd[nr++] = b->moving[s]; }
+    const int prc = flush_preprocessing_together(ctx, rd, nr); if (prc) return prc;
+  }
   int cols_max = 0, fcan_total = 0;
   for (int s = 0; s < ns; ++s) {
     const lsm2d_slice_params& sp = b->slices[s];

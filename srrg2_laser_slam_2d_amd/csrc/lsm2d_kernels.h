@@ -1305,14 +1305,14 @@ struct PrepArgs {
   float2* out_xy; float2* out_nrm; int32_t* out_count;
 };
 
-__global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs A) {
+LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
   __shared__ float2 s_p[kPrepMaxBeams];      // unprojected points, beam order
   __shared__ float2 s_q[kPrepMaxBeams];      // points that got a normal
   __shared__ float2 s_n[kPrepMaxBeams];      // their normals
   __shared__ u64 s_key[kPrepMaxBeams];       // (voxel key << 16) | index, bitonic-sorted
   __shared__ int s_wave_tot[kPrepBlock / 64];
   __shared__ int s_base;
-  const int tid = threadIdx.x, scan = blockIdx.x, nb = A.n_beams;
+  const int tid = threadIdx.x, nb = A.n_beams;
   const float* rg = A.ranges + (size_t) scan * nb;
   float2* oxy = A.out_xy + (size_t) scan * A.stride; float2* onr = A.out_nrm + (size_t) scan * A.stride;
   // ---- F2.1 unprojection, valid beams compacted in beam order
@@ -1430,6 +1430,12 @@ __global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs 
   }
   if (tid == 0) A.out_count[scan] = s_base;
 }
+__global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs A) { preprocess_scan_body(A, blockIdx.x); }
+// several scans, each with its own sensor geometry and its own output set, side by side (the live tracker's front and rear scanner:
+// lsm2d_preprocess_scan_into defers its launch, the aligner call that reads both sets queues them together)
+static constexpr int kPrepMulti = 4;
+struct PrepMultiArgs { PrepArgs a[kPrepMulti]; };
+__global__ __launch_bounds__(kPrepBlock) void k_preprocess_multi(const PrepMultiArgs M) { preprocess_scan_body(M.a[blockIdx.x], 0); }
 
 // ---- lane-chunked copy of every cloud of a set for k_align's streaming pass (project_cloud_lanes) -------------
 // slot t*nthreads + g of cloud c  <-  pair g*T_c + t of the cloud (two points), +inf where the cloud has ended

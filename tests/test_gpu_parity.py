@@ -887,11 +887,7 @@ def test_preprocessor_bit_exact_batch_and_feeds_aligner(ctx, po):
         assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
 
 
-def test_ranges_in_pose_out_tracker_step_without_host_round_trips(ctx, po):
-    """Row f2's point: raw ranges in, pose out, one synchronisation.  Two LaserMessages are preprocessed INTO reserved sets
-    (lsm2d_preprocess_scan_into: same bits as the batched call), the local map is clipped, the aligner runs on the three
-    size-pending sets, both measurements are merged -- every call but the aligner asynchronous.  Checked against the same
-    chain on the oracle."""
+def _ranges_in_pose_out_step(ctx, po):
     world = synth.make_world(6)
     a0, a1 = -2.34747, 2.35619
     S = [np.float32([0.2, 0.1, 0.1]), np.float32([-0.3, 0.0, math.pi])]
@@ -937,6 +933,45 @@ def test_ranges_in_pose_out_tracker_step_without_host_round_trips(ctx, po):
     for i, s in enumerate(S):       # merged at the DEVICE's estimate so that the maps can be compared bit for bit
         host_map, _ = po.merge_scene(opr, host_map, meas[i], np.float32(synth.compose_poses(est[None, :], s[None, :].astype(np.float64))[0]), 0.2)
     assert local_map.n_points == len(host_map) and np.array_equal(local_map.download(), host_map)
+
+
+def test_ranges_in_pose_out_tracker_step_without_host_round_trips(ctx, po):
+    """Row f2's point: raw ranges in, pose out, one synchronisation.  Two LaserMessages are preprocessed INTO reserved sets
+    (lsm2d_preprocess_scan_into: same bits as the batched call), the local map is clipped, the aligner runs on the three
+    size-pending sets, both measurements are merged -- every call but the aligner asynchronous.  Checked against the same
+    chain on the oracle."""
+    _ranges_in_pose_out_step(ctx, po)
+
+
+def test_deferred_preprocessing_is_queued_by_the_first_reader(po):
+    """Without kernel timing (the library's default) lsm2d_preprocess_scan_into only stages the ranges: the launch is queued by the
+    set's first reader, and an aligner call that reads several such sets queues them as ONE launch (k_preprocess_multi, one workgroup
+    per scan).  The same tracker step as above must come out bit for bit, and so must a set whose first reader is a size query, a
+    download, a finder, or a second preprocessing call that replaces the first."""
+    quiet = api.Context(0, kernel_timing=False)
+    try:
+        _ranges_in_pose_out_step(quiet, po)
+        world = synth.make_world(6); a0, a1 = -2.34747, 2.35619
+        rg = [synth.make_scan_ranges(world, synth.sample_poses(world, 1, seed=30 + i), n_beams=721, angle_min=a0, angle_max=a1, noise_sigma=0.004, seed=7 + i)[0] for i in range(3)]
+        pp = po.Preprocessor(721, a0, a1, 0.3, 20.0, 0.3, 5, 0.02)
+        want = [po.preprocess_scan(pp, r) for r in rg]
+        pre = api.RawDataPreprocessorProjective2D(quiet, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+        st = api.CloudSet.reserved(quiet, 1024)
+        pre.setRawData(rg[0], a0, a1, 0.0, 30.0); pre.compute_into(st)
+        assert st.n_points == len(want[0])                                     # first reader: the size query
+        pre.setRawData(rg[1], a0, a1, 0.0, 30.0); pre.compute_into(st)
+        assert np.array_equal(st.download(), want[1])                          # first reader: the download
+        pre.setRawData(rg[0], a0, a1, 0.0, 30.0); pre.compute_into(st)
+        pre.setRawData(rg[2], a0, a1, 0.0, 30.0); pre.compute_into(st)         # replaces the scan nobody read
+        m = synth.make_map(world, 5000, seed=2)
+        f = api.CorrespondenceFinderProjective2f(quiet, api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0), 0.5, 0.8)
+        f.setFixed(st); f.setMoving(m); f.setLocalMapInSensor(np.zeros(3, np.float32)); a = f.compute()      # first reader: the finder
+        f.setFixed(want[2]); b = f.compute()
+        assert np.array_equal(a, b) and np.array_equal(st.download(), want[2])
+        st.upload(want[0]); assert np.array_equal(st.download(), want[0])       # an upload replaces a pending scan too
+        pre.setRawData(rg[1], a0, a1, 0.0, 30.0); pre.compute_into(st); st.upload(want[2]); assert np.array_equal(st.download(), want[2])
+    finally:
+        quiet.close()
 
 
 def test_maximum_sizes_against_oracle(ctx, po):
