@@ -114,6 +114,7 @@ const char* lsm2d_status_string(int status);
 const char* lsm2d_last_error(const lsm2d_context* ctx);
 /* hip_stream: an existing hipStream_t to launch on (e.g. the caller's torch stream), or NULL to own one */
 int  lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out_ctx);
+/* waits for the stream, frees the context.  Cloud sets still alive on it stay the caller's to destroy (any time), but no call takes them any more. */
 void lsm2d_destroy(lsm2d_context* ctx);
 /* blocks until everything queued on the context's stream has finished */
 int  lsm2d_synchronize(lsm2d_context* ctx);

@@ -39,6 +39,7 @@ struct lsm2d_context {
   bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1, 2 or 3)
+  std::vector<lsm2d_cloudset*> live_sets;      // lsm2d_destroy orphans what is left (a set destroyed after its context must not touch it)
 };
 
 // every wait for the context's stream goes through here: the epoch lets a set know that a transfer it queued from its pinned
@@ -193,6 +194,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
   (void) hipStreamSynchronize(c->stream); ++c->sync_epoch;
+  for (lsm2d_cloudset* cs : c->live_sets) cs->ctx = nullptr;        // still owned by the caller: destroy them any time, use them no more
   if (c->h_stage) (void) hipHostFree(c->h_stage);
   if (c->d_scratch) (void) hipFree(c->d_scratch);
   if (c->d_split) (void) hipFree(c->d_split);
@@ -295,7 +297,7 @@ static int cloudset_create_impl(lsm2d_context* ctx, const void* points, bool on_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   lsm2d_cloudset* cs = new (std::nothrow) lsm2d_cloudset;
   if (!cs) return LSM2D_OUT_OF_MEMORY;
-  cs->ctx = ctx;
+  cs->ctx = ctx; ctx->live_sets.push_back(cs);
   int rc = cloudset_layout(cs, offsets, n_clouds, total);
   if (rc == LSM2D_SUCCESS) rc = cloudset_alloc(ctx, cs);
   if (rc != LSM2D_SUCCESS) { lsm2d_cloudset_destroy(cs); return rc; }
@@ -358,11 +360,13 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_lane_T) (void) hipFree(cs->d_lane_T);
   if (cs->ctx && cs->staged_epoch == cs->ctx->sync_epoch) (void) stream_sync(cs->ctx);      // a staged transfer may still be reading h_upload
   if (cs->h_upload) (void) hipHostFree(cs->h_upload);
+  if (cs->ctx) { auto& v = cs->ctx->live_sets; for (size_t i = 0; i < v.size(); ++i) if (v[i] == cs) { v[i] = v.back(); v.pop_back(); break; } }
   delete cs;
 }
 static int flush_upload(const lsm2d_cloudset* cs);
 static int resolve_count(const lsm2d_cloudset* cs) {
   if (!cs || !cs->count_pending) return LSM2D_SUCCESS;
+  if (!cs->ctx) return LSM2D_BAD_ARGUMENT;      // its context is gone
   { const int rc0 = flush_upload(cs); if (rc0) return rc0; }      // a preprocessing launch still pending: its result is the count asked for
   lsm2d_context* ctx = cs->ctx;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -374,6 +378,7 @@ static int resolve_count(const lsm2d_cloudset* cs) {
 }
 // queues the unpacking of a set whose latest upload still sits in its pinned buffer; every reader of the device arrays calls it
 static int flush_upload(const lsm2d_cloudset* cs) {
+  if (cs && !cs->ctx) return LSM2D_BAD_ARGUMENT;      // its context is gone
   if (cs && cs->prep_pending) {
     lsm2d_context* ctx = cs->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -442,7 +447,7 @@ extern "C" int lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capaci
   HIPCHK(ctx, hipSetDevice(ctx->device));
   lsm2d_cloudset* cs = new (std::nothrow) lsm2d_cloudset;
   if (!cs) return LSM2D_OUT_OF_MEMORY;
-  cs->ctx = ctx; cs->n_clouds = 1; cs->total = 0; cs->capacity = capacity; cs->padded_total = capacity + (capacity & 1) + 2;
+  cs->ctx = ctx; ctx->live_sets.push_back(cs); cs->n_clouds = 1; cs->total = 0; cs->capacity = capacity; cs->padded_total = capacity + (capacity & 1) + 2;
   cs->h_start.assign(1, 0); cs->h_count.assign(1, 0);
   int rc = cloudset_alloc(ctx, cs);
   if (rc == LSM2D_SUCCESS) { hipError_t e = stream_sync(ctx); if (e != hipSuccess) rc = LSM2D_DEVICE_ERROR; }
@@ -752,7 +757,7 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   if ((int64_t) stride * n_scans > 0x7ffffff0) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "preprocess_scans: too many points");
   lsm2d_cloudset* cs = new (std::nothrow) lsm2d_cloudset;
   if (!cs) return LSM2D_OUT_OF_MEMORY;
-  cs->ctx = ctx; cs->n_clouds = n_scans; cs->padded_total = (int64_t) stride * n_scans + 2;
+  cs->ctx = ctx; ctx->live_sets.push_back(cs); cs->n_clouds = n_scans; cs->padded_total = (int64_t) stride * n_scans + 2;
   cs->h_start.resize(n_scans); cs->h_count.assign(n_scans, 0);
   for (int c = 0; c < n_scans; ++c) cs->h_start[c] = c * stride;
   int rc = cloudset_alloc(ctx, cs);

@@ -801,6 +801,28 @@ def test_abi_error_paths_and_limits(ctx, small_workload):
         quiet.close()
 
 
+def test_sets_may_outlive_their_context(ctx, small_workload):
+    """lsm2d_destroy orphans the sets still alive on it: destroying them afterwards is fine, using them is an error, and nothing
+    of it disturbs another context."""
+    from srrg2_laser_slam_2d_amd import _capi
+    import ctypes as C
+    lib = _capi.load(); wl = small_workload
+    c2 = C.c_void_p(); assert lib.lsm2d_create(0, None, C.byref(c2)) == 0
+    pts = np.ascontiguousarray(wl.map_points[:1000]); h = C.c_void_p(); r = C.c_void_p()
+    assert lib.lsm2d_cloudset_create(c2, pts.ctypes.data_as(C.c_void_p), None, 1, len(pts), C.byref(h)) == 0
+    assert lib.lsm2d_cloudset_create_reserved(c2, 2048, C.byref(r)) == 0
+    assert lib.lsm2d_cloudset_upload(r, pts.ctypes.data_as(C.c_void_p), 500) == 0        # left pending on purpose
+    lib.lsm2d_destroy(c2)
+    out = np.empty((1000, 4), np.float32); n = C.c_int64(0)
+    assert lib.lsm2d_cloudset_download(r, 0, out.ctypes.data_as(C.c_void_p), 1000, C.byref(n)) < 0
+    assert lib.lsm2d_cloudset_upload(r, pts.ctypes.data_as(C.c_void_p), 10) < 0
+    assert lib.lsm2d_cloudset_num_points(h) == 1000                                      # host-side knowledge survives
+    lib.lsm2d_cloudset_destroy(h); lib.lsm2d_cloudset_destroy(r)
+    al = _aligner(ctx, 361, its=5)                                                        # the session's context is untouched
+    res = al.compute_batch([wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]], [wl.map_points], wl.x0[:1])
+    assert res.status[0] == 0
+
+
 def test_pending_sizes_are_resolved_where_the_host_needs_them(ctx, po):
     """Asynchronous clip / merge leave sizes on the device.  Every consumer must still be right: a point-query finder on a
     size-pending set (its grid needs the number), a download, a merge whose size BOUND no longer fits the capacity although the
