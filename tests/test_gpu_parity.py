@@ -1509,6 +1509,21 @@ def test_gpu_reproduces_the_frozen_golden_bits(ctx):
             assert [float(v).hex() for v in res.stats[i]["chi_inliers"][:k]] == w["chi_in_hex"]
 
 
+def test_gpu_reproduces_the_frozen_tracker_chain(ctx):
+    """tests/golden/tracker_chain.json (digests written by the oracle on the CPU box): the HIP path, fed the same raw ranges, must
+    produce the same preprocessed scans, clipped scenes, poses, information matrices and local maps at every step -- committed data
+    against the device, no oracle call; once with kernel timing (every call launches at once) and once without (deferred launches,
+    both scans preprocessed by one launch)."""
+    import tracker_chain
+    g = json.load(open(golden_path("tracker_chain.json")))
+    assert tracker_chain.run_device(api, ctx, len(g["steps"])) == g["steps"]
+    quiet = api.Context(0, kernel_timing=False)
+    try:
+        assert tracker_chain.run_device(api, quiet, len(g["steps"])) == g["steps"]
+    finally:
+        quiet.close()
+
+
 def test_nn_cooperative_search_is_chosen_per_alignment(ctx, po, small_workload):
     """A ragged NN batch: alignment 0 searches a fixed cloud more than four times its moving one (four lanes per query), alignment 1 a
     fixed cloud smaller than that (one lane per query).  The loop is picked per alignment from the device-side counts; both must

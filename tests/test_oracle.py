@@ -387,3 +387,15 @@ def test_fixed_log_accuracy(po):
     got = po.log_fixed(x).astype(np.float64); ref = np.log(x.astype(np.float64))
     assert (np.abs(got - ref) / np.maximum(ref, 0.1)).max() < 2e-7
     assert po.log_fixed([1.0])[0] == 0.0
+
+
+def test_tracker_chain_digests(po):
+    """tests/golden/tracker_chain.json: an 8-step live-tracker chain (ranges -> preprocess -> clip -> two-slice align with prior, the
+    kernels' summation order -> merge) reduced to digests of every intermediate array.  The oracle must reproduce the committed file
+    bit for bit; tests/test_gpu_parity.py holds the HIP path to the same file."""
+    import tracker_chain
+    g = json.load(open(golden_path("tracker_chain.json")))
+    got = tracker_chain.run_oracle(po, len(g["steps"]))
+    assert got == g["steps"]
+    assert all(st["status"] == 0 for st in got) and got[-1]["map_points"] > got[0]["map_points"]
+
