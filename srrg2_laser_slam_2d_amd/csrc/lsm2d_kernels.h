@@ -364,10 +364,11 @@ __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], 
 template <bool kHasProj, bool kHasNN, bool kHasDist>
 __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
-  u64* mcan = reinterpret_cast<u64*>(smem);
+  // the 16-byte rows first: behind the canvases they would sit on an odd 8-byte boundary whenever cols_max + fcan_total is odd
+  float4* fwin = reinterpret_cast<float4*>(smem);                 // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
+  u64* mcan = reinterpret_cast<u64*>(fwin + A.fcan_total);
   u64* fcan = mcan + A.cols_max;
-  float4* fwin = reinterpret_cast<float4*>(fcan + A.fcan_total);  // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
-  float* red = reinterpret_cast<float*>(fwin + A.fcan_total);     // [nwaves][kAccumWords]
+  float* red = reinterpret_cast<float*>(fcan + A.fcan_total);     // [nwaves][kAccumWords]
   // NN finder over a scan-sized fixed cloud (the tracker wiring: tree over the scan, every map point a query): the cloud's search
   // tables live in LDS for the whole alignment -- 20 iterations x N_m queries then touch global memory only for the query stream
   float2* l_sxy = reinterpret_cast<float2*>(red + (kAlignBlock / 64) * kAccumWords);
@@ -613,10 +614,10 @@ LSM2D_DEV void block_reduce_gather_pair(const float* red0, const float* red1, in
 
 __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
-  u64* mcan2 = reinterpret_cast<u64*>(smem);                       // [2][cols_max]: one moving canvas per slice
+  float4* fwin = reinterpret_cast<float4*>(smem);                  // 16-byte rows first (alignment), as in k_align
+  u64* mcan2 = reinterpret_cast<u64*>(fwin + A.fcan_total);        // [2][cols_max]: one moving canvas per slice
   u64* fcan = mcan2 + 2 * A.cols_max;
-  float4* fwin = reinterpret_cast<float4*>(fcan + A.fcan_total);
-  float* red2 = reinterpret_cast<float*>(fwin + A.fcan_total);     // [2][nwaves][kAccumWords]
+  float* red2 = reinterpret_cast<float*>(fcan + A.fcan_total);     // [2][nwaves][kAccumWords]
   __shared__ Iso   s_iso[2];
   __shared__ int   s_done;
   float pose[3] = {0.0f, 0.0f, 0.0f}, Hlast[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // thread 0's: estimate and information matrix stay in registers
