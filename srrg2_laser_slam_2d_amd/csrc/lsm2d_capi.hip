@@ -101,7 +101,7 @@ struct lsm2d_cloudset {
   void* h_upload = nullptr; size_t h_upload_bytes = 0; void* h_upload_dev = nullptr;
   mutable unsigned long long staged_epoch = 0;       // ctx->sync_epoch when the last transfer out of h_upload was queued (0: none pending)
   // lsm2d_cloudset_upload of a scan-sized set only fills h_upload: the unpacking into d_xy / d_nrm / d_count is queued by the first
-  // consumer (flush_upload) -- or done by the aligner kernel itself in its prologue (single-alignment calls: one launch less per scan)
+  // consumer (flush_pending) -- or done by the aligner kernel itself in its prologue (single-alignment calls: one launch less per scan)
   mutable bool unpack_pending = false;
   // lsm2d_preprocess_scan_into likewise only stages the ranges (unless kernel timing is on): the preprocessing launch is queued by the
   // first reader -- an aligner call that reads several such sets queues them as ONE launch, one workgroup per scan (k_preprocess_multi)
@@ -363,11 +363,11 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->ctx) { auto& v = cs->ctx->live_sets; for (size_t i = 0; i < v.size(); ++i) if (v[i] == cs) { v[i] = v.back(); v.pop_back(); break; } }
   delete cs;
 }
-static int flush_upload(const lsm2d_cloudset* cs);
+static int flush_pending(const lsm2d_cloudset* cs);
 static int resolve_count(const lsm2d_cloudset* cs) {
   if (!cs || !cs->count_pending) return LSM2D_SUCCESS;
   if (!cs->ctx) return LSM2D_BAD_ARGUMENT;      // its context is gone
-  { const int rc0 = flush_upload(cs); if (rc0) return rc0; }      // a preprocessing launch still pending: its result is the count asked for
+  { const int rc0 = flush_pending(cs); if (rc0) return rc0; }      // a preprocessing launch still pending: its result is the count asked for
   lsm2d_context* ctx = cs->ctx;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, stream_sync(ctx));
@@ -377,7 +377,7 @@ static int resolve_count(const lsm2d_cloudset* cs) {
   return LSM2D_SUCCESS;
 }
 // queues the unpacking of a set whose latest upload still sits in its pinned buffer; every reader of the device arrays calls it
-static int flush_upload(const lsm2d_cloudset* cs) {
+static int flush_pending(const lsm2d_cloudset* cs) {
   if (cs && !cs->ctx) return LSM2D_BAD_ARGUMENT;      // its context is gone
   if (cs && cs->prep_pending) {
     lsm2d_context* ctx = cs->ctx;
@@ -405,11 +405,11 @@ static int flush_preprocessing_together(lsm2d_context* ctx, const lsm2d_cloudset
     if (!cs || !cs->prep_pending) continue;
     bool seen = false; for (int k = 0; k < nt; ++k) seen = seen || todo[k] == cs;
     if (seen) continue;
-    if (nt == kPrepMulti) { const int rc = flush_upload(cs); if (rc) return rc; continue; }
+    if (nt == kPrepMulti) { const int rc = flush_pending(cs); if (rc) return rc; continue; }
     todo[nt++] = cs;
   }
   if (nt == 0) return LSM2D_SUCCESS;
-  if (nt == 1) return flush_upload(todo[0]);
+  if (nt == 1) return flush_pending(todo[0]);
   PrepMultiArgs M;
   for (int k = 0; k < nt; ++k) M.a[k] = todo[k]->prep_args;
   for (int k = nt; k < kPrepMulti; ++k) M.a[k] = todo[0]->prep_args;
@@ -493,7 +493,7 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
   if (n <= 16384) {
     // scan-sized: the points go into the pinned buffer as they are and ONE small kernel reads them over the bus, splits them into
     // the coordinate / normal arrays and sets the count (three host-to-device copies cost three times the API and launch overhead)
-    // -- queued by the set's first reader (flush_upload), or done by the aligner kernel itself
+    // -- queued by the set's first reader (flush_pending), or done by the aligner kernel itself
     if (n) memcpy(cs->h_upload, pts, sizeof(float) * 4 * (size_t) n);
     cs->unpack_pending = true;
     return LSM2D_SUCCESS;
@@ -518,7 +518,7 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
 extern "C" int lsm2d_cloudset_download(const lsm2d_cloudset* cs, int32_t ci, float* out, int64_t capacity, int64_t* out_n) {
   if (!cs || !cs->ctx || !out_n || !valid_cloud_index_fwd(cs, ci)) return fail(cs ? cs->ctx : nullptr, LSM2D_BAD_ARGUMENT, "cloudset_download: bad argument");
   lsm2d_context* ctx = cs->ctx;
-  { int rc0 = resolve_count(cs); if (rc0) return rc0; rc0 = flush_upload(cs); if (rc0) return rc0; }
+  { int rc0 = resolve_count(cs); if (rc0) return rc0; rc0 = flush_pending(cs); if (rc0) return rc0; }
   const int64_t n = cs->h_count[ci];
   *out_n = n;
   if (n > capacity || (n > 0 && !out)) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "cloudset_download: out buffer too small");
@@ -826,7 +826,7 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
   A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
   A.out_xy = out->d_xy; A.out_nrm = out->d_nrm; A.out_count = out->d_count;
   out->h_count[0] = nb; out->total = nb; out->count_pending = true;          // at most one point per beam
-  if (!ctx->kernel_timing) {                    // the launch is queued by the set's first reader (flush_upload / flush_preprocessing_together)
+  if (!ctx->kernel_timing) {                    // the launch is queued by the set's first reader (flush_pending / flush_preprocessing_together)
     out->prep_pending = true; out->prep_args = A;
     return LSM2D_SUCCESS;
   }
@@ -856,7 +856,7 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   if ((int) (sizeof(u64) * (size_t) P.cols) > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "clip_scene: canvas does not fit LDS");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   cloudset_drop_grids(clipped);
-  { const int rc0 = flush_upload(scene); if (rc0) return rc0; }
+  { const int rc0 = flush_pending(scene); if (rc0) return rc0; }
   clipped->unpack_pending = false; clipped->prep_pending = false;      // whatever was staged for the output set is replaced
   const size_t cols = (size_t) P.cols, o_src = cols * 8, o_cnt = o_src + cols * 4, bytes = o_cnt + 16;
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
@@ -919,7 +919,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   if ((int) (sizeof(u64) * (size_t) P.cols) > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "merge_scene: canvas does not fit LDS");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   cloudset_drop_grids(scene);
-  { int rc0 = flush_upload(scene); if (rc0) return rc0; rc0 = flush_upload(meas); if (rc0) return rc0; }
+  { int rc0 = flush_pending(scene); if (rc0) return rc0; rc0 = flush_pending(meas); if (rc0) return rc0; }
   const size_t cols = (size_t) P.cols, nm = (size_t) (n_meas > 0 ? n_meas : 1);
   const size_t o_mcan = cols * 8, o_out = o_mcan + cols * 8, o_txy = o_out + 64, o_tn = o_txy + ((nm * 8 + 15) & ~(size_t) 15) + 16, bytes = o_tn + nm * 8 + 16;
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
@@ -976,7 +976,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
 extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* cloud, int32_t ci,
                              const float pose[3], int32_t* out_src, float* out_depth, float* out_xynn) {
   if (!ctx || !pr || !pose || !valid_cloud_index(cloud, ci)) return fail(ctx, LSM2D_BAD_ARGUMENT, "project: bad argument");
-  { int rc0 = resolve_count(cloud); if (rc0) return rc0; rc0 = flush_upload(cloud); if (rc0) return rc0; }
+  { int rc0 = resolve_count(cloud); if (rc0) return rc0; rc0 = flush_pending(cloud); if (rc0) return rc0; }
   ProjectArgs A;
   if (!make_projk(*pr, &A.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "project: bad projector");
   const size_t lds = sizeof(u64) * (size_t) A.proj.cols;
@@ -1007,7 +1007,7 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
       (capacity > 0 && !out_pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad argument");
   { int rc0 = resolve_count(fixed); if (rc0) return rc0; rc0 = resolve_count(moving); if (rc0) return rc0; }
-  { int rc0 = flush_upload(fixed); if (rc0) return rc0; rc0 = flush_upload(moving); if (rc0) return rc0; }
+  { int rc0 = flush_pending(fixed); if (rc0) return rc0; rc0 = flush_pending(moving); if (rc0) return rc0; }
   *out_n = 0;
   if (sp->finder == LSM2D_FINDER_NN || sp->finder == LSM2D_FINDER_DISTMAP) {
     if (sp->finder == LSM2D_FINDER_NN && !(sp->max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: max_distance must be > 0");
@@ -1073,7 +1073,7 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
       (n_pairs > 0 && !pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "linearize: bad argument");
   { int rc0 = resolve_count(fixed); if (rc0) return rc0; rc0 = resolve_count(moving); if (rc0) return rc0; }
-  { int rc0 = flush_upload(fixed); if (rc0) return rc0; rc0 = flush_upload(moving); if (rc0) return rc0; }
+  { int rc0 = flush_pending(fixed); if (rc0) return rc0; rc0 = flush_pending(moving); if (rc0) return rc0; }
   for (int32_t k = 0; k < n_pairs; ++k)
     if (pairs[k].fixed_idx < 0 || pairs[k].fixed_idx >= fixed->h_count[fi] || pairs[k].moving_idx < 0 || pairs[k].moving_idx >= moving->h_count[mi])
       return fail(ctx, LSM2D_BAD_ARGUMENT, "linearize: correspondence index out of range");
@@ -1204,8 +1204,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     // a fixed set whose upload still sits in its pinned buffer: single-alignment projective calls unpack it in the kernel's prologue
     // (decided once the kernel is known, below); every other reader gets it unpacked by a launch of its own, here
     const bool defer_unpack = f->unpack_pending && n == 1 && !use_split && has_proj && !has_nn && !has_dist && f != m;
-    if (!defer_unpack) { const int urc = flush_upload(f); if (urc) return urc; }
-    { const int urc = flush_upload(m); if (urc) return urc; }
+    if (!defer_unpack) { const int urc = flush_pending(f); if (urc) return urc; }
+    { const int urc = flush_pending(m); if (urc) return urc; }
     if (sp.finder == LSM2D_FINDER_PROJECTIVE) { const int lrc = ensure_lane_layout(ctx, m); if (lrc) return lrc; }
     S.fixed = cloud_dev(f, d_fi); S.moving = cloud_dev(m, d_mi);
     S.unpack_src = defer_unpack ? (const float4*) f->h_upload_dev : nullptr; S.unpack_n = defer_unpack ? f->h_count[0] : 0;
