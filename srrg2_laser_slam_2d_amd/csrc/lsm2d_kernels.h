@@ -89,14 +89,33 @@ LSM2D_DEV int nn_query(const GridMeta& g, const CellT* __restrict__ cell_start, 
     const int y0 = cy - k < 0 ? 0 : cy - k, y1 = cy + k > g.gh - 1 ? g.gh - 1 : cy + k;
     if (x0 <= x1 && y0 <= y1) {
       // a candidate's original index is only needed when it improves on or ties with the best so far (ties -> lowest index)
+      auto consider = [&](int t, float2 p) {
+        const float dx = p.x - qx, dy = p.y - qy;
+        const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+        if (d2 <= md2 && d2 <= bd) {
+          const int i = (int) sidx[t];
+          if (d2 < bd || i < best || best < 0) { bd = d2; best = i; }
+        }
+      };
+      // two candidates per trip, both loads in flight (the (d2, index) minimum does not depend on the order of the candidates).
+      // Measured on configs[1] (A/B on one box, tools/variant_bench.sh): role B (4 lanes per query, tables in global memory) 2.63 ms
+      // one per trip, 2.34 two per trip in the array form below, 2.51 in the straight form; role A (one lane per query, tables in
+      // LDS) 9.62 / 9.40 / 9.18; three or four per trip lose on both (registers).
       auto scan_row = [&](int s, int e) {
-        for (int t = s + sub; t < e; t += group) {
-          const float2 p = sxy[t];
-          const float dx = p.x - qx, dy = p.y - qy;
-          const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-          if (d2 <= md2 && d2 <= bd) {
-            const int i = (int) sidx[t];
-            if (d2 < bd || i < best || best < 0) { bd = d2; best = i; }
+        if (group > 1) {
+          for (int t = s + sub; t < e; t += 2 * group) {
+            float2 p[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int tu = t + u * group; p[u] = sxy[tu < e ? tu : t]; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int tu = t + u * group; if (tu < e) consider(tu, p[u]); }
+          }
+        } else {
+          for (int t = s + sub; t < e; t += 2 * group) {
+            const int t1 = t + group; const bool h1 = t1 < e;
+            const float2 p0 = sxy[t], p1 = sxy[h1 ? t1 : t];
+            consider(t, p0);
+            if (h1) consider(t1, p1);
           }
         }
       };
