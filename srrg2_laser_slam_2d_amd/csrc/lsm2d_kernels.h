@@ -66,8 +66,12 @@ struct CloudDev {            // device view of a cloud set
 // (2k+1)^2 block around q for k = 1, 2, 4, ... and stops as soon as the best distance is strictly inside the
 // block (every point outside it is farther than k*h, so it can neither win nor tie) or the block covers
 // max_distance.  Converged ICP queries finish in the first 3x3 block.
-static constexpr int kNNGroup = 4;      // lanes that cooperate on one query on a dense fixed cloud: they read 4 consecutive candidates (32 bytes);
-                                        // measured on configs[1] role B with ~13 points per cell: 2 lanes 2.81 ms, 4 lanes 2.48, 8 lanes 2.76, 16 lanes 3.92
+#ifndef LSM2D_NN_GROUP
+#define LSM2D_NN_GROUP 4
+#endif
+static constexpr int kNNGroup = LSM2D_NN_GROUP;      // lanes that cooperate on one query on a dense fixed cloud: they read 4 consecutive candidates (32 bytes);
+                                        // measured on configs[1] role B with ~13 points per cell: 2 lanes 2.81 ms, 4 lanes 2.48, 8 lanes 2.76, 16 lanes 3.92;
+                                        // again with two candidates per trip: 2.53 / 2.36 / 2.73 (the oracle's device-order mode encodes 4)
 
 // CellT / IdxT: int32_t for the tables in global memory, uint16_t for a scan-sized cloud's tables staged in LDS (k_align)
 template <int group, typename CellT = int32_t, typename IdxT = int32_t>
