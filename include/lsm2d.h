@@ -119,10 +119,10 @@ void lsm2d_destroy(lsm2d_context* ctx);
 /* blocks until everything queued on the context's stream has finished */
 int  lsm2d_synchronize(lsm2d_context* ctx);
 /* tuning / test knobs.  "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align),
- * 2 = always the split path (k_split_project + k_split_finish per iteration; projective slices only), 3 = the slice-pair
- * kernel whenever the batch has exactly two projective slices (k_align_pair: both slices' passes side by side in one
- * 1024-thread workgroup; automatic for <= 256 alignments).  All paths return bit-identical results; the split path is for a
- * handful of alignments against a large cloud, the slice pair for the live tracker's two-scanner aligner.
+ * 2 = always the split path (k_split_project + k_split_finish per iteration; projective slices only), 3 = the latency
+ * kernel whenever the batch has one or two projective slices (k_align_pair: 512 threads per slice, two slices' passes side by
+ * side in one workgroup; automatic for <= 256 alignments).  All paths return bit-identical results; the split path is for a
+ * handful of alignments against a large cloud, the latency kernel for calls that cannot fill the chip (the live tracker).
  * "kernel_timing": 1 records HIP events around the hot-path launches so that lsm2d_last_kernel_ms can report them; 0 (default)
  * does not -- the two timed events per operation cost a latency-critical caller such as the live tracker ~20 % of its step --
  * and lsm2d_last_kernel_ms returns LSM2D_BAD_ARGUMENT. */

@@ -1239,11 +1239,13 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     if (mf > 0 && mf <= 65535 && need <= 38 * 1024 - lds) { A.nn_lds_points = mf; A.nn_lds_cells = cap * cap + 1; lds += need + 16; }
   }
   if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
-  // two projective slices and too few alignments to fill the chip (the live tracker: front + rear scanner, one alignment): the
-  // slices' passes run side by side in one 1024-thread workgroup (k_align_pair; bit-identical sums) instead of one after the other
-  const size_t lds_pair = lds + sizeof(u64) * (size_t) cols_max + sizeof(float) * kAccumWords * (kAlignBlock / 64);
-  const bool use_pair = !use_split && ctx->align_path != 1 && ns == 2 && has_proj && !has_nn && !has_dist && (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0 &&
-                        (int) lds_pair + 512 <= ctx->max_dyn_lds;
+  // one or two projective slices and too few alignments to fill the chip (the live tracker: one alignment per scan): the latency
+  // kernel (k_align_pair; bit-identical sums) -- 512 threads per slice, two slices' passes side by side instead of one after the
+  // other, registers to spare for the serial solve step.  Measured against k_align on single-slice calls (tools/latency_kernel_ab.py):
+  // 1 scan vs 10k points 0.163 -> 0.146 ms, vs a 700-point clipped scene with prior 0.063 -> 0.045, 256 candidates 0.172 -> 0.154
+  const size_t lds_pair = lds + (size_t) (ns - 1) * (sizeof(u64) * (size_t) cols_max + sizeof(float) * kAccumWords * (kAlignBlock / 64));
+  const bool use_pair = !use_split && ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist &&
+                        (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0 && (int) lds_pair + 512 <= ctx->max_dyn_lds;
 
   // ---- inputs
   memcpy(hs + o_pose_in, b->init_pose, sizeof(float) * 3 * (size_t) n);
@@ -1309,7 +1311,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     }
   } else {
     const dim3 grid((unsigned) n), block(kAlignBlock);
-    if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3(kPairBlock), lds_pair, ctx->stream, A);
+    if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3((unsigned) (kAlignBlock * ns)), lds_pair, ctx->stream, A);
     else if (has_proj && !has_nn && !has_dist) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && has_nn && !has_dist) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && !has_nn && has_dist) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);

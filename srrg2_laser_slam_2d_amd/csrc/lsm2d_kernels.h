@@ -609,7 +609,8 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   }
 }
 
-// ---- two projective slices side by side -------------------------------------------------------------------------
+// ---- the latency kernel: one alignment per workgroup, tuned for calls that cannot fill the chip ------------------
+// (one or two projective slices; with two, side by side)
 // The live tracker's aligner has two laser slices (front and rear scanner, MULTI.json:396-401) and runs one alignment at a
 // time: with one workgroup per alignment the chip is empty and the call is a chain of latencies, so the two slices' passes
 // run next to each other instead of one after the other.  1024 threads: waves 0-7 own slice 0, waves 8-15 slice 1, every
@@ -638,9 +639,9 @@ LSM2D_DEV void block_reduce_gather_pair(const float* red0, const float* red1, in
 __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   float4* fwin = reinterpret_cast<float4*>(smem);                  // 16-byte rows first (alignment), as in k_align
-  u64* mcan2 = reinterpret_cast<u64*>(fwin + A.fcan_total);        // [2][cols_max]: one moving canvas per slice
-  u64* fcan = mcan2 + 2 * A.cols_max;
-  float* red2 = reinterpret_cast<float*>(fcan + A.fcan_total);     // [2][nwaves][kAccumWords]
+  u64* mcan2 = reinterpret_cast<u64*>(fwin + A.fcan_total);        // [n_slices][cols_max]: one moving canvas per slice
+  u64* fcan = mcan2 + A.n_slices * A.cols_max;
+  float* red2 = reinterpret_cast<float*>(fcan + A.fcan_total);     // [n_slices][nwaves][kAccumWords]
   __shared__ Iso   s_iso[2];
   __shared__ int   s_done;
   float pose[3] = {0.0f, 0.0f, 0.0f}, Hlast[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // thread 0's: estimate and information matrix stay in registers
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   __shared__ PriorDev s_prior;
 
   constexpr int nwaves = kAlignBlock / 64;
-  const int a = blockIdx.x, gtid = threadIdx.x;
+  const int a = blockIdx.x, gtid = threadIdx.x, nthr = kAlignBlock * A.n_slices;      // launched with 512 threads per slice (one or two slices)
 #ifdef LSM2D_PHASE_CLOCKS      // debug build: where one alignment's time goes (10 ns ticks), printed by thread 0
   unsigned long long pc_t = __builtin_amdgcn_s_memrealtime(), pc_acc[6] = {0, 0, 0, 0, 0, 0};
 #define LSM2D_PC(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); pc_acc[k] += n_ - pc_t; pc_t = n_; } while (0)
@@ -663,10 +664,10 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   if (A.prior && gtid >= 64 && gtid < 64 + kPriorWords)
     ((float*) &s_prior)[gtid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[gtid - 64] : ((const float*) (A.prior + a))[gtid - 64];
   if (A.inline_n1 && A.s[half].unpack_src) unpack_fixed_set(A.s[half], tid, kAlignBlock);      // visible after the barrier below
-  for (int i = gtid; i < A.fcan_total; i += kPairBlock) fcan[i] = kEmptyCell;
-  for (int i = gtid; i < 2 * A.cols_max; i += kPairBlock) mcan2[i] = kEmptyCell;
+  for (int i = gtid; i < A.fcan_total; i += nthr) fcan[i] = kEmptyCell;
+  for (int i = gtid; i < A.n_slices * A.cols_max; i += nthr) mcan2[i] = kEmptyCell;
   auto begin_iteration = [&]() {
-    for (int s = 0; s < 2; ++s) s_iso[s] = slice_iso(A.s[s], pose);
+    for (int s = 0; s < A.n_slices; ++s) s_iso[s] = slice_iso(A.s[s], pose);
   };
   if (gtid == 0) {
     if (A.inline_n1) { pose[0] = A.pose1[0]; pose[1] = A.pose1[1]; pose[2] = A.pose1[2]; }
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
     LSM2D_PC(2);
     if (gtid < 64) {
       Accum t[2];
-      block_reduce_gather_pair(red2, red2 + nwaves * kAccumWords, nwaves, gtid, t[0], t[1]);
+      block_reduce_gather_pair(red2, red2 + (A.n_slices - 1) * nwaves * kAccumWords, nwaves, gtid, t[0], t[1]);      // one slice: t[1] repeats t[0], unused
       LSM2D_PC(3);
       if (gtid == 0) {
         // k_align's per-slice accumulation (zeroed sums, then slice 0, then slice 1) and its solve step, in its order
@@ -762,6 +763,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
         int n_in = 0, n_out = 0, n_corr = 0, active = 0; float chi_in = 0.0f, chi_out = 0.0f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+          if (s >= A.n_slices) break;
           n_corr += t[s].n_corr;
           if (t[s].n_corr > A.s[s].min_corr) {
             ++active;

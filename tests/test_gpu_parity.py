@@ -1145,9 +1145,19 @@ def test_slice_pair_kernel_is_bit_identical_to_one_slice_after_the_other(ctx, po
         (k1, _), (k3, _) = run(1, al4, fx, mv, xg, want_stats=True), run(3, al4, fx, mv, xg, want_stats=True)
         assert np.all(k3.status == 1)
         same(k1, k3)
-    # not two projective slices: the option falls back to the ordinary kernel
-    wl = synth.make_workload(2, 5000, seed=3)
-    r1, p = run(3, _aligner(ctx), [api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)], [api.CloudSet(ctx, wl.map_points)], wl.x0)
+    # one projective slice: the same kernel with 512 threads (automatic up to 256 alignments); with prior, statuses, statistics
+    wl = synth.make_workload(3, 5000, seed=3)
+    x0 = wl.x0.copy(); x0[1] += np.float32([70, 70, 0])
+    fx, mv = [api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)], [api.CloudSet(ctx, wl.map_points)]
+    for pri in (None, [(x0[i], np.eye(3, dtype=np.float32) * 30.0) for i in range(3)]):
+        (s1, q1), (s3, q3), (s0, q0) = (run(path, _aligner(ctx), fx, mv, x0, priors=pri, want_stats=True) for path in (1, 3, 0))
+        assert (q1, q3, q0) == (1, 3, 3)
+        same(s1, s3); same(s1, s0)
+        assert s1.status[0] == 0 and s1.status[1] == 1
+    # three slices, or another finder: the option falls back to the ordinary kernel
+    aln = api.MultiAligner2D(ctx, max_iterations=5, min_num_inliers=10)
+    aln.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=0.8), min_num_correspondences=5))
+    r1, p = run(3, aln, fx, mv, wl.x0)
     assert p == 1 and np.all(r1.status == 0)
 
 
@@ -1446,7 +1456,7 @@ def test_randomised_aligner_structure(ctx, po):
         if all_projective:                # the split path takes projective slices only
             b = run(2)
             assert np.array_equal(a.pose, b.pose) and np.array_equal(a.information, b.information) and np.array_equal(a.status, b.status), ("split != fused", trial)
-            if ns == 2:                   # two projective slices side by side in one workgroup (k_align_pair): the same bits, statistics included
+            if ns <= 2:                   # the latency kernel (k_align_pair; two slices side by side in one workgroup): the same bits, statistics included
                 c = run(3)
                 assert ctx.get_option("last_align_path") == 3
                 assert np.array_equal(a.pose, c.pose) and np.array_equal(a.information, c.information) and np.array_equal(a.status, c.status) and \
@@ -1481,7 +1491,7 @@ def test_randomised_aligner_structure(ctx, po):
                 print("  pose gpu", a.pose[i].tolist(), "f32", r["pose"].tolist(), "f64", rd["pose"].tolist())
             assert d.max() < tol, (trial, i, d, dd, same_sets)
             checked += 1; soft += int(tol > POSE_TOL_M)
-    print("structure fuzz: %d trials, %d alignments checked (%d against a widened bar), split == fused in all, slice pair == fused in all %d two-slice trials"
+    print("structure fuzz: %d trials, %d alignments checked (%d against a widened bar), split == fused in all, latency kernel == fused in all %d one- and two-slice trials"
           % (n_trials, checked, soft, paired))
     assert checked >= n_trials // 2
 
