@@ -651,7 +651,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   constexpr int nwaves = kAlignBlock / 64;
   const int a = blockIdx.x, gtid = threadIdx.x, nthr = kAlignBlock * A.n_slices;      // launched with 512 threads per slice (one or two slices)
 #ifdef LSM2D_PHASE_CLOCKS      // debug build: where one alignment's time goes (10 ns ticks), printed by thread 0
-  unsigned long long pc_t = __builtin_amdgcn_s_memrealtime(), pc_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long pc_t = __builtin_amdgcn_s_memrealtime(), pc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LSM2D_PC(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); pc_acc[k] += n_ - pc_t; pc_t = n_; } while (0)
 #else
 #define LSM2D_PC(k) do { } while (0)
@@ -750,9 +750,11 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
           accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm1, nm1, S.cauchy != 0, S.tau, acc);
       }
     }
+    LSM2D_PC(6);                 // thread 0's wave: bin walk
     block_reduce_store(acc, red, tid);
+    LSM2D_PC(7);                 // its wave sums
     __syncthreads();
-    LSM2D_PC(2);
+    LSM2D_PC(2);                 // waiting for the other waves
     if (gtid < 64) {
       Accum t[2];
       block_reduce_gather_pair(red2, red2 + (A.n_slices - 1) * nwaves * kAccumWords, nwaves, gtid, t[0], t[1]);      // one slice: t[1] repeats t[0], unused
@@ -793,8 +795,8 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
     if (s_done) { ++it; break; }
   }
 #ifdef LSM2D_PHASE_CLOCKS
-  if (gtid == 0 && a == 0) printf("k_align_pair ticks(10ns): prologue %llu project %llu walk+reduce %llu gather %llu solve %llu barrier %llu its %d\n",
-                                  pc_acc[0], pc_acc[1], pc_acc[2], pc_acc[3], pc_acc[4], pc_acc[5], it);
+  if (gtid == 0 && a == 0) printf("k_align_pair ticks(10ns): prologue %llu project %llu walk %llu wave-sums %llu wait %llu gather %llu solve %llu barrier %llu its %d\n",
+                                  pc_acc[0], pc_acc[1], pc_acc[6], pc_acc[7], pc_acc[2], pc_acc[3], pc_acc[4], pc_acc[5], it);
 #endif
 #undef LSM2D_PC
   if (gtid == 0) {
