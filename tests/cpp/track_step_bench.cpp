@@ -66,16 +66,20 @@ int main(int argc, char** argv) {
   const float g32[3] = {(float) guess[0], (float) guess[1], (float) guess[2]};
   double est[3] = {0, 0, 0}, est_fresh[3] = {0, 0, 0}; int status = -1; float ms_kernel = 0.0f, kernel_sum = 0.0f;
   const int reset = 50;
-  std::chrono::duration<double> total(0);
+  std::chrono::duration<double> total(0), ph[4] = {};      // host time inside: clip call, scan calls, aligner call (includes the wait), pose + merge calls
   for (int k = -20; k < steps; ++k) {          // 20 warm-up steps
     if ((k + 20) % reset == 0) { CK(lsm2d_cloudset_upload(local_map, map.data(), (int64_t) (map.size() / 4))); CK(lsm2d_synchronize(ctx)); }
     const auto t0 = std::chrono::steady_clock::now();
     int32_t n_clip = 0, n_map = 0;
     CK(lsm2d_clip_scene(ctx, &pr, local_map, 0, g32, S0, clipped, async ? nullptr : &n_clip, nullptr));
+    const auto tc = std::chrono::steady_clock::now();
     if (mode == 2) { CK(lsm2d_preprocess_scan_into(ctx, &pp, r0.data(), m0)); CK(lsm2d_preprocess_scan_into(ctx, &pp, r1.data(), m1)); }
     else { CK(lsm2d_cloudset_upload(m0, s0.data(), (int64_t) (s0.size() / 4))); CK(lsm2d_cloudset_upload(m1, s1.data(), (int64_t) (s1.size() / 4))); }
+    const auto tu = std::chrono::steady_clock::now();
     float x[3];
     CK(lsm2d_align_batch(ctx, &ap, &b, x, nullptr, &status, nullptr, nullptr));
+    const auto ta = std::chrono::steady_clock::now();
+    if (k >= 0) { ph[0] += tc - t0; ph[1] += tu - tc; ph[2] += ta - tu; }
     if (k >= 0 && timing) { lsm2d_last_kernel_ms(ctx, &ms_kernel); kernel_sum += ms_kernel; }
     const double xd[3] = {x[0], x[1], x[2]}; double xi[3]; inverse(xd, xi); compose(guess, xi, est);
     if ((k + 20) % reset == 0) memcpy(est_fresh, est, sizeof est);      // the step right after a map reset: comparable with the oracle
@@ -85,11 +89,12 @@ int main(int argc, char** argv) {
       CK(lsm2d_merge_scene(ctx, &pr, local_map, i ? m1 : m0, 0, mf, 0.2f, async ? nullptr : &n_map, nullptr));
     }
     const auto t1 = std::chrono::steady_clock::now();
-    if (k >= 0) total += t1 - t0;
+    if (k >= 0) { total += t1 - t0; ph[3] += t1 - ta; }
   }
   CK(lsm2d_synchronize(ctx));
-  printf("{\"steps\": %d, \"mode\": %d, \"asynchronous\": %s, \"ms_per_step_wall\": %.5f, \"align_kernel_ms_per_step\": %.5f, \"status\": %d, \"map_points\": %lld, \"est_on_fresh_map\": [%.9f, %.9f, %.9f]}\n",
-         steps, mode, async ? "true" : "false", 1e3 * total.count() / steps, kernel_sum / steps, status, (long long) lsm2d_cloudset_num_points(local_map), est_fresh[0], est_fresh[1], est_fresh[2]);
+  printf("{\"steps\": %d, \"mode\": %d, \"asynchronous\": %s, \"ms_per_step_wall\": %.5f, \"align_kernel_ms_per_step\": %.5f, \"host_us_in_calls\": {\"clip\": %.2f, \"scans\": %.2f, \"align_incl_wait\": %.2f, \"pose_and_merges\": %.2f}, \"status\": %d, \"map_points\": %lld, \"est_on_fresh_map\": [%.9f, %.9f, %.9f]}\n",
+         steps, mode, async ? "true" : "false", 1e3 * total.count() / steps, kernel_sum / steps,
+         1e6 * ph[0].count() / steps, 1e6 * ph[1].count() / steps, 1e6 * ph[2].count() / steps, 1e6 * ph[3].count() / steps, status, (long long) lsm2d_cloudset_num_points(local_map), est_fresh[0], est_fresh[1], est_fresh[2]);
   lsm2d_cloudset_destroy(m0); lsm2d_cloudset_destroy(m1); lsm2d_cloudset_destroy(clipped); lsm2d_cloudset_destroy(local_map);
   lsm2d_destroy(ctx);
   return 0;
