@@ -29,8 +29,8 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 111 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
-                             0.1.11: + lsm2d_get_option, align_path 3 */
+#define LSM2D_VERSION 112 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
+                             0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -212,6 +212,13 @@ int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* projector, const
 int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* projector, lsm2d_cloudset* scene,
                       const lsm2d_cloudset* measurement, int32_t measurement_index, const float measurement_in_scene[3],
                       float merge_threshold, int32_t* out_scene_size, int32_t* out_counts);
+/* Several measurements merged into the scene one after the other, exactly as n calls of lsm2d_merge_scene in this order would (the live
+ * tracker merges the front and the rear scan at the corrected pose) -- but as ONE launch when the scene and the measurements are small
+ * (<= 4 measurements, scene + (n-1) canvas_cols <= 32 768 points, kernel timing off).  meas_index NULL: cloud 0 of every set;
+ * measurement_in_scene: [n][3]; out_size NULL: asynchronous (see lsm2d_clip_scene); out_counts: [n][3] (new, merged, replaced) or NULL. */
+int lsm2d_merge_scenes(lsm2d_context* ctx, const lsm2d_projector* projector, lsm2d_cloudset* scene, int32_t n_measurements,
+                       const lsm2d_cloudset* const* measurements, const int32_t* meas_index, const float* measurement_in_scene,
+                       float merge_threshold, int32_t* out_size, int32_t* out_counts);
 
 /* ---- plugin interface #1: CorrespondenceFinder_::compute ---------------------------------------
  * Replaces compute() of the three finders (registration/correspondence_finder_projective_2d.cpp:18-77,

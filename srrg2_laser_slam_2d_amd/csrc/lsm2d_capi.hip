@@ -183,6 +183,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_clip_small, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_merge_small, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_merge_multi, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_split_project<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_split_project<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipGetLastError();
@@ -971,6 +972,70 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   return LSM2D_SUCCESS;
 }
 
+
+// several measurements into one scene, in order: ONE launch when everything is small (the live tracker's two scans), else the
+// calls one by one -- the same result either way
+extern "C" int lsm2d_merge_scenes(lsm2d_context* ctx, const lsm2d_projector* pr, lsm2d_cloudset* scene, int32_t n_measurements,
+                                  const lsm2d_cloudset* const* meas, const int32_t* meas_index, const float* measurement_in_scene,
+                                  float merge_threshold, int32_t* out_size, int32_t* out_counts) {
+  if (!ctx || !pr || !scene || !meas || !measurement_in_scene || n_measurements < 1 || scene->n_clouds != 1 || (!out_size && out_counts))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "merge_scenes: bad argument");
+  for (int k = 0; k < n_measurements; ++k)
+    if (!valid_cloud_index(meas[k], meas_index ? meas_index[k] : 0) || meas[k] == scene) return fail(ctx, LSM2D_BAD_ARGUMENT, "merge_scenes: bad measurement");
+  ProjK P;
+  if (!make_projk(*pr, &P)) return fail(ctx, LSM2D_BAD_ARGUMENT, "merge_scenes: bad projector");
+  const int64_t cap = scene->capacity > 0 ? scene->capacity : scene->padded_total - 2;
+  const int n = n_measurements;
+  bool together = n >= 2 && n <= kMergeMulti && (int) (sizeof(u64) * 2 * (size_t) P.cols) <= ctx->max_dyn_lds && !ctx->kernel_timing;
+  if (together && scene->count_pending && (int64_t) scene->h_count[0] + (int64_t) n * P.cols > cap) { const int rc0 = resolve_count(scene); if (rc0) return rc0; }
+  together = together && (int64_t) scene->h_count[0] + (int64_t) n * P.cols <= cap && (int64_t) scene->h_count[0] + (int64_t) (n - 1) * P.cols <= 32768;
+  for (int k = 0; k < n && together; ++k) together = meas[k]->h_count[meas_index ? meas_index[k] : 0] <= 32768;
+  if (!together) {                            // one by one (large scenes, one measurement, timed launches)
+    for (int k = 0; k < n; ++k) {
+      int32_t size = 0;
+      const int rc = lsm2d_merge_scene(ctx, pr, scene, meas[k], meas_index ? meas_index[k] : 0, measurement_in_scene + 3 * k, merge_threshold,
+                                       out_size ? &size : nullptr, out_counts ? out_counts + 3 * k : nullptr);
+      if (rc) return rc;
+      if (out_size) *out_size = size;
+    }
+    return LSM2D_SUCCESS;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  cloudset_drop_grids(scene);
+  { const int rc0 = flush_pending(scene); if (rc0) return rc0; }
+  for (int k = 0; k < n; ++k) { const int rc0 = flush_pending(meas[k]); if (rc0) return rc0; }
+  const size_t cols = (size_t) P.cols, o_out = 0, bytes = 16 * (size_t) n + 64;
+  int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+  rc = ensure_stage(ctx, bytes); if (rc) return rc;
+  char* dvo = (char*) ctx->d_scratch;         // synchronous form: the counters go straight to the pinned staging buffer, the last size last
+  if (out_size) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; *(int32_t*) ((char*) ctx->h_stage + o_out + 16 * (size_t) (n - 1)) = kStatusNotWritten; }
+  MergeMultiArgs MM; MM.n = n;
+  for (int k = 0; k < n; ++k) {
+    const lsm2d_cloudset* ms = meas[k]; const int mi = meas_index ? meas_index[k] : 0;
+    const float* mis = measurement_in_scene + 3 * k;
+    float cam_inv[3]; inverse_host(mis, cam_inv);
+    MergeSmallArgs& MS = MM.a[k];
+    MS.m.scanvas = nullptr; MS.m.mcanvas = nullptr; MS.m.cols = P.cols; MS.m.sxy = scene->d_xy; MS.m.snrm = scene->d_nrm; MS.m.n_scene = scene->h_count[0];
+    MS.m.mxy = ms->d_xy + ms->h_start[mi]; MS.m.mnrm = ms->d_nrm + ms->h_start[mi];
+    MS.m.far_limit = 0.9f * pr->range_max; MS.m.merge_threshold = merge_threshold;
+    MS.m.out = (int32_t*) (dvo + o_out + 16 * (size_t) k); MS.m.count_dev = scene->d_count; MS.m.host_polls = out_size != nullptr && k == n - 1;
+    MS.proj = P; MS.Tinv = make_iso(cam_inv); MS.M = make_iso(mis); MS.n_meas = ms->h_count[mi];
+    MS.n_scene_dev = scene->count_pending ? scene->d_count : nullptr; MS.n_meas_dev = ms->count_pending ? ms->d_count + mi : nullptr;
+  }
+  for (int k = n; k < kMergeMulti; ++k) MM.a[k] = MM.a[0];
+  hipLaunchKernelGGL(k_merge_multi, dim3(1), dim3(kFindBlock), sizeof(u64) * 2 * cols, ctx->stream, MM);
+  HIPCHK(ctx, hipGetLastError());
+  ctx->have_timing = false;
+  if (!out_size) {                            // every merge appends at most one point per column
+    scene->h_count[0] = scene->h_count[0] + n * P.cols; scene->total = scene->h_count[0]; scene->count_pending = true;
+    return LSM2D_SUCCESS;
+  }
+  HIPCHK(ctx, wait_for_statuses(ctx, (const int32_t*) ((char*) ctx->h_stage + o_out + 16 * (size_t) (n - 1)), 1));
+  const int32_t* h = (const int32_t*) ((char*) ctx->h_stage + o_out);
+  scene->h_count[0] = h[4 * (n - 1)]; scene->total = scene->h_count[0]; scene->count_pending = false; *out_size = scene->h_count[0];
+  if (out_counts) for (int k = 0; k < n; ++k) { out_counts[3 * k] = h[4 * k + 1]; out_counts[3 * k + 1] = h[4 * k + 2]; out_counts[3 * k + 2] = h[4 * k + 3]; }
+  return LSM2D_SUCCESS;
+}
 
 // ---- a3 ------------------------------------------------------------------------------------------------
 extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* cloud, int32_t ci,

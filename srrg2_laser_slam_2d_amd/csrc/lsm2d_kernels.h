@@ -1315,6 +1315,40 @@ __global__ __launch_bounds__(kFindBlock) void k_merge_small(const MergeSmallArgs
   merge_apply_body(m, scan, mcan, &A.M, s_wave_tot, s_cnt, tid);
 }
 
+// several measurements merged into the scene one after the other by ONE launch (lsm2d_merge_scenes: the live tracker's front and
+// rear scan): the same passes as k_merge_small per measurement, the scene's new size carried from one to the next in the workgroup
+static constexpr int kMergeMulti = 4;
+struct MergeMultiArgs { MergeSmallArgs a[kMergeMulti]; int32_t n; };
+__global__ __launch_bounds__(kFindBlock) void k_merge_multi(const MergeMultiArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64* scan = reinterpret_cast<u64*>(smem);
+  u64* mcan = scan + A.a[0].proj.cols;                             // one projector for all of them
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_cnt[4];
+  const int tid = threadIdx.x;
+  int n_scene = 0;
+  for (int k = 0; k < A.n; ++k) {
+    const MergeSmallArgs& S = A.a[k];
+    for (int i = tid; i < S.proj.cols; i += kFindBlock) { scan[i] = kEmptyCell; mcan[i] = kEmptyCell; }
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+    MergeArgs m = S.m;
+    if (k == 0) { if (S.n_scene_dev) m.n_scene = *S.n_scene_dev; } else m.n_scene = n_scene;
+    const int n_meas = S.n_meas_dev ? *S.n_meas_dev : S.n_meas;
+    project_cloud(m.sxy, m.n_scene, S.Tinv, S.proj, scan, tid, kFindBlock);
+    for (int i = tid; i < n_meas; i += kFindBlock) {
+      const float2 p = m.mxy[i];
+      float x, y; xf_point(S.M, p.x, p.y, x, y);
+      project_point(S.Tinv, S.proj, x, y, i, mcan);
+    }
+    __syncthreads();
+    merge_apply_body(m, scan, mcan, &S.M, s_wave_tot, s_cnt, tid);
+    __syncthreads();
+    n_scene = m.n_scene + s_cnt[0];          // what the next measurement is merged into (the body appended s_cnt[0] points)
+    __syncthreads();
+  }
+}
+
 // split a single device cloud back into AoS (download)
 __global__ void k_pack_aos(const float2* __restrict__ xy, const float2* __restrict__ nrm, int n, float4* __restrict__ out) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

@@ -223,6 +223,17 @@ class MergerProjective2D {
           "lsm2d_merge_scene", _ctx.get());
     return size;
   }
+  // several device-resident measurements, each at its own pose, in order: one call (one launch when everything is small)
+  int computeAll(const std::vector<const ReservedCloud*>& measurements, const std::vector<Vector3f>& poses) {
+    if (!param_projector) throw std::runtime_error("MergerProjective2D::compute| Missing Projector");
+    if (!_scene || measurements.empty() || measurements.size() != poses.size()) throw std::runtime_error("MergerProjective2D::compute| missing scene or measurement");
+    std::vector<const lsm2d_cloudset*> sets; std::vector<float> p;
+    for (size_t k = 0; k < measurements.size(); ++k) { sets.push_back(measurements[k]->get()); p.insert(p.end(), poses[k].begin(), poses[k].end()); }
+    const lsm2d_projector pr = param_projector->abi(); int32_t size = -1;
+    check(lsm2d_merge_scenes(_ctx.get(), &pr, _scene->get(), (int32_t) sets.size(), sets.data(), nullptr, p.data(), param_merge_threshold,
+                             asynchronous ? nullptr : &size, nullptr), "lsm2d_merge_scenes", _ctx.get());
+    return size;
+  }
   bool asynchronous = false;
   std::array<int32_t, 3> counts{{0, 0, 0}};                                // new, merged, replaced
  private:

@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
   }
   lsm2d_context* ctx = nullptr;
   CK(lsm2d_create(0, nullptr, &ctx));
+  const bool single_merges = getenv("LSM2D_TSB_SINGLE_MERGES") != nullptr;      // one lsm2d_merge_scene call per scan instead of one lsm2d_merge_scenes
   const bool timing = getenv("LSM2D_TSB_TIMING") != nullptr;        // kernel events cost ~30 us per step: off unless asked for
   if (timing) CK(lsm2d_set_option(ctx, "kernel_timing", 1));
   lsm2d_cloudset *local_map, *clipped, *m0, *m1;
@@ -83,11 +84,13 @@ int main(int argc, char** argv) {
     if (k >= 0 && timing) { lsm2d_last_kernel_ms(ctx, &ms_kernel); kernel_sum += ms_kernel; }
     const double xd[3] = {x[0], x[1], x[2]}; double xi[3]; inverse(xd, xi); compose(guess, xi, est);
     if ((k + 20) % reset == 0) memcpy(est_fresh, est, sizeof est);      // the step right after a map reset: comparable with the oracle
+    float mf[6];                                 // both scans at the corrected pose: one call (one launch: lsm2d_merge_scenes)
     for (int i = 0; i < 2; ++i) {
       const double Sd[3] = {(i ? S1 : S0)[0], (i ? S1 : S0)[1], (i ? S1 : S0)[2]}; double mis[3]; compose(est, Sd, mis);
-      const float mf[3] = {(float) mis[0], (float) mis[1], (float) mis[2]};
-      CK(lsm2d_merge_scene(ctx, &pr, local_map, i ? m1 : m0, 0, mf, 0.2f, async ? nullptr : &n_map, nullptr));
+      mf[3 * i] = (float) mis[0]; mf[3 * i + 1] = (float) mis[1]; mf[3 * i + 2] = (float) mis[2];
     }
+    if (single_merges) { for (int i = 0; i < 2; ++i) CK(lsm2d_merge_scene(ctx, &pr, local_map, i ? m1 : m0, 0, mf + 3 * i, 0.2f, async ? nullptr : &n_map, nullptr)); }
+    else { const lsm2d_cloudset* ms[2] = {m0, m1}; CK(lsm2d_merge_scenes(ctx, &pr, local_map, 2, ms, nullptr, mf, 0.2f, async ? nullptr : &n_map, nullptr)); }
     const auto t1 = std::chrono::steady_clock::now();
     if (k >= 0) { total += t1 - t0; ph[3] += t1 - ta; }
   }

@@ -547,6 +547,47 @@ def test_merger_bit_exact_and_grows_in_place(ctx, po):
         merger.compute()
 
 
+def test_merging_several_measurements_in_one_call(ctx, po):
+    """lsm2d_merge_scenes: n measurements, each at its own pose, merged in order by ONE launch -- bit for bit what n lsm2d_merge_scene
+    calls (and the oracle) give, synchronous and asynchronous, with sizes the device alone knows, and falling back to single calls for
+    large scenes."""
+    world = synth.make_world(5)
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
+    opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    robots = synth.sample_poses(world, 3, seed=9)
+    scans = [synth.make_scans(world, robots[i:i + 1], n_beams=721, noise_sigma=0.01, seed=4 + i)[0] for i in range(3)]
+    poses = [np.float32(r) for r in robots]
+    for n_map in (0, 1500, 40000):                                   # empty scene, tracker-sized, large (multi-launch path: one by one)
+        base = synth.make_map(world, n_map, noise_sigma=0.01, seed=1) if n_map else np.zeros((0, 4), np.float32)
+        want = base; want_counts = []
+        for sc, p in zip(scans, poses):
+            want, c = po.merge_scene(opr, want, sc, p, 0.2); want_counts.append(tuple(int(v) for v in c))
+        for asynchronous in (False, True):
+            for quiet in (False, True):                              # with timing events every merge is a launch of its own
+                cx = api.Context(0, kernel_timing=False) if quiet else ctx
+                try:
+                    scene = api.CloudSet.reserved(cx, 60000); scene.upload(base)
+                    mg = api.MergerProjective2D(cx, proj, 0.2, asynchronous=asynchronous); mg.setScene(scene)
+                    sets = [api.CloudSet.reserved(cx, 1024) for _ in scans]
+                    for st, sc in zip(sets, scans):
+                        st.upload(sc)                                # left to the merge to unpack
+                    size = mg.compute_all(sets, poses)
+                    if not asynchronous:
+                        assert size == len(want) and [tuple(c) for c in mg.counts] == want_counts
+                    assert scene.n_points == len(want) and np.array_equal(scene.download(), want), (n_map, asynchronous, quiet)
+                    # a second round on sizes the device alone knows (asynchronous) gives what the oracle gives from `want`
+                    size2 = mg.compute_all(sets[:2], [poses[1], poses[0]])
+                    want2 = want
+                    for sc, p in ((scans[0], poses[1]), (scans[1], poses[0])):
+                        want2, _ = po.merge_scene(opr, want2, sc, p, 0.2)
+                    assert np.array_equal(scene.download(), want2) and (asynchronous or size2 == len(want2))
+                finally:
+                    if quiet:
+                        cx.close()
+    with pytest.raises(Exception):
+        api.MergerProjective2D(ctx, proj, 0.2).compute_all([], [])
+
+
 def test_tracker_step_clip_align_merge_device_resident(ctx, po):
     """One tracker step as in apps/visual_test_tracker_2d.cpp:167-183 (clip -> align -> merge) with the local map kept
     on the device, against the same three steps of the oracle; MULTI-like wiring: two laser slices with extrinsics."""
