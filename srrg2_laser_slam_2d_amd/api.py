@@ -649,7 +649,7 @@ class MergerProjective2D:
         return size.value
 
 
-    def compute_all(self, measurements: Sequence, poses) -> int:
+    def compute_all(self, measurements: Sequence, poses, indices: Optional[Sequence[int]] = None) -> int:
         """Merges several measurements, each at its own pose in the scene, in the given order -- what one setMeasurement /
         setMeasurementInScene / compute() round per measurement does, as ONE call (lsm2d_merge_scenes: one launch when the scene and
         the measurements are small).  Returns the scene's new size (-1 when asynchronous); ``counts`` then holds one triple per measurement."""
@@ -661,15 +661,16 @@ class MergerProjective2D:
         n = len(sets)
         handles = (C.c_void_p * n)(*[s_.handle for s_ in sets])
         p = np.ascontiguousarray(poses, np.float32).reshape(n, 3)
+        idx = None if indices is None else (C.c_int32 * n)(*[int(i) for i in indices])      # which cloud of each (multi-cloud) set
         pr = self.param_projector.struct()
         if self.asynchronous:
-            check(self._ctx._lib.lsm2d_merge_scenes(self._ctx.handle, C.byref(pr), self._scene.handle, n, handles, None, p.ctypes.data_as(C.c_void_p),
+            check(self._ctx._lib.lsm2d_merge_scenes(self._ctx.handle, C.byref(pr), self._scene.handle, n, handles, idx, p.ctypes.data_as(C.c_void_p),
                                                     float(self.param_merge_threshold), None, None), "lsm2d_merge_scenes", self._ctx.handle)
             self._scene._set_pending()
             self.counts = (0, 0, 0)
             return -1
         size = C.c_int32(0); counts = (C.c_int32 * (3 * n))()
-        check(self._ctx._lib.lsm2d_merge_scenes(self._ctx.handle, C.byref(pr), self._scene.handle, n, handles, None, p.ctypes.data_as(C.c_void_p),
+        check(self._ctx._lib.lsm2d_merge_scenes(self._ctx.handle, C.byref(pr), self._scene.handle, n, handles, idx, p.ctypes.data_as(C.c_void_p),
                                                 float(self.param_merge_threshold), C.byref(size), counts), "lsm2d_merge_scenes", self._ctx.handle)
         self._scene._set_count(size.value)
         self.counts = [tuple(counts[3 * k:3 * k + 3]) for k in range(n)]

@@ -584,6 +584,19 @@ def test_merging_several_measurements_in_one_call(ctx, po):
                 finally:
                     if quiet:
                         cx.close()
+    # clouds picked out of ONE multi-cloud set by index (a batch of scans as lsm2d_preprocess_scans returns it), in another order
+    pts = np.concatenate(scans); offs = np.cumsum([0] + [len(s) for s in scans]).astype(np.int32)
+    batch = api.CloudSet(ctx, pts, offs)
+    base = synth.make_map(world, 1500, noise_sigma=0.01, seed=1)
+    scene = api.CloudSet.reserved(ctx, 60000); scene.upload(base)
+    mg = api.MergerProjective2D(ctx, proj, 0.2); mg.setScene(scene)
+    size = mg.compute_all([batch, batch, batch], [poses[2], poses[0], poses[1]], indices=[2, 0, 1])
+    want = base
+    for i in (2, 0, 1):
+        want, _ = po.merge_scene(opr, want, scans[i], poses[i], 0.2)
+    assert size == len(want) and np.array_equal(scene.download(), want)
+    with pytest.raises(Exception):
+        mg.compute_all([batch], [poses[0]], indices=[3])
     with pytest.raises(Exception):
         api.MergerProjective2D(ctx, proj, 0.2).compute_all([], [])
 
