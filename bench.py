@@ -10,6 +10,14 @@ no data-path collective.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+The roofline block: the map (0.8 MB of coordinates at 1e5 points) is served from every XCD's L2, so
+the bound that binds is VALU ISSUE, not HBM.  roofline.achieved / peak are wave64 VALU issue slots per second:
+  achieved = (SQ_INSTS_VALU + transcendentals, which take two slots) per launch / launch time (HIP events, this run)
+  peak     = 1024 SIMDs x the clock the chip held INSIDE this run's launches (s_memtime / s_memrealtime stamps) / 2 cycles
+SQ_INSTS_VALU and the HBM traffic come from the rocprofv3 --pmc passes recorded in profiles/counters.json; they are only
+reported when the sha256 of the kernel sources they were taken on matches the library that ran (else null + a warning).
+The SURVEY 8(d) algorithmic-bytes figure is kept as hbm.effective_l2_served_GBs next to the real DRAM rate.
 """
 from __future__ import annotations
 
@@ -27,6 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+N_SIMD = 256 * 4             # same guide: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles,
+VALU_CYCLES = 2.0            # v_rcp / v_rsq (the stream's two transcendentals per point) over 4
 
 
 def algorithmic_bytes_per_alignment(role: str, finder: str, n_map: int, n_scan_mean: float, bins: int, iterations: int) -> float:
@@ -44,11 +54,52 @@ def algorithmic_bytes_per_alignment(role: str, finder: str, n_map: int, n_scan_m
     raise SystemExit("unsupported role/finder combination")
 
 
+def host_cpu() -> dict:
+    """Model string and PHYSICAL core count of the host (BASELINE.md section 3 asks for both next to the CPU number)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip(); v = v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return {"model": model, "physical_cores": len(cores) or None, "threads_allowed": len(os.sched_getaffinity(0))}
+
+
+def load_counters(cfg_key: str):
+    """profiles/counters.json (written by tools/write_counters.py from the rocprofv3 --pmc passes) if it was taken on the
+    kernels that are running now, else None."""
+    from srrg2_laser_slam_2d_amd import build as hip_build
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        cj = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "profiles/counters.json missing"
+    if cj.get("csrc_sha256") != hip_build.source_hash():
+        return None, "profiles/counters.json was taken on other kernel sources (sha256 mismatch): PMC-derived fields are null"
+    ent = cj.get("configs", {}).get(cfg_key)
+    if not ent:
+        return None, "profiles/counters.json has no entry for this workload (%s)" % cfg_key
+    ent = dict(ent); ent["source"] = cj.get("source")
+    return ent, None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: >= 0.5 s of timed region at ~2 ms per step)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scans", type=int, default=1000, help="alignments per GPU per step")
     ap.add_argument("--map-points", type=int, default=100000)
     ap.add_argument("--iterations", type=int, default=20)
@@ -59,6 +110,7 @@ def main() -> None:
     ap.add_argument("--role", choices=["A", "B"], default="A", help="A: fixed=scan, moving=map (reference tracker wiring); B: fixed=map, moving=scan")
     ap.add_argument("--finder", choices=["projective", "nn"], default="projective")
     ap.add_argument("--max-distance", type=float, default=0.5, help="NN finder gate [m]")
+    ap.add_argument("--cauchy", type=float, default=0.0, help="Cauchy chi_threshold (0 = no robustifier); configs[3] uses 0.05 (MULTI.json:957-962)")
     ap.add_argument("--total-candidates", type=int, default=0,
                     help="BASELINE configs[3]: a fixed sweep of this many candidate alignments sharded over the ranks (strong scaling); "
                          "overrides --scans with this rank's share and gathers the poses on every rank at the end")
@@ -79,6 +131,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ranks_seen = dist.get_world_size() if use_dist else 1
 
     from srrg2_laser_slam_2d_amd import api, distributed, synth
 
@@ -116,7 +169,8 @@ def main() -> None:
     else:
         finder = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=args.max_distance, normal_cos=0.8)
     aligner = api.MultiAligner2D(ctx, max_iterations=args.iterations, min_num_inliers=10)
-    aligner.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10))
+    robust = api.RobustifierCauchy(args.cauchy) if args.cauchy > 0 else None
+    aligner.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10, robustifier=robust))
     if args.role == "A":
         x0, x_true = wl.x0, wl.x_true
         idx = None if scan_index is None else scan_index[None, :]
@@ -137,21 +191,24 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kernel_ms = []
+    kernel_ms = []; clock_mhz = []; wg_ms = []
     for _ in range(args.steps):
         res = step()
         kernel_ms.append(res.kernel_ms)          # HIP events around the k_align launch, on the launch stream
+        clock_mhz.append(res.kernel_clock_mhz)   # s_memtime / s_memrealtime stamps inside the same launch
+        wg_ms.append(res.workgroup_lifetime_ms)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    if strong and use_dist:          # the sweep's consumer wants every candidate's pose: one all_gather of 12 B per candidate
-        counts = [distributed.shard_range(args.total_candidates, r, world) for r in range(world)]
-        pad = max(h - l for l, h in counts)
-        mine = np.zeros((pad, 3), np.float32); mine[: len(res.pose)] = res.pose
-        allp = distributed.gather_results(mine)
-        assert allp.shape == (pad * world, 3)
     elapsed = time.perf_counter() - t0
+    gathered = None
+    if strong and use_dist:          # the sweep's consumer wants every candidate's pose: one all_gather of 12 B per candidate (not timed:
+        counts = [distributed.shard_range(args.total_candidates, r, world) for r in range(world)]      # K steps are K sweeps, the gather is per sweep
+        pad = max(h - l for l, h in counts)                                                              # and costs microseconds)
+        mine = np.zeros((pad, 3), np.float32); mine[: len(res.pose)] = res.pose
+        gathered = distributed.gather_results(mine)
+        assert gathered.shape == (pad * world, 3)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -166,50 +223,96 @@ def main() -> None:
     if use_dist:
         f = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(f, op=dist.ReduceOp.MIN); ok = bool(f.item())
 
+    # cross-rank check: every rank's first 16 candidates (scans, initial guesses) and the poses it got for them are gathered, and rank 0
+    # aligns each rank's 16 alone on its own GPU: the poses must agree BIT FOR BIT -- sharding changes where an alignment runs, never
+    # its result
+    cross = None
+    if use_dist:
+        ncheck = min(16, args.scans)
+        pts = np.zeros((16, args.beams, 4), np.float32); cnt = np.zeros((16, 1), np.float32); head = np.zeros((16, 6), np.float32)
+        for i in range(ncheck):
+            si = int(scan_index[i]) if scan_index is not None else i
+            sc = wl.scan_points[wl.scan_offsets[si]:wl.scan_offsets[si + 1]]
+            pts[i, : len(sc)] = sc; cnt[i, 0] = len(sc)
+        head[:ncheck, :3] = res.pose[:ncheck]; head[:ncheck, 3:] = x0[:ncheck]
+        all_pts = distributed.gather_results(pts.reshape(16 * args.beams, 4)).reshape(world, 16, args.beams, 4)
+        all_cnt = distributed.gather_results(cnt).reshape(world, 16).astype(np.int64)
+        all_head = distributed.gather_results(head).reshape(world, 16, 6)
+        if rank == 0:
+            same = 0
+            for r in range(world):
+                nr = int((all_cnt[r] > 0).sum())
+                clouds = [all_pts[r, i, : all_cnt[r, i]] for i in range(nr)]
+                offs_r = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+                set_r = api.CloudSet(ctx, np.concatenate(clouds, 0), offs_r)
+                x0_r = np.ascontiguousarray(all_head[r, :nr, 3:])
+                rr = (aligner.compute_batch([set_r], [map_set], x0_r) if args.role == "A" else aligner.compute_batch([map_set], [set_r], x0_r))
+                same += int(np.array_equal(rr.pose, all_head[r, :nr, :3]))
+                set_r.close()
+            cross = "%d of %d ranks: first %d poses bit-identical to rank 0 aligning the same candidates alone" % (same, world, ncheck)
+            ok = ok and same == world
+
     if rank == 0:
         n_total = (args.total_candidates if strong else args.scans * world) * args.steps
-        bytes_per_alignment = algorithmic_bytes_per_alignment(args.role, args.finder, args.map_points,
-                                                              float(np.diff(wl.scan_offsets).mean()), args.beams, args.iterations)
+        n_scan_mean = float(np.diff(wl.scan_offsets).mean())
+        bytes_per_alignment = algorithmic_bytes_per_alignment(args.role, args.finder, args.map_points, n_scan_mean, args.beams, args.iterations)
         k_ms = float(np.mean(kernel_ms))
-        achieved = bytes_per_alignment * args.scans / (k_ms * 1e-3) / 1e9
-        traffic = None; valu = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written from the rocprofv3 --pmc passes, see profiles/README.md
-        default_cfg = (args.role, args.finder, args.scans, args.map_points, args.iterations, args.beams) == ("A", "projective", 1000, 100000, 20, 1081)
-        if os.path.exists(tpath) and default_cfg:
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("k_align_hbm_bytes_per_launch")
-                vi = tj.get("k_align_valu_insts_per_launch")      # SQ_INSTS_VALU of the same launch: the limiter that matters here
-                if vi:
-                    visits = args.scans * args.iterations * (args.map_points + float(np.diff(wl.scan_offsets).mean())) / 64.0
-                    valu = {"insts_per_launch": vi, "insts_per_point_visit": vi / visits, "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
-            except Exception:
-                traffic = None
+        clk = float(np.median([c for c in clock_mhz if c > 0])) if any(c > 0 for c in clock_mhz) else None
+        default_cfg = (args.role, args.finder, args.scans, args.map_points, args.iterations, args.beams, args.cauchy, n_unique) == \
+                      ("A", "projective", 1000, 100000, 20, 1081, 0.0, 1000)
+        cfg_key = "role%s/%s/scans%d/map%d/it%d/beams%d" % (args.role, args.finder, args.scans, args.map_points, args.iterations, args.beams)
+        counters, warn = load_counters(cfg_key)
+        effective = bytes_per_alignment * args.scans / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave64-VALU issue slots/s", "frac": None, "traffic": None,
+                "kernel": "k_align", "kernel_ms": k_ms, "clock_mhz_in_kernel": clk, "workgroup_lifetime_ms": float(np.median(wg_ms)) if wg_ms else None,
+                "hbm": {"effective_l2_served_GBs": effective, "effective_over_hbm_peak": effective / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": bytes_per_alignment * args.scans, "hbm_real_GBs": None, "hbm_real_frac": None,
+                        "peak_GBs": HBM_PEAK_GBS},
+                "note": "the map is L2-resident (TCC hit > 99 %), so HBM does not bind: frac = VALU issue slots used / slots the 1024 SIMDs had at the "
+                        "clock measured inside the launch; hbm.* keeps the SURVEY 8(d) algorithmic figure and the counter-measured DRAM rate"}
+        if clk:
+            roof["peak"] = N_SIMD * clk * 1e6 / VALU_CYCLES / 1e9
+        if counters and clk:
+            # transcendentals (one v_rcp_f32 + one v_rsq_f32 per point slot of the stream) hold the issue port for 4 cycles, i.e. one slot more
+            # than SQ_INSTS_VALU counts for them
+            slots = counters["valu_insts_per_launch"] + counters.get("trans_insts_per_launch", 0.0)
+            roof["achieved"] = slots / (k_ms * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["valu_insts_per_launch"] = counters["valu_insts_per_launch"]
+            roof["trans_insts_per_launch"] = counters.get("trans_insts_per_launch")
+            roof["traffic"] = counters.get("hbm_bytes_per_launch")
+            if roof["traffic"]:
+                roof["hbm"]["hbm_real_GBs"] = roof["traffic"] / (k_ms * 1e-3) / 1e9
+                roof["hbm"]["hbm_real_frac"] = roof["hbm"]["hbm_real_GBs"] / HBM_PEAK_GBS
+            roof["counters_source"] = counters.get("source")
+        if warn:
+            roof["warning"] = warn
+            print("bench.py: " + warn, file=sys.stderr)
         out = {
             "metric": "scan-to-map alignments/sec (1081-beam vs 100k-pt map, 20 GN iters)",
-            "value": n_total / elapsed, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s%d scans/GPU x %d-beam vs one %d-pt map, %d GN iters, role %s (%s), %s finder"
+            "value": n_total / elapsed, "unit": "alignments/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s%d scans/GPU x %d-beam vs one %d-pt map, %d GN iters, role %s (%s), %s finder%s"
                                    % ("configs[1]: " if default_cfg else "", args.scans, args.beams, args.map_points, args.iterations, args.role,
-                                      "fixed=scan, moving=map" if args.role == "A" else "fixed=map, moving=scan", args.finder),
+                                      "fixed=scan, moving=map" if args.role == "A" else "fixed=map, moving=scan", args.finder,
+                                      ", Cauchy tau %g" % args.cauchy if args.cauchy > 0 else ""),
                        "unique_scans": n_unique,
                        "alignments_per_gpu": args.scans, "map_points": args.map_points, "beams": args.beams,
                        "iterations": args.iterations, "parallelism": "alignments sharded, map replicated (RCCL broadcast)"},
             "parity_ok": ok, "max_pose_err_m": float(err[:, :2].max()), "max_pose_err_rad": float(err[:, 2].max()),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "valu": valu, "kernel": "k_align", "kernel_ms": k_ms,
-                         "note": "achieved = SURVEY.md 8(d) algorithmic bytes / launch time; the map (<= 8 MB of xy) is L2 / Infinity-Cache "
-                                 "resident, so achieved can exceed the HBM peak: the measured limiter is VALU issue (DESIGN.md section 5)",
-                         "algorithmic_bytes_per_launch": bytes_per_alignment * args.scans},
+            "roofline": roof,
         }
+        if cross:
+            out["cross_rank_check"] = cross
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle as po       # the checker, timed as the CPU baseline ("port")
             ns = min(args.cpu_sample, n_unique)
             offs = wl.scan_offsets[: ns + 1]
             map_host = map_dev.cpu().numpy()
             osp = po.slice_params(finder=po.FINDER_PROJECTIVE if args.finder == "projective" else po.FINDER_NN,
-                                  canvas_cols=args.beams, max_distance=args.max_distance)
+                                  canvas_cols=args.beams, max_distance=args.max_distance,
+                                  **({"robustifier": po.ROBUST_CAUCHY, "chi_threshold": args.cauchy} if args.cauchy > 0 else {}))
             po.lib()                                   # load (or build) the checker before the clock starts
             t1 = time.perf_counter()
             if args.role == "A":
@@ -220,24 +323,22 @@ def main() -> None:
                     r = po.align(po.aligner_params(args.iterations), [osp], [map_host], [wl.scan_points[offs[i]:offs[i + 1]]], x0[i])
                     xo[i] = r["pose"]
             cpu_s = time.perf_counter() - t1
+            cpu = host_cpu()
             all_cores = None
             if args.role == "A" and ns >= 64:       # BASELINE.md section 3, second row: one alignment per host thread
-                nt = max(1, len(os.sched_getaffinity(0)))
+                nt = max(1, cpu["threads_allowed"])
                 t2 = time.perf_counter()
                 po.align_batch(po.aligner_params(args.iterations), osp, wl.scan_points[: offs[-1]], offs, map_host, x0[:ns], n_threads=nt)
-                all_cores = {"value": ns / (time.perf_counter() - t2), "cores": nt}
+                all_cores = {"value": ns / (time.perf_counter() - t2), "threads": nt, "physical_cores": cpu["physical_cores"]}
             d = np.abs(res.pose[:ns] - xo)
             # the same checker summing in the kernels' order must reproduce the device BIT FOR BIT (a handful of alignments)
             nbit = min(16, ns); bit_equal = 0
-            if args.role == "A":
-                for i in range(nbit):
-                    rt = po.align(po.aligner_params(args.iterations, device_order=True), [osp], [wl.scan_points[offs[i]:offs[i + 1]]], [map_host], x0[i])
-                    bit_equal += int(np.array_equal(res.pose[i], rt["pose"]) and np.array_equal(res.information[i], rt["H"]))
-            else:
-                for i in range(nbit):
-                    rt = po.align(po.aligner_params(args.iterations, device_order=True), [osp], [map_host], [wl.scan_points[offs[i]:offs[i + 1]]], x0[i])
-                    bit_equal += int(np.array_equal(res.pose[i], rt["pose"]) and np.array_equal(res.information[i], rt["H"]))
-            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "alignments/s", "cores": 1, "kind": "port",
+            for i in range(nbit):
+                sc = wl.scan_points[offs[i]:offs[i + 1]]
+                fx, mv = ([sc], [map_host]) if args.role == "A" else ([map_host], [sc])
+                rt = po.align(po.aligner_params(args.iterations, device_order=True), [osp], fx, mv, x0[i])
+                bit_equal += int(np.array_equal(res.pose[i], rt["pose"]) and np.array_equal(res.information[i], rt["H"]))
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "alignments/s", "cores": 1, "kind": "port", "cpu_model": cpu["model"],
                                    "sample": "first %d alignments of the same batch, CPU restatement of the reference algorithm (oracle/, gcc -O3 -march=native, fp32), %.1f s"
                                              % (ns, cpu_s),
                                    "max_pose_diff_gpu_vs_cpu_m": float(d[:, :2].max()), "max_pose_diff_gpu_vs_cpu_rad": float(d[:, 2].max()),

@@ -401,6 +401,8 @@ class BatchResult:
     iterations: np.ndarray    # [n]
     stats: Optional[np.ndarray]  # structured [n, max_it] or None
     kernel_ms: float
+    kernel_clock_mhz: float = 0.0      # clock the chip held inside the k_align launch (in-kernel stamps; 0 when not timed / another kernel ran)
+    workgroup_lifetime_ms: float = 0.0  # median lifetime of the stamped workgroups
 
     def status_names(self):
         return [STATUS_NAMES.get(int(s), str(int(s))) for s in self.status]
@@ -525,7 +527,10 @@ class MultiAligner2D:
                                     its.ctypes.data_as(C.c_void_p),
                                     stats.ctypes.data_as(C.c_void_p) if want_stats else None),
               "lsm2d_align_batch", ctx.handle)
-        return BatchResult(pose, H.reshape(n, 3, 3), status, its, stats, ctx.last_kernel_ms() if (n and ctx.kernel_timing) else 0.0)
+        timed = bool(n and ctx.kernel_timing)
+        return BatchResult(pose, H.reshape(n, 3, 3), status, its, stats, ctx.last_kernel_ms() if timed else 0.0,
+                           ctx.get_option("last_kernel_clock_khz") * 1e-3 if timed else 0.0,
+                           ctx.get_option("last_workgroup_lifetime_ns") * 1e-6 if timed else 0.0)
 
 
 def linearize(ctx: Context, slice_params: SliceParams, fixed, moving, correspondences, pose,

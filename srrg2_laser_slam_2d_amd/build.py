@@ -34,6 +34,19 @@ def hipcc() -> str:
     return "hipcc"
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources, the ABI header and the compiler flags: what the counters under profiles/ were taken on
+    (bench.py reports PMC-derived numbers only when this matches profiles/counters.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -46,12 +59,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     extra = os.environ.get("LSM2D_EXTRA_HIPCC_FLAGS", "").split()      # tuning experiments only
-    cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH, *SOURCES]
+    # compile next to the target and rename: several ranks of one job may get here together (torchrun), and none of them must
+    # ever dlopen a half-written file
+    tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+    cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", tmp, *SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

@@ -15,6 +15,7 @@ using lsm2d::LSM2D_RUNNING;
 #include <string>
 #include <chrono>
 #include <vector>
+#include <algorithm>
 
 using namespace lsm2d;
 
@@ -39,6 +40,8 @@ struct lsm2d_context {
   bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1, 2 or 3)
+  long long last_clock_khz = 0;       // in-kernel clock of the most recent timed k_align launch (median over the stamped workgroups), 0 = none
+  long long last_wg_lifetime_ns = 0;  // median lifetime of its stamped workgroups
   std::vector<lsm2d_cloudset*> live_sets;      // lsm2d_destroy orphans what is left (a set destroyed after its context must not touch it)
 };
 
@@ -225,6 +228,8 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "kernel_timing")) { *out_value = ctx->kernel_timing ? 1 : 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { *out_value = ctx->align_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_align_path")) { *out_value = ctx->last_align_path; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "last_kernel_clock_khz")) { *out_value = ctx->last_clock_khz; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "last_workgroup_lifetime_ns")) { *out_value = ctx->last_wg_lifetime_ns; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
 
@@ -241,7 +246,7 @@ static int ensure_stage(lsm2d_context* ctx, size_t bytes) {
   if (bytes <= ctx->h_stage_bytes) return LSM2D_SUCCESS;
   if (ctx->h_stage) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipHostFree(ctx->h_stage)); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
   size_t cap = bytes + bytes / 2 + 4096;
-  HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocCoherent | hipHostMallocMapped));
   HIPCHK(ctx, hipHostGetDevicePointer(&ctx->h_stage_dev, ctx->h_stage, 0));      // looked up once: kernels read / write the buffer directly
   ctx->h_stage_bytes = cap;
   return LSM2D_SUCCESS;
@@ -404,6 +409,7 @@ static int flush_preprocessing_together(lsm2d_context* ctx, const lsm2d_cloudset
   for (int i = 0; i < n_sets; ++i) {
     const lsm2d_cloudset* cs = sets[i];
     if (!cs || !cs->prep_pending) continue;
+    if (cs->ctx != ctx) return fail(ctx, LSM2D_BAD_ARGUMENT, "cloud set from another (or a destroyed) context");
     bool seen = false; for (int k = 0; k < nt; ++k) seen = seen || todo[k] == cs;
     if (seen) continue;
     if (nt == kPrepMulti) { const int rc = flush_pending(cs); if (rc) return rc; continue; }
@@ -472,7 +478,7 @@ static int acquire_upload_stage(lsm2d_cloudset* cs, size_t need) {
   if (need > cs->h_upload_bytes) {
     if (cs->h_upload) { HIPCHK(ctx, hipHostFree(cs->h_upload)); cs->h_upload = nullptr; cs->h_upload_bytes = 0; }
     const size_t want = cs->capacity > 0 ? sizeof(float) * 4 * (size_t) cs->capacity + 16 : need;
-    HIPCHK(ctx, hipHostMalloc(&cs->h_upload, want > need ? want : need, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc(&cs->h_upload, want > need ? want : need, hipHostMallocCoherent | hipHostMallocMapped));
     HIPCHK(ctx, hipHostGetDevicePointer(&cs->h_upload_dev, cs->h_upload, 0));
     cs->h_upload_bytes = want > need ? want : need;
   }
@@ -562,6 +568,12 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
   k->rmin = fmaxf(p.range_min, 1e-15f); k->rmax = fminf(p.range_max, 1e18f); k->colsf = (float) p.canvas_cols;
   if (!(k->rmax >= k->rmin)) return false;
   k->r2lo = r2_lower_threshold(k->rmin); k->r2hi = r2_upper_threshold(k->rmax);
+  // The stream's short divide is exact for min(|x|,|y|) >= 1e-12 (div_rn_unit); below that its result is merely SOME value a' with
+  // |a'| <= A = 2.1e-12 / max(|x|,|y|), max >= 0.7 rmin.  That cannot move a column when (i) pi/2 - a' and pi - a' round back to
+  // pi/2 and pi (A below a quarter ulp of pi/2) and (ii) K00 * (+-a') + K01 rounds to K01 (K00 A below a quarter ulp of K01): then the
+  // kernels drop the guard branch in front of the divide.  True for every sane projector (cols 1081, 2 pi: K00 A ~ 2e-9 vs 1.5e-5).
+  const double A = 2.1e-12 / (0.7 * (double) k->rmin);
+  k->tiny_ok = (A < 2.5e-8 && k->K01 >= 0.25f && (double) k->K00 * A < (double) k->K01 * 1.4e-8) ? 1 : 0;
   return true;
 }
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
@@ -1205,6 +1217,9 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   const size_t o_pose = take(sizeof(float) * 3 * (size_t) n), o_H = take(sizeof(float) * 9 * (size_t) n);
   const size_t o_status = take(sizeof(int32_t) * (size_t) n), o_its = take(sizeof(int32_t) * (size_t) n);
   const size_t o_stats = out_stats ? take(sizeof(StatsDev) * (size_t) n * (size_t) (ap->max_iterations > 0 ? ap->max_iterations : 1)) : 0;
+  // in-kernel clock stamps of ~32 workgroups spread over the grid (timed k_align launches only)
+  const int clock_stride = n / 32 > 1 ? n / 32 : 1, n_clock = (n + clock_stride - 1) / clock_stride;
+  const size_t o_clock = ctx->kernel_timing ? take(sizeof(unsigned long long) * 2 * (size_t) n_clock) : 0;
   const size_t total_bytes = off, out_bytes = total_bytes - o_pose;
   int rc = ensure_scratch(ctx, total_bytes); if (rc) return rc;
   rc = ensure_stage(ctx, total_bytes); if (rc) return rc;
@@ -1231,6 +1246,9 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   if (zero_copy) ds = (char*) ctx->h_stage_dev;
 
   // ---- slices
+  for (int s = 0; s < ns; ++s)        // ownership first: nothing is launched for a set that is not this context's (or is orphaned)
+    if (!b->fixed[s] || !b->moving[s] || b->fixed[s]->ctx != ctx || b->moving[s]->ctx != ctx)
+      return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: cloud set missing or from another context");
   {   // scans whose preprocessing is still pending (lsm2d_preprocess_scan_into): one launch for all of them
     const lsm2d_cloudset* rd[2 * kMaxSlices]; int nr = 0;
     for (int s = 0; s < ns; ++s) { rd[nr++] = b->fixed[s]; rd[nr++] = b->moving[s]; }
@@ -1331,6 +1349,9 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   A.out_pose = (float*) (ds + o_pose); A.out_H = (float*) (ds + o_H); A.out_status = (int32_t*) (ds + o_status); A.out_its = (int32_t*) (ds + o_its);
   A.out_stats = out_stats ? (StatsDev*) (ds + o_stats) : nullptr;
 
+  ctx->last_clock_khz = 0; ctx->last_wg_lifetime_ns = 0;
+  const bool stamps = ctx->kernel_timing && !use_split && !use_pair;
+  if (stamps) { A.clock_out = (unsigned long long*) (ds + o_clock); A.clock_stride = clock_stride; }
   A.host_polls = zero_copy;
   if (zero_copy) {
     memset(hs + o_pose, 0, out_bytes);
@@ -1395,5 +1416,14 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   memcpy(out_status, hs + o_status, sizeof(int32_t) * (size_t) n);
   if (out_its) memcpy(out_its, hs + o_its, sizeof(int32_t) * (size_t) n);
   if (out_stats) memcpy(out_stats, hs + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) ap->max_iterations);
+  if (stamps) {     // median over the stamped workgroups: shader cycles per 10 ns tick of the constant 100 MHz counter
+    const unsigned long long* ck = (const unsigned long long*) (hs + o_clock);
+    std::vector<double> khz; std::vector<unsigned long long> life;
+    for (int i = 0; i < n_clock; ++i) if (ck[2 * i + 1] > 0) { khz.push_back((double) ck[2 * i] / (double) ck[2 * i + 1] * 1e5); life.push_back(ck[2 * i + 1] * 10ull); }
+    if (!khz.empty()) {
+      std::nth_element(khz.begin(), khz.begin() + khz.size() / 2, khz.end()); ctx->last_clock_khz = (long long) khz[khz.size() / 2];
+      std::nth_element(life.begin(), life.begin() + life.size() / 2, life.end()); ctx->last_wg_lifetime_ns = (long long) life[life.size() / 2];
+    }
+  }
   return LSM2D_SUCCESS;
 }

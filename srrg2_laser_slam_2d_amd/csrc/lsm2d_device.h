@@ -32,6 +32,7 @@ struct ProjK {
   float r2lo, r2hi;     // ... restated on r2: rmin <= sqrt_rn(r2) <= rmax  <=>  r2lo <= r2 <= r2hi (host-proved, sqrt_rn is monotone)
   float colsf;          // (float) canvas_cols
   int   cols;
+  int   tiny_ok;        // host-proved: a quotient min/max below 1e-12 / max cannot move a column, whatever tiny value it gets (make_projk)
 };
 
 // cos / sin of a pose angle as a fixed operation sequence (the CPU restatement evaluates the same sequence, operation for operation; coefficients from
@@ -174,6 +175,63 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
   }
 }
 
+// Both points of one 16-byte load in ONE straight-line block (the lane-chunked stream of k_align, where the z-buffer update is a
+// fire-and-forget atomic): the same operation sequence per point as project_point, hence the same bits, but without a branch
+// until the two updates themselves -- a point that fails a gate is carried along and masked at the end (on a map inside the
+// sensor's range nearly every point passes, so the early exits bought nothing), the two dependent chains interleave (the wait
+// states behind v_cmp -> v_cndmask, v_rcp, v_rsq are filled by the other point's instructions) and the exec-mask bookkeeping of
+// three nested branches per point is gone.  kGuardTiny: keep div_rn_unit's branch for quotients that may be subnormal; the host
+// drops it when it has proved that such a quotient cannot move a column (ProjK::tiny_ok).
+#ifndef LSM2D_STREAM_PAIR
+#define LSM2D_STREAM_PAIR 1
+#endif
+template <bool kGuardTiny>
+LSM2D_DEV float atan2_poly_stream(float y, float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const bool swap = ay > ax;
+  const float mx = swap ? ay : ax, mn = swap ? ax : ay;
+  float a;
+  if (kGuardTiny) a = div_rn_unit(mn, mx);
+  else {
+    const float r0 = __builtin_amdgcn_rcpf(mx);
+    const float e0 = __builtin_fmaf(-mx, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = mn * r1;
+    const float e1 = __builtin_fmaf(-mx, q0, mn);
+    a = __builtin_fmaf(e1, r1, q0);
+  }
+  const float s = a * a;
+  float p = 2.622197615e-03f;
+  p = __builtin_fmaf(p, s, -1.513234153e-02f);
+  p = __builtin_fmaf(p, s, 4.112152755e-02f);
+  p = __builtin_fmaf(p, s, -7.366676629e-02f);
+  p = __builtin_fmaf(p, s, 1.057391763e-01f);
+  p = __builtin_fmaf(p, s, -1.418597102e-01f);
+  p = __builtin_fmaf(p, s, 1.999039650e-01f);
+  p = __builtin_fmaf(p, s, -3.333298564e-01f);
+  float r = __builtin_fmaf(a * s, p, a);
+  if (swap) r = 1.57079637050628662f - r;
+  if (x < 0.0f) r = 3.14159274101257324f - r;
+  return __builtin_copysignf(r, y);
+}
+template <bool kGuardTiny>
+LSM2D_DEV void project_pair_stream(const Iso& T, const ProjK& P, float4 v, int idx, u64* canvas) {
+  float qx0, qy0, qx1, qy1;
+  xf_point(T, v.x, v.y, qx0, qy0);
+  xf_point(T, v.z, v.w, qx1, qy1);
+  const float r20 = __builtin_fmaf(qx0, qx0, qy0 * qy0), r21 = __builtin_fmaf(qx1, qx1, qy1 * qy1);
+  const float th0 = atan2_poly_stream<kGuardTiny>(qy0, qx0), th1 = atan2_poly_stream<kGuardTiny>(qy1, qx1);
+  const float u0 = __builtin_fmaf(P.K00, th0, P.K01), u1 = __builtin_fmaf(P.K00, th1, P.K01);
+  int col0, col1;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col0) : "v"(u0));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col1) : "v"(u1));
+  const float d0 = sqrt_rn_normal(r20), d1 = sqrt_rn_normal(r21);
+  const bool ok0 = r20 >= P.r2lo && r20 <= P.r2hi && (unsigned) col0 < (unsigned) P.cols;
+  const bool ok1 = r21 >= P.r2lo && r21 <= P.r2hi && (unsigned) col1 < (unsigned) P.cols;
+  if (ok0) atomicMin(&canvas[col0], ((u64) __float_as_uint(d0) << 32) | (u64) (uint32_t) idx);
+  if (ok1) atomicMin(&canvas[col1], ((u64) __float_as_uint(d1) << 32) | (u64) (uint32_t) (idx + 1));
+}
+
 // Stream one cloud through the z-buffer.  xy is 16-byte aligned (cloud starts are padded to an even
 // point index by the host) so every lane loads two points with one 16-byte global_load_dwordx4; the next
 // load is issued before the current pair is processed.
@@ -205,8 +263,9 @@ LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& Ti
 // neighbouring points in neighbouring lanes) is gone, and with it the reason to read a cell before updating it -- the
 // update is one fire-and-forget LDS atomic and the stream never waits on the LDS.  Padding slots hold +inf and fail the
 // range gate.
-LSM2D_DEV void project_cloud_lanes(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin,
-                                   u64* canvas, int tid, int nthreads) {
+template <bool kGuardTiny>
+LSM2D_DEV void project_cloud_lanes_t(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin,
+                                     u64* canvas, int tid, int nthreads) {
   const Iso T = Tin; ProjK P = Pin;
   asm volatile("" : "+v"(P.K01));        // keep K01 in a VGPR: fma(K00, th, K01) may read only one SGPR, the compiler would v_mov it per point
   if (T_steps <= 0) return;
@@ -228,20 +287,28 @@ LSM2D_DEV void project_cloud_lanes(const float4* __restrict__ lane_xy, int T_ste
   };
   int idx = 2 * base, t = 0;
   float4 va = load(row);
+#if LSM2D_STREAM_PAIR
+  auto pair = [&](const float4& v, int i) { project_pair_stream<kGuardTiny>(T, P, v, i, canvas); };
+#else
+  auto pair = [&](const float4& v, int i) {
+    project_point<false>(T, P, v.x, v.y, i, canvas);
+    project_point<false>(T, P, v.z, v.w, i + 1, canvas);
+  };
+#endif
   for (; t + 2 <= T_steps; t += 2) {
     const float4 vb = load(row + row_bytes);
-    project_point<false>(T, P, va.x, va.y, idx, canvas);
-    project_point<false>(T, P, va.z, va.w, idx + 1, canvas);
+    pair(va, idx);
     if (t + 2 < T_steps) row += 2 * row_bytes;            // else: a harmless re-read of the current row, never used
     va = load(row);
-    project_point<false>(T, P, vb.x, vb.y, idx + 2, canvas);
-    project_point<false>(T, P, vb.z, vb.w, idx + 3, canvas);
+    pair(vb, idx + 2);
     idx += 4;
   }
-  if (t < T_steps) {
-    project_point<false>(T, P, va.x, va.y, idx, canvas);
-    project_point<false>(T, P, va.z, va.w, idx + 1, canvas);
-  }
+  if (t < T_steps) pair(va, idx);
+}
+LSM2D_DEV void project_cloud_lanes(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P,
+                                   u64* canvas, int tid, int nthreads) {
+  if (P.tiny_ok) project_cloud_lanes_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads);
+  else project_cloud_lanes_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads);
 }
 
 // ---- factor ---------------------------------------------------------------------------------

@@ -305,6 +305,10 @@ struct AlignArgs {
   float    pose1[3];
   PriorDev prior1;
   float* out_pose; float* out_H; int32_t* out_status; int32_t* out_its; StatsDev* out_stats;
+  // kernel timing on (lsm2d_set_option "kernel_timing"): thread 0 of every clock_stride-th workgroup stamps s_memtime (shader
+  // cycles) and s_memrealtime (100 MHz) once at its start and once at its end -- [a / clock_stride][2] = {cycles, 10 ns ticks} of
+  // the workgroup's lifetime, from which the host reads the clock the chip held under THIS load (MI355X_MICROARCH.md, DVFS note 6)
+  unsigned long long* clock_out; int32_t clock_stride;
   SliceDev s[kMaxSlices];
 };
 
@@ -400,13 +404,16 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   __shared__ float s_pose[3];
   __shared__ Iso   s_iso[kMaxSlices];
   __shared__ float s_H[9], s_Hs[9], s_b[3];      // s_H: information matrix (H of the last solved iteration); s_Hs: this iteration's sum
-  __shared__ int   s_n_in, s_n_out, s_n_corr, s_active, s_done, s_status;
+  __shared__ int   s_n_in, s_n_out, s_n_corr, s_active, s_done, s_status, s_last_n_in;
   __shared__ float s_chi_in, s_chi_out;
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   const int a = blockIdx.x, tid = threadIdx.x;
   constexpr int nwaves = kAlignBlock / 64;
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
+  __shared__ unsigned long long s_clk[2];      // start stamps wait in LDS: no register is held across the kernel for them
+  const bool stamp = A.clock_out && tid == 0 && a % A.clock_stride == 0;
+  if (stamp) { s_clk[0] = __builtin_amdgcn_s_memtime(); s_clk[1] = __builtin_amdgcn_s_memrealtime(); }
   if (A.prior && tid >= 64 && tid < 64 + kPriorWords)
     ((float*) &s_prior)[tid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[tid - 64] : ((const float*) (A.prior + a))[tid - 64];
 
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   if (tid == 0) {
     if (A.inline_n1) { s_pose[0] = A.pose1[0]; s_pose[1] = A.pose1[1]; s_pose[2] = A.pose1[2]; }
     else { s_pose[0] = A.init_pose[3 * a + 0]; s_pose[1] = A.init_pose[3 * a + 1]; s_pose[2] = A.init_pose[3 * a + 2]; }
-    s_done = 0; s_status = LSM2D_RUNNING;
+    s_done = 0; s_status = LSM2D_RUNNING; s_last_n_in = 0;
     for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
     begin_iteration();
   }
@@ -474,7 +481,6 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   __syncthreads();
 
   int it = 0;
-  StatsDev last = {0, 0, 0, 0.0f, 0.0f};
   for (; it < A.max_it; ++it) {
     for (int s = 0; s < A.n_slices; ++s) {
       const SliceDev& S = A.s[s];
@@ -576,7 +582,9 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
       if (kHasNN || kHasDist) __syncthreads();
     }
     if (tid == 0) {
-      last.n_corr = s_n_corr; last.n_in = s_n_in; last.n_out = s_n_out; last.chi_in = s_chi_in; last.chi_out = s_chi_out;
+      // (thread 0's serial state lives in LDS, not in registers every thread would carry -- and spill -- across the loops)
+      StatsDev last; last.n_corr = s_n_corr; last.n_in = s_n_in; last.n_out = s_n_out; last.chi_in = s_chi_in; last.chi_out = s_chi_out;
+      s_last_n_in = s_n_in;
       if (A.out_stats) A.out_stats[(size_t) a * A.max_it + it] = last;
       if (!s_active) { s_status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
       else {
@@ -598,12 +606,16 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
   }
   if (tid == 0) {
     int st = s_status;
-    if (st == LSM2D_RUNNING) st = (A.max_it > 0 && last.n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
+    if (st == LSM2D_RUNNING) st = (A.max_it > 0 && s_last_n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
     A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
     if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = s_H[k];
     if (A.out_its) A.out_its[a] = it;
     // the status goes last, behind a system-scope release: with results written straight to pinned host memory the host polls
     // this word instead of waiting for the stream (lsm2d_align_batch), and whoever sees it sees everything above
+    if (stamp) {
+      A.clock_out[2 * (a / A.clock_stride)] = __builtin_amdgcn_s_memtime() - s_clk[0];
+      A.clock_out[2 * (a / A.clock_stride) + 1] = __builtin_amdgcn_s_memrealtime() - s_clk[1];
+    }
     if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     else A.out_status[a] = st;
   }

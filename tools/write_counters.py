@@ -1,0 +1,72 @@
+"""Turn the rocprofv3 --pmc passes of one bench.py workload into profiles/counters.json (read back by bench.py).
+
+usage (GPU box, after tools/profile_round.sh <tag>):  python tools/write_counters.py gpurun_out/<tag> [--scans 1000 --map-points 100000 ...]
+The file records the sha256 of the kernel sources the counters were taken on (srrg2_laser_slam_2d_amd.build.source_hash):
+bench.py reports PMC-derived numbers only while that hash matches the library it runs.
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KB, and on gfx950 FETCH_SIZE reads half
+of a wide coalesced stream (MI355X_MICROARCH.md, HBM section).
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from srrg2_laser_slam_2d_amd import build as hip_build  # noqa: E402
+
+
+def pmc_means(root, want):
+    acc = defaultdict(list)
+    for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+        per = defaultdict(dict)
+        for row in csv.DictReader(open(path)):
+            if want in row["Kernel_Name"]:
+                per[row["Dispatch_Id"]][row["Counter_Name"]] = float(row["Counter_Value"])
+        for d in per.values():
+            for k, v in d.items():
+                acc[k].append(v)
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("root")
+    ap.add_argument("--kernel", default="k_align")
+    ap.add_argument("--role", default="A"); ap.add_argument("--finder", default="projective")
+    ap.add_argument("--scans", type=int, default=1000); ap.add_argument("--map-points", type=int, default=100000)
+    ap.add_argument("--iterations", type=int, default=20); ap.add_argument("--beams", type=int, default=1081)
+    ap.add_argument("--tag", default="")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "counters.json"))
+    a = ap.parse_args()
+    m, cnt = pmc_means(a.root, a.kernel)
+    if "SQ_INSTS_VALU" not in m:
+        raise SystemExit("no SQ_INSTS_VALU for %s under %s" % (a.kernel, a.root))
+    key = "role%s/%s/scans%d/map%d/it%d/beams%d" % (a.role, a.finder, a.scans, a.map_points, a.iterations, a.beams)
+    ent = {"valu_insts_per_launch": m["SQ_INSTS_VALU"], "launches_averaged": cnt["SQ_INSTS_VALU"], "pmc_means": m}
+    if a.role == "A" and a.finder == "projective":
+        # one v_rcp_f32 + one v_rsq_f32 per point slot of the lane-chunked stream (padding slots included: they run the same code)
+        T = -(-(-(-a.map_points // 2)) // 512)
+        ent["trans_insts_per_launch"] = 2.0 * a.scans * a.iterations * (T * 512 * 2) / 64.0
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        ent["fetch_size_kb"] = m["FETCH_SIZE"]; ent["write_size_kb"] = m["WRITE_SIZE"]
+        ent["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
+    try:
+        cj = json.load(open(a.out))
+    except (OSError, ValueError):
+        cj = {}
+    h = hip_build.source_hash()
+    if cj.get("csrc_sha256") != h:
+        cj = {"csrc_sha256": h, "configs": {}}
+    cj["configs"][key] = ent
+    cj["source"] = ("rocprofv3 --pmc passes (each counter group in its own run, --kernel-trace only) of `python3 bench.py --steps 3 --warmup 1 "
+                    "--no-cpu-baseline`, per-launch means over the profiled k_align launches; %s" % (a.tag or a.root))
+    json.dump(cj, open(a.out, "w"), indent=1)
+    print("wrote", a.out, key, {k: ent[k] for k in ent if k != "pmc_means"})
+
+
+if __name__ == "__main__":
+    main()
