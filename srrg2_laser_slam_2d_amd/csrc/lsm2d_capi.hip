@@ -10,6 +10,7 @@ using lsm2d::LSM2D_RUNNING;
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <new>
 #include <string>
@@ -40,6 +41,7 @@ struct lsm2d_context {
   bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1, 2 or 3)
+  int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
   long long last_clock_khz = 0;       // in-kernel clock of the most recent timed k_align launch (median over the stamped workgroups), 0 = none
   long long last_wg_lifetime_ns = 0;  // median lifetime of its stamped workgroups
   std::vector<lsm2d_cloudset*> live_sets;      // lsm2d_destroy orphans what is left (a set destroyed after its context must not touch it)
@@ -218,6 +220,7 @@ extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
 
 extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return LSM2D_BAD_ARGUMENT;
+  if (!strcmp(key, "clock_stride")) { if (value < 0 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "clock_stride: out of range"); ctx->clock_stride = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kernel_timing")) { ctx->kernel_timing = value != 0; if (!ctx->kernel_timing) ctx->have_timing = false; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { if (value < 0 || value > 3) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1, 2 or 3"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
@@ -921,9 +924,13 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   const int64_t cap = scene->capacity > 0 ? scene->capacity : scene->padded_total - 2;
   // out_size == NULL: asynchronous.  Sizes only the device knows are upper bounds here; when a bound no longer settles a
   // decision (room left, single-workgroup path) it is replaced by the real number (one synchronisation)
-  if (scene->count_pending && ((int64_t) scene->h_count[0] + P.cols > cap || scene->h_count[0] > 32768)) { const int rc0 = resolve_count(scene); if (rc0) return rc0; }
-  if (meas->count_pending && meas->h_count[mi] > 32768) { const int rc0 = resolve_count(meas); if (rc0) return rc0; }
-  if ((int) (sizeof(u64) * 2 * (size_t) P.cols) > ctx->max_dyn_lds) {       // multi-launch path: it takes the sizes by value
+  if (scene->count_pending && (int64_t) scene->h_count[0] + P.cols > cap) { const int rc0 = resolve_count(scene); if (rc0) return rc0; }
+  // The single-workgroup path reads device-side sizes; the multi-launch path takes BOTH sizes by value (k_transform_cloud,
+  // project_split, k_merge_apply), so whenever the bounds do not settle for the small path -- either set above 32 768 points, or
+  // canvases beyond LDS -- every pending size is replaced by the real number first: an upper bound there would run stale slots of the
+  // reserved set through the merge.
+  const bool small_by_bounds = scene->h_count[0] <= 32768 && meas->h_count[mi] <= 32768 && (int) (sizeof(u64) * 2 * (size_t) P.cols) <= ctx->max_dyn_lds;
+  if (!small_by_bounds) {
     int rc0 = resolve_count(scene); if (rc0) return rc0;
     rc0 = resolve_count(meas); if (rc0) return rc0;
   }
@@ -1218,8 +1225,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   const size_t o_status = take(sizeof(int32_t) * (size_t) n), o_its = take(sizeof(int32_t) * (size_t) n);
   const size_t o_stats = out_stats ? take(sizeof(StatsDev) * (size_t) n * (size_t) (ap->max_iterations > 0 ? ap->max_iterations : 1)) : 0;
   // in-kernel clock stamps of ~32 workgroups spread over the grid (timed k_align launches only)
-  const int clock_stride = n / 32 > 1 ? n / 32 : 1, n_clock = (n + clock_stride - 1) / clock_stride;
-  const size_t o_clock = ctx->kernel_timing ? take(sizeof(unsigned long long) * 2 * (size_t) n_clock) : 0;
+  const int clock_stride = ctx->clock_stride > 0 ? ctx->clock_stride : (n / 32 > 1 ? n / 32 : 1), n_clock = (n + clock_stride - 1) / clock_stride;
+  const size_t o_clock = ctx->kernel_timing ? take(sizeof(unsigned long long) * 4 * (size_t) n_clock) : 0;
   const size_t total_bytes = off, out_bytes = total_bytes - o_pose;
   int rc = ensure_scratch(ctx, total_bytes); if (rc) return rc;
   rc = ensure_stage(ctx, total_bytes); if (rc) return rc;
@@ -1419,7 +1426,16 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   if (stamps) {     // median over the stamped workgroups: shader cycles per 10 ns tick of the constant 100 MHz counter
     const unsigned long long* ck = (const unsigned long long*) (hs + o_clock);
     std::vector<double> khz; std::vector<unsigned long long> life;
-    for (int i = 0; i < n_clock; ++i) if (ck[2 * i + 1] > 0) { khz.push_back((double) ck[2 * i] / (double) ck[2 * i + 1] * 1e5); life.push_back(ck[2 * i + 1] * 10ull); }
+    for (int i = 0; i < n_clock; ++i) if (ck[4 * i + 1] > 0) { khz.push_back((double) ck[4 * i] / (double) ck[4 * i + 1] * 1e5); life.push_back(ck[4 * i + 1] * 10ull); }
+    if (const char* dump = getenv("LSM2D_DUMP_STAMPS")) {      // diagnostics: one line per stamped workgroup (tools/occupancy_probe.py reads them)
+      if (FILE* f = fopen(dump, "a")) {
+        unsigned long long t0 = ~0ull; for (int i = 0; i < n_clock; ++i) if (ck[4 * i + 1] > 0 && ck[4 * i + 2] < t0) t0 = ck[4 * i + 2];
+        fprintf(f, "# launch n=%d stride=%d\n", n, clock_stride);
+        for (int i = 0; i < n_clock; ++i)
+          fprintf(f, "%d %llu %llu %llu 0x%llx\n", i * clock_stride, ck[4 * i], ck[4 * i + 1], ck[4 * i + 2] - t0, ck[4 * i + 3]);
+        fclose(f);
+      }
+    }
     if (!khz.empty()) {
       std::nth_element(khz.begin(), khz.begin() + khz.size() / 2, khz.end()); ctx->last_clock_khz = (long long) khz[khz.size() / 2];
       std::nth_element(life.begin(), life.begin() + life.size() / 2, life.end()); ctx->last_wg_lifetime_ns = (long long) life[life.size() / 2];

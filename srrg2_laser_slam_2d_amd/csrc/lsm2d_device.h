@@ -175,6 +175,65 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
   }
 }
 
+// One point of k_align's lane-chunked stream (fire-and-forget z-buffer update).  Same operation sequence as project_point, so the
+// same bits.  What tools/valu_issue_probe.hip measured on the MI355X (profiles/r02/valu_issue_probe.txt): a plain VALU instruction
+// costs 2.15 cycles of a saturated SIMD, two waves saturate it, instruction-level parallelism inside a wave buys nothing, and a
+// transcendental holds the SIMD for ~8 cycles plus ~5 for the pipe switch, whichever wave issues next.  Issuing v_rcp_f32 (the
+// divide of atan2) and v_rsq_f32 (the depth) back to back in one asm block (LSM2D_STREAM_TRANS_PAIR) measured no gain in the kernel.
+// kGuardTiny = false: the host has proved that a quotient below 1e-12 / max cannot move a column (ProjK::tiny_ok), so the divide
+// needs no branch for it.
+#ifndef LSM2D_STREAM_TRANS_PAIR
+#define LSM2D_STREAM_TRANS_PAIR 0      // measured on configs[1]: 1.694 ms paired vs 1.695 ms unpaired (profiles/r02/variants_r02a.log) -- no gain, so the
+#endif                                 // compiler keeps the placement (and the hazard bookkeeping) of the two transcendentals
+template <bool kGuardTiny>
+LSM2D_DEV void project_point_stream(const Iso& T, const ProjK& P, float px, float py, int idx, u64* canvas) {
+  float qx, qy;
+  xf_point(T, px, py, qx, qy);
+  const float r2 = __builtin_fmaf(qx, qx, qy * qy);
+  if (r2 >= P.r2lo && r2 <= P.r2hi) {
+    const float ax = __builtin_fabsf(qx), ay = __builtin_fabsf(qy);
+    const bool swap = ay > ax;
+    const float mx = swap ? ay : ax, mn = swap ? ax : ay;
+    float r0, y;
+#if LSM2D_STREAM_TRANS_PAIR
+    asm("v_rcp_f32 %0, %2\n\tv_rsq_f32 %1, %3\n\ts_nop 0" : "=&v"(r0), "=v"(y) : "v"(mx), "v"(r2));
+#else
+    r0 = __builtin_amdgcn_rcpf(mx); y = __builtin_amdgcn_rsqf(r2);
+#endif
+    float a;
+    if (kGuardTiny && __builtin_expect(mn < 1e-12f, 0)) a = mn / mx;
+    else {                                                   // div_rn_unit's sequence
+      const float e0 = __builtin_fmaf(-mx, r0, 1.0f);
+      const float r1 = __builtin_fmaf(e0, r0, r0);
+      const float q0 = mn * r1;
+      const float e1 = __builtin_fmaf(-mx, q0, mn);
+      a = __builtin_fmaf(e1, r1, q0);
+    }
+    const float s = a * a;
+    float p = 2.622197615e-03f;
+    p = __builtin_fmaf(p, s, -1.513234153e-02f);
+    p = __builtin_fmaf(p, s, 4.112152755e-02f);
+    p = __builtin_fmaf(p, s, -7.366676629e-02f);
+    p = __builtin_fmaf(p, s, 1.057391763e-01f);
+    p = __builtin_fmaf(p, s, -1.418597102e-01f);
+    p = __builtin_fmaf(p, s, 1.999039650e-01f);
+    p = __builtin_fmaf(p, s, -3.333298564e-01f);
+    float r = __builtin_fmaf(a * s, p, a);
+    if (swap) r = 1.57079637050628662f - r;
+    if (qx < 0.0f) r = 3.14159274101257324f - r;
+    const float th = __builtin_copysignf(r, qy);
+    const float u  = __builtin_fmaf(P.K00, th, P.K01);
+    int col;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col) : "v"(u));
+    if ((unsigned) col < (unsigned) P.cols) {
+      const float s0 = r2 * y, h = 0.5f * y;                 // sqrt_rn_normal's sequence
+      const float e  = __builtin_fmaf(-s0, s0, r2);
+      const float d  = __builtin_fmaf(e, h, s0);
+      atomicMin(&canvas[col], ((u64) __float_as_uint(d) << 32) | (u64) (uint32_t) idx);
+    }
+  }
+}
+
 // Both points of one 16-byte load in ONE straight-line block (the lane-chunked stream of k_align, where the z-buffer update is a
 // fire-and-forget atomic): the same operation sequence per point as project_point, hence the same bits, but without a branch
 // until the two updates themselves -- a point that fails a gate is carried along and masked at the end (on a map inside the
@@ -183,7 +242,7 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
 // three nested branches per point is gone.  kGuardTiny: keep div_rn_unit's branch for quotients that may be subnormal; the host
 // drops it when it has proved that such a quotient cannot move a column (ProjK::tiny_ok).
 #ifndef LSM2D_STREAM_PAIR
-#define LSM2D_STREAM_PAIR 1
+#define LSM2D_STREAM_PAIR 0      // measured: 2.04 ms against 1.91 for the per-point form on configs[1] (profiles/r02): kept for reference only
 #endif
 template <bool kGuardTiny>
 LSM2D_DEV float atan2_poly_stream(float y, float x) {
@@ -291,8 +350,8 @@ LSM2D_DEV void project_cloud_lanes_t(const float4* __restrict__ lane_xy, int T_s
   auto pair = [&](const float4& v, int i) { project_pair_stream<kGuardTiny>(T, P, v, i, canvas); };
 #else
   auto pair = [&](const float4& v, int i) {
-    project_point<false>(T, P, v.x, v.y, i, canvas);
-    project_point<false>(T, P, v.z, v.w, i + 1, canvas);
+    project_point_stream<kGuardTiny>(T, P, v.x, v.y, i, canvas);
+    project_point_stream<kGuardTiny>(T, P, v.z, v.w, i + 1, canvas);
   };
 #endif
   for (; t + 2 <= T_steps; t += 2) {

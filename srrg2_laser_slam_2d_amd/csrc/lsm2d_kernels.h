@@ -19,6 +19,14 @@
 namespace lsm2d {
 
 static constexpr int kMaxSlices = 4;
+// Wave priority by progress.  The SIMD arbitrates by priority, then AGE: with equal priorities the oldest two waves of a SIMD run
+// at full single-wave speed and the younger workgroups of a CU wait (tools/occupancy_probe.py: lifetimes 0.97 .. 2.19 ms in one
+// launch), so the last workgroup of a CU ends up alone, with nobody to issue under its barriers, bin walks and solves.  A
+// workgroup that lowers its priority as it advances lets the ones behind it catch up: all of a CU's workgroups finish together.
+// 0 off (1.86 ms on configs[1]), 1 quarters of the iterations (1.69), 2 halving intervals -- 1/2, 3/4, 7/8 (1.65).
+#ifndef LSM2D_PRIO_BY_PROGRESS
+#define LSM2D_PRIO_BY_PROGRESS 2
+#endif
 #ifndef LSM2D_ALIGN_BLOCK
 #define LSM2D_ALIGN_BLOCK 512
 #endif
@@ -306,7 +314,7 @@ struct AlignArgs {
   PriorDev prior1;
   float* out_pose; float* out_H; int32_t* out_status; int32_t* out_its; StatsDev* out_stats;
   // kernel timing on (lsm2d_set_option "kernel_timing"): thread 0 of every clock_stride-th workgroup stamps s_memtime (shader
-  // cycles) and s_memrealtime (100 MHz) once at its start and once at its end -- [a / clock_stride][2] = {cycles, 10 ns ticks} of
+  // cycles) and s_memrealtime (100 MHz) once at its start and once at its end -- [a / clock_stride][4] = {cycles, 10 ns ticks, start tick, hardware id} of
   // the workgroup's lifetime, from which the host reads the clock the chip held under THIS load (MI355X_MICROARCH.md, DVFS note 6)
   unsigned long long* clock_out; int32_t clock_stride;
   SliceDev s[kMaxSlices];
@@ -482,6 +490,11 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
 
   int it = 0;
   for (; it < A.max_it; ++it) {
+#if LSM2D_PRIO_BY_PROGRESS == 1
+    { const int q = (4 * it) / A.max_it; if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif LSM2D_PRIO_BY_PROGRESS == 2
+    { if (2 * it < A.max_it) __builtin_amdgcn_s_setprio(3); else if (4 * it < 3 * A.max_it) __builtin_amdgcn_s_setprio(2); else if (8 * it < 7 * A.max_it) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
     for (int s = 0; s < A.n_slices; ++s) {
       const SliceDev& S = A.s[s];
       const Iso T = s_iso[s];
@@ -613,8 +626,12 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
     // the status goes last, behind a system-scope release: with results written straight to pinned host memory the host polls
     // this word instead of waiting for the stream (lsm2d_align_batch), and whoever sees it sees everything above
     if (stamp) {
-      A.clock_out[2 * (a / A.clock_stride)] = __builtin_amdgcn_s_memtime() - s_clk[0];
-      A.clock_out[2 * (a / A.clock_stride) + 1] = __builtin_amdgcn_s_memrealtime() - s_clk[1];
+      unsigned long long* co = A.clock_out + 4 * (a / A.clock_stride);
+      co[0] = __builtin_amdgcn_s_memtime() - s_clk[0];
+      co[1] = __builtin_amdgcn_s_memrealtime() - s_clk[1];
+      co[2] = s_clk[1];                                                            // when it started (100 MHz ticks): which dispatch round it was in
+      co[3] = (unsigned long long) __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |      // HW_REG_HW_ID (id 4): wave / SIMD / CU / SE it ran on
+              ((unsigned long long) __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);  // HW_REG_XCC_ID (id 20)
     }
     if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     else A.out_status[a] = st;

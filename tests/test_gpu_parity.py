@@ -1456,6 +1456,51 @@ def test_randomised_mapping_and_preprocessing(ctx, po):
     assert clipped_pts > 1000 and prep_pts > 1000
 
 
+def test_merge_into_large_scene_with_pending_measurement_count(ctx, po):
+    """A measurement whose size only the device knows (lsm2d_preprocess_scan_into, no download) merged into a scene beyond the
+    one-workgroup limit: the multi-launch merge path takes sizes by value, so the pending count must be resolved first -- an upper
+    bound (n_beams) would push the stale tail a LONGER earlier scan left in the same reserved set through the merge.  And the mirror
+    case: a scene whose size is pending (asynchronous merge before) with a measurement beyond the limit."""
+    world = synth.make_world(8)
+    m = synth.make_map(world, 40000, noise_sigma=0.004, seed=3)
+    poses = synth.sample_poses(world, 2, seed=21)
+    proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0); opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    beams, fov = 1081, 2.3
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=20.0, voxelize_resolution=0.0, normal_point_distance=0.3, normal_min_points=5)
+    opre = po.Preprocessor(beams, -fov / 2, fov / 2, 0.3, 20.0, 0.3, 5, 0.0)
+    meas_set = api.CloudSet.reserved(ctx, 2048)
+    # first a full scan fills the set's slots ...
+    r_long = synth.make_scan_ranges(world, poses[:1], n_beams=beams, angle_min=-fov / 2, angle_max=fov / 2, seed=1)[0]
+    pre.setRawData(r_long, -fov / 2, fov / 2, 0.0, 40.0); pre.compute_into(meas_set)
+    assert len(meas_set.download(0)) > 900
+    # ... then a scan with two thirds of its beams out of range reuses it: real count ~1/3, upper bound still n_beams, no download
+    r_short = synth.make_scan_ranges(world, poses[1:2], n_beams=beams, angle_min=-fov / 2, angle_max=fov / 2, seed=2)[0].copy()
+    r_short[: 2 * beams // 3] = np.inf
+    pre.setRawData(r_short, -fov / 2, fov / 2, 0.0, 40.0); pre.compute_into(meas_set)
+    want_meas = po.preprocess_scan(opre, r_short)
+    assert 0 < len(want_meas) < 500
+    scene = api.CloudSet.reserved(ctx, len(m) + 4 * 721); scene.upload(m)
+    merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=True); merger.setScene(scene); merger.setMeasurement(meas_set)
+    mis = np.float32(poses[1]); merger.setMeasurementInScene(mis); merger.compute()
+    host, _ = po.merge_scene(opr, m, want_meas, mis, 0.2)
+    got = scene.download()
+    assert len(got) == len(host) and np.array_equal(got, host)
+    # mirror case: pending scene size (<= 32768 bound) and an exact measurement beyond the limit
+    small = synth.make_map(world, 6000, noise_sigma=0.004, seed=5)
+    big_meas_pts = synth.make_map(world, 36000, noise_sigma=0.004, seed=6)
+    scene2 = api.CloudSet.reserved(ctx, 6000 + 40 * 721); scene2.upload(small)
+    merger2 = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=True); merger2.setScene(scene2); merger2.setMeasurement(meas_set)
+    merger2.setMeasurementInScene(mis); merger2.compute()                  # leaves scene2's size pending
+    host2, _ = po.merge_scene(opr, small, want_meas, mis, 0.2)
+    big = api.CloudSet(ctx, big_meas_pts)
+    ident = np.zeros(3, np.float32)
+    merger3 = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=True); merger3.setScene(scene2); merger3.setMeasurement(big)
+    merger3.setMeasurementInScene(ident); merger3.compute()
+    host3, _ = po.merge_scene(opr, host2, big_meas_pts, ident, 0.2)
+    got3 = scene2.download()
+    assert len(got3) == len(host3) and np.array_equal(got3, host3)
+
+
 def test_randomised_aligner_structure(ctx, po):
     """Fuzz the aligner's STRUCTURE: 1-3 projective slices with their own projectors and extrinsics, Cauchy on some, an odometry
     prior on some, batches of 1-5 alignments choosing their scans through an index array, 1-12 iterations.  The split path must
