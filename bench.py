@@ -191,9 +191,11 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kernel_ms = []; clock_mhz = []; wg_ms = []
+    kernel_ms = []; clock_mhz = []; wg_ms = []; step_s = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         res = step()
+        step_s.append(time.perf_counter() - ts)
         kernel_ms.append(res.kernel_ms)          # HIP events around the k_align launch, on the launch stream
         clock_mhz.append(res.kernel_clock_mhz)   # s_memtime / s_memrealtime stamps inside the same launch
         wg_ms.append(res.workgroup_lifetime_ms)
@@ -291,7 +293,8 @@ def main() -> None:
         out = {
             "metric": "scan-to-map alignments/sec (1081-beam vs 100k-pt map, 20 GN iters)",
             "value": n_total / elapsed, "unit": "alignments/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed,
+            "ms_per_step_median_rank0": float(np.median(step_s)) * 1e3, "ms_per_step_max_rank0": float(np.max(step_s)) * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s%d scans/GPU x %d-beam vs one %d-pt map, %d GN iters, role %s (%s), %s finder%s"
                                    % ("configs[1]: " if default_cfg else "", args.scans, args.beams, args.map_points, args.iterations, args.role,

@@ -111,6 +111,42 @@ static float lsmo_sinf_fixed(float a) { float s, c; lsmo_sincosf(a, &s, &c); ret
 #undef R_PI
 #undef R_TWO_PI
 
+/* ---- fp32 in the reference's own arithmetic ------------------------------------------------------
+ * libm calls where the reference (Eigen's Rotation2D, the upstream polar projector, the Cauchy robustifier) calls libm, every
+ * product and sum rounded on its own (no FMA contraction: the reference is plain x86-64 C++), Eigen's association for an
+ * isometry applied to a point.  Not bit-reproducible across libms -- it is a measuring stick, not a mirror. */
+#define REAL float
+#define LSMO_REFERENCE_PASS 1
+#define SFX(n) n##_r
+#define R_FMA(a, b, c) ((a) * (b) + (c))
+#define R_SQRT(a) sqrtf(a)
+#define R_COS(a) cosf(a)
+#define R_SIN(a) sinf(a)
+#define R_ATAN2(y, x) atan2f((y), (x))
+#define R_LOG(a) logf(a)
+#define R_FABS(a) fabsf(a)
+#define R_FLOOR(a) floorf(a)
+#define R_MAX FLT_MAX
+#define R_TINY FLT_MIN
+#define R_PI LSMO_PI_F
+#define R_TWO_PI 6.28318548202514648f
+#include "lsm2d_oracle_impl.inc"
+#undef REAL
+#undef LSMO_REFERENCE_PASS
+#undef SFX
+#undef R_FMA
+#undef R_SQRT
+#undef R_COS
+#undef R_SIN
+#undef R_ATAN2
+#undef R_LOG
+#undef R_FABS
+#undef R_FLOOR
+#undef R_MAX
+#undef R_TINY
+#undef R_PI
+#undef R_TWO_PI
+
 /* ---- fp64 truth ------------------------------------------------------------------------------ */
 #define REAL double
 #define SFX(n) n##_d

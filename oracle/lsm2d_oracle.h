@@ -19,8 +19,13 @@
  * Who may use this: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- as the
  * checker / the timed CPU baseline, never as (part of) the shipped product path.
  *
- * Two instantiations of every routine: `_f` = fp32 "mirror" (same IEEE operation sequence the
- * HIP kernels use, so index outputs agree bit-for-bit) and `_d` = fp64 "truth".
+ * Three instantiations of every routine: `_f` = fp32 "mirror" (same IEEE operation sequence the
+ * HIP kernels use, so index outputs agree bit-for-bit), `_d` = fp64 "truth", and `_r` = fp32 in the
+ * REFERENCE'S OWN ARITHMETIC as far as it can be known without the upstream sources: libm atan2f / sinf /
+ * cosf / logf (what Eigen and the projector call), no fused multiply-add (x86-64 builds of the reference
+ * have none), Eigen's association in R p + t, sums pair after pair.  `_r` is what the HIP path is measured
+ * against to show how much the fixed-polynomial arithmetic of `_f` moves z-buffer winners, pairs and poses
+ * (tests/test_reference_arithmetic.py, PARITY.md section 5).
  */
 #ifndef LSM2D_ORACLE_H
 #define LSM2D_ORACLE_H
@@ -44,7 +49,11 @@ typedef struct {
   float col_offset;             /* 0 = floor(K00*theta+K01) (SURVEY App. A.3 assumption); 0.5 = round-to-nearest */
 } lsmo_projector;
 
-enum { LSMO_FINDER_PROJECTIVE = 0, LSMO_FINDER_NN = 1, LSMO_FINDER_DISTMAP = 2 };
+enum { LSMO_FINDER_PROJECTIVE = 0, LSMO_FINDER_NN = 1, LSMO_FINDER_DISTMAP = 2,
+       /* oracle only (the HIP library has no such finder): the KD-tree as upstream is BELIEVED to search it --
+        * descent to the single leaf on the query's side, no backtracking, hence approximate; quantifies what the exact search of
+        * LSMO_FINDER_NN changes (PARITY.md section 5) */
+       LSMO_FINDER_KDTREE_APPROX = 3 };
 enum { LSMO_ROBUST_NONE = 0, LSMO_ROBUST_CAUCHY = 1 };
 enum {
   LSMO_SUCCESS = 0,
@@ -65,6 +74,8 @@ typedef struct {
   float chi_threshold;                /* Cauchy tau (MULTI.json:153-158) */
   int   min_num_correspondences;      /* slice skipped if #pairs <= this (MULTI.json:179) */
   float sensor_in_robot[3];           /* WithSensor variant (aligner_slice_processor_laser_2d_impl.cpp:7-10); (0,0,0) = plain */
+  float kd_max_leaf_range;            /* LSMO_FINDER_KDTREE_APPROX: param_max_leaf_range  (correspondence_finder_kd_tree_2d.h:26-28, default 1e-2) */
+  int   kd_min_leaf_points;           /*                            param_min_leaf_points (.h:29-33, default 20) */
 } lsmo_slice_params;
 
 typedef struct {
@@ -191,6 +202,35 @@ int lsmo_align_batch_f(const lsmo_aligner_params* ap, const lsmo_slice_params* s
                        const lsmo_point* moving, int n_moving,
                        const float* x0 /* [n][3] */, float* x_out /* [n][3] */, float* H_out /* [n][9] */,
                        int* status_out, lsmo_iter_stats* last_stats /* [n] or NULL */, int n_threads);
+
+/* ---- `_r`: the same routines in the reference's own arithmetic (see the header comment) ------------------------------ */
+int lsmo_project_r(const lsmo_projector* pr, const lsmo_point* cloud, int n, const float pose[3],
+                   int* out_src, float* out_depth, float* out_xyn);
+int lsmo_find_projective_r(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                           const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
+int lsmo_find_nn_r(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                   const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
+int lsmo_find_distmap_r(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                        const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
+int lsmo_linearize_r(const lsmo_slice_params* sp, const lsmo_point* fixed, const lsmo_point* moving,
+                     const lsmo_corr* corr, int n_corr, const float pose[3], float H[9], float b[3], lsmo_iter_stats* st);
+int lsmo_solve_update_r(const float H[9], const float b[3], float damping, float pose[3], float dx[3]);
+int lsmo_align_r(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_params* sp,
+                 const lsmo_point* const* fixed, const int* n_fixed, const lsmo_point* const* moving, const int* n_moving,
+                 const float x0[3], float x_out[3], float H_out[9], lsmo_iter_stats* stats, int* iterations_done);
+int lsmo_clip_scene_r(const lsmo_projector* pr, const lsmo_point* scene, int n_scene, const float robot_in_local_map[3],
+                      const float sensor_in_robot[3], lsmo_point* out, int* out_src);
+int lsmo_merge_scene_r(const lsmo_projector* pr, lsmo_point* scene, int n_scene, const lsmo_point* meas, int n_meas,
+                       const float measurement_in_scene[3], float merge_threshold, int counts[3]);
+void lsmo_compose_r(const float a[3], const float b[3], float out[3]);
+void lsmo_inverse_r(const float a[3], float out[3]);
+/* the believed upstream KD-tree search (LSMO_FINDER_KDTREE_APPROX), all three arithmetics */
+int lsmo_find_kdtree_f(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                       const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
+int lsmo_find_kdtree_d(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                       const lsmo_point* moving, int n_moving, const double pose[3], lsmo_corr* out);
+int lsmo_find_kdtree_r(const lsmo_slice_params* sp, const lsmo_point* fixed, int n_fixed,
+                       const lsmo_point* moving, int n_moving, const float pose[3], lsmo_corr* out);
 
 #ifdef __cplusplus
 }

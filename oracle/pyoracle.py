@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liblsm2d_oracle.so")
 
-FINDER_PROJECTIVE, FINDER_NN, FINDER_DISTMAP = 0, 1, 2
+FINDER_PROJECTIVE, FINDER_NN, FINDER_DISTMAP, FINDER_KDTREE_APPROX = 0, 1, 2, 3
 ROBUST_NONE, ROBUST_CAUCHY = 0, 1
 SUCCESS, NOT_ENOUGH_CORRESPONDENCES, NOT_ENOUGH_INLIERS, SINGULAR_H, BAD_ARGUMENT = 0, 1, 2, 3, -1
 
@@ -31,7 +31,8 @@ class SliceParams(C.Structure):
     _fields_ = [("finder", C.c_int), ("projector", Projector), ("point_distance", C.c_float),
                 ("normal_cos", C.c_float), ("max_distance", C.c_float), ("resolution", C.c_float),
                 ("robustifier", C.c_int), ("chi_threshold", C.c_float),
-                ("min_num_correspondences", C.c_int), ("sensor_in_robot", C.c_float * 3)]
+                ("min_num_correspondences", C.c_int), ("sensor_in_robot", C.c_float * 3),
+                ("kd_max_leaf_range", C.c_float), ("kd_min_leaf_points", C.c_int)]
 
 
 class AlignerParams(C.Structure):
@@ -109,13 +110,14 @@ def sincos(x):
 def slice_params(finder=FINDER_PROJECTIVE, canvas_cols=1081, angle_min=-np.pi, angle_max=np.pi, range_min=0.3,
                  range_max=30.0, col_offset=0.0, point_distance=0.5, normal_cos=0.8, max_distance=0.5,
                  resolution=0.05, robustifier=ROBUST_NONE, chi_threshold=0.05, min_num_correspondences=10,
-                 sensor_in_robot=(0.0, 0.0, 0.0)) -> SliceParams:
+                 sensor_in_robot=(0.0, 0.0, 0.0), kd_max_leaf_range=1e-2, kd_min_leaf_points=20) -> SliceParams:
     sp = SliceParams()
     sp.finder = finder
     sp.projector = Projector(canvas_cols, angle_min, angle_max, range_min, range_max, col_offset)
     sp.point_distance, sp.normal_cos, sp.max_distance, sp.resolution = point_distance, normal_cos, max_distance, resolution
     sp.robustifier, sp.chi_threshold, sp.min_num_correspondences = robustifier, chi_threshold, min_num_correspondences
     sp.sensor_in_robot = (C.c_float * 3)(*sensor_in_robot)
+    sp.kd_max_leaf_range, sp.kd_min_leaf_points = kd_max_leaf_range, kd_min_leaf_points
     return sp
 
 
@@ -138,6 +140,11 @@ def _pts(a):
 
 
 def _real(double):
+    """double: False -> fp32 mirror `_f`; True -> fp64 truth `_d`; "ref" -> fp32 in the reference's own arithmetic `_r`
+    (libm atan2f / sinf / cosf / logf, no FMA, Eigen's association; lsm2d_oracle.h)."""
+    if isinstance(double, str):
+        assert double == "ref", double
+        return np.float32, "_r"
     return (np.float64, "_d") if double else (np.float32, "_f")
 
 
@@ -168,7 +175,7 @@ def find(sp: SliceParams, fixed, moving, pose, double=False, brute=False):
     out = np.empty((max(cap, 1), 2), np.int32)
     pose = np.ascontiguousarray(pose, dt)
     name = {FINDER_PROJECTIVE: "lsmo_find_projective", FINDER_NN: "lsmo_find_nn_brute" if brute else "lsmo_find_nn",
-            FINDER_DISTMAP: "lsmo_find_distmap"}[sp.finder]
+            FINDER_DISTMAP: "lsmo_find_distmap", FINDER_KDTREE_APPROX: "lsmo_find_kdtree"}[sp.finder]
     k = getattr(lib(), name + sfx)(C.byref(sp), pf, len(fixed), pm, len(moving), pose.ctypes.data_as(C.c_void_p),
                                    out.ctypes.data_as(C.c_void_p))
     assert k >= 0, k
@@ -214,7 +221,7 @@ def solve_update(H, b, pose, damping=0.0, double=False):
     H = np.ascontiguousarray(H, dt).ravel(); b = np.ascontiguousarray(b, dt); pose = np.array(pose, dt)
     dx = np.empty(3, dt)
     fn = getattr(lib(), "lsmo_solve_update" + sfx)
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_double if double else C.c_float, C.c_void_p, C.c_void_p]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_double if double is True else C.c_float, C.c_void_p, C.c_void_p]
     rc = fn(H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), damping, pose.ctypes.data_as(C.c_void_p),
             dx.ctypes.data_as(C.c_void_p))
     return rc, pose, dx
@@ -268,7 +275,7 @@ def merge_scene(pr: Projector, scene, meas, measurement_in_scene, merge_threshol
     buf = np.zeros((len(scene) + pr.canvas_cols, 4), np.float32); buf[:len(scene)] = scene
     m = np.ascontiguousarray(measurement_in_scene, dt); counts = (C.c_int * 3)()
     fn = getattr(lib(), "lsmo_merge_scene" + sfx)
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double if double else C.c_float, C.c_void_p]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double if double is True else C.c_float, C.c_void_p]
     n = fn(C.cast(C.byref(pr), C.c_void_p), buf.ctypes.data_as(C.c_void_p), len(scene), pm, len(meas), m.ctypes.data_as(C.c_void_p), merge_threshold, counts)
     assert n >= 0, n
     return buf[:n].copy(), tuple(counts)

@@ -734,6 +734,104 @@ def test_loop_closure_sweep_acceptance(ctx, po):
     assert acc[:8].all() and not acc[8:].any()
 
 
+def test_configs3_full_size_loop_closure_sweep(ctx, po):
+    """BASELINE configs[3] at its size on one GPU: 65 536 candidate (scan, initial guess) pairs -- 2 048 distinct scans chosen
+    through the index array, as MultiLoopDetectorBruteForce2D's candidate loop would (MULTI.json:964-986) -- against one 100k-point
+    submap, Cauchy tau 0.05 (MULTI.json:957-962).  Size-independent properties over the whole sweep (generating pose,
+    equivariance under a permutation of the candidates, run-to-run bits, acceptance decisions) and 16 sampled candidates against
+    the oracle: within the north_star tolerance of the reference-order mirror, bit-identical to the device-order mirror."""
+    n_cand, n_unique, iters = 65536, 2048, 20
+    world = synth.make_world(3)
+    wl = synth.make_workload(n_unique, 100000, seed=3, world=world)
+    scan_index = (np.arange(n_cand) % n_unique).astype(np.int32)
+    st = synth.Stream(4242, salt=9)
+    delta = st.uniform(3 * n_cand, -0.05, 0.05).reshape(n_cand, 3)
+    x_true = wl.x_true[scan_index]
+    x0 = synth.invert_poses(synth.compose_poses(synth.invert_poses(wl.x_true)[scan_index], delta)).astype(np.float32)
+    proj = api.PointNormal2fProjectorPolar(1081, -math.pi, math.pi, 0.3, 30.0)
+    al = api.MultiAligner2D(ctx, max_iterations=iters, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(
+        api.CorrespondenceFinderProjective2f(ctx, proj, point_distance=0.5, normal_cos=0.8), robustifier=api.RobustifierCauchy(0.05),
+        min_num_correspondences=10))
+    scans = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); submap = api.CloudSet(ctx, wl.map_points)
+    res = al.compute_batch([scans], [submap], x0, fixed_index=scan_index[None, :], want_stats=True)
+    assert ctx.get_option("last_align_path") == 1                      # the throughput kernel
+    # (1) noise-free data: every candidate converges to the pose its scan was rendered from
+    err = np.abs(res.pose - x_true); err[:, 2] = np.abs((err[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+    assert (res.status == 0).all() and err[:, :2].max() < 1e-4 and err[:, 2].max() < 1e-4, (err[:, :2].max(), err[:, 2].max())
+    assert (res.iterations == iters).all()
+    # (2) the acceptance test of the sweep's consumer (MULTI.json:979-985): all of these are true closures
+    assert res.loop_closure_accept(500, 0.1, 0.8).all()
+    # (3) run-to-run: the same bits
+    res2 = al.compute_batch([scans], [submap], x0, fixed_index=scan_index[None, :])
+    assert np.array_equal(res.pose, res2.pose) and np.array_equal(res.information, res2.information)
+    # (4) a permutation of the candidates permutes the results, bit for bit (an alignment does not depend on its neighbours)
+    perm = np.random.default_rng(5).permutation(n_cand)
+    resp = al.compute_batch([scans], [submap], x0[perm], fixed_index=scan_index[perm][None, :])
+    assert np.array_equal(resp.pose, res.pose[perm]) and np.array_equal(resp.information, res.information[perm])
+    # (5) 16 sampled candidates against the oracle
+    osp = po.slice_params(robustifier=po.ROBUST_CAUCHY, chi_threshold=0.05)
+    for i in np.random.default_rng(6).choice(n_cand, 16, replace=False):
+        sc = wl.scan_points[wl.scan_offsets[scan_index[i]]:wl.scan_offsets[scan_index[i] + 1]]
+        ref = po.align(po.aligner_params(iters), [osp], [sc], [wl.map_points], x0[i])
+        d = np.abs(res.pose[i] - ref["pose"])
+        assert ref["status"] == 0 and d[:2].max() < 1e-4 and d[2] < 1e-4, (i, d)
+        dev = po.align(po.aligner_params(iters, device_order=True), [osp], [sc], [wl.map_points], x0[i])
+        assert np.array_equal(res.pose[i], dev["pose"]) and np.array_equal(res.information[i], dev["H"]), i
+
+
+def test_hip_path_against_the_reference_arithmetic_mode(ctx, po):
+    """The HIP path (fixed-polynomial atan2 / sin / cos / log, fused multiply-adds, tree sums) against the oracle in the REFERENCE'S
+    OWN ARITHMETIC (`_r`: libm, no FMA, Eigen's association, sums pair after pair -- oracle/lsm2d_oracle.h): poses within the
+    north_star tolerance on BASELINE configs[1], [3] and [4], with the fraction of first-iteration pairs that differ reported
+    (PARITY.md section 5 holds the full table)."""
+    cases = (("configs[1]", 100000, 16, 0.0, 0), ("configs[3] Cauchy", 100000, 8, 0.05, 3), ("configs[4]", 1000000, 3, 0.0, 5))
+    proj = api.PointNormal2fProjectorPolar(1081, -math.pi, math.pi, 0.3, 30.0)
+    for name, n_map, n, tau, seed in cases:
+        wl = synth.make_workload(n, n_map, seed=seed)
+        al = api.MultiAligner2D(ctx, max_iterations=20, min_num_inliers=10)
+        finder = api.CorrespondenceFinderProjective2f(ctx, proj, point_distance=0.5, normal_cos=0.8)
+        al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, robustifier=api.RobustifierCauchy(tau) if tau > 0 else None,
+                                                                          min_num_correspondences=10))
+        fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+        res = al.compute_batch([fixed], [moving], wl.x0)
+        osp = po.slice_params(**({"robustifier": po.ROBUST_CAUCHY, "chi_threshold": tau} if tau > 0 else {}))
+        worst = np.zeros(2); differing = []
+        for i in range(n):
+            sc = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+            ref = po.align(po.aligner_params(20), [osp], [sc], [wl.map_points], wl.x0[i], double="ref")
+            assert ref["status"] == 0 and res.status[i] == 0
+            d = np.abs(res.pose[i] - ref["pose"]); worst = np.maximum(worst, [d[:2].max(), d[2]])
+            finder.setFixed(fixed, i); finder.setMoving(moving); finder.setLocalMapInSensor(wl.x0[i])
+            got = {tuple(p) for p in finder.compute().tolist()}
+            want = {tuple(p) for p in po.find(osp, sc, wl.map_points, wl.x0[i], double="ref").tolist()}
+            differing.append(len(got ^ want) / max(len(got | want), 1))
+        print("%s: HIP vs reference arithmetic: max pose delta %.2e m / %.2e rad, first-iteration pairs differing %.3f %% (mean over %d scans)"
+              % (name, worst[0], worst[1], 100 * np.mean(differing), n))
+        assert worst[0] < 1e-4 and worst[1] < 1e-4, (name, worst)
+        assert np.mean(differing) < 0.08, (name, differing)
+        fixed.close(); moving.close()
+
+
+def test_bench_strong_scaling_leg_runs_over_rccl_on_one_gpu(tmp_path):
+    """bench.py's N > 1 leg for configs[3] (shard the candidates, RCCL broadcast of the submap, all_gather of the poses, the
+    cross-rank bit check) executed on hardware with a world of one rank: LSM2D_BENCH_FORCE_DIST=1 initialises the nccl (= RCCL)
+    process group and takes every collective the 8-GPU run takes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LSM2D_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--total-candidates", "65536", "--unique-scans", "2048",
+                        "--cauchy", "0.05", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["parity_ok"] and d["ranks_seen"] == 1 and d["scaling"] == "strong" and d["config"]["alignments_per_gpu"] == 65536
+    assert d["cross_rank_check"].startswith("1 of 1 ranks"), d["cross_rank_check"]
+    assert d["value"] > 10000 and d["max_pose_err_m"] < 1e-4
+
+
 # ---- distance-map finder (CorrespondenceFinderNN2D, row a5 / f4) ----------------------------------------------
 def test_distmap_finder_bit_exact_and_aligner(ctx, po, small_workload):
     wl = small_workload
@@ -925,6 +1023,17 @@ def test_preprocessor_reference_fixture_on_gpu(ctx):
     assert pre.setRawData(np.ones(n, np.float32), angle_min=-1.0, angle_max=1.0, range_min=0.0, range_max=1000.0)
     meas = pre.compute()
     assert meas.counts[0] == 100 and len(meas.download(0)) == 100
+    # ... and the geometry the reference's own TODO asks for (tests/test_measurement_adaptor.cpp:38 "validate computed polar positions"):
+    # every point on the unit circle, at the bearing of its beam (sensor matrix [[n / (angle_max - angle_min), n / 2]],
+    # sensor_processing/raw_data_preprocessor_projective_2d.cpp:87-90), unit normals along the ray, facing the sensor
+    pts = meas.download(0)
+    assert np.allclose(np.hypot(pts[:, 0], pts[:, 1]), 1.0, atol=1e-6) and np.allclose(np.hypot(pts[:, 2], pts[:, 3]), 1.0, atol=1e-6)
+    raw = api.RawDataPreprocessorProjective2D(ctx, range_min=0.0, range_max=1000.0, voxelize_resolution=0.0)
+    raw.setRawData(np.ones(n, np.float32), angle_min=-1.0, angle_max=1.0, range_min=0.0, range_max=1000.0)
+    rp = raw.compute().download(0)
+    assert len(rp) == n and np.allclose(np.arctan2(rp[:, 1], rp[:, 0]), (np.arange(n) - n / 2) * (2.0 / n), atol=1e-6)
+    assert np.all(np.sum(rp[:, :2] * rp[:, 2:], 1) < -0.999)          # a circle around the sensor: the normal is the (reversed) ray
+    assert {tuple(np.round(p, 5)) for p in pts[:, :2]} == {tuple(np.round(p, 5)) for p in rp[:, :2]}     # 1 cm voxels keep all 100 (2 cm apart)
 
 
 def test_preprocessor_bit_exact_batch_and_feeds_aligner(ctx, po):
