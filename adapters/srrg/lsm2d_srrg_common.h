@@ -1,0 +1,140 @@
+// Shared plumbing of the SRRG-side adapters (adapters/srrg/*): device clouds that live as long as the adapter object, parameter
+// translation from the reference's finder / projector / robustifier objects to the C ABI's plain structs, error conversion.
+#pragma once
+#include "upstream_access.h"
+
+#include <srrg2_laser_slam_2d/registration/correspondence_finder_kd_tree_2d.h>
+#include <srrg2_laser_slam_2d/registration/correspondence_finder_nn_2d.h>
+#include <srrg2_laser_slam_2d/registration/correspondence_finder_projective_2d.h>
+#include <srrg_pcl/point_projector_types.h>
+#include <srrg_solver/solver_core/robustifier.h>
+
+#include <memory>
+#include <vector>
+
+namespace lsm2d_srrg {
+
+  // C-ABI errors become the exceptions the reference's modules throw (registration/correspondence_finder_projective_2d.cpp:21-31)
+  inline void throwOnError(int rc_, const std::string& where_, const lsm2d_context* ctx_) {
+    if (rc_ < 0) {
+      throw std::runtime_error(where_ + "| " + lsm2d_status_string(rc_) + ": " + lsm2d_last_error(ctx_));
+    }
+  }
+
+  // One PointNormal2fVectorCloud on the device, in a reserved set that is REFILLED (lsm2d_cloudset_upload: a copy into pinned
+  // memory, unpacked by the kernel that reads it) instead of being created and destroyed per call.  Owns the set.
+  class DeviceCloud {
+  public:
+    DeviceCloud() {
+    }
+    DeviceCloud(const DeviceCloud&) = delete;
+    DeviceCloud& operator=(const DeviceCloud&) = delete;
+    ~DeviceCloud() {
+      lsm2d_cloudset_destroy(_set);
+    }
+    // PointNormal2f -> (x, y, nx, ny).  The preprocessor never emits invalid points
+    // (sensor_processing/raw_data_preprocessor_projective_2d.cpp:42-47), so indices are the host cloud's.
+    void upload(lsm2d_context* ctx_, const PointNormal2fVectorCloud& cloud_, const char* who_) {
+      const size_t n = cloud_.size();
+      if (!_set || n > _capacity) {
+        lsm2d_cloudset_destroy(_set);
+        _set      = nullptr;
+        _capacity = n + n / 2 + 1024;
+        throwOnError(lsm2d_cloudset_create_reserved(ctx_, (int64_t) _capacity, &_set), std::string(who_) + " reserve", ctx_);
+      }
+      _staging.resize(4 * n);
+      size_t k = 0;
+      for (const auto& p : cloud_) {
+        _staging[k++] = p.coordinates().x();
+        _staging[k++] = p.coordinates().y();
+        _staging[k++] = p.normal().x();
+        _staging[k++] = p.normal().y();
+      }
+      throwOnError(lsm2d_cloudset_upload(_set, _staging.data(), (int64_t) n), std::string(who_) + " upload", ctx_);
+      _host = &cloud_;
+    }
+    lsm2d_cloudset* set() const {
+      return _set;
+    }
+    const PointNormal2fVectorCloud* host() const {
+      return _host;
+    }
+
+  private:
+    lsm2d_cloudset* _set                  = nullptr;
+    size_t _capacity                      = 0;
+    const PointNormal2fVectorCloud* _host = nullptr;
+    std::vector<float> _staging;
+  };
+
+  inline void fillProjector(const PointNormal2fProjectorPolar& projector_, lsm2d_projector* out_) {
+    out_->canvas_cols = projector_.param_canvas_cols.value();
+    out_->angle_min   = projector_.param_angle_col_min.value();
+    out_->angle_max   = projector_.param_angle_col_max.value();
+    out_->range_min   = projector_.param_range_min.value();
+    out_->range_max   = projector_.param_range_max.value();
+    out_->col_offset  = 0.f;
+  }
+
+  // HIP siblings of the reference finders implement this, so an aligner slice configured with one of THEM translates too
+  class SliceParamsSource {
+  public:
+    virtual ~SliceParamsSource() {
+    }
+    virtual void fillSliceParams(lsm2d_slice_params* sp_) const = 0;
+  };
+
+  // finder object of a slice -> finder part of lsm2d_slice_params.  The three finders the reference registers
+  // (instances.cpp:27-29) and their HIP siblings are understood; anything else is an error, never silently skipped.
+  template <typename FinderPtr_>
+  inline void fillFinderParams(const FinderPtr_& finder_, lsm2d_slice_params* sp_, const char* who_) {
+    using namespace srrg2_laser_slam_2d;
+    if (!finder_) {
+      throw std::runtime_error(std::string(who_) + "| slice without a correspondence finder");
+    }
+    if (auto src = dynamic_cast<const SliceParamsSource*>(finder_.get())) {
+      src->fillSliceParams(sp_);
+    } else if (auto proj = dynamic_cast<const CorrespondenceFinderProjective2f*>(finder_.get())) {
+      if (!proj->param_projector.value()) {
+        throw std::runtime_error(std::string(who_) + "| Missing Projector");
+      }
+      sp_->finder = LSM2D_FINDER_PROJECTIVE;
+      fillProjector(*proj->param_projector.value(), &sp_->projector);
+      sp_->point_distance = proj->param_point_distance.value();
+      sp_->normal_cos     = proj->param_normal_cos.value();
+    } else if (auto kd = dynamic_cast<const CorrespondenceFinderKDTree2D*>(finder_.get())) {
+      sp_->finder       = LSM2D_FINDER_NN; // exact nearest neighbour; max_leaf_range / min_leaf_points have no counterpart
+      sp_->max_distance = kd->param_max_distance_m.value();
+      sp_->normal_cos   = kd->param_normal_cos.value();
+    } else if (auto nn = dynamic_cast<const CorrespondenceFinderNN2D*>(finder_.get())) {
+      sp_->finder       = LSM2D_FINDER_DISTMAP;
+      sp_->max_distance = nn->param_max_distance_m.value();
+      sp_->resolution   = nn->param_resolution.value();
+      sp_->normal_cos   = nn->param_normal_cos.value();
+    } else {
+      throw std::runtime_error(std::string(who_) + "| unsupported correspondence finder type in a laser slice");
+    }
+  }
+
+  template <typename RobustifierPtr_>
+  inline void fillRobustifier(const RobustifierPtr_& robustifier_, lsm2d_slice_params* sp_, const char* who_) {
+    sp_->robustifier   = LSM2D_ROBUST_NONE;
+    sp_->chi_threshold = 0.f;
+    if (!robustifier_) {
+      return; // "#pointer": -1 (MULTI.json:184-187)
+    }
+    if (auto cauchy = dynamic_cast<const srrg2_solver::RobustifierCauchy*>(robustifier_.get())) {
+      sp_->robustifier   = LSM2D_ROBUST_CAUCHY;
+      sp_->chi_threshold = cauchy->param_chi_threshold.value();
+      return;
+    }
+    throw std::runtime_error(std::string(who_) + "| unsupported robustifier type (only RobustifierCauchy runs on the device)");
+  }
+
+  inline void poseToArray(const Isometry2f& T_, float out_[3]) {
+    const Vector3f v = geometry2d::t2v(T_);
+    out_[0]          = v.x();
+    out_[1]          = v.y();
+    out_[2]          = v.z();
+  }
+} // namespace lsm2d_srrg

@@ -1,116 +1,179 @@
-// See multi_aligner_hip_2d.h.  NOT compiled in this repository's container (srrg2 stack absent); the calls into the
-// upstream base class are limited to what the reference itself uses in-tree:
-//   param_max_iterations / param_min_num_inliers / param_slice_processors   MULTI.json:700-732
+// See multi_aligner_hip_2d.h.  Calls into the upstream base class are limited to what the reference itself uses in-tree:
+//   param_max_iterations / param_min_num_inliers / param_slice_processors    MULTI.json:700-732
 //   slice->param_fixed_slice_name / param_moving_slice_name / param_finder / param_robustifier /
-//   param_min_num_correspondences                                            MULTI.json:160-188
-//   setMovingInFixed / movingInFixed                                          apps/visual_test_aligner_2d.cpp:126,145
-// Members whose upstream names could not be verified here are marked  /*UPSTREAM*/ .
+//   param_min_num_correspondences                                             MULTI.json:160-188
+//   setMovingInFixed / movingInFixed / iterationStats                          apps/visual_test_aligner_2d.cpp:126,145,156
+// everything else goes through adapters/srrg/upstream_access.h (tagged UPSTREAM there) or _writeBack() below.
 #include "multi_aligner_hip_2d.h"
-#include <srrg_geometry/geometry2d.h>
-#include <srrg_solver/solver_core/robustifier.h>
+
+#include <functional>
+#include <set>
 
 namespace srrg2_laser_slam_2d {
   using namespace srrg2_core;
   using namespace srrg2_slam_interfaces;
+  using lsm2d_srrg::throwOnError;
 
   MultiAlignerHIP2D::~MultiAlignerHIP2D() {
+    _device_clouds.clear();
     lsm2d_destroy(_ctx);
   }
 
-  static lsm2d_cloudset* uploadCloud(lsm2d_context* ctx_, const PointNormal2fVectorCloud& cloud_) {
-    std::vector<float> staging(4 * cloud_.size());
-    size_t k = 0;
-    for (const auto& p : cloud_) {
-      staging[k++] = p.coordinates().x();
-      staging[k++] = p.coordinates().y();
-      staging[k++] = p.normal().x();
-      staging[k++] = p.normal().y();
+  void MultiAlignerHIP2D::_writeBack(int status_, const float information_[9], int iterations_, const std::vector<lsm2d_iteration_stats>& stats_) {
+    // UPSTREAM: member names of the aligner base class behind status() / informationMatrix() / iterationStats()
+    switch (status_) {
+      case LSM2D_SUCCESS: _status = Success; break;
+      case LSM2D_NOT_ENOUGH_CORRESPONDENCES: _status = NotEnoughCorrespondences; break;
+      case LSM2D_NOT_ENOUGH_INLIERS: _status = NotEnoughInliers; break;
+      default: _status = Fail; break; // LSM2D_SINGULAR_H: the reference's linear solver would fail here
     }
-    lsm2d_cloudset* set = nullptr;
-    if (lsm2d_cloudset_create(ctx_, staging.data(), nullptr, 1, (int64_t) cloud_.size(), &set) < 0) {
-      throw std::runtime_error(std::string("MultiAlignerHIP2D| upload: ") + lsm2d_last_error(ctx_));
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        _information_matrix(r, c) = information_[3 * r + c];
+      }
     }
-    return set;
+    _iteration_stats.clear();
+    for (int it = 0; it < iterations_; ++it) {
+      srrg2_solver::IterationStats st;
+      st.iteration    = it;
+      st.num_inliers  = stats_[it].n_inliers;
+      st.num_outliers = stats_[it].n_outliers;
+      st.chi_inliers  = stats_[it].chi_inliers;
+      st.chi_outliers = stats_[it].chi_outliers;
+      _iteration_stats.push_back(st);
+    }
   }
 
   void MultiAlignerHIP2D::compute() {
-    if (!_ctx && lsm2d_create(param_device_id.value(), nullptr, &_ctx) < 0) {
-      throw std::runtime_error(std::string("MultiAlignerHIP2D::compute| ") + lsm2d_last_error(nullptr));
+    const char* who = "MultiAlignerHIP2D::compute";
+    if (!_fixed || !_moving) {
+      throw std::runtime_error(std::string(who) + "| fixed / moving scene not set");
+    }
+    if (!_ctx) {
+      throwOnError(lsm2d_create(param_device_id.value(), nullptr, &_ctx), std::string(who) + " create", nullptr);
     }
     std::vector<lsm2d_slice_params> slices;
-    std::vector<lsm2d_cloudset*> fixed_sets, moving_sets;
+    std::vector<const lsm2d_cloudset*> fixed_sets, moving_sets;
+    struct PublishTarget {      // where a laser slice's pairs go when publish_correspondences is on
+      std::function<CorrespondenceVector&()> correspondences;
+      size_t n_moving;
+    };
+    std::vector<PublishTarget> laser_slices;
     lsm2d_prior prior{};
     bool has_prior = false;
+    std::set<const PointNormal2fVectorCloud*> refreshed; // a cloud shared by several slices is uploaded once per compute()
+
+    auto deviceCloud = [&](PointNormal2fVectorCloud* cloud_) -> lsm2d_cloudset* {
+      auto& slot = _device_clouds[cloud_];
+      if (!slot) {
+        slot.reset(new lsm2d_srrg::DeviceCloud);
+      }
+      if (!refreshed.count(cloud_)) { // contents may have changed in place since the last call: always refill (pinned copy)
+        slot->upload(_ctx, *cloud_, who);
+        refreshed.insert(cloud_);
+      }
+      return slot->set();
+    };
 
     for (size_t s = 0; s < param_slice_processors.size(); ++s) {
-      auto laser = std::dynamic_pointer_cast<AlignerSliceProcessorLaser2D>(param_slice_processors.value(s));
-      auto laser_ws = std::dynamic_pointer_cast<AlignerSliceProcessorLaser2DWithSensor>(param_slice_processors.value(s));
-      if (!laser && !laser_ws) {
-        // non-laser cue (e.g. AlignerSliceOdom2DPrior, MULTI.json:402-422): expressed as the lsm2d prior
-        // e = t2v(Z^-1 X) with information Omega.  /*UPSTREAM*/ accessor names of the prior slice:
-        //   Isometry2f Z; Matrix3f omega;  -> fill prior.z = t2v(Z), prior.omega row-major, has_prior = true
+      auto processor = param_slice_processors.value(s);
+      auto laser     = std::dynamic_pointer_cast<AlignerSliceProcessorLaser2D>(processor);
+      auto laser_ws  = std::dynamic_pointer_cast<AlignerSliceProcessorLaser2DWithSensor>(processor);
+      if (laser || laser_ws) {
+        lsm2d_slice_params sp{};
+        auto fill = [&](const auto& slice_) {
+          PointNormal2fVectorCloud* fixed  = lsm2d_srrg::cloudInContainer(_fixed, slice_->param_fixed_slice_name.value());
+          PointNormal2fVectorCloud* moving = lsm2d_srrg::cloudInContainer(_moving, slice_->param_moving_slice_name.value());
+          if (!fixed || !moving) {
+            throw std::runtime_error(std::string(who) + "| slice '" + slice_->param_fixed_slice_name.value() + "' / '" +
+                                     slice_->param_moving_slice_name.value() + "' not found in the fixed / moving scene");
+          }
+          lsm2d_srrg::fillFinderParams(slice_->param_finder.value(), &sp, who);
+          lsm2d_srrg::fillRobustifier(slice_->param_robustifier.value(), &sp, who);
+          sp.min_num_correspondences = slice_->param_min_num_correspondences.value();
+          fixed_sets.push_back(deviceCloud(fixed));
+          moving_sets.push_back(deviceCloud(moving));
+          lsm2d_srrg::publishSliceBinding(slice_, fixed, moving);
+          laser_slices.push_back(PublishTarget{[slice_]() -> CorrespondenceVector& { return lsm2d_srrg::sliceCorrespondences(slice_); }, moving->size()});
+        };
+        if (laser_ws) {
+          fill(laser_ws);
+          // WithSensor: the estimate lives in the robot frame, the fixed scan in the sensor frame
+          // (registration/aligner_slice_processor_laser_2d_impl.cpp:7-10)
+          lsm2d_srrg::poseToArray(lsm2d_srrg::sensorInRobot(laser_ws), sp.sensor_in_robot);
+        } else {
+          fill(laser);
+        }
+        slices.push_back(sp);
         continue;
       }
-      lsm2d_slice_params sp{};
-      auto fill = [&](auto& slice_) {
-        auto finder = std::dynamic_pointer_cast<CorrespondenceFinderProjective2f>(slice_->param_finder.value());
-        if (!finder || !finder->param_projector.value()) {
-          throw std::runtime_error("MultiAlignerHIP2D::compute| laser slice without a projective finder");
+      if (auto odom = std::dynamic_pointer_cast<AlignerSliceOdom2DPrior>(processor)) {
+        // the odometry cue (MULTI.json:402-422): both scenes carry the robot's odometry pose under the slice names; the factor's
+        // measurement is the moving scene's origin seen from the fixed one, Z = odom_fixed^-1 * odom_moving, its error e = t2v(Z^-1 X)
+        if (has_prior) {
+          throw std::runtime_error(std::string(who) + "| more than one prior slice: the device path takes one");
         }
-        auto projector           = finder->param_projector.value();
-        sp.finder                = LSM2D_FINDER_PROJECTIVE;
-        sp.projector.canvas_cols = projector->param_canvas_cols.value();
-        sp.projector.angle_min   = projector->param_angle_col_min.value();
-        sp.projector.angle_max   = projector->param_angle_col_max.value();
-        sp.projector.range_min   = projector->param_range_min.value();
-        sp.projector.range_max   = projector->param_range_max.value();
-        sp.point_distance        = finder->param_point_distance.value();
-        sp.normal_cos            = finder->param_normal_cos.value();
-        sp.min_num_correspondences = slice_->param_min_num_correspondences.value();
-        if (auto cauchy = std::dynamic_pointer_cast<srrg2_solver::RobustifierCauchy>(slice_->param_robustifier.value())) {
-          sp.robustifier   = LSM2D_ROBUST_CAUCHY;
-          sp.chi_threshold = cauchy->param_chi_threshold.value();
+        if (odom->param_robustifier.value()) {
+          throw std::runtime_error(std::string(who) + "| a robustifier on the odometry prior slice is not supported on the device");
         }
-        // clouds by slice name out of the fixed / moving property containers
-        // (apps/visual_test_aligner_2d.cpp:108-118): /*UPSTREAM*/ slice_->fixed() / slice_->moving() after bind
-        fixed_sets.push_back(uploadCloud(_ctx, *slice_->fixed()));
-        moving_sets.push_back(uploadCloud(_ctx, *slice_->moving()));
-      };
-      if (laser_ws) {
-        fill(laser_ws);
-        // WithSensor: sensor_in_robot from the tf Platform (registration/aligner_slice_processor_laser_2d_impl.cpp:7-10)
-        const Vector3f sv = geometry2d::t2v(laser_ws->sensorInRobot() /*UPSTREAM*/);
-        sp.sensor_in_robot[0] = sv.x(); sp.sensor_in_robot[1] = sv.y(); sp.sensor_in_robot[2] = sv.z();
-      } else {
-        fill(laser);
+        Isometry2f odom_fixed, odom_moving;
+        if (!lsm2d_srrg::isometryInContainer(_fixed, odom->param_fixed_slice_name.value(), &odom_fixed) ||
+            !lsm2d_srrg::isometryInContainer(_moving, odom->param_moving_slice_name.value(), &odom_moving)) {
+          throw std::runtime_error(std::string(who) + "| odometry slice '" + odom->param_fixed_slice_name.value() + "' not found in the fixed / moving scene");
+        }
+        lsm2d_srrg::poseToArray(odom_fixed.inverse() * odom_moving, prior.z);
+        lsm2d_srrg::priorInformation(prior.omega);
+        has_prior = true;
+        continue;
       }
-      slices.push_back(sp);
+      throw std::runtime_error(std::string(who) + "| slice processor " + std::to_string(s) +
+                               " is neither a laser slice nor the odometry prior: refusing to run without it");
+    }
+    if (slices.empty()) {
+      throw std::runtime_error(std::string(who) + "| no laser slice");
     }
 
-    const Vector3f x0  = geometry2d::t2v(movingInFixed());
-    float pose[3]      = {x0.x(), x0.y(), x0.z()};
-    float information[9];
+    float pose[3], information[9];
+    lsm2d_srrg::poseToArray(movingInFixed(), pose);
     int32_t status = 0, iterations = 0;
-    std::vector<const lsm2d_cloudset*> fx(fixed_sets.begin(), fixed_sets.end()), mv(moving_sets.begin(), moving_sets.end());
     lsm2d_batch batch{};
     batch.n_alignments = 1;
     batch.n_slices     = (int32_t) slices.size();
     batch.slices       = slices.data();
-    batch.fixed        = fx.data();
-    batch.moving       = mv.data();
+    batch.fixed        = fixed_sets.data();
+    batch.moving       = moving_sets.data();
     batch.init_pose    = pose;
     batch.prior        = has_prior ? &prior : nullptr;
-    lsm2d_aligner_params ap{param_max_iterations.value(), param_min_num_inliers.value(), 0.f};
-    std::vector<lsm2d_iteration_stats> stats(std::max(1, ap.max_iterations));
-    const int rc = lsm2d_align_batch(_ctx, &ap, &batch, pose, information, &status, &iterations, stats.data());
-    for (auto* s : fixed_sets) { lsm2d_cloudset_destroy(s); }
-    for (auto* s : moving_sets) { lsm2d_cloudset_destroy(s); }
-    if (rc < 0) {
-      throw std::runtime_error(std::string("MultiAlignerHIP2D::compute| ") + lsm2d_last_error(_ctx));
-    }
+    lsm2d_aligner_params ap{};
+    ap.max_iterations  = param_max_iterations.value();
+    ap.min_num_inliers = param_min_num_inliers.value();
+    ap.damping         = 0.f; // GN, MULTI.json:254-259
+    std::vector<lsm2d_iteration_stats> stats((size_t) (ap.max_iterations > 0 ? ap.max_iterations : 1));
+    throwOnError(lsm2d_align_batch(_ctx, &ap, &batch, pose, information, &status, &iterations, stats.data()), who, _ctx);
+    _last_status     = status;
+    _last_iterations = iterations;
     setMovingInFixed(geometry2d::v2t(Vector3f(pose[0], pose[1], pose[2])));
-    // status / information matrix / iteration stats back into the base class  /*UPSTREAM*/ member names:
-    //   _status = Success | NotEnoughCorrespondences | NotEnoughInliers | Fail ; _information_matrix ; _iteration_stats
+    _writeBack(status, information, iterations, stats);
+
+    if (param_publish_correspondences.value()) {
+      std::vector<lsm2d_correspondence> pairs;
+      for (size_t s = 0; s < laser_slices.size(); ++s) {
+        // X_eff = S^-1 X is what the slice's finder saw in the last iteration
+        Isometry2f S = geometry2d::v2t(Vector3f(slices[s].sensor_in_robot[0], slices[s].sensor_in_robot[1], slices[s].sensor_in_robot[2]));
+        float xe[3];
+        lsm2d_srrg::poseToArray(S.inverse() * movingInFixed(), xe);
+        const size_t capacity = slices[s].finder == LSM2D_FINDER_PROJECTIVE ? (size_t) slices[s].projector.canvas_cols : laser_slices[s].n_moving;
+        pairs.resize(capacity > 0 ? capacity : 1);
+        int32_t k = 0;
+        throwOnError(lsm2d_find_correspondences(_ctx, &slices[s], fixed_sets[s], 0, moving_sets[s], 0, xe, pairs.data(), (int32_t) pairs.size(), &k),
+                     who, _ctx);
+        CorrespondenceVector& out = laser_slices[s].correspondences();
+        out.resize(k);
+        for (int32_t i = 0; i < k; ++i) {
+          out[i] = Correspondence(pairs[i].fixed_idx, pairs[i].moving_idx);
+        }
+      }
+    }
   }
 
 } // namespace srrg2_laser_slam_2d

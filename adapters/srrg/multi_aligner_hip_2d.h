@@ -1,15 +1,19 @@
-// SRRG-side adapter for the aligner (same caveat as correspondence_finder_hip_2d.h: needs the srrg2 stack).
-//
-// MultiAlignerHIP2D derives from the upstream srrg2_slam_interfaces::MultiAligner2D and overrides compute():
-// instead of {finder->compute(); solver->compute()} x max_iterations on the host
-// (driver apps/visual_test_aligner_2d.cpp:123-156) it makes ONE lsm2d_align_batch call that runs the
-// whole loop on the device.  It consumes the same configuration: max_iterations, min_num_inliers, slice_processors
-// (configurations/stage_segway_double_config_MULTI.json:700-732); laser slices
-// (AlignerSliceProcessorLaser2D[WithSensor]) become lsm2d slices, an AlignerSliceOdom2DPrior becomes the lsm2d_prior.
+// SRRG-side adapter for plugin interface #2: MultiAlignerHIP2D derives from the upstream
+// srrg2_slam_interfaces::MultiAligner2D and overrides compute(): instead of {finder->compute(); solver->compute()} x
+// max_iterations on the host (driver apps/visual_test_aligner_2d.cpp:123-156) it makes ONE lsm2d_align_batch
+// call that runs the whole loop on the device.  It consumes the same configuration -- max_iterations, min_num_inliers,
+// slice_processors (configurations/stage_segway_double_config_MULTI.json:700-732): every AlignerSliceProcessorLaser2D[WithSensor]
+// becomes an lsm2d slice (finder, robustifier, min_num_correspondences, sensor extrinsics), the AlignerSliceOdom2DPrior
+// (MULTI.json:402-422) becomes the lsm2d_prior; a slice processor of any other type is an ERROR, never skipped.  After the call
+// the pose, the status, the information matrix and the iteration statistics are written back into the base class.
+// Device clouds persist across calls (reserved sets, refilled), one per distinct host cloud.
 #pragma once
-#include <lsm2d.h>
+#include "lsm2d_srrg_common.h"
+
 #include <srrg2_laser_slam_2d/registration/aligner_slice_processor_laser_2d.h>
 #include <srrg2_slam_interfaces/registration/aligners/multi_aligner.h>
+
+#include <map>
 
 namespace srrg2_laser_slam_2d {
 
@@ -18,11 +22,28 @@ namespace srrg2_laser_slam_2d {
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
     using BaseType = srrg2_slam_interfaces::MultiAligner2D;
     PARAM(srrg2_core::PropertyInt, device_id, "HIP device ordinal", 0, 0);
+    PARAM(srrg2_core::PropertyInt,
+          publish_correspondences,
+          "1: after compute() every laser slice's correspondences() holds the pairs at the final estimate (one extra finder call per slice; "
+          "callers use them for drawing only: apps/visual_test_aligner_2d.cpp:129-143)",
+          0,
+          0);
     virtual ~MultiAlignerHIP2D();
     void compute() override;
+    // per-alignment outcome of the last compute(), in the C ABI's terms (lsm2d_status >= 0)
+    int lastDeviceStatus() const {
+      return _last_status;
+    }
+    int lastIterations() const {
+      return _last_iterations;
+    }
 
   protected:
+    void _writeBack(int status_, const float information_[9], int iterations_, const std::vector<lsm2d_iteration_stats>& stats_);
     lsm2d_context* _ctx = nullptr;
+    // one device cloud per host cloud object (two laser slices usually share the moving cloud: MULTI.json:372-400,160-188)
+    std::map<const srrg2_core::PointNormal2fVectorCloud*, std::unique_ptr<lsm2d_srrg::DeviceCloud>> _device_clouds;
+    int _last_status = -1, _last_iterations = 0;
   };
 
   using MultiAlignerHIP2DPtr = std::shared_ptr<MultiAlignerHIP2D>;

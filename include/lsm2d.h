@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 112 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
-                             0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes */
+#define LSM2D_VERSION 120 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
+                             0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes;
+                             0.2.0: + lsm2d_clip_scene_voxelized, lsm2d_sweep_* (multi-device loop-closure sweep), in-kernel clock options */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -202,6 +203,14 @@ int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_preprocessor* par
 int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* projector, const lsm2d_cloudset* full_scene,
                      int32_t scene_index, const float robot_in_local_map[3], const float sensor_in_robot[3],
                      lsm2d_cloudset* clipped, int32_t* out_n_points, int32_t* out_source_idx);
+
+/* The same with the clipper's voxelize_resolution > 0 branch (mapping/scene_clipper_projective_2d.cpp:36-48): the clipped points, still
+ * in the sensor frame, are voxelised with coefficients (res, res, 0.1, 0.1) -- equal keys averaged, ascending key order (assumption
+ * F2.3, oracle/lsm2d_oracle.c) -- and then moved to the robot frame.  out_source_idx must be NULL (a voxel has no source point);
+ * canvas_cols <= 2048; voxelize_resolution <= 0 is lsm2d_clip_scene. */
+int lsm2d_clip_scene_voxelized(lsm2d_context* ctx, const lsm2d_projector* projector, const lsm2d_cloudset* full_scene,
+                               int32_t scene_index, const float robot_in_local_map[3], const float sensor_in_robot[3],
+                               float voxelize_resolution, lsm2d_cloudset* clipped, int32_t* out_n_points, int32_t* out_source_idx);
 
 /* ---- MergerProjective2D::compute (mapping/merger_projective_2d.cpp:9-100): folds `measurement` (cloud
  * measurement_index, in its own sensor/robot frame) into the single-cloud reserved set `scene`, in place: per projector

@@ -192,11 +192,32 @@ static int lsmo_vox_cmp(const void* a, const void* b) {
   if (x->key != y->key) return x->key < y->key ? -1 : 1;
   return x->idx - y->idx;
 }
-/* voxel key packed in 64 bits: (kx+2^15) | (ky+2^15) | (knx+1) | (kny+1); returns -1 when out of the packable range */
-static long long lsmo_vox_key(float x, float y, float nx, float ny, float inv_res) {
-  const float kx = floorf(x * inv_res), ky = floorf(y * inv_res), knx = floorf(nx), kny = floorf(ny);
-  if (!(kx >= -32768.0f && kx < 32768.0f && ky >= -32768.0f && ky < 32768.0f && knx >= -1.0f && knx <= 1.0f && kny >= -1.0f && kny <= 1.0f)) return -1;
-  return ((long long) ((int) kx + 32768) << 20) | ((long long) ((int) ky + 32768) << 4) | ((long long) ((int) knx + 1) << 2) | (long long) ((int) kny + 1);
+/* voxel key packed in 64 bits: (kx+2^15) | (ky+2^15) | (knx+16) | (kny+16); returns -1 when out of the packable range.
+ * inv_rn = 1 / (coefficient of the normal components): 1 for the preprocessor (.cpp:40), 10 for the clipper (coefficients
+ * res, res, 0.1, 0.1: mapping/scene_clipper_projective_2d.cpp:46) */
+static long long lsmo_vox_key(float x, float y, float nx, float ny, float inv_res, float inv_rn) {
+  const float kx = floorf(x * inv_res), ky = floorf(y * inv_res), knx = floorf(nx * inv_rn), kny = floorf(ny * inv_rn);
+  if (!(kx >= -32768.0f && kx < 32768.0f && ky >= -32768.0f && ky < 32768.0f && knx >= -16.0f && knx <= 15.0f && kny >= -16.0f && kny <= 15.0f)) return -1;
+  return ((long long) ((int) kx + 32768) << 26) | ((long long) ((int) ky + 32768) << 10) | ((long long) ((int) knx + 16) << 5) | (long long) ((int) kny + 16);
+}
+/* F2.3: PointCloud::voxelize over k points given as four arrays; returns the number of voxels written to out */
+static int lsmo_voxelize(const float* ox, const float* oy, const float* onx, const float* ony, int k, float inv_res, float inv_rn, lsmo_point* out) {
+  lsmo_vox* vx = (lsmo_vox*) malloc(sizeof(lsmo_vox) * (size_t) (k > 0 ? k : 1));
+  int nv = 0, n_out = 0;
+  for (int i = 0; i < k; ++i) { const long long key = lsmo_vox_key(ox[i], oy[i], onx[i], ony[i], inv_res, inv_rn); if (key >= 0) { vx[nv].key = key; vx[nv].idx = i; ++nv; } }
+  qsort(vx, (size_t) nv, sizeof(lsmo_vox), lsmo_vox_cmp);
+  for (int b = 0; b < nv;) {
+    int e = b; float ax = 0.0f, ay = 0.0f, anx = 0.0f, any_ = 0.0f;
+    while (e < nv && vx[e].key == vx[b].key) { const int i = vx[e].idx; ax += ox[i]; ay += oy[i]; anx += onx[i]; any_ += ony[i]; ++e; }
+    const float inv = 1.0f / (float) (e - b);
+    ax *= inv; ay *= inv; anx *= inv; any_ *= inv;
+    const float nn = sqrtf(fmaf(anx, anx, any_ * any_));
+    if (nn > 0.0f) { anx = anx / nn; any_ = any_ / nn; }
+    out[n_out].x = ax; out[n_out].y = ay; out[n_out].nx = anx; out[n_out].ny = any_; ++n_out;
+    b = e;
+  }
+  free(vx);
+  return n_out;
 }
 
 int lsmo_preprocess_scan_f(const lsmo_preprocessor* pp, const float* ranges, lsmo_point* out) {
@@ -243,25 +264,38 @@ int lsmo_preprocess_scan_f(const lsmo_preprocessor* pp, const float* ranges, lsm
     for (int i = 0; i < k; ++i) { out[i].x = ox[i]; out[i].y = oy[i]; out[i].nx = onx[i]; out[i].ny = ony[i]; }
     n_out = k;
   } else {                                                        /* F2.3 */
-    const float inv_res = 1.0f / pp->voxelize_resolution;
-    lsmo_vox* vx = (lsmo_vox*) malloc(sizeof(lsmo_vox) * (size_t) (k > 0 ? k : 1));
-    int nv = 0;
-    for (int i = 0; i < k; ++i) { const long long key = lsmo_vox_key(ox[i], oy[i], onx[i], ony[i], inv_res); if (key >= 0) { vx[nv].key = key; vx[nv].idx = i; ++nv; } }
-    qsort(vx, (size_t) nv, sizeof(lsmo_vox), lsmo_vox_cmp);
-    for (int b = 0; b < nv;) {
-      int e = b; float ax = 0.0f, ay = 0.0f, anx = 0.0f, any_ = 0.0f;
-      while (e < nv && vx[e].key == vx[b].key) { const int i = vx[e].idx; ax += ox[i]; ay += oy[i]; anx += onx[i]; any_ += ony[i]; ++e; }
-      const float inv = 1.0f / (float) (e - b);
-      ax *= inv; ay *= inv; anx *= inv; any_ *= inv;
-      const float nn = sqrtf(fmaf(anx, anx, any_ * any_));
-      if (nn > 0.0f) { anx = anx / nn; any_ = any_ / nn; }
-      out[n_out].x = ax; out[n_out].y = ay; out[n_out].nx = anx; out[n_out].ny = any_; ++n_out;
-      b = e;
-    }
-    free(vx);
+    n_out = lsmo_voxelize(ox, oy, onx, ony, k, 1.0f / pp->voxelize_resolution, 1.0f, out);
   }
   free(px); free(ox);
   return n_out;
+}
+
+/* SceneClipperProjective2D::compute with voxelize_resolution > 0 (mapping/scene_clipper_projective_2d.cpp:36-48): the filled cells'
+ * transformed points, in ascending column and still in the SENSOR frame, are voxelised with coefficients (res, res, 0.1, 0.1) --
+ * assumption F2.3 with the normal components scaled by 1 / 0.1 -- and only then moved to the robot frame (:60-62). */
+int lsmo_clip_scene_voxelized_f(const lsmo_projector* pr, const lsmo_point* scene, int n_scene, const float robot_in_local_map[3],
+                                const float sensor_in_robot[3], float voxelize_resolution, lsmo_point* out) {
+  if (!(voxelize_resolution > 0.0f)) return lsmo_clip_scene_f(pr, scene, n_scene, robot_in_local_map, sensor_in_robot, out, NULL);
+  if (!pr || pr->canvas_cols <= 0) return LSMO_BAD_ARGUMENT;
+  const int cols = pr->canvas_cols;
+  float cam[3]; lsmo_compose_f(robot_in_local_map, sensor_in_robot, cam);
+  const float ident[3] = {0.0f, 0.0f, 0.0f};
+  lsmo_point* tmp = (lsmo_point*) malloc(sizeof(lsmo_point) * (size_t) cols);
+  const int k = lsmo_clip_scene_f(pr, scene, n_scene, cam, ident, tmp, NULL);      /* camera at robot * sensor, points left in the sensor frame */
+  if (k < 0) { free(tmp); return k; }
+  float* ox = (float*) malloc(sizeof(float) * 4 * (size_t) (k > 0 ? k : 1)); float* oy = ox + k; float* onx = oy + k; float* ony = onx + k;
+  for (int i = 0; i < k; ++i) { ox[i] = tmp[i].x; oy[i] = tmp[i].y; onx[i] = tmp[i].nx; ony[i] = tmp[i].ny; }
+  const int n = lsmo_voxelize(ox, oy, onx, ony, k, 1.0f / voxelize_resolution, 1.0f / 0.1f, out);
+  if (!(sensor_in_robot[0] == 0.0f && sensor_in_robot[1] == 0.0f && sensor_in_robot[2] == 0.0f)) {
+    iso_f S = v2t_f(sensor_in_robot);
+    for (int i = 0; i < n; ++i) {
+      float x, y, nx, ny;
+      xf_point_f(&S, out[i].x, out[i].y, &x, &y); xf_normal_f(&S, out[i].nx, out[i].ny, &nx, &ny);
+      out[i].x = x; out[i].y = y; out[i].nx = nx; out[i].ny = ny;
+    }
+  }
+  free(ox); free(tmp);
+  return n;
 }
 
 /* ---- batch driver (cpu_baseline): static block partition over pthreads ---------------------- */

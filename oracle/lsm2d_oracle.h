@@ -190,6 +190,9 @@ int lsmo_clip_scene_f(const lsmo_projector* pr, const lsmo_point* scene, int n_s
                       const float sensor_in_robot[3], lsmo_point* out, int* out_src);
 int lsmo_clip_scene_d(const lsmo_projector* pr, const lsmo_point* scene, int n_scene, const double robot_in_local_map[3],
                       const double sensor_in_robot[3], lsmo_point* out, int* out_src);
+/* voxelize_resolution > 0 branch of the clipper (scene_clipper_projective_2d.cpp:36-48); <= 0: lsmo_clip_scene_f */
+int lsmo_clip_scene_voxelized_f(const lsmo_projector* pr, const lsmo_point* scene, int n_scene, const float robot_in_local_map[3],
+                                const float sensor_in_robot[3], float voxelize_resolution, lsmo_point* out);
 int lsmo_merge_scene_f(const lsmo_projector* pr, lsmo_point* scene, int n_scene, const lsmo_point* meas, int n_meas,
                        const float measurement_in_scene[3], float merge_threshold, int counts[3]);
 int lsmo_merge_scene_d(const lsmo_projector* pr, lsmo_point* scene, int n_scene, const lsmo_point* meas, int n_meas,

@@ -268,6 +268,19 @@ def clip_scene(pr: Projector, scene, robot_in_local_map, sensor_in_robot=(0.0, 0
     return out[:k].copy(), src[:k].copy()
 
 
+def clip_scene_voxelized(pr: Projector, scene, robot_in_local_map, sensor_in_robot=(0.0, 0.0, 0.0), voxelize_resolution=0.05):
+    """SceneClipperProjective2D::compute, voxelize_resolution > 0 branch (fp32 mirror).  Returns clipped float32 [k,4] in the robot frame."""
+    scene, ps = _pts(scene)
+    out = np.empty((pr.canvas_cols, 4), np.float32)
+    r = np.ascontiguousarray(robot_in_local_map, np.float32); s_ = np.ascontiguousarray(sensor_in_robot, np.float32)
+    fn = lib().lsmo_clip_scene_voxelized_f
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    k = fn(C.cast(C.byref(pr), C.c_void_p), ps, len(scene), r.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p), float(voxelize_resolution),
+           out.ctypes.data_as(C.c_void_p))
+    assert k >= 0, k
+    return out[:k].copy()
+
+
 def merge_scene(pr: Projector, scene, meas, measurement_in_scene, merge_threshold=0.2, double=False):
     """MergerProjective2D::compute. Returns (new scene float32 [n',4], counts (new, merged, replaced))."""
     dt, sfx = _real(double)

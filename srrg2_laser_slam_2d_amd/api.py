@@ -548,9 +548,10 @@ def linearize(ctx: Context, slice_params: SliceParams, fixed, moving, correspond
 
 
 class SceneClipperProjective2D:
-    """mapping/scene_clipper_projective_2d.{h,cpp} with voxelize_resolution = 0 (both shipped configs, MULTI.json:673-683):
-    keeps what the sensor sees of the local map, at most one point per projector column, in the robot frame.  The clipped
-    scene stays on the device (a reserved CloudSet) and is what the tracker hands to the aligner as ``moving``."""
+    """mapping/scene_clipper_projective_2d.{h,cpp}: keeps what the sensor sees of the local map, at most one point per projector
+    column, in the robot frame; ``voxelize_resolution`` > 0 additionally voxelises the clipped cloud (.cpp:36-48; both shipped configs
+    use 0, MULTI.json:673-683).  The clipped scene stays on the device (a reserved CloudSet) and is what the tracker hands to the
+    aligner as ``moving``."""
 
     def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, voxelize_resolution: float = 0.0,
                  asynchronous: bool = False):
@@ -583,27 +584,29 @@ class SceneClipperProjective2D:
             raise RuntimeError("SceneClipperProjective2D::compute| missing local OR global scene")
         if self.param_projector is None:
             raise RuntimeError("SceneClipperProjective2D::compute| Missing Projector")
-        if self.param_voxelize_resolution > 0:
-            raise NotImplementedError("voxelize_resolution > 0 is not on the device path (shipped configs use 0)")
         cols = self.param_projector.param_canvas_cols
         if self._clipped is None:
             self._clipped = CloudSet.reserved(self._ctx, cols)
         pr = self.param_projector.struct()
+        vox = float(self.param_voxelize_resolution)
+        lib = self._ctx._lib
+        args = (self._ctx.handle, C.byref(pr), self._full_scene.handle, 0, self._robot_in_local_map.ctypes.data_as(C.c_void_p),
+                self._sensor_in_robot.ctypes.data_as(C.c_void_p))
+
+        def call(out_n, out_src):      # voxelize_resolution > 0: the branch of scene_clipper_projective_2d.cpp:36-48 (no source indices)
+            if vox > 0:
+                return check(lib.lsm2d_clip_scene_voxelized(*args, vox, self._clipped.handle, out_n, None), "lsm2d_clip_scene_voxelized", self._ctx.handle)
+            return check(lib.lsm2d_clip_scene(*args, self._clipped.handle, out_n, out_src), "lsm2d_clip_scene", self._ctx.handle)
+
         if self.asynchronous:
-            check(self._ctx._lib.lsm2d_clip_scene(self._ctx.handle, C.byref(pr), self._full_scene.handle, 0,
-                                                  self._robot_in_local_map.ctypes.data_as(C.c_void_p),
-                                                  self._sensor_in_robot.ctypes.data_as(C.c_void_p), self._clipped.handle, None, None),
-                  "lsm2d_clip_scene", self._ctx.handle)
+            call(None, None)
             self._clipped._set_pending()
             self.source_indices = np.zeros(0, np.int32)
             return self._clipped
         n = C.c_int32(0); src = np.empty(cols, np.int32)
-        check(self._ctx._lib.lsm2d_clip_scene(self._ctx.handle, C.byref(pr), self._full_scene.handle, 0,
-                                              self._robot_in_local_map.ctypes.data_as(C.c_void_p),
-                                              self._sensor_in_robot.ctypes.data_as(C.c_void_p), self._clipped.handle, C.byref(n),
-                                              src.ctypes.data_as(C.c_void_p)), "lsm2d_clip_scene", self._ctx.handle)
+        call(C.byref(n), src.ctypes.data_as(C.c_void_p))
         self._clipped._set_count(n.value)
-        self.source_indices = src[: n.value].copy()
+        self.source_indices = src[: n.value].copy() if not vox > 0 else np.zeros(0, np.int32)
         return self._clipped
 
 

@@ -857,12 +857,17 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
 }
 
 // ---- SceneClipperProjective2D ------------------------------------------------------------------------------
-extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* scene, int32_t si,
-                                const float robot_in_local_map[3], const float sensor_in_robot[3], lsm2d_cloudset* clipped,
-                                int32_t* out_n, int32_t* out_src) {
+// vox_res > 0: the voxelize_resolution branch (mapping/scene_clipper_projective_2d.cpp:36-48) -- the clip kernels leave the cloud in the
+// SENSOR frame and k_voxelize_clipped voxelises it and moves it to the robot frame
+static int clip_scene_impl(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* scene, int32_t si,
+                           const float robot_in_local_map[3], const float sensor_in_robot[3], float vox_res, lsm2d_cloudset* clipped,
+                           int32_t* out_n, int32_t* out_src) {
   if (!ctx || !pr || !robot_in_local_map || !sensor_in_robot || !clipped || !valid_cloud_index(scene, si) || clipped->n_clouds != 1 ||
       clipped == scene || (!out_n && out_src))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "clip_scene: bad argument");
+  const bool vox = vox_res > 0.0f;
+  if (vox && out_src) return fail(ctx, LSM2D_BAD_ARGUMENT, "clip_scene: a voxelised cloud has no source indices");
+  if (vox && pr->canvas_cols > kVoxMax) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "clip_scene: voxelisation takes at most 2048 columns");
   // out_n == NULL: asynchronous -- nothing comes back, the clipped set's size stays on the device until somebody asks
   if (scene->count_pending && scene->h_count[si] > 32768) { const int rc0 = resolve_count(scene); if (rc0) return rc0; }
   ProjK P;
@@ -887,12 +892,14 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   ClipEmitArgs A;
   A.gcanvas = d_canvas; A.cols = P.cols; A.xy = scene->d_xy + scene->h_start[si]; A.nrm = scene->d_nrm + scene->h_start[si];
   A.T = T; A.S = make_iso(sensor_in_robot);
-  A.s_identity = sensor_in_robot[0] == 0.0f && sensor_in_robot[1] == 0.0f && sensor_in_robot[2] == 0.0f;
+  const bool s_ident = sensor_in_robot[0] == 0.0f && sensor_in_robot[1] == 0.0f && sensor_in_robot[2] == 0.0f;
+  A.s_identity = s_ident || vox;                  // voxelisation happens in the sensor frame
   // synchronous form: source indices and the count go straight to the pinned staging buffer (no device-to-host copy)
   char* dvo = (char*) ctx->d_scratch;
   if (out_n) { rc = stage_device_view(ctx, &dvo); if (rc) return rc; *(int32_t*) ((char*) ctx->h_stage + o_cnt) = kStatusNotWritten; }
   A.out_xy = clipped->d_xy; A.out_nrm = clipped->d_nrm; A.out_src = (int32_t*) (dvo + o_src);
-  A.out_count = (int32_t*) (dvo + o_cnt); A.out_count_dev = clipped->d_count; A.host_polls = out_n != nullptr;
+  A.out_count = vox ? (int32_t*) ((char*) ctx->d_scratch + o_cnt) : (int32_t*) (dvo + o_cnt);      // with voxelisation the final count is k_voxelize_clipped's
+  A.out_count_dev = clipped->d_count; A.host_polls = out_n != nullptr && !vox;
   if (small) {
     ClipSmallArgs CS; CS.xy = A.xy; CS.nrm = A.nrm; CS.n = scene->h_count[si]; CS.n_dev = scene->count_pending ? scene->d_count : nullptr; CS.proj = P; CS.emit = A;
     hipLaunchKernelGGL(k_clip_small, dim3(1), dim3(kFindBlock), sizeof(u64) * (size_t) P.cols, ctx->stream, CS);
@@ -900,6 +907,15 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
     hipLaunchKernelGGL(k_clip_emit, dim3(1), dim3(kFindBlock), 0, ctx->stream, A);
   }
   HIPCHK(ctx, hipGetLastError());
+  if (vox) {
+    VoxArgs V;
+    V.xy = clipped->d_xy; V.nrm = clipped->d_nrm; V.count_dev = clipped->d_count;
+    V.inv_rx = 1.0f / vox_res; V.inv_rn = 1.0f / 0.1f;      // coefficients (res, res, 0.1, 0.1): scene_clipper_projective_2d.cpp:46
+    V.S = make_iso(sensor_in_robot); V.s_identity = s_ident;
+    V.out_count = out_n ? (int32_t*) (dvo + o_cnt) : nullptr; V.host_polls = out_n != nullptr;
+    hipLaunchKernelGGL(k_voxelize_clipped, dim3(1), dim3(kVoxBlock), 0, ctx->stream, V);
+    HIPCHK(ctx, hipGetLastError());
+  }
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = ctx->kernel_timing;
   if (!out_n) {                               // at most one point per column
@@ -911,6 +927,17 @@ extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, c
   clipped->h_count[0] = n; clipped->total = n; clipped->count_pending = false; *out_n = n;
   if (out_src) memcpy(out_src, (char*) ctx->h_stage + o_src, sizeof(int32_t) * (size_t) n);
   return LSM2D_SUCCESS;
+}
+
+extern "C" int lsm2d_clip_scene(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* scene, int32_t si,
+                                const float robot_in_local_map[3], const float sensor_in_robot[3], lsm2d_cloudset* clipped,
+                                int32_t* out_n, int32_t* out_src) {
+  return clip_scene_impl(ctx, pr, scene, si, robot_in_local_map, sensor_in_robot, 0.0f, clipped, out_n, out_src);
+}
+extern "C" int lsm2d_clip_scene_voxelized(lsm2d_context* ctx, const lsm2d_projector* pr, const lsm2d_cloudset* scene, int32_t si,
+                                          const float robot_in_local_map[3], const float sensor_in_robot[3], float voxelize_resolution,
+                                          lsm2d_cloudset* clipped, int32_t* out_n, int32_t* out_src) {
+  return clip_scene_impl(ctx, pr, scene, si, robot_in_local_map, sensor_in_robot, voxelize_resolution, clipped, out_n, out_src);
 }
 
 // ---- MergerProjective2D ----------------------------------------------------------------------------------------

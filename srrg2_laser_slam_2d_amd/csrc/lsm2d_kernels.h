@@ -1386,9 +1386,110 @@ __global__ void k_pack_aos(const float2* __restrict__ xy, const float2* __restri
   }
 }
 
+// ---- PointCloud::voxelize as the reference uses it (sensor_processing/raw_data_preprocessor_projective_2d.cpp:38-41 with
+// coefficients (res, res, 1, 1); mapping/scene_clipper_projective_2d.cpp:44-48 with (res, res, 0.1, 0.1); assumption F2.3,
+// PARITY.md section 3): k points staged in LDS (s_q coordinates, s_n normals), key = floor of (x, y) * inv_rx and of the normal
+// components * inv_rn, equal keys averaged (normal re-normalised), voxels in ascending lexicographic key order.  One workgroup of
+// kVoxBlock threads, k <= kVoxMax; emit(pos, x, y, nx, ny) is called once per voxel; returns the number of voxels (every thread).
+static constexpr int kVoxBlock = 1024;
+static constexpr int kVoxMax = 2048;
+template <typename Emit>
+LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int k, float inv_rx, float inv_rn, int* s_wave_tot, int* s_base,
+                           int tid, Emit emit) {
+  int np2 = 1; while (np2 < k) np2 <<= 1;
+  for (int i = tid; i < np2; i += kVoxBlock) {
+    u64 key = ~0ull;
+    if (i < k) {
+      const float kx = __builtin_floorf(s_q[i].x * inv_rx), ky = __builtin_floorf(s_q[i].y * inv_rx);
+      const float knx = __builtin_floorf(s_n[i].x * inv_rn), kny = __builtin_floorf(s_n[i].y * inv_rn);
+      if (kx >= -32768.0f && kx < 32768.0f && ky >= -32768.0f && ky < 32768.0f && knx >= -16.0f && knx <= 15.0f && kny >= -16.0f && kny <= 15.0f) {
+        const u64 v = ((u64) ((int) kx + 32768) << 26) | ((u64) ((int) ky + 32768) << 10) | ((u64) ((int) knx + 16) << 5) | (u64) ((int) kny + 16);
+        key = (v << 16) | (u64) i;
+      }
+    }
+    s_key[i] = key;
+  }
+  __syncthreads();
+  // bitonic network, one compare-exchange per thread and step (np2 / 2 <= kVoxBlock).  Pair t touches elements inside the
+  // aligned 128-element block of its wave whenever stride <= 64, so those steps need no workgroup barrier -- LDS operations
+  // of one wave complete in order -- only the compiler must keep them in order (wavefront fence).  6 of the 55 steps of a
+  // 1024-key sort cross waves.
+  static_assert(kVoxMax / 2 <= kVoxBlock, "one compare-exchange per thread");
+  for (int size = 2; size <= np2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int t = tid;
+      if (t < (np2 >> 1)) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const u64 a = s_key[lo], b = s_key[hi];
+        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+      }
+      // the next step's stride is stride / 2, or `size` when this was the last step of its stage
+      if (stride > 64 || (stride == 1 && size > 64)) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) *s_base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < np2; t0 += kVoxBlock) {
+    const int t = t0 + tid;
+    bool head = false; u64 key = ~0ull;
+    if (t < np2) { key = s_key[t]; head = key != ~0ull && (t == 0 || (s_key[t - 1] >> 16) != (key >> 16)); }
+    const int pos = block_compact_offset(head, s_wave_tot, s_base, tid, kVoxBlock / 64);
+    if (head) {
+      float ax = 0.0f, ay = 0.0f, anx = 0.0f, any_ = 0.0f; int cnt = 0;
+      for (int e = t; e < np2 && (s_key[e] >> 16) == (key >> 16); ++e) {
+        const int i = (int) (s_key[e] & 0xFFFFull);
+        ax += s_q[i].x; ay += s_q[i].y; anx += s_n[i].x; any_ += s_n[i].y; ++cnt;
+      }
+      const float inv = 1.0f / (float) cnt;
+      ax *= inv; ay *= inv; anx *= inv; any_ *= inv;
+      const float nn = __builtin_sqrtf(__builtin_fmaf(anx, anx, any_ * any_));
+      if (nn > 0.0f) { anx = anx / nn; any_ = any_ / nn; }
+      emit(pos, ax, ay, anx, any_);
+    }
+  }
+  __syncthreads();
+  return *s_base;
+}
+
+// the clipper's voxelize_resolution > 0 branch (mapping/scene_clipper_projective_2d.cpp:36-48,60-62): the clipped cloud -- written
+// by the clip kernels in the SENSOR frame, ascending column -- is voxelised with coefficients (res, res, 0.1, 0.1) and only then
+// moved to the robot frame by sensor_in_robot.  In place: everything is staged in LDS first and a voxelised cloud never grows.
+struct VoxArgs {
+  float2* xy; float2* nrm; int32_t* count_dev;      // the clipped set (one cloud)
+  float inv_rx, inv_rn; Iso S; int32_t s_identity;
+  int32_t* out_count; int32_t host_polls;            // the synchronous form's count, in pinned memory, written last
+};
+__global__ __launch_bounds__(kVoxBlock) void k_voxelize_clipped(const VoxArgs A) {
+  __shared__ float2 s_q[kVoxMax];
+  __shared__ float2 s_n[kVoxMax];
+  __shared__ u64 s_key[kVoxMax];
+  __shared__ int s_wave_tot[kVoxBlock / 64];
+  __shared__ int s_base;
+  const int tid = threadIdx.x;
+  int k = *A.count_dev; if (k > kVoxMax) k = kVoxMax;      // the host refuses canvases beyond kVoxMax columns
+  for (int i = tid; i < k; i += kVoxBlock) { s_q[i] = A.xy[i]; s_n[i] = A.nrm[i]; }
+  __syncthreads();
+  const int nv = voxelize_lds(s_q, s_n, s_key, k, A.inv_rx, A.inv_rn, s_wave_tot, &s_base, tid, [&](int pos, float x, float y, float nx, float ny) {
+    if (!A.s_identity) {
+      float tx, ty, tnx, tny;
+      xf_point(A.S, x, y, tx, ty); xf_normal(A.S, nx, ny, tnx, tny);
+      x = tx; y = ty; nx = tnx; ny = tny;
+    }
+    A.xy[pos] = make_float2(x, y); A.nrm[pos] = make_float2(nx, ny);
+  });
+  if (A.host_polls) {
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) { *A.count_dev = nv; __hip_atomic_store(A.out_count, nv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  } else if (tid == 0) { *A.count_dev = nv; if (A.out_count) *A.out_count = nv; }
+}
+
 // ---- RawDataPreprocessorProjective2D (row f2): one workgroup per scan, everything in LDS -----------------------
-static constexpr int kPrepBlock = 1024;     // one beam per thread for the window walks; one compare-exchange per thread in the sort
-static constexpr int kPrepMaxBeams = 2048;
+static constexpr int kPrepBlock = kVoxBlock;     // one beam per thread for the window walks; one compare-exchange per thread in the sort
+static constexpr int kPrepMaxBeams = kVoxMax;
 struct PrepArgs {
   const float* ranges; const float2* beam_dir;      // [n_scans][n_beams]; (cos, sin) per beam, host-computed
   int32_t n_beams, stride;                           // stride: points reserved per output cloud (even)
@@ -1465,61 +1566,9 @@ LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
     return;
   }
   // ---- F2.3 voxelisation: sort (key, index), average equal-key runs, ascending key order
-  int np2 = 1; while (np2 < k) np2 <<= 1;
-  for (int i = tid; i < np2; i += kPrepBlock) {
-    u64 key = ~0ull;
-    if (i < k) {
-      const float kx = __builtin_floorf(s_q[i].x * A.inv_res), ky = __builtin_floorf(s_q[i].y * A.inv_res);
-      const float knx = __builtin_floorf(s_n[i].x), kny = __builtin_floorf(s_n[i].y);
-      if (kx >= -32768.0f && kx < 32768.0f && ky >= -32768.0f && ky < 32768.0f && knx >= -1.0f && knx <= 1.0f && kny >= -1.0f && kny <= 1.0f) {
-        const u64 v = ((u64) ((int) kx + 32768) << 20) | ((u64) ((int) ky + 32768) << 4) | ((u64) ((int) knx + 1) << 2) | (u64) ((int) kny + 1);
-        key = (v << 16) | (u64) i;
-      }
-    }
-    s_key[i] = key;
-  }
-  __syncthreads();
-  // bitonic network, one compare-exchange per thread and step (np2 / 2 <= kPrepBlock).  Pair t touches elements inside the
-  // aligned 128-element block of its wave whenever stride <= 64, so those steps need no workgroup barrier -- LDS operations
-  // of one wave complete in order -- only the compiler must keep them in order (wavefront fence).  6 of the 55 steps of a
-  // 1024-key sort cross waves.
-  static_assert(kPrepMaxBeams / 2 <= kPrepBlock, "one compare-exchange per thread");
-  for (int size = 2; size <= np2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const int t = tid;
-      if (t < (np2 >> 1)) {
-        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const u64 a = s_key[lo], b = s_key[hi];
-        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
-      }
-      // the next step's stride is stride / 2, or `size` when this was the last step of its stage
-      if (stride > 64 || (stride == 1 && size > 64)) __syncthreads();
-      else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (int t0 = 0; t0 < np2; t0 += kPrepBlock) {
-    const int t = t0 + tid;
-    bool head = false; u64 key = ~0ull;
-    if (t < np2) { key = s_key[t]; head = key != ~0ull && (t == 0 || (s_key[t - 1] >> 16) != (key >> 16)); }
-    const int pos = block_compact_offset(head, s_wave_tot, &s_base, tid, kPrepBlock / 64);
-    if (head) {
-      float ax = 0.0f, ay = 0.0f, anx = 0.0f, any_ = 0.0f; int cnt = 0;
-      for (int e = t; e < np2 && (s_key[e] >> 16) == (key >> 16); ++e) {
-        const int i = (int) (s_key[e] & 0xFFFFull);
-        ax += s_q[i].x; ay += s_q[i].y; anx += s_n[i].x; any_ += s_n[i].y; ++cnt;
-      }
-      const float inv = 1.0f / (float) cnt;
-      ax *= inv; ay *= inv; anx *= inv; any_ *= inv;
-      const float nn = __builtin_sqrtf(__builtin_fmaf(anx, anx, any_ * any_));
-      if (nn > 0.0f) { anx = anx / nn; any_ = any_ / nn; }
-      oxy[pos] = make_float2(ax, ay); onr[pos] = make_float2(anx, any_);
-    }
-  }
-  if (tid == 0) A.out_count[scan] = s_base;
+  const int nv = voxelize_lds(s_q, s_n, s_key, k, A.inv_res, 1.0f, s_wave_tot, &s_base, tid,
+                              [&](int pos, float x, float y, float nx, float ny) { oxy[pos] = make_float2(x, y); onr[pos] = make_float2(nx, ny); });
+  if (tid == 0) A.out_count[scan] = nv;
 }
 __global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs A) { preprocess_scan_body(A, blockIdx.x); }
 // several scans, each with its own sensor geometry and its own output set, side by side (the live tracker's front and rear scanner:

@@ -177,7 +177,7 @@ class ReservedCloud {
   Context& _ctx; lsm2d_cloudset* _h = nullptr;
 };
 
-// SceneClipperProjective2D (mapping/scene_clipper_projective_2d.{h,cpp}), voxelize_resolution = 0
+// SceneClipperProjective2D (mapping/scene_clipper_projective_2d.{h,cpp})
 class SceneClipperProjective2D {
  public:
   explicit SceneClipperProjective2D(Context& ctx) : _ctx(ctx) {}
@@ -191,12 +191,13 @@ class SceneClipperProjective2D {
     if (!param_projector) throw std::runtime_error("SceneClipperProjective2D::compute| Missing Projector");                     // .cpp:19-21
     const lsm2d_projector pr = param_projector->abi(); int32_t n = -1;
     // asynchronous: the call only queues the work; the clipped set's size stays on the device until somebody asks (returns -1)
-    check(lsm2d_clip_scene(_ctx.get(), &pr, _scene->get(), 0, _robot_in_local_map.data(), _sensor_in_robot.data(), _clipped->get(),
-                           asynchronous ? nullptr : &n, nullptr),
+    check(lsm2d_clip_scene_voxelized(_ctx.get(), &pr, _scene->get(), 0, _robot_in_local_map.data(), _sensor_in_robot.data(),
+                                     param_voxelize_resolution, _clipped->get(), asynchronous ? nullptr : &n, nullptr),
           "lsm2d_clip_scene", _ctx.get());
     return n;
   }
   bool asynchronous = false;
+  float param_voxelize_resolution = 0.f;                                   // .h: "unproject voxelization resolution"; > 0: .cpp:36-48
  private:
   Context& _ctx; const ReservedCloud* _scene = nullptr; ReservedCloud* _clipped = nullptr;
   Vector3f _robot_in_local_map{{0.f, 0.f, 0.f}}, _sensor_in_robot{{0.f, 0.f, 0.f}};

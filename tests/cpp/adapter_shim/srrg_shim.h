@@ -1,0 +1,277 @@
+// srrg_shim.h -- TEST INFRASTRUCTURE ONLY, never shipped, never part of the product.
+//
+// Minimal stand-ins for the parts of the srrg2 stack (srrg2_core, srrg2_solver, srrg2_slam_interfaces -- absent from this image
+// and from the GPU box) and of the reference package's own class declarations that the SRRG-side adapter sources under
+// adapters/srrg/ are written against.  They exist for ONE purpose: so that those translation units are compiled (here, by g++) and
+// driven on the GPU (tests/cpp/adapter_driver.cpp) instead of being un-compiled text.  Only what the adapters touch is declared,
+// with the names the reference itself uses in-tree:
+//   base-class members of a finder     registration/correspondence_finder_projective_2d.cpp:18-77, ..._kd_tree_2d.cpp:5-29
+//   PARAM / property accessors          registration/correspondence_finder_kd_tree_2d.h:23-34, ..._nn_2d.h:20-30
+//   aligner / slice driving surface     apps/visual_test_aligner_2d.cpp:102-156
+//   property containers                 apps/visual_test_aligner_2d.cpp:108-118
+// Names that could NOT be confirmed from the reference tree are the ones adapters/srrg/upstream_access.h isolates; the shim
+// implements exactly those accessors, so a maintainer with the real stack adjusts one header.
+// Nothing here restates reference ALGORITHMS: every compute() of a shim base class is empty or aborts.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#define PARAM(TYPE, NAME, DESC, DEFAULT, FLAG) TYPE param_##NAME = TYPE(#NAME, DESC, this, DEFAULT, FLAG)
+#define PARAM_VECTOR(TYPE, NAME, DESC, FLAG) TYPE param_##NAME = TYPE(#NAME, DESC, this, FLAG)
+
+namespace srrg2_core {
+  // ---- the handful of Eigen types / operations the adapters use
+  struct Vector2f {
+    float v[2] = {0, 0};
+    Vector2f() {}
+    Vector2f(float x_, float y_) { v[0] = x_; v[1] = y_; }
+    float& x() { return v[0]; } float& y() { return v[1]; }
+    const float& x() const { return v[0]; } const float& y() const { return v[1]; }
+  };
+  struct Vector3f {
+    float v[3] = {0, 0, 0};
+    Vector3f() {}
+    Vector3f(float x_, float y_, float z_) { v[0] = x_; v[1] = y_; v[2] = z_; }
+    float& x() { return v[0]; } float& y() { return v[1]; } float& z() { return v[2]; }
+    const float& x() const { return v[0]; } const float& y() const { return v[1]; } const float& z() const { return v[2]; }
+  };
+  struct Matrix3f {
+    float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float& operator()(int r, int c) { return m[3 * r + c]; }
+    const float& operator()(int r, int c) const { return m[3 * r + c]; }
+    void setIdentity() { for (int i = 0; i < 9; ++i) m[i] = (i % 4 == 0) ? 1.f : 0.f; }
+    void setZero() { for (int i = 0; i < 9; ++i) m[i] = 0.f; }
+    static Matrix3f Identity() { Matrix3f r; r.setIdentity(); return r; }
+  };
+  struct Isometry2f {       // R = [[c, -s], [s, c]], t
+    float c = 1.f, s = 0.f, tx = 0.f, ty = 0.f;
+    static Isometry2f Identity() { return Isometry2f(); }
+    Isometry2f inverse() const { Isometry2f r; r.c = c; r.s = -s; r.tx = -(c * tx + s * ty); r.ty = -(-s * tx + c * ty); return r; }
+    Isometry2f operator*(const Isometry2f& o) const {
+      Isometry2f r; r.c = c * o.c - s * o.s; r.s = s * o.c + c * o.s; r.tx = c * o.tx - s * o.ty + tx; r.ty = s * o.tx + c * o.ty + ty; return r;
+    }
+  };
+  namespace geometry2d {
+    inline Vector3f t2v(const Isometry2f& T) { return Vector3f(T.tx, T.ty, std::atan2(T.s, T.c)); }
+    inline Isometry2f v2t(const Vector3f& v) { Isometry2f T; T.c = std::cos(v.z()); T.s = std::sin(v.z()); T.tx = v.x(); T.ty = v.y(); return T; }
+  } // namespace geometry2d
+
+  // ---- point cloud types (srrg_pcl)
+  struct PointNormal2f {
+    Vector2f _c, _n;
+    Vector2f& coordinates() { return _c; } const Vector2f& coordinates() const { return _c; }
+    Vector2f& normal() { return _n; } const Vector2f& normal() const { return _n; }
+  };
+  using PointNormal2fVectorCloud = std::vector<PointNormal2f>;
+  struct Correspondence {
+    int fixed_idx = -1, moving_idx = -1; float response = 0.f;
+    Correspondence() {}
+    Correspondence(int f_, int m_, float r_ = 0.f) : fixed_idx(f_), moving_idx(m_), response(r_) {}
+  };
+  using CorrespondenceVector = std::vector<Correspondence>;
+
+  // ---- properties / configurables (srrg_property, srrg_config)
+  class Configurable { public: virtual ~Configurable() {} };
+  class PropertyBase { public: virtual ~PropertyBase() {} };
+  template <typename T>
+  class Property_ : public PropertyBase {
+  public:
+    Property_(const char* name_, const char*, void*, const T& def_, bool* flag_ = nullptr) : _name(name_), _value(def_), _flag(flag_) {}
+    Property_(const std::string& name_, const std::string&, class PropertyContainerBase* owner_);
+    const T& value() const { return _value; }
+    void setValue(const T& v_) { _value = v_; if (_flag) *_flag = true; }
+    const std::string& name() const { return _name; }
+  protected:
+    std::string _name; T _value{}; bool* _flag = nullptr;
+  };
+  using PropertyFloat = Property_<float>;
+  using PropertyInt = Property_<int>;
+  using PropertyString = Property_<std::string>;
+  template <typename C>
+  class PropertyConfigurable_ {
+  public:
+    PropertyConfigurable_(const char*, const char*, void*, std::shared_ptr<C> def_, bool* flag_ = nullptr) : _value(def_), _flag(flag_) {}
+    std::shared_ptr<C> value() const { return _value; }
+    C* operator->() const { return _value.get(); }
+    template <typename D> void setValue(std::shared_ptr<D> v_) { _value = v_; if (_flag) *_flag = true; }
+  protected:
+    std::shared_ptr<C> _value; bool* _flag = nullptr;
+  };
+  template <typename C>
+  class PropertyConfigurableVector_ {
+  public:
+    PropertyConfigurableVector_(const char*, const char*, void*, bool* = nullptr) {}
+    size_t size() const { return _v.size(); }
+    std::shared_ptr<C> value(size_t i) const { return _v[i]; }
+    template <typename D> void pushBack(std::shared_ptr<D> v_) { _v.push_back(v_); }
+  protected:
+    std::vector<std::shared_ptr<C>> _v;
+  };
+  // dynamic containers holding named properties (apps/visual_test_aligner_2d.cpp:108-118)
+  class PropertyContainerBase {
+  public:
+    virtual ~PropertyContainerBase() {}
+    std::map<std::string, PropertyBase*> _props;
+    PropertyBase* property(const std::string& name_) const { auto it = _props.find(name_); return it == _props.end() ? nullptr : it->second; }
+  };
+  using PropertyContainerDynamic = PropertyContainerBase;
+  template <typename T>
+  Property_<T>::Property_(const std::string& name_, const std::string&, PropertyContainerBase* owner_) : _name(name_) { if (owner_) owner_->_props[name_] = this; }
+
+  // ---- projector parameters (srrg_pcl/point_projector_types.h): only the PARAMs the reference sets (apps/synthetic_scene_generator.cpp:69-75)
+  class PointNormal2fProjectorPolar : public Configurable {
+  public:
+    PARAM(PropertyInt, canvas_cols, "", 721, 0);
+    PARAM(PropertyInt, canvas_rows, "", 1, 0);
+    PARAM(PropertyFloat, angle_col_min, "", -3.14159f, 0);
+    PARAM(PropertyFloat, angle_col_max, "", 3.14159f, 0);
+    PARAM(PropertyFloat, range_min, "", 0.3f, 0);
+    PARAM(PropertyFloat, range_max, "", 20.f, 0);
+  };
+  using PointNormal2fProjectorPolarPtr = std::shared_ptr<PointNormal2fProjectorPolar>;
+} // namespace srrg2_core
+
+namespace srrg2_solver {
+  class RobustifierBase : public srrg2_core::Configurable {};
+  class RobustifierCauchy : public RobustifierBase {
+  public:
+    PARAM(srrg2_core::PropertyFloat, chi_threshold, "threshold of chi after which the kernel is active", 1.f, 0);
+  };
+  struct IterationStats {     // what aligner->iterationStats() prints (apps/visual_test_aligner_2d.cpp:156)
+    int iteration = 0, num_inliers = 0, num_outliers = 0; float chi_inliers = 0.f, chi_outliers = 0.f;
+  };
+  using IterationStatsVector = std::vector<IterationStats>;
+} // namespace srrg2_solver
+
+namespace srrg2_slam_interfaces {
+  using namespace srrg2_core;
+  // CorrespondenceFinder_ : members as the reference's subclasses use them (registration/correspondence_finder_projective_2d.cpp:25-49)
+  template <typename Est_, typename Fixed_, typename Moving_>
+  class CorrespondenceFinder_ : public Configurable {
+  public:
+    using EstimateType = Est_; using FixedType = Fixed_; using MovingType = Moving_;
+    virtual void setFixed(FixedType* f_) { _fixed = f_; _fixed_changed_flag = true; }
+    virtual void setMoving(MovingType* m_) { _moving = m_; _moving_changed_flag = true; }
+    void setLocalMapInSensor(const EstimateType& e_) { _local_map_in_sensor = e_; }
+    void setCorrespondences(CorrespondenceVector* c_) { _correspondences = c_; }
+    virtual void compute() = 0;
+    virtual void reset() {}
+  protected:
+    FixedType* _fixed = nullptr; MovingType* _moving = nullptr; CorrespondenceVector* _correspondences = nullptr;
+    EstimateType _local_map_in_sensor = EstimateType::Identity();
+    bool _fixed_changed_flag = true, _moving_changed_flag = true;
+  };
+  class AlignerBase : public Configurable {
+  public:
+    enum Status { Fail = 0, NotEnoughCorrespondences = 1, NotEnoughInliers = 2, Success = 3 };
+  };
+  // slice processors: what apps/visual_test_aligner_2d.cpp:102-143 and MULTI.json:160-188 show
+  class AlignerSliceProcessorBase : public Configurable {
+  public:
+    PARAM(PropertyString, fixed_slice_name, "name of the slice in the fixed scene", "", 0);
+    PARAM(PropertyString, moving_slice_name, "name of the slice in the moving scene", "", 0);
+    PARAM(PropertyString, base_frame_id, "", "", 0);
+    PARAM(PropertyString, frame_id, "", "", 0);
+    PARAM(PropertyConfigurable_<srrg2_solver::RobustifierBase>, robustifier, "robustifier used on this slice", nullptr, 0);
+  };
+  template <typename Fixed_, typename Moving_>
+  class AlignerSliceProcessorCloud_ : public AlignerSliceProcessorBase {
+  public:
+    using FinderType = CorrespondenceFinder_<Isometry2f, Fixed_, Moving_>;
+    PARAM(PropertyConfigurable_<FinderType>, finder, "correspondence finder used in this cue", nullptr, 0);
+    PARAM(PropertyInt, min_num_correspondences, "minimum number of correspondences in this slice", 0, 0);
+    Fixed_* fixed() { return _fixed_slice; } Moving_* moving() { return _moving_slice; }
+    const CorrespondenceVector& correspondences() const { return _correspondences; }
+    CorrespondenceVector _correspondences; Fixed_* _fixed_slice = nullptr; Moving_* _moving_slice = nullptr;
+    Isometry2f _sensor_in_robot = Isometry2f::Identity();
+    const Isometry2f& sensorInRobot() const { return _sensor_in_robot; }
+  };
+  class AlignerSliceOdom2DPrior : public AlignerSliceProcessorBase {};      // MULTI.json:402-422: fixed / moving slices "odom" hold Isometry2f
+  class MultiAligner2D : public AlignerBase {
+  public:
+    PARAM(PropertyInt, max_iterations, "maximum number of iterations", 10, 0);
+    PARAM(PropertyInt, min_num_inliers, "minimum number of inliers", 10, 0);
+    PARAM_VECTOR(PropertyConfigurableVector_<AlignerSliceProcessorBase>, slice_processors, "slices", 0);
+    virtual void setFixed(PropertyContainerBase* f_) { _fixed = f_; }
+    virtual void setMoving(PropertyContainerBase* m_) { _moving = m_; }
+    void setMovingInFixed(const Isometry2f& e_) { _moving_in_fixed = e_; }
+    const Isometry2f& movingInFixed() const { return _moving_in_fixed; }
+    virtual void compute() = 0;
+    Status status() const { return _status; }
+    const Matrix3f& informationMatrix() const { return _information_matrix; }
+    const srrg2_solver::IterationStatsVector& iterationStats() const { return _iteration_stats; }
+  protected:
+    PropertyContainerBase* _fixed = nullptr; PropertyContainerBase* _moving = nullptr;
+    Isometry2f _moving_in_fixed = Isometry2f::Identity();
+    Status _status = Fail; Matrix3f _information_matrix; srrg2_solver::IterationStatsVector _iteration_stats;
+  };
+} // namespace srrg2_slam_interfaces
+
+namespace srrg2_slam_interfaces {
+  // mapping bases: members as scene_clipper_projective_2d.cpp:12-64 and merger_projective_2d.cpp:17-99 use them
+  class MergerBase : public Configurable { public: enum Status { Error = 0, Success = 1 }; };
+  template <typename Est_, typename Scene_, typename Meas_>
+  class Merger_ : public MergerBase {
+  public:
+    void setScene(Scene_* s_) { _scene = s_; } void setMeasurement(Meas_* m_) { _measurement = m_; }
+    void setMeasurementInScene(const Est_& e_) { _measurement_in_scene = e_; }
+    virtual void compute() = 0;
+    Status status() const { return _status; }
+  protected:
+    Scene_* _scene = nullptr; Meas_* _measurement = nullptr; Est_ _measurement_in_scene = Est_::Identity(); Status _status = Error;
+  };
+  template <typename Est_, typename Scene_>
+  class SceneClipper_ : public Configurable {
+  public:
+    using EstimateType = Est_; using ThisType = SceneClipper_<Est_, Scene_>;
+    enum Status { Error = 0, Successful = 1 };
+    void setFullScene(Scene_* s_) { _full_scene = s_; } void setClippedSceneInRobot(Scene_* s_) { _clipped_scene_in_robot = s_; }
+    void setRobotInLocalMap(const Est_& e_) { _robot_in_local_map = e_; } void setSensorInRobot(const Est_& e_) { _sensor_in_robot = e_; }
+    virtual void compute() = 0;
+    Status status() const { return _status; }
+  protected:
+    Scene_* _full_scene = nullptr; Scene_* _clipped_scene_in_robot = nullptr;
+    Est_ _robot_in_local_map = Est_::Identity(), _sensor_in_robot = Est_::Identity(); Status _status = Error;
+  };
+} // namespace srrg2_slam_interfaces
+
+namespace srrg2_laser_slam_2d {
+  using namespace srrg2_core;
+  using srrg2_slam_interfaces::MergerBase;
+  using MergerPointNormal2f = srrg2_slam_interfaces::Merger_<Isometry2f, PointNormal2fVectorCloud, PointNormal2fVectorCloud>;
+  using SceneClipperPointNormal2f = srrg2_slam_interfaces::SceneClipper_<Isometry2f, PointNormal2fVectorCloud>;
+  // the reference package's own declarations the adapters derive from / recognise (interface only: PARAM names and defaults
+  // from registration/correspondence_finder_normal_2f.h:9-13, ..._projective_2d.h:16-26, ..._kd_tree_2d.h:23-34, ..._nn_2d.h:20-30,
+  // registration/aligner_slice_processor_laser_2d.h:7-42); their compute() bodies are NOT restated
+  using CorrespondenceFinderNormal2f = srrg2_slam_interfaces::CorrespondenceFinder_<Isometry2f, PointNormal2fVectorCloud, PointNormal2fVectorCloud>;
+  class CorrespondenceFinderProjective2f : public CorrespondenceFinderNormal2f {
+  public:
+    PARAM(PropertyFloat, point_distance, "", 0.5f, 0);
+    PARAM(PropertyFloat, normal_cos, "", 0.8f, 0);
+    PARAM(PropertyConfigurable_<PointNormal2fProjectorPolar>, projector, "", PointNormal2fProjectorPolarPtr(new PointNormal2fProjectorPolar), 0);
+    void compute() override { throw std::logic_error("shim: the reference finder is not restated"); }
+  };
+  class CorrespondenceFinderKDTree2D : public CorrespondenceFinderNormal2f {
+  public:
+    PARAM(PropertyFloat, max_distance_m, "", 1e-2f, 0);
+    PARAM(PropertyFloat, max_leaf_range, "", 1e-2f, 0);
+    PARAM(PropertyInt, min_leaf_points, "", 20, 0);
+    PARAM(PropertyFloat, normal_cos, "", 0.8f, 0);
+    void compute() override { throw std::logic_error("shim: the reference finder is not restated"); }
+  };
+  class CorrespondenceFinderNN2D : public CorrespondenceFinderNormal2f {
+  public:
+    PARAM(PropertyFloat, max_distance_m, "", 1.f, 0);
+    PARAM(PropertyFloat, resolution, "", 0.05f, 0);
+    PARAM(PropertyFloat, normal_cos, "", 0.8f, 0);
+    void compute() override { throw std::logic_error("shim: the reference finder is not restated"); }
+  };
+  class AlignerSliceProcessorLaser2D : public srrg2_slam_interfaces::AlignerSliceProcessorCloud_<PointNormal2fVectorCloud, PointNormal2fVectorCloud> {};
+  class AlignerSliceProcessorLaser2DWithSensor : public srrg2_slam_interfaces::AlignerSliceProcessorCloud_<PointNormal2fVectorCloud, PointNormal2fVectorCloud> {};
+} // namespace srrg2_laser_slam_2d

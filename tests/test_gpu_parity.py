@@ -340,6 +340,61 @@ def test_device_resident_input(ctx, small_workload):
     assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
 
 
+def test_srrg_adapters_compile_and_run(ctx, po, small_workload, tmp_path):
+    """The SRRG-side adapter sources (adapters/srrg/*: three finder siblings, MultiAlignerHIP2D, clipper / merger siblings) compiled
+    against the stand-in srrg2 headers of tests/cpp/adapter_shim, linked with the real library and driven as the reference drives its own
+    classes (tests/cpp/adapter_driver.cpp): same pairs as the oracle, the aligner's pose / status / statistics written back, the
+    odometry-prior slice translated, an in-place change of the moving cloud seen, an unknown slice processor refused."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "adapter_driver")
+    lib_dir = os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "lib"); ad = os.path.join(ROOT, "adapters", "srrg")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + ad, "-I" + os.path.join(ROOT, "tests", "cpp", "adapter_shim"),
+                    os.path.join(ROOT, "tests", "cpp", "adapter_driver.cpp"), os.path.join(ad, "correspondence_finder_hip_2d.cpp"),
+                    os.path.join(ad, "multi_aligner_hip_2d.cpp"), "-L" + lib_dir, "-llsm2d_hip", "-Wl,-rpath," + lib_dir, "-o", exe], check=True)
+    wl = small_workload
+    f = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    f.tofile(tmp_path / "fixed.bin"); wl.map_points.tofile(tmp_path / "moving.bin")
+    x0 = wl.x0[0]; iters = 12
+    out = subprocess.run([exe, str(tmp_path / "fixed.bin"), str(tmp_path / "moving.bin"), repr(float(x0[0])), repr(float(x0[1])), repr(float(x0[2])), "1081", str(iters)],
+                         check=True, capture_output=True, text=True, timeout=180).stdout
+    r = json.loads(out.strip().splitlines()[-1])
+    # finders: the pose reaches the ABI as t2v(v2t(x0)) (one atan2 / cos / sin round trip of the stand-in geometry): pairs may differ from the
+    # oracle's at x0 by a column or two, not more
+    want = po.find(po.slice_params(), f, wl.map_points, x0)
+    got = np.array(r["pairs_projective"], np.int32).reshape(-1, 2)
+    sa = {tuple(p) for p in want.tolist()}; sb = {tuple(p) for p in got.tolist()}
+    assert r["threw_on_missing_inputs"] == 1 and len(sa ^ sb) <= 0.01 * len(sa) and len(sb) > 500
+    assert r["in_place_change_seen"] == 1 and r["pairs_before_change"] == len(got) and r["pairs_after_change"] != r["pairs_before_change"]
+    assert abs(r["n_kdtree"] - len(po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.3), f, wl.map_points, x0))) <= 5
+    assert abs(r["n_nn"] - len(po.find(po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.1), f, wl.map_points, x0))) <= 5
+    # aligner: pose, status enum (stand-in: Success = 3, NotEnoughInliers = 2), iteration statistics, information matrix, slice binding
+    o = po.align(po.aligner_params(iters), [po.slice_params()], [f], [wl.map_points], x0)
+    d = np.abs(np.array(r["pose"]) - o["pose"])
+    assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+    assert r["status"] == 3 and r["device_status"] == 0 and r["iterations"] == iters and r["slice_fixed_bound"] == 1
+    assert abs(r["last_inliers"] - o["stats"][-1].n_in) <= 3 and abs(r["H00"] - o["H"][0, 0]) < 1e-2 * o["H"][0, 0] and r["H22"] > 0
+    assert abs(r["slice_pairs"] - o["stats"][-1].n_corr) <= 3
+    assert r["pose_again"] == r["pose"]                           # reused device clouds, same bits
+    assert r["status_not_enough_inliers"] == 2
+    # the tracker's three-slice configuration: two laser slices (normal_cos 0.9 + Cauchy 0.01, normal_cos 0.8) and the odometry prior z = x0
+    sp0 = po.slice_params(normal_cos=0.9, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.01); sp1 = po.slice_params()
+    om = po.align(po.aligner_params(iters, prior_z=x0, prior_omega=np.eye(3, dtype=np.float32)), [sp0, sp1], [f, f], [wl.map_points, wl.map_points], x0)
+    dm = np.abs(np.array(r["pose_multi"]) - om["pose"])
+    assert r["status_multi"] == 3 and dm[:2].max() < POSE_TOL_M and dm[2] < POSE_TOL_RAD, dm
+    no_prior = po.align(po.aligner_params(iters), [sp0, sp1], [f, f], [wl.map_points, wl.map_points], x0)
+    assert np.abs(no_prior["pose"] - om["pose"]).max() > 1e-5      # the prior does pull: dropping it (round 1's adapter) would show
+    assert r["threw_on_unknown_slice"] == 1
+    # mapping siblings
+    opr = po.Projector(1081, -math.pi, math.pi, 0.3, 30.0, 0.0)
+    robot = synth.invert_poses(x0[None, :].astype(np.float64))[0].astype(np.float32)
+    n_clip = len(po.clip_scene(opr, wl.map_points, robot)[0])
+    assert abs(r["clipped"] - n_clip) <= 3 and 10 < r["clipped_voxelized"] < r["clipped"] and r["clip_status"] == 1
+    n_merge = len(po.merge_scene(opr, wl.map_points, f, robot, 0.2)[0])
+    assert abs(r["merged_size"] - n_merge) <= 5 and r["merge_status"] == 1
+
+
 def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     """The header-only C++ mirror (srrg2_laser_slam_2d_amd/host/lsm2d.hpp), built with plain g++ and driven like
     apps/visual_test_correspondence_finder_projective_2d.cpp / apps/visual_test_aligner_2d.cpp."""
@@ -1564,6 +1619,29 @@ def test_randomised_mapping_and_preprocessing(ctx, po):
         merged_pts += len(host)
     print("mapping fuzz: %d trials, %d clipped / %d merged / %d preprocessed points bit-exact" % (n_trials, clipped_pts, merged_pts, prep_pts))
     assert clipped_pts > 1000 and prep_pts > 1000
+
+
+def test_clipper_voxelize_branch_bit_exact(ctx, po):
+    """SceneClipperProjective2D with voxelize_resolution > 0 (mapping/scene_clipper_projective_2d.cpp:36-48) on the device: bit-exact
+    against the oracle for small and large scenes, several resolutions, with and without sensor extrinsics, synchronous and
+    asynchronous; the voxelised scene then serves as the aligner's moving cloud."""
+    world = synth.make_world(8)
+    poses = synth.sample_poses(world, 4, seed=31)
+    for n_scene, cols in ((700, 361), (6000, 721), (40000, 1081)):
+        m = synth.make_map(world, n_scene, noise_sigma=0.004, seed=n_scene)
+        proj = api.PointNormal2fProjectorPolar(cols, -math.pi, math.pi, 0.3, 20.0); opr = po.Projector(cols, -math.pi, math.pi, 0.3, 20.0, 0.0)
+        scene = api.CloudSet.reserved(ctx, n_scene + 16); scene.upload(m)
+        for k, res in enumerate((0.02, 0.05, 0.3)):
+            robot = np.float32(poses[k]); S = np.float32([0.2, -0.1, 0.5]) if k % 2 else np.zeros(3, np.float32)
+            for asynchronous in (False, True):
+                clipper = api.SceneClipperProjective2D(ctx, proj, voxelize_resolution=res, asynchronous=asynchronous)
+                clipper.setFullScene(scene); clipper.setRobotInLocalMap(robot); clipper.setSensorInRobot(S)
+                got = clipper.compute().download()
+                want = po.clip_scene_voxelized(opr, m, robot, S, res)
+                assert len(want) > 10 and len(got) == len(want) and np.array_equal(got, want), (n_scene, res, asynchronous)
+    with pytest.raises(api.Lsm2dError):           # voxelisation is limited to 2048 columns
+        c = api.SceneClipperProjective2D(ctx, api.PointNormal2fProjectorPolar(4096, -math.pi, math.pi, 0.3, 20.0), voxelize_resolution=0.1)
+        c.setFullScene(scene); c.compute()
 
 
 def test_merge_into_large_scene_with_pending_measurement_count(ctx, po):

@@ -294,6 +294,33 @@ def test_clipper_and_merger_semantics(po):
     assert np.array_equal(new_scene[[1, 3, 4]], scene[[1, 3, 4]])
 
 
+def test_clipper_voxelize_branch_semantics(po):
+    """mapping/scene_clipper_projective_2d.cpp:36-48: with voxelize_resolution > 0 the clipped points are voxelised in the SENSOR frame
+    with coefficients (res, res, 0.1, 0.1) and then moved to the robot frame; resolution <= 0 is the plain clipper."""
+    wl = synth.make_workload(1, 6000, seed=4)
+    pr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
+    robot = np.float32([0.4, -0.3, 0.2]); S = np.float32([0.15, 0.05, -0.4])
+    plain, _ = po.clip_scene(pr, wl.map_points, robot, S)
+    assert np.array_equal(po.clip_scene_voxelized(pr, wl.map_points, robot, S, 0.0), plain)
+    fine = po.clip_scene_voxelized(pr, wl.map_points, robot, S, 2e-3)        # voxels far smaller than the point spacing: a re-ordering only
+    assert len(fine) == len(plain)
+    assert np.allclose(np.sort(fine[:, 0]), np.sort(plain[:, 0]), atol=2e-6) and np.allclose(np.sort(fine[:, 1]), np.sort(plain[:, 1]), atol=2e-6)
+    coarse = po.clip_scene_voxelized(pr, wl.map_points, robot, S, 0.25)
+    assert 20 < len(coarse) < 0.7 * len(plain)
+    assert np.allclose(np.hypot(coarse[:, 2], coarse[:, 3]), 1.0, atol=1e-5)
+    # voxel keys are formed in the sensor frame: undo S and check one point per (x, y, nx, ny) voxel, ascending key order
+    Si = synth.invert_poses(S[None, :].astype(np.float64))[0]
+    c, s_ = math.cos(Si[2]), math.sin(Si[2])
+    xs = c * coarse[:, 0] - s_ * coarse[:, 1] + Si[0]; ys = s_ * coarse[:, 0] + c * coarse[:, 1] + Si[1]
+    kx = np.floor(xs / 0.25); ky = np.floor(ys / 0.25)
+    order = kx * 1e6 + ky
+    assert np.all(np.diff(order) >= 0)                        # ascending (x, y) voxel; ties differ in the normal's voxel
+    # every clipped point falls into the voxel of exactly one output point's (x, y) cell or a neighbour (averaging stays inside a voxel)
+    plain_s, _ = po.clip_scene(pr, wl.map_points, np.float32(synth.compose_poses(robot[None, :].astype(np.float64), S[None, :].astype(np.float64))[0]), np.zeros(3, np.float32))
+    cells = {(int(np.floor(p[0] / 0.25)), int(np.floor(p[1] / 0.25))) for p in plain_s}
+    assert {(int(a), int(b)) for a, b in zip(kx, ky)} <= cells
+
+
 def test_preprocessor_reference_fixture_and_semantics(po):
     """Row f2.  The one value the reference's own tests pin on this path: the `Synthetic` fixture (tests/fixtures.hpp:8-53:
     (1 - -1)/0.02 beams, every range 1 m, range limits [0, 1000], voxelize 0.01) must give exactly 100 points
