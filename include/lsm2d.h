@@ -276,6 +276,27 @@ int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params* aligner, c
                       int32_t* out_iterations,          /* [n]     iterations started; may be NULL */
                       lsm2d_iteration_stats* out_stats  /* [n][max_iterations]; may be NULL */);
 
+/* ---- the candidate loop of MultiLoopDetectorBruteForce2D / MultiRelocalizer2D (MULTI.json:964-986, :749-769) over the GPUs of one
+ * node, in ONE process and without Python: a context per device, the submap uploaded to device_ids[0] once and replicated device to
+ * device (xGMI), the distinct candidate scans replicated likewise, candidates block-sharded [r N / G, (r + 1) N / G) over the
+ * devices, one host thread per device, results in candidate order.  Alignments are independent, so there is no collective on the
+ * data path and the result of a candidate does not depend on G (tests: bit-identical to one lsm2d_align_batch).  Role assignment of
+ * the reference tracker / loop detector: fixed = the candidate's scan, moving = the submap; one laser slice.
+ * device_ids may name a device more than once (a rehearsal of G > 1 on a one-GPU box). */
+typedef struct lsm2d_sweep lsm2d_sweep;
+int     lsm2d_sweep_create(const int32_t* device_ids, int32_t n_devices, lsm2d_sweep** out_sweep);
+void    lsm2d_sweep_destroy(lsm2d_sweep* sweep);
+int32_t lsm2d_sweep_num_devices(const lsm2d_sweep* sweep);
+const char* lsm2d_sweep_last_error(const lsm2d_sweep* sweep);
+int     lsm2d_sweep_set_map(lsm2d_sweep* sweep, const float* map_xynn, int64_t n_points);
+/* the distinct scans the candidates refer to: packed back to back, offsets[n_scans + 1] */
+int     lsm2d_sweep_set_scans(lsm2d_sweep* sweep, const float* scans_xynn, const int32_t* offsets, int32_t n_scans);
+/* candidate i = (scan scan_index[i] -- or scan i when scan_index is NULL -- , init_pose[i]); out_last_stats: the statistics of the last
+ * iteration each candidate started (what the acceptance test of MULTI.json:979-985 reads); out_H / out_iterations / out_last_stats may be NULL */
+int     lsm2d_sweep_align(lsm2d_sweep* sweep, const lsm2d_aligner_params* aligner, const lsm2d_slice_params* slice, int32_t n_candidates,
+                          const int32_t* scan_index, const float* init_pose, float* out_pose, float* out_H, int32_t* out_status,
+                          int32_t* out_iterations, lsm2d_iteration_stats* out_last_stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,13 @@ SYMBOLS = [
     ("lsm2d_preprocess_scans", C.c_int, [_P, C.POINTER(Preprocessor), _P, C.c_int32, C.POINTER(_P)]),
     ("lsm2d_preprocess_scan_into", C.c_int, [_P, C.POINTER(Preprocessor), _P, _P]),
     ("lsm2d_clip_scene", C.c_int, [_P, C.POINTER(Projector), _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), _P]),
+    ("lsm2d_sweep_create", C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
+    ("lsm2d_sweep_destroy", None, [_P]),
+    ("lsm2d_sweep_num_devices", C.c_int32, [_P]),
+    ("lsm2d_sweep_last_error", C.c_char_p, [_P]),
+    ("lsm2d_sweep_set_map", C.c_int, [_P, _P, C.c_int64]),
+    ("lsm2d_sweep_set_scans", C.c_int, [_P, _P, _P, C.c_int32]),
+    ("lsm2d_sweep_align", C.c_int, [_P, C.POINTER(AlignerParams), C.POINTER(SliceParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     ("lsm2d_clip_scene_voxelized", C.c_int, [_P, C.POINTER(Projector), _P, C.c_int32, _P, _P, C.c_float, _P, C.POINTER(C.c_int32), _P]),
     ("lsm2d_merge_scene", C.c_int, [_P, C.POINTER(Projector), _P, _P, C.c_int32, _P, C.c_float, C.POINTER(C.c_int32), _P]),
     ("lsm2d_merge_scenes", C.c_int, [_P, C.POINTER(Projector), _P, C.c_int32, _P, _P, _P, C.c_float, C.POINTER(C.c_int32), _P]),

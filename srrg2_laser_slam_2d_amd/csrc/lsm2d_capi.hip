@@ -17,6 +17,7 @@ using lsm2d::LSM2D_RUNNING;
 #include <chrono>
 #include <vector>
 #include <algorithm>
+#include <thread>
 
 using namespace lsm2d;
 
@@ -1468,5 +1469,118 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
       std::nth_element(life.begin(), life.begin() + life.size() / 2, life.end()); ctx->last_wg_lifetime_ns = (long long) life[life.size() / 2];
     }
   }
+  return LSM2D_SUCCESS;
+}
+
+// ---- loop-closure / relocalisation sweep over several devices in ONE process (no Python, no MPI) ------------------------------
+// What MultiLoopDetectorBruteForce2D's candidate loop (MULTI.json:964-986) becomes on a node of MI355Xs: every device gets its own
+// context, a replica of the submap (device-to-device copies from the first device) and of the distinct candidate scans; the
+// candidates are block-sharded, one host thread drives each device, results land in candidate order.  No collective on the data
+// path; several entries of device_ids may name the same device (rehearsal on a one-GPU box).
+struct lsm2d_sweep {
+  std::vector<lsm2d_context*> ctx;
+  std::vector<lsm2d_cloudset*> map, scans;
+  std::string last_error;
+};
+static int sweep_fail(lsm2d_sweep* sw, int code, const std::string& msg) { if (sw) sw->last_error = msg; g_last_error = msg; return code; }
+static void sweep_drop(std::vector<lsm2d_cloudset*>& v) { for (auto* s : v) lsm2d_cloudset_destroy(s); v.clear(); }
+
+extern "C" int lsm2d_sweep_create(const int32_t* device_ids, int32_t n_devices, lsm2d_sweep** out) {
+  if (!device_ids || n_devices < 1 || n_devices > 64 || !out) return fail(nullptr, LSM2D_BAD_ARGUMENT, "sweep_create: bad argument");
+  lsm2d_sweep* sw = new (std::nothrow) lsm2d_sweep;
+  if (!sw) return fail(nullptr, LSM2D_OUT_OF_MEMORY, "sweep_create: out of memory");
+  for (int r = 0; r < n_devices; ++r) {
+    lsm2d_context* c = nullptr;
+    const int rc = lsm2d_create(device_ids[r], nullptr, &c);
+    if (rc) { for (auto* k : sw->ctx) lsm2d_destroy(k); delete sw; return rc; }
+    sw->ctx.push_back(c);
+  }
+  *out = sw;
+  return LSM2D_SUCCESS;
+}
+extern "C" void lsm2d_sweep_destroy(lsm2d_sweep* sw) {
+  if (!sw) return;
+  sweep_drop(sw->map); sweep_drop(sw->scans);
+  for (auto* c : sw->ctx) lsm2d_destroy(c);
+  delete sw;
+}
+extern "C" int32_t lsm2d_sweep_num_devices(const lsm2d_sweep* sw) { return sw ? (int32_t) sw->ctx.size() : 0; }
+extern "C" const char* lsm2d_sweep_last_error(const lsm2d_sweep* sw) { return sw ? sw->last_error.c_str() : g_last_error.c_str(); }
+
+// one host cloud set replicated on every device of the sweep: host -> first device once, then device -> device
+static int sweep_replicate(lsm2d_sweep* sw, const float* pts, const int32_t* offsets, int32_t n_clouds, int64_t total, std::vector<lsm2d_cloudset*>* out) {
+  sweep_drop(*out);
+  if (!pts || total < 0 || n_clouds < 1) return sweep_fail(sw, LSM2D_BAD_ARGUMENT, "sweep: bad cloud");
+  const size_t bytes = sizeof(float) * 4 * (size_t) (total > 0 ? total : 1);
+  lsm2d_context* c0 = sw->ctx[0];
+  void* d0 = nullptr;
+  if (hipSetDevice(c0->device) != hipSuccess || hipMalloc(&d0, bytes) != hipSuccess) return sweep_fail(sw, LSM2D_OUT_OF_MEMORY, "sweep: staging allocation failed");
+  if (total > 0 && hipMemcpy(d0, pts, sizeof(float) * 4 * (size_t) total, hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d0); return sweep_fail(sw, LSM2D_DEVICE_ERROR, "sweep: upload failed"); }
+  int rc = LSM2D_SUCCESS;
+  for (size_t r = 0; r < sw->ctx.size() && rc == LSM2D_SUCCESS; ++r) {
+    lsm2d_context* c = sw->ctx[r];
+    void* dr = d0;
+    if (r > 0) {      // a replica of its own, filled over the fabric (xGMI between the GPUs of a node) -- never through the host again
+      if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&dr, bytes) != hipSuccess) { rc = sweep_fail(sw, LSM2D_OUT_OF_MEMORY, "sweep: replica allocation failed"); break; }
+      if (total > 0 && hipMemcpyPeer(dr, c->device, d0, c0->device, sizeof(float) * 4 * (size_t) total) != hipSuccess) { (void) hipFree(dr); rc = sweep_fail(sw, LSM2D_DEVICE_ERROR, "sweep: device-to-device copy failed"); break; }
+    }
+    lsm2d_cloudset* set = nullptr;
+    rc = lsm2d_cloudset_create_from_device(c, dr, offsets, n_clouds, total, &set);
+    if (rc == LSM2D_SUCCESS) { rc = lsm2d_synchronize(c); out->push_back(set); }      // the split of the AoS staging buffer has run before it is freed
+    if (r > 0) { (void) hipSetDevice(c->device); (void) hipFree(dr); }
+  }
+  (void) hipSetDevice(c0->device); (void) hipFree(d0);
+  if (rc != LSM2D_SUCCESS) { sweep_drop(*out); return rc; }
+  return LSM2D_SUCCESS;
+}
+extern "C" int lsm2d_sweep_set_map(lsm2d_sweep* sw, const float* map_xynn, int64_t n_points) {
+  if (!sw) return fail(nullptr, LSM2D_BAD_ARGUMENT, "sweep_set_map: null sweep");
+  return sweep_replicate(sw, map_xynn, nullptr, 1, n_points, &sw->map);
+}
+extern "C" int lsm2d_sweep_set_scans(lsm2d_sweep* sw, const float* scans_xynn, const int32_t* offsets, int32_t n_scans) {
+  if (!sw || !offsets || n_scans < 1) return fail(nullptr, LSM2D_BAD_ARGUMENT, "sweep_set_scans: bad argument");
+  return sweep_replicate(sw, scans_xynn, offsets, n_scans, offsets[n_scans], &sw->scans);
+}
+
+extern "C" int lsm2d_sweep_align(lsm2d_sweep* sw, const lsm2d_aligner_params* ap, const lsm2d_slice_params* slice, int32_t n_candidates,
+                                 const int32_t* scan_index, const float* init_pose, float* out_pose, float* out_H, int32_t* out_status,
+                                 int32_t* out_iterations, lsm2d_iteration_stats* out_last_stats) {
+  if (!sw || !ap || !slice || n_candidates < 0 || (n_candidates > 0 && (!init_pose || !out_pose || !out_status)))
+    return fail(nullptr, LSM2D_BAD_ARGUMENT, "sweep_align: bad argument");
+  if (sw->map.size() != sw->ctx.size() || sw->scans.size() != sw->ctx.size()) return sweep_fail(sw, LSM2D_BAD_ARGUMENT, "sweep_align: set_map / set_scans first");
+  const int G = (int) sw->ctx.size();
+  const int n_scans = lsm2d_cloudset_num_clouds(sw->scans[0]);
+  if (!scan_index && n_scans != n_candidates && n_scans != 1) return sweep_fail(sw, LSM2D_BAD_ARGUMENT, "sweep_align: scan_index needed unless there is one scan per candidate");
+  std::vector<int> rcs((size_t) G, LSM2D_SUCCESS);
+  std::vector<std::thread> workers;
+  for (int r = 0; r < G; ++r) {
+    const long long lo = (long long) n_candidates * r / G, hi = (long long) n_candidates * (r + 1) / G;
+    if (hi <= lo) continue;
+    workers.emplace_back([=, &rcs]() {
+      const int n = (int) (hi - lo);
+      // without an index array candidate i uses scan i: the shard needs an explicit index then (its scans start at lo)
+      std::vector<int32_t> own_index;
+      const int32_t* idx = scan_index ? scan_index + lo : nullptr;
+      if (!idx && n_scans != 1) { own_index.resize((size_t) n); for (int i = 0; i < n; ++i) own_index[(size_t) i] = (int32_t) (lo + i); idx = own_index.data(); }
+      const lsm2d_cloudset* fx = sw->scans[(size_t) r]; const lsm2d_cloudset* mv = sw->map[(size_t) r];
+      lsm2d_batch b; memset(&b, 0, sizeof b);
+      b.n_alignments = n; b.n_slices = 1; b.slices = slice; b.fixed = &fx; b.moving = &mv; b.fixed_index = idx; b.init_pose = init_pose + 3 * lo;
+      std::vector<lsm2d_iteration_stats> stats;
+      if (out_last_stats) stats.resize((size_t) n * (size_t) (ap->max_iterations > 0 ? ap->max_iterations : 1));
+      std::vector<int32_t> its((size_t) n);
+      const int rc = lsm2d_align_batch(sw->ctx[(size_t) r], ap, &b, out_pose + 3 * lo, out_H ? out_H + 9 * lo : nullptr, out_status + lo, its.data(),
+                                       out_last_stats ? stats.data() : nullptr);
+      rcs[(size_t) r] = rc;
+      if (rc != LSM2D_SUCCESS) return;
+      if (out_iterations) memcpy(out_iterations + lo, its.data(), sizeof(int32_t) * (size_t) n);
+      if (out_last_stats)
+        for (int i = 0; i < n; ++i) {
+          lsm2d_iteration_stats z; memset(&z, 0, sizeof z);
+          out_last_stats[lo + i] = its[(size_t) i] > 0 ? stats[(size_t) i * (size_t) ap->max_iterations + (size_t) (its[(size_t) i] - 1)] : z;
+        }
+    });
+  }
+  for (auto& w : workers) w.join();
+  for (int r = 0; r < G; ++r) if (rcs[(size_t) r] != LSM2D_SUCCESS) return sweep_fail(sw, rcs[(size_t) r], std::string("sweep_align: device ") + std::to_string(r) + ": " + lsm2d_last_error(sw->ctx[(size_t) r]));
   return LSM2D_SUCCESS;
 }

@@ -311,4 +311,67 @@ class MultiAligner2D {
   lsm2d_prior _prior{}; bool _has_prior = false; int _status = 0;
 };
 
+// The candidate loop of MultiLoopDetectorBruteForce2D / MultiRelocalizer2D (MULTI.json:964-986, :749-769) over the GPUs of one node,
+// in this process: one context and one host thread per device, the submap replicated device to device, candidates block-sharded,
+// results in candidate order (lsm2d_sweep_* in include/lsm2d.h).  accept() is the reference's acceptance test (MULTI.json:979-985).
+class LoopClosureSweep {
+ public:
+  explicit LoopClosureSweep(const std::vector<int>& device_ids) {
+    std::vector<int32_t> ids(device_ids.begin(), device_ids.end());
+    const int rc = lsm2d_sweep_create(ids.data(), (int32_t) ids.size(), &_sw);
+    if (rc < 0) throw std::runtime_error(std::string("LoopClosureSweep| ") + lsm2d_status_string(rc) + ": " + lsm2d_sweep_last_error(nullptr));
+  }
+  ~LoopClosureSweep() { lsm2d_sweep_destroy(_sw); }
+  LoopClosureSweep(const LoopClosureSweep&) = delete;
+  LoopClosureSweep& operator=(const LoopClosureSweep&) = delete;
+  int numDevices() const { return lsm2d_sweep_num_devices(_sw); }
+  // relocalize_aligner's parameters (MULTI.json:602-630) and its one laser slice (MULTI.json:572-600,771-784: projective finder,
+  // point_distance 1.414, normal_cos 0.8, Cauchy 0.05, min_num_correspondences 10)
+  int param_max_iterations = 30, param_min_num_inliers = 10;
+  lsm2d_slice_params param_slice = projectiveSlice(PointNormal2fProjectorPolar(), 1.414f, 0.8f, 0.05f, 10);
+  static lsm2d_slice_params projectiveSlice(const PointNormal2fProjectorPolar& projector, float point_distance, float normal_cos,
+                                            float cauchy_chi_threshold /* <= 0: no robustifier */, int min_num_correspondences) {
+    lsm2d_slice_params sp{};
+    sp.finder = LSM2D_FINDER_PROJECTIVE; sp.projector = projector.abi(); sp.point_distance = point_distance; sp.normal_cos = normal_cos;
+    sp.robustifier = cauchy_chi_threshold > 0.f ? LSM2D_ROBUST_CAUCHY : LSM2D_ROBUST_NONE; sp.chi_threshold = cauchy_chi_threshold > 0.f ? cauchy_chi_threshold : 0.f;
+    sp.min_num_correspondences = min_num_correspondences;
+    return sp;
+  }
+  // acceptance thresholds (MULTI.json:964-986)
+  int param_relocalize_min_inliers = 500; float param_relocalize_max_chi_inliers = 0.1f, param_relocalize_min_inliers_ratio = 0.8f;
+
+  void setMap(const PointNormal2fVectorCloud& map) { checkSweep(lsm2d_sweep_set_map(_sw, map.empty() ? nullptr : &map[0].x, (int64_t) map.size()), "set_map"); }
+  void setScans(const std::vector<PointNormal2fVectorCloud>& scans) {
+    std::vector<float> packed; std::vector<int32_t> offs(1, 0);
+    for (const auto& c : scans) { for (const auto& p : c) { packed.push_back(p.x); packed.push_back(p.y); packed.push_back(p.nx); packed.push_back(p.ny); } offs.push_back((int32_t) (packed.size() / 4)); }
+    checkSweep(lsm2d_sweep_set_scans(_sw, packed.data(), offs.data(), (int32_t) scans.size()), "set_scans");
+  }
+  void setScansPacked(const float* xynn, const int32_t* offsets, int n_scans) { checkSweep(lsm2d_sweep_set_scans(_sw, xynn, offsets, n_scans), "set_scans"); }
+  // candidates: (scan index, initial guess of moving-in-fixed); results in candidate order
+  void compute(const std::vector<int32_t>& scan_index, const std::vector<Vector3f>& init_pose) {
+    const int n = (int) init_pose.size();
+    if ((int) scan_index.size() != n) throw std::runtime_error("LoopClosureSweep::compute| one scan index per candidate");
+    const lsm2d_slice_params sp = param_slice;
+    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, 0.f};
+    pose.assign((size_t) n, Vector3f{{0.f, 0.f, 0.f}}); information.assign((size_t) n, std::array<float, 9>{});
+    status.assign((size_t) n, 0); iterations.assign((size_t) n, 0); last_stats.assign((size_t) n, lsm2d_iteration_stats{});
+    static_assert(sizeof(Vector3f) == 3 * sizeof(float), "poses are packed");
+    checkSweep(lsm2d_sweep_align(_sw, &ap, &sp, n, scan_index.data(), n ? init_pose[0].data() : nullptr, n ? pose[0].data() : nullptr,
+                                 n ? information[0].data() : nullptr, status.data(), iterations.data(), last_stats.data()), "align");
+  }
+  bool accept(size_t i) const {
+    const auto& st = last_stats[i];
+    const float n_in = (float) st.n_inliers, n_c = (float) (st.n_correspondences > 0 ? st.n_correspondences : 1);
+    return status[i] == LSM2D_SUCCESS && st.n_inliers >= param_relocalize_min_inliers &&
+           st.chi_inliers / (n_in > 1.f ? n_in : 1.f) <= param_relocalize_max_chi_inliers && n_in / n_c >= param_relocalize_min_inliers_ratio;
+  }
+  std::vector<Vector3f> pose; std::vector<std::array<float, 9>> information;
+  std::vector<int32_t> status, iterations; std::vector<lsm2d_iteration_stats> last_stats;
+ private:
+  void checkSweep(int rc, const char* where) const {
+    if (rc < 0) throw std::runtime_error(std::string("LoopClosureSweep::") + where + "| " + lsm2d_status_string(rc) + ": " + lsm2d_sweep_last_error(_sw));
+  }
+  lsm2d_sweep* _sw = nullptr;
+};
+
 }  // namespace lsm2d_host

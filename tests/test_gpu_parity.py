@@ -395,6 +395,47 @@ def test_srrg_adapters_compile_and_run(ctx, po, small_workload, tmp_path):
     assert abs(r["merged_size"] - n_merge) <= 5 and r["merge_status"] == 1
 
 
+def test_cpp_loop_closure_sweep_over_several_contexts(ctx, po, tmp_path):
+    """lsm2d_host::LoopClosureSweep / lsm2d_sweep_* (the multi-device candidate loop without Python): 1, 2 and 3 contexts on this one GPU --
+    one host thread each, the submap replicated device to device, candidates block-sharded -- must give, bit for bit, the poses,
+    information matrices, statuses and last-iteration statistics of ONE lsm2d_align_batch over all candidates; acceptance decisions
+    as MULTI.json:979-985."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "sweep_driver")
+    lib_dir = os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "host"),
+                    os.path.join(ROOT, "tests", "cpp", "sweep_driver.cpp"), "-L" + lib_dir, "-llsm2d_hip", "-Wl,-rpath," + lib_dir, "-pthread", "-o", exe], check=True)
+    n_cand, n_unique, iters, tau = 1500, 64, 15, 0.05
+    wl = synth.make_workload(n_unique, 50000, seed=21)
+    scan_index = (np.arange(n_cand) * 7 % n_unique).astype(np.int32)
+    delta = synth.Stream(77, salt=9).uniform(3 * n_cand, -0.05, 0.05).reshape(n_cand, 3)
+    x0 = synth.invert_poses(synth.compose_poses(synth.invert_poses(wl.x_true)[scan_index], delta)).astype(np.float32)
+    x0[-40:] += np.float32([3.0, -2.0, 0.7])            # hopeless candidates: must be rejected, whatever the device count
+    proj = api.PointNormal2fProjectorPolar(1081, -np.float32(math.pi), np.float32(math.pi), 0.3, 30.0)
+    al = api.MultiAligner2D(ctx, max_iterations=iters, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(
+        api.CorrespondenceFinderProjective2f(ctx, proj, point_distance=0.5, normal_cos=0.8), robustifier=api.RobustifierCauchy(tau), min_num_correspondences=10))
+    ref = al.compute_batch([api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)], [api.CloudSet(ctx, wl.map_points)], x0, fixed_index=scan_index[None, :], want_stats=True)
+    want_acc = ref.loop_closure_accept(500, 0.1, 0.8)
+    assert want_acc[:-40].all() and not want_acc[-40:].any()
+    last = ref.last_stats()
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        d = tmp_path / ("g%d" % len(devices)); d.mkdir()
+        wl.scan_points.tofile(d / "scans.bin"); wl.scan_offsets.astype(np.int32).tofile(d / "offsets.bin"); wl.map_points.tofile(d / "map.bin")
+        scan_index.tofile(d / "index.bin"); x0.tofile(d / "x0.bin")
+        (d / "params.txt").write_text("1081 %d %r 30.0\n" % (iters, tau))
+        r = subprocess.run([exe, str(d), str(len(devices))] + [str(v) for v in devices], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert json.loads(r.stdout.strip().splitlines()[-1]) == {"devices": len(devices), "candidates": n_cand}
+        pose = np.fromfile(d / "out_pose.bin", np.float32).reshape(n_cand, 3); H = np.fromfile(d / "out_H.bin", np.float32).reshape(n_cand, 3, 3)
+        status = np.fromfile(d / "out_status.bin", np.int32); stats = np.fromfile(d / "out_stats.bin", api.STATS_DTYPE)
+        acc = np.fromfile(d / "out_accept.bin", np.uint8).astype(bool)
+        assert np.array_equal(pose, ref.pose) and np.array_equal(H, ref.information) and np.array_equal(status, ref.status), len(devices)
+        assert np.array_equal(stats, last) and np.array_equal(acc, want_acc), len(devices)
+
+
 def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     """The header-only C++ mirror (srrg2_laser_slam_2d_amd/host/lsm2d.hpp), built with plain g++ and driven like
     apps/visual_test_correspondence_finder_projective_2d.cpp / apps/visual_test_aligner_2d.cpp."""
