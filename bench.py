@@ -230,29 +230,17 @@ def main() -> None:
     # its result
     cross = None
     if use_dist:
-        ncheck = min(16, args.scans)
-        pts = np.zeros((16, args.beams, 4), np.float32); cnt = np.zeros((16, 1), np.float32); head = np.zeros((16, 6), np.float32)
-        for i in range(ncheck):
-            si = int(scan_index[i]) if scan_index is not None else i
-            sc = wl.scan_points[wl.scan_offsets[si]:wl.scan_offsets[si + 1]]
-            pts[i, : len(sc)] = sc; cnt[i, 0] = len(sc)
-        head[:ncheck, :3] = res.pose[:ncheck]; head[:ncheck, 3:] = x0[:ncheck]
-        all_pts = distributed.gather_results(pts.reshape(16 * args.beams, 4)).reshape(world, 16, args.beams, 4)
-        all_cnt = distributed.gather_results(cnt).reshape(world, 16).astype(np.int64)
-        all_head = distributed.gather_results(head).reshape(world, 16, 6)
+        def align_alone(clouds, x0_r):
+            offs_r = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+            set_r = api.CloudSet(ctx, np.concatenate(clouds, 0), offs_r)
+            rr = (aligner.compute_batch([set_r], [map_set], x0_r) if args.role == "A" else aligner.compute_batch([map_set], [set_r], x0_r))
+            set_r.close()
+            return rr.pose
+        chk = distributed.cross_rank_check(wl.scan_points, wl.scan_offsets, scan_index, x0, res.pose, args.beams, align_alone)
         if rank == 0:
-            same = 0
-            for r in range(world):
-                nr = int((all_cnt[r] > 0).sum())
-                clouds = [all_pts[r, i, : all_cnt[r, i]] for i in range(nr)]
-                offs_r = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
-                set_r = api.CloudSet(ctx, np.concatenate(clouds, 0), offs_r)
-                x0_r = np.ascontiguousarray(all_head[r, :nr, 3:])
-                rr = (aligner.compute_batch([set_r], [map_set], x0_r) if args.role == "A" else aligner.compute_batch([map_set], [set_r], x0_r))
-                same += int(np.array_equal(rr.pose, all_head[r, :nr, :3]))
-                set_r.close()
-            cross = "%d of %d ranks: first %d poses bit-identical to rank 0 aligning the same candidates alone" % (same, world, ncheck)
-            ok = ok and same == world
+            same, nw, ncheck = chk
+            cross = "%d of %d ranks: first %d poses bit-identical to rank 0 aligning the same candidates alone" % (same, nw, ncheck)
+            ok = ok and same == nw
 
     if rank == 0:
         n_total = (args.total_candidates if strong else args.scans * world) * args.steps

@@ -46,3 +46,32 @@ def gather_results(local: np.ndarray, device: str | None = None) -> np.ndarray:
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return torch.cat(out, 0).cpu().numpy()
+
+
+def cross_rank_check(scan_points, scan_offsets, scan_index, x0, poses, n_beams: int, align_fn, n_check: int = 16, device: str | None = None):
+    """Sharding must change WHERE an alignment runs, never its result.  Every rank contributes its first ``n_check`` candidates
+    (scan, initial guess) and the poses it got for them; rank 0 re-aligns each rank's candidates alone with
+    ``align_fn(clouds: list[np.ndarray], x0: np.ndarray[n, 3]) -> np.ndarray[n, 3]`` and compares BIT FOR BIT.
+    Returns (n_ranks_identical, world, n_checked) on rank 0, None elsewhere.  Collectives: three all_gathers of fixed-size rows."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 or (dist.is_available() and dist.is_initialized()) else 0
+    ncheck = min(n_check, len(x0))
+    pts = np.zeros((n_check, n_beams, 4), np.float32); cnt = np.zeros((n_check, 1), np.float32); head = np.zeros((n_check, 6), np.float32)
+    for i in range(ncheck):
+        si = int(scan_index[i]) if scan_index is not None else i
+        sc = scan_points[scan_offsets[si]:scan_offsets[si + 1]]
+        pts[i, : len(sc)] = sc; cnt[i, 0] = len(sc)
+    head[:ncheck, :3] = poses[:ncheck]; head[:ncheck, 3:] = x0[:ncheck]
+    all_pts = gather_results(pts.reshape(n_check * n_beams, 4), device).reshape(world, n_check, n_beams, 4)
+    all_cnt = gather_results(cnt, device).reshape(world, n_check).astype(np.int64)
+    all_head = gather_results(head, device).reshape(world, n_check, 6)
+    if rank != 0:
+        return None
+    same = 0
+    for r in range(world):
+        nr = int((all_cnt[r] > 0).sum())
+        clouds = [np.ascontiguousarray(all_pts[r, i, : all_cnt[r, i]]) for i in range(nr)]
+        got = align_fn(clouds, np.ascontiguousarray(all_head[r, :nr, 3:]))
+        same += int(np.array_equal(np.asarray(got, np.float32), all_head[r, :nr, :3]))
+    return same, world, ncheck

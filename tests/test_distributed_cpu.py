@@ -50,3 +50,44 @@ def test_gloo_world_size_2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _align_worker(rank, world, port, out_dir):
+    """Every rank ALIGNS its shard of a candidate sweep (with the CPU oracle standing in for the device -- tests may use it) and the
+    ranks then run bench.py's cross-rank check: rank 0 re-aligns each rank's first candidates alone and compares bit for bit."""
+    from oracle import pyoracle as po
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    world_geom = synth.make_world(0)
+    m = synth.make_map(world_geom, 4000) if rank == 0 else None
+    map_pts = distributed.broadcast_map(m, 4000, device="cpu").numpy()
+    n_total, n_beams = 10, 181
+    lo, hi = distributed.shard_range(n_total, rank, world)
+    wl = synth.make_workload(hi - lo, 4000, seed=0, n_beams=n_beams, pose_seed_offset=rank, world=world_geom, map_points=np.zeros((0, 4), np.float32))
+    sp = po.slice_params(canvas_cols=n_beams)
+
+    def align_alone(clouds, x0):
+        return np.stack([po.align(po.aligner_params(8), [sp], [c], [map_pts], x)["pose"] for c, x in zip(clouds, x0)])
+    mine = align_alone([wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]] for i in range(hi - lo)], wl.x0)
+    err = np.abs(mine - wl.x_true); assert err[:, :2].max() < 1e-3                        # the shard really was aligned
+    chk = distributed.cross_rank_check(wl.scan_points, wl.scan_offsets, None, wl.x0, mine, n_beams, align_alone, n_check=4, device="cpu")
+    if rank == 0:
+        assert chk == (world, world, 4), chk
+        # ... and a rank whose poses were tampered with is caught
+    bad = mine.copy(); bad[0, 0] += 1e-6 if rank == 1 else 0.0
+    chk2 = distributed.cross_rank_check(wl.scan_points, wl.scan_offsets, None, wl.x0, bad, n_beams, align_alone, n_check=4, device="cpu")
+    if rank == 0:
+        assert chk2 == (world - 1, world, 4), chk2
+    # the sweep's consumer sees every candidate's pose, in candidate order
+    pad = max(distributed.shard_range(n_total, r, world)[1] - distributed.shard_range(n_total, r, world)[0] for r in range(world))
+    rows = np.zeros((pad, 3), np.float32); rows[: hi - lo] = mine
+    allp = distributed.gather_results(rows, device="cpu")
+    assert allp.shape == (pad * world, 3) and np.array_equal(allp[rank * pad: rank * pad + (hi - lo)], mine)
+    dist.barrier(); dist.destroy_process_group()
+    open(os.path.join(out_dir, f"aligned{rank}"), "w").write("ok")
+
+
+def test_gloo_world_size_2_shards_align_and_cross_check(tmp_path):
+    port = _free_port()
+    mp.spawn(_align_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "aligned0").exists() and (tmp_path / "aligned1").exists()
