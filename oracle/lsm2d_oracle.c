@@ -12,27 +12,38 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* atan2 as a FIXED operation sequence (IEEE div, fmaf Horner, exact octant fix-ups) so the column
- * index floor(K00*atan2+K01) is bit-identical on CPU and GPU.  atan(a) = a + a*s*P(s), s = a*a,
- * a in [0,1]; coefficients from tools/fit_atan.py (degree 7, max abs error 7.3e-8 rad on [0,1],
- * i.e. < 3e-7 rad after the fix-ups: 5e-5 of a 1081-column bin). Stands in for the libm atan2f the
- * upstream projector calls; the two differ by a few ULP. */
-static const float LSMO_ATAN_C[8] = {
-  -3.333298564e-01f, 1.999039650e-01f, -1.418597102e-01f, 1.057391763e-01f,
-  -7.366676629e-02f, 4.112152755e-02f, -1.513234153e-02f, 2.622197615e-03f};
+/* The bearing of a point as a FIXED operation sequence (IEEE sqrt, IEEE divide, fmaf Horner, exact octant fix-ups) so the column
+ * index floor(K00*theta+K01) is bit-identical on CPU and GPU.  With r = sqrtf(x*x + y*y) -- the depth the projector needs anyway --
+ * the octant angle is phi = asin(t), t = min(|x|,|y|) / r in [0, sqrt(1/2)]: asin(t) = t + t*s*P(s), s = t*t; coefficients from
+ * tools/fit_asin.py (degree 6, max abs error 4.6e-8 rad, i.e. ~1e-7 rad after the fix-ups: 2e-5 of a 1081-column bin).  The HIP
+ * kernels reach the same r and t from ONE v_rsq_f32 by sequences proved correctly rounded on the card (tools/fp_exact_check.hip).
+ * Stands in for the libm atan2f the upstream projector calls; the two differ by a few ULP (PARITY.md section 5).
+ * (Round 1 used atan(min/max) with a degree-7 polynomial: one more transcendental per point on the device.) */
+static const float LSMO_ASIN_C[7] = {
+  1.666723490e-01f, 7.478348911e-02f, 4.762428626e-02f, 1.043075230e-02f, 9.340071678e-02f, -1.153038889e-01f, 1.237212196e-01f};
 #define LSMO_PI_F      3.14159274101257324f
 #define LSMO_HALF_PI_F 1.57079637050628662f
 
 float lsmo_atan2f(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
-  const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+  const float mn = ax > ay ? ay : ax;
+  const float r2 = fmaf(x, x, y * y);       /* the projector's own r2 (lsm2d_oracle_impl.inc: project_cells) */
   float r = 0.0f;
-  if (mx > 0.0f) {
-    const float a = mn / mx;
-    const float s = a * a;
-    float p = LSMO_ATAN_C[7];
-    for (int i = 6; i >= 0; --i) p = fmaf(p, s, LSMO_ATAN_C[i]);
-    r = fmaf(a * s, p, a);
+  if (r2 >= 1e-30f && r2 <= 3e38f) {        /* every point the range gate lets through (ranges are clamped to [1e-15, 1e18] m) */
+    const float rr = sqrtf(r2);
+    float t = mn / rr;
+    /* The device's short quotient sequence (csrc/lsm2d_device.h: div_by_depth) is the correctly rounded mn / r for every input of the
+     * range gate EXCEPT the exact ties its last fused step cannot see: r with an all-ones mantissa (2 - ulp, scaled) and mn a power of
+     * two, where it returns the float below (tools/fp_exact_check.hip enumerates all 2^47 mantissa pairs on the card and checks this
+     * very rule).  The restatement follows it: one ulp of the sine (3e-8 rad) on inputs of probability ~1e-14 per point. */
+    { unsigned int rb, nb; memcpy(&rb, &rr, 4); memcpy(&nb, &mn, 4);
+      if ((rb & 0x7FFFFFu) == 0x7FFFFFu && (nb & 0x7FFFFFu) == 0u && mn >= 1e-12f) { unsigned int tb; memcpy(&tb, &t, 4); tb -= 1u; memcpy(&t, &tb, 4); } }
+    const float s = t * t;
+    float p = LSMO_ASIN_C[6];
+    for (int i = 5; i >= 0; --i) p = fmaf(p, s, LSMO_ASIN_C[i]);
+    r = fmaf(t * s, p, t);
+  } else if (ax > 0.0f || ay > 0.0f) {      /* outside the gate nothing reads the bearing: any sane value (scale-free, through double) */
+    r = (float) asin((double) mn / hypot((double) x, (double) y));
   }
   if (ay > ax) r = LSMO_HALF_PI_F - r;
   if (x < 0.0f) r = LSMO_PI_F - r;

@@ -572,10 +572,10 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
   k->rmin = fmaxf(p.range_min, 1e-15f); k->rmax = fminf(p.range_max, 1e18f); k->colsf = (float) p.canvas_cols;
   if (!(k->rmax >= k->rmin)) return false;
   k->r2lo = r2_lower_threshold(k->rmin); k->r2hi = r2_upper_threshold(k->rmax);
-  // The stream's short divide is exact for min(|x|,|y|) >= 1e-12 (div_rn_unit); below that its result is merely SOME value a' with
-  // |a'| <= A = 2.1e-12 / max(|x|,|y|), max >= 0.7 rmin.  That cannot move a column when (i) pi/2 - a' and pi - a' round back to
-  // pi/2 and pi (A below a quarter ulp of pi/2) and (ii) K00 * (+-a') + K01 rounds to K01 (K00 A below a quarter ulp of K01): then the
-  // kernels drop the guard branch in front of the divide.  True for every sane projector (cols 1081, 2 pi: K00 A ~ 2e-9 vs 1.5e-5).
+  // The stream's short quotient min(|x|,|y|) / r (div_by_depth) is exact for min >= 1e-12; below that its result is merely SOME value
+  // t' with |t'| <= A = 2.1e-12 / r, r >= rmin.  That cannot move a column when (i) pi/2 - t' and pi - t' round back to pi/2 and pi
+  // (A below a quarter ulp of pi/2) and (ii) K00 * (+-t') + K01 rounds to K01 (K00 A below a quarter ulp of K01): then the kernels
+  // drop the guard branch in front of the quotient.  True for every sane projector (cols 1081, 2 pi: K00 A ~ 2e-9 vs 1.5e-5).
   const double A = 2.1e-12 / (0.7 * (double) k->rmin);
   k->tiny_ok = (A < 2.5e-8 && k->K01 >= 0.25f && (double) k->K00 * A < (double) k->K01 * 1.4e-8) ? 1 : 0;
   return true;

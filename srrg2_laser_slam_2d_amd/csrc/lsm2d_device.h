@@ -81,69 +81,65 @@ LSM2D_DEV void xf_normal(const Iso& T, float nx, float ny, float& ox, float& oy)
   oy = __builtin_fmaf(T.s, nx, T.c * ny);
 }
 
-// IEEE-754 correctly rounded n/d for 0 <= n <= d, d a normal number in [2^-100, 2^100] and n >= 1e-12: v_rcp_f32, one
-// refinement of the reciprocal and ONE residual correction of the quotient (Markstein's sequence; the compiler's '/' spends two
-// more operations on a second correction plus v_div_scale / v_div_fixup range handling these inputs never need).  Every step
-// scales exactly with powers of two inside that range, so exactness is a property of the (mantissa of n, mantissa of d) pair
-// alone: tools/fp_exact_check.hip compares this function with '/' on ALL 2^46 pairs on the MI355X -- 0 mismatches
-// (profiles/r01/fp_exact_full.log; the cheaper sequences it also tries fail 2.7e4 / 4.7e4 times).  n < 1e-12 (a quotient that could
-// be subnormal, and n == 0) takes the compiler's full divide.
-LSM2D_DEV float div_rn_unit(float n, float d) {
-  if (__builtin_expect(n < 1e-12f, 0)) return n / d;
-  const float r0 = __builtin_amdgcn_rcpf(d);
-  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-  const float r1 = __builtin_fmaf(e0, r0, r0);
-  const float q0 = n * r1;
-  const float e1 = __builtin_fmaf(-d, q0, n);
-  return __builtin_fmaf(e1, r1, q0);
-}
-
-// atan2 as a fixed polynomial: atan(a) = a + a*s*P(s), s = a*a, a = min/max in [0,1] (IEEE divide),
-// degree-7 P (tools/fit_atan.py: max abs error 7.3e-8 rad on [0,1]), exact octant fix-ups, sign of y copied
-// onto the result (so atan2(-0, x<0) = -pi like libm).  kUnitDiv: the caller guarantees max(|x|,|y|) in
-// [1e-15, 1e18] (the projector's range gate), which lets the divide skip its range handling.
-template <bool kUnitDiv>
-LSM2D_DEV float atan2_poly_t(float y, float x) {
-  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-  // one compare serves the operand order AND the octant fix-up below (selects with |.| folded in; equal magnitudes give the
-  // same two values either way)
-  const bool swap = ay > ax;
-  const float mx = swap ? ay : ax, mn = swap ? ax : ay;
-  float r = 0.0f;
-  if (kUnitDiv || mx > 0.0f) {
-    const float a = kUnitDiv ? div_rn_unit(mn, mx) : mn / mx;
-    const float s = a * a;
-    float p = 2.622197615e-03f;
-    p = __builtin_fmaf(p, s, -1.513234153e-02f);
-    p = __builtin_fmaf(p, s, 4.112152755e-02f);
-    p = __builtin_fmaf(p, s, -7.366676629e-02f);
-    p = __builtin_fmaf(p, s, 1.057391763e-01f);
-    p = __builtin_fmaf(p, s, -1.418597102e-01f);
-    p = __builtin_fmaf(p, s, 1.999039650e-01f);
-    p = __builtin_fmaf(p, s, -3.333298564e-01f);
-    r = __builtin_fmaf(a * s, p, a);
-  }
-  if (swap) r = 1.57079637050628662f - r;
-  if (x < 0.0f) r = 3.14159274101257324f - r;
-  return __builtin_copysignf(r, y);
-}
-LSM2D_DEV float atan2_poly(float y, float x) { return atan2_poly_t<false>(y, x); }
-
 LSM2D_DEV float wrap_angle(float a) {
   while (a > 3.14159274101257324f) a -= 6.28318548202514648f;
   while (a <= -3.14159274101257324f) a += 6.28318548202514648f;
   return a;
 }
 
-// Correctly rounded sqrt for inputs in [1e-30, FLT_MAX] (the range gate's r2 and beyond): v_rsq_f32, s0 = x*y, one residual correction
-// s0 + (x - s0*s0) * (y/2).  tools/fp_exact_check.hip compares it with sqrtf on every fp32 bit pattern of that interval
-// (1.88e9 inputs) on the MI355X: 0 mismatches (profiles/r01/fp_exact_full.log).  Six issue slots instead of the eleven of
-// v_sqrt_f32 + the two-sided residual test hipcc emits for sqrtf().
-LSM2D_DEV float sqrt_rn_normal(float x) {
-  const float y  = __builtin_amdgcn_rsqf(x);
-  const float s0 = x * y, h = 0.5f * y;
+// ---- depth and bearing of a point from ONE transcendental ------------------------------------------------------------------
+// tools/valu_issue_probe.hip: in this stream a transcendental costs ~18 cycles of a saturated SIMD (a plain instruction 2.15), and
+// round 1 spent two per point -- v_rcp_f32 for atan(min / max) and v_rsq_f32 for the depth.  Both now grow from the depth's seed:
+//   r   = sqrt_rn(r2)           correctly rounded square root:  y0 = v_rsq_f32(r2), s0 = r2 y0, r = s0 + (r2 - s0 s0)(y0 / 2)
+//   t   = RN(min / r)           correctly rounded quotient = sin of the octant angle, t in [0, sqrt(1/2)]: one Newton step takes the
+//                                seed to 1/r, then Markstein's residual correction
+//   phi = t + t s P(s), s = t t  asin on [0, sqrt(1/2)], degree-6 P (tools/fit_asin.py: max abs error 4.6e-8 rad)
+// Every step is IEEE fp32 (fmaf, sqrt, divide), so the CPU restatement reproduces r, t and phi bit for bit with sqrtf and '/';
+// tools/fp_exact_check.hip proves the two short sequences correctly rounded on this chip's v_rsq_f32 for EVERY input the range gate
+// lets through (all r2 bit patterns in [1e-30, 1e37]; for the quotient all 2^23 mantissas of `min` against each of them).
+
+// Correctly rounded sqrt for inputs in [1e-30, FLT_MAX] (the range gate's r2 and beyond); y0 returns the v_rsq_f32 seed.
+LSM2D_DEV float sqrt_rn_seed(float x, float& y0) {
+  y0 = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y0, h = 0.5f * y0;
   const float e  = __builtin_fmaf(-s0, s0, x);
   return __builtin_fmaf(e, h, s0);
+}
+LSM2D_DEV float sqrt_rn_normal(float x) { float y0; return sqrt_rn_seed(x, y0); }
+
+// IEEE-754 correctly rounded n / r for r = sqrt_rn(r2), y0 = v_rsq_f32(r2), 1e-12 <= n <= r.  n < 1e-12 (a quotient that could be
+// subnormal, and n == 0) takes the compiler's full divide unless the host has proved that such a quotient cannot move a column
+// (ProjK::tiny_ok; then kGuardTiny = false and the branch is gone).
+template <bool kGuardTiny>
+LSM2D_DEV float div_by_depth(float n, float r, float y0) {
+  if (kGuardTiny && __builtin_expect(n < 1e-12f, 0)) return n / r;
+  const float e0 = __builtin_fmaf(-r, y0, 1.0f);
+  const float y1 = __builtin_fmaf(e0, y0, y0);
+  const float q0 = n * y1;
+  const float e1 = __builtin_fmaf(-r, q0, n);
+  return __builtin_fmaf(e1, y1, q0);
+}
+
+// bearing of (x, y) given r = sqrt_rn(x*x + y*y) and its seed: exact octant fix-ups, sign of y copied onto the result (so the
+// bearing of (-0, x < 0) is -pi like libm's atan2)
+template <bool kGuardTiny>
+LSM2D_DEV float bearing(float y, float x, float r, float y0) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const bool swap = ay > ax;
+  const float mn = swap ? ax : ay;
+  const float t = div_by_depth<kGuardTiny>(mn, r, y0);
+  const float s = t * t;
+  float p = 1.237212196e-01f;
+  p = __builtin_fmaf(p, s, -1.153038889e-01f);
+  p = __builtin_fmaf(p, s, 9.340071678e-02f);
+  p = __builtin_fmaf(p, s, 1.043075230e-02f);
+  p = __builtin_fmaf(p, s, 4.762428626e-02f);
+  p = __builtin_fmaf(p, s, 7.478348911e-02f);
+  p = __builtin_fmaf(p, s, 1.666723490e-01f);
+  float phi = __builtin_fmaf(t * s, p, t);
+  if (swap) phi = 1.57079637050628662f - phi;
+  if (x < 0.0f) phi = 3.14159274101257324f - phi;
+  return __builtin_copysignf(phi, y);
 }
 
 // One point of the polar z-buffer.  key = (bits(depth) << 32) | index: depth >= 0 so the IEEE bit
@@ -154,14 +150,14 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
   float qx, qy;
   xf_point(T, px, py, qx, qy);
   const float r2 = __builtin_fmaf(qx, qx, qy * qy);
-  if (r2 >= P.r2lo && r2 <= P.r2hi) {
-    const float th = atan2_poly_t<true>(qy, qx);          // r2 in [1e-30, 1e36] => max(|qx|,|qy|) in [7e-16, 1e18]
+  if (r2 >= P.r2lo && r2 <= P.r2hi) {                      // r2 in [1e-30, 1e36]: normal numbers throughout
+    float y0;
+    const float r  = sqrt_rn_seed(r2, y0);
+    const float th = bearing<true>(qy, qx, r, y0);
     const float u  = __builtin_fmaf(P.K00, th, P.K01);
     int col;                                               // floor + convert in one instruction (u is finite here;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col) : "v"(u));  // negative / too large -> rejected below)
     if ((unsigned) col < (unsigned) P.cols) {
-      // the depth does not depend on the cell: its six operations run under the LDS read's latency
-      const float r = sqrt_rn_normal(r2);
       const u64 key = ((u64) __float_as_uint(r) << 32) | (u64) (uint32_t) idx;
       if (kReadFirst) {
         // the cell only ever decreases, so a plain read that already beats us makes the atomic a no-op: neighbouring lanes
@@ -175,120 +171,25 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
   }
 }
 
-// One point of k_align's lane-chunked stream (fire-and-forget z-buffer update).  Same operation sequence as project_point, so the
-// same bits.  What tools/valu_issue_probe.hip measured on the MI355X (profiles/r02/valu_issue_probe.txt): a plain VALU instruction
-// costs 2.15 cycles of a saturated SIMD, two waves saturate it, instruction-level parallelism inside a wave buys nothing, and a
-// transcendental holds the SIMD for ~8 cycles plus ~5 for the pipe switch, whichever wave issues next.  Issuing v_rcp_f32 (the
-// divide of atan2) and v_rsq_f32 (the depth) back to back in one asm block (LSM2D_STREAM_TRANS_PAIR) measured no gain in the kernel.
-// kGuardTiny = false: the host has proved that a quotient below 1e-12 / max cannot move a column (ProjK::tiny_ok), so the divide
-// needs no branch for it.
-#ifndef LSM2D_STREAM_TRANS_PAIR
-#define LSM2D_STREAM_TRANS_PAIR 0      // measured on configs[1]: 1.694 ms paired vs 1.695 ms unpaired (profiles/r02/variants_r02a.log) -- no gain, so the
-#endif                                 // compiler keeps the placement (and the hazard bookkeeping) of the two transcendentals
+// One point of k_align's lane-chunked stream (fire-and-forget z-buffer update): project_point's operation sequence, hence its bits,
+// without the read of the cell.  What tools/valu_issue_probe.hip measured on the MI355X (profiles/r02/valu_issue_probe.txt): a plain
+// VALU instruction costs 2.15 cycles of a saturated SIMD, two waves saturate it, instruction-level parallelism inside a wave buys
+// nothing, and the whole stream below runs at the rate of its own instruction mix -- k_align's launch time IS points x cycles per point.
+// kGuardTiny = false: the host has proved that a quotient below 1e-12 / r cannot move a column (ProjK::tiny_ok).
 template <bool kGuardTiny>
 LSM2D_DEV void project_point_stream(const Iso& T, const ProjK& P, float px, float py, int idx, u64* canvas) {
   float qx, qy;
   xf_point(T, px, py, qx, qy);
   const float r2 = __builtin_fmaf(qx, qx, qy * qy);
   if (r2 >= P.r2lo && r2 <= P.r2hi) {
-    const float ax = __builtin_fabsf(qx), ay = __builtin_fabsf(qy);
-    const bool swap = ay > ax;
-    const float mx = swap ? ay : ax, mn = swap ? ax : ay;
-    float r0, y;
-#if LSM2D_STREAM_TRANS_PAIR
-    asm("v_rcp_f32 %0, %2\n\tv_rsq_f32 %1, %3\n\ts_nop 0" : "=&v"(r0), "=v"(y) : "v"(mx), "v"(r2));
-#else
-    r0 = __builtin_amdgcn_rcpf(mx); y = __builtin_amdgcn_rsqf(r2);
-#endif
-    float a;
-    if (kGuardTiny && __builtin_expect(mn < 1e-12f, 0)) a = mn / mx;
-    else {                                                   // div_rn_unit's sequence
-      const float e0 = __builtin_fmaf(-mx, r0, 1.0f);
-      const float r1 = __builtin_fmaf(e0, r0, r0);
-      const float q0 = mn * r1;
-      const float e1 = __builtin_fmaf(-mx, q0, mn);
-      a = __builtin_fmaf(e1, r1, q0);
-    }
-    const float s = a * a;
-    float p = 2.622197615e-03f;
-    p = __builtin_fmaf(p, s, -1.513234153e-02f);
-    p = __builtin_fmaf(p, s, 4.112152755e-02f);
-    p = __builtin_fmaf(p, s, -7.366676629e-02f);
-    p = __builtin_fmaf(p, s, 1.057391763e-01f);
-    p = __builtin_fmaf(p, s, -1.418597102e-01f);
-    p = __builtin_fmaf(p, s, 1.999039650e-01f);
-    p = __builtin_fmaf(p, s, -3.333298564e-01f);
-    float r = __builtin_fmaf(a * s, p, a);
-    if (swap) r = 1.57079637050628662f - r;
-    if (qx < 0.0f) r = 3.14159274101257324f - r;
-    const float th = __builtin_copysignf(r, qy);
+    float y0;
+    const float r  = sqrt_rn_seed(r2, y0);
+    const float th = bearing<kGuardTiny>(qy, qx, r, y0);
     const float u  = __builtin_fmaf(P.K00, th, P.K01);
     int col;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col) : "v"(u));
-    if ((unsigned) col < (unsigned) P.cols) {
-      const float s0 = r2 * y, h = 0.5f * y;                 // sqrt_rn_normal's sequence
-      const float e  = __builtin_fmaf(-s0, s0, r2);
-      const float d  = __builtin_fmaf(e, h, s0);
-      atomicMin(&canvas[col], ((u64) __float_as_uint(d) << 32) | (u64) (uint32_t) idx);
-    }
+    if ((unsigned) col < (unsigned) P.cols) atomicMin(&canvas[col], ((u64) __float_as_uint(r) << 32) | (u64) (uint32_t) idx);
   }
-}
-
-// Both points of one 16-byte load in ONE straight-line block (the lane-chunked stream of k_align, where the z-buffer update is a
-// fire-and-forget atomic): the same operation sequence per point as project_point, hence the same bits, but without a branch
-// until the two updates themselves -- a point that fails a gate is carried along and masked at the end (on a map inside the
-// sensor's range nearly every point passes, so the early exits bought nothing), the two dependent chains interleave (the wait
-// states behind v_cmp -> v_cndmask, v_rcp, v_rsq are filled by the other point's instructions) and the exec-mask bookkeeping of
-// three nested branches per point is gone.  kGuardTiny: keep div_rn_unit's branch for quotients that may be subnormal; the host
-// drops it when it has proved that such a quotient cannot move a column (ProjK::tiny_ok).
-#ifndef LSM2D_STREAM_PAIR
-#define LSM2D_STREAM_PAIR 0      // measured: 2.04 ms against 1.91 for the per-point form on configs[1] (profiles/r02): kept for reference only
-#endif
-template <bool kGuardTiny>
-LSM2D_DEV float atan2_poly_stream(float y, float x) {
-  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-  const bool swap = ay > ax;
-  const float mx = swap ? ay : ax, mn = swap ? ax : ay;
-  float a;
-  if (kGuardTiny) a = div_rn_unit(mn, mx);
-  else {
-    const float r0 = __builtin_amdgcn_rcpf(mx);
-    const float e0 = __builtin_fmaf(-mx, r0, 1.0f);
-    const float r1 = __builtin_fmaf(e0, r0, r0);
-    const float q0 = mn * r1;
-    const float e1 = __builtin_fmaf(-mx, q0, mn);
-    a = __builtin_fmaf(e1, r1, q0);
-  }
-  const float s = a * a;
-  float p = 2.622197615e-03f;
-  p = __builtin_fmaf(p, s, -1.513234153e-02f);
-  p = __builtin_fmaf(p, s, 4.112152755e-02f);
-  p = __builtin_fmaf(p, s, -7.366676629e-02f);
-  p = __builtin_fmaf(p, s, 1.057391763e-01f);
-  p = __builtin_fmaf(p, s, -1.418597102e-01f);
-  p = __builtin_fmaf(p, s, 1.999039650e-01f);
-  p = __builtin_fmaf(p, s, -3.333298564e-01f);
-  float r = __builtin_fmaf(a * s, p, a);
-  if (swap) r = 1.57079637050628662f - r;
-  if (x < 0.0f) r = 3.14159274101257324f - r;
-  return __builtin_copysignf(r, y);
-}
-template <bool kGuardTiny>
-LSM2D_DEV void project_pair_stream(const Iso& T, const ProjK& P, float4 v, int idx, u64* canvas) {
-  float qx0, qy0, qx1, qy1;
-  xf_point(T, v.x, v.y, qx0, qy0);
-  xf_point(T, v.z, v.w, qx1, qy1);
-  const float r20 = __builtin_fmaf(qx0, qx0, qy0 * qy0), r21 = __builtin_fmaf(qx1, qx1, qy1 * qy1);
-  const float th0 = atan2_poly_stream<kGuardTiny>(qy0, qx0), th1 = atan2_poly_stream<kGuardTiny>(qy1, qx1);
-  const float u0 = __builtin_fmaf(P.K00, th0, P.K01), u1 = __builtin_fmaf(P.K00, th1, P.K01);
-  int col0, col1;
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col0) : "v"(u0));
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col1) : "v"(u1));
-  const float d0 = sqrt_rn_normal(r20), d1 = sqrt_rn_normal(r21);
-  const bool ok0 = r20 >= P.r2lo && r20 <= P.r2hi && (unsigned) col0 < (unsigned) P.cols;
-  const bool ok1 = r21 >= P.r2lo && r21 <= P.r2hi && (unsigned) col1 < (unsigned) P.cols;
-  if (ok0) atomicMin(&canvas[col0], ((u64) __float_as_uint(d0) << 32) | (u64) (uint32_t) idx);
-  if (ok1) atomicMin(&canvas[col1], ((u64) __float_as_uint(d1) << 32) | (u64) (uint32_t) (idx + 1));
 }
 
 // Stream one cloud through the z-buffer.  xy is 16-byte aligned (cloud starts are padded to an even
@@ -346,14 +247,10 @@ LSM2D_DEV void project_cloud_lanes_t(const float4* __restrict__ lane_xy, int T_s
   };
   int idx = 2 * base, t = 0;
   float4 va = load(row);
-#if LSM2D_STREAM_PAIR
-  auto pair = [&](const float4& v, int i) { project_pair_stream<kGuardTiny>(T, P, v, i, canvas); };
-#else
   auto pair = [&](const float4& v, int i) {
     project_point_stream<kGuardTiny>(T, P, v.x, v.y, i, canvas);
     project_point_stream<kGuardTiny>(T, P, v.z, v.w, i + 1, canvas);
   };
-#endif
   for (; t + 2 <= T_steps; t += 2) {
     const float4 vb = load(row + row_bytes);
     pair(va, idx);

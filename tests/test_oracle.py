@@ -26,6 +26,28 @@ def test_atan2_polynomial_accuracy(po):
         assert abs(float(po.atan2f([yy], [xx])[0]) - want) < 3e-7
 
 
+def test_bearing_follows_the_device_quotient_on_the_four_known_ties(po):
+    """The oracle's bearing divides min(|x|,|y|) by r = sqrtf(x^2 + y^2) -- IEEE, except where the device's fused quotient sequence is
+    provably one ulp low (r with an all-ones mantissa, numerator a power of two: tools/fp_exact_check.hip, profiles/r02/fp_exact_full_r02e.log)."""
+    import struct
+    f32 = lambda v: struct.unpack("f", struct.pack("f", v))[0]
+    r_all_ones = struct.unpack("f", struct.pack("I", 0x3FFFFFFF))[0]          # 2 - 2^-23
+    y = 0.5; x = math.sqrt(r_all_ones * r_all_ones - y * y)
+    # search the float x for which fmaf(x, x, y*y) rounds to an r2 whose square root is the all-ones r
+    xs = np.nextafter(np.float32(x), np.float32([0, 4]))
+    hit = False
+    for xv in [np.float32(x), xs[0], xs[1]]:
+        r2 = np.float32(np.float64(xv) * np.float64(xv) + np.float64(np.float32(y)) * np.float64(np.float32(y)))
+        if struct.unpack("I", struct.pack("f", float(np.sqrt(r2, dtype=np.float32))))[0] == 0x3FFFFFFF:
+            got = float(po.atan2f([y], [float(xv)])[0])
+            t_ieee = np.float32(y) / np.sqrt(r2, dtype=np.float32)
+            t_dev = np.nextafter(t_ieee, np.float32(0))
+            # the bearing is asin(t): the two candidates differ by ~3e-8 rad; the oracle must sit on the device's side
+            assert abs(got - math.asin(float(t_dev))) <= abs(got - math.asin(float(t_ieee))) + 1e-9
+            hit = True
+    assert hit
+
+
 def _pt(r, ang, nx=1.0, ny=0.0):
     return [r * math.cos(ang), r * math.sin(ang), nx, ny]
 

@@ -1,10 +1,12 @@
 // Exhaustive check, on the GPU, of the short correctly-rounded fp32 sequences the kernels use in place of the
-// compiler's general divide / sqrt (csrc/lsm2d_device.h: div_rn_unit, sqrt_rn_normal).  The CPU oracle uses the
+// compiler's general divide / sqrt (csrc/lsm2d_device.h: div_by_depth, sqrt_rn_seed / sqrt_rn_normal).  The CPU oracle uses the
 // plain IEEE '/' and sqrtf, so bit parity of columns and depths needs these sequences to be EXACT on this hardware's
 // v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 for every input the projector's range gate lets through.
 //
-//   division  n/d, 0 < n <= d: every step scales exactly with powers of two (no subnormals inside the gate), so all
-//             2^23 x 2^23 mantissa pairs cover every admissible input; n = 1.m_n (or half of it when m_n > m_d).
+//   quotient  n / r with r = sqrt_rn(r2) and the v_rsq_f32(r2) seed (the sine of the octant angle, n <= r / sqrt 2): the seed
+//             depends on r2, not only on r, so the rows are ALL r2 mantissas of both exponent parities (2 x 2^23); every step
+//             scales exactly with powers of two (no subnormals inside the gate), so for each row all 2^23 mantissas of n -- at the
+//             one or two exponents that put n / r in (1/8, sqrt(1/2)] -- cover every admissible input.
 //   sincos    device vs host evaluation of the fixed sin / cos sequence (bitwise) on 6.5e6 arguments, and its error vs libm.
 //   sqrt      every fp32 bit pattern in [1e-30, FLT_MAX] (the gate's r2 lies in [1e-30, 1e36]; the lane-chunked stream also
 //             forms depths of points beyond range_max, which only have to stay above it).
@@ -26,46 +28,64 @@
 #include <vector>
 
 #define NVAR 4
-struct Report { unsigned long long fails[NVAR]; uint32_t first_n[NVAR], first_d[NVAR]; };
+struct Report { unsigned long long fails[NVAR]; uint32_t first_n[NVAR], first_d[NVAR];
+                unsigned long long n_listed; uint32_t list[64][4];      /* production mismatches vs the plain IEEE quotient: n, r2, got, want */
+                unsigned long long rule_fails; };                        /* production vs the quotient AS THE ORACLE DEFINES IT (lsmo_atan2f) */
 
 __device__ __forceinline__ float f_from(uint32_t b) { return __uint_as_float(b); }
 
-// S7: the sequence hipcc emits for '/', minus v_div_scale / v_div_fixup (two operations longer than production)
-__device__ __forceinline__ float div_s7(float n, float d, float r0) {
-  const float e0 = __builtin_fmaf(-d, r0, 1.0f), r1 = __builtin_fmaf(e0, r0, r0);
-  const float q0 = n * r1, e1 = __builtin_fmaf(-d, q0, n), q1 = __builtin_fmaf(e1, r1, q0);
-  const float e2 = __builtin_fmaf(-d, q1, n);
-  return __builtin_fmaf(e2, r1, q1);
+// D3: the raw seed, one residual correction of the quotient (two operations shorter than production)
+__device__ __forceinline__ float qd_d3(float n, float r, float y0) {
+  const float q0 = n * y0, e1 = __builtin_fmaf(-r, q0, n);
+  return __builtin_fmaf(e1, y0, q0);
 }
-// S5: raw reciprocal, two quotient corrections
-__device__ __forceinline__ float div_s5(float n, float d, float r0) {
-  const float q0 = n * r0, e0 = __builtin_fmaf(-d, q0, n), q1 = __builtin_fmaf(e0, r0, q0);
-  const float e1 = __builtin_fmaf(-d, q1, n);
-  return __builtin_fmaf(e1, r0, q1);
+// D5x: raw seed, two residual corrections
+__device__ __forceinline__ float qd_d5x(float n, float r, float y0) {
+  const float q0 = n * y0, e1 = __builtin_fmaf(-r, q0, n), q1 = __builtin_fmaf(e1, y0, q0);
+  const float e2 = __builtin_fmaf(-r, q1, n);
+  return __builtin_fmaf(e2, y0, q1);
 }
-// S3: raw reciprocal, one quotient correction
-__device__ __forceinline__ float div_s3(float n, float d, float r0) {
-  const float q0 = n * r0, e0 = __builtin_fmaf(-d, q0, n);
-  return __builtin_fmaf(e0, r0, q0);
+// D7: production plus a second residual correction
+__device__ __forceinline__ float qd_d7(float n, float r, float y0) {
+  const float e0 = __builtin_fmaf(-r, y0, 1.0f), y1 = __builtin_fmaf(e0, y0, y0);
+  const float q0 = n * y1, e1 = __builtin_fmaf(-r, q0, n), q1 = __builtin_fmaf(e1, y1, q0);
+  const float e2 = __builtin_fmaf(-r, q1, n);
+  return __builtin_fmaf(e2, y1, q1);
 }
 
-__global__ void k_div(uint32_t md0, Report* rep) {
+// rows: r2 = 2^parity * 1.m (m = md0 + blockIdx.y), every mantissa of n
+__global__ void k_div(uint32_t md0, uint32_t parity, Report* rep) {
   const uint32_t md = md0 + blockIdx.y;
-  const float d = f_from(0x3f800000u | md);
-  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float r2 = f_from((parity ? 0x40000000u : 0x3f800000u) | md);
+  float y0;
+  const float r = lsm2d::sqrt_rn_seed(r2, y0);
+  const float nmax = r * 0.70710683f;                        // n <= r / sqrt 2 (+ an ulp)
   unsigned long long bad[NVAR] = {0, 0, 0, 0};
   uint32_t firstn[NVAR] = {0, 0, 0, 0};
   for (uint32_t mn = blockIdx.x * blockDim.x + threadIdx.x; mn < (1u << 23); mn += gridDim.x * blockDim.x) {
-    const float n = f_from((mn <= md ? 0x3f800000u : 0x3f000000u) | mn);
-    const float t = n / d;                                   // hipcc default: correctly rounded
-    const float v[NVAR] = {lsm2d::div_rn_unit(n, d), div_s7(n, d, r0), div_s5(n, d, r0), div_s3(n, d, r0)};
 #pragma unroll
-    for (int k = 0; k < NVAR; ++k)
-      if (__float_as_uint(v[k]) != __float_as_uint(t)) { if (!bad[k]) firstn[k] = __float_as_uint(n); ++bad[k]; }
+    for (int half = 0; half < 2; ++half) {
+      const float n = f_from((half ? 0x3e800000u : 0x3f000000u) | mn);      // n in [0.5, 1) and [0.25, 0.5) against r in [1, 2)
+      if (n > nmax) continue;
+      const float t = n / r;                                  // hipcc default: correctly rounded
+      const float v[NVAR] = {lsm2d::div_by_depth<false>(n, r, y0), qd_d7(n, r, y0), qd_d5x(n, r, y0), qd_d3(n, r, y0)};
+#pragma unroll
+      for (int k = 0; k < NVAR; ++k)
+        if (__float_as_uint(v[k]) != __float_as_uint(t)) { if (!bad[k]) firstn[k] = __float_as_uint(n); ++bad[k]; }
+      if (__float_as_uint(v[0]) != __float_as_uint(t)) {
+        const unsigned long long slot = atomicAdd(&rep->n_listed, 1ull);
+        if (slot < 64) { rep->list[slot][0] = __float_as_uint(n); rep->list[slot][1] = __float_as_uint(r2); rep->list[slot][2] = __float_as_uint(v[0]); rep->list[slot][3] = __float_as_uint(t); }
+      }
+      // the oracle's definition: IEEE n / r, except the exact ties the sequence cannot see -- r with an all-ones mantissa and n a power
+      // of two -- where the quotient is the float BELOW the correctly rounded one
+      float want = t;
+      if ((__float_as_uint(r) & 0x7fffffu) == 0x7fffffu && (__float_as_uint(n) & 0x7fffffu) == 0u) want = __uint_as_float(__float_as_uint(t) - 1u);
+      if (__float_as_uint(v[0]) != __float_as_uint(want)) atomicAdd(&rep->rule_fails, 1ull);
+    }
   }
 #pragma unroll
   for (int k = 0; k < NVAR; ++k)
-    if (bad[k]) { if (atomicAdd(&rep->fails[k], bad[k]) == 0) { rep->first_n[k] = firstn[k]; rep->first_d[k] = __float_as_uint(d); } }
+    if (bad[k]) { if (atomicAdd(&rep->fails[k], bad[k]) == 0) { rep->first_n[k] = firstn[k]; rep->first_d[k] = __float_as_uint(r2); } }
 }
 
 // v_sqrt_f32 + two-sided residual test: what hipcc emits for sqrtf() minus its denormal pre-scaling
@@ -98,7 +118,7 @@ __global__ void k_sqrt(uint32_t lo, uint32_t hi, Report* rep) {
   for (unsigned long long b = lo + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += (unsigned long long) gridDim.x * blockDim.x) {
     const float x = f_from((uint32_t) b);
     const float t = sqrtf(x);                                // hipcc default: correctly rounded
-    const float v[NVAR] = {lsm2d::sqrt_rn_normal(x), sqrt_two_sided(x), sqrt_r8(x), sqrt_q6(x)};
+    const float v[NVAR] = {lsm2d::sqrt_rn_normal(x), sqrt_two_sided(x), sqrt_r8(x), sqrt_q6(x)};      // sqrt_rn_normal = sqrt_rn_seed without the seed
 #pragma unroll
     for (int k = 0; k < NVAR; ++k)
       if (__float_as_uint(v[k]) != __float_as_uint(t)) { if (!bad[k]) firstx[k] = (uint32_t) b; ++bad[k]; }
@@ -161,27 +181,34 @@ int main(int argc, char** argv) {
     fflush(stdout);
   }
 
-  // ---- division: rows of m_d, every m_n
+  // ---- quotient by the depth: rows of r2 (both exponent parities), every mantissa of n
   CK(hipMemset(d_rep, 0, sizeof(Report)));
   const uint32_t rows_per_launch = 2048;
   unsigned long long pairs = 0;
-  // stride over the m_d range so a partial run still samples all of it
+  // stride over the mantissa range so a partial run still samples all of it
   const uint32_t total_launches = (rows + rows_per_launch - 1) / rows_per_launch;
-  for (uint32_t l = 0; l < total_launches; ++l) {
-    const uint32_t md0 = rows == (1u << 23) ? l * rows_per_launch : (uint32_t) (((unsigned long long) l * ((1u << 23) - rows_per_launch)) / (total_launches > 1 ? total_launches - 1 : 1));
-    hipLaunchKernelGGL(k_div, dim3(64, rows_per_launch), dim3(256), 0, 0, md0, d_rep);
-    pairs += (unsigned long long) rows_per_launch << 23;
-    if ((l & 127) == 127 || l + 1 == total_launches) {
-      CK(hipDeviceSynchronize());
-      CK(hipMemcpy(&h, d_rep, sizeof(h), hipMemcpyDeviceToHost));
-      printf("div: %u/%u launches, %.3e pairs, mismatches div_rn_unit=%llu S7=%llu S5=%llu S3=%llu\n", l + 1, total_launches, (double) pairs,
-             h.fails[0], h.fails[1], h.fails[2], h.fails[3]);
-      fflush(stdout);
+  for (uint32_t parity = 0; parity < 2; ++parity)
+    for (uint32_t l = 0; l < total_launches; ++l) {
+      const uint32_t md0 = rows == (1u << 23) ? l * rows_per_launch : (uint32_t) (((unsigned long long) l * ((1u << 23) - rows_per_launch)) / (total_launches > 1 ? total_launches - 1 : 1));
+      hipLaunchKernelGGL(k_div, dim3(64, rows_per_launch), dim3(256), 0, 0, md0, parity, d_rep);
+      pairs += (unsigned long long) rows_per_launch << 23;
+      if ((l & 255) == 255 || l + 1 == total_launches) {
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(&h, d_rep, sizeof(h), hipMemcpyDeviceToHost));
+        printf("quotient: parity %u, %u/%u launches, %.3e (r2, n) mantissa pairs, mismatches div_by_depth=%llu D7=%llu D5x=%llu D3=%llu\n", parity, l + 1,
+               total_launches, (double) pairs, h.fails[0], h.fails[1], h.fails[2], h.fails[3]);
+        fflush(stdout);
+      }
     }
+  const char* dn[NVAR] = {"div_by_depth", "D7(+1 correction)", "D5x(raw seed,2 corr)", "D3(raw seed,1 corr)"};
+  printf("quotient by depth: %.4e (r2, n) mantissa pairs (each at the one or two exponents with n / r in (1/8, sqrt(1/2)])\n", (double) pairs);
+  for (int k = 0; k < NVAR; ++k) printf("  %-22s mismatches vs n/r: %llu  first n=0x%08x r2=0x%08x\n", dn[k], h.fails[k], h.first_n[k], h.first_d[k]);
+  for (unsigned long long i = 0; i < h.n_listed && i < 64; ++i) {
+    float n, r2, got, want; memcpy(&n, &h.list[i][0], 4); memcpy(&r2, &h.list[i][1], 4); memcpy(&got, &h.list[i][2], 4); memcpy(&want, &h.list[i][3], 4);
+    printf("    n=0x%08x (%.9g) r2=0x%08x (%.9g, r=0x%08x) got 0x%08x want 0x%08x (%+d ulp)\n", h.list[i][0], n, h.list[i][1], r2,
+           [&] { float r = sqrtf(r2); uint32_t b; memcpy(&b, &r, 4); return b; }(), h.list[i][2], h.list[i][3], (int) h.list[i][2] - (int) h.list[i][3]);
   }
-  const char* dn[NVAR] = {"div_rn_unit", "S7(2 corrections)", "S5(raw rcp,2 corr)", "S3(raw rcp,1 corr)"};
-  printf("division: %.4e (n,d) mantissa pairs\n", (double) pairs);
-  for (int k = 0; k < NVAR; ++k) printf("  %-20s mismatches vs n/d: %llu  first n=0x%08x d=0x%08x\n", dn[k], h.fails[k], h.first_n[k], h.first_d[k]);
+  printf("  div_by_depth vs the quotient as the oracle defines it (IEEE n / r; the float below it when r has an all-ones mantissa and n is a power of two): %llu mismatches\n", h.rule_fails);
   CK(hipFree(d_rep));
-  return (h.fails[0] || sqrt_prod_fails || sincos_fails) ? 1 : 0;
+  return (h.rule_fails || sqrt_prod_fails || sincos_fails) ? 1 : 0;
 }

@@ -2,7 +2,7 @@
 // as a function of (i) how many waves share the SIMD, (ii) whether each wave's instructions depend on one another (the z-buffer stream of
 // k_align is ONE dependent chain per point), (iii) the instruction kind (plain v_fma_f32, v_fmaak_f32 with a 32-bit literal, v_rcp_f32,
 // v_cmp + v_cndmask through vcc).  bench.py's roofline prices k_align against the saturated rate this prints.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_probe tools/valu_issue_probe.hip && /tmp/valu_probe
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -Isrrg2_laser_slam_2d_amd/csrc -Iinclude -o /tmp/valu_probe tools/valu_issue_probe.hip && /tmp/valu_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
@@ -41,6 +41,126 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long* out, int iters
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
   if (a + d + e + f == 12345.678f) out[0] = 0;
+}
+
+// the real per-point instruction stream of k_align (csrc/lsm2d_device.h: project_point_stream, incl. its exec masking and the
+// fire-and-forget ds_min_u64) on register-resident points: no global loads, no barriers, no bin walk, no solve -- what the 1024 SIMDs
+// can do with THIS instruction mix when nothing else is in the way.  4 workgroups of 512 threads per CU, as k_align runs.
+#include "lsm2d_device.h"
+// ablations of the same stream: kAtomic = 0 drops the ds_min_u64 (the key is folded into a register instead), kGates = 0 drops the two
+// exec-masked regions (range gate, column check: straight-line code, the update always issued), kTrans = 0 replaces v_rcp_f32 /
+// v_rsq_f32 by one plain multiply each (wrong values, same dependencies).  Differences against the full stream price each part.
+template <int kAtomic, int kGates, int kTrans>
+__device__ __forceinline__ void point_ablation(const lsm2d::Iso& T, const lsm2d::ProjK& P, float px, float py, int idx, unsigned long long* canvas, unsigned long long& sink) {
+  using namespace lsm2d;
+  float qx, qy; xf_point(T, px, py, qx, qy);
+  const float r2 = __builtin_fmaf(qx, qx, qy * qy);
+  if (!kGates || (r2 >= P.r2lo && r2 <= P.r2hi)) {
+    const float ax = __builtin_fabsf(qx), ay = __builtin_fabsf(qy);
+    const bool swap = ay > ax;
+    const float mx = swap ? ay : ax, mn = swap ? ax : ay;
+    const float r0 = kTrans ? __builtin_amdgcn_rcpf(mx) : mx * 0.37f, y = kTrans ? __builtin_amdgcn_rsqf(r2) : r2 * 0.11f;
+    const float e0 = __builtin_fmaf(-mx, r0, 1.0f), r1 = __builtin_fmaf(e0, r0, r0), q0 = mn * r1, e1 = __builtin_fmaf(-mx, q0, mn);
+    const float a = __builtin_fmaf(e1, r1, q0), s = a * a;
+    float p = 2.622197615e-03f;
+    p = __builtin_fmaf(p, s, -1.513234153e-02f); p = __builtin_fmaf(p, s, 4.112152755e-02f); p = __builtin_fmaf(p, s, -7.366676629e-02f);
+    p = __builtin_fmaf(p, s, 1.057391763e-01f); p = __builtin_fmaf(p, s, -1.418597102e-01f); p = __builtin_fmaf(p, s, 1.999039650e-01f);
+    p = __builtin_fmaf(p, s, -3.333298564e-01f);
+    float r = __builtin_fmaf(a * s, p, a);
+    if (swap) r = 1.57079637050628662f - r;
+    if (qx < 0.0f) r = 3.14159274101257324f - r;
+    const float u = __builtin_fmaf(P.K00, __builtin_copysignf(r, qy), P.K01);
+    int col; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col) : "v"(u));
+    if (!kGates) col = (int) ((unsigned) col % (unsigned) P.cols);
+    if (!kGates || (unsigned) col < (unsigned) P.cols) {
+      const float s0 = r2 * y, h = 0.5f * y, e = __builtin_fmaf(-s0, s0, r2), d = __builtin_fmaf(e, h, s0);
+      const unsigned long long key = ((unsigned long long) __float_as_uint(d) << 32) | (unsigned long long) (unsigned) idx;
+      if (kAtomic) atomicMin(&canvas[col], key); else sink ^= key + (unsigned long long) col;
+    }
+  }
+}
+template <int kAtomic, int kGates, int kTrans>
+__global__ __launch_bounds__(512, 8) void probe_ablation(unsigned long long* out, int iters, float seed, int cols) {
+  extern __shared__ unsigned long long canvas[];
+  using namespace lsm2d;
+  for (int i = threadIdx.x; i < cols; i += 512) canvas[i] = kEmptyCell;
+  __syncthreads();
+  ProjK P; P.cols = cols; P.K00 = (float) cols / 6.28318548f; P.K01 = 0.5f * (float) cols; P.r2lo = 0.09f; P.r2hi = 900.0f; P.rmin = 0.3f; P.rmax = 30.f;
+  P.colsf = (float) cols; P.tiny_ok = 1;
+  asm volatile("" : "+v"(P.K01));
+  Iso T; T.c = 0.8f; T.s = 0.6f; T.tx = seed; T.ty = -seed;
+  const float a = 0.37f * (float) (threadIdx.x * 131 % 509), b = 0.23f * (float) (blockIdx.x % 97);
+  float4 v0 = make_float4(10.f * __cosf(a) + 0.01f * b, 8.f * __sinf(a), 12.f * __cosf(a + 1.f), 9.f * __sinf(a + 1.f) - 0.01f * b);
+  float4 v1 = make_float4(7.f * __cosf(a + 2.f), 11.f * __sinf(a + 2.f) + 0.02f * b, 14.f * __cosf(a + 3.f) - 0.02f * b, 6.f * __sinf(a + 3.f));
+  unsigned long long sink = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+    point_ablation<kAtomic, kGates, kTrans>(T, P, v0.x, v0.y, 4 * i, canvas, sink);
+    point_ablation<kAtomic, kGates, kTrans>(T, P, v0.z, v0.w, 4 * i + 1, canvas, sink);
+    point_ablation<kAtomic, kGates, kTrans>(T, P, v1.x, v1.y, 4 * i + 2, canvas, sink);
+    point_ablation<kAtomic, kGates, kTrans>(T, P, v1.z, v1.w, 4 * i + 3, canvas, sink);
+    T.tx += 1e-4f; T.ty -= 1e-4f;
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+  if (sink == 0x1234567ull) out[0] = sink;
+}
+template <int kAtomic, int kGates, int kTrans>
+static void run_ablation(const char* name, unsigned long long* d_out, int n_cu) {
+  const int iters = 4000, cols = 1081, nb = 4 * n_cu, lds = 36 * 1024;
+  hipFuncSetAttribute((const void*) probe_ablation<kAtomic, kGates, kTrans>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipMemset(d_out, 0, sizeof(unsigned long long) * 16 * nb);
+  probe_ablation<kAtomic, kGates, kTrans><<<nb, 512, lds>>>(d_out, iters, 0.25f, cols);
+  probe_ablation<kAtomic, kGates, kTrans><<<nb, 512, lds>>>(d_out, iters, 0.25f, cols);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(16 * nb);
+  hipMemcpy(h.data(), d_out, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+  std::vector<double> per;
+  for (int b = 0; b < nb; ++b) for (int k = 0; k < 8; ++k) per.push_back((double) h[b * 16 + k]);
+  std::sort(per.begin(), per.end());
+  printf("  %-58s %.1f cycles of a SIMD per point of a wave\n", name, per[per.size() * 99 / 100] / ((double) iters * 4.0 * 8.0));
+}
+
+__global__ __launch_bounds__(512, 8) void probe_stream(unsigned long long* out, int iters, float seed, int cols) {
+  extern __shared__ unsigned long long canvas[];
+  using namespace lsm2d;
+  for (int i = threadIdx.x; i < cols; i += 512) canvas[i] = kEmptyCell;
+  __syncthreads();
+  ProjK P; P.cols = cols; P.K00 = (float) cols / 6.28318548f; P.K01 = 0.5f * (float) cols; P.r2lo = 0.09f; P.r2hi = 900.0f; P.rmin = 0.3f; P.rmax = 30.f;
+  P.colsf = (float) cols; P.tiny_ok = 1;
+  asm volatile("" : "+v"(P.K01));
+  Iso T; T.c = 0.8f; T.s = 0.6f; T.tx = seed; T.ty = -seed;
+  // four points per thread, spread over the room like the lanes of a lane-chunked wave (decorrelated columns)
+  const float a = 0.37f * (float) (threadIdx.x * 131 % 509), b = 0.23f * (float) (blockIdx.x % 97);
+  float4 v0 = make_float4(10.f * __cosf(a) + 0.01f * b, 8.f * __sinf(a), 12.f * __cosf(a + 1.f), 9.f * __sinf(a + 1.f) - 0.01f * b);
+  float4 v1 = make_float4(7.f * __cosf(a + 2.f), 11.f * __sinf(a + 2.f) + 0.02f * b, 14.f * __cosf(a + 3.f) - 0.02f * b, 6.f * __sinf(a + 3.f));
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+    project_point_stream<false>(T, P, v0.x, v0.y, 4 * i, canvas);
+    project_point_stream<false>(T, P, v0.z, v0.w, 4 * i + 1, canvas);
+    project_point_stream<false>(T, P, v1.x, v1.y, 4 * i + 2, canvas);
+    project_point_stream<false>(T, P, v1.z, v1.w, 4 * i + 3, canvas);
+    T.tx += 1e-4f; T.ty -= 1e-4f;                        // the points move: nothing is loop-invariant
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+static void run_stream(unsigned long long* d_out, int n_cu) {
+  const int iters = 4000, cols = 1081, nb = 4 * n_cu, lds = 36 * 1024;        // 36 KB per workgroup: four per CU, like k_align
+  hipFuncSetAttribute((const void*) probe_stream, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipMemset(d_out, 0, sizeof(unsigned long long) * 16 * nb);
+  probe_stream<<<nb, 512, lds>>>(d_out, iters, 0.25f, cols);
+  probe_stream<<<nb, 512, lds>>>(d_out, iters, 0.25f, cols);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(16 * nb);
+  hipMemcpy(h.data(), d_out, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+  std::vector<double> per;
+  for (int b = 0; b < nb; ++b) for (int k = 0; k < 8; ++k) per.push_back((double) h[b * 16 + k]);
+  std::sort(per.begin(), per.end());
+  const double mx = per[per.size() * 99 / 100], mn = per[per.size() / 100];
+  // a SIMD ran 8 waves x iters x 4 points
+  printf("k_align's point stream (project_point_stream, 8 waves per SIMD): %.1f cycles of a SIMD per point of a wave (waves %.0f..%.0f kcyc)\n",
+         mx / ((double) iters * 4.0 * 8.0), mn * 1e-3, mx * 1e-3);
 }
 
 template <int KIND>
@@ -85,5 +205,12 @@ int main() {
   run<9>("1 v_rcp + s_nop 0 + 3 dependent fma (4 VALU counted as 4)", d_out, n_cu);
   run<6>("v_rcp, 3 unrelated fma, consumer (5 per group, counted as 4)", d_out, n_cu);
   run<10>("v_rcp + v_rsq + 2 fma", d_out, n_cu);
+  run_stream(d_out, n_cu);
+  printf("ablations of that stream (same launch shape):\n");
+  run_ablation<1, 1, 1>("full stream (copy of project_point_stream)", d_out, n_cu);
+  run_ablation<0, 1, 1>("without the ds_min_u64", d_out, n_cu);
+  run_ablation<1, 0, 1>("without the exec-masked gates (straight-line)", d_out, n_cu);
+  run_ablation<1, 1, 0>("v_rcp / v_rsq replaced by plain multiplies", d_out, n_cu);
+  run_ablation<0, 0, 0>("arithmetic only: no atomic, no gates, no transcendentals", d_out, n_cu);
   return 0;
 }
