@@ -32,7 +32,7 @@ struct ProjK {
   float r2lo, r2hi;     // ... restated on r2: rmin <= sqrt_rn(r2) <= rmax  <=>  r2lo <= r2 <= r2hi (host-proved, sqrt_rn is monotone)
   float colsf;          // (float) canvas_cols
   int   cols;
-  int   tiny_ok;        // host-proved: a quotient min/max below 1e-12 / max cannot move a column, whatever tiny value it gets (make_projk)
+  int   tiny_ok;        // host-proved: a quotient min / r below 1e-12 / r cannot move a column, whatever tiny value it gets (make_projk)
 };
 
 // cos / sin of a pose angle as a fixed operation sequence (the CPU restatement evaluates the same sequence, operation for operation; coefficients from
@@ -175,8 +175,11 @@ LSM2D_DEV void project_point(const Iso& T, const ProjK& P, float px, float py, i
 // without the read of the cell.  What tools/valu_issue_probe.hip measured on the MI355X (profiles/r02/valu_issue_probe.txt): a plain
 // VALU instruction costs 2.15 cycles of a saturated SIMD, two waves saturate it, instruction-level parallelism inside a wave buys
 // nothing, and the whole stream below runs at the rate of its own instruction mix -- k_align's launch time IS points x cycles per point.
-// kGuardTiny = false: the host has proved that a quotient below 1e-12 / r cannot move a column (ProjK::tiny_ok).
-template <bool kGuardTiny>
+// kGuarded = false: the host has proved that a quotient below 1e-12 / r cannot move a column (ProjK::tiny_ok): no branch for it.
+// Measured and rejected on top of this (same box, profiles/r02/variants_r02e.log): dropping the column check as well (a spare cell
+// behind the canvas takes column `cols`, a full-circle canvas cannot produce any other) 1.494 ms against 1.478 with the check; pinning
+// the gate's bounds in SGPRs in front of the loop (which removes an s_waitcnt lgkmcnt(0) per trip) 1.495 against 1.494.
+template <bool kGuarded>
 LSM2D_DEV void project_point_stream(const Iso& T, const ProjK& P, float px, float py, int idx, u64* canvas) {
   float qx, qy;
   xf_point(T, px, py, qx, qy);
@@ -184,7 +187,7 @@ LSM2D_DEV void project_point_stream(const Iso& T, const ProjK& P, float px, floa
   if (r2 >= P.r2lo && r2 <= P.r2hi) {
     float y0;
     const float r  = sqrt_rn_seed(r2, y0);
-    const float th = bearing<kGuardTiny>(qy, qx, r, y0);
+    const float th = bearing<kGuarded>(qy, qx, r, y0);
     const float u  = __builtin_fmaf(P.K00, th, P.K01);
     int col;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col) : "v"(u));
@@ -223,7 +226,7 @@ LSM2D_DEV void project_cloud(const float2* __restrict__ xy, int n, const Iso& Ti
 // neighbouring points in neighbouring lanes) is gone, and with it the reason to read a cell before updating it -- the
 // update is one fire-and-forget LDS atomic and the stream never waits on the LDS.  Padding slots hold +inf and fail the
 // range gate.
-template <bool kGuardTiny>
+template <bool kGuarded>
 LSM2D_DEV void project_cloud_lanes_t(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin,
                                      u64* canvas, int tid, int nthreads) {
   const Iso T = Tin; ProjK P = Pin;
@@ -248,8 +251,8 @@ LSM2D_DEV void project_cloud_lanes_t(const float4* __restrict__ lane_xy, int T_s
   int idx = 2 * base, t = 0;
   float4 va = load(row);
   auto pair = [&](const float4& v, int i) {
-    project_point_stream<kGuardTiny>(T, P, v.x, v.y, i, canvas);
-    project_point_stream<kGuardTiny>(T, P, v.z, v.w, i + 1, canvas);
+    project_point_stream<kGuarded>(T, P, v.x, v.y, i, canvas);
+    project_point_stream<kGuarded>(T, P, v.z, v.w, i + 1, canvas);
   };
   for (; t + 2 <= T_steps; t += 2) {
     const float4 vb = load(row + row_bytes);

@@ -48,34 +48,33 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long* out, int iters
 // can do with THIS instruction mix when nothing else is in the way.  4 workgroups of 512 threads per CU, as k_align runs.
 #include "lsm2d_device.h"
 // ablations of the same stream: kAtomic = 0 drops the ds_min_u64 (the key is folded into a register instead), kGates = 0 drops the two
-// exec-masked regions (range gate, column check: straight-line code, the update always issued), kTrans = 0 replaces v_rcp_f32 /
-// v_rsq_f32 by one plain multiply each (wrong values, same dependencies).  Differences against the full stream price each part.
+// exec-masked regions (range gate, column check: straight-line code, the column clamped, the update always issued), kTrans = 0
+// replaces v_rsq_f32 by a plain multiply (wrong values, same dependencies).  Differences against the full stream price each part.
 template <int kAtomic, int kGates, int kTrans>
 __device__ __forceinline__ void point_ablation(const lsm2d::Iso& T, const lsm2d::ProjK& P, float px, float py, int idx, unsigned long long* canvas, unsigned long long& sink) {
   using namespace lsm2d;
   float qx, qy; xf_point(T, px, py, qx, qy);
   const float r2 = __builtin_fmaf(qx, qx, qy * qy);
   if (!kGates || (r2 >= P.r2lo && r2 <= P.r2hi)) {
+    const float y0 = kTrans ? __builtin_amdgcn_rsqf(r2) : r2 * 0.11f;
+    const float s0 = r2 * y0, h = 0.5f * y0, e = __builtin_fmaf(-s0, s0, r2), r = __builtin_fmaf(e, h, s0);
     const float ax = __builtin_fabsf(qx), ay = __builtin_fabsf(qy);
     const bool swap = ay > ax;
-    const float mx = swap ? ay : ax, mn = swap ? ax : ay;
-    const float r0 = kTrans ? __builtin_amdgcn_rcpf(mx) : mx * 0.37f, y = kTrans ? __builtin_amdgcn_rsqf(r2) : r2 * 0.11f;
-    const float e0 = __builtin_fmaf(-mx, r0, 1.0f), r1 = __builtin_fmaf(e0, r0, r0), q0 = mn * r1, e1 = __builtin_fmaf(-mx, q0, mn);
-    const float a = __builtin_fmaf(e1, r1, q0), s = a * a;
-    float p = 2.622197615e-03f;
-    p = __builtin_fmaf(p, s, -1.513234153e-02f); p = __builtin_fmaf(p, s, 4.112152755e-02f); p = __builtin_fmaf(p, s, -7.366676629e-02f);
-    p = __builtin_fmaf(p, s, 1.057391763e-01f); p = __builtin_fmaf(p, s, -1.418597102e-01f); p = __builtin_fmaf(p, s, 1.999039650e-01f);
-    p = __builtin_fmaf(p, s, -3.333298564e-01f);
-    float r = __builtin_fmaf(a * s, p, a);
-    if (swap) r = 1.57079637050628662f - r;
-    if (qx < 0.0f) r = 3.14159274101257324f - r;
-    const float u = __builtin_fmaf(P.K00, __builtin_copysignf(r, qy), P.K01);
+    const float mn = swap ? ax : ay;
+    const float e0 = __builtin_fmaf(-r, y0, 1.0f), y1 = __builtin_fmaf(e0, y0, y0), q0 = mn * y1, e1 = __builtin_fmaf(-r, q0, mn);
+    const float t = __builtin_fmaf(e1, y1, q0), s = t * t;
+    float p = 1.237212196e-01f;
+    p = __builtin_fmaf(p, s, -1.153038889e-01f); p = __builtin_fmaf(p, s, 9.340071678e-02f); p = __builtin_fmaf(p, s, 1.043075230e-02f);
+    p = __builtin_fmaf(p, s, 4.762428626e-02f); p = __builtin_fmaf(p, s, 7.478348911e-02f); p = __builtin_fmaf(p, s, 1.666723490e-01f);
+    float phi = __builtin_fmaf(t * s, p, t);
+    if (swap) phi = 1.57079637050628662f - phi;
+    if (qx < 0.0f) phi = 3.14159274101257324f - phi;
+    const float u = __builtin_fmaf(P.K00, __builtin_copysignf(phi, qy), P.K01);
     int col; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(col) : "v"(u));
-    if (!kGates) col = (int) ((unsigned) col % (unsigned) P.cols);
+    if (!kGates) col = (int) min((unsigned) col, (unsigned) P.cols - 1u);
     if (!kGates || (unsigned) col < (unsigned) P.cols) {
-      const float s0 = r2 * y, h = 0.5f * y, e = __builtin_fmaf(-s0, s0, r2), d = __builtin_fmaf(e, h, s0);
-      const unsigned long long key = ((unsigned long long) __float_as_uint(d) << 32) | (unsigned long long) (unsigned) idx;
-      if (kAtomic) atomicMin(&canvas[col], key); else sink ^= key + (unsigned long long) col;
+      const unsigned long long key = ((unsigned long long) __float_as_uint(r) << 32) | (unsigned long long) (unsigned) idx;
+      if (kAtomic) atomicMin(&canvas[col], key); else sink ^= key + (unsigned long long) (unsigned) col;
     }
   }
 }
@@ -210,7 +209,7 @@ int main() {
   run_ablation<1, 1, 1>("full stream (copy of project_point_stream)", d_out, n_cu);
   run_ablation<0, 1, 1>("without the ds_min_u64", d_out, n_cu);
   run_ablation<1, 0, 1>("without the exec-masked gates (straight-line)", d_out, n_cu);
-  run_ablation<1, 1, 0>("v_rcp / v_rsq replaced by plain multiplies", d_out, n_cu);
+  run_ablation<1, 1, 0>("v_rsq_f32 replaced by a plain multiply", d_out, n_cu);
   run_ablation<0, 0, 0>("arithmetic only: no atomic, no gates, no transcendentals", d_out, n_cu);
   return 0;
 }
