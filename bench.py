@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 N_SIMD = 256 * 4             # same guide: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles,
-VALU_CYCLES = 2.0            # v_rcp / v_rsq (the stream's two transcendentals per point) over 4
+VALU_CYCLES = 2.0            # a transcendental (the stream's one v_rsq_f32 per point) over 4: one slot more than SQ_INSTS_VALU counts for it
 
 
 def algorithmic_bytes_per_alignment(role: str, finder: str, n_map: int, n_scan_mean: float, bins: int, iterations: int) -> float:
@@ -268,8 +268,9 @@ def main() -> None:
         if clk:
             roof["peak"] = N_SIMD * clk * 1e6 / VALU_CYCLES / 1e9
         if counters and clk:
-            # transcendentals (one v_rcp_f32 + one v_rsq_f32 per point slot of the stream) hold the issue port for 4 cycles, i.e. one slot more
-            # than SQ_INSTS_VALU counts for them
+            # nominal costs (MI355X_MICROARCH.md): a wave64 VALU instruction issues over 2 cycles, a transcendental (one v_rsq_f32 per point
+            # slot of the stream) over 4, i.e. one slot more than SQ_INSTS_VALU counts for it.  (Measured, tools/valu_issue_probe.hip: 2.15 and
+            # ~12-18 cycles -- the stream_floor block below prices the launch with the measured costs instead.)
             slots = counters["valu_insts_per_launch"] + counters.get("trans_insts_per_launch", 0.0)
             roof["achieved"] = slots / (k_ms * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] / roof["peak"]
@@ -280,6 +281,15 @@ def main() -> None:
                 roof["hbm"]["hbm_real_GBs"] = roof["traffic"] / (k_ms * 1e-3) / 1e9
                 roof["hbm"]["hbm_real_frac"] = roof["hbm"]["hbm_real_GBs"] / HBM_PEAK_GBS
             roof["counters_source"] = counters.get("source")
+            if counters.get("stream_cycles_per_wave_point") and counters.get("wave_points_per_launch"):
+                # the second, sharper yardstick: what the 1024 SIMDs need for THIS instruction stream when nothing else is in the way
+                # (tools/valu_issue_probe.hip runs csrc's project_point_stream on register-resident points: cycles per point of a wave)
+                cyc = counters["stream_cycles_per_wave_point"] * counters["wave_points_per_launch"] / N_SIMD
+                floor_ms = cyc / (clk * 1e6) * 1e3
+                roof["stream_floor"] = {"cycles_per_wave_point": counters["stream_cycles_per_wave_point"], "floor_ms_at_measured_clock": floor_ms,
+                                        "frac": floor_ms / k_ms,
+                                        "note": "kernel time / (point visits x the stream's own measured issue cost): bin walk, reductions, 3x3 solves and "
+                                                "barriers of the other workgroups on a CU run underneath the stream when this is ~1"}
         if warn:
             roof["warning"] = warn
             print("bench.py: " + warn, file=sys.stderr)

@@ -48,9 +48,17 @@ def main():
     key = "role%s/%s/scans%d/map%d/it%d/beams%d" % (a.role, a.finder, a.scans, a.map_points, a.iterations, a.beams)
     ent = {"valu_insts_per_launch": m["SQ_INSTS_VALU"], "launches_averaged": cnt["SQ_INSTS_VALU"], "pmc_means": m}
     if a.role == "A" and a.finder == "projective":
-        # one v_rcp_f32 + one v_rsq_f32 per point slot of the lane-chunked stream (padding slots included: they run the same code)
+        # ONE transcendental (v_rsq_f32) per point slot of the lane-chunked stream since round 2's bearing = asin(min / r) (padding slots
+        # fail the range gate in front of it; they are counted anyway: an upper bound of 0.4 %)
         T = -(-(-(-a.map_points // 2)) // 512)
-        ent["trans_insts_per_launch"] = 2.0 * a.scans * a.iterations * (T * 512 * 2) / 64.0
+        ent["trans_insts_per_launch"] = 1.0 * a.scans * a.iterations * (T * 512 * 2) / 64.0
+        ent["wave_points_per_launch"] = 1.0 * a.scans * a.iterations * (T * 512 * 2) / 64.0
+        probe = os.path.join(a.root, "valu_issue_probe.txt")      # tools/valu_issue_probe.hip run in the same pass: the stream's own issue rate
+        if os.path.exists(probe):
+            import re
+            mm = re.search(r"k_align's point stream.*?:\s*([0-9.]+) cycles of a SIMD per point", open(probe).read())
+            if mm:
+                ent["stream_cycles_per_wave_point"] = float(mm.group(1))
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         ent["fetch_size_kb"] = m["FETCH_SIZE"]; ent["write_size_kb"] = m["WRITE_SIZE"]
         ent["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
