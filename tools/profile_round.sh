@@ -11,5 +11,9 @@ run fetch FETCH_SIZE && run write WRITE_SIZE \
  && run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVES \
  && run tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
 cd $R; python tools/pmc_summary.py $O k_align > $O/pmc_k_align.csv; cat $O/pmc_k_align.csv; cat $O/trace/*/*kernel_stats.csv | head -5
+# the stream's own issue rate (register-resident points, no loads / barriers / bin walk): the second yardstick of bench.py's roofline block
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -Wno-unused-value -Isrrg2_laser_slam_2d_amd/csrc -Iinclude -o /tmp/valu_probe tools/valu_issue_probe.hip 2>/dev/null \
+  && timeout -k 5 120 /tmp/valu_probe > $O/valu_issue_probe.txt; tail -7 $O/valu_issue_probe.txt | cut -c1-160
+timeout -k 5 100 python tools/occupancy_probe.py > $O/occupancy_probe.txt 2>&1; tail -3 $O/occupancy_probe.txt
 # counters -> profiles/counters.json (hash-stamped), then the bench line that reads them back
 python tools/write_counters.py $O --tag $tag && cp profiles/counters.json $O/counters.json && python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json
