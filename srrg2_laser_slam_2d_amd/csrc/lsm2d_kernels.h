@@ -438,9 +438,13 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
       if (A.s[s].has_sensor) compose(A.s[s].cSinv, A.s[s].sSinv, A.s[s].Sinv, s_pose, Xe);
       sincos_fixed(Xe[2], s_iso[s].s, s_iso[s].c); s_iso[s].tx = Xe[0]; s_iso[s].ty = Xe[1];
     }
-    for (int k = 0; k < 9; ++k) s_Hs[k] = 0.0f;
-    s_b[0] = s_b[1] = s_b[2] = 0.0f;
-    s_n_in = s_n_out = s_n_corr = s_active = 0; s_chi_in = s_chi_out = 0.0f;
+    // (the zero is made HERE, every time: a constant the compiler may hoist becomes a zero quad that every thread keeps -- and spills --
+    // across the whole kernel for thread 0's sake)
+    float zf = 0.0f; int zi = 0;
+    asm volatile("" : "+v"(zf), "+v"(zi));
+    for (int k = 0; k < 9; ++k) s_Hs[k] = zf;
+    s_b[0] = s_b[1] = s_b[2] = zf;
+    s_n_in = s_n_out = s_n_corr = s_active = zi; s_chi_in = s_chi_out = zf;
   };
   if (tid == 0) {
     if (A.inline_n1) { s_pose[0] = A.pose1[0]; s_pose[1] = A.pose1[1]; s_pose[2] = A.pose1[2]; }
