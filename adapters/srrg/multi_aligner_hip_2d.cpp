@@ -7,6 +7,7 @@
 #include "multi_aligner_hip_2d.h"
 
 #include <functional>
+#include <iterator>
 #include <set>
 
 namespace srrg2_laser_slam_2d {
@@ -131,6 +132,11 @@ namespace srrg2_laser_slam_2d {
     }
     if (slices.empty()) {
       throw std::runtime_error(std::string(who) + "| no laser slice");
+    }
+    // device clouds of host clouds this call did not see are released (a tracker hands over a fresh measurement cloud object
+    // now and then: the cache must not grow with them)
+    for (auto it = _device_clouds.begin(); it != _device_clouds.end();) {
+      it = refreshed.count(it->first) ? std::next(it) : _device_clouds.erase(it);
     }
 
     float pose[3], information[9];
