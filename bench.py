@@ -51,6 +51,9 @@ def algorithmic_bytes_per_alignment(role: str, finder: str, n_map: int, n_scan_m
     if role == "B" and finder == "nn":
         d = math.ceil(math.log2(n_map / 20.0))
         return iterations * (16.0 * n_scan_mean + n_scan_mean * (24.0 * d + 8.0 * 20 + 8.0) + 64.0)
+    if finder == "distmap":      # per query: its own 16 B, one 4-byte parent lookup instead of a tree walk, 16 B of the parent
+        nq = n_map if role == "A" else n_scan_mean
+        return iterations * (36.0 * nq + 64.0)
     raise SystemExit("unsupported role/finder combination")
 
 
@@ -108,7 +111,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--role", choices=["A", "B"], default="A", help="A: fixed=scan, moving=map (reference tracker wiring); B: fixed=map, moving=scan")
-    ap.add_argument("--finder", choices=["projective", "nn"], default="projective")
+    ap.add_argument("--finder", choices=["projective", "nn", "distmap"], default="projective",
+                    help="projective: CorrespondenceFinderProjective2f (reference default); nn: CorrespondenceFinderKDTree2D; distmap: CorrespondenceFinderNN2D (row f4)")
+    ap.add_argument("--resolution", type=float, default=0.05, help="distance-map finder: metres per pixel")
     ap.add_argument("--max-distance", type=float, default=0.5, help="NN finder gate [m]")
     ap.add_argument("--cauchy", type=float, default=0.0, help="Cauchy chi_threshold (0 = no robustifier); configs[3] uses 0.05 (MULTI.json:957-962)")
     ap.add_argument("--total-candidates", type=int, default=0,
@@ -166,8 +171,10 @@ def main() -> None:
     if args.finder == "projective":
         proj = api.PointNormal2fProjectorPolar(args.beams, -np.pi, np.pi, 0.3, 30.0)
         finder = api.CorrespondenceFinderProjective2f(ctx, proj, point_distance=0.5, normal_cos=0.8)
-    else:
+    elif args.finder == "nn":
         finder = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=args.max_distance, normal_cos=0.8)
+    else:
+        finder = api.CorrespondenceFinderNN2D(ctx, max_distance_m=args.max_distance, resolution=args.resolution, normal_cos=0.8)
     aligner = api.MultiAligner2D(ctx, max_iterations=args.iterations, min_num_inliers=10)
     robust = api.RobustifierCauchy(args.cauchy) if args.cauchy > 0 else None
     aligner.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10, robustifier=robust))
@@ -316,8 +323,8 @@ def main() -> None:
             ns = min(args.cpu_sample, n_unique)
             offs = wl.scan_offsets[: ns + 1]
             map_host = map_dev.cpu().numpy()
-            osp = po.slice_params(finder=po.FINDER_PROJECTIVE if args.finder == "projective" else po.FINDER_NN,
-                                  canvas_cols=args.beams, max_distance=args.max_distance,
+            osp = po.slice_params(finder={"projective": po.FINDER_PROJECTIVE, "nn": po.FINDER_NN, "distmap": po.FINDER_DISTMAP}[args.finder],
+                                  canvas_cols=args.beams, max_distance=args.max_distance, resolution=args.resolution,
                                   **({"robustifier": po.ROBUST_CAUCHY, "chi_threshold": args.cauchy} if args.cauchy > 0 else {}))
             po.lib()                                   # load (or build) the checker before the clock starts
             t1 = time.perf_counter()

@@ -1548,6 +1548,7 @@ extern "C" int lsm2d_sweep_align(lsm2d_sweep* sw, const lsm2d_aligner_params* ap
   if (!sw || !ap || !slice || n_candidates < 0 || (n_candidates > 0 && (!init_pose || !out_pose || !out_status)))
     return fail(nullptr, LSM2D_BAD_ARGUMENT, "sweep_align: bad argument");
   if (sw->map.size() != sw->ctx.size() || sw->scans.size() != sw->ctx.size()) return sweep_fail(sw, LSM2D_BAD_ARGUMENT, "sweep_align: set_map / set_scans first");
+  if (n_candidates == 0) return LSM2D_SUCCESS;      // an empty candidate list is a no-op, as an empty batch is for lsm2d_align_batch
   const int G = (int) sw->ctx.size();
   const int n_scans = lsm2d_cloudset_num_clouds(sw->scans[0]);
   if (!scan_index && n_scans != n_candidates && n_scans != 1) return sweep_fail(sw, LSM2D_BAD_ARGUMENT, "sweep_align: scan_index needed unless there is one scan per candidate");

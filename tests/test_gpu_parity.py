@@ -436,6 +436,60 @@ def test_cpp_loop_closure_sweep_over_several_contexts(ctx, po, tmp_path):
         assert np.array_equal(stats, last) and np.array_equal(acc, want_acc), len(devices)
 
 
+def test_sweep_api_error_paths_and_index_defaults(ctx, small_workload):
+    """lsm2d_sweep_* through the C ABI directly: a device that does not exist, aligning before the clouds are set, a candidate list
+    that needs an index array and has none, an index out of range -- all refused with a message, none of them fatal to the sweep;
+    then the two index-free forms (one scan for every candidate, one scan per candidate) against lsm2d_align_batch."""
+    import ctypes as C
+    from srrg2_laser_slam_2d_amd import _capi
+    lib = _capi.load(); wl = small_workload
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    bad = (C.c_int32 * 1)(9999); sw = C.c_void_p()
+    assert lib.lsm2d_sweep_create(bad, 1, C.byref(sw)) < 0 and not sw.value
+    assert lib.lsm2d_sweep_create(None, 1, C.byref(sw)) == _capi.BAD_ARGUMENT
+    assert lib.lsm2d_sweep_create((C.c_int32 * 1)(0), 0, C.byref(sw)) == _capi.BAD_ARGUMENT
+    assert lib.lsm2d_sweep_num_devices(None) == 0
+    lib.lsm2d_sweep_destroy(None)
+    devs = (C.c_int32 * 2)(0, 0)
+    assert lib.lsm2d_sweep_create(devs, 2, C.byref(sw)) == 0 and lib.lsm2d_sweep_num_devices(sw) == 2
+    try:
+        n = len(wl.x0); its = 6
+        ap = _capi.AlignerParams(its, 10, 0.0)
+        sp = api.make_slice_params(projector=_projector(), robustifier=0, min_num_correspondences=10)
+        x0 = np.ascontiguousarray(wl.x0, np.float32)
+        pose = np.zeros((n, 3), np.float32); status = np.full(n, -7, np.int32); iters = np.zeros(n, np.int32)
+        call = lambda k, idx, x: lib.lsm2d_sweep_align(sw, C.byref(ap), C.byref(sp), k, idx, P(x), P(pose), None, P(status), P(iters), None)
+        # nothing set yet
+        assert call(n, None, x0) == _capi.BAD_ARGUMENT and b"set_map" in lib.lsm2d_sweep_last_error(sw)
+        scans = np.ascontiguousarray(wl.scan_points); offs = np.ascontiguousarray(wl.scan_offsets, np.int32); mp = np.ascontiguousarray(wl.map_points)
+        assert lib.lsm2d_sweep_set_scans(sw, P(scans), P(offs), n) == 0
+        assert call(n, None, x0) == _capi.BAD_ARGUMENT                          # still no map
+        assert lib.lsm2d_sweep_set_map(sw, None, 10) == _capi.BAD_ARGUMENT
+        assert lib.lsm2d_sweep_set_scans(sw, P(scans), None, n) == _capi.BAD_ARGUMENT
+        assert call(n, None, x0) == _capi.BAD_ARGUMENT                          # the refused calls changed nothing: still no map
+        assert lib.lsm2d_sweep_set_scans(sw, P(scans), P(offs), n) == 0 and lib.lsm2d_sweep_set_map(sw, P(mp), len(mp)) == 0
+        # n scans, fewer candidates, no index array
+        assert call(n - 1, None, x0) == _capi.BAD_ARGUMENT and b"scan_index" in lib.lsm2d_sweep_last_error(sw)
+        # index out of range on the SECOND device's shard only: the whole call fails and says which device
+        idx = np.arange(n, dtype=np.int32); idx[-1] = n
+        assert call(n, P(idx), x0) == _capi.BAD_ARGUMENT and b"device 1" in lib.lsm2d_sweep_last_error(sw)
+        assert call(0, None, x0) == 0                                           # empty sweep
+        # one scan per candidate, no index array: candidate i of the second shard uses scan lo + i, not scan i
+        al = _aligner(ctx, its=its)
+        want = al.compute_batch([api.CloudSet(ctx, scans, offs)], [api.CloudSet(ctx, mp)], x0)
+        assert call(n, None, x0) == 0
+        assert np.array_equal(pose, want.pose) and np.array_equal(status, want.status) and np.array_equal(iters, want.iterations)
+        # one scan for every candidate
+        one = np.ascontiguousarray(scans[offs[2]:offs[3]]); o1 = np.array([0, len(one)], np.int32)
+        xs = np.ascontiguousarray(np.repeat(x0[2:3], 5, axis=0) + np.linspace(0, 0.02, 5, dtype=np.float32)[:, None])
+        assert lib.lsm2d_sweep_set_scans(sw, P(one), P(o1), 1) == 0
+        assert call(5, None, xs) == 0
+        want = al.compute_batch([api.CloudSet(ctx, one)], [api.CloudSet(ctx, mp)], xs)
+        assert np.array_equal(pose[:5], want.pose) and np.array_equal(status[:5], want.status)
+    finally:
+        lib.lsm2d_sweep_destroy(sw)
+
+
 def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     """The header-only C++ mirror (srrg2_laser_slam_2d_amd/host/lsm2d.hpp), built with plain g++ and driven like
     apps/visual_test_correspondence_finder_projective_2d.cpp / apps/visual_test_aligner_2d.cpp."""
