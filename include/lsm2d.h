@@ -126,7 +126,12 @@ int  lsm2d_synchronize(lsm2d_context* ctx);
  * handful of alignments against a large cloud, the latency kernel for calls that cannot fill the chip (the live tracker).
  * "kernel_timing": 1 records HIP events around the hot-path launches so that lsm2d_last_kernel_ms can report them; 0 (default)
  * does not -- the two timed events per operation cost a latency-critical caller such as the live tracker ~20 % of its step --
- * and lsm2d_last_kernel_ms returns LSM2D_BAD_ARGUMENT. */
+ * and lsm2d_last_kernel_ms returns LSM2D_BAD_ARGUMENT.
+ * "distmap_build": 0 = automatic (default: the distance maps of CorrespondenceFinderNN2D are built from the points' side, one disc of
+ * atomic minima per point, whenever squared pixel distance and point index pack into 31 bits), 1 = always the per-pixel gather build;
+ * the two produce identical correspondences.
+ * "grid_big_threshold" (default 16384): fixed clouds of at least this many points get the NN finder's search grid built by chip-wide
+ * kernels (histogram / scan / scatter over many workgroups) instead of one workgroup per cloud; results do not depend on it. */
 int  lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value);
 /* reads a knob back; also "last_align_path": what the most recent lsm2d_align_batch ran (1 k_align, 2 split, 3 slice pair) */
 int  lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* out_value);

@@ -42,6 +42,8 @@ struct lsm2d_context {
   bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1, 2 or 3)
+  int grid_big_threshold = 16384;   // clouds of at least this many points get their search grid built by the chip-wide kernels (k_grid_big_*)
+  int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
   long long last_clock_khz = 0;       // in-kernel clock of the most recent timed k_align launch (median over the stamped workgroups), 0 = none
   long long last_wg_lifetime_ns = 0;  // median lifetime of its stamped workgroups
@@ -78,6 +80,7 @@ static hipError_t wait_for_statuses(lsm2d_context* ctx, const int32_t* st, int n
 
 struct GridCache {     // one search grid per (cloud set, max_distance), built on first use
   float max_distance = 0.0f;
+  void* d_block = nullptr;      // ONE allocation (hipMalloc costs ~0.1 ms a call); the pointers below are views into it
   GridMeta* d_meta = nullptr; int32_t* d_cell_start = nullptr; int32_t* d_cursor = nullptr;
   int32_t* d_sorted_idx = nullptr; float2* d_sorted_xy = nullptr;
 };
@@ -224,6 +227,8 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "clock_stride")) { if (value < 0 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "clock_stride: out of range"); ctx->clock_stride = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kernel_timing")) { ctx->kernel_timing = value != 0; if (!ctx->kernel_timing) ctx->have_timing = false; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { if (value < 0 || value > 3) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1, 2 or 3"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "grid_big_threshold")) { if (value < 1 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_threshold: out of range"); ctx->grid_big_threshold = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
 
@@ -231,6 +236,8 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!ctx || !key || !out_value) return LSM2D_BAD_ARGUMENT;
   if (!strcmp(key, "kernel_timing")) { *out_value = ctx->kernel_timing ? 1 : 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { *out_value = ctx->align_path; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "distmap_build")) { *out_value = ctx->distmap_build; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "grid_big_threshold")) { *out_value = ctx->grid_big_threshold; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_align_path")) { *out_value = ctx->last_align_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kernel_clock_khz")) { *out_value = ctx->last_clock_khz; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_workgroup_lifetime_ns")) { *out_value = ctx->last_wg_lifetime_ns; return LSM2D_SUCCESS; }
@@ -357,13 +364,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_nrm) (void) hipFree(cs->d_nrm);
   if (cs->d_start) (void) hipFree(cs->d_start);
   if (cs->d_count) (void) hipFree(cs->d_count);
-  for (auto& g : cs->grids) {
-    if (g.d_meta) (void) hipFree(g.d_meta);
-    if (g.d_cell_start) (void) hipFree(g.d_cell_start);
-    if (g.d_cursor) (void) hipFree(g.d_cursor);
-    if (g.d_sorted_idx) (void) hipFree(g.d_sorted_idx);
-    if (g.d_sorted_xy) (void) hipFree(g.d_sorted_xy);
-  }
+  for (auto& g : cs->grids) if (g.d_block) (void) hipFree(g.d_block);
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   if (cs->d_lane_xy) (void) hipFree(cs->d_lane_xy);
   if (cs->d_lane_start) (void) hipFree(cs->d_lane_start);
@@ -437,13 +438,7 @@ extern "C" int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* cs, int32_t i
 }
 
 static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents changed: cached NN grids are stale
-  for (auto& g : cs->grids) {
-    if (g.d_meta) (void) hipFree(g.d_meta);
-    if (g.d_cell_start) (void) hipFree(g.d_cell_start);
-    if (g.d_cursor) (void) hipFree(g.d_cursor);
-    if (g.d_sorted_idx) (void) hipFree(g.d_sorted_idx);
-    if (g.d_sorted_xy) (void) hipFree(g.d_sorted_xy);
-  }
+  for (auto& g : cs->grids) if (g.d_block) (void) hipFree(g.d_block);
   cs->grids.clear();
   if (cs->d_lane_xy) { (void) hipFree(cs->d_lane_xy); cs->d_lane_xy = nullptr; }
   if (cs->d_lane_start) { (void) hipFree(cs->d_lane_start); cs->d_lane_start = nullptr; }
@@ -605,27 +600,45 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
     if (cells > 0x7fffffff) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "grid: too many cells");
   }
   GridCache g; g.max_distance = max_distance;
-  DevTmp t_meta, t_start, t_cursor, t_sidx, t_sxy, t_base, t_gcap;
-  HIPCHK(ctx, hipMalloc(&t_meta.p, sizeof(GridMeta) * (size_t) nc));
-  HIPCHK(ctx, hipMalloc(&t_start.p, sizeof(int32_t) * (size_t) cells));
-  HIPCHK(ctx, hipMalloc(&t_cursor.p, sizeof(int32_t) * (size_t) cells));
-  HIPCHK(ctx, hipMalloc(&t_sidx.p, sizeof(int32_t) * (size_t) cs->padded_total));
-  HIPCHK(ctx, hipMalloc(&t_sxy.p, sizeof(float2) * (size_t) cs->padded_total));
-  HIPCHK(ctx, hipMalloc(&t_base.p, sizeof(int32_t) * (size_t) nc));
-  HIPCHK(ctx, hipMalloc(&t_gcap.p, sizeof(int32_t) * (size_t) nc));
-  g.d_meta = (GridMeta*) t_meta.p; g.d_cell_start = (int32_t*) t_start.p; g.d_cursor = (int32_t*) t_cursor.p;
-  g.d_sorted_idx = (int32_t*) t_sidx.p; g.d_sorted_xy = (float2*) t_sxy.p;
-  int32_t* d_base = (int32_t*) t_base.p; int32_t* d_gcap = (int32_t*) t_gcap.p;
+  DevTmp t_block;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
+  const size_t o_meta = take(sizeof(GridMeta) * (size_t) nc), o_start = take(sizeof(int32_t) * (size_t) cells), o_cursor = take(sizeof(int32_t) * (size_t) cells);
+  const size_t o_sidx = take(sizeof(int32_t) * (size_t) cs->padded_total), o_sxy = take(sizeof(float2) * (size_t) cs->padded_total);
+  const size_t o_base = take(sizeof(int32_t) * (size_t) nc), o_gcap = take(sizeof(int32_t) * (size_t) nc), o_tiles = take(sizeof(int32_t) * 2048);
+  HIPCHK(ctx, hipMalloc(&t_block.p, off));
+  char* blk = (char*) t_block.p;
+  g.d_meta = (GridMeta*) (blk + o_meta); g.d_cell_start = (int32_t*) (blk + o_start); g.d_cursor = (int32_t*) (blk + o_cursor);
+  g.d_sorted_idx = (int32_t*) (blk + o_sidx); g.d_sorted_xy = (float2*) (blk + o_sxy);
+  int32_t* d_base = (int32_t*) (blk + o_base); int32_t* d_gcap = (int32_t*) (blk + o_gcap); int32_t* d_tiles = (int32_t*) (blk + o_tiles);
   HIPCHK(ctx, hipMemcpyAsync(d_base, cell_base.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_gcap, gcap.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   GridBuildArgs A;
   A.xy = cs->d_xy; A.start = cs->d_start; A.count = cs->d_count; A.n_clouds = nc; A.h_min = max_distance * 0.015625f;
   A.cell_base = d_base; A.gcap = d_gcap; A.meta = g.d_meta; A.cell_start = g.d_cell_start; A.cursor = g.d_cursor;
   A.sorted_idx = g.d_sorted_idx; A.sorted_xy = g.d_sorted_xy;
+  A.big_threshold = ctx->grid_big_threshold;
   hipLaunchKernelGGL(k_grid_build, dim3((unsigned) nc), dim3(1024), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
+  // map-sized clouds: k_grid_build left them with their meta only; the counting sort runs over the whole chip, one cloud after the other
+  for (int c = 0; c < nc; ++c) {
+    if (cs->h_count[c] < ctx->grid_big_threshold) continue;
+    const int64_t cells_max = (int64_t) gcap[c] * gcap[c] + 1;
+    const int n_tiles = (int) ((cells_max + kGridTile - 1) / kGridTile);            // <= 1025: gcap <= 2048
+    HIPCHK(ctx, hipMemsetAsync(g.d_cursor + cell_base[c], 0, sizeof(int32_t) * (size_t) cells_max, ctx->stream));
+    GridBigArgs B;
+    B.xy = cs->d_xy; B.start = cs->d_start; B.count = cs->d_count; B.cloud = c; B.meta = g.d_meta; B.cell_start = g.d_cell_start; B.cursor = g.d_cursor;
+    B.tile_sums = d_tiles; B.sorted_idx = g.d_sorted_idx; B.sorted_xy = g.d_sorted_xy;
+    int pb = (cs->h_count[c] + 1023) / 1024; pb = pb < 1 ? 1 : (pb > 2048 ? 2048 : pb);
+    hipLaunchKernelGGL(k_grid_big_hist, dim3((unsigned) pb), dim3(256), 0, ctx->stream, B);
+    hipLaunchKernelGGL(k_grid_big_scan<0>, dim3((unsigned) n_tiles), dim3(1024), 0, ctx->stream, B);
+    hipLaunchKernelGGL(k_grid_big_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, B.tile_sums, n_tiles);
+    hipLaunchKernelGGL(k_grid_big_scan<1>, dim3((unsigned) n_tiles), dim3(1024), 0, ctx->stream, B);
+    hipLaunchKernelGGL(k_grid_big_scatter, dim3((unsigned) pb), dim3(256), 0, ctx->stream, B);
+    HIPCHK(ctx, hipGetLastError());
+  }
   HIPCHK(ctx, stream_sync(ctx));      // host vectors above must outlive the copies
-  t_meta.release(); t_start.release(); t_cursor.release(); t_sidx.release(); t_sxy.release();   // owned by the cache from here on
+  g.d_block = t_block.release();      // owned by the cache from here on
   cs->grids.push_back(g);
   *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy};
   return LSM2D_SUCCESS;
@@ -698,27 +711,41 @@ static int ensure_distmap(lsm2d_context* ctx, const lsm2d_cloudset* cs, float ma
     if (m.rows * (long long) m.cols > max_rows_cols) max_rows_cols = (int) (m.rows * (long long) m.cols > 0x7fffffff ? 0x7fffffff : m.rows * (long long) m.cols);
     if (total > (1ll << 33)) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "distmap: more than 8 Gi pixels in one set");
   }
+  // scatter build (every point stamps its disc, k_distmap_stamp) whenever (d2, index) packs into 31 bits; else the gather build
+  int max_pts = 1; for (int c = 0; c < nc; ++c) if (cs->h_count[c] > max_pts) max_pts = cs->h_count[c];
+  int gbits = 1; while (gbits < 31 && (1ll << gbits) < (long long) max_pts) ++gbits;
+  const bool scatter = ctx->distmap_build != 1 && R <= 511 && (((long long) R * R + 1) << gbits) <= (1ll << 31);
+  for (auto& m : meta) { m.gbits = scatter ? gbits : 31; m.gmask = scatter ? (int32_t) ((1u << gbits) - 1u) : 0x7fffffff; }
   DistCache d; d.max_distance = max_distance; d.resolution = resolution;
   DevTmp t_dmeta, t_parent, t_goal;
   HIPCHK(ctx, hipMalloc(&t_dmeta.p, sizeof(DistMeta) * (size_t) nc));
   HIPCHK(ctx, hipMalloc(&t_parent.p, sizeof(int32_t) * (size_t) total));
-  HIPCHK(ctx, hipMalloc(&t_goal.p, sizeof(int32_t) * (size_t) total));
   d.d_meta = (DistMeta*) t_dmeta.p; d.d_parent = (int32_t*) t_parent.p;
-  int32_t* d_cellgoal = (int32_t*) t_goal.p;
   HIPCHK(ctx, hipMemcpyAsync(d.d_meta, meta.data(), sizeof(DistMeta) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(d_cellgoal, 0x7f, sizeof(int32_t) * (size_t) total, ctx->stream));
-  int max_pts = 1; for (int c = 0; c < nc; ++c) if (cs->h_count[c] > max_pts) max_pts = cs->h_count[c];
-  int gb = (max_pts + 255) / 256; if (gb > 1024) gb = 1024;
-  int fb = (max_rows_cols + 255) / 256; if (fb > 4096) fb = 4096; if (fb < 1) fb = 1;
-  for (int c0 = 0; c0 < nc; c0 += 32768) {         // gridDim.y is limited to 65535
-    const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
-    hipLaunchKernelGGL(k_distmap_goals, dim3((unsigned) gb, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
-                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const DistMeta*) d.d_meta, d_cellgoal, c0);
-  }
-  for (int c0 = 0; c0 < nc; c0 += 32768) {
-    const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
-    hipLaunchKernelGGL(k_distmap_fill, dim3((unsigned) fb, (unsigned) ny), dim3(256), 0, ctx->stream, (const DistMeta*) d.d_meta,
-                       (const int32_t*) d_cellgoal, d.d_parent, mds_px, R, c0);
+  if (scatter) {
+    HIPCHK(ctx, hipMemsetAsync(d.d_parent, 0xff, sizeof(int32_t) * (size_t) total, ctx->stream));
+    int sb = (max_pts + 3) / 4; if (sb > 16384) sb = 16384;
+    for (int c0 = 0; c0 < nc; c0 += 32768) {         // gridDim.y is limited to 65535
+      const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
+      hipLaunchKernelGGL(k_distmap_stamp, dim3((unsigned) sb, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const DistMeta*) d.d_meta, (uint32_t*) d.d_parent, mds_px, R, c0);
+    }
+  } else {
+    HIPCHK(ctx, hipMalloc(&t_goal.p, sizeof(int32_t) * (size_t) total));
+    int32_t* d_cellgoal = (int32_t*) t_goal.p;
+    HIPCHK(ctx, hipMemsetAsync(d_cellgoal, 0x7f, sizeof(int32_t) * (size_t) total, ctx->stream));
+    int gb = (max_pts + 255) / 256; if (gb > 1024) gb = 1024;
+    int fb = (max_rows_cols + 255) / 256; if (fb > 4096) fb = 4096; if (fb < 1) fb = 1;
+    for (int c0 = 0; c0 < nc; c0 += 32768) {
+      const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
+      hipLaunchKernelGGL(k_distmap_goals, dim3((unsigned) gb, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const DistMeta*) d.d_meta, d_cellgoal, c0);
+    }
+    for (int c0 = 0; c0 < nc; c0 += 32768) {
+      const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
+      hipLaunchKernelGGL(k_distmap_fill, dim3((unsigned) fb, (unsigned) ny), dim3(256), 0, ctx->stream, (const DistMeta*) d.d_meta,
+                         (const int32_t*) d_cellgoal, d.d_parent, mds_px, R, c0);
+    }
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, stream_sync(ctx));

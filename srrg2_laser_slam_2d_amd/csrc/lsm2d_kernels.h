@@ -45,14 +45,16 @@ struct GridDev {
 };
 
 // Distance map over every cloud of a set (CorrespondenceFinderNN2D, registration/correspondence_finder_nn_2d.cpp):
-// parent[r*cols + c] = index of the nearest fixed point's pixel within max_distance, or -1.
-struct DistMeta { float lx, ly, inv_res, half_pad; int32_t rows, cols; long long base; };
+// parent[r*cols + c] = the nearest fixed point's pixel within max_distance as (squared pixel distance << gbits | lowest point index in
+// that pixel) -- the form the scatter build (k_distmap_stamp) takes its minimum over -- or -1.
+struct DistMeta { float lx, ly, inv_res, half_pad; int32_t rows, cols; long long base; int32_t gbits, gmask; };
 struct DistDev { const DistMeta* meta; const int32_t* parent; };
 
 LSM2D_DEV int distmap_lookup(const DistMeta& d, const int32_t* __restrict__ parent, float qx, float qy) {
   const float gx = (qx - d.lx) * d.inv_res + d.half_pad, gy = (qy - d.ly) * d.inv_res + d.half_pad;
   if (!(gx >= 0.0f && gy >= 0.0f && gx < (float) d.rows && gy < (float) d.cols)) return -1;
-  return parent[d.base + (long long) (int) gx * d.cols + (int) gy];
+  const int v = parent[d.base + (long long) (int) gx * d.cols + (int) gy];
+  return v < 0 ? -1 : (v & d.gmask);
 }
 
 struct CloudDev {            // device view of a cloud set
@@ -203,6 +205,39 @@ __global__ __launch_bounds__(256) void k_distmap_fill(const DistMeta* __restrict
   }
 }
 
+// The same map built from the points' side: every point stamps the disc of pixels it can be the nearest goal of with an unsigned
+// minimum over (d2 << gbits | index) -- the lexicographic (d2, index) minimum k_distmap_fill gathers, so the two builds agree bit for
+// bit -- (2R+1)^2 atomics per POINT instead of (2R+1)^2 reads per PIXEL: a scan's map has ~600 pixels per point (the reference pads
+// every side by 75 pixels, correspondence_finder_nn_2d.cpp:28-43).  One wave per point; a point that finds a lower index already in
+// its own pixel stops there (that point stamps the same disc).  The map starts as all ones (= -1: nobody within reach).
+__global__ __launch_bounds__(256) void k_distmap_stamp(const float2* __restrict__ xy, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
+                                                       const DistMeta* __restrict__ meta, uint32_t* __restrict__ parent, float mds_px, int R, int cloud0) {
+  const int c = cloud0 + blockIdx.y; const DistMeta d = meta[c];
+  const int lane = threadIdx.x & 63, n = count[c];
+  const float2* p = xy + start[c];
+  uint32_t* map = parent + d.base;
+  const int side = 2 * R + 1, area = side * side;
+  const float inv_side = 1.0f / (float) side;
+  for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < n; f += gridDim.x * 4) {
+    const float2 v = p[f];
+    const float gx = (v.x - d.lx) * d.inv_res + d.half_pad, gy = (v.y - d.ly) * d.inv_res + d.half_pad;
+    if (!(gx >= 0.0f && gy >= 0.0f && gx < (float) d.rows && gy < (float) d.cols)) continue;
+    const int r = (int) gx, cc = (int) gy;
+    uint32_t old = 0;
+    if (lane == 0) old = atomicMin(&map[(long long) r * d.cols + cc], (uint32_t) f);      // d2 = 0
+    old = (uint32_t) __shfl((int) old, 0, 64);
+    if (old < (uint32_t) f) continue;
+    for (int k = lane; k < area; k += 64) {
+      const int kr = (int) (((float) k + 0.5f) * inv_side);      // k / side, exact for k < 2^20
+      const int dr = kr - R, dc = k - kr * side - R;
+      const int d2 = dr * dr + dc * dc;
+      const int rr = r + dr, c2 = cc + dc;
+      if (d2 == 0 || (float) d2 > mds_px || rr < 0 || rr >= d.rows || c2 < 0 || c2 >= d.cols) continue;
+      atomicMin(&map[(long long) rr * d.cols + c2], ((uint32_t) d2 << d.gbits) | (uint32_t) f);
+    }
+  }
+}
+
 // One workgroup builds the grid of one cloud: bounding box -> cell size -> counting sort by cell.
 struct GridBuildArgs {
   const float2* xy; const int32_t* start; const int32_t* count; int32_t n_clouds;
@@ -210,7 +245,15 @@ struct GridBuildArgs {
   const int32_t* cell_base;     // [n_clouds] host-computed: room for gcap^2 + 1 entries per cloud
   const int32_t* gcap;          // [n_clouds] max grid dimension per cloud
   GridMeta* meta; int32_t* cell_start; int32_t* cursor; int32_t* sorted_idx; float2* sorted_xy;
+  int32_t big_threshold;        // clouds of at least this many points only get their bounding box and meta here; the chip-wide
+                                // kernels below (k_grid_big_*) do the rest -- one workgroup scanning 3.6 M cells took 5 ms for a 100k-point map
 };
+
+LSM2D_DEV int grid_cell_of(const GridMeta& g, float2 p) {
+  int cx = (int) floorf((p.x - g.minx) * g.inv_h), cy = (int) floorf((p.y - g.miny) * g.inv_h);
+  cx = cx < 0 ? 0 : (cx > g.gw - 1 ? g.gw - 1 : cx); cy = cy < 0 ? 0 : (cy > g.gh - 1 ? g.gh - 1 : cy);
+  return cy * g.gw + cx;
+}
 
 __global__ __launch_bounds__(1024) void k_grid_build(const GridBuildArgs A) {
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -241,17 +284,14 @@ __global__ __launch_bounds__(1024) void k_grid_build(const GridBuildArgs A) {
     s_g = g; A.meta[c] = g; s_carry = 0;
   }
   __syncthreads();
+  if (n >= A.big_threshold) return;
   const GridMeta g = s_g;
   const int ncell = g.gw * g.gh;
   int32_t* cstart = A.cell_start + g.cell_base; int32_t* cur = A.cursor + g.cell_base;
   for (int i = tid; i <= ncell; i += 1024) cur[i] = 0;
   __syncthreads();
   // ---- histogram
-  auto cell_of = [&](float2 p) {
-    int cx = (int) floorf((p.x - g.minx) * g.inv_h), cy = (int) floorf((p.y - g.miny) * g.inv_h);
-    cx = cx < 0 ? 0 : (cx > g.gw - 1 ? g.gw - 1 : cx); cy = cy < 0 ? 0 : (cy > g.gh - 1 ? g.gh - 1 : cy);
-    return cy * g.gw + cx;
-  };
+  auto cell_of = [&](float2 p) { return grid_cell_of(g, p); };
   for (int i = tid; i < n; i += 1024) atomicAdd(&cur[cell_of(xy[i])], 1);
   __syncthreads();
   // ---- exclusive scan of the counts, 1024 cells per round, carried in LDS
@@ -275,6 +315,79 @@ __global__ __launch_bounds__(1024) void k_grid_build(const GridBuildArgs A) {
   for (int i = tid; i < n; i += 1024) {
     const float2 p = xy[i];
     const int pos = atomicAdd(&cur[cell_of(p)], 1);
+    A.sorted_idx[base + pos] = i; A.sorted_xy[base + pos] = p;
+  }
+}
+
+// ---- the same counting sort for ONE map-sized cloud, over the whole chip: histogram (global atomics on a zeroed cursor table), exclusive
+// scan of the cell counts in tiles of kGridTile cells (tile totals -> their scan by one workgroup -> tiles again), scatter.  The order
+// of the points inside a cell differs from launch to launch; the query's (d2, index) minimum does not depend on it.
+static constexpr int kGridTile = 4096;      // cells per workgroup of the scan: 4 per thread
+struct GridBigArgs {
+  const float2* xy; const int32_t* start; const int32_t* count; int32_t cloud;
+  const GridMeta* meta; int32_t* cell_start; int32_t* cursor; int32_t* tile_sums; int32_t* sorted_idx; float2* sorted_xy;
+};
+
+__global__ __launch_bounds__(256) void k_grid_big_hist(const GridBigArgs A) {
+  const GridMeta g = A.meta[A.cloud];
+  const int n = A.count[A.cloud];
+  const float2* xy = A.xy + A.start[A.cloud];
+  int32_t* cur = A.cursor + g.cell_base;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) atomicAdd(&cur[grid_cell_of(g, xy[i])], 1);
+}
+
+// exclusive scan of this workgroup's tile of counts; kPhase 0: only the tile's total goes out; kPhase 1: cell_start = scanned tile total
+// + position in the tile (entry ncell, the end of the last cell, included) and the cursor restarts from it
+template <int kPhase>
+__global__ __launch_bounds__(1024) void k_grid_big_scan(const GridBigArgs A) {
+  const GridMeta g = A.meta[A.cloud];
+  const int ncell = g.gw * g.gh, tid = threadIdx.x;
+  const int i0 = blockIdx.x * kGridTile + tid * 4;
+  if (blockIdx.x * kGridTile > ncell) { if (kPhase == 0 && tid == 0) A.tile_sums[blockIdx.x] = 0; return; }      // launched for the largest grid the cloud may get
+  int32_t* cur = A.cursor + g.cell_base; int32_t* cstart = A.cell_start + g.cell_base;
+  __shared__ int s_wtot[16];
+  int v[4], sum = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { v[u] = i0 + u < ncell ? cur[i0 + u] : 0; sum += v[u]; }
+  int incl = sum;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+  if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < (tid >> 6); ++w) before += s_wtot[w];
+  if (kPhase == 0) {
+    if (tid == 1023) A.tile_sums[blockIdx.x] = before + incl;
+  } else {
+    int run = A.tile_sums[blockIdx.x] + before + incl - sum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { if (i0 + u <= ncell) { cstart[i0 + u] = run; if (i0 + u < ncell) cur[i0 + u] = run; } run += v[u]; }
+  }
+}
+
+// tile totals -> exclusive scan in place (at most 2048 tiles: grids are capped at 2048 x 2048 cells)
+__global__ __launch_bounds__(1024) void k_grid_big_scan_tiles(int32_t* __restrict__ tile_sums, int n_tiles) {
+  const int tid = threadIdx.x;
+  __shared__ int s_wtot[16];
+  const int a = 2 * tid < n_tiles ? tile_sums[2 * tid] : 0, b = 2 * tid + 1 < n_tiles ? tile_sums[2 * tid + 1] : 0;
+  int incl = a + b;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+  if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < (tid >> 6); ++w) before += s_wtot[w];
+  const int ex = before + incl - (a + b);
+  if (2 * tid < n_tiles) tile_sums[2 * tid] = ex;
+  if (2 * tid + 1 < n_tiles) tile_sums[2 * tid + 1] = ex + a;
+}
+
+__global__ __launch_bounds__(256) void k_grid_big_scatter(const GridBigArgs A) {
+  const GridMeta g = A.meta[A.cloud];
+  const int n = A.count[A.cloud], base = A.start[A.cloud];
+  const float2* xy = A.xy + base;
+  int32_t* cur = A.cursor + g.cell_base;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float2 p = xy[i];
+    const int pos = atomicAdd(&cur[grid_cell_of(g, p)], 1);
     A.sorted_idx[base + pos] = i; A.sorted_xy[base + pos] = p;
   }
 }
@@ -356,6 +469,9 @@ LSM2D_DEV void unpack_fixed_set(const SliceDev& S, int tid, int nthreads) {
 #ifndef LSM2D_ALIGN_MIN_WAVES
 #define LSM2D_ALIGN_MIN_WAVES 8      // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef LSM2D_QUERY_MIN_WAVES
+#define LSM2D_QUERY_MIN_WAVES 8      // the same for the instantiations without a projective slice (point-query finders); 6 and 4 measured 15-50 % slower
+#endif
 // SE2 odometry prior (AlignerSliceOdom2DPrior, MULTI.json:402-422): e = t2v(Z^-1 X), J = blkdiag(R_e, 1) for the right perturbation;
 // adds J^T Omega J to H and J^T Omega e to b.  One definition for k_align and the split path: the same operation order in both.
 LSM2D_DEV void add_prior_inline(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) {
@@ -397,7 +513,7 @@ __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], 
 // projective hot loop does not carry the NN path's register pressure (and vice versa).
 // kHasDist: a slice uses the distance-map finder (compiled out otherwise so the NN search keeps its registers).
 template <bool kHasProj, bool kHasNN, bool kHasDist>
-__global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(const AlignArgs A) {
+__global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LSM2D_QUERY_MIN_WAVES)) void k_align(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   // the 16-byte rows first: behind the canvases they would sit on an odd 8-byte boundary whenever cols_max + fcan_total is odd
   float4* fwin = reinterpret_cast<float4*>(smem);                 // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
@@ -576,6 +692,8 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align(co
         // decided per alignment from the device-side counts, so ragged batches get the right loop for each cloud (the oracle's
         // device-order mode applies the same rule)
         const bool coop = use_grid && (long long) S.fixed.count[fc] >= 4ll * nm_pts;
+        // (several queries of a thread in flight together -- all points, then all pixels, then all parents -- measured with the registers
+        // for it: 4 waves per SIMD and 3-4 trips tie with this loop at 8 waves per SIMD on role B and lose 10-50 % elsewhere; DESIGN App. A)
         if (coop) query_loop(std::integral_constant<int, kNNGroup>{});
         else query_loop(std::integral_constant<int, 1>{});
       }

@@ -1018,6 +1018,79 @@ def test_distmap_finder_bit_exact_and_aligner(ctx, po, small_workload):
     assert al.iterationStats()["n_correspondences"][0] == r["stats"][0].n_corr
 
 
+def test_nn_grid_build_one_workgroup_and_chip_wide_agree(ctx, po, small_workload):
+    """The NN finder's grid over a map-sized cloud is built by chip-wide kernels (k_grid_big_*), over a scan-sized one by one workgroup
+    (k_grid_build); option "grid_big_threshold" moves the border.  Both builds, on a scan, a 20k map and a 150k map (37 scan tiles), in a
+    set that mixes sizes (and holds an empty cloud): the same pairs as the oracle, and the same aligner bits."""
+    wl = small_workload
+    scan = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    big = synth.make_map(synth.make_world(5), 150000, noise_sigma=0.01, seed=3)
+    inv = synth.invert_poses(wl.x0[1:2].astype(np.float64))[0].astype(np.float32)
+    mixed_pts = np.concatenate([scan, wl.map_points, scan[:0], scan[::2]]).astype(np.float32)
+    mixed_off = np.cumsum([0, len(scan), len(wl.map_points), 0, len(scan[::2])]).astype(np.int32)
+    osp = po.slice_params(finder=po.FINDER_NN, max_distance=0.4)
+    want_map = po.find(osp, wl.map_points, scan, inv)
+    want_scan = po.find(osp, scan, wl.map_points, wl.x0[1])
+    want_big = po.find(osp, big, scan, inv)
+    assert len(want_map) > 300 and len(want_scan) > 300
+    results = []
+    try:
+        for thr in (1, 16384, 1 << 30):
+            ctx.set_option("grid_big_threshold", thr)
+            f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.4)
+            ms = api.CloudSet(ctx, mixed_pts, mixed_off)
+            f.setMoving(scan); f.setLocalMapInSensor(inv); f.setFixed(ms, 1)
+            assert np.array_equal(f.compute(), want_map), thr
+            f.setFixed(ms, 2); assert len(f.compute()) == 0
+            f.setMoving(wl.map_points); f.setLocalMapInSensor(wl.x0[1]); f.setFixed(ms, 0)
+            assert np.array_equal(f.compute(), want_scan), thr
+            f.setFixed(big); f.setMoving(scan); f.setLocalMapInSensor(inv)
+            assert np.array_equal(f.compute(), want_big), thr
+            al = api.MultiAligner2D(ctx, max_iterations=8, min_num_inliers=10)
+            al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.4), min_num_correspondences=10))
+            r = al.compute_batch([api.CloudSet(ctx, wl.map_points)], [api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)],
+                                 synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32))
+            results.append((r.pose.copy(), r.information.copy()))
+    finally:
+        ctx.set_option("grid_big_threshold", 16384)
+    for pose, info in results[1:]:
+        assert np.array_equal(pose, results[0][0]) and np.array_equal(info, results[0][1])
+
+
+def test_distmap_scatter_build_equals_gather_build_and_oracle(ctx, po, small_workload):
+    """The distance maps are built from the points' side (k_distmap_stamp: one disc of atomic minima per point) unless the packed
+    (d2, index) key does not fit; option "distmap_build" = 1 forces the per-pixel gather (k_distmap_fill).  Same pairs from both and from
+    the oracle: many points per pixel (coarse pixels), a reach of zero pixels, a reach wider than the padding, a multi-cloud set, an
+    empty cloud in the set, and a reach the scatter form cannot pack (falls back by itself)."""
+    wl = small_workload
+    scan = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    empty_then_scans = np.concatenate([[0, 0], wl.scan_offsets[1:]]).astype(np.int32)       # cloud 0 empty, cloud 1 = scan 0 .. (offsets shifted by one cloud)
+    cases = [(0.5, 0.05, scan, wl.map_points, wl.x0[1]), (0.4, 0.25, scan, wl.map_points, wl.x0[1]), (0.02, 0.05, scan, wl.map_points, wl.x0[1]),
+             (4.5, 0.05, scan[::4], wl.map_points[::7], wl.x0[1]),                            # R = 90 pixels > half the padding (83): discs cross the border
+             (0.5, 0.05, wl.map_points, scan, synth.invert_poses(wl.x0[1:2].astype(np.float64))[0].astype(np.float32)),
+             (26.0, 0.1, wl.map_points, scan[::16], synth.invert_poses(wl.x0[1:2].astype(np.float64))[0].astype(np.float32))]   # R = 260 with 15 index bits: (d2, index) does not pack -> gather build under both settings
+    try:
+        for md, res, fixed, moving, pose in cases:
+            want = po.find(po.slice_params(finder=po.FINDER_DISTMAP, max_distance=md, resolution=res), fixed, moving, pose)
+            for mode in (0, 1):
+                ctx.set_option("distmap_build", mode)
+                f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=md, resolution=res)
+                f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
+                assert np.array_equal(f.compute(), want), (md, res, mode)
+            assert len(want) > 0 or md < 0.05
+        for mode in (0, 1):
+            ctx.set_option("distmap_build", mode)
+            fs = api.CloudSet(ctx, wl.scan_points, empty_then_scans)
+            f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=0.5, resolution=0.05)
+            f.setMoving(wl.map_points); f.setLocalMapInSensor(wl.x0[1])
+            f.setFixed(fs, 2)
+            assert np.array_equal(f.compute(), po.find(po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.05), scan, wl.map_points, wl.x0[1]))
+            f.setFixed(fs, 0)
+            assert len(f.compute()) == 0
+    finally:
+        ctx.set_option("distmap_build", 0)
+
+
 def test_projection_arithmetic_exhaustive_random(ctx, po):
     """Stress the fixed-operation-sequence contract (hand-written divide, polynomial atan2, filtered sqrt): 3 million random
     points, all magnitudes and octants, 16 384 columns -- any single column or depth mismatch changes a winner."""

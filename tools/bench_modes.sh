@@ -7,7 +7,8 @@ run() { timeout -k 10 400 python bench.py "$@" 2>> $O/bench_modes.err | tail -1 
 run                                                                  # configs[1], role A / projective (the headline line)
 run --role B --finder nn --cpu-sample 200                            # configs[1], role B / NN
 run --role A --finder nn --max-distance 0.3 --cpu-sample 100 --steps 5      # configs[1], role A / NN
-run --role A --finder distmap --max-distance 0.5 --cpu-sample 100 --steps 10       # configs[1], distance-map finder (CorrespondenceFinderNN2D, row f4)
+run --role A --finder distmap --max-distance 0.5 --cpu-sample 100 --steps 10       # configs[1], distance-map finder (CorrespondenceFinderNN2D, row f4): a map per scan
+run --role B --finder distmap --max-distance 0.5 --cpu-sample 200 --steps 100      # same finder, ONE map over the 100k-point cloud serving every alignment (SURVEY f4's case)
 run --map-points 1000000 --cpu-sample 100 --steps 5                  # configs[4]
 run --scans 65536 --unique-scans 2048 --cauchy 0.05 --steps 3 --warmup 1 --cpu-sample 1000      # configs[3], one GPU's view (Cauchy 0.05: MULTI.json:957-962)
 run --scans 1 --map-points 10000 --steps 2000 --warmup 2000 --cpu-sample 1       # configs[0] (long warm-up: the first ~0.1 s of calls in a process wake the host side up slowly)
