@@ -29,9 +29,11 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 120 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
+#define LSM2D_VERSION 121 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
                              0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes;
-                             0.2.0: + lsm2d_clip_scene_voxelized, lsm2d_sweep_* (multi-device loop-closure sweep), in-kernel clock options */
+                             0.2.0: + lsm2d_clip_scene_voxelized, lsm2d_sweep_* (multi-device loop-closure sweep), in-kernel clock options;
+                             0.2.1: + lsm2d_cloudset_cloud_sizes, pinned / device-resident ranges in lsm2d_preprocess_scans, options
+                                    "distmap_build", "grid_big_threshold" */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -164,6 +166,8 @@ int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* set);
 /* points in cloud `cloud_index` (-1 when out of range).  After an asynchronous lsm2d_clip_scene / lsm2d_merge_scene the size
  * of the set they wrote is known to the device only; the size queries (and lsm2d_cloudset_download) then wait for the stream. */
 int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* set, int32_t cloud_index);
+/* all sizes at once (a preprocessed batch holds thousands of clouds): fills out_sizes[0 .. min(capacity, num_clouds)), returns the number written or a negative status */
+int32_t lsm2d_cloudset_cloud_sizes(const lsm2d_cloudset* set, int32_t* out_sizes, int32_t capacity);
 
 /* ---- a3: PointNormal2fProjectorPolar::compute -------------------------------------------------
  * One polar z-buffer pass of cloud `cloud_index` seen through `pose` (points are mapped by pose,
@@ -187,7 +191,9 @@ typedef struct {
   int32_t normal_min_points;
   float   voxelize_resolution;
 } lsm2d_preprocessor;
-int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges /* host [n_scans][n_beams] */,
+/* `ranges` [n_scans][n_beams] may live in pageable host memory (staged through the context's pinned buffer), in pinned / registered host
+ * memory (copied from directly) or in device memory of the context's device (read in place: nothing crosses the host link). */
+int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges,
                            int32_t n_scans, lsm2d_cloudset** out_set);
 /* The live tracker's form of the same operation: ONE scan into an existing reserved single-cloud set (capacity >= n_beams) --
  * no allocation, nothing waits: the ranges are staged in the set's pinned buffer, the cloud's size stays on the device until

@@ -85,6 +85,7 @@ SYMBOLS = [
     ("lsm2d_preprocess_scans", C.c_int, [_P, C.POINTER(Preprocessor), _P, C.c_int32, C.POINTER(_P)]),
     ("lsm2d_preprocess_scan_into", C.c_int, [_P, C.POINTER(Preprocessor), _P, _P]),
     ("lsm2d_clip_scene", C.c_int, [_P, C.POINTER(Projector), _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), _P]),
+    ("lsm2d_cloudset_cloud_sizes", C.c_int32, [_P, _P, C.c_int32]),
     ("lsm2d_sweep_create", C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
     ("lsm2d_sweep_destroy", None, [_P]),
     ("lsm2d_sweep_num_devices", C.c_int32, [_P]),

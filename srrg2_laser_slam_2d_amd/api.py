@@ -685,6 +685,10 @@ class MergerProjective2D:
         return size.value
 
 
+def _data_pointer(a):
+    return C.c_void_p(a.data_ptr()) if hasattr(a, "data_ptr") else a.ctypes.data_as(C.c_void_p)
+
+
 class RawDataPreprocessorProjective2D:
     """sensor_processing/raw_data_preprocessor_projective_2d.{h,cpp}: LaserMessage ranges -> PointNormal2fVectorCloud
     (polar unprojection, sliding-window normals, voxelisation), batched over scans; the clouds stay on the device."""
@@ -701,10 +705,16 @@ class RawDataPreprocessorProjective2D:
         self._meas: Optional[CloudSet] = None
 
     def setRawData(self, ranges, angle_min: float, angle_max: float, range_min: float = 0.0, range_max: float = float("inf")) -> bool:
-        """One LaserMessage (ranges [n_beams]) or a batch of them ([n_scans, n_beams]) with the message's own limits."""
-        r = np.ascontiguousarray(ranges, np.float32)
-        if r.ndim == 1:
-            r = r[None, :]
+        """One LaserMessage (ranges [n_beams]) or a batch of them ([n_scans, n_beams]) with the message's own limits.  A torch tensor is
+        taken as it is: on the context's GPU the ranges are read in place, in pinned host memory they are copied from directly."""
+        if hasattr(ranges, "data_ptr"):
+            r = ranges if ranges.dim() == 2 else ranges[None, :]
+            if r.dtype.itemsize != 4 or not r.dtype.is_floating_point or not r.is_contiguous():
+                raise ValueError("tensor ranges must be contiguous float32")
+        else:
+            r = np.ascontiguousarray(ranges, np.float32)
+            if r.ndim == 1:
+                r = r[None, :]
         if r.ndim != 2 or r.shape[1] < 1:
             raise RuntimeError("RawDataPreprocessorProjective2D::setMeasurement|measurement is not set")     # .cpp:54-57
         self._msg = (r, float(angle_min), float(angle_max), float(range_min), float(range_max))
@@ -717,14 +727,16 @@ class RawDataPreprocessorProjective2D:
         pp = _capi.Preprocessor(r.shape[1], a0, a1, max(m_rmin, self.param_range_min), min(m_rmax, self.param_range_max),   # .cpp:83-84
                                 self.param_normal_point_distance, self.param_normal_min_points, self.param_voxelize_resolution)
         h = C.c_void_p()
-        check(self._ctx._lib.lsm2d_preprocess_scans(self._ctx.handle, C.byref(pp), r.ctypes.data_as(C.c_void_p), r.shape[0], C.byref(h)),
+        check(self._ctx._lib.lsm2d_preprocess_scans(self._ctx.handle, C.byref(pp), _data_pointer(r), r.shape[0], C.byref(h)),
               "lsm2d_preprocess_scans", self._ctx.handle)
         cs = CloudSet.__new__(CloudSet)
         cs._ctx, cs._lib, cs._h = self._ctx, self._ctx._lib, h
         self._ctx._sets.add(cs)
         cs.n_clouds = r.shape[0]
         cs.n_points = int(self._ctx._lib.lsm2d_cloudset_num_points(h))
-        cs.counts = np.array([self._ctx._lib.lsm2d_cloudset_cloud_size(h, i) for i in range(r.shape[0])], np.int64)
+        sizes = np.empty(r.shape[0], np.int32)
+        check(min(self._ctx._lib.lsm2d_cloudset_cloud_sizes(h, sizes.ctypes.data_as(C.c_void_p), len(sizes)), 0), "lsm2d_cloudset_cloud_sizes", self._ctx.handle)
+        cs.counts = sizes.astype(np.int64)
         self._meas = cs
         return cs
 
@@ -738,7 +750,9 @@ class RawDataPreprocessorProjective2D:
             raise ValueError("compute_into takes one scan")
         pp = _capi.Preprocessor(r.shape[1], a0, a1, max(m_rmin, self.param_range_min), min(m_rmax, self.param_range_max),
                                 self.param_normal_point_distance, self.param_normal_min_points, self.param_voxelize_resolution)
-        check(self._ctx._lib.lsm2d_preprocess_scan_into(self._ctx.handle, C.byref(pp), r.ctypes.data_as(C.c_void_p), out.handle),
+        if hasattr(r, "data_ptr") and r.is_cuda:
+            raise ValueError("compute_into stages the scan from host memory")
+        check(self._ctx._lib.lsm2d_preprocess_scan_into(self._ctx.handle, C.byref(pp), _data_pointer(r), out.handle),
               "lsm2d_preprocess_scan_into", self._ctx.handle)
         out._set_pending()
         self._meas = out

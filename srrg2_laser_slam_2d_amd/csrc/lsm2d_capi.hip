@@ -253,6 +253,16 @@ extern "C" int lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms) {
 }
 
 static bool valid_cloud_index_fwd(const lsm2d_cloudset* cs, int32_t i);
+// what a caller's buffer is to the runtime (entry points that take bulk input accept all three)
+enum class PtrKind { pageable, pinned, device };
+static PtrKind pointer_kind(const void* p) {
+  hipPointerAttribute_t at; memset(&at, 0, sizeof at);
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void) hipGetLastError(); return PtrKind::pageable; }     // plain malloc memory: an error on some runtimes
+  if (at.type == hipMemoryTypeDevice) return PtrKind::device;
+  if (at.type == hipMemoryTypeHost) return PtrKind::pinned;
+  return PtrKind::pageable;                      // unregistered; managed memory is treated as host memory the runtime can page
+}
+
 static int ensure_stage(lsm2d_context* ctx, size_t bytes) {
   if (bytes <= ctx->h_stage_bytes) return LSM2D_SUCCESS;
   if (ctx->h_stage) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipHostFree(ctx->h_stage)); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
@@ -435,6 +445,14 @@ extern "C" int32_t lsm2d_cloudset_num_clouds(const lsm2d_cloudset* cs) { return 
 extern "C" int64_t lsm2d_cloudset_num_points(const lsm2d_cloudset* cs) { return (cs && resolve_count(cs) == LSM2D_SUCCESS) ? cs->total : 0; }
 extern "C" int64_t lsm2d_cloudset_cloud_size(const lsm2d_cloudset* cs, int32_t i) {
   return (cs && i >= 0 && i < cs->n_clouds && resolve_count(cs) == LSM2D_SUCCESS) ? cs->h_count[i] : -1;
+}
+
+extern "C" int32_t lsm2d_cloudset_cloud_sizes(const lsm2d_cloudset* cs, int32_t* out, int32_t capacity) {
+  if (!cs || capacity < 0 || (capacity > 0 && !out)) return LSM2D_BAD_ARGUMENT;
+  const int rc = resolve_count(cs); if (rc != LSM2D_SUCCESS) return rc;
+  const int32_t n = capacity < cs->n_clouds ? capacity : cs->n_clouds;
+  for (int32_t i = 0; i < n; ++i) out[i] = cs->h_count[(size_t) i];
+  return n;
 }
 
 static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents changed: cached NN grids are stale
@@ -806,22 +824,26 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   for (int c = 0; c < n_scans; ++c) cs->h_start[c] = c * stride;
   int rc = cloudset_alloc(ctx, cs);
   if (rc != LSM2D_SUCCESS) { lsm2d_cloudset_destroy(cs); return rc; }
+  // where the ranges live: device memory is read in place, pinned (or registered) host memory is copied from directly, pageable
+  // host memory goes through the context's pinned staging buffer (one more pass over it on the host)
+  const PtrKind kind = pointer_kind(ranges);
   // beam directions with the host libm (the oracle does the same): angle = (c - n/2) * sensor_res
   const size_t rbytes = sizeof(float) * (size_t) nb * (size_t) n_scans, dbytes = sizeof(float2) * (size_t) nb;
-  const size_t o_dir = (rbytes + 255) & ~(size_t) 255;
-  rc = ensure_scratch(ctx, o_dir + dbytes); if (rc) { lsm2d_cloudset_destroy(cs); return rc; }
-  rc = ensure_stage(ctx, o_dir + dbytes); if (rc) { lsm2d_cloudset_destroy(cs); return rc; }
-  memcpy(ctx->h_stage, ranges, rbytes);
-  float2* hd = (float2*) ((char*) ctx->h_stage + o_dir);
+  const size_t o_rng = (dbytes + 255) & ~(size_t) 255;
+  rc = ensure_scratch(ctx, o_rng + (kind == PtrKind::device ? 0 : rbytes)); if (rc) { lsm2d_cloudset_destroy(cs); return rc; }
+  rc = ensure_stage(ctx, o_rng + (kind == PtrKind::pageable ? rbytes : 0)); if (rc) { lsm2d_cloudset_destroy(cs); return rc; }
+  if (kind == PtrKind::pageable) memcpy((char*) ctx->h_stage + o_rng, ranges, rbytes);
+  float2* hd = (float2*) ctx->h_stage;
   const float sensor_res = (pp->angle_max - pp->angle_min) / (float) nb, k01 = (float) nb * 0.5f;
   for (int c = 0; c < nb; ++c) { const float a = ((float) c - k01) * sensor_res; hd[c] = make_float2(cosf(a), sinf(a)); }
   PrepArgs A;
-  A.ranges = (const float*) ctx->d_scratch; A.beam_dir = (const float2*) ((char*) ctx->d_scratch + o_dir);
+  A.ranges = kind == PtrKind::device ? ranges : (const float*) ((char*) ctx->d_scratch + o_rng); A.beam_dir = (const float2*) ctx->d_scratch;
   A.n_beams = nb; A.stride = stride; A.rmin = pp->range_min; A.rmax = pp->range_max;
   A.d2max = pp->normal_point_distance * pp->normal_point_distance; A.min_points = pp->normal_min_points;
   A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
   A.out_xy = cs->d_xy; A.out_nrm = cs->d_nrm; A.out_count = cs->d_count;
-  hipError_t e = hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, o_dir + dbytes, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, kind == PtrKind::pageable ? o_rng + rbytes : dbytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && kind == PtrKind::pinned) e = hipMemcpyAsync((char*) ctx->d_scratch + o_rng, ranges, rbytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && ctx->kernel_timing) e = hipEventRecord(ctx->ev0, ctx->stream);
   if (e == hipSuccess) { hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, ctx->stream, A); e = hipGetLastError(); }
   if (e == hipSuccess && ctx->kernel_timing) e = hipEventRecord(ctx->ev1, ctx->stream);

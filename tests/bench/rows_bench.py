@@ -78,7 +78,15 @@ def main():
     cpu_s = time.perf_counter() - t0                       # includes the downloads; the oracle dominates
     k_ms = float(np.median(kernel_ms[1:]))
     alg = 4.0 * args.beams * args.scans + 16.0 * float(meas.counts.sum())
+    # the same call with the ranges in pinned host memory (no staging pass) and already on the device (nothing crosses the host link)
+    import torch
+    walls = {}
+    for where, src in (("pinned", torch.from_numpy(ranges).pin_memory()), ("device", torch.from_numpy(ranges).to("cuda:0"))):
+        pre.setRawData(src, a0, a1, 0.0, 60.0)
+        walls[where], _ = timed(run_pre, args.reps, sync)
+        ok = ok and np.array_equal(run_pre.last.counts, meas.counts) and np.array_equal(run_pre.last.download(7), meas.download(7))
     emit("f2 preprocess_scans", scans=args.scans, beams=args.beams, points_out=int(meas.counts.sum()), wall_ms=wall, kernel_ms=k_ms,
+         wall_ms_pinned_ranges=walls["pinned"], wall_ms_device_ranges=walls["device"], scans_per_s_wall_device_ranges=args.scans / (walls["device"] * 1e-3),
          scans_per_s_kernel=args.scans / (k_ms * 1e-3), scans_per_s_wall_host_ranges_in=args.scans / (wall * 1e-3),
          algorithmic_GBs_kernel=alg / (k_ms * 1e-3) / 1e9, frac_of_hbm_peak=alg / (k_ms * 1e-3) / 8e12,
          cpu_port_scans_per_s_1core=ns / cpu_s, parity_bit_identical=bool(ok), sample=ns)

@@ -1301,6 +1301,30 @@ def test_preprocessor_bit_exact_batch_and_feeds_aligner(ctx, po):
         assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
 
 
+def test_preprocessor_reads_pinned_and_device_resident_ranges(ctx, po):
+    """lsm2d_preprocess_scans takes its ranges from pageable host memory (staged), pinned host memory (copied from directly) or the
+    device (read in place): the same clouds, bit for bit, and the oracle's."""
+    import torch
+    world = synth.make_world(2)
+    poses = synth.sample_poses(world, 40, seed=14)
+    a0, a1 = -2.34747, 2.35619
+    ranges = synth.make_scan_ranges(world, poses, n_beams=1081, angle_min=a0, angle_max=a1, noise_sigma=0.005, seed=3)
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+    got = []
+    for src in (ranges, torch.from_numpy(ranges).pin_memory(), torch.from_numpy(ranges).to("cuda:0")):
+        pre.setRawData(src, a0, a1, 0.0, 30.0)
+        cs = pre.compute()
+        got.append([cs.download(i) for i in range(len(poses))])
+    pp = po.Preprocessor(1081, a0, a1, 0.3, 20.0, 0.3, 5, 0.02)
+    for i in range(len(poses)):
+        want = po.preprocess_scan(pp, ranges[i])
+        assert len(want) > 200
+        for g in got:
+            assert np.array_equal(g[i], want), i
+    with pytest.raises(ValueError):
+        pre.setRawData(torch.from_numpy(ranges).to("cuda:0")[:1], a0, a1, 0.0, 30.0); pre.compute_into(api.CloudSet.reserved(ctx, 2048))
+
+
 def _ranges_in_pose_out_step(ctx, po):
     world = synth.make_world(6)
     a0, a1 = -2.34747, 2.35619

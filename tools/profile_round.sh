@@ -17,6 +17,8 @@ hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -Wno-unused
 timeout -k 5 100 python tools/occupancy_probe.py > $O/occupancy_probe.txt 2>&1; tail -3 $O/occupancy_probe.txt
 # counters -> profiles/counters.json (hash-stamped), then the bench line that reads them back
 python tools/write_counters.py $O --tag $tag && cp profiles/counters.json $O/counters.json && python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json
+# the command line the round-end driver used in round 1 (20 timed steps after 5 warm-up steps)
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2>> $O/bench.err; cut -c1-330 $O/bench_driver_cmd.json
 # the rows either side of the path (preprocessor batch, finder reset() structures, clip / merge): wall times + per-kernel durations
 cd /tmp; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rows_trace -- python3 $R/tests/bench/rows_bench.py > $O/rows.jsonl 2> $O/rows.err; echo "rows rc=$?"; cd $R
 cat $O/rows_trace/*/*kernel_stats.csv | head -12
