@@ -16,6 +16,8 @@ template <int KIND>
 __global__ __launch_bounds__(1024) void probe(unsigned long long* out, int iters, float seed) {
   extern __shared__ char pad[];      // the whole LDS: one workgroup per CU
   float a = seed + threadIdx.x, b = 1.0001f, c = 0.5f, d = seed * 2.0f, e = seed * 3.0f, f = seed * 5.0f;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f pa = {a, d}, pb = {b, b}, pc = {c, c};
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int i = 0; i < iters; ++i) {
     if (KIND == 0) asm volatile(REP64("v_fma_f32 %0, %0, %1, %2\n") : "+v"(a) : "v"(b), "v"(c));                       // 64 dependent
@@ -37,10 +39,12 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long* out, int iters
                                 : "+v"(a), "+v"(d) : "v"(b), "v"(c));                                                    // as the compiler emits it: s_nop 0 behind the rcp
     if (KIND == 10) asm volatile(REP16("v_rcp_f32 %1, %0\n v_rsq_f32 %2, %0\n v_fma_f32 %0, %1, %2, %3\n v_fma_f32 %0, %0, %3, %4\n")
                                 : "+v"(a), "+v"(d), "+v"(e) : "v"(b), "v"(c));                                           // two transcendentals back to back
+    if (KIND == 11) asm volatile(REP64("v_pk_fma_f32 %0, %0, %1, %2\n") : "+v"(pa) : "v"(pb), "v"(pc));                  // packed: two fp32 FMAs per lane per instruction
+    if (KIND == 12) asm volatile(REP64("v_pk_mul_f32 %0, %0, %1\n") : "+v"(pa) : "v"(pb));
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
-  if (a + d + e + f == 12345.678f) out[0] = 0;
+  if (a + d + e + f + pa.x + pa.y == 12345.678f) out[0] = 0;
 }
 
 // the real per-point instruction stream of k_align (csrc/lsm2d_device.h: project_point_stream, incl. its exec masking and the
@@ -204,6 +208,8 @@ int main() {
   run<9>("1 v_rcp + s_nop 0 + 3 dependent fma (4 VALU counted as 4)", d_out, n_cu);
   run<6>("v_rcp, 3 unrelated fma, consumer (5 per group, counted as 4)", d_out, n_cu);
   run<10>("v_rcp + v_rsq + 2 fma", d_out, n_cu);
+  run<11>("v_pk_fma_f32 (2 FMAs per lane), dependent", d_out, n_cu);
+  run<12>("v_pk_mul_f32, dependent", d_out, n_cu);
   run_stream(d_out, n_cu);
   printf("ablations of that stream (same launch shape):\n");
   run_ablation<1, 1, 1>("full stream (copy of project_point_stream)", d_out, n_cu);
