@@ -103,6 +103,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=250, help="timed steps (default: >= 0.5 s of timed region at ~2 ms per step)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spinup-s", type=float, default=0.3, help="seconds of untimed steps before the warm-up steps (clock ramp); 0 = none")
     ap.add_argument("--scans", type=int, default=1000, help="alignments per GPU per step")
     ap.add_argument("--map-points", type=int, default=100000)
     ap.add_argument("--iterations", type=int, default=20)
@@ -191,13 +192,21 @@ def main() -> None:
         def step():
             return aligner.compute_batch([map_set], [scan_set], x0, moving_index=idx)
 
-    for _ in range(args.warmup):
-        res = step()
     # the interpreter's cyclic collector walks every object torch has imported (tens of milliseconds, once or twice per few hundred
     # steps: one such pause was 8 % of a 0.46 s timed region).  Collect now and park what exists in the permanent generation, so
-    # the collector only ever looks at what the loop itself allocates -- nothing is switched off.
+    # the collector only ever looks at what the loop itself allocates -- nothing is switched off.  BEFORE the warm-up, not behind it: the
+    # chip drops its clock within an idle stretch of that length and needs ~25 launches (40 ms) of load to get it back
+    # (tools/clock_trace.py, profiles/r02/clock_trace_r02k.txt: 2.06 GHz for the first 25 steps after a pause, 2.19 GHz from then on) --
+    # with the collection between warm-up and timing, 20 timed steps ran entirely on the low clock.
     import gc
     gc.collect(); gc.freeze()
+    # clock ramp, untimed: the same step for --spinup-s seconds (the count is printed as `spinup_steps`), then the W warm-up steps
+    spinup_steps = 0
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup_s:
+        step(); spinup_steps += 1
+    for _ in range(args.warmup):
+        res = step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -302,7 +311,7 @@ def main() -> None:
             print("bench.py: " + warn, file=sys.stderr)
         out = {
             "metric": "scan-to-map alignments/sec (1081-beam vs 100k-pt map, 20 GN iters)",
-            "value": n_total / elapsed, "unit": "alignments/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "value": n_total / elapsed, "unit": "alignments/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup_steps,
             "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed,
             "ms_per_step_median_rank0": float(np.median(step_s)) * 1e3, "ms_per_step_max_rank0": float(np.max(step_s)) * 1e3, "slowest_step_rank0": int(np.argmax(step_s)), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
