@@ -255,9 +255,10 @@ extern "C" int lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms) {
 static bool valid_cloud_index_fwd(const lsm2d_cloudset* cs, int32_t i);
 // what a caller's buffer is to the runtime (entry points that take bulk input accept all three)
 enum class PtrKind { pageable, pinned, device };
-static PtrKind pointer_kind(const void* p) {
+static PtrKind pointer_kind(const void* p, int* device = nullptr) {
   hipPointerAttribute_t at; memset(&at, 0, sizeof at);
   if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void) hipGetLastError(); return PtrKind::pageable; }     // plain malloc memory: an error on some runtimes
+  if (device) *device = at.device;
   if (at.type == hipMemoryTypeDevice) return PtrKind::device;
   if (at.type == hipMemoryTypeHost) return PtrKind::pinned;
   return PtrKind::pageable;                      // unregistered; managed memory is treated as host memory the runtime can page
@@ -826,7 +827,9 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   if (rc != LSM2D_SUCCESS) { lsm2d_cloudset_destroy(cs); return rc; }
   // where the ranges live: device memory is read in place, pinned (or registered) host memory is copied from directly, pageable
   // host memory goes through the context's pinned staging buffer (one more pass over it on the host)
-  const PtrKind kind = pointer_kind(ranges);
+  int rdev = -1;
+  const PtrKind kind = pointer_kind(ranges, &rdev);
+  if (kind == PtrKind::device && rdev != ctx->device) { lsm2d_cloudset_destroy(cs); return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scans: device-resident ranges must live on the context's device"); }
   // beam directions with the host libm (the oracle does the same): angle = (c - n/2) * sensor_res
   const size_t rbytes = sizeof(float) * (size_t) nb * (size_t) n_scans, dbytes = sizeof(float2) * (size_t) nb;
   const size_t o_rng = (dbytes + 255) & ~(size_t) 255;
