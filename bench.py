@@ -305,7 +305,8 @@ def main() -> None:
                 roof["stream_floor"] = {"cycles_per_wave_point": counters["stream_cycles_per_wave_point"], "floor_ms_at_measured_clock": floor_ms,
                                         "frac": floor_ms / k_ms,
                                         "note": "kernel time / (point visits x the stream's own measured issue cost): bin walk, reductions, 3x3 solves and "
-                                                "barriers of the other workgroups on a CU run underneath the stream when this is ~1"}
+                                                "barriers of the other workgroups on a CU run underneath the stream when this is ~1 (the probe is a launch of its own: "
+                                                "+-2 % between passes, so values just above 1 are its error, not a faster-than-floor kernel)"}
         if warn:
             roof["warning"] = warn
             print("bench.py: " + warn, file=sys.stderr)
