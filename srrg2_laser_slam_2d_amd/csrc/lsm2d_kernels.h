@@ -691,6 +691,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         // cooperative search (kNNGroup lanes per query) when THIS alignment's fixed cloud is at least four times its moving one --
         // decided per alignment from the device-side counts, so ragged batches get the right loop for each cloud (the oracle's
         // device-order mode applies the same rule)
+        // (the cooperative search on a scan-sized fixed cloud with its tables in LDS: 2 / 4 / 8 lanes per query take 21 / 41 / 90 ms against
+        // 8.1 ms with one lane per query -- the time goes with the number of wave-queries, i.e. into the fixed cost of a query, not its candidates)
         const bool coop = use_grid && (long long) S.fixed.count[fc] >= 4ll * nm_pts;
         // (several queries of a thread in flight together -- all points, then all pixels, then all parents -- measured with the registers
         // for it: 4 waves per SIMD and 3-4 trips tie with this loop at 8 waves per SIMD on role B and lose 10-50 % elsewhere; DESIGN App. A)
