@@ -368,6 +368,14 @@ LSM2D_DEV void block_reduce_gather(const float* red, int nwaves, Accum& A) {
   }
 }
 
+// a lane's own share of the totals: lane k < 11 adds the k-th float quantity over the waves (wave order, from 0 -- the same bits as
+// block_reduce_gather), lanes 11..13 the integer counts.  Call from every lane of wave 0.
+LSM2D_DEV void block_reduce_gather_lane(const float* red, int nwaves, int lane, float& v, int& vi) {
+  v = 0.0f; vi = 0;
+  if (lane < 11) { for (int w = 0; w < nwaves; ++w) v += red[w * kAccumWords + lane]; }
+  else if (lane < kAccumWords) { for (int w = 0; w < nwaves; ++w) vi += __float_as_int(red[w * kAccumWords + lane]); }
+}
+
 // the same totals for lane 0 of wave 0, gathered in parallel: lanes 0..13 each add one quantity over the waves (same wave
 // order, hence the same bits as block_reduce_gather), lane 0 collects them with v_readlane.  Call from every lane of wave 0.
 LSM2D_DEV void block_reduce_gather_wave0(const float* red, int nwaves, int lane, Accum& A) {

@@ -527,15 +527,25 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   uint16_t* l_sidx = l_cst + ((A.nn_lds_cells + 2) & ~1);
   __shared__ float s_pose[3];
   __shared__ Iso   s_iso[kMaxSlices];
-  __shared__ float s_H[9], s_Hs[9], s_b[3];      // s_H: information matrix (H of the last solved iteration); s_Hs: this iteration's sum
-  __shared__ int   s_n_in, s_n_out, s_n_corr, s_active, s_done, s_status, s_last_n_in;
-  __shared__ float s_chi_in, s_chi_out;
+  // s_H: information matrix (H of the last solved iteration, built and solved IN LDS: thread 0's serial code has 64 registers like
+  // everybody else, and what it kept in private arrays went to scratch -- eleven dependent round trips to memory per iteration);
+  // s_sum: this iteration's sums in the order of Accum (h00 h01 h02 h11 h12 h22 b0 b1 b2 chi_in chi_out | n_in n_out as integers),
+  // each added by the lane of wave 0 that gathered it
+  __shared__ float s_H[9], s_rhs[3], s_sum[kAccumWords + 2];
+  __shared__ int   s_n_corr, s_active, s_done, s_status, s_last_n_in;
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   const int a = blockIdx.x, tid = threadIdx.x;
   constexpr int nwaves = kAlignBlock / 64;
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
   __shared__ unsigned long long s_clk[2];      // start stamps wait in LDS: no register is held across the kernel for them
+#ifdef LSM2D_PHASE_PROBE      // diagnostics build: thread 0 sums the cycles it spends in the query / projection phase, at the barrier + reduction, and in the solve
+  __shared__ unsigned long long s_ph[4];
+  if (tid == 0) { s_ph[0] = s_ph[1] = s_ph[2] = 0; s_ph[3] = __builtin_amdgcn_s_memtime(); }
+#define LSM2D_PH(k) do { if (tid == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); s_ph[k] += now__ - s_ph[3]; s_ph[3] = now__; } } while (0)
+#else
+#define LSM2D_PH(k) do { } while (0)
+#endif
   const bool stamp = A.clock_out && tid == 0 && a % A.clock_stride == 0;
   if (stamp) { s_clk[0] = __builtin_amdgcn_s_memtime(); s_clk[1] = __builtin_amdgcn_s_memrealtime(); }
   if (A.prior && tid >= 64 && tid < 64 + kPriorWords)
@@ -558,9 +568,9 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     // across the whole kernel for thread 0's sake)
     float zf = 0.0f; int zi = 0;
     asm volatile("" : "+v"(zf), "+v"(zi));
-    for (int k = 0; k < 9; ++k) s_Hs[k] = zf;
-    s_b[0] = s_b[1] = s_b[2] = zf;
-    s_n_in = s_n_out = s_n_corr = s_active = zi; s_chi_in = s_chi_out = zf;
+    for (int k = 0; k < 11; ++k) s_sum[k] = zf;
+    s_sum[11] = s_sum[12] = __int_as_float(zi);
+    s_n_corr = s_active = zi;
   };
   if (tid == 0) {
     if (A.inline_n1) { s_pose[0] = A.pose1[0]; s_pose[1] = A.pose1[1]; s_pose[2] = A.pose1[2]; }
@@ -619,6 +629,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       const SliceDev& S = A.s[s];
       const Iso T = s_iso[s];
       Accum acc; accum_zero(acc);
+      LSM2D_PH(2);
       if (kHasProj && ((!kHasNN && !kHasDist) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
         {
           // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
@@ -699,20 +710,21 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         if (coop) query_loop(std::integral_constant<int, kNNGroup>{});
         else query_loop(std::integral_constant<int, 1>{});
       }
+      LSM2D_PH(0);
       block_reduce_store(acc, red, tid);
       __syncthreads();
-      Accum t;
-      if (tid < 64) block_reduce_gather_wave0(red, nwaves, tid, t);
-      if (tid == 0) {
-        s_n_corr += t.n_corr;
-        if (t.n_corr > S.min_corr) {   // slices with #pairs <= min_num_correspondences are skipped
-          ++s_active;
-          s_Hs[0] += t.h00; s_Hs[1] += t.h01; s_Hs[2] += t.h02; s_Hs[3] += t.h01; s_Hs[4] += t.h11; s_Hs[5] += t.h12;
-          s_Hs[6] += t.h02; s_Hs[7] += t.h12; s_Hs[8] += t.h22;
-          s_b[0] += t.b0; s_b[1] += t.b1; s_b[2] += t.b2;
-          s_n_in += t.n_in; s_n_out += t.n_out; s_chi_in += t.chi_in; s_chi_out += t.chi_out;
+      if (tid < 64) {
+        // lanes 0..13 of wave 0 each add one quantity over the waves (wave order) and then into the iteration's sum themselves
+        float v; int vi; block_reduce_gather_lane(red, nwaves, tid, v, vi);
+        const int n_corr = __builtin_amdgcn_readlane(vi, 13);
+        if (tid == 0) s_n_corr += n_corr;
+        if (n_corr > S.min_corr) {     // slices with #pairs <= min_num_correspondences are skipped
+          if (tid < 11) s_sum[tid] += v;
+          else if (tid < 13) s_sum[tid] = __int_as_float(__float_as_int(s_sum[tid]) + vi);
+          if (tid == 0) ++s_active;
         }
       }
+      LSM2D_PH(1);
       // pure projective kernels need no barrier here: the other waves go on to the next slice's projection (the cells it
       // writes were reset by the bin walk) and touch `red` again only after the barrier that follows it, which lane 0
       // joins once it is done with the partials.  The point-query branches write `red` without such a barrier in between.
@@ -720,24 +732,23 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     }
     if (tid == 0) {
       // (thread 0's serial state lives in LDS, not in registers every thread would carry -- and spill -- across the loops)
-      StatsDev last; last.n_corr = s_n_corr; last.n_in = s_n_in; last.n_out = s_n_out; last.chi_in = s_chi_in; last.chi_out = s_chi_out;
-      s_last_n_in = s_n_in;
+      StatsDev last; last.n_corr = s_n_corr; last.n_in = __float_as_int(s_sum[11]); last.n_out = __float_as_int(s_sum[12]); last.chi_in = s_sum[9]; last.chi_out = s_sum[10];
+      s_last_n_in = last.n_in;
       if (A.out_stats) A.out_stats[(size_t) a * A.max_it + it] = last;
       if (!s_active) { s_status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
       else {
-        float H[9], b[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) H[k] = s_Hs[k];
-        b[0] = s_b[0]; b[1] = s_b[1]; b[2] = s_b[2];
-        if (A.prior) add_prior(s_prior, s_pose, H, b);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s_H[k] = H[k];     // information matrix = H of the last iteration
-        float X[3] = {s_pose[0], s_pose[1], s_pose[2]};
-        if (!solve_update(H, b, A.damping, X)) { s_status = LSM2D_SINGULAR_H; s_done = 1; }
-        else { s_pose[0] = X[0]; s_pose[1] = X[1]; s_pose[2] = X[2]; }
+        // information matrix = H of the last iteration: assembled, given its prior and solved where it lies
+        s_H[0] = s_sum[0]; s_H[1] = s_sum[1]; s_H[2] = s_sum[2]; s_H[3] = s_sum[1]; s_H[4] = s_sum[3]; s_H[5] = s_sum[4];
+        s_H[6] = s_sum[2]; s_H[7] = s_sum[4]; s_H[8] = s_sum[5];
+        s_rhs[0] = s_sum[6]; s_rhs[1] = s_sum[7]; s_rhs[2] = s_sum[8];
+        if (A.prior) add_prior(s_prior, s_pose, s_H, s_rhs);
+        float dmp = A.damping;
+        asm volatile("" : "+v"(dmp));      // (not a loop invariant to hoist -- as a double it was kept, and spilled, across the whole kernel)
+        if (!solve_update(s_H, s_rhs, dmp, s_pose)) { s_status = LSM2D_SINGULAR_H; s_done = 1; }
       }
       if (!s_done) begin_iteration();        // next iteration's transforms and zeroed sums, under the same barrier
     }
+    LSM2D_PH(2);
     __syncthreads();
     if (s_done) { ++it; break; }
   }
@@ -754,6 +765,11 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       co[0] = __builtin_amdgcn_s_memtime() - s_clk[0];
       co[1] = __builtin_amdgcn_s_memrealtime() - s_clk[1];
       co[2] = s_clk[1];                                                            // when it started (100 MHz ticks): which dispatch round it was in
+#ifdef LSM2D_PHASE_PROBE
+      co[1] = s_ph[0]; co[2] = s_ph[1]; co[3] = s_ph[2];      // cycles: query phase, barrier + reduction, solve + the rest (co[0] stays the lifetime)
+      if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); } else A.out_status[a] = st;
+      return;
+#endif
       co[3] = (unsigned long long) __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |      // HW_REG_HW_ID (id 4): wave / SIMD / CU / SE it ran on
               ((unsigned long long) __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);  // HW_REG_XCC_ID (id 20)
     }
