@@ -131,12 +131,20 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (tests): LSM2D_BENCH_BACKEND=gloo lets several ranks share a card
+    # (RCCL refuses two ranks on one device); the ranks then run the same kernels, shards and cross-rank check, only the transport differs
+    backend = os.environ.get("LSM2D_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or bool(os.environ.get("LSM2D_BENCH_FORCE_DIST"))   # the env var rehearses the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     ranks_seen = dist.get_world_size() if use_dist else 1
 
     from srrg2_laser_slam_2d_amd import api, distributed, synth

@@ -987,6 +987,33 @@ def test_bench_strong_scaling_leg_runs_over_rccl_on_one_gpu(tmp_path):
     assert d["value"] > 10000 and d["max_pose_err_m"] < 1e-4
 
 
+def test_bench_three_ranks_share_the_gpu_weak_and_strong(tmp_path):
+    """bench.py launched as the round-end driver launches it for N > 1 (torch.distributed.run, one process per rank) with three ranks
+    on THIS one GPU: RCCL refuses two ranks on a device, so the transport is gloo (LSM2D_BENCH_BACKEND) -- everything else is the N-GPU
+    run: per-rank scans, the submap broadcast from rank 0, sharding, barrier-bracketed timing with the maximum over ranks, the cross-rank
+    bit check.  Weak scaling (the default line) and the strong-scaling sweep of configs[3] at a reduced size."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LSM2D_BENCH_BACKEND="gloo")
+    for extra, scaling, per_rank in ((["--scans", "300"], "weak", 300), (["--total-candidates", "3001", "--unique-scans", "256", "--cauchy", "0.05"], "strong", None)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                            os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "3", "--warmup", "1", "--spinup-s", "0.05", "--no-cpu-baseline"] + extra,
+                           env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints, the others stay silent
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 3 and d["ranks_seen"] == 3 and d["scaling"] == scaling and d["parity_ok"], d
+        assert d["cross_rank_check"].startswith("3 of 3 ranks"), d["cross_rank_check"]
+        if per_rank:
+            assert d["config"]["alignments_per_gpu"] == per_rank and abs(d["value"] * d["ms_per_step"] * 1e-3 - 3 * per_rank) < 1e-6 * 3 * per_rank
+        else:
+            assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 3001) < 1e-2       # the whole sweep per step, whatever the shard sizes (1000 / 1000 / 1001)
+        assert d["max_pose_err_m"] < 1e-4
+
+
 # ---- distance-map finder (CorrespondenceFinderNN2D, row a5 / f4) ----------------------------------------------
 def test_distmap_finder_bit_exact_and_aligner(ctx, po, small_workload):
     wl = small_workload
