@@ -1208,6 +1208,42 @@ def test_abi_error_paths_and_limits(ctx, small_workload):
         quiet.close()
 
 
+def test_no_device_memory_is_left_behind(small_workload):
+    """Contexts, cloud sets, the finders' cached structures (grids, distance maps, lane-chunked copies), reserved sets that grow, sweeps:
+    created, used and destroyed 25 times over -- the device's free memory ends where it started (64 MB of slack for the runtime's own pools)."""
+    import ctypes as C
+    import torch
+    from srrg2_laser_slam_2d_amd import _capi
+    lib = _capi.load(); wl = small_workload
+    scan = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+
+    def cycle():
+        c = api.Context(0)
+        scans = api.CloudSet(c, wl.scan_points, wl.scan_offsets); mp = api.CloudSet(c, wl.map_points)
+        for f in (api.CorrespondenceFinderKDTree2D(c, max_distance_m=0.3), api.CorrespondenceFinderNN2D(c, max_distance_m=0.5, resolution=0.05),
+                  api.CorrespondenceFinderProjective2f(c, _projector())):
+            al = api.MultiAligner2D(c, max_iterations=3, min_num_inliers=10)
+            al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(f, min_num_correspondences=10))
+            al.compute_batch([scans], [mp], wl.x0)                                           # structures over the scans
+            al.compute_batch([mp], [scans], synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32)) if not isinstance(f, api.CorrespondenceFinderProjective2f) else None
+        grow = api.CloudSet.reserved(c, 40000); grow.upload(wl.map_points)
+        m = api.MergerProjective2D(c, _projector(), 0.2); m.setScene(grow); m.setMeasurement(scan); m.setMeasurementInScene(synth.invert_poses(wl.x_true[:1])[0].astype(np.float32)); m.compute()
+        clip = api.SceneClipperProjective2D(c, _projector()); clip.setFullScene(grow); clip.setRobotInLocalMap(synth.invert_poses(wl.x_true[:1])[0].astype(np.float32)); clip.compute()
+        sw = C.c_void_p(); assert lib.lsm2d_sweep_create((C.c_int32 * 2)(0, 0), 2, C.byref(sw)) == 0
+        pts = np.ascontiguousarray(wl.map_points)
+        assert lib.lsm2d_sweep_set_map(sw, pts.ctypes.data_as(C.c_void_p), len(pts)) == 0
+        lib.lsm2d_sweep_destroy(sw)
+        c.close()
+
+    cycle(); torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)
+
+
 def test_sets_may_outlive_their_context(ctx, small_workload):
     """lsm2d_destroy orphans the sets still alive on it: destroying them afterwards is fine, using them is an error, and nothing
     of it disturbs another context."""
