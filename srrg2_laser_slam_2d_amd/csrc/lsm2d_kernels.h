@@ -821,7 +821,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   constexpr int nwaves = kAlignBlock / 64;
   const int a = blockIdx.x, gtid = threadIdx.x, nthr = kAlignBlock * A.n_slices;      // launched with 512 threads per slice (one or two slices)
 #ifdef LSM2D_PHASE_CLOCKS      // debug build: where one alignment's time goes (10 ns ticks), printed by thread 0
-  unsigned long long pc_t = __builtin_amdgcn_s_memrealtime(), pc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pc_t = __builtin_amdgcn_s_memrealtime(), pc_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define LSM2D_PC(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); pc_acc[k] += n_ - pc_t; pc_t = n_; } while (0)
 #else
 #define LSM2D_PC(k) do { } while (0)
@@ -947,14 +947,17 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
         }
         last.n_corr = n_corr; last.n_in = n_in; last.n_out = n_out; last.chi_in = chi_in; last.chi_out = chi_out;
         if (A.out_stats) A.out_stats[(size_t) a * A.max_it + it] = last;
+        LSM2D_PC(8);               // sums of the slices, statistics
         if (!active) { status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
         else {
           if (A.prior) add_prior_inline(s_prior, pose, Hs, bs);      // inlined: no round trip through scratch on the serial path
+          LSM2D_PC(9);             // prior
 #pragma unroll
           for (int k = 0; k < 9; ++k) Hlast[k] = Hs[k];
           float X[3] = {pose[0], pose[1], pose[2]};
           if (!solve_update(Hs, bs, A.damping, X)) { status = LSM2D_SINGULAR_H; s_done = 1; }
           else { pose[0] = X[0]; pose[1] = X[1]; pose[2] = X[2]; }
+          LSM2D_PC(10);            // 3x3 solve and pose update
         }
         if (!s_done) begin_iteration();
       }
@@ -966,7 +969,8 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   }
 #ifdef LSM2D_PHASE_CLOCKS
   if (gtid == 0 && a == 0) printf("k_align_pair ticks(10ns): prologue %llu project %llu walk %llu wave-sums %llu wait %llu gather %llu solve %llu barrier %llu its %d\n",
-                                  pc_acc[0], pc_acc[1], pc_acc[6], pc_acc[7], pc_acc[2], pc_acc[3], pc_acc[4], pc_acc[5], it);
+                                  pc_acc[0], pc_acc[1], pc_acc[6], pc_acc[7], pc_acc[2], pc_acc[3], pc_acc[4] + pc_acc[8] + pc_acc[9] + pc_acc[10], pc_acc[5], it);
+  if (gtid == 0 && a == 0) printf("  solve = sums %llu + prior %llu + ldlt/update %llu + next transforms %llu\n", pc_acc[8], pc_acc[9], pc_acc[10], pc_acc[4]);
 #endif
 #undef LSM2D_PC
   if (gtid == 0) {
