@@ -451,11 +451,14 @@ LSM2D_DEV bool match_bin(u64 fk, u64 mk, const SliceDev& S, const Iso& T, const 
   return !(dot < S.normal_cos);
 }
 
-LSM2D_DEV Iso slice_iso(const SliceDev& S, const float pose[3]) {      // X_eff = S^-1 X (AlignerSliceProcessorLaser2DWithSensor) as rotation + translation
+LSM2D_DEV Iso slice_iso_of(int has_sensor, float cSinv, float sSinv, const float Sinv[3], const float pose[3]) {
   float Xe[3] = {pose[0], pose[1], pose[2]};
-  if (S.has_sensor) compose(S.cSinv, S.sSinv, S.Sinv, pose, Xe);
+  if (has_sensor) compose(cSinv, sSinv, Sinv, pose, Xe);
   Iso T; sincos_fixed(Xe[2], T.s, T.c); T.tx = Xe[0]; T.ty = Xe[1];
   return T;
+}
+LSM2D_DEV Iso slice_iso(const SliceDev& S, const float pose[3]) {      // X_eff = S^-1 X (AlignerSliceProcessorLaser2DWithSensor) as rotation + translation
+  return slice_iso_of(S.has_sensor, S.cSinv, S.sSinv, S.Sinv, pose);
 }
 // prologue of the single-alignment kernels: unpack the slices' freshly uploaded fixed sets (see SliceDev::unpack_src)
 LSM2D_DEV void unpack_fixed_set(const SliceDev& S, int tid, int nthreads) {
@@ -474,7 +477,11 @@ LSM2D_DEV void unpack_fixed_set(const SliceDev& S, int tid, int nthreads) {
 #endif
 // SE2 odometry prior (AlignerSliceOdom2DPrior, MULTI.json:402-422): e = t2v(Z^-1 X), J = blkdiag(R_e, 1) for the right perturbation;
 // adds J^T Omega J to H and J^T Omega e to b.  One definition for k_align and the split path: the same operation order in both.
-LSM2D_DEV void add_prior_inline(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) {
+// prior_terms: the nine and three values that go into H and b -- they do not depend on H or b, so whoever has the pose can have them ready
+// (the latency kernel's thread 0 computes them while it would otherwise wait at the barrier for the slowest wave)
+// (kAdd: the terms are added to H and b as they come -- the form k_align's out-of-line call takes: twelve registers fewer)
+template <bool kAdd>
+LSM2D_DEV void prior_apply(const PriorDev& Pz, const float pose[3], float Hp[9], float bp[3]) {
   float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, pose, E);
   float c, s_; sincos_fixed(E[2], s_, c);
   const float Jp[9] = {c, -s_, 0.0f, s_, c, 0.0f, 0.0f, 0.0f, 1.0f};
@@ -498,14 +505,16 @@ LSM2D_DEV void add_prior_inline(const PriorDev& Pz, const float pose[3], float H
       float v = 0.0f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * OJ[3 * k + cc];
-      H[3 * r + cc] += v;
+      if (kAdd) Hp[3 * r + cc] += v; else Hp[3 * r + cc] = v;
     }
     float v = 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) v += Jp[3 * k + r] * Oe[k];
-    b[r] += v;
+    if (kAdd) bp[r] += v; else bp[r] = v;
   }
 }
+LSM2D_DEV void prior_terms(const PriorDev& Pz, const float pose[3], float Hp[9], float bp[3]) { prior_apply<false>(Pz, pose, Hp, bp); }
+LSM2D_DEV void add_prior_inline(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) { prior_apply<true>(Pz, pose, H, b); }
 // k_align (64 VGPRs) and the split path call it: rarely taken, and out of the register allocation of their loops
 __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) { add_prior_inline(Pz, pose, H, b); }
 
@@ -923,6 +932,11 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
     LSM2D_PC(6);                 // thread 0's wave: bin walk
     block_reduce_store(acc, red, tid);
     LSM2D_PC(7);                 // its wave sums
+    // the odometry prior's terms depend on the pose alone: thread 0 computes them HERE, where its wave would otherwise wait ~0.5 us
+    // for the slowest of the sixteen (phase clocks: "wait"), instead of on the serial stretch behind the barrier
+    float Hp[9], bp[3];
+    if (gtid == 0 && A.prior) prior_terms(s_prior, pose, Hp, bp);
+    LSM2D_PC(9);                 // prior
     __syncthreads();
     LSM2D_PC(2);                 // waiting for the other waves
     if (gtid < 64) {
@@ -950,8 +964,12 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
         LSM2D_PC(8);               // sums of the slices, statistics
         if (!active) { status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
         else {
-          if (A.prior) add_prior_inline(s_prior, pose, Hs, bs);      // inlined: no round trip through scratch on the serial path
-          LSM2D_PC(9);             // prior
+          if (A.prior) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Hs[k] += Hp[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bs[k] += bp[k];
+          }
 #pragma unroll
           for (int k = 0; k < 9; ++k) Hlast[k] = Hs[k];
           float X[3] = {pose[0], pose[1], pose[2]};
@@ -959,7 +977,19 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
           else { pose[0] = X[0]; pose[1] = X[1]; pose[2] = X[2]; }
           LSM2D_PC(10);            // 3x3 solve and pose update
         }
-        if (!s_done) begin_iteration();
+        LSM2D_PC(4);               // (debug builds: the part of the transforms' time that is lane 0's alone is nil now)
+      }
+      // the next iteration's transforms: one slice per lane (lanes 0 and 1 of this wave), from the pose lane 0 has just written
+      {
+        float P3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P3[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pose[k]), 0));
+        if (!s_done && gtid < A.n_slices) {
+          const SliceDev& S0 = A.s[0]; const SliceDev& S1 = A.s[A.n_slices - 1];
+          const bool second = gtid == 1;
+          const float Sinv[3] = {second ? S1.Sinv[0] : S0.Sinv[0], second ? S1.Sinv[1] : S0.Sinv[1], second ? S1.Sinv[2] : S0.Sinv[2]};
+          s_iso[gtid] = slice_iso_of(second ? S1.has_sensor : S0.has_sensor, second ? S1.cSinv : S0.cSinv, second ? S1.sSinv : S0.sSinv, Sinv, P3);
+        }
       }
     }
     LSM2D_PC(4);
