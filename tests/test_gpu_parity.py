@@ -1244,6 +1244,62 @@ def test_no_device_memory_is_left_behind(small_workload):
     assert free0 - free1 < 64 << 20, (free0, free1)
 
 
+def test_non_finite_and_far_away_points_are_inert(ctx, po, small_workload):
+    """NaN, +-Inf and absurdly distant points (a corrupted message, an uninitialised buffer) must never become an index: appended to the
+    END of a cloud -- so the good points keep their indices -- they change nothing.  Projective paths (finder, aligner, clipper, merger)
+    take all of them; the point-query finders take NaN and far-away points (an infinite bounding box is refused with an error, not a fault);
+    the preprocessor takes NaN / Inf / negative ranges."""
+    wl = small_workload
+    scan = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    nan, inf = np.float32("nan"), np.float32("inf")
+    bad_all = np.float32([[nan, 1, 0, 1], [1, nan, 1, 0], [inf, 2, 0, 1], [-inf, inf, 1, 0], [3, -inf, 0, 1], [1e30, -1e30, 1, 0], [nan, nan, nan, nan]])
+    bad_fin = np.float32([[nan, 1, 0, 1], [1, nan, 1, 0], [2.5e5, -3e5, 1, 0], [nan, nan, nan, nan]])
+    x0 = wl.x0[1]
+    for finder, bad in ((api.CorrespondenceFinderProjective2f(ctx, _projector()), bad_all),
+                        (api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3), bad_fin),
+                        (api.CorrespondenceFinderNN2D(ctx, max_distance_m=0.5, resolution=0.05), bad_fin)):
+        for role in ("A", "B"):
+            if role == "B" and isinstance(finder, api.CorrespondenceFinderProjective2f):
+                continue
+            fixed, moving, pose = (scan, wl.map_points, x0) if role == "A" else (wl.map_points, scan, synth.invert_poses(x0[None, :].astype(np.float64))[0].astype(np.float32))
+            if isinstance(finder, api.CorrespondenceFinderNN2D):
+                bad = bad_fin[[0, 1, 3]]                     # (a 500 km bounding box at 5 cm per pixel is refused: covered below)
+            finder.setFixed(fixed); finder.setMoving(moving); finder.setLocalMapInSensor(pose)
+            clean = finder.compute()
+            finder.setFixed(np.concatenate([fixed, bad])); finder.setMoving(np.concatenate([moving, bad])); finder.setLocalMapInSensor(pose)
+            dirty = finder.compute()
+            assert len(clean) > 100 and np.array_equal(clean, dirty), (type(finder).__name__, role)
+            al = api.MultiAligner2D(ctx, max_iterations=6, min_num_inliers=10)
+            al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10))
+            a = al.compute_batch([fixed], [moving], pose[None, :]); b = al.compute_batch([np.concatenate([fixed, bad])], [np.concatenate([moving, bad])], pose[None, :])
+            assert a.status[0] == 0 and np.array_equal(a.pose, b.pose) and np.array_equal(a.information, b.information), (type(finder).__name__, role)
+    f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=0.5, resolution=0.05)
+    f.setFixed(np.concatenate([scan, bad_all])); f.setMoving(wl.map_points); f.setLocalMapInSensor(x0)
+    with pytest.raises(api.Lsm2dError):
+        f.compute()                                          # infinite bounding box: an error, and the context stays usable
+    # clipper / merger
+    robot = synth.invert_poses(wl.x_true[1:2])[0].astype(np.float32)
+    clip = api.SceneClipperProjective2D(ctx, _projector())
+    clip.setFullScene(wl.map_points); clip.setRobotInLocalMap(robot); c0 = clip.compute().download()
+    clip.setFullScene(np.concatenate([wl.map_points, bad_all])); c1 = clip.compute().download()
+    assert len(c0) > 300 and np.array_equal(c0, c1)
+    scene = api.CloudSet.reserved(ctx, 40000); scene.upload(np.concatenate([wl.map_points, bad_all]))
+    mg = api.MergerProjective2D(ctx, _projector(), 0.2); mg.setScene(scene); mg.setMeasurement(np.concatenate([scan, bad_all])); mg.setMeasurementInScene(robot)
+    mg.compute()
+    want, _ = po.merge_scene(po.Projector(1081, -math.pi, math.pi, 0.3, 30.0, 0.0), wl.map_points, scan, robot, 0.2)
+    got = scene.download()
+    keep = np.ones(len(got), bool); keep[len(wl.map_points):len(wl.map_points) + len(bad_all)] = False       # the bad scene points stay where they were, untouched
+    assert np.array_equal(got[keep], want) and np.array_equal(got[~keep], bad_all, equal_nan=True)
+    # preprocessor
+    world = synth.make_world(2); a0, a1 = -2.34747, 2.35619
+    r = synth.make_scan_ranges(world, synth.sample_poses(world, 2, seed=4), n_beams=721, angle_min=a0, angle_max=a1, noise_sigma=0.005, seed=1)
+    r[0, 10:20] = nan; r[0, 100] = inf; r[0, 200:205] = -1.0; r[1, :] = nan
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+    pre.setRawData(r, a0, a1, 0.0, 30.0); cs = pre.compute()
+    pp = po.Preprocessor(721, a0, a1, 0.3, 20.0, 0.3, 5, 0.02)
+    assert np.array_equal(cs.download(0), po.preprocess_scan(pp, r[0])) and cs.counts[1] == 0 and np.isfinite(cs.download(0)).all()
+
+
 def test_sets_may_outlive_their_context(ctx, small_workload):
     """lsm2d_destroy orphans the sets still alive on it: destroying them afterwards is fine, using them is an error, and nothing
     of it disturbs another context."""
