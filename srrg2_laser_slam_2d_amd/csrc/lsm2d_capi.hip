@@ -42,6 +42,7 @@ struct lsm2d_context {
   bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1, 2 or 3)
+  int find_path = 0;           // 0 auto (point-query finder calls with more queries than one trip of a workgroup: many workgroups), 1 one workgroup always
   int grid_big_threshold = 16384;   // clouds of at least this many points get their search grid built by the chip-wide kernels (k_grid_big_*)
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
@@ -227,6 +228,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "clock_stride")) { if (value < 0 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "clock_stride: out of range"); ctx->clock_stride = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kernel_timing")) { ctx->kernel_timing = value != 0; if (!ctx->kernel_timing) ctx->have_timing = false; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { if (value < 0 || value > 3) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1, 2 or 3"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "find_path")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_path must be 0 or 1"); ctx->find_path = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { if (value < 1 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_threshold: out of range"); ctx->grid_big_threshold = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
@@ -238,6 +240,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "align_path")) { *out_value = ctx->align_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { *out_value = ctx->distmap_build; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { *out_value = ctx->grid_big_threshold; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "find_path")) { *out_value = ctx->find_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_align_path")) { *out_value = ctx->last_align_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kernel_clock_khz")) { *out_value = ctx->last_clock_khz; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_workgroup_lifetime_ns")) { *out_value = ctx->last_wg_lifetime_ns; return LSM2D_SUCCESS; }
@@ -1182,16 +1185,27 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
     int rc = N.use_distmap ? ensure_distmap(ctx, fixed, sp->max_distance, sp->resolution, &N.fixed.dist) : ensure_grid(ctx, fixed, sp->max_distance, &N.fixed.grid);
     if (rc) return rc;
     const size_t nm = (size_t) moving->h_count[mi], bytes = nm * 8 + 16;
-    rc = ensure_scratch(ctx, bytes); if (rc) return rc;
-    rc = ensure_stage(ctx, bytes); if (rc) return rc;
     N.max_distance = sp->max_distance; N.normal_cos = sp->normal_cos; N.T = make_iso(pose);
     N.nn_group = fixed->h_count[fi] >= 4 * (int64_t) moving->h_count[mi] ? kNNGroup : 1;     // dense fixed cloud: cooperative search
+    // more queries than one workgroup takes in a trip: one workgroup per trip's worth, two launches (search, then ordered compaction)
+    const int per_step = kFindBlock / (N.use_distmap ? 1 : N.nn_group);
+    const int n_blocks = (int) ((nm + (size_t) per_step - 1) / (size_t) per_step);
+    const bool multi = n_blocks > 2 && ctx->find_path != 1;      // (two trips of one workgroup beat two launches: 23 vs 29 us for 1081 distance-map queries)
+    const size_t o_match = (bytes + 255) & ~(size_t) 255, o_cnt = o_match + ((nm * 4 + 255) & ~(size_t) 255);
+    rc = ensure_scratch(ctx, multi ? o_cnt + 4 * (size_t) n_blocks : bytes); if (rc) return rc;
+    rc = ensure_stage(ctx, bytes); if (rc) return rc;
     const bool direct = bytes <= (1u << 16);             // up to 8k pairs: written straight to pinned host memory
     char* dv = (char*) ctx->d_scratch;
     if (direct) { rc = stage_device_view(ctx, &dv); if (rc) return rc; }
     N.out_count = (int32_t*) dv; N.out_pairs = (int32_t*) (dv + 16);
+    N.match = (int32_t*) ((char*) ctx->d_scratch + o_match); N.block_count = (int32_t*) ((char*) ctx->d_scratch + o_cnt);
     if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_find_nn, dim3(1), dim3(kFindBlock), 0, ctx->stream, N);
+    if (multi) {
+      hipLaunchKernelGGL(k_find_nn_multi<0>, dim3((unsigned) n_blocks), dim3(kFindBlock), 0, ctx->stream, N);
+      hipLaunchKernelGGL(k_find_nn_multi<1>, dim3((unsigned) n_blocks), dim3(kFindBlock), 0, ctx->stream, N);
+    } else {
+      hipLaunchKernelGGL(k_find_nn, dim3(1), dim3(kFindBlock), 0, ctx->stream, N);
+    }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->have_timing = ctx->kernel_timing;

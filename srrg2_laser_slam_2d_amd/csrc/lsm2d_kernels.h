@@ -1194,6 +1194,7 @@ struct FindNNArgs {
   CloudDev fixed, moving; int32_t fc, mc; int32_t use_distmap;
   float max_distance, normal_cos; Iso T; int32_t nn_group;
   int32_t* out_pairs; int32_t* out_count;
+  int32_t* match; int32_t* block_count;      // k_find_nn_multi: per query the matched fixed index or -1; pairs per workgroup
 };
 
 __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
@@ -1243,6 +1244,64 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
     __syncthreads();
   }
   if (tid == 0) *A.out_count = s_base;
+}
+
+// The same finder over many workgroups (more queries than one workgroup takes in one trip: a map-sized moving cloud against a scan's
+// structure is 98 trips of one workgroup otherwise).  Workgroup b owns the queries [b * per_step, (b + 1) * per_step), ascending.
+// Phase 0: search, normal gate, match[j] = fixed index or -1, pairs per workgroup.  Phase 1 (a second launch of the same shape): every
+// workgroup adds up the counts in front of it, ranks its own pairs by ballot and writes them -- ascending moving index, as the
+// reference emits them (correspondence_finder_kd_tree_2d.cpp:12-27, correspondence_finder_nn_2d.cpp:63-80).
+template <int kPhase>
+__global__ __launch_bounds__(kFindBlock) void k_find_nn_multi(const FindNNArgs A) {
+  __shared__ int s_wave_tot[kFindBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = A.moving.count[A.mc];
+  const int group = A.use_distmap ? 1 : A.nn_group, sub = tid & (group - 1);
+  const int per_step = kFindBlock / group;
+  const int j = blockIdx.x * per_step + tid / group;
+  if (kPhase == 0) {
+    const int fbase = A.fixed.start[A.fc], mbase = A.moving.start[A.mc];
+    int best = -1; bool ok = false;
+    if (j < n) {
+      const float2 pm = A.moving.xy[mbase + j];
+      float qx, qy; xf_point(A.T, pm.x, pm.y, qx, qy);
+      if (A.use_distmap) best = distmap_lookup(A.fixed.dist.meta[A.fc], A.fixed.dist.parent, qx, qy);
+      else {
+        const GridMeta g = A.fixed.grid.meta[A.fc];
+        const int32_t* cst = A.fixed.grid.cell_start + g.cell_base; const int32_t* sidx = A.fixed.grid.sorted_idx + fbase; const float2* sxy = A.fixed.grid.sorted_xy + fbase;
+        const float md2 = A.max_distance * A.max_distance;
+        best = group == kNNGroup ? nn_query<kNNGroup>(g, cst, sidx, sxy, qx, qy, A.max_distance, md2, sub) : nn_query<1>(g, cst, sidx, sxy, qx, qy, A.max_distance, md2, sub);
+      }
+      if (best >= 0 && sub == 0) {
+        const float2 nm = A.moving.nrm[mbase + j], nf = A.fixed.nrm[fbase + best];
+        float nqx, nqy; xf_normal(A.T, nm.x, nm.y, nqx, nqy);
+        ok = !(__builtin_fmaf(nqx, nf.x, nqy * nf.y) < A.normal_cos);
+      }
+      if (sub == 0) A.match[j] = ok ? best : -1;
+    }
+    const u64 bal = __ballot(ok);
+    if (lane == 0) s_wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < kFindBlock / 64; ++w) t += s_wave_tot[w]; A.block_count[blockIdx.x] = t; }
+  } else {
+    __shared__ int s_before;
+    if (tid == 0) s_before = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int b = tid; b < (int) blockIdx.x; b += kFindBlock) mine += A.block_count[b];
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0 && mine) atomicAdd(&s_before, mine);
+    const int best = (j < n && sub == 0) ? A.match[j] : -1;
+    const bool ok = best >= 0;
+    const u64 bal = __ballot(ok);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int before = s_before, total = 0;
+    for (int w = 0; w < kFindBlock / 64; ++w) { const int t = s_wave_tot[w]; if (w < wave) before += t; total += t; }
+    if (ok) { A.out_pairs[2 * (before + prefix)] = best; A.out_pairs[2 * (before + prefix) + 1] = j; }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *A.out_count = s_before + total;
+  }
 }
 
 // ---- projector-level: canvas of one cloud --------------------------------------------------------

@@ -1084,6 +1084,29 @@ def test_nn_grid_build_one_workgroup_and_chip_wide_agree(ctx, po, small_workload
         assert np.array_equal(pose, results[0][0]) and np.array_equal(info, results[0][1])
 
 
+def test_point_query_finder_one_workgroup_and_many_agree(ctx, po, small_workload):
+    """lsm2d_find_correspondences with the NN and the distance-map finder runs on many workgroups when there are more queries than one
+    workgroup takes in a trip (option "find_path" = 1 keeps it on one): same pairs, same (ascending moving index) order, and the oracle's --
+    both roles, ragged sizes around the trip boundaries (256 queries with four lanes each, 1024 with one), no pair at all."""
+    wl = small_workload
+    scan = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    inv = synth.invert_poses(wl.x0[1:2].astype(np.float64))[0].astype(np.float32)
+    far = wl.map_points.copy(); far[:, :2] += np.float32([500, 500])
+    cases = [(scan, wl.map_points, wl.x0[1]), (wl.map_points, scan, inv), (wl.map_points, scan[:257], inv), (wl.map_points, scan[:256], inv),
+             (wl.map_points, scan[:513], inv), (scan, wl.map_points[:2049], wl.x0[1]), (scan, wl.map_points[:3072], wl.x0[1]), (scan, far, wl.x0[1])]
+    try:
+        for make, osp in ((lambda: api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.4), po.slice_params(finder=po.FINDER_NN, max_distance=0.4)),
+                          (lambda: api.CorrespondenceFinderNN2D(ctx, max_distance_m=0.5, resolution=0.05), po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.05))):
+            for fixed, moving, pose in cases:
+                want = po.find(osp, fixed, moving, pose)
+                for mode in (0, 1):
+                    ctx.set_option("find_path", mode)
+                    f = make(); f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
+                    assert np.array_equal(f.compute(), want), (osp.finder, len(fixed), len(moving), mode)
+    finally:
+        ctx.set_option("find_path", 0)
+
+
 def test_distmap_scatter_build_equals_gather_build_and_oracle(ctx, po, small_workload):
     """The distance maps are built from the points' side (k_distmap_stamp: one disc of atomic minima per point) unless the packed
     (d2, index) key does not fit; option "distmap_build" = 1 forces the per-pixel gather (k_distmap_fill).  Same pairs from both and from
