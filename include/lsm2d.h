@@ -135,7 +135,8 @@ int  lsm2d_synchronize(lsm2d_context* ctx);
  * "grid_big_threshold" (default 16384): fixed clouds of at least this many points get the NN finder's search grid built by chip-wide
  * kernels (histogram / scan / scatter over many workgroups) instead of one workgroup per cloud; results do not depend on it.
  * "find_path": 0 = automatic (default: a point-query lsm2d_find_correspondences call with more queries than one workgroup takes in a trip
- * runs on many workgroups, two launches), 1 = always one workgroup; same pairs, same order. */
+ * runs on many workgroups, two launches; the projective finder z-buffers a cloud of more than 32768 points over many workgroups first),
+ * 1 = always one workgroup; same pairs, same order. */
 int  lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value);
 /* reads a knob back; also "last_align_path": what the most recent lsm2d_align_batch ran (1 k_align, 2 split, 3 slice pair) */
 int  lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* out_value);

@@ -1224,13 +1224,27 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
   if ((int) lds > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "find_correspondences: canvases do not fit LDS");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = cols * 8 + 16;
-  int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
+  // a map-sized cloud is z-buffered over many workgroups first (the clipper's large-scene kernel; u64 minima do not depend on the order)
+  const bool big_f = fixed->h_count[fi] > 32768 && ctx->find_path != 1, big_m = moving->h_count[mi] > 32768 && ctx->find_path != 1;
+  const size_t o_can = (bytes + 255) & ~(size_t) 255;
+  int rc = ensure_scratch(ctx, o_can + 2 * cols * sizeof(u64)); if (rc) return rc;
   rc = ensure_stage(ctx, bytes); if (rc) return rc;
   A.fixed = cloud_dev(fixed, nullptr); A.moving = cloud_dev(moving, nullptr); A.fc = fi; A.mc = mi;
   A.point_distance = sp->point_distance; A.normal_cos = sp->normal_cos; A.T = make_iso(pose);
   char* dv = nullptr; rc = stage_device_view(ctx, &dv); if (rc) return rc;       // <= one pair per column: written straight to pinned host memory
   A.out_count = (int32_t*) dv; A.out_pairs = (int32_t*) (dv + 16);
+  A.fcan_global = nullptr; A.mcan_global = nullptr;
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (big_f) {
+    u64* g = (u64*) ((char*) ctx->d_scratch + o_can); const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
+    rc = project_split(ctx, fixed->d_xy + fixed->h_start[fi], fixed->h_count[fi], ident, A.proj, g); if (rc) return rc;
+    A.fcan_global = g;
+  }
+  if (big_m) {
+    u64* g = (u64*) ((char*) ctx->d_scratch + o_can) + cols;
+    rc = project_split(ctx, moving->d_xy + moving->h_start[mi], moving->h_count[mi], A.T, A.proj, g); if (rc) return rc;
+    A.mcan_global = g;
+  }
   hipLaunchKernelGGL(k_find_projective, dim3(1), dim3(kFindBlock), lds, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));

@@ -1151,6 +1151,7 @@ struct FindArgs {
   Iso T;
   int32_t* out_pairs;  // [cols][2]
   int32_t* out_count;
+  const u64* fcan_global; const u64* mcan_global;      // a map-sized cloud's canvas, projected over many workgroups beforehand (k_project_split), or nullptr
 };
 
 __global__ __launch_bounds__(kFindBlock) void k_find_projective(const FindArgs A) {
@@ -1165,8 +1166,10 @@ __global__ __launch_bounds__(kFindBlock) void k_find_projective(const FindArgs A
   __syncthreads();
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   const int fbase = A.fixed.start[A.fc], mbase = A.moving.start[A.mc];
-  project_cloud(A.fixed.xy + fbase, A.fixed.count[A.fc], ident, A.proj, fcan, tid, kFindBlock);
-  project_cloud(A.moving.xy + mbase, A.moving.count[A.mc], A.T, A.proj, mcan, tid, kFindBlock);
+  if (A.fcan_global) { for (int i = tid; i < A.proj.cols; i += kFindBlock) fcan[i] = A.fcan_global[i]; }
+  else project_cloud(A.fixed.xy + fbase, A.fixed.count[A.fc], ident, A.proj, fcan, tid, kFindBlock);
+  if (A.mcan_global) { for (int i = tid; i < A.proj.cols; i += kFindBlock) mcan[i] = A.mcan_global[i]; }
+  else project_cloud(A.moving.xy + mbase, A.moving.count[A.mc], A.T, A.proj, mcan, tid, kFindBlock);
   __syncthreads();
   SliceDev S; S.point_distance = A.point_distance; S.normal_cos = A.normal_cos;
   const int lane = tid & 63, wave = tid >> 6;

@@ -1103,6 +1103,15 @@ def test_point_query_finder_one_workgroup_and_many_agree(ctx, po, small_workload
                     ctx.set_option("find_path", mode)
                     f = make(); f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
                     assert np.array_equal(f.compute(), want), (osp.finder, len(fixed), len(moving), mode)
+        # the projective finder z-buffers a map-sized cloud over many workgroups first (either side)
+        big = synth.make_map(synth.make_world(3), 60000, noise_sigma=0.004, seed=5)
+        osp = po.slice_params(canvas_cols=1081, range_max=30.0)
+        for fixed, moving, pose in ((scan, np.concatenate([wl.map_points, big]), wl.x0[1]), (np.concatenate([wl.map_points, big]), scan, inv)):
+            want = po.find(osp, fixed, moving, pose)
+            for mode in (0, 1):
+                ctx.set_option("find_path", mode)
+                f = api.CorrespondenceFinderProjective2f(ctx, _projector()); f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
+                assert len(want) > 50 and np.array_equal(f.compute(), want), (len(fixed), len(moving), mode)
     finally:
         ctx.set_option("find_path", 0)
 
