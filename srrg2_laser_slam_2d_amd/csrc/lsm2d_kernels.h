@@ -249,6 +249,8 @@ struct GridBuildArgs {
                                 // kernels below (k_grid_big_*) do the rest -- one workgroup scanning 3.6 M cells took 5 ms for a 100k-point map
 };
 
+LSM2D_DEV float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }      // a value every lane holds alike, moved to an SGPR
+
 LSM2D_DEV int grid_cell_of(const GridMeta& g, float2 p) {
   int cx = (int) floorf((p.x - g.minx) * g.inv_h), cy = (int) floorf((p.y - g.miny) * g.inv_h);
   cx = cx < 0 ? 0 : (cx > g.gw - 1 ? g.gw - 1 : cx); cy = cy < 0 ? 0 : (cy > g.gh - 1 ? g.gh - 1 : cy);
@@ -677,7 +679,12 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         GridMeta g; DistMeta dm;
         const int32_t* cst = nullptr; const int32_t* sidx = nullptr; const float2* sxy = nullptr;
         if (use_grid) {
-          g = S.fixed.grid.meta[fc]; cst = S.fixed.grid.cell_start + g.cell_base;
+          g = S.fixed.grid.meta[fc];
+          // the meta comes through a vector load: tell the compiler it is wave-uniform -- seven VGPRs fewer across the query loops, which
+          // takes the last spills out of them (NN role B 2.27 -> 2.06 ms, role A 7.91 -> 7.82; variants_r02v_nn_scalar_meta.log)
+          g.minx = uniform_f(g.minx); g.miny = uniform_f(g.miny); g.h = uniform_f(g.h); g.inv_h = uniform_f(g.inv_h);
+          g.gw = __builtin_amdgcn_readfirstlane(g.gw); g.gh = __builtin_amdgcn_readfirstlane(g.gh); g.cell_base = __builtin_amdgcn_readfirstlane(g.cell_base);
+          cst = S.fixed.grid.cell_start + g.cell_base;
           sidx = S.fixed.grid.sorted_idx + fbase; sxy = S.fixed.grid.sorted_xy + fbase;
         } else {
           dm = S.fixed.dist.meta[fc];       // distance-map finder: one lookup per query (correspondence_finder_nn_2d.cpp:63-80)
