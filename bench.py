@@ -304,6 +304,11 @@ def main() -> None:
             if roof["traffic"]:
                 roof["hbm"]["hbm_real_GBs"] = roof["traffic"] / (k_ms * 1e-3) / 1e9
                 roof["hbm"]["hbm_real_frac"] = roof["hbm"]["hbm_real_GBs"] / HBM_PEAK_GBS
+                if roof["hbm"]["hbm_real_frac"] > roof["frac"]:
+                    # a mode whose counter-measured DRAM traffic is the larger fraction (a distance map per scan: 3 GB of maps gathered at random)
+                    roof["valu_issue"] = {"achieved": roof["achieved"], "peak": roof["peak"], "frac": roof["frac"], "unit": roof["unit"]}
+                    roof.update(bound="hbm", achieved=roof["hbm"]["hbm_real_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roof["hbm"]["hbm_real_frac"],
+                                note="counter-measured DRAM traffic (2 x FETCH_SIZE + WRITE_SIZE) / launch time against the HBM peak; valu_issue keeps the other yardstick")
             roof["counters_source"] = counters.get("source")
             if counters.get("stream_cycles_per_wave_point") and counters.get("wave_points_per_launch"):
                 # the second, sharper yardstick: what the 1024 SIMDs need for THIS instruction stream when nothing else is in the way

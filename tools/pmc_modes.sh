@@ -1,0 +1,19 @@
+#!/bin/bash
+# Counters for the OTHER bench.py modes (finders / roles / map sizes): three rocprofv3 --pmc passes each (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU),
+# merged into profiles/counters.json under the mode's own key, so that every line of tools/bench_modes.sh carries a measured roofline.
+# usage on the GPU box, AFTER tools/profile_round.sh <tag> (which writes the headline's entry): bash tools/pmc_modes.sh <tag>
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; tag=${1:-round}; O=$R/gpurun_out/$tag; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+mode() {      # name, write_counters flags, bench flags
+  name=$1; wc=$2; shift 2
+  for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+    timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$name/$c -- python3 $R/bench.py --steps 3 --warmup 1 --spinup-s 0.05 --no-cpu-baseline "$@" > $O/pmc_$name.$c.log 2>&1 || { echo "$name $c failed"; return 1; }
+  done
+  (cd $R && python tools/write_counters.py $O/pmc_$name $wc --tag $tag | cut -c1-200)
+}
+mode nnB   "--role B --finder nn"       --role B --finder nn \
+&& mode nnA   "--role A --finder nn"       --role A --finder nn --max-distance 0.3 \
+&& mode distA "--role A --finder distmap"  --role A --finder distmap --max-distance 0.5 \
+&& mode distB "--role B --finder distmap"  --role B --finder distmap --max-distance 0.5 \
+&& mode map1M "--map-points 1000000"       --map-points 1000000
+cp $R/profiles/counters.json $O/counters.json
