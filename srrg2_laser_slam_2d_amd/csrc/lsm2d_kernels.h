@@ -1077,17 +1077,19 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
   const AlignArgs& A = S.A;
   __shared__ float red[(kAlignBlock / 64) * kAccumWords];
   __shared__ Iso s_iso[kMaxSlices];
-  __shared__ float s_H[9], s_b[3], s_chi_in, s_chi_out;
-  __shared__ int s_n_in, s_n_out, s_n_corr, s_active;
+  // as in k_align: the iteration's sums are added in LDS by the lanes that gathered them, the matrix is assembled, given its prior and
+  // solved where it lies (no private arrays, no scratch on the serial stretch)
+  __shared__ float s_H[9], s_rhs[3], s_sum[kAccumWords + 2], s_pose[3];
+  __shared__ int s_n_corr, s_active;
   const int a = blockIdx.x, tid = threadIdx.x;
   constexpr int nwaves = kAlignBlock / 64;
   if (S.done[a]) return;
-  float pose[3] = {S.pose[3 * a], S.pose[3 * a + 1], S.pose[3 * a + 2]};
   if (tid == 0) {
-    for (int s = 0; s < A.n_slices; ++s) s_iso[s] = slice_iso(A.s[s], pose);
-    for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
-    s_b[0] = s_b[1] = s_b[2] = 0.0f;
-    s_n_in = s_n_out = s_n_corr = s_active = 0; s_chi_in = s_chi_out = 0.0f;
+    s_pose[0] = S.pose[3 * a]; s_pose[1] = S.pose[3 * a + 1]; s_pose[2] = S.pose[3 * a + 2];
+    for (int s = 0; s < A.n_slices; ++s) s_iso[s] = slice_iso(A.s[s], s_pose);
+    for (int k = 0; k < 11; ++k) s_sum[k] = 0.0f;
+    s_sum[11] = s_sum[12] = __int_as_float(0);
+    s_n_corr = s_active = 0;
   }
   __syncthreads();
   u64* gF = S.gcan + (size_t) a * 2 * A.fcan_total; u64* gM = gF + A.fcan_total;
@@ -1108,44 +1110,41 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
     }
     block_reduce_store(acc, red, tid);
     __syncthreads();
-    Accum t;
-    if (tid < 64) block_reduce_gather_wave0(red, nwaves, tid, t);
-    if (tid == 0) {
-      s_n_corr += t.n_corr;
-      if (t.n_corr > SL.min_corr) {
-        ++s_active;
-        s_H[0] += t.h00; s_H[1] += t.h01; s_H[2] += t.h02; s_H[3] += t.h01; s_H[4] += t.h11; s_H[5] += t.h12;
-        s_H[6] += t.h02; s_H[7] += t.h12; s_H[8] += t.h22;
-        s_b[0] += t.b0; s_b[1] += t.b1; s_b[2] += t.b2;
-        s_n_in += t.n_in; s_n_out += t.n_out; s_chi_in += t.chi_in; s_chi_out += t.chi_out;
+    if (tid < 64) {
+      float v; int vi; block_reduce_gather_lane(red, nwaves, tid, v, vi);
+      const int n_corr = __builtin_amdgcn_readlane(vi, 13);
+      if (tid == 0) s_n_corr += n_corr;
+      if (n_corr > SL.min_corr) {
+        if (tid < 11) s_sum[tid] += v;
+        else if (tid < 13) s_sum[tid] = __int_as_float(__float_as_int(s_sum[tid]) + vi);
+        if (tid == 0) ++s_active;
       }
     }
     __syncthreads();
   }
   if (tid == 0) {
-    StatsDev last; last.n_corr = s_n_corr; last.n_in = s_n_in; last.n_out = s_n_out; last.chi_in = s_chi_in; last.chi_out = s_chi_out;
+    StatsDev last; last.n_corr = s_n_corr; last.n_in = __float_as_int(s_sum[11]); last.n_out = __float_as_int(s_sum[12]); last.chi_in = s_sum[9]; last.chi_out = s_sum[10];
     if (A.out_stats) A.out_stats[(size_t) a * A.max_it + S.it] = last;
     int status = LSM2D_RUNNING;
-    float H[9];
-    for (int k = 0; k < 9; ++k) H[k] = S.it == 0 ? 0.0f : S.H_last[9 * a + k];
-    if (!s_active) status = LSM2D_NOT_ENOUGH_CORRESPONDENCES;
-    else {
-      float b[3] = {s_b[0], s_b[1], s_b[2]};
-#pragma unroll
-      for (int k = 0; k < 9; ++k) H[k] = s_H[k];
-      if (A.prior) add_prior(A.prior[a], pose, H, b);
-      if (!solve_update(H, b, A.damping, pose)) status = LSM2D_SINGULAR_H;
-      else { S.pose[3 * a] = pose[0]; S.pose[3 * a + 1] = pose[1]; S.pose[3 * a + 2] = pose[2]; }
+    if (!s_active) {
+      status = LSM2D_NOT_ENOUGH_CORRESPONDENCES;
+      for (int k = 0; k < 9; ++k) s_H[k] = S.it == 0 ? 0.0f : S.H_last[9 * a + k];      // the information matrix stays the last solved iteration's
+    } else {
+      s_H[0] = s_sum[0]; s_H[1] = s_sum[1]; s_H[2] = s_sum[2]; s_H[3] = s_sum[1]; s_H[4] = s_sum[3]; s_H[5] = s_sum[4];
+      s_H[6] = s_sum[2]; s_H[7] = s_sum[4]; s_H[8] = s_sum[5];
+      s_rhs[0] = s_sum[6]; s_rhs[1] = s_sum[7]; s_rhs[2] = s_sum[8];
+      if (A.prior) add_prior(A.prior[a], s_pose, s_H, s_rhs);
+      for (int k = 0; k < 9; ++k) S.H_last[9 * a + k] = s_H[k];
+      if (!solve_update(s_H, s_rhs, A.damping, s_pose)) status = LSM2D_SINGULAR_H;
+      else { S.pose[3 * a] = s_pose[0]; S.pose[3 * a + 1] = s_pose[1]; S.pose[3 * a + 2] = s_pose[2]; }
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) S.H_last[9 * a + k] = H[k];
     const bool last_it = S.it == A.max_it - 1;
     if (status == LSM2D_RUNNING && last_it) status = last.n_in < A.min_inliers ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
     if (status != LSM2D_RUNNING) {
       S.done[a] = 1;
       A.out_status[a] = status;
-      A.out_pose[3 * a] = pose[0]; A.out_pose[3 * a + 1] = pose[1]; A.out_pose[3 * a + 2] = pose[2];
-      if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = H[k];
+      A.out_pose[3 * a] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
+      if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = S.it == 0 && !s_active ? 0.0f : S.H_last[9 * a + k];
       if (A.out_its) A.out_its[a] = S.it + 1;
     }
   }
