@@ -33,7 +33,7 @@ extern "C" {
                              0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes;
                              0.2.0: + lsm2d_clip_scene_voxelized, lsm2d_sweep_* (multi-device loop-closure sweep), in-kernel clock options;
                              0.2.1: + lsm2d_cloudset_cloud_sizes, pinned / device-resident ranges in lsm2d_preprocess_scans, options
-                                    "distmap_build", "grid_big_threshold", "find_path" */
+                                    "distmap_build", "grid_big_threshold", "find_path", "zero_copy_max" */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -136,7 +136,9 @@ int  lsm2d_synchronize(lsm2d_context* ctx);
  * kernels (histogram / scan / scatter over many workgroups) instead of one workgroup per cloud; results do not depend on it.
  * "find_path": 0 = automatic (default: a point-query lsm2d_find_correspondences call with more queries than one workgroup takes in a trip
  * runs on many workgroups, two launches; the projective finder z-buffers a cloud of more than 32768 points over many workgroups first),
- * 1 = always one workgroup; same pairs, same order. */
+ * 1 = always one workgroup; same pairs, same order.
+ * "zero_copy_max" (default 256): batches of at most this many alignments without index arrays read their arguments from, and write their
+ * results to, pinned host memory directly (no transfers, status words polled); measured slower than the transfers at 1000 alignments. */
 int  lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value);
 /* reads a knob back; also "last_align_path": what the most recent lsm2d_align_batch ran (1 k_align, 2 split, 3 slice pair) */
 int  lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* out_value);

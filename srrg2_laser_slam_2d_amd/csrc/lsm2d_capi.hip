@@ -42,6 +42,7 @@ struct lsm2d_context {
   bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1, 2 or 3)
+  int zero_copy_max = 256;     // largest batch whose arguments and results travel through pinned host memory directly ("zero_copy_max" option, A/B knob)
   int find_path = 0;           // 0 auto (point-query finder calls with more queries than one trip of a workgroup: many workgroups), 1 one workgroup always
   int grid_big_threshold = 16384;   // clouds of at least this many points get their search grid built by the chip-wide kernels (k_grid_big_*)
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
@@ -228,6 +229,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "clock_stride")) { if (value < 0 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "clock_stride: out of range"); ctx->clock_stride = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kernel_timing")) { ctx->kernel_timing = value != 0; if (!ctx->kernel_timing) ctx->have_timing = false; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { if (value < 0 || value > 3) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1, 2 or 3"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "zero_copy_max")) { if (value < 0 || value > 65536) return fail(ctx, LSM2D_BAD_ARGUMENT, "zero_copy_max: out of range"); ctx->zero_copy_max = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "find_path")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_path must be 0 or 1"); ctx->find_path = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { if (value < 1 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_threshold: out of range"); ctx->grid_big_threshold = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
@@ -241,6 +243,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "distmap_build")) { *out_value = ctx->distmap_build; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { *out_value = ctx->grid_big_threshold; return LSM2D_SUCCESS; }
   if (!strcmp(key, "find_path")) { *out_value = ctx->find_path; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "zero_copy_max")) { *out_value = ctx->zero_copy_max; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_align_path")) { *out_value = ctx->last_align_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kernel_clock_khz")) { *out_value = ctx->last_clock_khz; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_workgroup_lifetime_ns")) { *out_value = ctx->last_wg_lifetime_ns; return LSM2D_SUCCESS; }
@@ -1357,7 +1360,9 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   // A handful of alignments in one launch (the live tracker: one): the kernel reads its few hundred bytes of arguments from, and
   // writes its results to, the PINNED staging buffer directly -- no host-to-device copy, no memset, no device-to-host copy, i.e.
   // three small transfers and their launch latencies off the critical path of the call.
-  const bool zero_copy = !use_split && n <= 256;
+  // (Not for big batches: with 1000 alignments reading their start poses and writing their results over the host link the step takes 1.485 ms
+  // against 1.467 with the three small transfers; tools/zero_copy_ab.py.)
+  const bool zero_copy = !use_split && (n <= 256 || (n <= ctx->zero_copy_max && !b->fixed_index && !b->moving_index));
   if (zero_copy) ds = (char*) ctx->h_stage_dev;
 
   // ---- slices
