@@ -54,7 +54,7 @@ namespace srrg2_laser_slam_2d {
     // kept so that a configuration written for CorrespondenceFinderKDTree2D loads unchanged; the device search is an exact
     // nearest-neighbour search on a uniform grid, for which they have no meaning (PARITY.md section 5 measures the difference)
     PARAM(srrg2_core::PropertyFloat, max_leaf_range, "unused by the device search (exact NN)", 1e-2, 0);
-    PARAM(srrg2_core::PropertyInt, min_leaf_points, "unused by the device search (exact NN)", 20, 0);
+    PARAM(srrg2_core::PropertyUnsignedInt, min_leaf_points, "unused by the device search (exact NN)", 20, 0);
     PARAM(srrg2_core::PropertyFloat, normal_cos, "min cosinus between normals", 0.8, 0);
     void fillSliceParams(lsm2d_slice_params* sp_) const override;
 

@@ -36,7 +36,7 @@ namespace srrg2_laser_slam_2d {
           "projector used to remap the points",
           srrg2_core::PointNormal2fProjectorPolarPtr(new srrg2_core::PointNormal2fProjectorPolar),
           nullptr);
-    PARAM(srrg2_core::PropertyFloat, voxelize_resolution, "unproject voxelization resolution", 0.0, nullptr);
+    PARAM(srrg2_core::PropertyFloat, voxelize_resolution, "resolution used to decimate the points in the scan on a grid [meters]", 0.1, nullptr);
     PARAM(srrg2_core::PropertyInt, device_id, "HIP device ordinal", 0, 0);
     virtual ~SceneClipperHIP2D() {
       lsm2d_cloudset_destroy(_clipped_set);

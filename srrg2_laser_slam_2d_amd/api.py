@@ -553,7 +553,7 @@ class SceneClipperProjective2D:
     use 0, MULTI.json:673-683).  The clipped scene stays on the device (a reserved CloudSet) and is what the tracker hands to the
     aligner as ``moving``."""
 
-    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, voxelize_resolution: float = 0.0,
+    def __init__(self, ctx: Context, projector: Optional[PointNormal2fProjectorPolar] = None, voxelize_resolution: float = 0.1,
                  asynchronous: bool = False):
         self._ctx = ctx
         self.param_projector = projector

@@ -197,7 +197,7 @@ class SceneClipperProjective2D {
     return n;
   }
   bool asynchronous = false;
-  float param_voxelize_resolution = 0.f;                                   // .h: "unproject voxelization resolution"; > 0: .cpp:36-48
+  float param_voxelize_resolution = 0.1f;                                  // the class default (.h:21-25); both shipped configurations set 0 (MULTI.json:673-683); > 0: .cpp:36-48
  private:
   Context& _ctx; const ReservedCloud* _scene = nullptr; ReservedCloud* _clipped = nullptr;
   Vector3f _robot_in_local_map{{0.f, 0.f, 0.f}}, _sensor_in_robot{{0.f, 0.f, 0.f}};

@@ -63,7 +63,7 @@ def main():
     opr = po.Projector(721, -math.pi, math.pi, 0.3, 20.0, 0.0)
     ctx = api.Context(0, kernel_timing=args.kernel_timing)
     local_map = api.CloudSet.reserved(ctx, 400000)
-    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=not args.sync_calls); clipper.setFullScene(local_map)
+    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=not args.sync_calls, voxelize_resolution=0.0); clipper.setFullScene(local_map)
     merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=not args.sync_calls); merger.setScene(local_map)
     al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
     al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(

@@ -133,7 +133,7 @@ def main():
     proj = api.PointNormal2fProjectorPolar(args.beams, -math.pi, math.pi, 0.3, 30.0)
     opr = po.Projector(args.beams, -math.pi, math.pi, 0.3, 30.0, 0.0)
     pose = synth.invert_poses(wl.x_true[5:6])[0].astype(np.float32)       # robot in local map
-    clipper = api.SceneClipperProjective2D(ctx, proj)
+    clipper = api.SceneClipperProjective2D(ctx, proj, voxelize_resolution=0.0)
     clipped = api.CloudSet.reserved(ctx, args.beams + 64)
     clipper.setFullScene(mp); clipper.setClippedSceneInRobot(clipped); clipper.setRobotInLocalMap(pose)
     wall, best = timed(lambda: clipper.compute(), args.reps * 5, sync)

@@ -140,6 +140,7 @@ int main(int argc, char** argv) {
   {
     PointNormal2fVectorCloud clipped;
     SceneClipperHIP2D clipper; clipper.param_projector.setValue(projector);
+    clipper.param_voxelize_resolution.setValue(0.f);      // as both shipped configurations set it (the class default is 0.1, as the reference's)
     clipper.setFullScene(&moving); clipper.setClippedSceneInRobot(&clipped);
     clipper.setRobotInLocalMap(geometry2d::v2t(x0).inverse()); clipper.setSensorInRobot(Isometry2f::Identity());
     clipper.compute();

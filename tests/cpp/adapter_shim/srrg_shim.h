@@ -92,6 +92,7 @@ namespace srrg2_core {
   };
   using PropertyFloat = Property_<float>;
   using PropertyInt = Property_<int>;
+  using PropertyUnsignedInt = Property_<unsigned int>;
   using PropertyString = Property_<std::string>;
   template <typename C>
   class PropertyConfigurable_ {
@@ -261,7 +262,7 @@ namespace srrg2_laser_slam_2d {
   public:
     PARAM(PropertyFloat, max_distance_m, "", 1e-2f, 0);
     PARAM(PropertyFloat, max_leaf_range, "", 1e-2f, 0);
-    PARAM(PropertyInt, min_leaf_points, "", 20, 0);
+    PARAM(PropertyUnsignedInt, min_leaf_points, "", 20, 0);
     PARAM(PropertyFloat, normal_cos, "", 0.8f, 0);
     void compute() override { throw std::logic_error("shim: the reference finder is not restated"); }
   };

@@ -58,6 +58,7 @@ int main(int argc, char** argv) {
     ReservedCloud scene(ctx, (int64_t) moving.size() + 4096), clipped(ctx, cols);
     scene.upload(moving);
     SceneClipperProjective2D clipper(ctx);
+    clipper.param_voxelize_resolution = 0.f;      // as both shipped configurations set it (the class default is 0.1)
     clipper.param_projector->param_canvas_cols = cols; clipper.param_projector->param_range_max = 30.f;
     clipper.param_projector->param_angle_col_min = -(float) M_PI; clipper.param_projector->param_angle_col_max = (float) M_PI;
     clipper.setFullScene(&scene); clipper.setClippedSceneInRobot(&clipped);

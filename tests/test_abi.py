@@ -80,3 +80,72 @@ def test_srrg_adapter_sources_compile_against_the_stand_in_headers(tmp_path):
             used |= set(re.findall(r"\b(lsm2d_[a-z_0-9]+)\s*\(", open(os.path.join(dp, f)).read()))
     declared = set(_declared_symbols())
     assert used and used <= declared, used - declared
+
+
+# ---- the adapters' and the compile shim's PARAMs against the reference's own headers ------------------------------------------
+def _params_of(text, class_name):
+    """(type, name, default) of every PARAM(...) inside `class class_name`; nesting-aware split, `srrg2_core::` stripped."""
+    import re
+    m = re.search(r"class\s+" + class_name + r"\b[^;{]*\{", text)
+    if not m:
+        return None
+    depth, i = 1, m.end()
+    while depth and i < len(text):
+        depth += {"{": 1, "}": -1}.get(text[i], 0); i += 1
+    body = text[m.end():i]
+    out = {}
+    for pm in re.finditer(r"\bPARAM\s*\(", body):
+        j, d, fields, cur, in_str = pm.end(), 1, [], "", False
+        while d and j < len(body):
+            ch = body[j]
+            if ch == '"' and body[j - 1] != "\\":
+                in_str = not in_str
+            if not in_str:
+                if ch in "(<":
+                    d += 1
+                elif ch in ")>":
+                    d -= 1
+                    if d == 0:
+                        break
+                elif ch == "," and d == 1:
+                    fields.append(cur.strip()); cur = ""; j += 1
+                    continue
+            cur += ch; j += 1
+        fields.append(cur.strip())
+        typ, name, default = fields[0].replace("srrg2_core::", "").replace(" ", ""), fields[1], fields[3]
+        try:
+            default = float(default.rstrip("fF")) if not default.endswith(")") else "expr"
+        except ValueError:
+            default = "expr"
+        out[name] = (typ, default)
+    return out
+
+
+def test_adapter_and_shim_params_match_the_reference_headers():
+    """Where the reference tree is present (this container, not the GPU box): every PARAM the reference declares for the classes the
+    adapters replace or recognise exists, with the same property type and default, in (a) the stand-in headers the adapters are
+    compile-checked against and (b) the adapters' own sibling classes -- a configuration written for the reference loads unchanged."""
+    ref = "/root/reference/srrg2_laser_slam_2d/src/srrg2_laser_slam_2d"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    rd = lambda *p: open(os.path.join(*p)).read()
+    shim = rd(ROOT, "tests", "cpp", "adapter_shim", "srrg_shim.h")
+    fh = rd(ROOT, "adapters", "srrg", "correspondence_finder_hip_2d.h"); mh = rd(ROOT, "adapters", "srrg", "mapping_hip_2d.h")
+    cases = [("registration/correspondence_finder_projective_2d.h", "CorrespondenceFinderProjective2f", shim, fh, "CorrespondenceFinderHIP2D"),
+             ("registration/correspondence_finder_kd_tree_2d.h", "CorrespondenceFinderKDTree2D", shim, fh, "CorrespondenceFinderKDTreeHIP2D"),
+             ("registration/correspondence_finder_nn_2d.h", "CorrespondenceFinderNN2D", shim, fh, "CorrespondenceFinderNNHIP2D"),
+             ("mapping/scene_clipper_projective_2d.h", "SceneClipperProjective2D", None, mh, "SceneClipperHIP2D"),
+             ("mapping/merger_projective_2d.h", "MergerProjective2D", None, mh, "MergerHIP2D")]
+    for header, cls, shim_text, adapter_text, adapter_cls in cases:
+        want = _params_of(rd(ref, header), cls)
+        assert want, (header, cls)
+        for where, text, name in (("shim", shim_text, cls), ("adapter", adapter_text, adapter_cls)):
+            if text is None:
+                continue
+            got = _params_of(text, name)
+            assert got is not None, (where, name)
+            for pname, (typ, default) in want.items():
+                assert pname in got, (where, name, "missing PARAM", pname)
+                assert got[pname][0] == typ, (where, name, pname, got[pname][0], typ)
+                if default != "expr":
+                    assert got[pname][1] == "expr" or abs(got[pname][1] - default) <= 1e-6 * max(1.0, abs(default)), (where, name, pname, got[pname][1], default)

@@ -659,7 +659,7 @@ def test_scene_clipper_bit_exact(ctx, po):
     robots = synth.sample_poses(world, 4, seed=5)
     proj = api.PointNormal2fProjectorPolar(721, -math.pi, math.pi, 0.3, 20.0)
     scene = api.CloudSet(ctx, m)
-    clipper = api.SceneClipperProjective2D(ctx, proj)
+    clipper = api.SceneClipperProjective2D(ctx, proj, voxelize_resolution=0.0)
     clipper.setFullScene(scene)
     for robot, S in zip(robots, ([0, 0, 0], [0.2, 0.1, 0.1], [-0.3, 0.0, math.pi], [0, 0, 0])):
         clipper.setRobotInLocalMap(robot); clipper.setSensorInRobot(S)
@@ -670,7 +670,7 @@ def test_scene_clipper_bit_exact(ctx, po):
         assert np.array_equal(clipper.source_indices, wsrc)
         assert np.array_equal(clipped.download(), want)
     with pytest.raises(RuntimeError):
-        api.SceneClipperProjective2D(ctx, proj).compute()          # missing scene (scene_clipper_projective_2d.cpp:12-17)
+        api.SceneClipperProjective2D(ctx, proj, voxelize_resolution=0.0).compute()          # missing scene (scene_clipper_projective_2d.cpp:12-17)
 
 
 def test_merger_bit_exact_and_grows_in_place(ctx, po):
@@ -769,7 +769,7 @@ def test_tracker_step_clip_align_merge_device_resident(ctx, po):
     guess = synth.compose_poses(robot, np.array([[0.03, -0.02, 0.02]]))[0].astype(np.float32)      # odometry-predicted robot pose
     # --- device pipeline
     local_map = api.CloudSet.reserved(ctx, 60000); local_map.upload(m)
-    clipper = api.SceneClipperProjective2D(ctx, proj); clipper.setFullScene(local_map)
+    clipper = api.SceneClipperProjective2D(ctx, proj, voxelize_resolution=0.0); clipper.setFullScene(local_map)
     clipper.setRobotInLocalMap(guess); clipper.setSensorInRobot(S0)
     clipped = clipper.compute()
     al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
@@ -818,7 +818,7 @@ def test_asynchronous_tracker_chain_equals_synchronous(ctx, po):
 
     def run(asynchronous):
         local_map = api.CloudSet.reserved(ctx, 40000); local_map.upload(np.zeros((0, 4), np.float32))
-        clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=asynchronous); clipper.setFullScene(local_map)
+        clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=asynchronous, voxelize_resolution=0.0); clipper.setFullScene(local_map)
         merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=asynchronous); merger.setScene(local_map)
         sets = [api.CloudSet.reserved(ctx, 1024), api.CloudSet.reserved(ctx, 1024)]
         al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
@@ -1260,7 +1260,7 @@ def test_no_device_memory_is_left_behind(small_workload):
             al.compute_batch([mp], [scans], synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32)) if not isinstance(f, api.CorrespondenceFinderProjective2f) else None
         grow = api.CloudSet.reserved(c, 40000); grow.upload(wl.map_points)
         m = api.MergerProjective2D(c, _projector(), 0.2); m.setScene(grow); m.setMeasurement(scan); m.setMeasurementInScene(synth.invert_poses(wl.x_true[:1])[0].astype(np.float32)); m.compute()
-        clip = api.SceneClipperProjective2D(c, _projector()); clip.setFullScene(grow); clip.setRobotInLocalMap(synth.invert_poses(wl.x_true[:1])[0].astype(np.float32)); clip.compute()
+        clip = api.SceneClipperProjective2D(c, _projector(), voxelize_resolution=0.0); clip.setFullScene(grow); clip.setRobotInLocalMap(synth.invert_poses(wl.x_true[:1])[0].astype(np.float32)); clip.compute()
         sw = C.c_void_p(); assert lib.lsm2d_sweep_create((C.c_int32 * 2)(0, 0), 2, C.byref(sw)) == 0
         pts = np.ascontiguousarray(wl.map_points)
         assert lib.lsm2d_sweep_set_map(sw, pts.ctypes.data_as(C.c_void_p), len(pts)) == 0
@@ -1311,7 +1311,7 @@ def test_non_finite_and_far_away_points_are_inert(ctx, po, small_workload):
         f.compute()                                          # infinite bounding box: an error, and the context stays usable
     # clipper / merger
     robot = synth.invert_poses(wl.x_true[1:2])[0].astype(np.float32)
-    clip = api.SceneClipperProjective2D(ctx, _projector())
+    clip = api.SceneClipperProjective2D(ctx, _projector(), voxelize_resolution=0.0)
     clip.setFullScene(wl.map_points); clip.setRobotInLocalMap(robot); c0 = clip.compute().download()
     clip.setFullScene(np.concatenate([wl.map_points, bad_all])); c1 = clip.compute().download()
     assert len(c0) > 300 and np.array_equal(c0, c1)
@@ -1377,7 +1377,7 @@ def test_pending_sizes_are_resolved_where_the_host_needs_them(ctx, po):
         host_map, _ = po.merge_scene(opr, host_map, scan, pose.astype(np.float32), 0.2)
     assert local_map.n_points == len(host_map) and np.array_equal(local_map.download(), host_map)
     # asynchronous clip, then consumers that need the exact size
-    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True); clipper.setFullScene(local_map)
+    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True, voxelize_resolution=0.0); clipper.setFullScene(local_map)
     clipper.setRobotInLocalMap(pose.astype(np.float32)); clipper.setSensorInRobot([0, 0, 0])
     clipped = clipper.compute()
     oclip, _ = po.clip_scene(opr, host_map, pose.astype(np.float32), np.zeros(3, np.float32))
@@ -1493,7 +1493,7 @@ def _ranges_in_pose_out_step(ctx, po):
     for i in range(2):
         pre.setRawData(ranges[i], a0, a1, 0.0, 30.0); pre.compute_into(sets[i])
     local_map = api.CloudSet.reserved(ctx, 30000); local_map.upload(m)
-    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True); clipper.setFullScene(local_map)
+    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True, voxelize_resolution=0.0); clipper.setFullScene(local_map)
     clipper.setRobotInLocalMap(guess); clipper.setSensorInRobot(S[0])
     clipped = clipper.compute()
     al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
@@ -1904,7 +1904,7 @@ def test_clipper_and_merger_small_and_large_scene_paths(ctx, po):
     for n_scene in (5000, 32768, 32769, 90000):
         m = synth.make_map(world, n_scene, noise_sigma=0.004, seed=n_scene)
         scene = api.CloudSet.reserved(ctx, n_scene + 2000); scene.upload(m)
-        clipper = api.SceneClipperProjective2D(ctx, proj); clipper.setFullScene(scene)
+        clipper = api.SceneClipperProjective2D(ctx, proj, voxelize_resolution=0.0); clipper.setFullScene(scene)
         clipper.setRobotInLocalMap(robot); clipper.setSensorInRobot(S)
         clipped = clipper.compute()
         want, wsrc = po.clip_scene(opr, m, np.float32(robot), S)
@@ -1947,7 +1947,7 @@ def test_randomised_mapping_and_preprocessing(ctx, po):
         prep_pts += len(want_meas)
         # clipper
         scene = api.CloudSet.reserved(ctx, n_scene + 4 * cols); scene.upload(m)
-        clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=asynchronous); clipper.setFullScene(scene)
+        clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=asynchronous, voxelize_resolution=0.0); clipper.setFullScene(scene)
         clipper.setRobotInLocalMap(np.float32(robot)); clipper.setSensorInRobot(S)
         clipped = clipper.compute()
         want_clip, want_src = po.clip_scene(opr, m, np.float32(robot), S)

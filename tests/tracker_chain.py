@@ -75,7 +75,7 @@ def run_device(api, ctx, steps: int = 8):
     pre = api.RawDataPreprocessorProjective2D(ctx, range_min=RMIN, range_max=RMAX, voxelize_resolution=0.02)
     sets = [api.CloudSet.reserved(ctx, 1024), api.CloudSet.reserved(ctx, 1024)]
     local_map = api.CloudSet.reserved(ctx, 50000)
-    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True); clipper.setFullScene(local_map)
+    clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True, voxelize_resolution=0.0); clipper.setFullScene(local_map)
     merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=True); merger.setScene(local_map)
     al = api.MultiAligner2D(ctx, max_iterations=ITS, min_num_inliers=10)
     al.param_slice_processors.append(api.AlignerSliceProcessorLaser2DWithSensor(
