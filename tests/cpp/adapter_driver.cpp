@@ -2,10 +2,11 @@
 // classes (apps/visual_test_correspondence_finder_projective_2d.cpp:60-80, apps/visual_test_aligner_2d.cpp:102-156), compiled against
 // the stand-in headers of tests/cpp/adapter_shim and linked with the real liblsm2d_hip.so.  Prints one JSON object; the Python test
 // (tests/test_gpu_parity.py::test_srrg_adapters_compile_and_run) compares it with the C ABI driven directly.
-//   adapter_driver fixed.bin moving.bin x y theta canvas_cols iterations
+//   adapter_driver fixed.bin moving.bin x y theta canvas_cols iterations [ranges.bin angle_min angle_max out_cloud.bin]
 #include <correspondence_finder_hip_2d.h>
 #include <mapping_hip_2d.h>
 #include <multi_aligner_hip_2d.h>
+#include <raw_data_preprocessor_hip_2d.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -152,6 +153,33 @@ int main(int argc, char** argv) {
     merger.setScene(&scene); merger.setMeasurement(&fixed); merger.setMeasurementInScene(geometry2d::v2t(x0).inverse());
     merger.compute();
     out << ",\"merged_size\":" << scene.size() << ",\"merge_status\":" << (int) merger.status();
+  }
+
+  // ---- raw-data preprocessor sibling (row f2), driven as the pipeline drives the reference module: setRawData(message), compute()
+  if (argc >= 12) {
+    std::ifstream rf(argv[8], std::ios::binary);
+    rf.seekg(0, std::ios::end); const size_t bytes = (size_t) rf.tellg(); rf.seekg(0);
+    auto msg = std::make_shared<LaserMessage>();
+    msg->ranges.value().resize(bytes / 4); rf.read((char*) msg->ranges.value().data(), (std::streamsize) bytes);
+    msg->angle_min.setValue((float) atof(argv[9])); msg->angle_max.setValue((float) atof(argv[10]));
+    msg->range_min.setValue(0.0f); msg->range_max.setValue(30.0f); msg->topic.setValue("/scan_front");
+    RawDataPreprocessorHIP2D pre;
+    pre.param_range_min.setValue(0.3f); pre.param_range_max.setValue(20.0f); pre.param_scan_topic.setValue("/scan_front");
+    PointNormal2fVectorCloud meas;
+    pre.compute();                                              // nothing set: status Error, no throw (.cpp:13-17)
+    const int status_unset = (int) pre.status();
+    pre.setMeas(&meas);
+    auto other = std::make_shared<LaserMessage>(); other->topic.setValue("/scan_rear");
+    const bool took_other = pre.setRawData(other);              // not this module's topic (.cpp:64-69)
+    int threw_null = 0;
+    try { pre.setRawData(nullptr); } catch (const std::runtime_error&) { threw_null = 1; }
+    const bool took = pre.setRawData(msg);
+    pre.compute();
+    std::ofstream of(argv[11], std::ios::binary);
+    for (const auto& p : meas) { const float v[4] = {p.coordinates().x(), p.coordinates().y(), p.normal().x(), p.normal().y()}; of.write((const char*) v, sizeof v); }
+    out << ",\"prep_status_unset\":" << status_unset << ",\"prep_took_other_topic\":" << (int) took_other << ",\"prep_threw_on_null\":" << threw_null
+        << ",\"prep_took\":" << (int) took << ",\"prep_status\":" << (int) pre.status() << ",\"prep_points\":" << meas.size()
+        << ",\"unprojector_range_max\":" << pre.param_unprojector->param_range_max.value() << ",\"unprojector_range_min\":" << pre.param_unprojector->param_range_min.value();
   }
   out << "}";
   printf("%s\n", out.str().c_str());

@@ -85,6 +85,7 @@ namespace srrg2_core {
     Property_(const char* name_, const char*, void*, const T& def_, bool* flag_ = nullptr) : _name(name_), _value(def_), _flag(flag_) {}
     Property_(const std::string& name_, const std::string&, class PropertyContainerBase* owner_);
     const T& value() const { return _value; }
+    T& value() { return _value; }
     void setValue(const T& v_) { _value = v_; if (_flag) *_flag = true; }
     const std::string& name() const { return _name; }
   protected:
@@ -136,6 +137,36 @@ namespace srrg2_core {
     PARAM(PropertyFloat, range_max, "", 20.f, 0);
   };
   using PointNormal2fProjectorPolarPtr = std::shared_ptr<PointNormal2fProjectorPolar>;
+
+  // ---- what the raw-data preprocessor touches (sensor_processing/raw_data_preprocessor_projective_2d.{h,cpp}): the laser message's fields
+  // (:78-85), the un-projector's PARAMs it sets per message (:96-101), the sliding-window normal computator's PARAMs (MULTI.json:845-853)
+  struct Matrix2f { float m[2][2] = {{1.f, 0.f}, {0.f, 1.f}}; };
+  class BaseSensorMessage { public: virtual ~BaseSensorMessage() {} };
+  using BaseSensorMessagePtr = std::shared_ptr<BaseSensorMessage>;
+  class LaserMessage : public BaseSensorMessage {
+  public:
+    Property_<std::string> topic{"topic", "", nullptr, std::string("/scan")};
+    Property_<std::vector<float>> ranges{"ranges", "", nullptr, std::vector<float>()};
+    PropertyFloat range_min{"range_min", "", nullptr, 0.f}, range_max{"range_max", "", nullptr, 0.f};
+    PropertyFloat angle_min{"angle_min", "", nullptr, 0.f}, angle_max{"angle_max", "", nullptr, 0.f};
+  };
+  using LaserMessagePtr = std::shared_ptr<LaserMessage>;
+  class PointNormal2fUnprojectorPolar : public Configurable {
+  public:
+    PARAM(PropertyFloat, range_min, "", 0.3f, 0);
+    PARAM(PropertyFloat, range_max, "", 20.f, 0);
+    PARAM(PropertyFloat, angle_min, "", -3.14159f, 0);
+    PARAM(PropertyFloat, angle_max, "", 3.14159f, 0);
+    void setCameraMatrix(const Matrix2f& m_) { _camera_matrix = m_; }
+    Matrix2f _camera_matrix;
+  };
+  using PointNormal2fUnprojectorPolarPtr = std::shared_ptr<PointNormal2fUnprojectorPolar>;
+  template <typename Cloud_, int idx_>
+  class NormalComputator1DSlidingWindow : public Configurable {
+  public:
+    PARAM(PropertyInt, normal_min_points, "min number of points to compute a normal", 5, 0);
+    PARAM(PropertyFloat, normal_point_distance, "max normal point distance", 0.3f, 0);
+  };
 } // namespace srrg2_core
 
 namespace srrg2_solver {
@@ -226,6 +257,26 @@ namespace srrg2_slam_interfaces {
     Status status() const { return _status; }
   protected:
     Scene_* _scene = nullptr; Meas_* _measurement = nullptr; Est_ _measurement_in_scene = Est_::Identity(); Status _status = Error;
+  };
+  // raw-data preprocessor base (srrg2_slam_interfaces/raw_data_preprocessors/raw_data_preprocessor.h): the members the reference's
+  // implementation uses (raw_data_preprocessor_projective_2d.cpp:13-17,42-51,59-60: _meas, _raw_data, _status, setRawData)
+  template <typename T>
+  std::shared_ptr<T> extractMessage(srrg2_core::BaseSensorMessagePtr msg_, const std::string& topic_) {
+    auto m = std::dynamic_pointer_cast<T>(msg_);
+    return (m && m->topic.value() == topic_) ? m : nullptr;
+  }
+  template <typename Meas_>
+  class RawDataPreprocessor_ : public Configurable {
+  public:
+    using MeasurementType = Meas_;
+    enum Status { Error = 0, Ready = 1 };
+    virtual ~RawDataPreprocessor_() {}
+    virtual bool setRawData(srrg2_core::BaseSensorMessagePtr msg_) { _raw_data = msg_; return true; }
+    void setMeas(Meas_* meas_) { _meas = meas_; }
+    Status status() const { return _status; }
+    virtual void compute() = 0;
+  protected:
+    Meas_* _meas = nullptr; srrg2_core::BaseSensorMessagePtr _raw_data; Status _status = Error;
   };
   template <typename Est_, typename Scene_>
   class SceneClipper_ : public Configurable {

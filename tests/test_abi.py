@@ -68,7 +68,7 @@ def test_srrg_adapter_sources_compile_against_the_stand_in_headers(tmp_path):
     import subprocess
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "adapters", "srrg"), "-I" + os.path.join(ROOT, "tests", "cpp", "adapter_shim")]
     units = [os.path.join(ROOT, "adapters", "srrg", "correspondence_finder_hip_2d.cpp"), os.path.join(ROOT, "adapters", "srrg", "multi_aligner_hip_2d.cpp"),
-             os.path.join(ROOT, "tests", "cpp", "adapter_driver.cpp")]      # the driver includes mapping_hip_2d.h (header-only)
+             os.path.join(ROOT, "tests", "cpp", "adapter_driver.cpp")]      # the driver includes mapping_hip_2d.h and raw_data_preprocessor_hip_2d.h (header-only)
     for u in units:
         r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-fsyntax-only", *inc, u], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -135,7 +135,9 @@ def test_adapter_and_shim_params_match_the_reference_headers():
              ("registration/correspondence_finder_kd_tree_2d.h", "CorrespondenceFinderKDTree2D", shim, fh, "CorrespondenceFinderKDTreeHIP2D"),
              ("registration/correspondence_finder_nn_2d.h", "CorrespondenceFinderNN2D", shim, fh, "CorrespondenceFinderNNHIP2D"),
              ("mapping/scene_clipper_projective_2d.h", "SceneClipperProjective2D", None, mh, "SceneClipperHIP2D"),
-             ("mapping/merger_projective_2d.h", "MergerProjective2D", None, mh, "MergerHIP2D")]
+             ("mapping/merger_projective_2d.h", "MergerProjective2D", None, mh, "MergerHIP2D"),
+             ("sensor_processing/raw_data_preprocessor_projective_2d.h", "RawDataPreprocessorProjective2D", None,
+              rd(ROOT, "adapters", "srrg", "raw_data_preprocessor_hip_2d.h"), "RawDataPreprocessorHIP2D")]
     for header, cls, shim_text, adapter_text, adapter_cls in cases:
         want = _params_of(rd(ref, header), cls)
         assert want, (header, cls)

@@ -341,7 +341,7 @@ def test_device_resident_input(ctx, small_workload):
 
 
 def test_srrg_adapters_compile_and_run(ctx, po, small_workload, tmp_path):
-    """The SRRG-side adapter sources (adapters/srrg/*: three finder siblings, MultiAlignerHIP2D, clipper / merger siblings) compiled
+    """The SRRG-side adapter sources (adapters/srrg/*: three finder siblings, MultiAlignerHIP2D, clipper / merger / raw-data preprocessor siblings) compiled
     against the stand-in srrg2 headers of tests/cpp/adapter_shim, linked with the real library and driven as the reference drives its own
     classes (tests/cpp/adapter_driver.cpp): same pairs as the oracle, the aligner's pose / status / statistics written back, the
     odometry-prior slice translated, an in-place change of the moving cloud seen, an unknown slice processor refused."""
@@ -357,7 +357,11 @@ def test_srrg_adapters_compile_and_run(ctx, po, small_workload, tmp_path):
     f = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
     f.tofile(tmp_path / "fixed.bin"); wl.map_points.tofile(tmp_path / "moving.bin")
     x0 = wl.x0[0]; iters = 12
-    out = subprocess.run([exe, str(tmp_path / "fixed.bin"), str(tmp_path / "moving.bin"), repr(float(x0[0])), repr(float(x0[1])), repr(float(x0[2])), "1081", str(iters)],
+    world = synth.make_world(2); a0, a1 = -2.34747, 2.35619
+    ranges = synth.make_scan_ranges(world, synth.sample_poses(world, 1, seed=4), n_beams=721, angle_min=a0, angle_max=a1, noise_sigma=0.005, seed=1)[0]
+    ranges[100:110] = np.inf; ranges.tofile(tmp_path / "ranges.bin")
+    out = subprocess.run([exe, str(tmp_path / "fixed.bin"), str(tmp_path / "moving.bin"), repr(float(x0[0])), repr(float(x0[1])), repr(float(x0[2])), "1081", str(iters),
+                          str(tmp_path / "ranges.bin"), repr(a0), repr(a1), str(tmp_path / "prep.bin")],
                          check=True, capture_output=True, text=True, timeout=180).stdout
     r = json.loads(out.strip().splitlines()[-1])
     # finders: the pose reaches the ABI as t2v(v2t(x0)) (one atan2 / cos / sin round trip of the stand-in geometry): pairs may differ from the
@@ -393,6 +397,13 @@ def test_srrg_adapters_compile_and_run(ctx, po, small_workload, tmp_path):
     assert abs(r["clipped"] - n_clip) <= 3 and 10 < r["clipped_voxelized"] < r["clipped"] and r["clip_status"] == 1
     n_merge = len(po.merge_scene(opr, wl.map_points, f, robot, 0.2)[0])
     assert abs(r["merged_size"] - n_merge) <= 5 and r["merge_status"] == 1
+    # raw-data preprocessor sibling: the reference module's behaviour on unset inputs / foreign topics / null messages, the un-projector it
+    # shares with other modules set per message (.cpp:96-101), and the cloud itself bit for bit (class defaults: voxelize 0.02, normals 0.3 / 5)
+    want = po.preprocess_scan(po.Preprocessor(721, np.float32(a0), np.float32(a1), 0.3, 20.0, 0.3, 5, 0.02), ranges)
+    got = np.fromfile(tmp_path / "prep.bin", np.float32).reshape(-1, 4)
+    assert r["prep_status_unset"] == 0 and r["prep_took_other_topic"] == 0 and r["prep_threw_on_null"] == 1 and r["prep_took"] == 1 and r["prep_status"] == 1
+    assert r["prep_points"] == len(want) > 300 and np.array_equal(got, want)
+    assert abs(r["unprojector_range_max"] - 20.0) < 1e-6 and abs(r["unprojector_range_min"] - 0.3) < 1e-6
 
 
 def test_cpp_loop_closure_sweep_over_several_contexts(ctx, po, tmp_path):
