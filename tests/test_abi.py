@@ -151,3 +151,31 @@ def test_adapter_and_shim_params_match_the_reference_headers():
                 assert got[pname][0] == typ, (where, name, pname, got[pname][0], typ)
                 if default != "expr":
                     assert got[pname][1] == "expr" or abs(got[pname][1] - default) <= 1e-6 * max(1.0, abs(default)), (where, name, pname, got[pname][1], default)
+
+
+def test_python_mirror_defaults_match_the_reference_headers():
+    """The Python mirror of the reference classes (srrg2_laser_slam_2d_amd/api.py) takes the reference's PARAM names as keyword arguments:
+    where the reference tree is present, every numeric default must be the reference's."""
+    import inspect
+    ref = "/root/reference/srrg2_laser_slam_2d/src/srrg2_laser_slam_2d"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    from srrg2_laser_slam_2d_amd import api
+    rd = lambda *p: open(os.path.join(*p)).read()
+    cases = [("registration/correspondence_finder_projective_2d.h", "CorrespondenceFinderProjective2f", api.CorrespondenceFinderProjective2f),
+             ("registration/correspondence_finder_kd_tree_2d.h", "CorrespondenceFinderKDTree2D", api.CorrespondenceFinderKDTree2D),
+             ("registration/correspondence_finder_nn_2d.h", "CorrespondenceFinderNN2D", api.CorrespondenceFinderNN2D),
+             ("mapping/scene_clipper_projective_2d.h", "SceneClipperProjective2D", api.SceneClipperProjective2D),
+             ("mapping/merger_projective_2d.h", "MergerProjective2D", api.MergerProjective2D),
+             ("sensor_processing/raw_data_preprocessor_projective_2d.h", "RawDataPreprocessorProjective2D", api.RawDataPreprocessorProjective2D)]
+    checked = 0
+    for header, cls, mirror in cases:
+        want = _params_of(rd(ref, header), cls)
+        sig = inspect.signature(mirror.__init__).parameters
+        for pname, (typ, default) in want.items():
+            if default == "expr" or typ == "PropertyString":
+                continue                                     # object-valued (projector, un-projector, normal computator) / topic strings: not numeric
+            assert pname in sig, (cls, "mirror lacks", pname)
+            assert abs(float(sig[pname].default) - default) <= 1e-6 * max(1.0, abs(default)), (cls, pname, sig[pname].default, default)
+            checked += 1
+    assert checked >= 12
