@@ -179,3 +179,35 @@ def test_python_mirror_defaults_match_the_reference_headers():
             assert abs(float(sig[pname].default) - default) <= 1e-6 * max(1.0, abs(default)), (cls, pname, sig[pname].default, default)
             checked += 1
     assert checked >= 12
+
+
+def test_adapters_touch_only_base_class_members_the_reference_uses():
+    """The adapters derive from upstream base classes this image does not have; the members they read and write there (`_fixed`,
+    `_full_scene`, `_meas`, ...) are the ones the reference's own implementations of the same classes use.  Where the reference tree is
+    present: every underscore-member an adapter touches is either declared by the adapter itself, used somewhere in the reference's
+    sources, or one of the names isolated (and tagged UPSTREAM) in adapters/srrg/upstream_access.h / multi_aligner_hip_2d.cpp."""
+    import glob
+    ref = "/root/reference/srrg2_laser_slam_2d"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    ref_ids = set()
+    for p in glob.glob(ref + "/**/*", recursive=True):
+        if os.path.isfile(p) and p.endswith((".h", ".hpp", ".cpp")):
+            ref_ids |= set(re.findall(r"\b_[a-z][a-zA-Z_0-9]*\b", open(p, errors="ignore").read()))
+    upstream_tagged = {"_fixed_slice", "_moving_slice", "_information_matrix", "_iteration_stats"}     # upstream_access.h:58-68, multi_aligner_hip_2d.cpp (_writeBack)
+    ad = os.path.join(ROOT, "adapters", "srrg")
+    texts = {f: re.sub(r"//.*", "", open(os.path.join(ad, f)).read()) for f in sorted(os.listdir(ad))}
+    own = set()
+    for t in texts.values():       # members, methods and locals the adapters declare themselves
+        own |= set(re.findall(r"[\w>\*&\]]\s+\**(_[a-z][a-zA-Z_0-9]*)\s*(?:=|;|\{|\[|,|\()", t))
+        for decl in re.findall(r"^\s*[\w:<>\*&, ]+?\s+\**(_[a-z][a-zA-Z_0-9]*(?:\s*(?:=[^,;]*)?,\s*\**_[a-z][a-zA-Z_0-9]*)+)\s*(?:=[^;]*)?;", t, re.M):
+            own |= set(re.findall(r"_[a-z][a-zA-Z_0-9]*", decl))              # "Type _a, _b;" declares both
+    seen_base = set()
+    for f, t in texts.items():
+        for name in set(re.findall(r"\b_[a-z][a-zA-Z_0-9]*\b", t)):
+            if name.endswith("_") or name in own:
+                continue
+            assert name in ref_ids or name in upstream_tagged, (f, name)
+            seen_base.add(name)
+    assert {"_fixed", "_moving", "_correspondences", "_local_map_in_sensor", "_full_scene", "_clipped_scene_in_robot", "_scene", "_measurement",
+            "_measurement_in_scene", "_robot_in_local_map", "_sensor_in_robot", "_meas", "_raw_data", "_status"} <= seen_base
