@@ -64,9 +64,18 @@ namespace srrg2_laser_slam_2d {
   }
 
   void CorrespondenceFinderKDTreeHIP2D::fillSliceParams(lsm2d_slice_params* sp_) const {
-    sp_->finder       = LSM2D_FINDER_NN;
-    sp_->max_distance = param_max_distance_m.value();
-    sp_->normal_cos   = param_normal_cos.value();
+    const std::string& search = param_search.value();
+    if (search == "kdtree") {
+      sp_->finder = LSM2D_FINDER_KDTREE;
+    } else if (search == "exact") {
+      sp_->finder = LSM2D_FINDER_NN;
+    } else {
+      throw std::runtime_error("CorrespondenceFinderKDTreeHIP2D::compute| search must be \"kdtree\" or \"exact\", got \"" + search + "\"");
+    }
+    sp_->max_distance       = param_max_distance_m.value();
+    sp_->normal_cos         = param_normal_cos.value();
+    sp_->kd_max_leaf_range  = param_max_leaf_range.value();
+    sp_->kd_min_leaf_points = (int32_t) param_min_leaf_points.value();
   }
 
   void CorrespondenceFinderNNHIP2D::fillSliceParams(lsm2d_slice_params* sp_) const {

@@ -51,11 +51,15 @@ namespace srrg2_laser_slam_2d {
   class CorrespondenceFinderKDTreeHIP2D : public CorrespondenceFinderHIPBase {
   public:
     PARAM(srrg2_core::PropertyFloat, max_distance_m, "max distance for correspondences [meters]", 1e-2, 0);
-    // kept so that a configuration written for CorrespondenceFinderKDTree2D loads unchanged; the device search is an exact
-    // nearest-neighbour search on a uniform grid, for which they have no meaning (PARITY.md section 5 measures the difference)
-    PARAM(srrg2_core::PropertyFloat, max_leaf_range, "unused by the device search (exact NN)", 1e-2, 0);
-    PARAM(srrg2_core::PropertyUnsignedInt, min_leaf_points, "unused by the device search (exact NN)", 20, 0);
+    PARAM(srrg2_core::PropertyFloat, max_leaf_range, "maximum range for a leaf of the KDTree [meters]", 1e-2, 0);
+    PARAM(srrg2_core::PropertyUnsignedInt, min_leaf_points, "minimum number of points in a leaf of the KDTree", 20, 0);
     PARAM(srrg2_core::PropertyFloat, normal_cos, "min cosinus between normals", 0.8, 0);
+    // "kdtree" (default): the reference's own structure on the device -- KDTree2D(coordinates, max_leaf_range, min_leaf_points) built in
+    // reset() (registration/correspondence_finder_kd_tree_2d.cpp:31-38) and findNeighbor's single-leaf descent (.cpp:18-19), restated as
+    // SURVEY.md App. A.4 believes upstream implements them: a configuration written for CorrespondenceFinderKDTree2D keeps its meaning.
+    // "exact": an exact nearest-neighbour search on a uniform grid (never a farther neighbour than the tree's; the two leaf
+    // parameters are not used by it).
+    PARAM(srrg2_core::PropertyString, search, "device search: kdtree (the reference's tree, approximate) | exact (uniform grid)", "kdtree", 0);
     void fillSliceParams(lsm2d_slice_params* sp_) const override;
 
   protected:

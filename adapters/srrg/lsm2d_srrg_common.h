@@ -103,9 +103,11 @@ namespace lsm2d_srrg {
       sp_->point_distance = proj->param_point_distance.value();
       sp_->normal_cos     = proj->param_normal_cos.value();
     } else if (auto kd = dynamic_cast<const CorrespondenceFinderKDTree2D*>(finder_.get())) {
-      sp_->finder       = LSM2D_FINDER_NN; // exact nearest neighbour; max_leaf_range / min_leaf_points have no counterpart
-      sp_->max_distance = kd->param_max_distance_m.value();
-      sp_->normal_cos   = kd->param_normal_cos.value();
+      sp_->finder             = LSM2D_FINDER_KDTREE; // the reference's own tree and descent, with its own parameters
+      sp_->max_distance       = kd->param_max_distance_m.value();
+      sp_->normal_cos         = kd->param_normal_cos.value();
+      sp_->kd_max_leaf_range  = kd->param_max_leaf_range.value();
+      sp_->kd_min_leaf_points = (int32_t) kd->param_min_leaf_points.value();
     } else if (auto nn = dynamic_cast<const CorrespondenceFinderNN2D*>(finder_.get())) {
       sp_->finder       = LSM2D_FINDER_DISTMAP;
       sp_->max_distance = nn->param_max_distance_m.value();

@@ -50,6 +50,20 @@ namespace srrg2_laser_slam_2d {
     if (!_fixed || !_moving) {
       throw std::runtime_error(std::string(who) + "| fixed / moving scene not set");
     }
+    // options of the upstream aligner that the device loop does not implement: refused, never silently dropped
+    // (MULTI.json:606-610,704-708: both 0 in the shipped aligners; :627-630,729-731: termination_criteria unset)
+    if (lsm2d_srrg::inlierOnlyRunsEnabled(*this)) {
+      throw std::runtime_error(std::string(who) + "| enable_inlier_only_runs is not supported on the device (the loop runs no inlier-only re-runs)");
+    }
+    if (lsm2d_srrg::keepOnlyInlierCorrespondences(*this)) {
+      throw std::runtime_error(std::string(who) + "| keep_only_inlier_correspondences is not supported on the device (every iteration searches afresh)");
+    }
+    if (lsm2d_srrg::terminationCriteriaSet(*this)) {
+      throw std::runtime_error(std::string(who) + "| a termination_criteria object cannot run on the device: unset it and use termination_chi_epsilon");
+    }
+    if (!(param_termination_chi_epsilon.value() >= 0.f)) {
+      throw std::runtime_error(std::string(who) + "| termination_chi_epsilon must be >= 0");
+    }
     if (!_ctx) {
       throwOnError(lsm2d_create(param_device_id.value(), nullptr, &_ctx), std::string(who) + " create", nullptr);
     }
@@ -154,6 +168,7 @@ namespace srrg2_laser_slam_2d {
     ap.max_iterations  = param_max_iterations.value();
     ap.min_num_inliers = param_min_num_inliers.value();
     ap.damping         = 0.f; // GN, MULTI.json:254-259
+    ap.termination_chi_epsilon = param_termination_chi_epsilon.value();
     std::vector<lsm2d_iteration_stats> stats((size_t) (ap.max_iterations > 0 ? ap.max_iterations : 1));
     throwOnError(lsm2d_align_batch(_ctx, &ap, &batch, pose, information, &status, &iterations, stats.data()), who, _ctx);
     _last_status     = status;

@@ -4,7 +4,8 @@
 // call that runs the whole loop on the device.  It consumes the same configuration -- max_iterations, min_num_inliers,
 // slice_processors (configurations/stage_segway_double_config_MULTI.json:700-732): every AlignerSliceProcessorLaser2D[WithSensor]
 // becomes an lsm2d slice (finder, robustifier, min_num_correspondences, sensor extrinsics), the AlignerSliceOdom2DPrior
-// (MULTI.json:402-422) becomes the lsm2d_prior; a slice processor of any other type is an ERROR, never skipped.  After the call
+// (MULTI.json:402-422) becomes the lsm2d_prior; a slice processor of any other type is an ERROR, never skipped, and so is a non-default
+// enable_inlier_only_runs / keep_only_inlier_correspondences / termination_criteria (MULTI.json:606-610,627-630).  After the call
 // the pose, the status, the information matrix and the iteration statistics are written back into the base class.
 // Device clouds persist across calls (reserved sets, refilled), one per distinct host cloud.
 #pragma once
@@ -27,6 +28,13 @@ namespace srrg2_laser_slam_2d {
           "1: after compute() every laser slice's correspondences() holds the pairs at the final estimate (one extra finder call per slice; "
           "callers use them for drawing only: apps/visual_test_aligner_2d.cpp:129-143)",
           0,
+          0);
+    PARAM(srrg2_core::PropertyFloat,
+          termination_chi_epsilon,
+          "device-side termination criterion: stop after an iteration whose total chi2 differs from the previous one's by less than this "
+          "ratio (0: run max_iterations, what an unset termination_criteria means; a termination_criteria OBJECT cannot run on the device "
+          "and is refused)",
+          0.f,
           0);
     virtual ~MultiAlignerHIP2D();
     void compute() override;

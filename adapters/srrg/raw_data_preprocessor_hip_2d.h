@@ -68,8 +68,8 @@ namespace srrg2_laser_slam_2d {
       _angle_max = laser_message->angle_max.value();
       _angle_min = laser_message->angle_min.value();
       const float sensor_res = (_angle_max - _angle_min) / (float) _ranges->size();
-      Matrix2f sensor_matrix;
-      sensor_matrix.m[0][0] = 1.f / sensor_res; sensor_matrix.m[0][1] = (float) _ranges->size() / 2.f; sensor_matrix.m[1][0] = 0.f; sensor_matrix.m[1][1] = 0.f;
+      Matrix2f sensor_matrix(Matrix2f::Identity()); // .cpp:89-90, Eigen's comma initialiser as the reference writes it
+      sensor_matrix << 1.f / sensor_res, (float) _ranges->size() / 2.f, 0, 0;
       PointNormal2fUnprojectorPolarPtr unprojector = param_unprojector.value();
       unprojector->param_range_min.setValue(_range_min); // .cpp:96-101: a shared un-projector sees the same values as with the reference module
       unprojector->param_range_max.setValue(_range_max);

@@ -66,6 +66,22 @@ namespace lsm2d_srrg {
   inline CorrespondenceVector& sliceCorrespondences(const SlicePtr_& slice_) {
     return slice_->_correspondences;
   }
+  // aligner options the shipped configurations carry (MULTI.json:606-610,627-630,704-708,729-731) and the device loop does not
+  // implement as objects: read here so that MultiAlignerHIP2D can REFUSE a non-default value instead of running another algorithm.
+  // UPSTREAM: the PARAM types behind "enable_inlier_only_runs" / "keep_only_inlier_correspondences" (bool or int) and the class behind
+  // "termination_criteria" -- only `.value()` and a conversion to bool are used.
+  template <typename Aligner_>
+  inline bool inlierOnlyRunsEnabled(const Aligner_& aligner_) {
+    return (bool) aligner_.param_enable_inlier_only_runs.value();
+  }
+  template <typename Aligner_>
+  inline bool keepOnlyInlierCorrespondences(const Aligner_& aligner_) {
+    return (bool) aligner_.param_keep_only_inlier_correspondences.value();
+  }
+  template <typename Aligner_>
+  inline bool terminationCriteriaSet(const Aligner_& aligner_) {
+    return (bool) aligner_.param_termination_criteria.value();
+  }
   // information matrix of the odometry prior factor.  UPSTREAM: the prior slice's factor carries its own information matrix; the
   // shipped configuration sets none (MULTI.json:402-422), i.e. the factor's default, taken to be identity.
   inline void priorInformation(float omega_row_major_[9]) {

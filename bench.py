@@ -292,6 +292,10 @@ def main() -> None:
         default_cfg = (args.role, args.finder, args.scans, args.map_points, args.iterations, args.beams, args.cauchy, n_unique) == \
                       ("A", "projective", 1000, 100000, 20, 1081, 0.0, 1000)
         cfg_key = "role%s/%s/scans%d/map%d/it%d/beams%d" % (args.role, args.finder, args.scans, args.map_points, args.iterations, args.beams)
+        if args.cauchy > 0:                       # a robustified run is another instruction stream (the log, the weights): its own counters
+            cfg_key += "/cauchy%g" % args.cauchy
+        if n_unique != args.scans:                # scans shared through the index array: another memory pattern
+            cfg_key += "/unique%d" % n_unique
         counters, warn = load_counters(cfg_key)
         effective = bytes_per_alignment * args.scans / (k_ms * 1e-3) / 1e9
         roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave64-VALU issue slots/s", "frac": None, "traffic": None,

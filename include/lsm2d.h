@@ -29,11 +29,14 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 121 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
+#define LSM2D_VERSION 130 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
                              0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes;
                              0.2.0: + lsm2d_clip_scene_voxelized, lsm2d_sweep_* (multi-device loop-closure sweep), in-kernel clock options;
                              0.2.1: + lsm2d_cloudset_cloud_sizes, pinned / device-resident ranges in lsm2d_preprocess_scans, options
-                                    "distmap_build", "grid_big_threshold", "find_path", "zero_copy_max" */
+                                    "distmap_build", "grid_big_threshold", "find_path", "zero_copy_max";
+                             0.3.0: + LSM2D_FINDER_KDTREE (the reference KD-tree's own build and single-leaf descent, honouring max_leaf_range /
+                                    min_leaf_points: lsm2d_slice_params grew two fields), lsm2d_aligner_params.termination_chi_epsilon,
+                                    sweep option "peer_copy" */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -64,8 +67,15 @@ typedef struct {
 
 typedef enum {
   LSM2D_FINDER_PROJECTIVE = 0, /* CorrespondenceFinderProjective2f  (registration/correspondence_finder_projective_2d.cpp:18-77) */
-  LSM2D_FINDER_NN         = 1, /* CorrespondenceFinderKDTree2D      (registration/correspondence_finder_kd_tree_2d.cpp:5-38), exact NN */
-  LSM2D_FINDER_DISTMAP    = 2  /* CorrespondenceFinderNN2D          (registration/correspondence_finder_nn_2d.cpp:54-97) */
+  LSM2D_FINDER_NN         = 1, /* CorrespondenceFinderKDTree2D      (registration/correspondence_finder_kd_tree_2d.cpp:5-38) with an EXACT
+                                  nearest-neighbour search (uniform grid): a superset-quality substitute, max_leaf_range / min_leaf_points unused */
+  LSM2D_FINDER_DISTMAP    = 2, /* CorrespondenceFinderNN2D          (registration/correspondence_finder_nn_2d.cpp:54-97) */
+  LSM2D_FINDER_KDTREE     = 3  /* CorrespondenceFinderKDTree2D as the reference runs it: reset() builds KDTree2D(coordinates, max_leaf_range,
+                                  min_leaf_points) (.cpp:31-38, .h:36-39), compute() calls findNeighbor per moved point (.cpp:12-27).  Upstream's
+                                  tree (srrg2_core, not in the reference tree) is restated as SURVEY.md App. A.4 believes it: split through the
+                                  mean along the principal eigenvector until a node holds fewer than min_leaf_points points or is smaller than
+                                  max_leaf_range; descent to the single leaf on the query's side, no backtracking -- hence APPROXIMATE: it may
+                                  return a farther neighbour than LSM2D_FINDER_NN, or none */
 } lsm2d_finder;
 
 typedef enum { LSM2D_ROBUST_NONE = 0, LSM2D_ROBUST_CAUCHY = 1 } lsm2d_robustifier;
@@ -83,6 +93,8 @@ typedef struct {
   float           chi_threshold;           /* Cauchy tau */
   int32_t         min_num_correspondences; /* slice skipped when #pairs <= this (MULTI.json:179,391,591) */
   float           sensor_in_robot[3];      /* WithSensor variant (registration/aligner_slice_processor_laser_2d_impl.cpp:7-10); zeros = plain */
+  float           kd_max_leaf_range;       /* KDTREE: param_max_leaf_range  (kd .h:26-28); <= 0: the class default 1e-2 */
+  int32_t         kd_min_leaf_points;      /* KDTREE: param_min_leaf_points (kd .h:29-33); <= 0: the class default 20 */
 } lsm2d_slice_params;
 
 /* MultiAligner2D parameters (MULTI.json:700-732, :602-630) + GN damping (MULTI.json:254-259). */
@@ -90,6 +102,11 @@ typedef struct {
   int32_t max_iterations;
   int32_t min_num_inliers;
   float   damping;
+  /* device-side counterpart of the aligner's "termination_criteria" (MULTI.json:627-630,729-731: unset in both shipped aligners = always
+   * max_iterations; the solver's SimpleTerminationCriteria, MULTI.json:218-223, documents epsilon as the "ratio of decay of chi2 between
+   * iteration"): 0 = off; > 0: the loop stops after an iteration whose total chi^2 (inliers + kernelised outliers) differs from the
+   * previous iteration's by less than epsilon times itself.  The iteration that triggers the stop is still solved and applied. */
+  float   termination_chi_epsilon;
 } lsm2d_aligner_params;
 
 /* Optional odometry-prior cue (AlignerSliceOdom2DPrior, MULTI.json:402-422): e = t2v(Z^-1 X), information omega. */
@@ -137,8 +154,9 @@ int  lsm2d_synchronize(lsm2d_context* ctx);
  * "find_path": 0 = automatic (default: a point-query lsm2d_find_correspondences call with more queries than one workgroup takes in a trip
  * runs on many workgroups, two launches; the projective finder z-buffers a cloud of more than 32768 points over many workgroups first),
  * 1 = always one workgroup; same pairs, same order.
- * "zero_copy_max" (default 256): batches of at most this many alignments without index arrays read their arguments from, and write their
- * results to, pinned host memory directly (no transfers, status words polled); measured slower than the transfers at 1000 alignments. */
+ * "zero_copy_max" (default 256): batches of at most this many alignments read their arguments from, and write their results to, pinned
+ * host memory directly (no transfers, status words polled) -- above 256 alignments only when the batch carries no index arrays; measured
+ * slower than the transfers at 1000 alignments.  0 switches the zero-copy form off. */
 int  lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value);
 /* reads a knob back; also "last_align_path": what the most recent lsm2d_align_batch ran (1 k_align, 2 split, 3 slice pair) */
 int  lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* out_value);
@@ -153,7 +171,10 @@ int  lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms);
  * shared by a batch is a set with ONE cloud. */
 int  lsm2d_cloudset_create(lsm2d_context* ctx, const float* points_xynn, const int32_t* offsets,
                            int32_t n_clouds, int64_t total_points, lsm2d_cloudset** out_set);
-/* same, from points already in device memory on ctx's device (float4 per point); offsets stay host */
+/* same, from points already in device memory on ctx's device (float4 per point); offsets stay host.
+ * ORDERING: the points are read on the CONTEXT's stream.  Whatever produced them (another stream, e.g. torch's current stream) must have
+ * finished -- synchronise that stream or make it wait-for -- or the context must have been created on that very stream
+ * (lsm2d_create's hip_stream); the library cannot know the producer.  The same holds for device-resident `ranges` below. */
 int  lsm2d_cloudset_create_from_device(lsm2d_context* ctx, const void* d_points_xynn, const int32_t* offsets,
                                        int32_t n_clouds, int64_t total_points, lsm2d_cloudset** out_set);
 /* a single growable cloud (count 0) with room for capacity_points: the device-resident local map / clipped scene */
@@ -197,7 +218,8 @@ typedef struct {
   float   voxelize_resolution;
 } lsm2d_preprocessor;
 /* `ranges` [n_scans][n_beams] may live in pageable host memory (staged through the context's pinned buffer), in pinned / registered host
- * memory (copied from directly) or in device memory of the context's device (read in place: nothing crosses the host link). */
+ * memory (copied from directly) or in device memory of the context's device (read in place: nothing crosses the host link; see the
+ * ORDERING note at lsm2d_cloudset_create_from_device: the producer's stream must have been synchronised with). */
 int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges,
                            int32_t n_scans, lsm2d_cloudset** out_set);
 /* The live tracker's form of the same operation: ONE scan into an existing reserved single-cloud set (capacity >= n_beams) --
@@ -304,6 +326,13 @@ int     lsm2d_sweep_create(const int32_t* device_ids, int32_t n_devices, lsm2d_s
 void    lsm2d_sweep_destroy(lsm2d_sweep* sweep);
 int32_t lsm2d_sweep_num_devices(const lsm2d_sweep* sweep);
 const char* lsm2d_sweep_last_error(const lsm2d_sweep* sweep);
+/* "peer_copy": 0 = automatic (default): a replica on another device is filled device to device when hipDeviceCanAccessPeer says the two
+ * devices reach each other (peer access is enabled for the pair once), else -- and whenever a peer copy fails -- straight from the caller's
+ * host buffer; 1 = always from the host buffer (what a node without xGMI / with peer access disabled gets; results do not depend on it).
+ * Read-only: "replicas_by_peer_copy", "replicas_through_host", "replicas_same_device" -- how the replicas of the most recent
+ * lsm2d_sweep_set_map / lsm2d_sweep_set_scans were filled. */
+int     lsm2d_sweep_set_option(lsm2d_sweep* sweep, const char* key, int64_t value);
+int     lsm2d_sweep_get_option(const lsm2d_sweep* sweep, const char* key, int64_t* out_value);
 int     lsm2d_sweep_set_map(lsm2d_sweep* sweep, const float* map_xynn, int64_t n_points);
 /* the distinct scans the candidates refer to: packed back to back, offsets[n_scans + 1] */
 int     lsm2d_sweep_set_scans(lsm2d_sweep* sweep, const float* scans_xynn, const int32_t* offsets, int32_t n_scans);

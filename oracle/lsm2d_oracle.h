@@ -93,6 +93,11 @@ typedef struct {
                                          switch the mirror reproduces the device's poses, H and statistics BIT FOR BIT through all
                                          iterations.  The two orders are
                                          equally valid fp32 evaluations of the same sums. */
+  float termination_chi_epsilon;      /* the aligner's "termination_criteria" (MULTI.json:627-630,729-731: unset in both shipped aligners = always
+                                         max_iterations).  ASSUMED (the upstream class is not in the tree; the solver's SimpleTerminationCriteria,
+                                         MULTI.json:218-223, documents its epsilon as the "ratio of decay of chi2 between iteration"): 0 = off;
+                                         > 0: stop after an iteration whose total chi^2 (inliers + kernelised outliers) differs from the previous
+                                         iteration's by less than epsilon times itself; that iteration is still solved and applied. */
 } lsmo_aligner_params;
 
 typedef struct {

@@ -37,7 +37,8 @@ class SliceParams(C.Structure):
 
 class AlignerParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("min_num_inliers", C.c_int), ("damping", C.c_float),
-                ("has_prior", C.c_int), ("prior_z", C.c_float * 3), ("prior_omega", C.c_float * 9), ("device_order", C.c_int)]
+                ("has_prior", C.c_int), ("prior_z", C.c_float * 3), ("prior_omega", C.c_float * 9), ("device_order", C.c_int),
+                ("termination_chi_epsilon", C.c_float)]
 
 
 class IterStats(C.Structure):
@@ -121,10 +122,12 @@ def slice_params(finder=FINDER_PROJECTIVE, canvas_cols=1081, angle_min=-np.pi, a
     return sp
 
 
-def aligner_params(max_iterations=20, min_num_inliers=10, damping=0.0, prior_z=None, prior_omega=None, device_order=False) -> AlignerParams:
+def aligner_params(max_iterations=20, min_num_inliers=10, damping=0.0, prior_z=None, prior_omega=None, device_order=False,
+                   termination_chi_epsilon=0.0) -> AlignerParams:
     """device_order: sum H, b and the statistics in the HIP kernels' order (fp32 mirror only) -> bit-identical to the device."""
     ap = AlignerParams()
     ap.device_order = 1 if device_order else 0
+    ap.termination_chi_epsilon = termination_chi_epsilon
     ap.max_iterations, ap.min_num_inliers, ap.damping = max_iterations, min_num_inliers, damping
     ap.has_prior = 0 if prior_z is None else 1
     if prior_z is not None:

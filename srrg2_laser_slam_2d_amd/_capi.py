@@ -14,7 +14,7 @@ from . import build as _build
 
 SUCCESS, NOT_ENOUGH_CORRESPONDENCES, NOT_ENOUGH_INLIERS, SINGULAR_H = 0, 1, 2, 3
 BAD_ARGUMENT, DEVICE_ERROR, OUT_OF_MEMORY, CAPACITY_EXCEEDED, NO_DEVICE = -1, -2, -3, -4, -5
-FINDER_PROJECTIVE, FINDER_NN, FINDER_DISTMAP = 0, 1, 2
+FINDER_PROJECTIVE, FINDER_NN, FINDER_DISTMAP, FINDER_KDTREE = 0, 1, 2, 3
 ROBUST_NONE, ROBUST_CAUCHY = 0, 1
 
 
@@ -27,11 +27,13 @@ class SliceParams(C.Structure):
     _fields_ = [("finder", C.c_int32), ("projector", Projector), ("point_distance", C.c_float),
                 ("normal_cos", C.c_float), ("max_distance", C.c_float), ("resolution", C.c_float),
                 ("robustifier", C.c_int32), ("chi_threshold", C.c_float),
-                ("min_num_correspondences", C.c_int32), ("sensor_in_robot", C.c_float * 3)]
+                ("min_num_correspondences", C.c_int32), ("sensor_in_robot", C.c_float * 3),
+                ("kd_max_leaf_range", C.c_float), ("kd_min_leaf_points", C.c_int32)]
 
 
 class AlignerParams(C.Structure):
-    _fields_ = [("max_iterations", C.c_int32), ("min_num_inliers", C.c_int32), ("damping", C.c_float)]
+    _fields_ = [("max_iterations", C.c_int32), ("min_num_inliers", C.c_int32), ("damping", C.c_float),
+                ("termination_chi_epsilon", C.c_float)]
 
 
 class Prior(C.Structure):
@@ -90,6 +92,8 @@ SYMBOLS = [
     ("lsm2d_sweep_destroy", None, [_P]),
     ("lsm2d_sweep_num_devices", C.c_int32, [_P]),
     ("lsm2d_sweep_last_error", C.c_char_p, [_P]),
+    ("lsm2d_sweep_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("lsm2d_sweep_get_option", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     ("lsm2d_sweep_set_map", C.c_int, [_P, _P, C.c_int64]),
     ("lsm2d_sweep_set_scans", C.c_int, [_P, _P, _P, C.c_int32]),
     ("lsm2d_sweep_align", C.c_int, [_P, C.POINTER(AlignerParams), C.POINTER(SliceParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P]),

@@ -103,6 +103,7 @@ class CloudSet:
             total = int(points.shape[0])
             offs = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
             n_clouds = 1 if offs is None else len(offs) - 1
+            _producer_stream_wait(points)
             rc = self._lib.lsm2d_cloudset_create_from_device(
                 ctx.handle, C.c_void_p(points.data_ptr()), None if offs is None else offs.ctypes.data_as(C.c_void_p),
                 n_clouds, total, C.byref(h))
@@ -196,6 +197,15 @@ class CloudSet:
             self.close()
         except Exception:
             pass
+
+
+def _producer_stream_wait(tensor):
+    """A device tensor handed to the C ABI is read on the CONTEXT's stream, which knows nothing about the stream that produced the
+    tensor (torch's current stream): wait for that stream here, so a tensor computed a moment ago is read complete (include/lsm2d.h,
+    ORDERING note).  A context created on torch's own stream would not need this; the wait is cheap when the stream is idle."""
+    if getattr(tensor, "is_cuda", False):
+        import torch
+        torch.cuda.current_stream(tensor.device).synchronize()
 
 
 def _as_cloudset(ctx: Context, cloud) -> CloudSet:
@@ -302,20 +312,30 @@ class CorrespondenceFinderProjective2f(_FinderBase):
 
 
 class CorrespondenceFinderKDTree2D(_FinderBase):
-    """registration/correspondence_finder_kd_tree_2d.{h,cpp} (exact nearest neighbour on the device)"""
-    finder_kind = FINDER_NN
+    """registration/correspondence_finder_kd_tree_2d.{h,cpp}.  ``search``: "exact" (LSM2D_FINDER_NN: exact nearest neighbour on a uniform
+    grid; max_leaf_range / min_leaf_points have no meaning there) or "kdtree" (LSM2D_FINDER_KDTREE: the reference's own tree --
+    KDTree2D(coordinates, max_leaf_range, min_leaf_points), .cpp:36-37 -- and its single-leaf descent, hence approximate).  The SRRG-side
+    sibling (adapters/srrg) defaults to "kdtree"; this mirror keeps "exact" as its default so that existing drivers read unchanged."""
 
     def __init__(self, ctx: Context, max_distance_m: float = 1e-2, normal_cos: float = 0.8,
-                 max_leaf_range: float = 1e-2, min_leaf_points: int = 20):
+                 max_leaf_range: float = 1e-2, min_leaf_points: int = 20, search: str = "exact"):
         super().__init__(ctx)
+        if search not in ("exact", "kdtree"):
+            raise ValueError('search must be "exact" or "kdtree"')
         self.param_max_distance_m = max_distance_m
         self.param_normal_cos = normal_cos
-        self.param_max_leaf_range = max_leaf_range      # kept for config compatibility; the device search is a grid
+        self.param_max_leaf_range = max_leaf_range      # honoured by search="kdtree"
         self.param_min_leaf_points = min_leaf_points
+        self.search = search
+
+    @property
+    def finder_kind(self):
+        return _capi.FINDER_KDTREE if self.search == "kdtree" else FINDER_NN
 
     def slice_params(self, **kw) -> SliceParams:
-        return make_slice_params(finder=FINDER_NN, projector=PointNormal2fProjectorPolar(),
-                                 max_distance=self.param_max_distance_m, normal_cos=self.param_normal_cos, **kw)
+        return make_slice_params(finder=self.finder_kind, projector=PointNormal2fProjectorPolar(),
+                                 max_distance=self.param_max_distance_m, normal_cos=self.param_normal_cos,
+                                 kd_max_leaf_range=self.param_max_leaf_range, kd_min_leaf_points=self.param_min_leaf_points, **kw)
 
     def _capacity(self) -> int:
         return int(self._moving.counts[self._moving_index])
@@ -347,13 +367,14 @@ class CorrespondenceFinderNN2D(_FinderBase):
 def make_slice_params(finder=FINDER_PROJECTIVE, projector: Optional[PointNormal2fProjectorPolar] = None,
                       point_distance=0.5, normal_cos=0.8, max_distance=0.5, resolution=0.05,
                       robustifier=ROBUST_NONE, chi_threshold=0.05, min_num_correspondences=10,
-                      sensor_in_robot=(0.0, 0.0, 0.0)) -> SliceParams:
+                      sensor_in_robot=(0.0, 0.0, 0.0), kd_max_leaf_range=1e-2, kd_min_leaf_points=20) -> SliceParams:
     sp = SliceParams()
     sp.finder = finder
     sp.projector = (projector or PointNormal2fProjectorPolar()).struct()
     sp.point_distance, sp.normal_cos, sp.max_distance, sp.resolution = point_distance, normal_cos, max_distance, resolution
     sp.robustifier, sp.chi_threshold, sp.min_num_correspondences = robustifier, chi_threshold, min_num_correspondences
     sp.sensor_in_robot = (C.c_float * 3)(*[float(v) for v in sensor_in_robot])
+    sp.kd_max_leaf_range, sp.kd_min_leaf_points = float(kd_max_leaf_range), int(kd_min_leaf_points)
     return sp
 
 
@@ -436,11 +457,18 @@ class MultiAligner2D:
     """The upstream aligner as the reference drives it (apps/visual_test_aligner_2d.cpp:123-156), with the
     whole iteration loop running on the device."""
 
-    def __init__(self, ctx: Context, max_iterations: int = 10, min_num_inliers: int = 10, damping: float = 0.0):
+    def __init__(self, ctx: Context, max_iterations: int = 10, min_num_inliers: int = 10, damping: float = 0.0,
+                 termination_chi_epsilon: float = 0.0):
         self._ctx = ctx
         self.param_max_iterations = max_iterations
         self.param_min_num_inliers = min_num_inliers
         self.param_damping = damping
+        # the options both shipped aligners carry at their defaults (MULTI.json:606-610,627-630,704-708,729-731).  The device loop has no
+        # inlier-only re-runs and keeps every correspondence: a non-default value is REFUSED by compute(), never ignored.  The termination
+        # criterion exists as an epsilon on the relative decay of the total chi^2 (lsm2d.h); 0 = not set = max_iterations.
+        self.param_enable_inlier_only_runs = False
+        self.param_keep_only_inlier_correspondences = False
+        self.param_termination_chi_epsilon = termination_chi_epsilon
         self.param_slice_processors: list[AlignerSliceProcessorLaser2D] = []
         self._fixed = {}
         self._moving = {}
@@ -518,7 +546,9 @@ class MultiAligner2D:
                 pr[i].z = (C.c_float * 3)(*np.asarray(z, np.float32).ravel())
                 pr[i].omega = (C.c_float * 9)(*np.asarray(om, np.float32).ravel())
             b.prior = pr
-        ap = AlignerParams(self.param_max_iterations, self.param_min_num_inliers, self.param_damping)
+        if self.param_enable_inlier_only_runs or self.param_keep_only_inlier_correspondences:
+            raise RuntimeError("MultiAligner2D::compute| enable_inlier_only_runs / keep_only_inlier_correspondences are not supported on the device")
+        ap = AlignerParams(self.param_max_iterations, self.param_min_num_inliers, self.param_damping, self.param_termination_chi_epsilon)
         pose = np.empty((n, 3), np.float32); H = np.empty((n, 9), np.float32)
         status = np.empty(n, np.int32); its = np.empty(n, np.int32)
         stats = np.zeros((n, max(self.param_max_iterations, 1)), STATS_DTYPE) if want_stats else None
@@ -727,6 +757,7 @@ class RawDataPreprocessorProjective2D:
         pp = _capi.Preprocessor(r.shape[1], a0, a1, max(m_rmin, self.param_range_min), min(m_rmax, self.param_range_max),   # .cpp:83-84
                                 self.param_normal_point_distance, self.param_normal_min_points, self.param_voxelize_resolution)
         h = C.c_void_p()
+        _producer_stream_wait(r)
         check(self._ctx._lib.lsm2d_preprocess_scans(self._ctx.handle, C.byref(pp), _data_pointer(r), r.shape[0], C.byref(h)),
               "lsm2d_preprocess_scans", self._ctx.handle)
         cs = CloudSet.__new__(CloudSet)

@@ -44,6 +44,9 @@ def source_hash() -> str:
         with open(path, "rb") as f:
             h.update(f.read())
     h.update(" ".join(HIPCC_FLAGS).encode())
+    extra = os.environ.get("LSM2D_EXTRA_HIPCC_FLAGS", "").split()      # a variant build is another instruction stream: its counters are its own
+    if extra:
+        h.update(b"\0extra:" + " ".join(extra).encode())
     return h.hexdigest()
 
 

@@ -34,6 +34,7 @@ struct lsm2d_context {
   void* h_stage = nullptr; size_t h_stage_bytes = 0; void* h_stage_dev = nullptr;
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_split = nullptr; size_t d_split_bytes = 0;      // workspace of the split aligner path
+  void* h_flag = nullptr;                                 // 256 pinned bytes of its own for small read-backs inside a call (the KD-tree build's level counts)
   struct BeamDirs { int n_beams; float angle_min, angle_max; float2* d_dir; };
   std::vector<BeamDirs> beam_dirs;                        // (cos, sin) per beam of the sensors seen so far (lsm2d_preprocess_scan_into)
   int max_dyn_lds = 0;
@@ -46,9 +47,12 @@ struct lsm2d_context {
   int find_path = 0;           // 0 auto (point-query finder calls with more queries than one trip of a workgroup: many workgroups), 1 one workgroup always
   int grid_big_threshold = 16384;   // clouds of at least this many points get their search grid built by the chip-wide kernels (k_grid_big_*)
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
+  int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
+  int kd_lds_nodes = 1024;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it)
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
   long long last_clock_khz = 0;       // in-kernel clock of the most recent timed k_align launch (median over the stamped workgroups), 0 = none
   long long last_wg_lifetime_ns = 0;  // median lifetime of its stamped workgroups
+  long long last_kd_levels = 0, last_kd_nodes = 0;      // shape of the most recently built KD-tree set (levels of the deepest tree, nodes in all of them)
   std::vector<lsm2d_cloudset*> live_sets;      // lsm2d_destroy orphans what is left (a set destroyed after its context must not touch it)
 };
 
@@ -92,10 +96,18 @@ struct DistCache {     // one distance map per (cloud set, max_distance, resolut
   DistMeta* d_meta = nullptr; int32_t* d_parent = nullptr;
 };
 
+struct KdCache {       // one KD-tree per cloud of the set, per (max_leaf_range, min_leaf_points)
+  float max_leaf_range = 0.0f; int min_leaf_points = 0;
+  void* d_block = nullptr;      // one allocation; the pointers below are views into it
+  KdMeta* d_meta = nullptr; float4* d_plane = nullptr; int2* d_link = nullptr; float2* d_leaf_xy = nullptr; int32_t* d_leaf_idx = nullptr;
+  int levels = 0; long long total_nodes = 0; int max_nodes_per_cloud = 0;
+};
+
 struct lsm2d_cloudset {
   lsm2d_context* ctx = nullptr;
   mutable std::vector<GridCache> grids;
   mutable std::vector<DistCache> dists;
+  mutable std::vector<KdCache> kds;
   // lane-chunked copy of xy for k_align's streaming pass (built on first use, dropped when the contents change)
   mutable float4* d_lane_xy = nullptr; mutable long long* d_lane_start = nullptr; mutable int32_t* d_lane_T = nullptr;
   int32_t n_clouds = 0;
@@ -181,6 +193,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   else if (e == hipSuccess) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); c->owns_stream = true; }
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e == hipSuccess) e = hipHostMalloc(&c->h_flag, 256, hipHostMallocDefault);
   if (e != hipSuccess) { g_last_error = hipGetErrorString(e); delete c; return LSM2D_DEVICE_ERROR; }
   // allow the big-canvas configurations to use the whole 160 KiB LDS of a CDNA4 CU
   hipDeviceProp_t prop;
@@ -188,6 +201,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   c->max_dyn_lds = (int) prop.sharedMemPerBlock;
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -208,6 +222,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   (void) hipStreamSynchronize(c->stream); ++c->sync_epoch;
   for (lsm2d_cloudset* cs : c->live_sets) cs->ctx = nullptr;        // still owned by the caller: destroy them any time, use them no more
   if (c->h_stage) (void) hipHostFree(c->h_stage);
+  if (c->h_flag) (void) hipHostFree(c->h_flag);
   if (c->d_scratch) (void) hipFree(c->d_scratch);
   if (c->d_split) (void) hipFree(c->d_split);
   for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
@@ -233,6 +248,8 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "find_path")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_path must be 0 or 1"); ctx->find_path = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { if (value < 1 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_threshold: out of range"); ctx->grid_big_threshold = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
 
@@ -241,6 +258,10 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "kernel_timing")) { *out_value = ctx->kernel_timing ? 1 : 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { *out_value = ctx->align_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { *out_value = ctx->distmap_build; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "last_kd_levels")) { *out_value = ctx->last_kd_levels; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "last_kd_nodes")) { *out_value = ctx->last_kd_nodes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { *out_value = ctx->grid_big_threshold; return LSM2D_SUCCESS; }
   if (!strcmp(key, "find_path")) { *out_value = ctx->find_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "zero_copy_max")) { *out_value = ctx->zero_copy_max; return LSM2D_SUCCESS; }
@@ -383,6 +404,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_count) (void) hipFree(cs->d_count);
   for (auto& g : cs->grids) if (g.d_block) (void) hipFree(g.d_block);
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
+  for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block);
   if (cs->d_lane_xy) (void) hipFree(cs->d_lane_xy);
   if (cs->d_lane_start) (void) hipFree(cs->d_lane_start);
   if (cs->d_lane_T) (void) hipFree(cs->d_lane_T);
@@ -470,6 +492,8 @@ static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents 
   if (cs->d_lane_T) { (void) hipFree(cs->d_lane_T); cs->d_lane_T = nullptr; }
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   cs->dists.clear();
+  for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block);
+  cs->kds.clear();
 }
 
 extern "C" int lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capacity, lsm2d_cloudset** out) {
@@ -605,6 +629,7 @@ static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   c.lane_xy = cs->d_lane_xy; c.lane_start = cs->d_lane_start; c.lane_T = cs->d_lane_T;
   c.grid = GridDev{nullptr, nullptr, nullptr, nullptr};
   c.dist = DistDev{nullptr, nullptr};
+  c.kd = KdDev{nullptr, nullptr, nullptr, nullptr, nullptr};
   return c;
 }
 // NN finder: uniform grid over every cloud of the (fixed) set, cached per max_distance.  Replaces
@@ -666,6 +691,84 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   g.d_block = t_block.release();      // owned by the cache from here on
   cs->grids.push_back(g);
   *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy};
+  return LSM2D_SUCCESS;
+}
+
+// KD-tree finder: CorrespondenceFinderKDTree2D::reset() (registration/correspondence_finder_kd_tree_2d.cpp:31-38) for every cloud of the
+// (fixed) set, cached per (max_leaf_range, min_leaf_points).  Built on the device, level by level (k_kd_level: one wave per node); the
+// host only learns, after each level, how many nodes the next one has.
+static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_leaf_range, int min_leaf_points, KdDev* out, const KdCache** out_cache = nullptr) {
+  if (!(max_leaf_range > 0.0f)) max_leaf_range = 1e-2f;         // the class defaults (correspondence_finder_kd_tree_2d.h:26-33), as the oracle applies them
+  if (min_leaf_points <= 0) min_leaf_points = 20;
+  for (const auto& k : cs->kds)
+    if (k.max_leaf_range == max_leaf_range && k.min_leaf_points == min_leaf_points) {
+      *out = KdDev{k.d_meta, k.d_plane, k.d_link, k.d_leaf_xy, k.d_leaf_idx}; if (out_cache) *out_cache = &k; return LSM2D_SUCCESS;
+    }
+  const int nc = cs->n_clouds;
+  // a cloud of n points has at most 2 n - 1 nodes (every split leaves both children non-empty); an empty cloud still has its root
+  std::vector<KdMeta> meta((size_t) nc);
+  long long nodes = 0;
+  for (int c = 0; c < nc; ++c) {
+    meta[(size_t) c].node_base = (int32_t) nodes; meta[(size_t) c].n_nodes = 0; meta[(size_t) c].pad0 = meta[(size_t) c].pad1 = 0;
+    nodes += 2ll * cs->h_count[c] > 2 ? 2ll * cs->h_count[c] : 2;
+    if (nodes > 0x7ffffff0ll) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "kdtree: too many nodes");
+  }
+  const size_t np = (size_t) cs->padded_total, nq = np / 2 + (size_t) nc + 2;
+  constexpr int kMaxLevels = 8192;
+  KdCache kc; kc.max_leaf_range = max_leaf_range; kc.min_leaf_points = min_leaf_points;
+  DevTmp t_block, t_work;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
+  const size_t o_meta = take(sizeof(KdMeta) * (size_t) nc), o_plane = take(sizeof(float4) * (size_t) nodes), o_link = take(sizeof(int2) * (size_t) nodes);
+  const size_t o_lxy = take(sizeof(float2) * np), o_lidx = take(sizeof(int32_t) * np);
+  HIPCHK(ctx, hipMalloc(&t_block.p, off));
+  char* blk = (char*) t_block.p;
+  kc.d_meta = (KdMeta*) (blk + o_meta); kc.d_plane = (float4*) (blk + o_plane); kc.d_link = (int2*) (blk + o_link);
+  kc.d_leaf_xy = (float2*) (blk + o_lxy); kc.d_leaf_idx = (int32_t*) (blk + o_lidx);
+  // working set of the build: two ping-pong copies of (xy, idx), two queues, per-cloud node counters, one queue counter per level
+  off = 0;
+  const size_t w_xy0 = take(sizeof(float2) * np), w_xy1 = take(sizeof(float2) * np), w_ix0 = take(sizeof(int32_t) * np), w_ix1 = take(sizeof(int32_t) * np);
+  const size_t w_q0 = take(sizeof(int4) * nq), w_q1 = take(sizeof(int4) * nq), w_nn = take(sizeof(int32_t) * (size_t) nc), w_cnt = take(sizeof(int32_t) * (size_t) (kMaxLevels + 1));
+  HIPCHK(ctx, hipMalloc(&t_work.p, off));
+  char* wk = (char*) t_work.p;
+  float2* xyb[2] = {(float2*) (wk + w_xy0), (float2*) (wk + w_xy1)}; int32_t* ixb[2] = {(int32_t*) (wk + w_ix0), (int32_t*) (wk + w_ix1)};
+  int4* qb[2] = {(int4*) (wk + w_q0), (int4*) (wk + w_q1)};
+  int32_t* d_nn = (int32_t*) (wk + w_nn); int32_t* d_cnt = (int32_t*) (wk + w_cnt);
+  HIPCHK(ctx, hipMemcpyAsync(kc.d_meta, meta.data(), sizeof(KdMeta) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t) (kMaxLevels + 1), ctx->stream));
+  hipLaunchKernelGGL(k_kd_init, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) cs->d_count, nc, qb[0], d_nn);
+  HIPCHK(ctx, hipGetLastError());
+  KdBuildArgs B;
+  B.start = cs->d_start; B.meta = kc.d_meta; B.plane = kc.d_plane; B.link = kc.d_link; B.n_nodes = d_nn;
+  B.leaf_xy = kc.d_leaf_xy; B.leaf_idx = kc.d_leaf_idx; B.max_leaf_range = max_leaf_range; B.min_leaf_points = min_leaf_points;
+  long long n_items = nc; int level = 0;
+  volatile int32_t* h_cnt = (volatile int32_t*) ctx->h_flag;
+  while (n_items > 0) {
+    if (level >= kMaxLevels) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "kdtree: deeper than 8192 levels");
+    B.xy_in = level == 0 ? cs->d_xy : xyb[level & 1]; B.idx_in = level == 0 ? nullptr : ixb[level & 1];
+    B.xy_out = xyb[(level + 1) & 1]; B.idx_out = ixb[(level + 1) & 1];
+    B.q_in = qb[level & 1]; B.q_out = qb[(level + 1) & 1]; B.q_out_count = d_cnt + level + 1; B.n_items = (int32_t) n_items;
+    const unsigned blocks = (unsigned) ((n_items + 3) / 4);
+    if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_level<1>, dim3(blocks), dim3(256), 0, ctx->stream, B);
+    else hipLaunchKernelGGL(k_kd_level<0>, dim3(blocks), dim3(256), 0, ctx->stream, B);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync((void*) h_cnt, d_cnt + level + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, stream_sync(ctx));
+    n_items = h_cnt[0];
+    ++level;
+  }
+  hipLaunchKernelGGL(k_kd_finish, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) d_nn, nc, kc.d_meta);
+  HIPCHK(ctx, hipGetLastError());
+  std::vector<int32_t> h_nn((size_t) nc);
+  HIPCHK(ctx, hipMemcpyAsync(h_nn.data(), d_nn, sizeof(int32_t) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
+  kc.levels = level; kc.total_nodes = 0; kc.max_nodes_per_cloud = 0;
+  for (int c = 0; c < nc; ++c) { kc.total_nodes += h_nn[(size_t) c]; if (h_nn[(size_t) c] > kc.max_nodes_per_cloud) kc.max_nodes_per_cloud = h_nn[(size_t) c]; }
+  ctx->last_kd_levels = level; ctx->last_kd_nodes = kc.total_nodes;
+  kc.d_block = t_block.release();      // owned by the cache from here on (the working set goes with its guard)
+  cs->kds.push_back(kc);
+  *out = KdDev{kc.d_meta, kc.d_plane, kc.d_link, kc.d_leaf_xy, kc.d_leaf_idx};
+  if (out_cache) *out_cache = &cs->kds.back();
   return LSM2D_SUCCESS;
 }
 
@@ -1179,19 +1282,21 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
   { int rc0 = resolve_count(fixed); if (rc0) return rc0; rc0 = resolve_count(moving); if (rc0) return rc0; }
   { int rc0 = flush_pending(fixed); if (rc0) return rc0; rc0 = flush_pending(moving); if (rc0) return rc0; }
   *out_n = 0;
-  if (sp->finder == LSM2D_FINDER_NN || sp->finder == LSM2D_FINDER_DISTMAP) {
-    if (sp->finder == LSM2D_FINDER_NN && !(sp->max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: max_distance must be > 0");
+  if (sp->finder == LSM2D_FINDER_NN || sp->finder == LSM2D_FINDER_DISTMAP || sp->finder == LSM2D_FINDER_KDTREE) {
+    if (sp->finder != LSM2D_FINDER_DISTMAP && !(sp->max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: max_distance must be > 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     FindNNArgs N;
     N.fixed = cloud_dev(fixed, nullptr); N.moving = cloud_dev(moving, nullptr); N.fc = fi; N.mc = mi;
-    N.use_distmap = sp->finder == LSM2D_FINDER_DISTMAP;
-    int rc = N.use_distmap ? ensure_distmap(ctx, fixed, sp->max_distance, sp->resolution, &N.fixed.dist) : ensure_grid(ctx, fixed, sp->max_distance, &N.fixed.grid);
+    N.use_distmap = sp->finder == LSM2D_FINDER_DISTMAP; N.use_kd = sp->finder == LSM2D_FINDER_KDTREE;
+    int rc = N.use_distmap ? ensure_distmap(ctx, fixed, sp->max_distance, sp->resolution, &N.fixed.dist)
+           : N.use_kd      ? ensure_kdtree(ctx, fixed, sp->kd_max_leaf_range, sp->kd_min_leaf_points, &N.fixed.kd)
+                           : ensure_grid(ctx, fixed, sp->max_distance, &N.fixed.grid);
     if (rc) return rc;
     const size_t nm = (size_t) moving->h_count[mi], bytes = nm * 8 + 16;
     N.max_distance = sp->max_distance; N.normal_cos = sp->normal_cos; N.T = make_iso(pose);
     N.nn_group = fixed->h_count[fi] >= 4 * (int64_t) moving->h_count[mi] ? kNNGroup : 1;     // dense fixed cloud: cooperative search
     // more queries than one workgroup takes in a trip: one workgroup per trip's worth, two launches (search, then ordered compaction)
-    const int per_step = kFindBlock / (N.use_distmap ? 1 : N.nn_group);
+    const int per_step = kFindBlock / ((N.use_distmap || N.use_kd) ? 1 : N.nn_group);
     const int n_blocks = (int) ((nm + (size_t) per_step - 1) / (size_t) per_step);
     const bool multi = n_blocks > 2 && ctx->find_path != 1;      // (two trips of one workgroup beat two launches: 23 vs 29 us for 1081 distance-map queries)
     const size_t o_match = (bytes + 255) & ~(size_t) 255, o_cnt = o_match + ((nm * 4 + 255) & ~(size_t) 255);
@@ -1321,6 +1426,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
 
   AlignArgs A; memset(&A, 0, sizeof A);
   A.n_align = n; A.n_slices = ns; A.max_it = ap->max_iterations; A.min_inliers = ap->min_num_inliers; A.damping = ap->damping;
+  if (!(ap->termination_chi_epsilon >= 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: termination_chi_epsilon must be >= 0");
+  A.term_eps = ap->termination_chi_epsilon;
   // ---- device scratch layout: [init_pose | prior | indices | out_pose | out_H | status | its | stats]
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
@@ -1344,15 +1451,15 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   char* hs = (char*) ctx->h_stage; char* ds = (char*) ctx->d_scratch;
 
   // ---- which path: few alignments against a big cloud are spread over many workgroups each (projective slices only)
-  bool has_proj = false, has_nn = false, has_dist = false;
+  bool has_proj = false, has_nn = false, has_dist = false, has_kd = false;
   int max_moving = 0;
   for (int s = 0; s < ns; ++s) {
     const int fd = b->slices[s].finder;
-    if (fd == LSM2D_FINDER_PROJECTIVE) has_proj = true; else if (fd == LSM2D_FINDER_NN) has_nn = true; else has_dist = true;
+    if (fd == LSM2D_FINDER_PROJECTIVE) has_proj = true; else if (fd == LSM2D_FINDER_NN) has_nn = true; else if (fd == LSM2D_FINDER_KDTREE) has_kd = true; else has_dist = true;
     const lsm2d_cloudset* m = b->moving[s];
     if (m) for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] > max_moving) max_moving = m->h_count[c];
   }
-  const bool split_ok = has_proj && !has_nn && !has_dist && ap->max_iterations > 0 && n <= 32768;
+  const bool split_ok = has_proj && !has_nn && !has_dist && !has_kd && ap->max_iterations > 0 && n <= 32768;
   // measured (tools/small_batch_bench.py, profiles/r01/small_batch*.jsonl): the split path costs two launches per iteration per
   // alignment call and wins whenever one workgroup per alignment would leave most of the chip idle for long enough
   const bool use_split = split_ok && (ctx->align_path == 2 ||
@@ -1362,7 +1469,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   // three small transfers and their launch latencies off the critical path of the call.
   // (Not for big batches: with 1000 alignments reading their start poses and writing their results over the host link the step takes 1.485 ms
   // against 1.467 with the three small transfers; tools/zero_copy_ab.py.)
-  const bool zero_copy = !use_split && (n <= 256 || (n <= ctx->zero_copy_max && !b->fixed_index && !b->moving_index));
+  // ("zero_copy_max" bounds every batch, so the A/B knob works below 256 too; batches that carry index arrays stay on the transfers above 256)
+  const bool zero_copy = !use_split && n <= ctx->zero_copy_max && (n <= 256 || (!b->fixed_index && !b->moving_index));
   if (zero_copy) ds = (char*) ctx->h_stage_dev;
 
   // ---- slices
@@ -1375,6 +1483,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     const int prc = flush_preprocessing_together(ctx, rd, nr); if (prc) return prc;
   }
   int cols_max = 0, fcan_total = 0;
+  const KdCache* kd_cache0 = nullptr;      // the KD-tree set of the (last) KD-tree slice
   for (int s = 0; s < ns; ++s) {
     const lsm2d_slice_params& sp = b->slices[s];
     SliceDev& S = A.s[s];
@@ -1383,12 +1492,12 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     // sizes that only the device knows yet (asynchronous clip / merge) are fine for the projective finder -- the kernels read the
     // device-side counts and the host needs upper bounds only; the search structures of the other finders need the numbers
     if (sp.finder != LSM2D_FINDER_PROJECTIVE) { int rc0 = resolve_count(f); if (rc0) return rc0; rc0 = resolve_count(m); if (rc0) return rc0; }
-    if (sp.finder != LSM2D_FINDER_PROJECTIVE && sp.finder != LSM2D_FINDER_NN && sp.finder != LSM2D_FINDER_DISTMAP)
+    if (sp.finder != LSM2D_FINDER_PROJECTIVE && sp.finder != LSM2D_FINDER_NN && sp.finder != LSM2D_FINDER_DISTMAP && sp.finder != LSM2D_FINDER_KDTREE)
       return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: unknown finder");
     if (sp.finder == LSM2D_FINDER_PROJECTIVE) {
       if (!make_projk(sp.projector, &S.proj)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad projector");
     } else {
-      if (sp.finder == LSM2D_FINDER_NN && !(sp.max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: max_distance must be > 0");
+      if ((sp.finder == LSM2D_FINDER_NN || sp.finder == LSM2D_FINDER_KDTREE) && !(sp.max_distance > 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: max_distance must be > 0");
       memset(&S.proj, 0, sizeof S.proj);
     }
     if (!b->fixed_index && f->n_clouds != 1 && f->n_clouds != n) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: fixed set must hold 1 or n_alignments clouds");
@@ -1406,7 +1515,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     }
     // a fixed set whose upload still sits in its pinned buffer: single-alignment projective calls unpack it in the kernel's prologue
     // (decided once the kernel is known, below); every other reader gets it unpacked by a launch of its own, here
-    const bool defer_unpack = f->unpack_pending && n == 1 && !use_split && has_proj && !has_nn && !has_dist && f != m;
+    const bool defer_unpack = f->unpack_pending && n == 1 && !use_split && has_proj && !has_nn && !has_dist && !has_kd && f != m;
     if (!defer_unpack) { const int urc = flush_pending(f); if (urc) return urc; }
     { const int urc = flush_pending(m); if (urc) return urc; }
     if (sp.finder == LSM2D_FINDER_PROJECTIVE) { const int lrc = ensure_lane_layout(ctx, m); if (lrc) return lrc; }
@@ -1414,6 +1523,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     S.unpack_src = defer_unpack ? (const float4*) f->h_upload_dev : nullptr; S.unpack_n = defer_unpack ? f->h_count[0] : 0;
     if (sp.finder == LSM2D_FINDER_NN) { const int grc = ensure_grid(ctx, f, sp.max_distance, &S.fixed.grid); if (grc) return grc; }
     if (sp.finder == LSM2D_FINDER_DISTMAP) { const int grc = ensure_distmap(ctx, f, sp.max_distance, sp.resolution, &S.fixed.dist); if (grc) return grc; }
+    if (sp.finder == LSM2D_FINDER_KDTREE) { const int grc = ensure_kdtree(ctx, f, sp.kd_max_leaf_range, sp.kd_min_leaf_points, &S.fixed.kd, &kd_cache0); if (grc) return grc; }
     {   // cooperative NN search pays when the fixed cloud is much denser than the queries (map as fixed, scans as queries)
       int64_t mf = 0, mm = 1;
       for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > mf) mf = f->h_count[c];
@@ -1441,13 +1551,21 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     const size_t need = sizeof(float2) * (size_t) mf + sizeof(uint16_t) * ((size_t) cap * cap + 4) + sizeof(uint16_t) * ((size_t) mf + 2);
     if (mf > 0 && mf <= 65535 && need <= 38 * 1024 - lds) { A.nn_lds_points = mf; A.nn_lds_cells = cap * cap + 1; lds += need + 16; }
   }
+  // one KD-tree slice: the top of the fixed cloud's tree (up to "kd_lds_nodes" nodes, 24 bytes each) rides in LDS -- same 38 KB budget
+  A.kd_lds_nodes = 0;
+  if (ns == 1 && b->slices[0].finder == LSM2D_FINDER_KDTREE && kd_cache0 && ctx->kd_lds_nodes > 0) {
+    int k = kd_cache0->max_nodes_per_cloud < ctx->kd_lds_nodes ? kd_cache0->max_nodes_per_cloud : ctx->kd_lds_nodes;
+    const size_t room = lds < 38 * 1024 ? (38 * 1024 - lds) / (sizeof(float4) + sizeof(int2)) : 0;
+    if ((size_t) k > room) k = (int) room;
+    if (k > 0) { A.kd_lds_nodes = k; lds += (size_t) k * (sizeof(float4) + sizeof(int2)) + 16; }
+  }
   if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
   // one or two projective slices and too few alignments to fill the chip (the live tracker: one alignment per scan): the latency
   // kernel (k_align_pair; bit-identical sums) -- 512 threads per slice, two slices' passes side by side instead of one after the
   // other, registers to spare for the serial solve step.  Measured against k_align on single-slice calls (tools/latency_kernel_ab.py):
   // 1 scan vs 10k points 0.163 -> 0.146 ms, vs a 700-point clipped scene with prior 0.063 -> 0.045, 256 candidates 0.172 -> 0.154
   const size_t lds_pair = lds + (size_t) (ns - 1) * (sizeof(u64) * (size_t) cols_max + sizeof(float) * kAccumWords * (kAlignBlock / 64));
-  const bool use_pair = !use_split && ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist &&
+  const bool use_pair = !use_split && ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist && !has_kd &&
                         (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0 && (int) lds_pair + 512 <= ctx->max_dyn_lds;
 
   // ---- inputs
@@ -1518,10 +1636,12 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   } else {
     const dim3 grid((unsigned) n), block(kAlignBlock);
     if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3((unsigned) (kAlignBlock * ns)), lds_pair, ctx->stream, A);
-    else if (has_proj && !has_nn && !has_dist) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
-    else if (!has_proj && has_nn && !has_dist) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
-    else if (!has_proj && !has_nn && has_dist) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
-    else hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
+    else if (has_proj && !has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
+    else if (!has_proj && has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
+    else if (!has_proj && !has_nn && has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
+    else if (!has_proj && !has_nn && !has_dist && has_kd) hipLaunchKernelGGL((k_align<false, false, false, true>), grid, block, lds, ctx->stream, A);
+    else if (!has_kd) hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
+    else hipLaunchKernelGGL((k_align<true, true, true, true>), grid, block, lds, ctx->stream, A);              // mixed finders, one of them the KD-tree
   }
   HIPCHK(ctx, hipGetLastError());
   for (int s = 0; s < ns; ++s)                  // sets the kernel's prologue unpacks (SliceDev::unpack_src)
@@ -1566,6 +1686,8 @@ struct lsm2d_sweep {
   std::vector<lsm2d_context*> ctx;
   std::vector<lsm2d_cloudset*> map, scans;
   std::string last_error;
+  int peer_copy = 0;                                                  // 0 automatic, 1 replicas always filled from the host buffer
+  long long by_peer = 0, through_host = 0, same_device = 0;           // how the replicas of the last set_map / set_scans were filled
 };
 static int sweep_fail(lsm2d_sweep* sw, int code, const std::string& msg) { if (sw) sw->last_error = msg; g_last_error = msg; return code; }
 static void sweep_drop(std::vector<lsm2d_cloudset*>& v) { for (auto* s : v) lsm2d_cloudset_destroy(s); v.clear(); }
@@ -1590,6 +1712,19 @@ extern "C" void lsm2d_sweep_destroy(lsm2d_sweep* sw) {
   delete sw;
 }
 extern "C" int32_t lsm2d_sweep_num_devices(const lsm2d_sweep* sw) { return sw ? (int32_t) sw->ctx.size() : 0; }
+extern "C" int lsm2d_sweep_set_option(lsm2d_sweep* sw, const char* key, int64_t value) {
+  if (!sw || !key) return fail(nullptr, LSM2D_BAD_ARGUMENT, "sweep_set_option: bad argument");
+  if (!strcmp(key, "peer_copy")) { if (value < 0 || value > 1) return sweep_fail(sw, LSM2D_BAD_ARGUMENT, "peer_copy must be 0 or 1"); sw->peer_copy = (int) value; return LSM2D_SUCCESS; }
+  return sweep_fail(sw, LSM2D_BAD_ARGUMENT, "sweep_set_option: unknown option");
+}
+extern "C" int lsm2d_sweep_get_option(const lsm2d_sweep* sw, const char* key, int64_t* out) {
+  if (!sw || !key || !out) return fail(nullptr, LSM2D_BAD_ARGUMENT, "sweep_get_option: bad argument");
+  if (!strcmp(key, "peer_copy")) { *out = sw->peer_copy; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "replicas_by_peer_copy")) { *out = sw->by_peer; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "replicas_through_host")) { *out = sw->through_host; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "replicas_same_device")) { *out = sw->same_device; return LSM2D_SUCCESS; }
+  return fail(nullptr, LSM2D_BAD_ARGUMENT, "sweep_get_option: unknown option");
+}
 extern "C" const char* lsm2d_sweep_last_error(const lsm2d_sweep* sw) { return sw ? sw->last_error.c_str() : g_last_error.c_str(); }
 
 // one host cloud set replicated on every device of the sweep: host -> first device once, then device -> device
@@ -1602,12 +1737,32 @@ static int sweep_replicate(lsm2d_sweep* sw, const float* pts, const int32_t* off
   if (hipSetDevice(c0->device) != hipSuccess || hipMalloc(&d0, bytes) != hipSuccess) return sweep_fail(sw, LSM2D_OUT_OF_MEMORY, "sweep: staging allocation failed");
   if (total > 0 && hipMemcpy(d0, pts, sizeof(float) * 4 * (size_t) total, hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d0); return sweep_fail(sw, LSM2D_DEVICE_ERROR, "sweep: upload failed"); }
   int rc = LSM2D_SUCCESS;
+  sw->by_peer = sw->through_host = sw->same_device = 0;
   for (size_t r = 0; r < sw->ctx.size() && rc == LSM2D_SUCCESS; ++r) {
     lsm2d_context* c = sw->ctx[r];
     void* dr = d0;
-    if (r > 0) {      // a replica of its own, filled over the fabric (xGMI between the GPUs of a node) -- never through the host again
+    if (r > 0) {      // a replica of its own: over the fabric (xGMI between the GPUs of a node) where the two devices reach each other, else from the host buffer
       if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&dr, bytes) != hipSuccess) { rc = sweep_fail(sw, LSM2D_OUT_OF_MEMORY, "sweep: replica allocation failed"); break; }
-      if (total > 0 && hipMemcpyPeer(dr, c->device, d0, c0->device, sizeof(float) * 4 * (size_t) total) != hipSuccess) { (void) hipFree(dr); rc = sweep_fail(sw, LSM2D_DEVICE_ERROR, "sweep: device-to-device copy failed"); break; }
+      const size_t nbytes = sizeof(float) * 4 * (size_t) total;
+      bool done = total == 0;
+      if (!done && sw->peer_copy == 0) {
+        if (c->device == c0->device) {                        // a rehearsal of several shards on one device: a plain device-to-device copy
+          done = hipMemcpy(dr, d0, nbytes, hipMemcpyDeviceToDevice) == hipSuccess;
+          if (done) ++sw->same_device;
+        } else {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, c->device, c0->device) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(c0->device, 0);      // current device: c->device; once per pair
+            if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) done = hipMemcpyPeer(dr, c->device, d0, c0->device, nbytes) == hipSuccess;
+            if (done) ++sw->by_peer;
+          }
+        }
+        (void) hipGetLastError();                             // a refused peer path is not an error: the host path follows
+      }
+      if (!done) {                                            // no peer access (or switched off, or the peer copy failed): the caller's host buffer is the source
+        if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(dr, pts, nbytes, hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(dr); rc = sweep_fail(sw, LSM2D_DEVICE_ERROR, "sweep: replica upload failed"); break; }
+        ++sw->through_host;
+      }
     }
     lsm2d_cloudset* set = nullptr;
     rc = lsm2d_cloudset_create_from_device(c, dr, offsets, n_clouds, total, &set);
@@ -1637,12 +1792,17 @@ extern "C" int lsm2d_sweep_align(lsm2d_sweep* sw, const lsm2d_aligner_params* ap
   const int G = (int) sw->ctx.size();
   const int n_scans = lsm2d_cloudset_num_clouds(sw->scans[0]);
   if (!scan_index && n_scans != n_candidates && n_scans != 1) return sweep_fail(sw, LSM2D_BAD_ARGUMENT, "sweep_align: scan_index needed unless there is one scan per candidate");
-  std::vector<int> rcs((size_t) G, LSM2D_SUCCESS);
-  std::vector<std::thread> workers;
-  for (int r = 0; r < G; ++r) {
+  // no exception crosses the C ABI: allocation failures inside a worker become that device's status, a failure to start a thread joins
+  // the ones already running and returns LSM2D_OUT_OF_MEMORY
+  std::vector<int> rcs; std::vector<std::thread> workers;
+  try { rcs.assign((size_t) G, LSM2D_SUCCESS); workers.reserve((size_t) G); } catch (...) { return sweep_fail(sw, LSM2D_OUT_OF_MEMORY, "sweep_align: out of memory"); }
+  bool spawn_failed = false;
+  for (int r = 0; r < G && !spawn_failed; ++r) {
     const long long lo = (long long) n_candidates * r / G, hi = (long long) n_candidates * (r + 1) / G;
     if (hi <= lo) continue;
+    try {
     workers.emplace_back([=, &rcs]() {
+      try {
       const int n = (int) (hi - lo);
       // without an index array candidate i uses scan i: the shard needs an explicit index then (its scans start at lo)
       std::vector<int32_t> own_index;
@@ -1664,9 +1824,12 @@ extern "C" int lsm2d_sweep_align(lsm2d_sweep* sw, const lsm2d_aligner_params* ap
           lsm2d_iteration_stats z; memset(&z, 0, sizeof z);
           out_last_stats[lo + i] = its[(size_t) i] > 0 ? stats[(size_t) i * (size_t) ap->max_iterations + (size_t) (its[(size_t) i] - 1)] : z;
         }
+      } catch (const std::bad_alloc&) { rcs[(size_t) r] = LSM2D_OUT_OF_MEMORY; } catch (...) { rcs[(size_t) r] = LSM2D_DEVICE_ERROR; }
     });
+    } catch (...) { spawn_failed = true; }      // std::system_error from the thread constructor, bad_alloc from the vector
   }
   for (auto& w : workers) w.join();
+  if (spawn_failed) return sweep_fail(sw, LSM2D_OUT_OF_MEMORY, "sweep_align: could not start a worker thread");
   for (int r = 0; r < G; ++r) if (rcs[(size_t) r] != LSM2D_SUCCESS) return sweep_fail(sw, rcs[(size_t) r], std::string("sweep_align: device ") + std::to_string(r) + ": " + lsm2d_last_error(sw->ctx[(size_t) r]));
   return LSM2D_SUCCESS;
 }

@@ -94,9 +94,13 @@ LSM2D_DEV float wrap_angle(float a) {
 //   t   = RN(min / r)           correctly rounded quotient = sin of the octant angle, t in [0, sqrt(1/2)]: one Newton step takes the
 //                                seed to 1/r, then Markstein's residual correction
 //   phi = t + t s P(s), s = t t  asin on [0, sqrt(1/2)], degree-6 P (tools/fit_asin.py: max abs error 4.6e-8 rad)
-// Every step is IEEE fp32 (fmaf, sqrt, divide), so the CPU restatement reproduces r, t and phi bit for bit with sqrtf and '/';
-// tools/fp_exact_check.hip proves the two short sequences correctly rounded on this chip's v_rsq_f32 for EVERY input the range gate
-// lets through (all r2 bit patterns in [1e-30, 1e37]; for the quotient all 2^23 mantissas of `min` against each of them).
+// Every step is IEEE fp32 (fmaf, sqrt, divide), so the CPU restatement reproduces r, t and phi bit for bit with sqrtf and '/'
+// -- with ONE enumerated exception: tools/fp_exact_check.hip runs the two short sequences on this chip's v_rsq_f32 over EVERY input the
+// range gate lets through (all r2 bit patterns in [1e-30, 1e37]; for the quotient all 2^23 mantissas of `min` against each of them):
+// the square root is correctly rounded everywhere, the quotient everywhere except the exact ties its last fused step cannot see (r with
+// an all-ones mantissa, `min` a power of two: the float BELOW the IEEE quotient comes out -- 4 inputs per binade).  The oracle's
+// definition of the quotient follows the device on those ties (the CPU restatement's atan2 says so in its source), so CPU / GPU parity on them holds
+// because the restatement mirrors the sequence, not because the sequence is exact.
 
 // Correctly rounded sqrt for inputs in [1e-30, FLT_MAX] (the range gate's r2 and beyond); y0 returns the v_rsq_f32 seed.
 LSM2D_DEV float sqrt_rn_seed(float x, float& y0) {
@@ -107,7 +111,8 @@ LSM2D_DEV float sqrt_rn_seed(float x, float& y0) {
 }
 LSM2D_DEV float sqrt_rn_normal(float x) { float y0; return sqrt_rn_seed(x, y0); }
 
-// IEEE-754 correctly rounded n / r for r = sqrt_rn(r2), y0 = v_rsq_f32(r2), 1e-12 <= n <= r.  n < 1e-12 (a quotient that could be
+// n / r for r = sqrt_rn(r2), y0 = v_rsq_f32(r2), 1e-12 <= n <= r: the IEEE-754 correctly rounded quotient except on the enumerated exact
+// ties described above (one ulp low there; the oracle mirrors them).  n < 1e-12 (a quotient that could be
 // subnormal, and n == 0) takes the compiler's full divide unless the host has proved that such a quotient cannot move a column
 // (ProjK::tiny_ok; then kGuardTiny = false and the branch is gone).
 template <bool kGuardTiny>

@@ -57,6 +57,52 @@ LSM2D_DEV int distmap_lookup(const DistMeta& d, const int32_t* __restrict__ pare
   return v < 0 ? -1 : (v & d.gmask);
 }
 
+// The reference's own search structure (LSM2D_FINDER_KDTREE): KDTree2D(coordinates, max_leaf_range, min_leaf_points) built in
+// CorrespondenceFinderKDTree2D::reset() (registration/correspondence_finder_kd_tree_2d.cpp:31-38) and searched by findNeighbor (.cpp:18-19),
+// restated as SURVEY.md App. A.4 believes upstream implements them (the CPU restatement's kd_build_node / kd_find mirror it).  One tree per
+// cloud of the set.  Node k of cloud c lives at meta[c].node_base + k (node 0 = root; the two children of a node are adjacent; nodes of a
+// level come before the nodes of the next): plane = (mean x, mean y, normal x, normal y) of the splitting plane; link.x >= 0: the LEFT
+// child's id (the right one is link.x + 1); link.x < 0: a leaf holding the points [-1 - link.x, link.y) of the cloud's leaf arrays.
+// leaf_xy / leaf_idx: the cloud's coordinates / original indices permuted into leaf order (ascending original index inside a leaf, as
+// the reference's stable partition leaves them) at the cloud's own offset start[c].
+struct KdMeta { int32_t node_base, n_nodes, pad0, pad1; };
+struct KdDev {
+  const KdMeta*  meta;       // [n_clouds]
+  const float4*  plane;      // [total nodes]
+  const int2*    link;       // [total nodes]
+  const float2*  leaf_xy;    // [padded total]
+  const int32_t* leaf_idx;   // [padded total]
+};
+
+// findNeighbor as the reference calls it (correspondence_finder_kd_tree_2d.cpp:18-19): descend to the ONE leaf on the query's side of
+// every splitting plane (no backtracking), scan it for the nearest point with squared distance < md2; first point wins ties, i.e. the
+// lowest original index; none -> -1 (.cpp:21).  The operation sequence is the oracle's kd_find: the plane test is two products and a sum,
+// NOT fused (the library is built with -ffp-contract=off); the distance is the fused form every finder of this library uses.
+// lds_nodes > 0: the first lds_nodes nodes of the tree (its top levels) are staged in LDS (l_plane / l_link) -- a descent pays one LDS
+// round trip per level up there instead of one trip to L2.
+LSM2D_DEV int kd_query(const float4* __restrict__ plane, const int2* __restrict__ link, const float2* __restrict__ lxy,
+                       const int32_t* __restrict__ lidx, float qx, float qy, float md2,
+                       const float4* l_plane = nullptr, const int2* l_link = nullptr, int lds_nodes = 0) {
+  int k = 0;
+  int2 L = lds_nodes > 0 ? l_link[0] : link[0];
+  while (L.x >= 0) {
+    const float4 P = k < lds_nodes ? l_plane[k] : plane[k];
+    const float t = (qx - P.x) * P.z + (qy - P.y) * P.w;
+    k = L.x + (t < 0.0f ? 0 : 1);
+    L = k < lds_nodes ? l_link[k] : link[k];
+  }
+  const int b = -1 - L.x, e = L.y;
+  int best = -1; float bd = md2;
+  // two candidates per trip, both loads in flight; the index of a candidate is read only when it improves on the best so far
+  for (int j = b; j < e; j += 2) {
+    const bool h1 = j + 1 < e;
+    const float2 p0 = lxy[j], p1 = lxy[h1 ? j + 1 : j];
+    { const float dx = p0.x - qx, dy = p0.y - qy; const float d2 = __builtin_fmaf(dx, dx, dy * dy); if (d2 < bd) { bd = d2; best = lidx[j]; } }
+    if (h1) { const float dx = p1.x - qx, dy = p1.y - qy; const float d2 = __builtin_fmaf(dx, dx, dy * dy); if (d2 < bd) { bd = d2; best = lidx[j + 1]; } }
+  }
+  return best;
+}
+
 struct CloudDev {            // device view of a cloud set
   const float2* xy;          // [padded total] coordinates
   const float2* nrm;         // [padded total] normals
@@ -69,6 +115,7 @@ struct CloudDev {            // device view of a cloud set
   const int32_t* lane_T;     // [n_clouds] steps per thread
   GridDev grid;              // valid only when the slice uses the NN finder on this (fixed) cloud
   DistDev dist;              // valid only when the slice uses the distance-map finder on this (fixed) cloud
+  KdDev kd;                  // valid only when the slice uses the KD-tree finder on this (fixed) cloud
 };
 
 // exact nearest neighbour of q among the cloud's points within sqrt(md2); ties -> lowest index
@@ -394,6 +441,158 @@ __global__ __launch_bounds__(256) void k_grid_big_scatter(const GridBigArgs A) {
   }
 }
 
+// ---- KD-tree build (CorrespondenceFinderKDTree2D::reset, registration/correspondence_finder_kd_tree_2d.cpp:31-38) -----------------------------
+// The oracle's kd_build_node, level by level over every cloud of the set at once: ONE WAVE owns one node of the current level.
+//   mean, covariance   sums over the node's points IN THEIR ORDER (ascending original index -- the partitions are stable), each a plain
+//                      SEQUENTIAL fp32 sum as the reference's loop forms it: ((0 + x0) + x1) + ...  A parallel reduction would round
+//                      differently, move a splitting plane by an ulp and send a point next to it into the other leaf, so the chain is kept
+//                      and made cheap instead: the wave holds 64 consecutive values, one per lane, and runs the chain as a systolic pass --
+//                      acc <- rotate_right(acc) + v, 64 times: lane 63 ends with ((carry + v0) + v1) + ... + v63, one DPP add per value and
+//                      chain, carry in lane 63 for the next 64 values (kChain 1); kChain 0 is the plain form of the same chain (a v_readlane
+//                      and an add per value), kept as the reference the systolic form is tested against on the card.
+//   principal axis     closed form of the 2x2 symmetric eigenproblem, IEEE sqrt and divide, every lane alike
+//   extents, split     projections on the two axes: minima / maxima do not depend on the order; (p - mean).v < 0 goes left
+//   partition          stable, by ballot ranks, chunk after chunk; a child too small to be split again is written straight into the leaf
+//                      arrays, the others into the next level's input and queue
+// No fused multiply-add anywhere in here: the CPU restatement's build has none, the library is built with -ffp-contract=off.
+struct KdBuildArgs {
+  const int32_t* start;                              // [n_clouds] first point of each cloud
+  const KdMeta*  meta;                               // [n_clouds] node_base
+  const float2*  xy_in; const int32_t* idx_in;       // this level's input, cloud-relative positions (idx_in == nullptr: the identity, level 0)
+  float2* xy_out; int32_t* idx_out;                  // ranges of the children the next level will process
+  float4* plane; int2* link; int32_t* n_nodes;       // n_nodes[c]: nodes handed out so far in cloud c's region
+  float2* leaf_xy; int32_t* leaf_idx;
+  const int4* q_in; int4* q_out; int32_t* q_out_count; int32_t n_items;      // work items: (cloud, node, begin, end)
+  float max_leaf_range; int32_t min_leaf_points;
+};
+
+template <int kChain>
+struct SeqSum {      // one sequential fp32 sum over values that arrive 64 at a time, one per lane, in lane order
+  float acc = 0.0f;  // kChain 1: lane 63 carries the running sum between chunks; kChain 0: every lane holds it
+  LSM2D_DEV void step(float v, int i) {
+    if (kChain == 1) acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x13C /* wave_ror:1 */, 0xF, 0xF, false)) + v;
+    else acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+  }
+  LSM2D_DEV float total() const { return kChain == 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63)) : acc; }
+};
+
+template <int kChain>
+__global__ __launch_bounds__(256) void k_kd_level(const KdBuildArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= A.n_items) return;                     // whole waves leave: no workgroup barrier below
+  const int4 it = A.q_in[item];
+  const int c = __builtin_amdgcn_readfirstlane(it.x), node = __builtin_amdgcn_readfirstlane(it.y);
+  const int begin = __builtin_amdgcn_readfirstlane(it.z), end = __builtin_amdgcn_readfirstlane(it.w);
+  const int n = end - begin, base = A.start[c], nbase = A.meta[c].node_base;
+  const float2* xin = A.xy_in + base + begin;
+  const int32_t* iin = A.idx_in ? A.idx_in + base + begin : nullptr;
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  bool split = false; int nl = 0;
+  float mx = 0.0f, my = 0.0f, vx = 0.0f, vy = 0.0f;
+  if (n >= A.min_leaf_points && n >= 2) {
+    // ---- mean: two sequential chains
+    { SeqSum<kChain> sx, sy;
+      for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const float2 p = k < n ? xin[k] : make_float2(0.0f, 0.0f);      // adding +0 is exact: the tail of the last chunk
+#pragma unroll
+        for (int i = 0; i < 64; ++i) { sx.step(p.x, i); sy.step(p.y, i); }
+      }
+      const float fn = (float) n;
+      mx = sx.total() / fn; my = sy.total() / fn; }
+    // ---- covariance: three sequential chains of unfused products
+    float sxx, sxy, syy;
+    { SeqSum<kChain> cxx, cxy, cyy;
+      for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        float pxx = 0.0f, pxy = 0.0f, pyy = 0.0f;
+        if (k < n) { const float2 p = xin[k]; const float dx = p.x - mx, dy = p.y - my; pxx = dx * dx; pxy = dx * dy; pyy = dy * dy; }
+#pragma unroll
+        for (int i = 0; i < 64; ++i) { cxx.step(pxx, i); cxy.step(pxy, i); cyy.step(pyy, i); }
+      }
+      sxx = cxx.total(); sxy = cxy.total(); syy = cyy.total(); }
+    // ---- principal eigenvector of [[sxx, sxy], [sxy, syy]] (closed form, as the oracle writes it)
+    const float tr = sxx + syy, df = sxx - syy;
+    const float disc = __builtin_sqrtf(df * df + 4.0f * sxy * sxy);
+    const float l1 = (tr + disc) / 2.0f;
+    if (__builtin_fabsf(sxy) > 0.0f) { vx = l1 - syy; vy = sxy; } else if (sxx >= syy) { vx = 1.0f; vy = 0.0f; } else { vx = 0.0f; vy = 1.0f; }
+    const float vn = __builtin_sqrtf(vx * vx + vy * vy);
+    if (vn > 0.0f) {
+      vx = vx / vn; vy = vy / vn;
+      // ---- extents along the two axes and the size of the left part
+      float lo1 = 3.402823466e+38f, hi1 = -3.402823466e+38f, lo2 = lo1, hi2 = hi1;
+      for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        bool left = false;
+        if (k < n) {
+          const float2 p = xin[k]; const float dx = p.x - mx, dy = p.y - my;
+          const float a = dx * vx + dy * vy, b = -dx * vy + dy * vx;
+          lo1 = a < lo1 ? a : lo1; hi1 = a > hi1 ? a : hi1; lo2 = b < lo2 ? b : lo2; hi2 = b > hi2 ? b : hi2;
+          left = a < 0.0f;
+        }
+        nl += __popcll(__ballot(left));
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        lo1 = fminf(lo1, __shfl_xor(lo1, o, 64)); hi1 = fmaxf(hi1, __shfl_xor(hi1, o, 64));
+        lo2 = fminf(lo2, __shfl_xor(lo2, o, 64)); hi2 = fmaxf(hi2, __shfl_xor(hi2, o, 64));
+      }
+      const float e1 = (hi1 - lo1) / 2.0f, e2 = (hi2 - lo2) / 2.0f;
+      split = (e1 > e2 ? e1 : e2) >= A.max_leaf_range && nl > 0 && nl < n;
+    }
+  }
+  if (!split) {      // a leaf: its points, in their order, go to their final place
+    if (lane == 0) A.link[nbase + node] = make_int2(-1 - begin, end);
+    float2* lxy = A.leaf_xy + base + begin; int32_t* lix = A.leaf_idx + base + begin;
+    for (int k = lane; k < n; k += 64) { lxy[k] = xin[k]; lix[k] = iin ? iin[k] : begin + k; }
+    return;
+  }
+  int left_id = 0;
+  if (lane == 0) left_id = atomicAdd(&A.n_nodes[c], 2);
+  left_id = __builtin_amdgcn_readfirstlane(left_id);
+  const int nr = n - nl;
+  // a child that cannot be split again (kd_build_node's first test) is a leaf already: straight into the leaf arrays
+  const bool leaf_l = !(nl >= A.min_leaf_points && nl >= 2), leaf_r = !(nr >= A.min_leaf_points && nr >= 2);
+  if (lane == 0) {
+    A.plane[nbase + node] = make_float4(mx, my, vx, vy);
+    A.link[nbase + node] = make_int2(left_id, 0);
+    if (leaf_l) A.link[nbase + left_id] = make_int2(-1 - begin, begin + nl);
+    if (leaf_r) A.link[nbase + left_id + 1] = make_int2(-1 - (begin + nl), end);
+    const int n_next = (leaf_l ? 0 : 1) + (leaf_r ? 0 : 1);
+    if (n_next) {
+      int q = atomicAdd(A.q_out_count, n_next);
+      if (!leaf_l) A.q_out[q++] = make_int4(c, left_id, begin, begin + nl);
+      if (!leaf_r) A.q_out[q] = make_int4(c, left_id + 1, begin + nl, end);
+    }
+  }
+  float2* oxy_l = (leaf_l ? A.leaf_xy : A.xy_out) + base + begin;  int32_t* oix_l = (leaf_l ? A.leaf_idx : A.idx_out) + base + begin;
+  float2* oxy_r = (leaf_r ? A.leaf_xy : A.xy_out) + base + begin + nl;  int32_t* oix_r = (leaf_r ? A.leaf_idx : A.idx_out) + base + begin + nl;
+  int cl = 0, cr = 0;
+  for (int k0 = 0; k0 < n; k0 += 64) {      // stable partition: ranks by ballot, chunk after chunk
+    const int k = k0 + lane;
+    const bool valid = k < n;
+    float2 p = make_float2(0.0f, 0.0f); bool left = false;
+    if (valid) { p = xin[k]; const float dx = p.x - mx, dy = p.y - my; left = dx * vx + dy * vy < 0.0f; }
+    const u64 bl = __ballot(valid && left), br = __ballot(valid && !left);
+    if (valid) {
+      const int src = iin ? iin[k] : begin + k;
+      if (left) { const int d = cl + __popcll(bl & lt_mask); oxy_l[d] = p; oix_l[d] = src; }
+      else { const int d = cr + __popcll(br & lt_mask); oxy_r[d] = p; oix_r[d] = src; }
+    }
+    cl += __popcll(bl); cr += __popcll(br);
+  }
+}
+
+// roots of every cloud's tree: work item (c, 0, 0, count[c]); one node handed out per cloud
+__global__ void k_kd_init(const int32_t* __restrict__ count, int n_clouds, int4* __restrict__ q, int32_t* __restrict__ n_nodes) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n_clouds) { q[c] = make_int4(c, 0, 0, count[c]); n_nodes[c] = 1; }
+}
+__global__ void k_kd_finish(const int32_t* __restrict__ n_nodes, int n_clouds, KdMeta* __restrict__ meta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n_clouds) meta[c].n_nodes = n_nodes[c];
+}
+
 struct SliceDev {
   CloudDev fixed, moving;
   int32_t finder;
@@ -419,8 +618,10 @@ struct StatsDev { int32_t n_corr, n_in, n_out; float chi_in, chi_out; };
 struct AlignArgs {
   int32_t n_align, n_slices, max_it, min_inliers;
   float   damping;
+  float   term_eps;                         // lsm2d_aligner_params.termination_chi_epsilon (0 = run all iterations)
   int32_t cols_max, fcan_total;
   int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
+  int32_t kd_lds_nodes;                     // > 0: single KD-tree slice -- room in LDS for this many nodes of the fixed cloud's tree (its top levels)
   const float* init_pose;
   const PriorDev* prior;
   int32_t  host_polls;                      // results go to pinned host memory and the host polls the status words: release them to the system
@@ -523,7 +724,8 @@ __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], 
 // kHasProj / kHasNN: which finders the batch's slices use -- the unused one is compiled out so the
 // projective hot loop does not carry the NN path's register pressure (and vice versa).
 // kHasDist: a slice uses the distance-map finder (compiled out otherwise so the NN search keeps its registers).
-template <bool kHasProj, bool kHasNN, bool kHasDist>
+// kHasKd: a slice uses the KD-tree finder (LSM2D_FINDER_KDTREE); compiled out otherwise.
+template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false>
 __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LSM2D_QUERY_MIN_WAVES)) void k_align(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   // the 16-byte rows first: behind the canvases they would sit on an odd 8-byte boundary whenever cols_max + fcan_total is odd
@@ -536,6 +738,10 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   float2* l_sxy = reinterpret_cast<float2*>(red + (kAlignBlock / 64) * kAccumWords);
   uint16_t* l_cst = reinterpret_cast<uint16_t*>(l_sxy + A.nn_lds_points);
   uint16_t* l_sidx = l_cst + ((A.nn_lds_cells + 2) & ~1);
+  // KD-tree finder: the top levels of the fixed cloud's tree (its first kd_lds_nodes nodes) live in LDS for the whole alignment -- every
+  // descent starts there (the host offers this only to pure KD-tree batches, where the region behind `red` is 16-byte aligned and free)
+  float4* l_kpl = reinterpret_cast<float4*>(red + (kAlignBlock / 64) * kAccumWords);
+  int2* l_klk = reinterpret_cast<int2*>(l_kpl + A.kd_lds_nodes);
   __shared__ float s_pose[3];
   __shared__ Iso   s_iso[kMaxSlices];
   // s_H: information matrix (H of the last solved iteration, built and solved IN LDS: thread 0's serial code has 64 registers like
@@ -544,6 +750,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   // each added by the lane of wave 0 that gathered it
   __shared__ float s_H[9], s_rhs[3], s_sum[kAccumWords + 2];
   __shared__ int   s_n_corr, s_active, s_done, s_status, s_last_n_in;
+  __shared__ float s_prev_chi;      // total chi^2 of the previous iteration (termination_chi_epsilon)
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   const int a = blockIdx.x, tid = threadIdx.x;
@@ -562,7 +769,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   if (A.prior && tid >= 64 && tid < 64 + kPriorWords)
     ((float*) &s_prior)[tid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[tid - 64] : ((const float*) (A.prior + a))[tid - 64];
 
-  if (kHasProj && !kHasNN && !kHasDist && A.inline_n1)
+  if (kHasProj && !kHasNN && !kHasDist && !kHasKd && A.inline_n1)
     for (int s = 0; s < A.n_slices; ++s) if (A.s[s].unpack_src) unpack_fixed_set(A.s[s], tid, kAlignBlock);      // visible after the barrier below
   // ---- prologue: fixed canvases, camera at identity (correspondence_finder_projective_2d.cpp:37-44)
   for (int i = tid; i < A.fcan_total; i += kAlignBlock) fcan[i] = kEmptyCell;
@@ -605,6 +812,13 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       for (int i = tid; i < nf; i += kAlignBlock) { l_sxy[i] = S.fixed.grid.sorted_xy[fbase + i]; l_sidx[i] = (uint16_t) S.fixed.grid.sorted_idx[fbase + i]; }
     }
   }
+  int kd_lds = 0;                            // nodes of this alignment's tree that were staged (workgroup-uniform)
+  if (kHasKd && A.kd_lds_nodes > 0) {
+    const SliceDev& S = A.s[0];
+    const KdMeta km = S.fixed.kd.meta[pick_cloud(S.fixed, a)];
+    kd_lds = km.n_nodes < A.kd_lds_nodes ? km.n_nodes : A.kd_lds_nodes;
+    for (int i = tid; i < kd_lds; i += kAlignBlock) { l_kpl[i] = S.fixed.kd.plane[km.node_base + i]; l_klk[i] = S.fixed.kd.link[km.node_base + i]; }
+  }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   for (int s = 0; s < A.n_slices; ++s) {
     const SliceDev& S = A.s[s];
@@ -641,7 +855,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       const Iso T = s_iso[s];
       Accum acc; accum_zero(acc);
       LSM2D_PH(2);
-      if (kHasProj && ((!kHasNN && !kHasDist) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
+      if (kHasProj && ((!kHasNN && !kHasDist && !kHasKd) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
         {
           // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
           const int mc = pick_cloud(S.moving, a);
@@ -668,17 +882,23 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
           if (__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos) continue;
           accumulate_pair(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, S.cauchy != 0, S.tau, acc);
         }
-      } else if (kHasNN || kHasDist) {
+      } else if (kHasNN || kHasDist || kHasKd) {
         // NN finder fused with the factor (correspondence_finder_kd_tree_2d.cpp:12-27): every moving point is
         // transformed, matched to its exact nearest fixed point within max_distance, normal-gated, accumulated
         const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
         const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
         const float2* fn = S.fixed.nrm + fbase; const float2* mn = S.moving.nrm + mbase;
         const float2* fp = S.fixed.xy + fbase;  const float2* mp = S.moving.xy + mbase;
-        const bool use_grid = kHasNN && (!kHasDist || S.finder == LSM2D_FINDER_NN);
+        const bool use_grid = kHasNN && ((!kHasDist && !kHasKd) || S.finder == LSM2D_FINDER_NN);
+        const bool use_kd = kHasKd && ((!kHasNN && !kHasDist) || S.finder == LSM2D_FINDER_KDTREE);
         GridMeta g; DistMeta dm;
         const int32_t* cst = nullptr; const int32_t* sidx = nullptr; const float2* sxy = nullptr;
-        if (use_grid) {
+        const float4* kpl = nullptr; const int2* klk = nullptr;
+        if (use_kd) {      // the reference's tree over the fixed cloud (correspondence_finder_kd_tree_2d.cpp:18-19): one descent + one leaf per query
+          const int nb = __builtin_amdgcn_readfirstlane(S.fixed.kd.meta[fc].node_base);
+          kpl = S.fixed.kd.plane + nb; klk = S.fixed.kd.link + nb;
+          sidx = S.fixed.kd.leaf_idx + fbase; sxy = S.fixed.kd.leaf_xy + fbase;
+        } else if (use_grid) {
           g = S.fixed.grid.meta[fc];
           // the meta comes through a vector load: tell the compiler it is wave-uniform -- seven VGPRs fewer across the query loops, which
           // takes the last spills out of them (NN role B 2.27 -> 2.06 ms, role A 7.91 -> 7.82; variants_r02v_nn_scalar_meta.log)
@@ -706,6 +926,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
               if (live) best = (group == 1 && nn_lds) ? nn_query<1, uint16_t, uint16_t>(g, l_cst, l_sidx, l_sxy, qx, qy, S.max_distance, md2, 0)
                                                       : nn_query<group>(g, cst, sidx, sxy, qx, qy, S.max_distance, md2, sub);
             }
+            else if (use_kd) { if (live) best = kd_query(kpl, klk, sxy, sidx, qx, qy, md2, l_kpl, l_klk, kd_lds); }
             else if (live) best = distmap_lookup(dm, S.fixed.dist.parent, qx, qy);
             if (best >= 0 && sub == 0) {                     // one lane per query accumulates
               const float2 nm = mn[j], nf = fn[best];
@@ -748,7 +969,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       // pure projective kernels need no barrier here: the other waves go on to the next slice's projection (the cells it
       // writes were reset by the bin walk) and touch `red` again only after the barrier that follows it, which lane 0
       // joins once it is done with the partials.  The point-query branches write `red` without such a barrier in between.
-      if (kHasNN || kHasDist) __syncthreads();
+      if (kHasNN || kHasDist || kHasKd) __syncthreads();
     }
     if (tid == 0) {
       // (thread 0's serial state lives in LDS, not in registers every thread would carry -- and spill -- across the loops)
@@ -765,6 +986,11 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         float dmp = A.damping;
         asm volatile("" : "+v"(dmp));      // (not a loop invariant to hoist -- as a double it was kept, and spilled, across the whole kernel)
         if (!solve_update(s_H, s_rhs, dmp, s_pose)) { s_status = LSM2D_SINGULAR_H; s_done = 1; }
+        else if (A.term_eps > 0.0f) {      // the aligner's termination criterion: relative decay of the total chi^2 (lsm2d.h)
+          const float chi_now = last.chi_in + last.chi_out;
+          if (it > 0 && __builtin_fabsf(s_prev_chi - chi_now) < A.term_eps * chi_now) s_done = 1;      // status stays RUNNING: decided below as after max_iterations
+          s_prev_chi = chi_now;
+        }
       }
       if (!s_done) begin_iteration();        // next iteration's transforms and zeroed sums, under the same barrier
     }
@@ -835,6 +1061,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   __shared__ int   s_done;
   float pose[3] = {0.0f, 0.0f, 0.0f}, Hlast[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // thread 0's: estimate and information matrix stay in registers
   int status = LSM2D_RUNNING;
+  float prev_chi = 0.0f;            // thread 0's: total chi^2 of the previous iteration (termination_chi_epsilon)
   __shared__ PriorDev s_prior;
 
   constexpr int nwaves = kAlignBlock / 64;
@@ -984,7 +1211,14 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
           for (int k = 0; k < 9; ++k) Hlast[k] = Hs[k];
           float X[3] = {pose[0], pose[1], pose[2]};
           if (!solve_update(Hs, bs, A.damping, X)) { status = LSM2D_SINGULAR_H; s_done = 1; }
-          else { pose[0] = X[0]; pose[1] = X[1]; pose[2] = X[2]; }
+          else {
+            pose[0] = X[0]; pose[1] = X[1]; pose[2] = X[2];
+            if (A.term_eps > 0.0f) {       // as in k_align
+              const float chi_now = chi_in + chi_out;
+              if (it > 0 && __builtin_fabsf(prev_chi - chi_now) < A.term_eps * chi_now) s_done = 1;
+              prev_chi = chi_now;
+            }
+          }
           LSM2D_PC(10);            // 3x3 solve and pose update
         }
         LSM2D_PC(4);               // (debug builds: the part of the transforms' time that is lane 0's alone is nil now)
@@ -1126,6 +1360,7 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
     StatsDev last; last.n_corr = s_n_corr; last.n_in = __float_as_int(s_sum[11]); last.n_out = __float_as_int(s_sum[12]); last.chi_in = s_sum[9]; last.chi_out = s_sum[10];
     if (A.out_stats) A.out_stats[(size_t) a * A.max_it + S.it] = last;
     int status = LSM2D_RUNNING;
+    bool stop_now = false;
     if (!s_active) {
       status = LSM2D_NOT_ENOUGH_CORRESPONDENCES;
       for (int k = 0; k < 9; ++k) s_H[k] = S.it == 0 ? 0.0f : S.H_last[9 * a + k];      // the information matrix stays the last solved iteration's
@@ -1136,9 +1371,16 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
       if (A.prior) add_prior(A.prior[a], s_pose, s_H, s_rhs);
       for (int k = 0; k < 9; ++k) S.H_last[9 * a + k] = s_H[k];
       if (!solve_update(s_H, s_rhs, A.damping, s_pose)) status = LSM2D_SINGULAR_H;
-      else { S.pose[3 * a] = s_pose[0]; S.pose[3 * a + 1] = s_pose[1]; S.pose[3 * a + 2] = s_pose[2]; }
+      else {
+        S.pose[3 * a] = s_pose[0]; S.pose[3 * a + 1] = s_pose[1]; S.pose[3 * a + 2] = s_pose[2];
+        if (A.term_eps > 0.0f) {       // as in k_align; the previous iteration's statistics wait in S.last
+          const float chi_now = last.chi_in + last.chi_out;
+          if (S.it > 0) { const StatsDev pv = S.last[a]; stop_now = __builtin_fabsf((pv.chi_in + pv.chi_out) - chi_now) < A.term_eps * chi_now; }
+          S.last[a] = last;
+        }
+      }
     }
-    const bool last_it = S.it == A.max_it - 1;
+    const bool last_it = S.it == A.max_it - 1 || stop_now;
     if (status == LSM2D_RUNNING && last_it) status = last.n_in < A.min_inliers ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
     if (status != LSM2D_RUNNING) {
       S.done[a] = 1;
@@ -1200,7 +1442,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_projective(const FindArgs A
 
 // ---- finder-level NN: pairs in ascending moving index (correspondence_finder_kd_tree_2d.cpp:12-27) ------
 struct FindNNArgs {
-  CloudDev fixed, moving; int32_t fc, mc; int32_t use_distmap;
+  CloudDev fixed, moving; int32_t fc, mc; int32_t use_distmap; int32_t use_kd;      // at most one of the two set; neither: the exact grid search
   float max_distance, normal_cos; Iso T; int32_t nn_group;
   int32_t* out_pairs; int32_t* out_count;
   int32_t* match; int32_t* block_count;      // k_find_nn_multi: per query the matched fixed index or -1; pairs per workgroup
@@ -1215,15 +1457,18 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
   const int fbase = A.fixed.start[A.fc], mbase = A.moving.start[A.mc], n = A.moving.count[A.mc];
   GridMeta g; DistMeta dm;
   const int32_t* cst = nullptr; const int32_t* sidx = nullptr; const float2* sxy = nullptr;
+  const float4* kpl = nullptr; const int2* klk = nullptr;
   if (A.use_distmap) dm = A.fixed.dist.meta[A.fc];
+  else if (A.use_kd) { const int nb = A.fixed.kd.meta[A.fc].node_base; kpl = A.fixed.kd.plane + nb; klk = A.fixed.kd.link + nb; sxy = A.fixed.kd.leaf_xy + fbase; sidx = A.fixed.kd.leaf_idx + fbase; }
   else {
     g = A.fixed.grid.meta[A.fc]; cst = A.fixed.grid.cell_start + g.cell_base;
     sidx = A.fixed.grid.sorted_idx + fbase; sxy = A.fixed.grid.sorted_xy + fbase;
   }
   const float md2 = A.max_distance * A.max_distance;
-  const int group = A.use_distmap ? 1 : A.nn_group, sub = tid & (group - 1);
+  const int group = (A.use_distmap || A.use_kd) ? 1 : A.nn_group, sub = tid & (group - 1);
   const int per_step = kFindBlock / group;
   auto query = [&](float qx, float qy) {
+    if (A.use_kd) return kd_query(kpl, klk, sxy, sidx, qx, qy, md2);
     return group == kNNGroup ? nn_query<kNNGroup>(g, cst, sidx, sxy, qx, qy, A.max_distance, md2, sub)
                              : nn_query<1>(g, cst, sidx, sxy, qx, qy, A.max_distance, md2, sub);
   };
@@ -1265,7 +1510,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn_multi(const FindNNArgs A
   __shared__ int s_wave_tot[kFindBlock / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = A.moving.count[A.mc];
-  const int group = A.use_distmap ? 1 : A.nn_group, sub = tid & (group - 1);
+  const int group = (A.use_distmap || A.use_kd) ? 1 : A.nn_group, sub = tid & (group - 1);
   const int per_step = kFindBlock / group;
   const int j = blockIdx.x * per_step + tid / group;
   if (kPhase == 0) {
@@ -1275,7 +1520,10 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn_multi(const FindNNArgs A
       const float2 pm = A.moving.xy[mbase + j];
       float qx, qy; xf_point(A.T, pm.x, pm.y, qx, qy);
       if (A.use_distmap) best = distmap_lookup(A.fixed.dist.meta[A.fc], A.fixed.dist.parent, qx, qy);
-      else {
+      else if (A.use_kd) {
+        const int nb = A.fixed.kd.meta[A.fc].node_base;
+        best = kd_query(A.fixed.kd.plane + nb, A.fixed.kd.link + nb, A.fixed.kd.leaf_xy + fbase, A.fixed.kd.leaf_idx + fbase, qx, qy, A.max_distance * A.max_distance);
+      } else {
         const GridMeta g = A.fixed.grid.meta[A.fc];
         const int32_t* cst = A.fixed.grid.cell_start + g.cell_base; const int32_t* sidx = A.fixed.grid.sorted_idx + fbase; const float2* sxy = A.fixed.grid.sorted_xy + fbase;
         const float md2 = A.max_distance * A.max_distance;

@@ -57,20 +57,25 @@ def cross_rank_check(scan_points, scan_offsets, scan_index, x0, poses, n_beams: 
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 or (dist.is_available() and dist.is_initialized()) else 0
     ncheck = min(n_check, len(x0))
-    pts = np.zeros((n_check, n_beams, 4), np.float32); cnt = np.zeros((n_check, 1), np.float32); head = np.zeros((n_check, 6), np.float32)
+    # counts travel as int32 next to the number of candidates a rank really checks: an empty scan stays in its place (row i of the clouds
+    # belongs to row i of x0 / poses), and a rank with fewer than n_check candidates says so itself
+    pts = np.zeros((n_check, n_beams, 4), np.float32); cnt = np.zeros((n_check + 1, 1), np.int32); head = np.zeros((n_check, 6), np.float32)
     for i in range(ncheck):
         si = int(scan_index[i]) if scan_index is not None else i
         sc = scan_points[scan_offsets[si]:scan_offsets[si + 1]]
+        if len(sc) > n_beams:
+            raise ValueError("cross_rank_check: scan %d has %d points, more than n_beams = %d rows reserved for it" % (si, len(sc), n_beams))
         pts[i, : len(sc)] = sc; cnt[i, 0] = len(sc)
+    cnt[n_check, 0] = ncheck
     head[:ncheck, :3] = poses[:ncheck]; head[:ncheck, 3:] = x0[:ncheck]
     all_pts = gather_results(pts.reshape(n_check * n_beams, 4), device).reshape(world, n_check, n_beams, 4)
-    all_cnt = gather_results(cnt, device).reshape(world, n_check).astype(np.int64)
+    all_cnt = gather_results(cnt, device).reshape(world, n_check + 1).astype(np.int64)
     all_head = gather_results(head, device).reshape(world, n_check, 6)
     if rank != 0:
         return None
     same = 0
     for r in range(world):
-        nr = int((all_cnt[r] > 0).sum())
+        nr = int(all_cnt[r, n_check])
         clouds = [np.ascontiguousarray(all_pts[r, i, : all_cnt[r, i]]) for i in range(nr)]
         got = align_fn(clouds, np.ascontiguousarray(all_head[r, :nr, 3:]))
         same += int(np.array_equal(np.asarray(got, np.float32), all_head[r, :nr, :3]))

@@ -125,6 +125,8 @@ class CorrespondenceFinderPointQuery {
   float param_max_distance_m = 1e-2f;   // kd .h:23 (nn .h:20-24 defaults to 1)
   float param_resolution = 5e-2f;       // nn .h:25-29
   float param_normal_cos = 0.8f;
+  float param_max_leaf_range = 1e-2f;   // kd .h:26-28 -- honoured by LSM2D_FINDER_KDTREE (search "kdtree")
+  unsigned param_min_leaf_points = 20;  // kd .h:29-33
   void setFixed(const PointNormal2fVectorCloud* fixed) { _fixed.reset(fixed ? new CloudSet(_ctx, *fixed) : nullptr); }
   void setMoving(const PointNormal2fVectorCloud* moving) { _moving.reset(moving ? new CloudSet(_ctx, *moving) : nullptr); _n_moving = moving ? moving->size() : 0; }
   void setLocalMapInSensor(const Vector3f& pose) { _local_map_in_sensor = pose; }
@@ -133,6 +135,7 @@ class CorrespondenceFinderPointQuery {
     lsm2d_slice_params sp{};
     sp.finder = _finder; sp.projector = PointNormal2fProjectorPolar().abi();
     sp.max_distance = param_max_distance_m; sp.resolution = param_resolution; sp.normal_cos = param_normal_cos;
+    sp.kd_max_leaf_range = param_max_leaf_range; sp.kd_min_leaf_points = (int32_t) param_min_leaf_points;
     return sp;
   }
   void compute() {
@@ -146,14 +149,23 @@ class CorrespondenceFinderPointQuery {
           "lsm2d_find_correspondences", _ctx.get());
     _correspondences->resize((size_t) k);
   }
- private:
+ protected:
   Context& _ctx; int _finder;
+ private:
   std::unique_ptr<CloudSet> _fixed, _moving; size_t _n_moving = 0;
   Vector3f _local_map_in_sensor{{0.f, 0.f, 0.f}};
   CorrespondenceVector* _correspondences = nullptr;
 };
+// search "kdtree" (default): the reference's own tree and single-leaf descent (approximate, honours max_leaf_range / min_leaf_points);
+// "exact": an exact nearest-neighbour search on a uniform grid (LSM2D_FINDER_NN), for which the two leaf parameters have no meaning
 struct CorrespondenceFinderKDTree2D : CorrespondenceFinderPointQuery {
-  explicit CorrespondenceFinderKDTree2D(Context& ctx) : CorrespondenceFinderPointQuery(ctx, LSM2D_FINDER_NN) {}
+  explicit CorrespondenceFinderKDTree2D(Context& ctx, const std::string& search = "kdtree") : CorrespondenceFinderPointQuery(ctx, finderOf(search)) {}
+  void setSearch(const std::string& search) { _finder = finderOf(search); }
+  static int finderOf(const std::string& search) {
+    if (search == "kdtree") return LSM2D_FINDER_KDTREE;
+    if (search == "exact") return LSM2D_FINDER_NN;
+    throw std::runtime_error("CorrespondenceFinderKDTree2D| search must be \"kdtree\" or \"exact\"");
+  }
 };
 struct CorrespondenceFinderNN2D : CorrespondenceFinderPointQuery {
   explicit CorrespondenceFinderNN2D(Context& ctx) : CorrespondenceFinderPointQuery(ctx, LSM2D_FINDER_DISTMAP) { param_max_distance_m = 1.f; }
@@ -270,6 +282,10 @@ class MultiAligner2D {
   explicit MultiAligner2D(Context& ctx) : _ctx(ctx) {}
   int param_max_iterations = 10, param_min_num_inliers = 10;             // MULTI.json:711,714
   float param_damping = 0.f;                                             // MULTI.json:254-259
+  // the options the shipped aligners carry at their defaults (MULTI.json:606-610,627-630): the device loop has no inlier-only re-runs and
+  // keeps every correspondence, so a non-default value is REFUSED, never ignored; the termination criterion exists as an epsilon (lsm2d.h)
+  bool param_enable_inlier_only_runs = false, param_keep_only_inlier_correspondences = false;
+  float param_termination_chi_epsilon = 0.f;                             // 0 = "termination_criteria" not set = max_iterations
   std::vector<AlignerSliceProcessorLaser2DPtr> param_slice_processors;
 
   void setFixed(const PropertyContainer* f) { _fixed = f; }
@@ -292,7 +308,9 @@ class MultiAligner2D {
     }
     lsm2d_batch b{}; b.n_alignments = 1; b.n_slices = ns; b.slices = sp.data(); b.fixed = fx.data(); b.moving = mv.data();
     b.init_pose = _moving_in_fixed.data(); b.prior = _has_prior ? &_prior : nullptr;
-    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, param_damping};
+    if (param_enable_inlier_only_runs || param_keep_only_inlier_correspondences)
+      throw std::runtime_error("MultiAligner2D::compute| enable_inlier_only_runs / keep_only_inlier_correspondences are not supported on the device");
+    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, param_damping, param_termination_chi_epsilon};
     _stats.assign((size_t) (param_max_iterations > 0 ? param_max_iterations : 1), lsm2d_iteration_stats{});
     int32_t st = 0, its = 0;
     check(lsm2d_align_batch(_ctx.get(), &ap, &b, _moving_in_fixed.data(), _information.data(), &st, &its, _stats.data()), "lsm2d_align_batch", _ctx.get());
@@ -352,7 +370,7 @@ class LoopClosureSweep {
     const int n = (int) init_pose.size();
     if ((int) scan_index.size() != n) throw std::runtime_error("LoopClosureSweep::compute| one scan index per candidate");
     const lsm2d_slice_params sp = param_slice;
-    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, 0.f};
+    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, 0.f, 0.f};
     pose.assign((size_t) n, Vector3f{{0.f, 0.f, 0.f}}); information.assign((size_t) n, std::array<float, 9>{});
     status.assign((size_t) n, 0); iterations.assign((size_t) n, 0); last_stats.assign((size_t) n, lsm2d_iteration_stats{});
     static_assert(sizeof(Vector3f) == 3 * sizeof(float), "poses are packed");

@@ -72,7 +72,16 @@ int main(int argc, char** argv) {
 
     auto fk = std::make_shared<CorrespondenceFinderKDTreeHIP2D>(); CorrespondenceVector ck;
     fk->param_max_distance_m.setValue(0.3f);
+    fk->param_search.setValue("exact");                                                       // the exact grid search
     fk->setFixed(&fixed); fk->setMoving(&moving); fk->setLocalMapInSensor(geometry2d::v2t(x0)); fk->setCorrespondences(&ck); fk->compute();
+    // the sibling's default: the reference's own tree and descent, with the leaf parameters a KDTree2D configuration carries
+    auto ft = std::make_shared<CorrespondenceFinderKDTreeHIP2D>(); CorrespondenceVector ct;
+    ft->param_max_distance_m.setValue(0.3f); ft->param_max_leaf_range.setValue(0.05f); ft->param_min_leaf_points.setValue(12);
+    ft->setFixed(&fixed); ft->setMoving(&moving); ft->setLocalMapInSensor(geometry2d::v2t(x0)); ft->setCorrespondences(&ct); ft->compute();
+    int threw_search = 0;
+    ft->param_search.setValue("octree");
+    try { ft->compute(); } catch (const std::runtime_error&) { threw_search = 1; }
+    out << ",\"n_kdtree_tree\":" << ct.size() << ",\"pairs_kdtree_tree\":" << pairsJson(ct) << ",\"threw_on_bad_search\":" << threw_search;
     auto fn = std::make_shared<CorrespondenceFinderNNHIP2D>(); CorrespondenceVector cn;
     fn->param_max_distance_m.setValue(0.5f); fn->param_resolution.setValue(0.1f);
     fn->setFixed(&fixed); fn->setMoving(&moving); fn->setLocalMapInSensor(geometry2d::v2t(x0)); fn->setCorrespondences(&cn); fn->compute();
@@ -112,6 +121,24 @@ int main(int argc, char** argv) {
     // NotEnoughInliers must come back as that status, not as a success with a moved pose
     aligner->param_min_num_inliers.setValue(1000000); aligner->setMovingInFixed(geometry2d::v2t(x0)); aligner->compute();
     out << ",\"status_not_enough_inliers\":" << (int) aligner->status();
+    aligner->param_min_num_inliers.setValue(10);
+    // aligner options the device loop does not implement (MULTI.json:606-610,627-630): each non-default value is REFUSED
+    auto refuses = [&]() { try { aligner->setMovingInFixed(geometry2d::v2t(x0)); aligner->compute(); } catch (const std::runtime_error&) { return 1; } return 0; };
+    aligner->param_enable_inlier_only_runs.setValue(true);
+    out << ",\"threw_on_inlier_only_runs\":" << refuses();
+    aligner->param_enable_inlier_only_runs.setValue(false);
+    aligner->param_keep_only_inlier_correspondences.setValue(true);
+    out << ",\"threw_on_keep_only_inliers\":" << refuses();
+    aligner->param_keep_only_inlier_correspondences.setValue(false);
+    aligner->param_termination_criteria.setValue(std::make_shared<AlignerTerminationCriteriaBase>());
+    out << ",\"threw_on_termination_criteria\":" << refuses();
+    aligner->param_termination_criteria.setValue(std::shared_ptr<AlignerTerminationCriteriaBase>());
+    aligner->param_termination_chi_epsilon.setValue(-1.f);
+    out << ",\"threw_on_negative_epsilon\":" << refuses();
+    // ... and the criterion the device does implement: with an epsilon the loop stops early, at the same pose to the tolerance
+    aligner->param_termination_chi_epsilon.setValue(1e-3f);
+    out << ",\"refused_after_reset\":" << refuses();
+    out << ",\"iterations_with_epsilon\":" << aligner->iterationStats().size() << ",\"pose_with_epsilon\":" << f3(geometry2d::t2v(aligner->movingInFixed()));
   }
   {
     // the tracker's configuration (MULTI.json:715-721): laser slice with sensor extrinsics + Cauchy, the odometry prior, a second laser slice

@@ -26,47 +26,84 @@
 #define PARAM_VECTOR(TYPE, NAME, DESC, FLAG) TYPE param_##NAME = TYPE(#NAME, DESC, this, FLAG)
 
 namespace srrg2_core {
-  // ---- the handful of Eigen types / operations the adapters use
-  struct Vector2f {
-    float v[2] = {0, 0};
+  // ---- the handful of Eigen types / operations the adapters use.  The stand-ins IMITATE EIGEN'S PUBLIC API (accessors x() / y() / z(),
+  // operator()(row, col), the comma initialiser `m << a, b, c, d`, Identity(), setZero(), Isometry2f::linear() / translation() /
+  // inverse() / operator*) and keep their storage PRIVATE (names ending in __shim), so an adapter that compiles here uses nothing Eigen
+  // does not have: tests/test_abi.py::test_adapters_use_no_shim_only_member greps for it as well.
+  template <int N_>
+  class ShimCommaInitializer_ {      // what `matrix << a, b, ...` returns (Eigen::CommaInitializer): row-major fill
+  public:
+    ShimCommaInitializer_(float* data_, float first_) : _d__shim(data_) { _d__shim[_k__shim++] = first_; }
+    template <typename S_> ShimCommaInitializer_& operator,(S_ v_) { if (_k__shim < N_) _d__shim[_k__shim++] = (float) v_; return *this; }
+  private:
+    float* _d__shim; int _k__shim = 0;
+  };
+  class Vector2f {
+  public:
     Vector2f() {}
-    Vector2f(float x_, float y_) { v[0] = x_; v[1] = y_; }
-    float& x() { return v[0]; } float& y() { return v[1]; }
-    const float& x() const { return v[0]; } const float& y() const { return v[1]; }
+    Vector2f(float x_, float y_) { _v__shim[0] = x_; _v__shim[1] = y_; }
+    float& x() { return _v__shim[0]; } float& y() { return _v__shim[1]; }
+    const float& x() const { return _v__shim[0]; } const float& y() const { return _v__shim[1]; }
+    float& operator()(int i_) { return _v__shim[i_]; } const float& operator()(int i_) const { return _v__shim[i_]; }
+  private:
+    float _v__shim[2] = {0, 0};
   };
-  struct Vector3f {
-    float v[3] = {0, 0, 0};
+  class Vector3f {
+  public:
     Vector3f() {}
-    Vector3f(float x_, float y_, float z_) { v[0] = x_; v[1] = y_; v[2] = z_; }
-    float& x() { return v[0]; } float& y() { return v[1]; } float& z() { return v[2]; }
-    const float& x() const { return v[0]; } const float& y() const { return v[1]; } const float& z() const { return v[2]; }
+    Vector3f(float x_, float y_, float z_) { _v__shim[0] = x_; _v__shim[1] = y_; _v__shim[2] = z_; }
+    float& x() { return _v__shim[0]; } float& y() { return _v__shim[1]; } float& z() { return _v__shim[2]; }
+    const float& x() const { return _v__shim[0]; } const float& y() const { return _v__shim[1]; } const float& z() const { return _v__shim[2]; }
+    float& operator()(int i_) { return _v__shim[i_]; } const float& operator()(int i_) const { return _v__shim[i_]; }
+  private:
+    float _v__shim[3] = {0, 0, 0};
   };
-  struct Matrix3f {
-    float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float& operator()(int r, int c) { return m[3 * r + c]; }
-    const float& operator()(int r, int c) const { return m[3 * r + c]; }
-    void setIdentity() { for (int i = 0; i < 9; ++i) m[i] = (i % 4 == 0) ? 1.f : 0.f; }
-    void setZero() { for (int i = 0; i < 9; ++i) m[i] = 0.f; }
-    static Matrix3f Identity() { Matrix3f r; r.setIdentity(); return r; }
+  template <int R_>
+  class ShimSquareMatrix_ {           // Matrix2f / Matrix3f: row-major storage behind Eigen's accessors
+  public:
+    float& operator()(int r_, int c_) { return _m__shim[R_ * r_ + c_]; }
+    const float& operator()(int r_, int c_) const { return _m__shim[R_ * r_ + c_]; }
+    void setIdentity() { for (int i = 0; i < R_ * R_; ++i) _m__shim[i] = (i % (R_ + 1) == 0) ? 1.f : 0.f; }
+    void setZero() { for (int i = 0; i < R_ * R_; ++i) _m__shim[i] = 0.f; }
+    static ShimSquareMatrix_ Identity() { ShimSquareMatrix_ r; r.setIdentity(); return r; }
+    static ShimSquareMatrix_ Zero() { return ShimSquareMatrix_(); }
+    template <typename S_> ShimCommaInitializer_<R_ * R_> operator<<(S_ first_) { return ShimCommaInitializer_<R_ * R_>(_m__shim, (float) first_); }
+  private:
+    float _m__shim[R_ * R_] = {};
   };
-  struct Isometry2f {       // R = [[c, -s], [s, c]], t
-    float c = 1.f, s = 0.f, tx = 0.f, ty = 0.f;
+  using Matrix2f = ShimSquareMatrix_<2>;
+  using Matrix3f = ShimSquareMatrix_<3>;
+  class Isometry2f {       // Eigen::Transform<float, 2, Isometry>: R = linear(), t = translation()
+  public:
     static Isometry2f Identity() { return Isometry2f(); }
-    Isometry2f inverse() const { Isometry2f r; r.c = c; r.s = -s; r.tx = -(c * tx + s * ty); r.ty = -(-s * tx + c * ty); return r; }
-    Isometry2f operator*(const Isometry2f& o) const {
-      Isometry2f r; r.c = c * o.c - s * o.s; r.s = s * o.c + c * o.s; r.tx = c * o.tx - s * o.ty + tx; r.ty = s * o.tx + c * o.ty + ty; return r;
+    void setIdentity() { *this = Isometry2f(); }
+    Matrix2f linear() const { Matrix2f r; r(0, 0) = _c__shim; r(0, 1) = -_s__shim; r(1, 0) = _s__shim; r(1, 1) = _c__shim; return r; }
+    Vector2f translation() const { return Vector2f(_tx__shim, _ty__shim); }
+    Isometry2f inverse() const {
+      Isometry2f r; r._c__shim = _c__shim; r._s__shim = -_s__shim;
+      r._tx__shim = -(_c__shim * _tx__shim + _s__shim * _ty__shim); r._ty__shim = -(-_s__shim * _tx__shim + _c__shim * _ty__shim); return r;
     }
+    Isometry2f operator*(const Isometry2f& o) const {
+      Isometry2f r; r._c__shim = _c__shim * o._c__shim - _s__shim * o._s__shim; r._s__shim = _s__shim * o._c__shim + _c__shim * o._s__shim;
+      r._tx__shim = _c__shim * o._tx__shim - _s__shim * o._ty__shim + _tx__shim; r._ty__shim = _s__shim * o._tx__shim + _c__shim * o._ty__shim + _ty__shim; return r;
+    }
+  private:
+    float _c__shim = 1.f, _s__shim = 0.f, _tx__shim = 0.f, _ty__shim = 0.f;
+    friend Isometry2f shimMakeIsometry(float c_, float s_, float tx_, float ty_);
   };
-  namespace geometry2d {
-    inline Vector3f t2v(const Isometry2f& T) { return Vector3f(T.tx, T.ty, std::atan2(T.s, T.c)); }
-    inline Isometry2f v2t(const Vector3f& v) { Isometry2f T; T.c = std::cos(v.z()); T.s = std::sin(v.z()); T.tx = v.x(); T.ty = v.y(); return T; }
+  inline Isometry2f shimMakeIsometry(float c_, float s_, float tx_, float ty_) { Isometry2f T; T._c__shim = c_; T._s__shim = s_; T._tx__shim = tx_; T._ty__shim = ty_; return T; }
+  namespace geometry2d {      // srrg_geometry/geometry2d.h: v2t / t2v as the reference calls them (apps/visual_test_aligner_2d.cpp:126,145)
+    inline Vector3f t2v(const Isometry2f& T) { const Matrix2f R = T.linear(); const Vector2f t = T.translation(); return Vector3f(t.x(), t.y(), std::atan2(R(1, 0), R(0, 0))); }
+    inline Isometry2f v2t(const Vector3f& v) { return shimMakeIsometry(std::cos(v.z()), std::sin(v.z()), v.x(), v.y()); }
   } // namespace geometry2d
 
   // ---- point cloud types (srrg_pcl)
-  struct PointNormal2f {
-    Vector2f _c, _n;
-    Vector2f& coordinates() { return _c; } const Vector2f& coordinates() const { return _c; }
-    Vector2f& normal() { return _n; } const Vector2f& normal() const { return _n; }
+  class PointNormal2f {
+  public:
+    Vector2f& coordinates() { return _c__shim; } const Vector2f& coordinates() const { return _c__shim; }
+    Vector2f& normal() { return _n__shim; } const Vector2f& normal() const { return _n__shim; }
+  private:
+    Vector2f _c__shim, _n__shim;
   };
   using PointNormal2fVectorCloud = std::vector<PointNormal2f>;
   struct Correspondence {
@@ -93,6 +130,7 @@ namespace srrg2_core {
   };
   using PropertyFloat = Property_<float>;
   using PropertyInt = Property_<int>;
+  using PropertyBool = Property_<bool>;
   using PropertyUnsignedInt = Property_<unsigned int>;
   using PropertyString = Property_<std::string>;
   template <typename C>
@@ -140,7 +178,6 @@ namespace srrg2_core {
 
   // ---- what the raw-data preprocessor touches (sensor_processing/raw_data_preprocessor_projective_2d.{h,cpp}): the laser message's fields
   // (:78-85), the un-projector's PARAMs it sets per message (:96-101), the sliding-window normal computator's PARAMs (MULTI.json:845-853)
-  struct Matrix2f { float m[2][2] = {{1.f, 0.f}, {0.f, 1.f}}; };
   class BaseSensorMessage { public: virtual ~BaseSensorMessage() {} };
   using BaseSensorMessagePtr = std::shared_ptr<BaseSensorMessage>;
   class LaserMessage : public BaseSensorMessage {
@@ -225,10 +262,15 @@ namespace srrg2_slam_interfaces {
     const Isometry2f& sensorInRobot() const { return _sensor_in_robot; }
   };
   class AlignerSliceOdom2DPrior : public AlignerSliceProcessorBase {};      // MULTI.json:402-422: fixed / moving slices "odom" hold Isometry2f
+  class AlignerTerminationCriteriaBase : public Configurable {};      // what "termination_criteria" points to (MULTI.json:627-630,729-731: unset in both shipped aligners)
   class MultiAligner2D : public AlignerBase {
   public:
     PARAM(PropertyInt, max_iterations, "maximum number of iterations", 10, 0);
     PARAM(PropertyInt, min_num_inliers, "minimum number of inliers", 10, 0);
+    // the aligner options the shipped configurations carry next to the two above (MULTI.json:606-610,704-708,627-630,729-731)
+    PARAM(PropertyBool, enable_inlier_only_runs, "toggles additional inlier only runs if sufficient inliers are available", false, 0);
+    PARAM(PropertyBool, keep_only_inlier_correspondences, "toggles removal of correspondences which factors are not inliers in the last iteration", false, 0);
+    PARAM(PropertyConfigurable_<AlignerTerminationCriteriaBase>, termination_criteria, "termination criteria, not set=max iterations", nullptr, 0);
     PARAM_VECTOR(PropertyConfigurableVector_<AlignerSliceProcessorBase>, slice_processors, "slices", 0);
     virtual void setFixed(PropertyContainerBase* f_) { _fixed = f_; }
     virtual void setMoving(PropertyContainerBase* m_) { _moving = m_; }

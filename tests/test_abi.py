@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     bound = {s[0] for s in _capi.SYMBOLS}
     assert set(declared) == bound
     l = _capi.load()
-    assert l.lsm2d_version() == 121
+    assert l.lsm2d_version() == 130
     assert l.lsm2d_status_string(0) == b"Success" and l.lsm2d_status_string(-4) == b"CapacityExceeded"
 
 
@@ -54,11 +54,51 @@ def test_product_package_does_not_import_the_oracle():
 def test_struct_layouts_match_header_sizes():
     from srrg2_laser_slam_2d_amd import _capi
     assert C.sizeof(_capi.Projector) == 24
-    assert C.sizeof(_capi.SliceParams) == 4 + 24 + 16 + 4 + 4 + 4 + 12
-    assert C.sizeof(_capi.AlignerParams) == 12
+    assert C.sizeof(_capi.SliceParams) == 4 + 24 + 16 + 4 + 4 + 4 + 12 + 4 + 4
+    assert C.sizeof(_capi.AlignerParams) == 16
     assert C.sizeof(_capi.Prior) == 48
     assert C.sizeof(_capi.Correspondence) == 8
     assert C.sizeof(_capi.IterationStats) == 20
+
+
+def test_struct_layouts_match_the_c_compiler(tmp_path):
+    """sizeof / offsetof of every ABI struct as gcc lays include/lsm2d.h out, against the ctypes mirror field by field."""
+    import subprocess
+    from srrg2_laser_slam_2d_amd import _capi
+    structs = {"lsm2d_projector": _capi.Projector, "lsm2d_slice_params": _capi.SliceParams, "lsm2d_aligner_params": _capi.AlignerParams,
+               "lsm2d_prior": _capi.Prior, "lsm2d_correspondence": _capi.Correspondence, "lsm2d_iteration_stats": _capi.IterationStats,
+               "lsm2d_preprocessor": _capi.Preprocessor, "lsm2d_batch": _capi.Batch}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lsm2d.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in st._fields_:
+            lines.append('printf(" %s=%%zu", offsetof(%s, %s));' % (fname, cname, fname))
+        lines.append('printf("\\n");')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"; src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        parts = line.split(); st = structs[parts[0]]
+        assert int(parts[1]) == C.sizeof(st), (parts[0], parts[1], C.sizeof(st))
+        for kv in parts[2:]:
+            k, v = kv.split("=")
+            assert getattr(st, k).offset == int(v), (parts[0], k, v, getattr(st, k).offset)
+
+
+def test_adapters_use_no_shim_only_member():
+    """The stand-in headers imitate Eigen's and srrg2's PUBLIC surface; what is theirs alone is private or carries `shim` in its name.  An
+    adapter that compiles against them can still only be trusted if it never names such a thing (round 2's raw-data preprocessor wrote
+    `sensor_matrix.m[0][0]`, a member of the stand-in, where Eigen wants `sensor_matrix << ...`)."""
+    ad = os.path.join(ROOT, "adapters", "srrg")
+    for f in sorted(os.listdir(ad)):
+        text = re.sub(r"//.*", "", open(os.path.join(ad, f)).read())
+        assert not re.search(r"shim", text, re.I), f
+        assert not re.search(r"\.\s*(m|v)\s*\[", text), (f, "raw storage of a stand-in matrix / vector")
+        assert not re.search(r"\._(c|s|tx|ty|m|v|props)\b", text), (f, "private storage of a stand-in type")
+    # and the one place where Eigen's comma initialiser is needed uses it, as the reference does (raw_data_preprocessor_projective_2d.cpp:89-90)
+    assert "sensor_matrix <<" in open(os.path.join(ad, "raw_data_preprocessor_hip_2d.h")).read()
 
 
 def test_srrg_adapter_sources_compile_against_the_stand_in_headers(tmp_path):

@@ -28,7 +28,8 @@ def _oracle_slice(po, sp):
                            col_offset=sp.projector.col_offset, point_distance=sp.point_distance, normal_cos=sp.normal_cos,
                            max_distance=sp.max_distance, resolution=sp.resolution, robustifier=sp.robustifier,
                            chi_threshold=sp.chi_threshold, min_num_correspondences=sp.min_num_correspondences,
-                           sensor_in_robot=tuple(sp.sensor_in_robot))
+                           sensor_in_robot=tuple(sp.sensor_in_robot), kd_max_leaf_range=sp.kd_max_leaf_range,
+                           kd_min_leaf_points=sp.kd_min_leaf_points)
 
 
 def _same_correspondence_sets(gpu_stats, oracle_stats, iterations):
@@ -372,6 +373,11 @@ def test_srrg_adapters_compile_and_run(ctx, po, small_workload, tmp_path):
     assert r["threw_on_missing_inputs"] == 1 and len(sa ^ sb) <= 0.01 * len(sa) and len(sb) > 500
     assert r["in_place_change_seen"] == 1 and r["pairs_before_change"] == len(got) and r["pairs_after_change"] != r["pairs_before_change"]
     assert abs(r["n_kdtree"] - len(po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.3), f, wl.map_points, x0))) <= 5
+    # the KD-tree sibling's default search is the reference's own tree, with the leaf parameters of the configuration; an unknown search is refused
+    want_t = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, kd_max_leaf_range=0.05, kd_min_leaf_points=12), f, wl.map_points, x0)
+    got_t = np.array(r["pairs_kdtree_tree"], np.int32).reshape(-1, 2)
+    st = {tuple(p) for p in want_t.tolist()}; sg = {tuple(p) for p in got_t.tolist()}
+    assert r["n_kdtree_tree"] == len(got_t) > 100 and len(st ^ sg) <= 0.01 * len(st) and r["threw_on_bad_search"] == 1
     assert abs(r["n_nn"] - len(po.find(po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.1), f, wl.map_points, x0))) <= 5
     # aligner: pose, status enum (stand-in: Success = 3, NotEnoughInliers = 2), iteration statistics, information matrix, slice binding
     o = po.align(po.aligner_params(iters), [po.slice_params()], [f], [wl.map_points], x0)
@@ -382,6 +388,11 @@ def test_srrg_adapters_compile_and_run(ctx, po, small_workload, tmp_path):
     assert abs(r["slice_pairs"] - o["stats"][-1].n_corr) <= 3
     assert r["pose_again"] == r["pose"]                           # reused device clouds, same bits
     assert r["status_not_enough_inliers"] == 2
+    # options of the upstream aligner that the device loop does not implement are refused one by one; the epsilon criterion stops early
+    assert (r["threw_on_inlier_only_runs"], r["threw_on_keep_only_inliers"], r["threw_on_termination_criteria"], r["threw_on_negative_epsilon"]) == (1, 1, 1, 1)
+    assert r["refused_after_reset"] == 0 and 2 <= r["iterations_with_epsilon"] < iters
+    oe = po.align(po.aligner_params(iters, termination_chi_epsilon=1e-3), [po.slice_params()], [f], [wl.map_points], x0)
+    assert abs(r["iterations_with_epsilon"] - oe["iterations"]) <= 1 and np.abs(np.array(r["pose_with_epsilon"]) - oe["pose"])[:2].max() < POSE_TOL_M
     # the tracker's three-slice configuration: two laser slices (normal_cos 0.9 + Cauchy 0.01, normal_cos 0.8) and the odometry prior z = x0
     sp0 = po.slice_params(normal_cos=0.9, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.01); sp1 = po.slice_params()
     om = po.align(po.aligner_params(iters, prior_z=x0, prior_omega=np.eye(3, dtype=np.float32)), [sp0, sp1], [f, f], [wl.map_points, wl.map_points], x0)
@@ -2203,3 +2214,237 @@ def test_nn_cooperative_search_is_chosen_per_alignment(ctx, po, small_workload):
         rt = po.align(po.aligner_params(12, device_order=True), [osp], [f], [m], x0[i])
         _assert_bitwise_equal_to_device_order_oracle(res, i, rt, ("ragged nn", i))
     assert res.status[0] == 0
+
+
+# ---- the reference's own KD-tree on the device (LSM2D_FINDER_KDTREE; registration/correspondence_finder_kd_tree_2d.cpp:5-38, .h:23-34) --------
+def _kd_finder(ctx, md, leaf_range=1e-2, leaf_points=20, normal_cos=0.8):
+    return api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=md, normal_cos=normal_cos, max_leaf_range=leaf_range, min_leaf_points=leaf_points, search="kdtree")
+
+
+@pytest.mark.parametrize("n_map", [10000, 100000, 1000000])
+def test_kdtree_finder_bit_exact_both_roles(ctx, po, n_map):
+    """KDTree2D(coordinates, max_leaf_range, min_leaf_points) built on the device + findNeighbor's single-leaf descent: the SAME pairs, in
+    the same order, as the oracle's restatement of the believed upstream tree (lsmo_find_kdtree_f -- unchanged by this build: sequential
+    sums, unfused products) in both roles at the three map sizes of BASELINE.json, for the class defaults and a second parameter set, and
+    with both forms of the build's sequential sums (systolic DPP pass / one v_readlane per value)."""
+    wl = synth.make_workload(3, n_map, seed=11)
+    scan = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    x = wl.x0[1]
+    xb = synth.invert_poses(x[None, :].astype(np.float64))[0].astype(np.float32)
+    for leaf_range, leaf_points in ((1e-2, 20), (0.05, 7)):
+        osp = po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.5, normal_cos=0.8, kd_max_leaf_range=leaf_range, kd_min_leaf_points=leaf_points)
+        for role, (fixed, moving, pose) in enumerate(((scan, wl.map_points, x), (wl.map_points, scan, xb))):     # role A (tracker wiring), role B (BASELINE wording)
+            want = po.find(osp, fixed, moving, pose)
+            assert len(want) > 300
+            for chain in (1, 0):
+                ctx.set_option("kd_chain", chain)
+                f = _kd_finder(ctx, 0.5, leaf_range, leaf_points)
+                f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
+                got = f.compute()
+                assert np.array_equal(got, want), (n_map, role, leaf_range, chain, len(got), len(want))
+            ctx.set_option("kd_chain", 1)
+            # the tree is approximate by construction: it must NOT be the exact search (else this test would not tell the two apart)
+            ex = po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.5, normal_cos=0.8), fixed, moving, pose)
+            assert not np.array_equal(ex, want)
+
+
+def test_kdtree_finder_edge_cases(ctx, po):
+    """Degenerate trees: empty / one-point / two-point clouds, fewer points than min_leaf_points (the root is a leaf), all points identical
+    (no axis), collinear and duplicate points (ties -> the lowest index of the leaf), a leaf range that makes the root a leaf, min_leaf_points
+    of 1 and 2 (the deepest trees), queries far outside the cloud."""
+    rng = np.random.default_rng(9)
+    def cloud(n, lo=-5, hi=5):
+        p = rng.uniform(lo, hi, size=(n, 2)); a = rng.uniform(-np.pi, np.pi, n)
+        return np.concatenate([p, np.cos(a)[:, None], np.sin(a)[:, None]], 1).astype(np.float32)
+    moving = cloud(700, -6, 6)
+    pose = np.float32([0.1, -0.2, 0.3])
+    cases = []
+    for n in (0, 1, 2, 3, 19, 20, 21, 64, 65, 129, 1000):
+        cases.append((cloud(n), 1e-2, 20))
+    ident = np.tile(cloud(1), (300, 1)); cases.append((ident, 1e-2, 20))
+    line = cloud(500); line[:, 1] = np.float32(0.25); cases.append((line, 1e-2, 20))
+    dup = cloud(400); dup[100:200] = dup[0:100]; cases.append((dup, 1e-3, 2))
+    cases.append((cloud(3000), 100.0, 20))             # extent below max_leaf_range at once: one leaf holding everything
+    cases.append((cloud(3000), 1e-3, 1)); cases.append((cloud(3000), 1e-3, 2)); cases.append((cloud(5000), 0.3, 50))
+    grid = np.stack(np.meshgrid(np.arange(40), np.arange(40)), -1).reshape(-1, 2).astype(np.float32) * 0.25        # exact ties in the covariance
+    cases.append((np.concatenate([grid, np.tile(np.float32([1, 0]), (len(grid), 1))], 1), 0.2, 4))
+    for k, (fixed, lr, lp) in enumerate(cases):
+        for md in (0.05, 0.4, 3.0):
+            f = _kd_finder(ctx, md, lr, lp, normal_cos=-1.0)
+            f.setFixed(fixed) if len(fixed) else f.setFixed(np.zeros((0, 4), np.float32))
+            f.setMoving(moving); f.setLocalMapInSensor(pose)
+            got = f.compute()
+            want = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=md, normal_cos=-1.0, kd_max_leaf_range=lr, kd_min_leaf_points=lp),
+                           fixed if len(fixed) else np.zeros((0, 4), np.float32), moving, pose)
+            assert np.array_equal(got, want), (k, len(fixed), lr, lp, md, len(got), len(want))
+    # the class defaults apply when the parameters are not set (<= 0), as in the oracle
+    f = _kd_finder(ctx, 0.4, 0.0, 0, normal_cos=-1.0); fixed = cloud(4000)
+    f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
+    assert np.array_equal(f.compute(), po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.4, normal_cos=-1.0), fixed, moving, pose))
+
+
+def _kd_aligner(ctx, md=0.5, its=20, leaf_range=1e-2, leaf_points=20, robustifier=None):
+    al = api.MultiAligner2D(ctx, max_iterations=its, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(_kd_finder(ctx, md, leaf_range, leaf_points), robustifier=robustifier, min_num_correspondences=10))
+    return al
+
+
+def test_aligner_kdtree_both_roles_bitwise(ctx, po):
+    """k_align with the KD-tree finder fused in: status, iterations, pose, information matrix and every iteration's statistics BITWISE equal to
+    the oracle running the believed upstream tree and summing in the device's order -- role B (tree over the 100k-point map, scans as queries:
+    BASELINE's wording) and role A (a tree per scan, every map point a query: the reference tracker's wiring), with and without the top of
+    the tree staged in LDS, with the Cauchy kernel."""
+    wl = synth.make_workload(12, 100000, seed=6)
+    x0_b = synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32); xt_b = synth.invert_poses(wl.x_true)
+    fixed = api.CloudSet(ctx, wl.map_points); moving = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
+    results = []
+    for lds_nodes in (1024, 0, 37):
+        ctx.set_option("kd_lds_nodes", lds_nodes)
+        results.append(_kd_aligner(ctx).compute_batch([fixed], [moving], x0_b, want_stats=True))
+    ctx.set_option("kd_lds_nodes", 1024)
+    res = results[0]
+    for other in results[1:]:
+        assert np.array_equal(res.pose, other.pose) and np.array_equal(res.information, other.information) and np.array_equal(res.status, other.status)
+    osp = po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.5)
+    for i in range(0, 12, 3):
+        s = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+        rt = po.align(po.aligner_params(20, device_order=True), [osp], [wl.map_points], [s], x0_b[i])
+        _assert_bitwise_equal_to_device_order_oracle(res, i, rt, ("kd role B", i))
+    dt = np.abs(res.pose - xt_b)
+    assert np.all(res.status == 0) and dt[:, :2].max() < 5e-3 and dt[:, 2].max() < 2e-3
+    # role A, ragged scans, Cauchy, non-default leaf parameters
+    wl2 = synth.make_workload(6, 30000, seed=7)
+    fixed2 = api.CloudSet(ctx, wl2.scan_points, wl2.scan_offsets); moving2 = api.CloudSet(ctx, wl2.map_points)
+    al = _kd_aligner(ctx, md=0.3, leaf_range=0.03, leaf_points=10, robustifier=api.RobustifierCauchy(0.05))
+    res2 = al.compute_batch([fixed2], [moving2], wl2.x0, want_stats=True)
+    osp2 = po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, kd_max_leaf_range=0.03, kd_min_leaf_points=10, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.05)
+    for i in (0, 3, 5):
+        s = wl2.scan_points[wl2.scan_offsets[i]:wl2.scan_offsets[i + 1]]
+        rt = po.align(po.aligner_params(20, device_order=True), [osp2], [s], [wl2.map_points], wl2.x0[i])
+        _assert_bitwise_equal_to_device_order_oracle(res2, i, rt, ("kd role A", i))
+
+
+def test_mixed_finders_with_a_kdtree_slice(ctx, po, small_workload):
+    """projective + KD-tree slices sharing one pose: the k_align<true, true, true, true> instantiation."""
+    wl = small_workload
+    s = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    al = api.MultiAligner2D(ctx, max_iterations=10, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector()), min_num_correspondences=10))
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(_kd_finder(ctx, 0.3), min_num_correspondences=10))
+    al.setFixed({"points": s}); al.setMoving({"points": wl.map_points}); al.setMovingInFixed(wl.x0[0])
+    assert al.compute() == 0
+    osl = [po.slice_params(), po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3)]
+    r = po.align(po.aligner_params(10, device_order=True), osl, [s, s], [wl.map_points, wl.map_points], wl.x0[0])
+    assert np.array_equal(al.movingInFixed(), r["pose"]) and np.array_equal(al.informationMatrix(), r["H"])
+
+
+def test_termination_chi_epsilon_all_aligner_paths(ctx, po, small_workload):
+    """lsm2d_aligner_params.termination_chi_epsilon (the device-side counterpart of the aligner's termination_criteria): the loop stops
+    where the oracle's stops, bit for bit, in the batch kernel, the latency kernel and the split path; 0 keeps max_iterations."""
+    wl = synth.make_workload(6, 20000, seed=3, map_noise=0.01, scan_noise=0.01)      # noisy data: the criterion fires at 3 ... 9 iterations, or never
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    n = len(wl.x0)
+    for eps in (1e-4, 1e-3, 1e-1):
+        outs = []
+        for path in (1, 3, 2):
+            ctx.set_option("align_path", path)
+            al = api.MultiAligner2D(ctx, max_iterations=20, min_num_inliers=10, termination_chi_epsilon=eps)
+            al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector()), min_num_correspondences=10))
+            res = al.compute_batch([fixed], [moving], wl.x0, want_stats=True)
+            assert ctx.get_option("last_align_path") == path
+            outs.append(res)
+        ctx.set_option("align_path", 0)
+        for i in range(n):
+            s = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+            rt = po.align(po.aligner_params(20, device_order=True, termination_chi_epsilon=eps), [po.slice_params()], [s], [wl.map_points], wl.x0[i])
+            assert 2 <= rt["iterations"] <= 20 and (eps < 1e-3 or rt["iterations"] < 20)
+            for res in outs:
+                _assert_bitwise_equal_to_device_order_oracle(res, i, rt, ("eps", eps, i))
+    with pytest.raises(api.Lsm2dError):
+        _neg_eps(ctx, fixed, moving, wl)
+    al = api.MultiAligner2D(ctx, max_iterations=5)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector())))
+    al.param_enable_inlier_only_runs = True
+    with pytest.raises(RuntimeError):
+        al.compute_batch([fixed], [moving], wl.x0)
+    al.param_enable_inlier_only_runs = False; al.param_keep_only_inlier_correspondences = True
+    with pytest.raises(RuntimeError):
+        al.compute_batch([fixed], [moving], wl.x0)
+
+
+def _neg_eps(ctx, fixed, moving, wl):
+    al = api.MultiAligner2D(ctx, max_iterations=5, termination_chi_epsilon=-1.0)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector())))
+    return al.compute_batch([fixed], [moving], wl.x0)
+
+
+def test_device_tensors_computed_a_moment_ago_are_read_complete(ctx, po):
+    """Device-resident inputs are read on the context's own (non-blocking) stream: the Python mirror waits for the stream that produced the
+    tensor (include/lsm2d.h, ORDERING).  Ranges and map points that are the result of a long chain of GPU operations queued immediately
+    before the call must come through complete."""
+    import torch
+    world = synth.make_world(2)
+    poses = synth.sample_poses(world, 64, seed=21)
+    a0, a1 = -2.34747, 2.35619
+    ranges = synth.make_scan_ranges(world, poses, n_beams=1081, angle_min=a0, angle_max=a1, noise_sigma=0.0, seed=3)
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+    pre.setRawData(ranges, a0, a1, 0.0, 30.0)
+    want = [c for c in (pre.compute().download(i) for i in range(len(poses)))]
+    base = torch.from_numpy(ranges).to("cuda:0")
+    big = torch.randn(4096, 4096, device="cuda:0")
+    for _ in range(3):
+        junk = big
+        for _ in range(12):
+            junk = junk @ big * 1e-2                       # tens of milliseconds of queued work on torch's stream
+        r = (base * 2.0 + junk[0, 0] * 0.0) * 0.5          # exact in fp32: == base, but only once the chain above has run
+        pre.setRawData(r, a0, a1, 0.0, 30.0)
+        cs = pre.compute()
+        for i in (0, 31, 63):
+            assert np.array_equal(cs.download(i), want[i])
+    wl = synth.make_workload(2, 20000, seed=5)
+    m = torch.from_numpy(wl.map_points).to("cuda:0")
+    junk = big
+    for _ in range(12):
+        junk = junk @ big * 1e-2
+    m2 = (m * 2.0 + junk[0, 0] * 0.0) * 0.5
+    assert np.array_equal(api.CloudSet(ctx, m2).download(0), wl.map_points)
+
+
+def test_sweep_replication_paths_peer_same_device_and_host(ctx, small_workload):
+    """lsm2d_sweep_*: how a replica gets onto its device -- device to device on one card (the rehearsal), over the fabric where
+    hipDeviceCanAccessPeer allows it, from the caller's host buffer otherwise ("peer_copy" 1 forces that path: what a node without peer
+    access gets) -- never changes a result.  With two or more GPUs visible the same runs on DISTINCT devices (skipped on a one-GPU box)."""
+    import ctypes as C
+    import torch
+    from srrg2_laser_slam_2d_amd import _capi
+    lib = _capi.load(); wl = small_workload
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = len(wl.x0); its = 8
+    ap = _capi.AlignerParams(its, 10, 0.0, 0.0)
+    sp = api.make_slice_params(projector=_projector(), robustifier=0, min_num_correspondences=10)
+    x0 = np.ascontiguousarray(wl.x0, np.float32)
+    scans = np.ascontiguousarray(wl.scan_points); offs = np.ascontiguousarray(wl.scan_offsets, np.int32); mp = np.ascontiguousarray(wl.map_points)
+    want = _aligner(ctx, its=its).compute_batch([api.CloudSet(ctx, scans, offs)], [api.CloudSet(ctx, mp)], x0)
+    opt = lambda sw, key: (lambda v: (lib.lsm2d_sweep_get_option(sw, key, C.byref(v)), v.value)[1])(C.c_int64(-1))
+    device_sets = [[0, 0, 0]]
+    if torch.cuda.device_count() >= 2:
+        device_sets.append([0, 1] + ([2] if torch.cuda.device_count() >= 3 else []))
+    for devices in device_sets:
+        for peer_copy in (0, 1):
+            sw = C.c_void_p()
+            assert lib.lsm2d_sweep_create((C.c_int32 * len(devices))(*devices), len(devices), C.byref(sw)) == 0
+            try:
+                assert lib.lsm2d_sweep_set_option(sw, b"peer_copy", 7) == _capi.BAD_ARGUMENT and lib.lsm2d_sweep_set_option(sw, b"nonsense", 0) == _capi.BAD_ARGUMENT
+                assert lib.lsm2d_sweep_set_option(sw, b"peer_copy", peer_copy) == 0 and opt(sw, b"peer_copy") == peer_copy
+                assert lib.lsm2d_sweep_set_scans(sw, P(scans), P(offs), n) == 0 and lib.lsm2d_sweep_set_map(sw, P(mp), len(mp)) == 0
+                by_peer, host, same = opt(sw, b"replicas_by_peer_copy"), opt(sw, b"replicas_through_host"), opt(sw, b"replicas_same_device")
+                assert by_peer + host + same == len(devices) - 1
+                if peer_copy == 1:
+                    assert host == len(devices) - 1
+                elif len(set(devices)) == 1:
+                    assert same == len(devices) - 1
+                pose = np.zeros((n, 3), np.float32); status = np.full(n, -7, np.int32); iters = np.zeros(n, np.int32)
+                assert lib.lsm2d_sweep_align(sw, C.byref(ap), C.byref(sp), n, None, P(x0), P(pose), None, P(status), P(iters), None) == 0
+                assert np.array_equal(pose, want.pose) and np.array_equal(status, want.status) and np.array_equal(iters, want.iterations), (devices, peer_copy)
+            finally:
+                lib.lsm2d_sweep_destroy(sw)

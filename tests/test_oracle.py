@@ -448,3 +448,41 @@ def test_tracker_chain_digests(po):
     assert got == g["steps"]
     assert all(st["status"] == 0 for st in got) and got[-1]["map_points"] > got[0]["map_points"]
 
+
+
+def test_termination_chi_epsilon_semantics(po, small_workload):
+    """lsmo_aligner_params.termination_chi_epsilon (the aligner's "termination_criteria", MULTI.json:627-630: unset in the shipped aligners):
+    0 runs max_iterations; epsilon > 0 stops after the first iteration whose total chi^2 differs from the previous one's by less than
+    epsilon times itself -- that iteration is still solved and applied; a looser epsilon never stops later; the pose at the stop is the pose
+    of the full run's same iteration."""
+    wl = small_workload
+    s = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    full = po.align(po.aligner_params(20), [po.slice_params()], [s], [wl.map_points], wl.x0[0])
+    assert full["iterations"] == 20
+    its = []
+    for eps in (1e-4, 1e-2, 0.5):
+        r = po.align(po.aligner_params(20, termination_chi_epsilon=eps), [po.slice_params()], [s], [wl.map_points], wl.x0[0])
+        assert r["status"] == 0 and 2 <= r["iterations"] <= 20
+        k = r["iterations"]
+        chi = [st.chi_in + st.chi_out for st in full["stats"]]
+        assert abs(np.float32(chi[k - 2]) - np.float32(chi[k - 1])) < eps * chi[k - 1]             # the stopping iteration satisfies the criterion ...
+        assert all(not (abs(np.float32(chi[j - 1]) - np.float32(chi[j])) < np.float32(eps) * np.float32(chi[j])) for j in range(1, k - 1))      # ... and no earlier one did
+        short = po.align(po.aligner_params(k), [po.slice_params()], [s], [wl.map_points], wl.x0[0])
+        assert np.array_equal(short["pose"], r["pose"]) and np.array_equal(short["H"], r["H"])
+        its.append(k)
+    assert its[0] >= its[1] >= its[2] >= 2 and its[0] < 20
+
+
+def test_kdtree_oracle_is_approximate_and_honours_its_parameters(po, small_workload):
+    """The believed upstream tree: never a nearer neighbour than the exact search, sometimes a farther one or none; a leaf
+    range above the cloud's extent (one leaf holding everything) makes it the exact search; min_leaf_points changes the pairs."""
+    wl = small_workload
+    s = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    x = wl.x0[0]
+    ex = po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.5, normal_cos=-1.0), s, wl.map_points[::7], x)
+    kd = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.5, normal_cos=-1.0), s, wl.map_points[::7], x)
+    one_leaf = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.5, normal_cos=-1.0, kd_max_leaf_range=1e3), s, wl.map_points[::7], x)
+    other = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.5, normal_cos=-1.0, kd_min_leaf_points=4), s, wl.map_points[::7], x)
+    assert len(kd) <= len(ex) and not np.array_equal(kd, ex) and not np.array_equal(kd, other)
+    # one leaf: every query scans every point; strict '<' against max_distance^2 (exact search: '<=') -- same pairs unless a pair sits exactly on the gate
+    assert np.array_equal(one_leaf, ex)
