@@ -48,7 +48,7 @@ struct lsm2d_context {
   int grid_big_threshold = 16384;   // clouds of at least this many points get their search grid built by the chip-wide kernels (k_grid_big_*)
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
   int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
-  int kd_lds_nodes = 1024;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it)
+  int kd_lds_nodes = 1536;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it; 512 / 1024 / 1536: 0.830 / 0.804 / 0.778 ms on configs[1] role B)
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
   long long last_clock_khz = 0;       // in-kernel clock of the most recent timed k_align launch (median over the stamped workgroups), 0 = none
   long long last_wg_lifetime_ns = 0;  // median lifetime of its stamped workgroups
@@ -99,7 +99,7 @@ struct DistCache {     // one distance map per (cloud set, max_distance, resolut
 struct KdCache {       // one KD-tree per cloud of the set, per (max_leaf_range, min_leaf_points)
   float max_leaf_range = 0.0f; int min_leaf_points = 0;
   void* d_block = nullptr;      // one allocation; the pointers below are views into it
-  KdMeta* d_meta = nullptr; float4* d_plane = nullptr; int2* d_link = nullptr; float2* d_leaf_xy = nullptr; int32_t* d_leaf_idx = nullptr;
+  KdMeta* d_meta = nullptr; KdNode* d_nodes = nullptr; float2* d_leaf_xy = nullptr; int32_t* d_leaf_idx = nullptr; float2* d_leaf_nrm = nullptr;
   int levels = 0; long long total_nodes = 0; int max_nodes_per_cloud = 0;
 };
 
@@ -702,7 +702,7 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   if (min_leaf_points <= 0) min_leaf_points = 20;
   for (const auto& k : cs->kds)
     if (k.max_leaf_range == max_leaf_range && k.min_leaf_points == min_leaf_points) {
-      *out = KdDev{k.d_meta, k.d_plane, k.d_link, k.d_leaf_xy, k.d_leaf_idx}; if (out_cache) *out_cache = &k; return LSM2D_SUCCESS;
+      *out = KdDev{k.d_meta, k.d_nodes, k.d_leaf_xy, k.d_leaf_idx, k.d_leaf_nrm}; if (out_cache) *out_cache = &k; return LSM2D_SUCCESS;
     }
   const int nc = cs->n_clouds;
   // a cloud of n points has at most 2 n - 1 nodes (every split leaves both children non-empty); an empty cloud still has its root
@@ -719,12 +719,12 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   DevTmp t_block, t_work;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
-  const size_t o_meta = take(sizeof(KdMeta) * (size_t) nc), o_plane = take(sizeof(float4) * (size_t) nodes), o_link = take(sizeof(int2) * (size_t) nodes);
-  const size_t o_lxy = take(sizeof(float2) * np), o_lidx = take(sizeof(int32_t) * np);
+  const size_t o_meta = take(sizeof(KdMeta) * (size_t) nc), o_nodes = take(sizeof(KdNode) * (size_t) nodes);
+  const size_t o_lxy = take(sizeof(float2) * np), o_lidx = take(sizeof(int32_t) * np), o_lnr = take(sizeof(float2) * np);
   HIPCHK(ctx, hipMalloc(&t_block.p, off));
   char* blk = (char*) t_block.p;
-  kc.d_meta = (KdMeta*) (blk + o_meta); kc.d_plane = (float4*) (blk + o_plane); kc.d_link = (int2*) (blk + o_link);
-  kc.d_leaf_xy = (float2*) (blk + o_lxy); kc.d_leaf_idx = (int32_t*) (blk + o_lidx);
+  kc.d_meta = (KdMeta*) (blk + o_meta); kc.d_nodes = (KdNode*) (blk + o_nodes);
+  kc.d_leaf_xy = (float2*) (blk + o_lxy); kc.d_leaf_idx = (int32_t*) (blk + o_lidx); kc.d_leaf_nrm = (float2*) (blk + o_lnr);
   // working set of the build: two ping-pong copies of (xy, idx), two queues, per-cloud node counters, one queue counter per level
   off = 0;
   const size_t w_xy0 = take(sizeof(float2) * np), w_xy1 = take(sizeof(float2) * np), w_ix0 = take(sizeof(int32_t) * np), w_ix1 = take(sizeof(int32_t) * np);
@@ -739,7 +739,7 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   hipLaunchKernelGGL(k_kd_init, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) cs->d_count, nc, qb[0], d_nn);
   HIPCHK(ctx, hipGetLastError());
   KdBuildArgs B;
-  B.start = cs->d_start; B.meta = kc.d_meta; B.plane = kc.d_plane; B.link = kc.d_link; B.n_nodes = d_nn;
+  B.start = cs->d_start; B.meta = kc.d_meta; B.nodes = kc.d_nodes; B.n_nodes = d_nn;
   B.leaf_xy = kc.d_leaf_xy; B.leaf_idx = kc.d_leaf_idx; B.max_leaf_range = max_leaf_range; B.min_leaf_points = min_leaf_points;
   long long n_items = nc; int level = 0;
   volatile int32_t* h_cnt = (volatile int32_t*) ctx->h_flag;
@@ -758,6 +758,15 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
     ++level;
   }
   hipLaunchKernelGGL(k_kd_finish, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) d_nn, nc, kc.d_meta);
+  {
+    int max_pts = 1; for (int c = 0; c < nc; ++c) if (cs->h_count[c] > max_pts) max_pts = cs->h_count[c];
+    int gx = (max_pts + 255) / 256; if (gx > 1024) gx = 1024;
+    for (int c0 = 0; c0 < nc; c0 += 32768) {         // gridDim.y is limited to 65535
+      const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
+      hipLaunchKernelGGL(k_kd_permute_normals, dim3((unsigned) gx, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_nrm,
+                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) kc.d_leaf_idx, kc.d_leaf_nrm, c0);
+    }
+  }
   HIPCHK(ctx, hipGetLastError());
   std::vector<int32_t> h_nn((size_t) nc);
   HIPCHK(ctx, hipMemcpyAsync(h_nn.data(), d_nn, sizeof(int32_t) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
@@ -767,7 +776,7 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   ctx->last_kd_levels = level; ctx->last_kd_nodes = kc.total_nodes;
   kc.d_block = t_block.release();      // owned by the cache from here on (the working set goes with its guard)
   cs->kds.push_back(kc);
-  *out = KdDev{kc.d_meta, kc.d_plane, kc.d_link, kc.d_leaf_xy, kc.d_leaf_idx};
+  *out = KdDev{kc.d_meta, kc.d_nodes, kc.d_leaf_xy, kc.d_leaf_idx, kc.d_leaf_nrm};
   if (out_cache) *out_cache = &cs->kds.back();
   return LSM2D_SUCCESS;
 }
@@ -1552,12 +1561,17 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     if (mf > 0 && mf <= 65535 && need <= 38 * 1024 - lds) { A.nn_lds_points = mf; A.nn_lds_cells = cap * cap + 1; lds += need + 16; }
   }
   // one KD-tree slice: the top of the fixed cloud's tree (up to "kd_lds_nodes" nodes, 24 bytes each) rides in LDS -- same 38 KB budget
-  A.kd_lds_nodes = 0;
+  A.kd_lds_nodes = 0; A.kd_lds_points = 0;
   if (ns == 1 && b->slices[0].finder == LSM2D_FINDER_KDTREE && kd_cache0 && ctx->kd_lds_nodes > 0) {
     int k = kd_cache0->max_nodes_per_cloud < ctx->kd_lds_nodes ? kd_cache0->max_nodes_per_cloud : ctx->kd_lds_nodes;
     const size_t room = lds < 38 * 1024 ? (38 * 1024 - lds) / (sizeof(float4) + sizeof(int2)) : 0;
     if ((size_t) k > room) k = (int) room;
     if (k > 0) { A.kd_lds_nodes = k; lds += (size_t) k * (sizeof(float4) + sizeof(int2)) + 16; }
+    // scan-sized fixed clouds whose whole tree fits: the leaf arrays too (coordinates and normals: 16 bytes per point)
+    const lsm2d_cloudset* f = b->fixed[0];
+    int mf = 0; for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > mf) mf = f->h_count[c];
+    const size_t need = (size_t) (mf + 2) * (sizeof(float2) + sizeof(float2)) + 32;
+    if (k > 0 && k == kd_cache0->max_nodes_per_cloud && mf > 0 && mf <= 65535 && lds + need <= 38 * 1024) { A.kd_lds_points = mf; lds += need; }
   }
   if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
   // one or two projective slices and too few alignments to fill the chip (the live tracker: one alignment per scan): the latency

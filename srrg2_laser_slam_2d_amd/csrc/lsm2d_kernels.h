@@ -61,46 +61,66 @@ LSM2D_DEV int distmap_lookup(const DistMeta& d, const int32_t* __restrict__ pare
 // CorrespondenceFinderKDTree2D::reset() (registration/correspondence_finder_kd_tree_2d.cpp:31-38) and searched by findNeighbor (.cpp:18-19),
 // restated as SURVEY.md App. A.4 believes upstream implements them (the CPU restatement's kd_build_node / kd_find mirror it).  One tree per
 // cloud of the set.  Node k of cloud c lives at meta[c].node_base + k (node 0 = root; the two children of a node are adjacent; nodes of a
-// level come before the nodes of the next): plane = (mean x, mean y, normal x, normal y) of the splitting plane; link.x >= 0: the LEFT
-// child's id (the right one is link.x + 1); link.x < 0: a leaf holding the points [-1 - link.x, link.y) of the cloud's leaf arrays.
-// leaf_xy / leaf_idx: the cloud's coordinates / original indices permuted into leaf order (ascending original index inside a leaf, as
-// the reference's stable partition leaves them) at the cloud's own offset start[c].
+// level come before the nodes of the next), ONE 32-byte record -- a descent touches one cache line per level: (mx, my, nx, ny) = mean and
+// unit normal of the splitting plane; link_x >= 0: the LEFT child's id (the right one is link_x + 1); link_x < 0: a leaf holding the points
+// [-1 - link_x, link_y) of the cloud's leaf arrays.  leaf_xy / leaf_idx: the cloud's coordinates / original indices permuted into leaf
+// order (ascending original index inside a leaf, as the reference's stable partition leaves them) at the cloud's own offset start[c].
 struct KdMeta { int32_t node_base, n_nodes, pad0, pad1; };
+struct __attribute__((aligned(32))) KdNode { float mx, my, nx, ny; int32_t link_x, link_y, pad0, pad1; };
 struct KdDev {
   const KdMeta*  meta;       // [n_clouds]
-  const float4*  plane;      // [total nodes]
-  const int2*    link;       // [total nodes]
+  const KdNode*  nodes;      // [total nodes]
   const float2*  leaf_xy;    // [padded total]
   const int32_t* leaf_idx;   // [padded total]
+  const float2*  leaf_nrm;   // [padded total] the normals in the same order: the fused aligner takes a match's point and normal from where the
+                             // leaf scan found it -- no detour through the original index (two requests to L2 fewer per query)
 };
 
 // findNeighbor as the reference calls it (correspondence_finder_kd_tree_2d.cpp:18-19): descend to the ONE leaf on the query's side of
 // every splitting plane (no backtracking), scan it for the nearest point with squared distance < md2; first point wins ties, i.e. the
-// lowest original index; none -> -1 (.cpp:21).  The operation sequence is the oracle's kd_find: the plane test is two products and a sum,
-// NOT fused (the library is built with -ffp-contract=off); the distance is the fused form every finder of this library uses.
+// lowest original index; none -> -1 (.cpp:21).  The operation sequence is the CPU restatement's kd_find: the plane test is two products
+// and a sum, NOT fused (the library is built with -ffp-contract=off); the distance is the fused form every finder of this library uses.
 // lds_nodes > 0: the first lds_nodes nodes of the tree (its top levels) are staged in LDS (l_plane / l_link) -- a descent pays one LDS
-// round trip per level up there instead of one trip to L2.
-LSM2D_DEV int kd_query(const float4* __restrict__ plane, const int2* __restrict__ link, const float2* __restrict__ lxy,
-                       const int32_t* __restrict__ lidx, float qx, float qy, float md2,
-                       const float4* l_plane = nullptr, const int2* l_link = nullptr, int lds_nodes = 0) {
+// round trip per level up there instead of one trip to L2.  The leaf is read two points per 16-byte load, two loads in flight (leaf
+// arrays start 16-byte aligned at even positions); the winner's original index is fetched once, at the end.
+// XyT / IdxT: float2 / int32_t for the arrays in global memory; a scan-sized cloud's leaf arrays staged in LDS use uint16_t indices.
+// kd_query_pos: the winner's POSITION in the leaf arrays (-1: none) and its coordinates; kd_query: its original index.
+// kAllLds: the WHOLE tree is staged (scan-sized clouds): no node ever comes from global memory, no range checks in the descent.
+template <bool kAllLds = false>
+LSM2D_DEV int kd_query_pos(const KdNode* __restrict__ nodes, const float2* __restrict__ lxy, float qx, float qy, float md2, float2& best_xy,
+                           const float4* l_plane = nullptr, const int2* l_link = nullptr, int lds_nodes = 0) {
   int k = 0;
-  int2 L = lds_nodes > 0 ? l_link[0] : link[0];
+  int2 L;
+  if (kAllLds || lds_nodes > 0) L = l_link[0]; else { const int4 w = reinterpret_cast<const int4*>(nodes)[1]; L = make_int2(w.x, w.y); }
   while (L.x >= 0) {
-    const float4 P = k < lds_nodes ? l_plane[k] : plane[k];
+    float4 P;
+    if (kAllLds || k < lds_nodes) P = l_plane[k]; else P = reinterpret_cast<const float4*>(nodes)[2 * k];
     const float t = (qx - P.x) * P.z + (qy - P.y) * P.w;
     k = L.x + (t < 0.0f ? 0 : 1);
-    L = k < lds_nodes ? l_link[k] : link[k];
+    if (kAllLds || k < lds_nodes) L = l_link[k]; else { const int4 w = reinterpret_cast<const int4*>(nodes)[2 * k + 1]; L = make_int2(w.x, w.y); }
   }
   const int b = -1 - L.x, e = L.y;
-  int best = -1; float bd = md2;
-  // two candidates per trip, both loads in flight; the index of a candidate is read only when it improves on the best so far
-  for (int j = b; j < e; j += 2) {
-    const bool h1 = j + 1 < e;
-    const float2 p0 = lxy[j], p1 = lxy[h1 ? j + 1 : j];
-    { const float dx = p0.x - qx, dy = p0.y - qy; const float d2 = __builtin_fmaf(dx, dx, dy * dy); if (d2 < bd) { bd = d2; best = lidx[j]; } }
-    if (h1) { const float dx = p1.x - qx, dy = p1.y - qy; const float d2 = __builtin_fmaf(dx, dx, dy * dy); if (d2 < bd) { bd = d2; best = lidx[j + 1]; } }
+  int bestpos = -1; float bd = md2;
+  auto consider = [&](int j, float px, float py) {
+    const float dx = px - qx, dy = py - qy;
+    const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+    if (d2 < bd) { bd = d2; bestpos = j; best_xy = make_float2(px, py); }
+  };
+  int j = b;
+  if (j < e && (j & 1)) { const float2 p = lxy[j]; consider(j, p.x, p.y); ++j; }      // up to an even position: pairs are 16-byte aligned from here
+  for (; j + 3 < e; j += 4) {
+    const float4 v0 = *reinterpret_cast<const float4*>(lxy + j), v1 = *reinterpret_cast<const float4*>(lxy + j + 2);
+    consider(j, v0.x, v0.y); consider(j + 1, v0.z, v0.w); consider(j + 2, v1.x, v1.y); consider(j + 3, v1.z, v1.w);
   }
-  return best;
+  if (j + 1 < e) { const float4 v = *reinterpret_cast<const float4*>(lxy + j); consider(j, v.x, v.y); consider(j + 1, v.z, v.w); j += 2; }
+  if (j < e) { const float2 p = lxy[j]; consider(j, p.x, p.y); }
+  return bestpos;
+}
+template <typename IdxT = int32_t>
+LSM2D_DEV int kd_query(const KdNode* __restrict__ nodes, const float2* __restrict__ lxy, const IdxT* __restrict__ lidx, float qx, float qy, float md2) {
+  float2 bxy;
+  const int pos = kd_query_pos(nodes, lxy, qx, qy, md2, bxy);
+  return pos >= 0 ? (int) lidx[pos] : -1;
 }
 
 struct CloudDev {            // device view of a cloud set
@@ -460,7 +480,7 @@ struct KdBuildArgs {
   const KdMeta*  meta;                               // [n_clouds] node_base
   const float2*  xy_in; const int32_t* idx_in;       // this level's input, cloud-relative positions (idx_in == nullptr: the identity, level 0)
   float2* xy_out; int32_t* idx_out;                  // ranges of the children the next level will process
-  float4* plane; int2* link; int32_t* n_nodes;       // n_nodes[c]: nodes handed out so far in cloud c's region
+  KdNode* nodes; int32_t* n_nodes;                   // n_nodes[c]: nodes handed out so far in cloud c's region
   float2* leaf_xy; int32_t* leaf_idx;
   const int4* q_in; int4* q_out; int32_t* q_out_count; int32_t n_items;      // work items: (cloud, node, begin, end)
   float max_leaf_range; int32_t min_leaf_points;
@@ -542,7 +562,7 @@ __global__ __launch_bounds__(256) void k_kd_level(const KdBuildArgs A) {
     }
   }
   if (!split) {      // a leaf: its points, in their order, go to their final place
-    if (lane == 0) A.link[nbase + node] = make_int2(-1 - begin, end);
+    if (lane == 0) { KdNode nd = {0.0f, 0.0f, 0.0f, 0.0f, -1 - begin, end, 0, 0}; A.nodes[nbase + node] = nd; }
     float2* lxy = A.leaf_xy + base + begin; int32_t* lix = A.leaf_idx + base + begin;
     for (int k = lane; k < n; k += 64) { lxy[k] = xin[k]; lix[k] = iin ? iin[k] : begin + k; }
     return;
@@ -554,10 +574,9 @@ __global__ __launch_bounds__(256) void k_kd_level(const KdBuildArgs A) {
   // a child that cannot be split again (kd_build_node's first test) is a leaf already: straight into the leaf arrays
   const bool leaf_l = !(nl >= A.min_leaf_points && nl >= 2), leaf_r = !(nr >= A.min_leaf_points && nr >= 2);
   if (lane == 0) {
-    A.plane[nbase + node] = make_float4(mx, my, vx, vy);
-    A.link[nbase + node] = make_int2(left_id, 0);
-    if (leaf_l) A.link[nbase + left_id] = make_int2(-1 - begin, begin + nl);
-    if (leaf_r) A.link[nbase + left_id + 1] = make_int2(-1 - (begin + nl), end);
+    { KdNode nd = {mx, my, vx, vy, left_id, 0, 0, 0}; A.nodes[nbase + node] = nd; }
+    if (leaf_l) { KdNode nd = {0.0f, 0.0f, 0.0f, 0.0f, -1 - begin, begin + nl, 0, 0}; A.nodes[nbase + left_id] = nd; }
+    if (leaf_r) { KdNode nd = {0.0f, 0.0f, 0.0f, 0.0f, -1 - (begin + nl), end, 0, 0}; A.nodes[nbase + left_id + 1] = nd; }
     const int n_next = (leaf_l ? 0 : 1) + (leaf_r ? 0 : 1);
     if (n_next) {
       int q = atomicAdd(A.q_out_count, n_next);
@@ -593,6 +612,13 @@ __global__ void k_kd_finish(const int32_t* __restrict__ n_nodes, int n_clouds, K
   if (c < n_clouds) meta[c].n_nodes = n_nodes[c];
 }
 
+// the normals in leaf order, next to leaf_xy (every cloud of the set at once)
+__global__ void k_kd_permute_normals(const float2* __restrict__ nrm, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
+                                     const int32_t* __restrict__ leaf_idx, float2* __restrict__ leaf_nrm, int cloud0) {
+  const int c = cloud0 + blockIdx.y, n = count[c], base = start[c];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) leaf_nrm[base + i] = nrm[base + leaf_idx[base + i]];
+}
+
 struct SliceDev {
   CloudDev fixed, moving;
   int32_t finder;
@@ -622,6 +648,7 @@ struct AlignArgs {
   int32_t cols_max, fcan_total;
   int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
   int32_t kd_lds_nodes;                     // > 0: single KD-tree slice -- room in LDS for this many nodes of the fixed cloud's tree (its top levels)
+  int32_t kd_lds_points;                    // > 0: ... and, for scan-sized fixed clouds, for this many leaf points (whole trees on chip)
   const float* init_pose;
   const PriorDev* prior;
   int32_t  host_polls;                      // results go to pinned host memory and the host polls the status words: release them to the system
@@ -742,6 +769,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   // descent starts there (the host offers this only to pure KD-tree batches, where the region behind `red` is 16-byte aligned and free)
   float4* l_kpl = reinterpret_cast<float4*>(red + (kAlignBlock / 64) * kAccumWords);
   int2* l_klk = reinterpret_cast<int2*>(l_kpl + A.kd_lds_nodes);
+  float2* l_kxy = reinterpret_cast<float2*>(l_klk + A.kd_lds_nodes + (A.kd_lds_nodes & 1));      // 16-byte aligned: pairs of points are read as one
+  float2* l_knr = l_kxy + A.kd_lds_points + (A.kd_lds_points & 1);
   __shared__ float s_pose[3];
   __shared__ Iso   s_iso[kMaxSlices];
   // s_H: information matrix (H of the last solved iteration, built and solved IN LDS: thread 0's serial code has 64 registers like
@@ -813,11 +842,23 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     }
   }
   int kd_lds = 0;                            // nodes of this alignment's tree that were staged (workgroup-uniform)
+  bool kd_leaves_lds = false;                // ... and its leaf arrays
   if (kHasKd && A.kd_lds_nodes > 0) {
     const SliceDev& S = A.s[0];
     const KdMeta km = S.fixed.kd.meta[pick_cloud(S.fixed, a)];
     kd_lds = km.n_nodes < A.kd_lds_nodes ? km.n_nodes : A.kd_lds_nodes;
-    for (int i = tid; i < kd_lds; i += kAlignBlock) { l_kpl[i] = S.fixed.kd.plane[km.node_base + i]; l_klk[i] = S.fixed.kd.link[km.node_base + i]; }
+    const KdNode* nd = S.fixed.kd.nodes + km.node_base;
+    for (int i = tid; i < kd_lds; i += kAlignBlock) {
+      l_kpl[i] = reinterpret_cast<const float4*>(nd)[2 * i];
+      const int4 w = reinterpret_cast<const int4*>(nd)[2 * i + 1]; l_klk[i] = make_int2(w.x, w.y);
+    }
+    // a scan-sized fixed cloud (the tracker wiring: a tree per scan, every map point a query): its leaf arrays ride in LDS too -- the whole
+    // tree is on chip and 20 iterations x N_m queries touch global memory for the query stream only
+    if (A.kd_lds_points > 0) {
+      const int fc = pick_cloud(S.fixed, a), nf = S.fixed.count[fc], fb = S.fixed.start[fc];
+      kd_leaves_lds = nf <= A.kd_lds_points && kd_lds == km.n_nodes;      // workgroup-uniform
+      if (kd_leaves_lds) for (int i = tid; i < nf; i += kAlignBlock) { l_kxy[i] = S.fixed.kd.leaf_xy[fb + i]; l_knr[i] = S.fixed.kd.leaf_nrm[fb + i]; }
+    }
   }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   for (int s = 0; s < A.n_slices; ++s) {
@@ -893,11 +934,10 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         const bool use_kd = kHasKd && ((!kHasNN && !kHasDist) || S.finder == LSM2D_FINDER_KDTREE);
         GridMeta g; DistMeta dm;
         const int32_t* cst = nullptr; const int32_t* sidx = nullptr; const float2* sxy = nullptr;
-        const float4* kpl = nullptr; const int2* klk = nullptr;
+        const KdNode* knd = nullptr; const float2* knr = nullptr;
         if (use_kd) {      // the reference's tree over the fixed cloud (correspondence_finder_kd_tree_2d.cpp:18-19): one descent + one leaf per query
-          const int nb = __builtin_amdgcn_readfirstlane(S.fixed.kd.meta[fc].node_base);
-          kpl = S.fixed.kd.plane + nb; klk = S.fixed.kd.link + nb;
-          sidx = S.fixed.kd.leaf_idx + fbase; sxy = S.fixed.kd.leaf_xy + fbase;
+          knd = S.fixed.kd.nodes + __builtin_amdgcn_readfirstlane(S.fixed.kd.meta[fc].node_base);
+          sxy = S.fixed.kd.leaf_xy + fbase; knr = S.fixed.kd.leaf_nrm + fbase;
         } else if (use_grid) {
           g = S.fixed.grid.meta[fc];
           // the meta comes through a vector load: tell the compiler it is wave-uniform -- seven VGPRs fewer across the query loops, which
@@ -922,11 +962,22 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
             const float2 pm = live ? mp[j] : make_float2(0.0f, 0.0f);
             float qx, qy; xf_point(T, pm.x, pm.y, qx, qy);
             int best = -1;
+            if (use_kd) {      // the match's point and normal come from the leaf arrays, where the scan found it: the original index is never needed
+              if (live) {
+                float2 bxy;
+                const int pos = kd_leaves_lds ? kd_query_pos<true>(knd, l_kxy, qx, qy, md2, bxy, l_kpl, l_klk, kd_lds) : kd_query_pos(knd, sxy, qx, qy, md2, bxy, l_kpl, l_klk, kd_lds);
+                if (pos >= 0) {
+                  const float2 nm = mn[j], nf = kd_leaves_lds ? l_knr[pos] : knr[pos];
+                  float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+                  const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
+                  if (!(dot < S.normal_cos)) accumulate_pair(T, bxy, nf, pm, nm, S.cauchy != 0, S.tau, acc);
+                }
+              }
+            } else
             if (use_grid) {
               if (live) best = (group == 1 && nn_lds) ? nn_query<1, uint16_t, uint16_t>(g, l_cst, l_sidx, l_sxy, qx, qy, S.max_distance, md2, 0)
                                                       : nn_query<group>(g, cst, sidx, sxy, qx, qy, S.max_distance, md2, sub);
             }
-            else if (use_kd) { if (live) best = kd_query(kpl, klk, sxy, sidx, qx, qy, md2, l_kpl, l_klk, kd_lds); }
             else if (live) best = distmap_lookup(dm, S.fixed.dist.parent, qx, qy);
             if (best >= 0 && sub == 0) {                     // one lane per query accumulates
               const float2 nm = mn[j], nf = fn[best];
@@ -1457,9 +1508,9 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
   const int fbase = A.fixed.start[A.fc], mbase = A.moving.start[A.mc], n = A.moving.count[A.mc];
   GridMeta g; DistMeta dm;
   const int32_t* cst = nullptr; const int32_t* sidx = nullptr; const float2* sxy = nullptr;
-  const float4* kpl = nullptr; const int2* klk = nullptr;
+  const KdNode* knd = nullptr;
   if (A.use_distmap) dm = A.fixed.dist.meta[A.fc];
-  else if (A.use_kd) { const int nb = A.fixed.kd.meta[A.fc].node_base; kpl = A.fixed.kd.plane + nb; klk = A.fixed.kd.link + nb; sxy = A.fixed.kd.leaf_xy + fbase; sidx = A.fixed.kd.leaf_idx + fbase; }
+  else if (A.use_kd) { knd = A.fixed.kd.nodes + A.fixed.kd.meta[A.fc].node_base; sxy = A.fixed.kd.leaf_xy + fbase; sidx = A.fixed.kd.leaf_idx + fbase; }
   else {
     g = A.fixed.grid.meta[A.fc]; cst = A.fixed.grid.cell_start + g.cell_base;
     sidx = A.fixed.grid.sorted_idx + fbase; sxy = A.fixed.grid.sorted_xy + fbase;
@@ -1468,7 +1519,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
   const int group = (A.use_distmap || A.use_kd) ? 1 : A.nn_group, sub = tid & (group - 1);
   const int per_step = kFindBlock / group;
   auto query = [&](float qx, float qy) {
-    if (A.use_kd) return kd_query(kpl, klk, sxy, sidx, qx, qy, md2);
+    if (A.use_kd) return kd_query(knd, sxy, sidx, qx, qy, md2);
     return group == kNNGroup ? nn_query<kNNGroup>(g, cst, sidx, sxy, qx, qy, A.max_distance, md2, sub)
                              : nn_query<1>(g, cst, sidx, sxy, qx, qy, A.max_distance, md2, sub);
   };
@@ -1521,8 +1572,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn_multi(const FindNNArgs A
       float qx, qy; xf_point(A.T, pm.x, pm.y, qx, qy);
       if (A.use_distmap) best = distmap_lookup(A.fixed.dist.meta[A.fc], A.fixed.dist.parent, qx, qy);
       else if (A.use_kd) {
-        const int nb = A.fixed.kd.meta[A.fc].node_base;
-        best = kd_query(A.fixed.kd.plane + nb, A.fixed.kd.link + nb, A.fixed.kd.leaf_xy + fbase, A.fixed.kd.leaf_idx + fbase, qx, qy, A.max_distance * A.max_distance);
+        best = kd_query(A.fixed.kd.nodes + A.fixed.kd.meta[A.fc].node_base, A.fixed.kd.leaf_xy + fbase, A.fixed.kd.leaf_idx + fbase, qx, qy, A.max_distance * A.max_distance);
       } else {
         const GridMeta g = A.fixed.grid.meta[A.fc];
         const int32_t* cst = A.fixed.grid.cell_start + g.cell_base; const int32_t* sidx = A.fixed.grid.sorted_idx + fbase; const float2* sxy = A.fixed.grid.sorted_xy + fbase;

@@ -50,9 +50,11 @@ int main(int argc, char** argv) {
     aligner.compute();
 
     // the other two finders and the mapping steps, through their reference-named classes
-    CorrespondenceVector nn_pairs, dm_pairs;
-    { CorrespondenceFinderKDTree2D kd(ctx); kd.param_max_distance_m = 0.3f;
+    CorrespondenceVector nn_pairs, dm_pairs, kd_pairs;
+    { CorrespondenceFinderKDTree2D kd(ctx, "exact"); kd.param_max_distance_m = 0.3f;      // the exact grid search
       kd.setFixed(&fixed); kd.setMoving(&moving); kd.setLocalMapInSensor(pose); kd.setCorrespondences(&nn_pairs); kd.compute(); }
+    { CorrespondenceFinderKDTree2D kd(ctx); kd.param_max_distance_m = 0.3f; kd.param_max_leaf_range = 0.02f; kd.param_min_leaf_points = 9;      // the reference's own tree (the default)
+      kd.setFixed(&fixed); kd.setMoving(&moving); kd.setLocalMapInSensor(pose); kd.setCorrespondences(&kd_pairs); kd.compute(); }
     { CorrespondenceFinderNN2D dm(ctx); dm.param_max_distance_m = 0.5f; dm.param_resolution = 0.1f;
       dm.setFixed(&fixed); dm.setMoving(&moving); dm.setLocalMapInSensor(pose); dm.setCorrespondences(&dm_pairs); dm.compute(); }
     ReservedCloud scene(ctx, (int64_t) moving.size() + 4096), clipped(ctx, cols);
@@ -71,8 +73,8 @@ int main(int argc, char** argv) {
     const int merged_size = merger.compute();
     (void) robot;
 
-    printf("{\"threw_on_missing_inputs\": %d, \"n_nn\": %zu, \"n_distmap\": %zu, \"n_clipped\": %d, \"merged_size\": %d, \"merge_counts\": [%d,%d,%d], \"n_pairs\": %zu, \"pairs\": [",
-           threw, nn_pairs.size(), dm_pairs.size(), n_clipped, merged_size, merger.counts[0], merger.counts[1], merger.counts[2], correspondences.size());
+    printf("{\"threw_on_missing_inputs\": %d, \"n_nn\": %zu, \"n_kdtree\": %zu, \"n_distmap\": %zu, \"n_clipped\": %d, \"merged_size\": %d, \"merge_counts\": [%d,%d,%d], \"n_pairs\": %zu, \"pairs\": [",
+           threw, nn_pairs.size(), kd_pairs.size(), dm_pairs.size(), n_clipped, merged_size, merger.counts[0], merger.counts[1], merger.counts[2], correspondences.size());
     for (size_t i = 0; i < correspondences.size(); ++i) printf("%s[%d,%d]", i ? "," : "", correspondences[i].fixed_idx, correspondences[i].moving_idx);
     const Vector3f& x = aligner.movingInFixed();
     printf("], \"status\": %d, \"pose\": [%.9g, %.9g, %.9g], \"iterations\": %zu, \"last_n_corr\": %d}\n", aligner.status(), x[0], x[1], x[2],

@@ -538,6 +538,7 @@ def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     assert r["status"] == 0 and r["iterations"] == 20 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
     # the other finders and the mapping classes of the C++ mirror give the oracle's counts on the same inputs
     assert r["n_nn"] == len(po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.3), f, wl.map_points, x0))
+    assert r["n_kdtree"] == len(po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, kd_max_leaf_range=0.02, kd_min_leaf_points=9), f, wl.map_points, x0))
     assert r["n_distmap"] == len(po.find(po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.1), f, wl.map_points, x0))
     xi = synth.invert_poses(x0[None, :].astype(np.float64))[0]
     c, s_ = math.cos(float(x0[2])), math.sin(float(x0[2]))

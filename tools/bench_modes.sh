@@ -6,7 +6,9 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; tag=${1:-round}; O=$R/g
 run() { timeout -k 10 400 python bench.py "$@" 2>> $O/bench_modes.err | tail -1 >> $O/bench_modes.jsonl; echo "mode [$*] rc=$?"; }
 run                                                                  # configs[1], role A / projective (the headline line)
 run --role B --finder nn --cpu-sample 200                            # configs[1], role B / NN
+run --role B --finder kdtree --cpu-sample 200                        # configs[1], role B / the reference's own KD-tree (BASELINE's wording: tree over the map, scans as queries)
 run --role A --finder nn --max-distance 0.3 --cpu-sample 100 --steps 5      # configs[1], role A / NN
+run --role A --finder kdtree --max-distance 0.3 --cpu-sample 100 --steps 5  # configs[1], role A / KD-tree (a tree per scan, every map point a query: the tracker's wiring)
 run --role A --finder distmap --max-distance 0.5 --cpu-sample 100 --steps 10       # configs[1], distance-map finder (CorrespondenceFinderNN2D, row f4): a map per scan
 run --role B --finder distmap --max-distance 0.5 --cpu-sample 200 --steps 100      # same finder, ONE map over the 100k-point cloud serving every alignment (SURVEY f4's case)
 run --map-points 1000000 --cpu-sample 100 --steps 5                  # configs[4]
