@@ -47,6 +47,7 @@ struct lsm2d_context {
   int find_path = 0;           // 0 auto (point-query finder calls with more queries than one trip of a workgroup: many workgroups), 1 one workgroup always
   int grid_big_threshold = 16384;   // clouds of at least this many points get their search grid built by the chip-wide kernels (k_grid_big_*)
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
+  int cull = 1;                // k_align, projective slices: exact culling of the moving cloud against the fixed canvas (0: off; results do not depend on it)
   int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
   int kd_lds_nodes = 1536;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it; 512 / 1024 / 1536: 0.830 / 0.804 / 0.778 ms on configs[1] role B)
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
@@ -110,6 +111,7 @@ struct lsm2d_cloudset {
   mutable std::vector<KdCache> kds;
   // lane-chunked copy of xy for k_align's streaming pass (built on first use, dropped when the contents change)
   mutable float4* d_lane_xy = nullptr; mutable long long* d_lane_start = nullptr; mutable int32_t* d_lane_T = nullptr;
+  mutable float4* d_lane_bounds = nullptr;      // bounding circle of every thread's chunk of every cloud (k_lane_bounds): what the culling tests
   int32_t n_clouds = 0;
   mutable int64_t total = 0;  // logical points
   int64_t padded_total = 0;   // device points incl. even-alignment padding
@@ -248,6 +250,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "find_path")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_path must be 0 or 1"); ctx->find_path = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { if (value < 1 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_threshold: out of range"); ctx->grid_big_threshold = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull must be 0 or 1"); ctx->cull = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
@@ -258,6 +261,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "kernel_timing")) { *out_value = ctx->kernel_timing ? 1 : 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "align_path")) { *out_value = ctx->align_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { *out_value = ctx->distmap_build; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull")) { *out_value = ctx->cull; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kd_levels")) { *out_value = ctx->last_kd_levels; return LSM2D_SUCCESS; }
@@ -408,6 +412,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_lane_xy) (void) hipFree(cs->d_lane_xy);
   if (cs->d_lane_start) (void) hipFree(cs->d_lane_start);
   if (cs->d_lane_T) (void) hipFree(cs->d_lane_T);
+  if (cs->d_lane_bounds) (void) hipFree(cs->d_lane_bounds);
   if (cs->ctx && cs->staged_epoch == cs->ctx->sync_epoch) (void) stream_sync(cs->ctx);      // a staged transfer may still be reading h_upload
   if (cs->h_upload) (void) hipHostFree(cs->h_upload);
   if (cs->ctx) { auto& v = cs->ctx->live_sets; for (size_t i = 0; i < v.size(); ++i) if (v[i] == cs) { v[i] = v.back(); v.pop_back(); break; } }
@@ -490,6 +495,7 @@ static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents 
   if (cs->d_lane_xy) { (void) hipFree(cs->d_lane_xy); cs->d_lane_xy = nullptr; }
   if (cs->d_lane_start) { (void) hipFree(cs->d_lane_start); cs->d_lane_start = nullptr; }
   if (cs->d_lane_T) { (void) hipFree(cs->d_lane_T); cs->d_lane_T = nullptr; }
+  if (cs->d_lane_bounds) { (void) hipFree(cs->d_lane_bounds); cs->d_lane_bounds = nullptr; }
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   cs->dists.clear();
   for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block);
@@ -626,7 +632,7 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
 }
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
-  c.lane_xy = cs->d_lane_xy; c.lane_start = cs->d_lane_start; c.lane_T = cs->d_lane_T;
+  c.lane_xy = cs->d_lane_xy; c.lane_start = cs->d_lane_start; c.lane_T = cs->d_lane_T; c.lane_bounds = cs->d_lane_bounds;
   c.grid = GridDev{nullptr, nullptr, nullptr, nullptr};
   c.dist = DistDev{nullptr, nullptr};
   c.kd = KdDev{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -799,7 +805,10 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
     lstart[c] = slots; lT[c] = T; slots += (long long) T * kAlignBlock; if (T > maxT) maxT = T;
   }
   if (slots == 0) slots = 1;
+  slots += 2 * kAlignBlock;      // two spare rows behind the last cloud: project_cloud_units' look-ahead load may read one row past a cloud's last
   HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_xy, sizeof(float4) * (size_t) slots));
+  HIPCHK(ctx, hipMemsetAsync(cs->d_lane_xy + (slots - 2 * kAlignBlock), 0x7f, sizeof(float4) * 2 * kAlignBlock, ctx->stream));
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_bounds, sizeof(float4) * (size_t) nc * kAlignBlock));
   HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_start, sizeof(long long) * (size_t) nc));
   HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_T, sizeof(int32_t) * (size_t) nc));
   HIPCHK(ctx, hipMemcpyAsync(cs->d_lane_start, lstart.data(), sizeof(long long) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
@@ -810,6 +819,8 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
     hipLaunchKernelGGL(k_lane_layout, dim3((unsigned) gx, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
                        (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const long long*) cs->d_lane_start,
                        (const int32_t*) cs->d_lane_T, (int) kAlignBlock, cs->d_lane_xy, c0);
+    hipLaunchKernelGGL(k_lane_bounds, dim3((unsigned) (kAlignBlock / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) cs->d_lane_T, (int) kAlignBlock, cs->d_lane_bounds, c0);
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, stream_sync(ctx));        // the host vectors above back the async copies
@@ -1547,6 +1558,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     S.fcan_offset = fcan_total; fcan_total += S.proj.cols; if (S.proj.cols > cols_max) cols_max = S.proj.cols;
   }
   A.cols_max = cols_max; A.fcan_total = fcan_total;
+  A.cull = ctx->cull;      // (the test's column loop wraps once: canvases below 64 columns are not worth it and would need a second wrap)
+  for (int s = 0; s < ns; ++s) if (b->slices[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].proj.cols < 64) A.cull = 0;
   size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float4) * (size_t) fcan_total +
                sizeof(float) * kAccumWords * (kAlignBlock / 64);      // moving canvas, fixed canvases, fixed winners, reduction
   // one NN slice whose fixed clouds are scan-sized (one lane per query): stage each cloud's search tables in LDS.  Budget 38 KB

@@ -269,6 +269,99 @@ LSM2D_DEV void project_cloud_lanes_t(const float4* __restrict__ lane_xy, int T_s
   }
   if (t < T_steps) pair(va, idx);
 }
+// ---- exact culling of the moving cloud against the FIXED canvas ---------------------------------------------------------------------
+// The bin walk pairs a column's moving winner with its fixed cell only when the fixed cell is filled and |depth_f - depth_m| <=
+// point_distance (correspondence_finder_projective_2d.cpp:61-65).  A moving point whose column has an EMPTY fixed cell, or whose depth
+// exceeds depth_f + point_distance, therefore never yields a pair -- and dropping ALL such points leaves every pair as it was: if the
+// column's winner is one of them, the pair it would have formed is rejected by the depth gate, and every other point of the column that
+// could take its place is farther still, i.e. dropped as well; if the winner is not one of them, it stays the winner.  The moving canvas
+// differs, the correspondences (hence H, b, the statistics and the pose) do not: bit for bit.
+// The test is made per CHUNK (the contiguous run of map points one thread of k_align owns), on its bounding circle (centre c, radius
+// rho, computed once per cloud: k_lane_bounds): under the pose T every point of the chunk has depth >= |T c| - rho and a bearing within
+// asin(rho / |T c|) of the centre's.  The chunk is dropped when that depth bound exceeds depth_f + point_distance in EVERY column its
+// bearing range can reach (empty fixed cells count as "no depth at all"), or the range gate, with margins far above fp32 rounding.
+// On configs[1] (a 270-degree scan in a room with pillars) 57 % of the chunks of a 100k-point map fall to it: blind sector 22 %, beyond
+// range_max 16 %, behind what the scan saw 19 %.
+LSM2D_DEV bool chunk_may_matter(const Iso& T, const ProjK& P, float4 bd /* cx, cy, rho (< 0: no points) */, const u64* fcan, float point_distance) {
+  if (bd.z < 0.0f) return false;
+  float qx, qy;
+  xf_point(T, bd.x, bd.y, qx, qy);
+  const float r2 = __builtin_fmaf(qx, qx, qy * qy);
+  if (!(r2 >= 1e-30f && r2 <= 1e37f)) return true;                  // degenerate: no claim
+  float y0;
+  const float D = sqrt_rn_seed(r2, y0), rho = bd.z;
+  const float near = D - rho - (1e-3f + 1e-5f * D);                 // every point of the chunk is at least this deep (triangle inequality, minus slack)
+  if (near > P.rmax) return false;                                   // the range gate takes them all
+  if (!(D > 2.0f * rho + 0.05f)) return true;                       // the sensor is next to (or inside) the chunk: its bearings spread over more than 30 degrees
+  const float th = bearing<true>(qy, qx, D, y0);
+  const float u = __builtin_fmaf(P.K00, th, P.K01);
+  const float dc = P.K00 * (rho / D) * 1.06f + 1.5f;                // asin(x) <= 1.048 x on [0, 1/2]; 1.5 columns for the floors and the arithmetic
+  if (!(dc <= 24.0f)) return true;
+  const int c_lo = (int) __builtin_floorf(u - dc), c_hi = (int) __builtin_floorf(u + dc);
+  float deepest = -__builtin_huge_valf();                            // deepest fixed cell among the columns in reach; empty cells (a NaN pattern) do not count
+  for (int c = c_lo; c <= c_hi; ++c) {
+    const int cc = c < 0 ? c + P.cols : (c >= P.cols ? c - P.cols : c);      // a full-circle canvas wraps; for a partial one the wrapped column is a harmless extra
+    if ((unsigned) cc < (unsigned) P.cols) deepest = __builtin_fmaxf(deepest, __uint_as_float((uint32_t) (fcan[cc] >> 32)));
+  }
+  return !(near > deepest + point_distance);
+}
+
+// The surviving chunks' points through the z-buffer, spread evenly over the workgroup: a chunk's T steps are cut into nb blocks of B
+// steps; unit v = (block v / s, survivor v mod s); thread u takes the units u, u + nthreads, ...  Neighbouring lanes hold neighbouring
+// SURVIVORS at the same block offset -- still a chunk (>= 43 cm of wall on configs[1]) apart, so a wave-instruction's ds_min_u64s almost
+// never share a cell (the reason for the lane-chunked layout), and their 16-byte loads fall into one or two rows of the copy.
+template <bool kGuarded>
+LSM2D_DEV void project_cloud_units_t(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin, u64* canvas, int tid, int nthreads,
+                                     const uint16_t* surv, int s, int B, int nb) {
+  const Iso T = Tin; ProjK P = Pin;
+  asm volatile("" : "+v"(P.K01));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long pb = reinterpret_cast<unsigned long long>(lane_xy);
+  const unsigned pb_hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (pb >> 32));
+  const unsigned pb_lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) pb);
+  float4* ubase = reinterpret_cast<float4*>(((unsigned long long) pb_hi << 32) | (unsigned long long) pb_lo);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, (short) 0, 0x7fffffff, 0x00020000);
+  const int row_bytes = nthreads * (int) sizeof(float4);
+  int i = tid, blk = 0;
+  while (i >= s && blk < nb) { i -= s; ++blk; }
+  while (blk < nb) {
+    const int g = (int) surv[i];
+    const int t0 = blk * B;
+    const int nsteps = T_steps - t0 < B ? T_steps - t0 : B;
+    const int voff = g * (int) sizeof(float4) + t0 * row_bytes;      // this lane's chunk and block; the step advances in the scalar offset
+    int idx = 2 * (g * T_steps + t0);
+    auto load = [&](int soff) {
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+      return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    };
+    auto pair = [&](const float4& v, int k) {
+      project_point_stream<kGuarded>(T, P, v.x, v.y, k, canvas);
+      project_point_stream<kGuarded>(T, P, v.z, v.w, k + 1, canvas);
+    };
+    // two steps per trip, the two load buffers swapping roles.  The scalar offset advances unconditionally (it must stay wave-uniform: the
+    // last block of a chunk is shorter in some lanes): the last trip's look-ahead load reads one row past the block -- the next block's,
+    // the next cloud's, or one of the two spare rows ensure_lane_layout() keeps behind the last cloud -- and is never used.
+    int t = 0, soff = 0;
+    float4 va = load(0);
+    for (; t + 2 <= nsteps; t += 2) {
+      const float4 vb = load(soff + row_bytes);
+      pair(va, idx);
+      soff += 2 * row_bytes;
+      va = load(soff);
+      pair(vb, idx + 2);
+      idx += 4;
+    }
+    if (t < nsteps) pair(va, idx);
+    i += nthreads;
+    while (i >= s && blk < nb) { i -= s; ++blk; }
+  }
+}
+LSM2D_DEV void project_cloud_units(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P, u64* canvas, int tid, int nthreads,
+                                   const uint16_t* surv, int s, int B, int nb) {
+  if (P.tiny_ok) project_cloud_units_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads, surv, s, B, nb);
+  else project_cloud_units_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads, surv, s, B, nb);
+}
+
 LSM2D_DEV void project_cloud_lanes(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P,
                                    u64* canvas, int tid, int nthreads) {
   if (P.tiny_ok) project_cloud_lanes_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads);

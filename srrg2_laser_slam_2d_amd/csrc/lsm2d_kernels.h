@@ -133,6 +133,7 @@ struct CloudDev {            // device view of a cloud set
   const float4* lane_xy;     // lane-chunked copy of xy for the k_align streaming pass (see project_cloud_lanes), or nullptr
   const long long* lane_start; // [n_clouds] first float4 slot of each cloud in lane_xy
   const int32_t* lane_T;     // [n_clouds] steps per thread
+  const float4* lane_bounds; // [n_clouds][kAlignBlock] bounding circle (cx, cy, rho; rho < 0: no points) of the chunk each thread owns, or nullptr
   GridDev grid;              // valid only when the slice uses the NN finder on this (fixed) cloud
   DistDev dist;              // valid only when the slice uses the distance-map finder on this (fixed) cloud
   KdDev kd;                  // valid only when the slice uses the KD-tree finder on this (fixed) cloud
@@ -649,6 +650,7 @@ struct AlignArgs {
   int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
   int32_t kd_lds_nodes;                     // > 0: single KD-tree slice -- room in LDS for this many nodes of the fixed cloud's tree (its top levels)
   int32_t kd_lds_points;                    // > 0: ... and, for scan-sized fixed clouds, for this many leaf points (whole trees on chip)
+  int32_t cull;                             // 1: projective slices drop the chunks of the moving cloud that cannot yield a pair (chunk_may_matter), results unchanged
   const float* init_pose;
   const PriorDev* prior;
   int32_t  host_polls;                      // results go to pinned host memory and the host polls the status words: release them to the system
@@ -780,6 +782,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   __shared__ float s_H[9], s_rhs[3], s_sum[kAccumWords + 2];
   __shared__ int   s_n_corr, s_active, s_done, s_status, s_last_n_in;
   __shared__ float s_prev_chi;      // total chi^2 of the previous iteration (termination_chi_epsilon)
+  __shared__ uint16_t s_surv[kAlignBlock];      // culling: the chunks of the moving cloud that survived this iteration's test, compacted in thread order
+  __shared__ int s_wcnt[kAlignBlock / 64];
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   const int a = blockIdx.x, tid = threadIdx.x;
@@ -901,7 +905,24 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
           // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
           const int mc = pick_cloud(S.moving, a);
           // clouds of at most one pair per thread (the tracker's clipped scenes) need no lane-chunked copy
-          if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
+          if (S.moving.lane_xy && S.moving.lane_bounds && A.cull) {
+            // exact culling against the fixed canvas (chunk_may_matter): every thread tests the chunk it would stream, the survivors are
+            // compacted (two barriers: counts, then the list) and their points spread evenly over the workgroup (project_cloud_units)
+            const int lane = tid & 63, wave = tid >> 6;
+            const bool keep = chunk_may_matter(T, S.proj, S.moving.lane_bounds[(size_t) mc * kAlignBlock + tid], fcan + S.fcan_offset, S.point_distance);
+            const u64 bal = __ballot(keep);
+            if (lane == 0) s_wcnt[wave] = __popcll(bal);
+            __syncthreads();
+            int before = 0, n_surv = 0;
+#pragma unroll
+            for (int w = 0; w < nwaves; ++w) { const int cw = s_wcnt[w]; before += w < wave ? cw : 0; n_surv += cw; }
+            if (keep) s_surv[before + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t) tid;
+            __syncthreads();
+            const int Tm = S.moving.lane_T[mc];
+            const int B = 2 * ((Tm + 15) / 16), nb = (Tm + B - 1) / B;      // at most 8 blocks of an even number of steps
+            if (n_surv > 0) project_cloud_units(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv, B, nb);
+          }
+          else if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
           else project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
         }
         __syncthreads();
@@ -2139,6 +2160,35 @@ __global__ void k_lane_layout(const float2* __restrict__ xy, const int32_t* __re
     if (2 * pair + 1 < n) { const float2 b = p[2 * pair + 1]; v.z = b.x; v.w = b.y; }
     o[m] = v;
   }
+}
+
+// bounding circle of every thread's chunk of the lane-chunked copy (chunk g of cloud c = the points [2 g T, 2 (g + 1) T) of the cloud):
+// centre = centre of the chunk's bounding box, radius = the largest distance to it, rounded up; what chunk_may_matter() tests.
+// One wave per chunk.
+__global__ __launch_bounds__(256) void k_lane_bounds(const float2* __restrict__ xy, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
+                                                     const int32_t* __restrict__ lane_T, int nthreads, float4* __restrict__ out, int cloud0) {
+  const int c = cloud0 + blockIdx.y, g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= nthreads) return;
+  const int n = count[c], T = lane_T[c];
+  const long long lo = 2ll * g * T, hi = lo + 2ll * T < n ? lo + 2ll * T : n;
+  const float2* p = xy + start[c];
+  float mnx = 3.402823466e+38f, mny = mnx, mxx = -mnx, mxy = -mnx;
+  for (long long i = lo + lane; i < hi; i += 64) { const float2 v = p[i]; mnx = fminf(mnx, v.x); mxx = fmaxf(mxx, v.x); mny = fminf(mny, v.y); mxy = fmaxf(mxy, v.y); }
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+    mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+  }
+  float4 r = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
+  if (hi > lo) {
+    const float cx = 0.5f * (mnx + mxx), cy = 0.5f * (mny + mxy);
+    float d2 = 0.0f;
+    for (long long i = lo + lane; i < hi; i += 64) { const float2 v = p[i]; const float dx = v.x - cx, dy = v.y - cy; d2 = fmaxf(d2, dx * dx + dy * dy); }
+    for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o, 64));
+    // non-finite points (they fail the range gate anyway) must not poison the circle: a chunk holding one keeps its points (rho = +inf never culls)
+    const float rho = (d2 == d2) ? __builtin_sqrtf(d2) * 1.00001f + 1e-6f : __builtin_huge_valf();
+    r = make_float4(cx, cy, (cx == cx && cy == cy) ? rho : __builtin_huge_valf(), 0.0f);
+  }
+  if (lane == 0) out[(size_t) c * nthreads + g] = r;
 }
 
 // ---- refill of a small single-cloud set straight from its pinned staging buffer (lsm2d_cloudset_upload): the kernel reads the
