@@ -47,6 +47,9 @@ struct lsm2d_context {
   int find_path = 0;           // 0 auto (point-query finder calls with more queries than one trip of a workgroup: many workgroups), 1 one workgroup always
   int grid_big_threshold = 16384;   // clouds of at least this many points get their search grid built by the chip-wide kernels (k_grid_big_*)
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
+  int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / k_balance_order); 0: workgroup b = alignment b
+  int n_cu = 0;                // compute units of the device (hipDeviceProp_t.multiProcessorCount)
+  int cull_block = 0;          // steps per unit of the culled stream (0: automatic, ~1/25 of a chunk; even; tuning knob)
   int cull = 1;                // k_align, projective slices: exact culling of the moving cloud against the fixed canvas (0: off; results do not depend on it)
   int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
   int kd_lds_nodes = 1536;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it; 512 / 1024 / 1536: 0.830 / 0.804 / 0.778 ms on configs[1] role B)
@@ -201,10 +204,12 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   hipDeviceProp_t prop;
   HIPCHK(ctx, hipGetDeviceProperties(&prop, device_id));
   c->max_dyn_lds = (int) prop.sharedMemPerBlock;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_cull_estimate, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -250,7 +255,9 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "find_path")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_path must be 0 or 1"); ctx->find_path = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { if (value < 1 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_threshold: out of range"); ctx->grid_big_threshold = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull must be 0 or 1"); ctx->cull = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull must be 0, 1 or 2"); ctx->cull = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
@@ -262,6 +269,8 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "align_path")) { *out_value = ctx->align_path; return LSM2D_SUCCESS; }
   if (!strcmp(key, "distmap_build")) { *out_value = ctx->distmap_build; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull")) { *out_value = ctx->cull; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_block")) { *out_value = ctx->cull_block; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kd_levels")) { *out_value = ctx->last_kd_levels; return LSM2D_SUCCESS; }
@@ -1465,6 +1474,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   // in-kernel clock stamps of ~32 workgroups spread over the grid (timed k_align launches only)
   const int clock_stride = ctx->clock_stride > 0 ? ctx->clock_stride : (n / 32 > 1 ? n / 32 : 1), n_clock = (n + clock_stride - 1) / clock_stride;
   const size_t o_clock = ctx->kernel_timing ? take(sizeof(unsigned long long) * 4 * (size_t) n_clock) : 0;
+  const size_t o_work = take(sizeof(int32_t) * (size_t) n), o_order = take(sizeof(int32_t) * (size_t) n);      // balanced placement (device only)
   const size_t total_bytes = off, out_bytes = total_bytes - o_pose;
   int rc = ensure_scratch(ctx, total_bytes); if (rc) return rc;
   rc = ensure_stage(ctx, total_bytes); if (rc) return rc;
@@ -1558,6 +1568,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     S.fcan_offset = fcan_total; fcan_total += S.proj.cols; if (S.proj.cols > cols_max) cols_max = S.proj.cols;
   }
   A.cols_max = cols_max; A.fcan_total = fcan_total;
+  A.cull_block = ctx->cull_block;
   A.cull = ctx->cull;      // (the test's column loop wraps once: canvases below 64 columns are not worth it and would need a second wrap)
   for (int s = 0; s < ns; ++s) if (b->slices[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].proj.cols < 64) A.cull = 0;
   size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float4) * (size_t) fcan_total +
@@ -1625,6 +1636,19 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   }
   else HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
   ctx->last_align_path = use_split ? 2 : (use_pair ? 3 : 1);
+  // culled batches that run in about one dispatch round: balanced placement (two small launches ahead of k_align; see k_cull_estimate)
+  A.order = nullptr;
+  if (!use_split && !use_pair && !zero_copy && A.cull && ctx->balance && n > 256 && has_proj) {
+    int bs = -1;
+    for (int s = 0; s < ns && bs < 0; ++s) if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].moving.lane_xy && A.s[s].moving.lane_bounds) bs = s;
+    if (bs >= 0) {
+      int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work); int32_t* d_order = (int32_t*) ((char*) ctx->d_scratch + o_order);
+      hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), sizeof(u64) * (size_t) A.s[bs].proj.cols, ctx->stream, A, bs, d_work);
+      hipLaunchKernelGGL(k_balance_order, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*) d_work, n, ctx->n_cu, 4, d_order);
+      HIPCHK(ctx, hipGetLastError());
+      A.order = d_order;
+    }
+  }
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   if (use_split) {
     // workspace: global canvases + running pose / flags, grown on demand and kept by the context

@@ -356,6 +356,59 @@ LSM2D_DEV void project_cloud_units_t(const float4* __restrict__ lane_xy, int T_s
     while (i >= s && blk < nb) { i -= s; ++blk; }
   }
 }
+// The same survivors, balanced to within one step: the s surviving chunks x T steps form a matrix (row = step t, column = survivor i);
+// thread u takes the elements u, u + nthreads, ... of its row-major order.  The lanes of a wave then hold consecutive survivors at the SAME
+// step -- their 16-byte loads fall into one row of the copy, and they stay a chunk apart along the map -- and every thread gets
+// floor or ceil of s T / nthreads steps.  One step (two points) per element: the column is advanced incrementally (no division in the
+// loop), the survivor's chunk comes from the LDS list one element ahead, two loads are in flight.
+template <bool kGuarded>
+LSM2D_DEV void project_cloud_rows_t(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin, u64* canvas, int tid, int nthreads,
+                                    const uint16_t* surv, int s) {
+  const Iso T = Tin; ProjK P = Pin;
+  asm volatile("" : "+v"(P.K01));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long pb = reinterpret_cast<unsigned long long>(lane_xy);
+  const unsigned pb_hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (pb >> 32));
+  const unsigned pb_lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) pb);
+  float4* ubase = reinterpret_cast<float4*>(((unsigned long long) pb_hi << 32) | (unsigned long long) pb_lo);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, (short) 0, 0x7fffffff, 0x00020000);
+  const int row_bytes = nthreads * (int) sizeof(float4);
+  const int q0 = nthreads / s, d = nthreads - q0 * s;          // one division per call, wave-uniform: an element's successor is q0 rows and d columns on
+  // (t, i): step and column of the NEXT element to be loaded
+  int t = 0, i = tid;
+  if (i >= s) { const int q = i / s; t = q; i -= q * s; }
+  auto advance = [&]() { t += q0; i += d; if (i >= s) { i -= s; ++t; } };
+  auto issue = [&](int g, int tt, float4& buf, int& idx) {
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * (int) sizeof(float4) + tt * row_bytes, 0, 0);
+    buf = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    idx = 2 * (g * T_steps + tt);
+  };
+  auto pair = [&](const float4& v, int k) {
+    project_point_stream<kGuarded>(T, P, v.x, v.y, k, canvas);
+    project_point_stream<kGuarded>(T, P, v.z, v.w, k + 1, canvas);
+  };
+  float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va; int ia = 0, ib = 0;
+  bool ha = t < T_steps;
+  if (ha) { issue((int) surv[i], t, va, ia); advance(); }
+  bool hb = ha && t < T_steps;
+  if (hb) { issue((int) surv[i], t, vb, ib); advance(); }
+  int g_next = (hb && t < T_steps) ? (int) surv[i] : 0;        // the survivor of the element after those two, fetched ahead of its use
+  while (ha) {
+    pair(va, ia);
+    ha = hb && t < T_steps;
+    if (ha) { issue(g_next, t, va, ia); advance(); g_next = t < T_steps ? (int) surv[i] : 0; }
+    if (!hb) break;
+    pair(vb, ib);
+    hb = ha && t < T_steps;
+    if (hb) { issue(g_next, t, vb, ib); advance(); g_next = t < T_steps ? (int) surv[i] : 0; }
+  }
+}
+LSM2D_DEV void project_cloud_rows(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P, u64* canvas, int tid, int nthreads,
+                                  const uint16_t* surv, int s) {
+  if (P.tiny_ok) project_cloud_rows_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads, surv, s);
+  else project_cloud_rows_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads, surv, s);
+}
+
 LSM2D_DEV void project_cloud_units(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P, u64* canvas, int tid, int nthreads,
                                    const uint16_t* surv, int s, int B, int nb) {
   if (P.tiny_ok) project_cloud_units_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads, surv, s, B, nb);

@@ -650,6 +650,8 @@ struct AlignArgs {
   int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
   int32_t kd_lds_nodes;                     // > 0: single KD-tree slice -- room in LDS for this many nodes of the fixed cloud's tree (its top levels)
   int32_t kd_lds_points;                    // > 0: ... and, for scan-sized fixed clouds, for this many leaf points (whole trees on chip)
+  const int32_t* order;                     // alignment handled by workgroup b (nullptr: b itself) -- the balanced placement of k_balance_order
+  int32_t cull_block;                       // steps per unit of the culled stream (0: automatic; tuning knob)
   int32_t cull;                             // 1: projective slices drop the chunks of the moving cloud that cannot yield a pair (chunk_may_matter), results unchanged
   const float* init_pose;
   const PriorDev* prior;
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   __shared__ int s_wcnt[kAlignBlock / 64];
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
-  const int a = blockIdx.x, tid = threadIdx.x;
+  const int a = A.order ? A.order[blockIdx.x] : (int) blockIdx.x, tid = threadIdx.x;
   constexpr int nwaves = kAlignBlock / 64;
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
   __shared__ unsigned long long s_clk[2];      // start stamps wait in LDS: no register is held across the kernel for them
@@ -919,8 +921,14 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
             if (keep) s_surv[before + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t) tid;
             __syncthreads();
             const int Tm = S.moving.lane_T[mc];
-            const int B = 2 * ((Tm + 15) / 16), nb = (Tm + B - 1) / B;      // at most 8 blocks of an even number of steps
-            if (n_surv > 0) project_cloud_units(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv, B, nb);
+            // blocks of an even number of steps, 7 per chunk (measured on configs[1], T = 98: blocks of 2 / 4 / 6 / 8 / 14 steps 1.098 / 1.017 /
+            // 0.991 / 0.983 / 0.969 ms -- what a unit costs to set up outweighs the better balance of smaller ones; element-wise row-major
+            // order, balanced to one step, 1.066: project_cloud_rows, "cull" 2)
+            const int B = A.cull_block > 0 ? A.cull_block : 2 * ((Tm + 13) / 14), nb = (Tm + B - 1) / B;
+            if (n_surv > 0) {
+              if (A.cull == 2) project_cloud_rows(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv);
+              else project_cloud_units(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv, B, nb);
+            }
           }
           else if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
           else project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
@@ -1093,6 +1101,54 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     }
     if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     else A.out_status[a] = st;
+  }
+}
+
+// ---- balanced placement for culled batches -------------------------------------------------------------------------------------------
+// With the exact culling an alignment's work depends on its pose and scan (33 .. 59 % of the map's chunks survive on configs[1]), and a
+// batch of about one workgroup per slot of the chip runs in ONE dispatch round: the CU that happens to get four heavy alignments ends the
+// launch (workgroup lifetimes 0.64 .. 1.07 ms in one launch, tools/occupancy_probe.py).  Two small launches ahead of k_align fix that:
+// k_cull_estimate counts, per alignment, the chunks that survive at the START pose (what the first iteration will stream; later iterations
+// move the pose by centimetres); k_balance_order ranks the alignments by that count and deals them to workgroup ids so that the ids which
+// share a CU -- b, b + n_cu, b + 2 n_cu, ... as the dispatcher deals them (same probe) -- get a heavy, a light, a heavy, a light one
+// (boustrophedon rows); beyond the first round the heaviest go first.  Only WHERE an alignment runs changes; every result is the same.
+__global__ __launch_bounds__(kAlignBlock) void k_cull_estimate(const AlignArgs A, int slice, int32_t* __restrict__ work) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64* fcan = reinterpret_cast<u64*>(smem);
+  __shared__ Iso s_T;
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const SliceDev& S = A.s[slice];
+  for (int i = tid; i < S.proj.cols; i += kAlignBlock) fcan[i] = kEmptyCell;
+  if (tid == 0) { const float p[3] = {A.init_pose[3 * a], A.init_pose[3 * a + 1], A.init_pose[3 * a + 2]}; s_T = slice_iso(S, p); }
+  __syncthreads();
+  const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
+  const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
+  project_cloud(S.fixed.xy + S.fixed.start[fc], S.fixed.count[fc], ident, S.proj, fcan, tid, kAlignBlock);
+  __syncthreads();
+  const bool keep = chunk_may_matter(s_T, S.proj, S.moving.lane_bounds[(size_t) mc * kAlignBlock + tid], fcan, S.point_distance);
+  const int n_keep = __syncthreads_count(keep);
+  if (tid == 0) work[a] = n_keep;
+}
+
+__global__ __launch_bounds__(1024) void k_balance_order(const int32_t* __restrict__ work, int n, int n_cu, int per_cu, int32_t* __restrict__ order) {
+  __shared__ int s_bin[kAlignBlock + 2];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kAlignBlock + 2; i += 1024) s_bin[i] = 0;
+  __syncthreads();
+  for (int a = tid; a < n; a += 1024) atomicAdd(&s_bin[work[a]], 1);
+  __syncthreads();
+  if (tid == 0) { int pos = 0; for (int w = kAlignBlock; w >= 0; --w) { const int c = s_bin[w]; s_bin[w] = pos; pos += c; } }      // heaviest first
+  __syncthreads();
+  const int first = n < n_cu * per_cu ? n : n_cu * per_cu;      // the ranks that go out in the first dispatch round
+  for (int a = tid; a < n; a += 1024) {
+    const int r = atomicAdd(&s_bin[work[a]], 1);                // rank among all alignments (ties in any order: placement only)
+    int b = r;
+    if (r < first) {
+      const int row = r / n_cu; int col = r - row * n_cu;
+      if (row & 1) { const int len = first - row * n_cu < n_cu ? first - row * n_cu : n_cu; col = len - 1 - col; }
+      b = row * n_cu + col;
+    }
+    order[b] = a;
   }
 }
 

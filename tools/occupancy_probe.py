@@ -40,6 +40,18 @@ def main():
     wg, cyc, ticks, start, hw = rows.T
     xcc = hw >> 32; hwid = hw & 0xffffffff
     cu = (xcc << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 12) & 1) << 4) | ((hwid >> 8) & 15)
+    # which workgroup ids share a CU: the dispatcher's dealing order (speed only -- the balanced ordering of lsm2d_align_batch assumes one)
+    by_cu = collections.defaultdict(list)
+    for w_, c_ in zip(wg.tolist(), cu.tolist()):
+        by_cu[c_].append(w_)
+    diffs = collections.Counter()
+    for ids in by_cu.values():
+        ids.sort()
+        for a_, b_ in zip(ids[:-1], ids[1:]):
+            diffs[b_ - a_] += 1
+    print("workgroup-id distance between neighbours on one CU (most common):", diffs.most_common(6))
+    print("first CUs:", [sorted(v) for v in list(by_cu.values())[:6]])
+    print("XCD of workgroups 0..15:", xcc[np.argsort(wg)][:16].tolist())
     per_cu = collections.Counter(cu.tolist())
     print("CUs used %d; workgroups per CU over the launch: %s" % (len(per_cu), sorted(collections.Counter(per_cu.values()).items())))
     first = start < 0.2 * (start + ticks).max()

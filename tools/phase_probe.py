@@ -9,6 +9,8 @@ from srrg2_laser_slam_2d_amd import api, synth
 
 role, kind = (sys.argv + ["B", "distmap"])[1:3]
 ctx = api.Context(0, kernel_timing=True); ctx.set_option("clock_stride", 1)
+for kv in filter(None, os.environ.get("LSM2D_BENCH_OPTIONS", "").split(",")):
+    ctx.set_option(kv.partition("=")[0].strip(), int(kv.partition("=")[2]))
 wl = synth.make_workload(1000, 100000, seed=0)
 if kind == "projective":
     f = api.CorrespondenceFinderProjective2f(ctx, api.PointNormal2fProjectorPolar(1081, -math.pi, math.pi, 0.3, 30.0), 0.5, 0.8)
