@@ -20,3 +20,10 @@ if __name__ == "__main__":
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tracker_chain.json")
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path, "final map", out["steps"][-1]["map_points"], "points")
+    # BASELINE configs[2] at its stated size: 1000 steps of the same chain (MULTI parameters: 721 columns, 10 iterations, two WithSensor
+    # laser slices + odometry prior, clip + merge), digests of every 50th step (apps/visual_test_tracker_2d.cpp:167-183 is the usage contract)
+    out = {"note": "oracle-generated digests (sha256[:20] of the float32 arrays), not reference outputs", "scenario": "tests/tracker_chain.py scenario(1000)",
+           "steps_total": 1000, "record_every": 50, "steps": tracker_chain.run_oracle(po, 1000, record_every=50)}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tracker_replay_1000.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print("wrote", path, "final map", out["steps"][-1]["map_points"], "points")

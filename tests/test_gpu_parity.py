@@ -2449,3 +2449,130 @@ def test_sweep_replication_paths_peer_same_device_and_host(ctx, small_workload):
                 assert np.array_equal(pose, want.pose) and np.array_equal(status, want.status) and np.array_equal(iters, want.iterations), (devices, peer_copy)
             finally:
                 lib.lsm2d_sweep_destroy(sw)
+
+
+# ---- BASELINE configs[2] and configs[4] at their stated sizes ---------------------------------------------------------------------------
+def test_configs2_full_replay_1000_steps_against_committed_digests(ctx):
+    """BASELINE configs[2] at its size (usage contract apps/visual_test_tracker_2d.cpp:167-183): 1 000 tracker steps with the
+    MULTI parameters -- 721-column projectors, 10 iterations, two WithSensor laser slices (Cauchy 0.01 / none) plus the odometry prior,
+    raw ranges in, preprocess, clip, align, merge, everything chained on the DEVICE's own state (asynchronous clip / merge: one
+    synchronisation per step, for the pose).  tests/golden/tracker_replay_1000.json holds the oracle's digests of every 50th step (scans,
+    clipped scene, pose bits, information matrix, local map), written on the CPU box by tests/golden/make_tracker_chain.py and re-checked
+    against the oracle by tests/test_oracle.py: a single flipped bit anywhere in the 1 000 steps changes every later digest."""
+    import time
+    import tracker_chain
+    g = json.load(open(golden_path("tracker_replay_1000.json")))
+    assert g["steps_total"] == 1000 and g["record_every"] == 50 and len(g["steps"]) == 20
+    quiet = api.Context(0, kernel_timing=False)
+    try:
+        t0 = time.perf_counter()
+        got = tracker_chain.run_device(api, quiet, 1000, record_every=50, map_capacity=60000)
+        dt = time.perf_counter() - t0
+    finally:
+        quiet.close()
+    assert [r["step"] for r in got] == [r["step"] for r in g["steps"]]
+    for a, b in zip(got, g["steps"]):
+        assert a == b, (a["step"], {k: (a[k], b[k]) for k in b if a[k] != b[k]})
+    assert all(r["status"] == 0 for r in got) and got[-1]["map_points"] > 4000
+    print("configs[2] replay: 1000 steps in %.2f s (Python driver, ranges in -> pose out, %.3f ms per step incl. the digests' downloads)" % (dt, dt))
+
+
+def test_configs4_full_size_properties_1000_scans_vs_1m_map(ctx, po):
+    """BASELINE configs[4] at its size: 1 000 scans x 1M-point map x 20 iterations -- too slow for the scalar oracle as a unit test beyond a
+    few alignments, so: convergence to the generating pose on noise-free data (1e-4 m / 1e-4 rad), run-to-run bitwise determinism,
+    permutation equivariance through the index array, the culled and the un-culled stream bit for bit, and three sampled alignments
+    bitwise against the device-order oracle."""
+    wl = synth.make_workload(1000, 1000000, seed=4)
+    al = _aligner(ctx)
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    res = al.compute_batch([fixed], [moving], wl.x0)
+    assert np.all(res.status == 0)
+    d = np.abs(res.pose - wl.x_true)
+    assert d[:, :2].max() < POSE_TOL_M and d[:, 2].max() < POSE_TOL_RAD
+    again = al.compute_batch([fixed], [moving], wl.x0)
+    assert np.array_equal(again.pose, res.pose) and np.array_equal(again.information, res.information)
+    perm = np.argsort(synth.Stream(11).uniform(1000)).astype(np.int32)
+    res_p = al.compute_batch([fixed], [moving], wl.x0[perm], fixed_index=perm[None, :])
+    assert np.array_equal(res_p.pose, res.pose[perm]) and np.array_equal(res_p.information, res.information[perm])
+    ctx.set_option("cull", 0)
+    try:
+        plain = al.compute_batch([fixed], [moving], wl.x0)
+    finally:
+        ctx.set_option("cull", 1)
+    assert np.array_equal(plain.pose, res.pose) and np.array_equal(plain.information, res.information) and np.array_equal(plain.iterations, res.iterations)
+    for i in (0, 499, 999):
+        sc = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+        rt = po.align(po.aligner_params(20, device_order=True), [po.slice_params()], [sc], [wl.map_points], wl.x0[i])
+        assert np.array_equal(res.pose[i], rt["pose"]) and np.array_equal(res.information[i], rt["H"]), i
+
+
+def test_culling_and_placement_change_no_bit(ctx, po):
+    """The exact culling of the moving cloud against the fixed canvas (chunk_may_matter), both forms of the culled stream (units /
+    row-major), and the balanced placement of a culled batch (k_cull_estimate / k_balance_order) change WHERE and WHETHER a map point is
+    visited, never a result: poses, information matrices, iteration counts and every iteration's statistics are bit-identical to the
+    plain stream -- on a batch that fills the chip, on a shuffled map (chunks without locality: nothing is culled), on a partial-FOV
+    canvas, with the Cauchy kernel, and with a second slice."""
+    wl = synth.make_workload(600, 60000, seed=8)
+    shuffled = wl.map_points[np.argsort(synth.Stream(3).uniform(len(wl.map_points)))]
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
+    def run(al, moving_sets, **opts):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            return al.compute_batch([fixed] * len(moving_sets), moving_sets, wl.x0, want_stats=True)
+        finally:
+            ctx.set_option("cull", 1); ctx.set_option("balance", 1); ctx.set_option("cull_block", 0)
+    for name, mp in (("ordered", wl.map_points), ("shuffled", shuffled)):
+        moving = api.CloudSet(ctx, mp)
+        for tag, al in (("plain", _aligner(ctx)), ("cauchy 270 deg", _aligner(ctx, robustifier=api.RobustifierCauchy(0.05)))):
+            if tag != "plain":      # a partial field of view: columns outside the canvas never hold a fixed point
+                al.param_slice_processors[0].param_finder.param_projector = api.PointNormal2fProjectorPolar(811, -0.75 * math.pi, 0.75 * math.pi, 0.3, 25.0)
+            ref = run(al, [moving], cull=0)
+            for opts in (dict(cull=1), dict(cull=1, balance=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98)):
+                got = run(al, [moving], **opts)
+                assert np.array_equal(got.pose, ref.pose) and np.array_equal(got.information, ref.information), (name, tag, opts)
+                assert np.array_equal(got.status, ref.status) and np.array_equal(got.iterations, ref.iterations) and np.array_equal(got.stats, ref.stats), (name, tag, opts)
+    # two projective slices (the same clouds twice, different gates): culling per slice
+    al2 = _aligner(ctx, its=10)
+    al2.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector(721), 0.3, 0.9), min_num_correspondences=10))
+    moving = api.CloudSet(ctx, wl.map_points)
+    ref = run(al2, [moving, moving], cull=0)
+    got = run(al2, [moving, moving], cull=1)
+    assert np.array_equal(got.pose, ref.pose) and np.array_equal(got.information, ref.information) and np.array_equal(got.stats, ref.stats)
+    # ... and the oracle agrees bit for bit with the culled run
+    for i in (0, 300, 599):
+        sc = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+        rt = po.align(po.aligner_params(10, device_order=True), [po.slice_params(), po.slice_params(canvas_cols=721, point_distance=0.3, normal_cos=0.9)],
+                      [sc, sc], [wl.map_points, wl.map_points], wl.x0[i])
+        _assert_bitwise_equal_to_device_order_oracle(got, i, rt, ("two slices culled", i))
+
+
+def test_point_query_finders_against_the_reference_arithmetic_mode(ctx, po):
+    """test_hip_path_against_the_reference_arithmetic_mode for the other finders: the exact grid NN, the reference's own KD-tree and the
+    distance map on the device against the oracle in the REFERENCE'S OWN ARITHMETIC (`_r`: libm, no FMA, Eigen's association, sums pair
+    after pair).  Poses within the north_star tolerance of 1e-4 m / 1e-4 rad; the fraction of first-iteration pairs that differ is
+    reported per finder (PARITY.md section 5)."""
+    wl = synth.make_workload(8, 100000, seed=12)
+    x0_b = synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32)
+    fixed = api.CloudSet(ctx, wl.map_points); moving = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
+    finders = (("exact NN", api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.5), po.slice_params(finder=po.FINDER_NN, max_distance=0.5)),
+               ("KD-tree", api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.5, search="kdtree"), po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.5)),
+               ("distance map", api.CorrespondenceFinderNN2D(ctx, max_distance_m=0.5, resolution=0.05), po.slice_params(finder=po.FINDER_DISTMAP, max_distance=0.5, resolution=0.05)))
+    report = []
+    for name, finder, osp in finders:
+        al = api.MultiAligner2D(ctx, max_iterations=20, min_num_inliers=10)
+        al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10))
+        res = al.compute_batch([fixed], [moving], x0_b)
+        worst = np.zeros(2); differing = []
+        for i in range(len(x0_b)):
+            sc = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+            ref = po.align(po.aligner_params(20), [osp], [wl.map_points], [sc], x0_b[i], double="ref")
+            assert ref["status"] == 0 and res.status[i] == 0, (name, i)
+            d = np.abs(res.pose[i] - ref["pose"]); worst = np.maximum(worst, [d[:2].max(), d[2]])
+            finder.setFixed(fixed, 0); finder.setMoving(moving, i); finder.setLocalMapInSensor(x0_b[i])
+            got = {tuple(p) for p in finder.compute().tolist()}
+            want = {tuple(p) for p in po.find(osp, wl.map_points, sc, x0_b[i], double="ref").tolist()}
+            differing.append(len(got ^ want) / max(1, len(want)))
+        assert worst[0] < POSE_TOL_M and worst[1] < POSE_TOL_RAD, (name, worst)
+        report.append("%s: max pose delta %.1e m / %.1e rad, pairs differing at x0 %.3f %% (mean)" % (name, worst[0], worst[1], 100 * float(np.mean(differing))))
+    print("HIP vs reference arithmetic, point-query finders, role B, 100k map: " + "; ".join(report))

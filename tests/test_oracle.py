@@ -486,3 +486,13 @@ def test_kdtree_oracle_is_approximate_and_honours_its_parameters(po, small_workl
     assert len(kd) <= len(ex) and not np.array_equal(kd, ex) and not np.array_equal(kd, other)
     # one leaf: every query scans every point; strict '<' against max_distance^2 (exact search: '<=') -- same pairs unless a pair sits exactly on the gate
     assert np.array_equal(one_leaf, ex)
+
+
+def test_tracker_replay_1000_digests(po):
+    """tests/golden/tracker_replay_1000.json (BASELINE configs[2] at its size: 1 000 steps of the MULTI-parameter tracker chain, digests of
+    every 50th step): the oracle must reproduce the committed file bit for bit; tests/test_gpu_parity.py holds the HIP path to it."""
+    import tracker_chain
+    g = json.load(open(golden_path("tracker_replay_1000.json")))
+    got = tracker_chain.run_oracle(po, g["steps_total"], record_every=g["record_every"])
+    assert got == g["steps"]
+    assert len(got) == 20 and all(st["status"] == 0 for st in got)

@@ -43,7 +43,8 @@ def _sensor_pose(est, s):
     return np.float32(synth.compose_poses(np.asarray(est, np.float64)[None, :], s[None, :].astype(np.float64))[0])
 
 
-def run_oracle(po, steps: int = 8):
+def run_oracle(po, steps: int = 8, record_every: int = 1):
+    """record_every > 1: digests only of every record_every-th step and of the last one (the 1000-step replay of BASELINE configs[2])"""
     traj, ranges, odo = scenario(steps)
     pp = po.Preprocessor(N_BEAMS, A0, A1, RMIN, RMAX, 0.3, 5, 0.02)
     opr = po.Projector(COLS, -math.pi, math.pi, RMIN, RMAX, 0.0)
@@ -62,19 +63,22 @@ def run_oracle(po, steps: int = 8):
         est = synth.compose_poses(guess[None, :].astype(np.float64), synth.invert_poses(np.asarray(r["pose"], np.float64)[None, :]))[0]
         for i, s in enumerate(S):
             host_map, _ = po.merge_scene(opr, host_map, meas[i], _sensor_pose(est, s), 0.2)
+        if k % record_every and k != steps:
+            continue
         out.append({"step": k, "scans": [digest(m) for m in meas], "scan_points": [int(len(m)) for m in meas], "clip_points": int(len(clip)), "clip": digest(clip),
                     "status": int(r["status"]), "pose_hex": [float(v).hex() for v in np.asarray(r["pose"], np.float32)],
                     "information": digest(np.asarray(r["H"], np.float32)), "map_points": int(len(host_map)), "map": digest(host_map)})
     return out
 
 
-def run_device(api, ctx, steps: int = 8):
-    """the same chain through the C ABI's Python mirror: ranges in, everything else stays on the device (asynchronous clip / merge)"""
+def run_device(api, ctx, steps: int = 8, record_every: int = 1, map_capacity: int = 50000):
+    """the same chain through the C ABI's Python mirror: ranges in, everything else stays on the device (asynchronous clip / merge);
+    between recorded steps nothing but the aligner's pose comes back to the host"""
     traj, ranges, odo = scenario(steps)
     proj = api.PointNormal2fProjectorPolar(COLS, -math.pi, math.pi, RMIN, RMAX)
     pre = api.RawDataPreprocessorProjective2D(ctx, range_min=RMIN, range_max=RMAX, voxelize_resolution=0.02)
     sets = [api.CloudSet.reserved(ctx, 1024), api.CloudSet.reserved(ctx, 1024)]
-    local_map = api.CloudSet.reserved(ctx, 50000)
+    local_map = api.CloudSet.reserved(ctx, map_capacity)
     clipper = api.SceneClipperProjective2D(ctx, proj, asynchronous=True, voxelize_resolution=0.0); clipper.setFullScene(local_map)
     merger = api.MergerProjective2D(ctx, proj, 0.2, asynchronous=True); merger.setScene(local_map)
     al = api.MultiAligner2D(ctx, max_iterations=ITS, min_num_inliers=10)
@@ -103,9 +107,13 @@ def run_device(api, ctx, steps: int = 8):
         x = al.movingInFixed()
         est = synth.compose_poses(guess[None, :].astype(np.float64), synth.invert_poses(x[None, :].astype(np.float64)))[0]
         rec = {"step": k, "status": int(status), "pose_hex": [float(v).hex() for v in x], "information": digest(al.informationMatrix().astype(np.float32))}
-        meas = [s_.download() for s_ in sets]; clip = clipped.download()          # read back for the digests only (after the aligner)
+        recorded = not (k % record_every and k != steps)
+        if recorded:
+            meas = [s_.download() for s_ in sets]; clip = clipped.download()          # read back for the digests only (after the aligner)
         for i, s in enumerate(S):
             merger.setMeasurement(sets[i]); merger.setMeasurementInScene(_sensor_pose(est, s)); merger.compute()
+        if not recorded:
+            continue
         m = local_map.download()
         rec.update({"scans": [digest(v) for v in meas], "scan_points": [int(len(v)) for v in meas], "clip_points": int(len(clip)), "clip": digest(clip),
                     "map_points": int(len(m)), "map": digest(m)})
