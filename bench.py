@@ -235,12 +235,23 @@ def main() -> None:
     kernel_ms = []; clock_mhz = []; wg_ms = []; step_s = []
     # The kernel's own duration is taken live, inside the timed region, on every --event-every-th step (default: every step; measured: timing
     # every step or every fourth makes no difference to a 1000-alignment step, 1.539 vs 1.534 ms).  Steps 0, e, 2e, ... are timed.
+    # strong scaling (a fixed sweep sharded over the ranks): the sweep's consumer wants every candidate's pose, so the all_gather of 12 bytes per
+    # candidate is PART OF THE STEP and is timed with it (round 2 gathered once, behind the timed region)
+    gather_pad = 0
+    if strong and use_dist:
+        counts = [distributed.shard_range(args.total_candidates, r, world) for r in range(world)]
+        gather_pad = max(h - l for l, h in counts)
+        gather_buf = np.zeros((gather_pad, 3), np.float32)
+    gathered = None
     for i_step in range(args.steps):
         timed_step = i_step % args.event_every == 0
         if ctx.kernel_timing != timed_step:
             ctx.set_option("kernel_timing", int(timed_step))
         ts = time.perf_counter()
         res = step()
+        if gather_pad:
+            gather_buf[: len(res.pose)] = res.pose
+            gathered = distributed.gather_results(gather_buf)
         step_s.append(time.perf_counter() - ts)
         if timed_step:
             kernel_ms.append(res.kernel_ms)          # HIP events around the k_align launch, on the launch stream
@@ -253,17 +264,17 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     if gc_was_on:
         gc.enable()
-    gathered = None
-    if strong and use_dist:          # the sweep's consumer wants every candidate's pose: one all_gather of 12 B per candidate (not timed:
-        counts = [distributed.shard_range(args.total_candidates, r, world) for r in range(world)]      # K steps are K sweeps, the gather is per sweep
-        pad = max(h - l for l, h in counts)                                                              # and costs microseconds)
-        mine = np.zeros((pad, 3), np.float32); mine[: len(res.pose)] = res.pose
-        gathered = distributed.gather_results(mine)
-        assert gathered.shape == (pad * world, 3)
+    if gather_pad:
+        assert gathered is not None and gathered.shape == (gather_pad * world, 3)
+    per_rank_ms = None
     if use_dist:
+        mine_ms = elapsed / args.steps * 1e3
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own ms per step (barrier to barrier), rank order: the spread shows which rank the maximum waits for
+        pr = distributed.gather_results(np.array([[mine_ms]], np.float32))
+        per_rank_ms = [float(v) for v in np.asarray(pr).ravel()]
 
     # correctness gate: a timing only counts if the poses are right (noise-free data -> generating pose)
     # (the NN finder matches discrete map points ~N_m/220 m apart, so it lands within millimetres, not 1e-4)
@@ -343,6 +354,11 @@ def main() -> None:
                     roof["valu_issue"] = {"achieved": roof["achieved"], "peak": roof["peak"], "frac": roof["frac"], "unit": roof["unit"]}
                     roof.update(bound="hbm", achieved=roof["hbm"]["hbm_real_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roof["hbm"]["hbm_real_frac"],
                                 note="counter-measured DRAM traffic (2 x FETCH_SIZE + WRITE_SIZE) / launch time against the HBM peak; valu_issue keeps the other yardstick")
+            if counters.get("point_visits_frac") is not None:
+                # the exact culling against the fixed canvas (round 3): which fraction of the (point, iteration) visits of the plain stream the
+                # kernel still makes -- counted (v_rsq_f32 wave-instructions), not modelled; the results are bit-identical either way
+                roof["culling"] = {"point_visits_frac": counters["point_visits_frac"], "wave_point_visits_per_launch": counters.get("wave_points_per_launch"),
+                                   "wave_point_visits_without_culling": counters.get("wave_points_full")}
             roof["counters_source"] = counters.get("source")
             if counters.get("stream_cycles_per_wave_point") and counters.get("wave_points_per_launch"):
                 # the second, sharper yardstick: what the 1024 SIMDs need for THIS instruction stream when nothing else is in the way
@@ -375,6 +391,10 @@ def main() -> None:
         }
         if cross:
             out["cross_rank_check"] = cross
+        if per_rank_ms is not None:
+            out["ms_per_step_per_rank"] = per_rank_ms
+        if gather_pad:
+            out["strong_scaling_gather"] = "all_gather of %d x 12 B per rank inside every timed step" % gather_pad
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle as po       # the checker, timed as the CPU baseline ("port")
             ns = min(args.cpu_sample, n_unique)

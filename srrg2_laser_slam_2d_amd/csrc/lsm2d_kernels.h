@@ -788,7 +788,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   __shared__ int s_wcnt[kAlignBlock / 64];
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
-  const int a = A.order ? A.order[blockIdx.x] : (int) blockIdx.x, tid = threadIdx.x;
+  // (the alignment's index is wave-uniform: said so, or everything indexed by it would live in vector registers)
+  const int a = A.order ? __builtin_amdgcn_readfirstlane(A.order[blockIdx.x]) : (int) blockIdx.x, tid = threadIdx.x;
   constexpr int nwaves = kAlignBlock / 64;
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
   __shared__ unsigned long long s_clk[2];      // start stamps wait in LDS: no register is held across the kernel for them
@@ -911,14 +912,22 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
             // exact culling against the fixed canvas (chunk_may_matter): every thread tests the chunk it would stream, the survivors are
             // compacted (two barriers: counts, then the list) and their points spread evenly over the workgroup (project_cloud_units)
             const int lane = tid & 63, wave = tid >> 6;
-            const bool keep = chunk_may_matter(T, S.proj, S.moving.lane_bounds[(size_t) mc * kAlignBlock + tid], fcan + S.fcan_offset, S.point_distance);
+            // (the chunk's circle through a buffer resource: base in SGPRs, one 32-bit lane offset -- a per-thread 64-bit pointer would be
+            // hoisted out of the iteration loop and spilled: 64 registers)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned long long bb = reinterpret_cast<unsigned long long>(S.moving.lane_bounds + (size_t) mc * kAlignBlock);
+            float4* bbase = reinterpret_cast<float4*>(((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (bb >> 32)) << 32) |
+                                                      (unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) bb));
+            const u32x4 bw = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(bbase, (short) 0, kAlignBlock * 16, 0x00020000), tid * 16, 0, 0);
+            const bool keep = chunk_may_matter(T, S.proj, make_float4(__uint_as_float(bw.x), __uint_as_float(bw.y), __uint_as_float(bw.z), 0.0f), fcan + S.fcan_offset, S.point_distance);
             const u64 bal = __ballot(keep);
             if (lane == 0) s_wcnt[wave] = __popcll(bal);
             __syncthreads();
             int before = 0, n_surv = 0;
 #pragma unroll
             for (int w = 0; w < nwaves; ++w) { const int cw = s_wcnt[w]; before += w < wave ? cw : 0; n_surv += cw; }
-            if (keep) s_surv[before + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t) tid;
+            // (rank below the lane by v_mbcnt: a hoisted 64-bit lane mask would be two more registers held -- and spilled -- across the loops)
+            if (keep) s_surv[before + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) bal, 0u))] = (uint16_t) tid;
             __syncthreads();
             const int Tm = S.moving.lane_T[mc];
             // blocks of an even number of steps, 7 per chunk (measured on configs[1], T = 98: blocks of 2 / 4 / 6 / 8 / 14 steps 1.098 / 1.017 /

@@ -1030,6 +1030,8 @@ def test_bench_three_ranks_share_the_gpu_weak_and_strong(tmp_path):
         d = json.loads(lines[0])
         assert d["n_gpus"] == 3 and d["ranks_seen"] == 3 and d["scaling"] == scaling and d["parity_ok"], d
         assert d["cross_rank_check"].startswith("3 of 3 ranks"), d["cross_rank_check"]
+        assert len(d["ms_per_step_per_rank"]) == 3 and max(d["ms_per_step_per_rank"]) <= d["ms_per_step"] * 1.001      # the line's time is the slowest rank's
+        assert ("strong_scaling_gather" in d) == (scaling == "strong")                                                   # ... and the sweep's gather is inside it
         if per_rank:
             assert d["config"]["alignments_per_gpu"] == per_rank and abs(d["value"] * d["ms_per_step"] * 1e-3 - 3 * per_rank) < 1e-6 * 3 * per_rank
         else:

@@ -9,6 +9,7 @@ run() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --
 run fetch FETCH_SIZE && run write WRITE_SIZE \
  && run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU \
  && run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVES \
+ && run sq3 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS_ATOMIC SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VMEM \
  && run tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
 cd $R; python tools/pmc_summary.py $O k_align > $O/pmc_k_align.csv; cat $O/pmc_k_align.csv; cat $O/trace/*/*kernel_stats.csv | head -5
 # the stream's own issue rate (register-resident points, no loads / barriers / bin walk): the second yardstick of bench.py's roofline block

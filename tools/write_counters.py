@@ -51,14 +51,22 @@ def main():
         # ONE transcendental (v_rsq_f32) per point slot of the lane-chunked stream since round 2's bearing = asin(min / r) (padding slots
         # fail the range gate in front of it; they are counted anyway: an upper bound of 0.4 %)
         T = -(-(-(-a.map_points // 2)) // 512)
-        ent["trans_insts_per_launch"] = 1.0 * a.scans * a.iterations * (T * 512 * 2) / 64.0
-        ent["wave_points_per_launch"] = 1.0 * a.scans * a.iterations * (T * 512 * 2) / 64.0
+        full = 1.0 * a.scans * a.iterations * (T * 512 * 2) / 64.0      # every point slot of the lane-chunked copy, every iteration (no culling)
+        ent["wave_points_full"] = full
+        # with the exact culling (round 3) the point visits are data dependent: the stream's one v_rsq_f32 per point visit is COUNTED
+        # (SQ_INSTS_VALU_TRANS_F32: wave-instructions), minus the handful the culling test itself and the fixed cloud's pass issue
+        visits = m.get("SQ_INSTS_VALU_TRANS_F32", full)
+        ent["trans_insts_per_launch"] = visits
+        ent["wave_points_per_launch"] = visits
+        ent["point_visits_frac"] = visits / full
         probe = os.path.join(a.root, "valu_issue_probe.txt")      # tools/valu_issue_probe.hip run in the same pass: the stream's own issue rate
         if os.path.exists(probe):
             import re
             mm = re.search(r"k_align's point stream.*?:\s*([0-9.]+) cycles of a SIMD per point", open(probe).read())
             if mm:
                 ent["stream_cycles_per_wave_point"] = float(mm.group(1))
+    if "SQ_INSTS_VMEM_RD" in m:
+        ent["vmem_rd_insts_per_launch"] = m["SQ_INSTS_VMEM_RD"]
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         ent["fetch_size_kb"] = m["FETCH_SIZE"]; ent["write_size_kb"] = m["WRITE_SIZE"]
         ent["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
