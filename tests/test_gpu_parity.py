@@ -1826,6 +1826,7 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
     import os
     n_trials = int(os.environ.get("LSM2D_FUZZ_TRIALS", "36")); rng = np.random.default_rng(int(os.environ.get("LSM2D_FUZZ_SEED", "2024")))      # soak: more trials, other seeds
     only = int(os.environ.get("LSM2D_FUZZ_ONLY", "-1"))          # reproduce one trial of a soak run, verbosely
+    rng_kd = np.random.default_rng(int(os.environ.get("LSM2D_FUZZ_SEED", "2024")) + 1000)
     world = synth.make_world(9)
     maps = {n: synth.make_map(world, n, noise_sigma=0.003, seed=n) for n in (3000, 20000)}
     poses = synth.sample_poses(world, 12, seed=3)
@@ -1837,7 +1838,7 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
         scan, _ = synth.make_scans(world, poses[trial % 12:trial % 12 + 1], n_beams=beams, fov_deg=float(rng.uniform(90, 300)))
         x_true, x0 = synth.initial_guesses(poses[trial % 12:trial % 12 + 1], seed=trial, scale=float(rng.uniform(0.0, 0.08)))
         x0 = x0[0].astype(np.float32)
-        finder = trial % 3
+        finder = trial % 3 if trial % 7 else 3          # every seventh trial: the reference's own KD-tree, built on the device, random leaf parameters
         a0 = float(rng.uniform(-math.pi, -0.5)); a1 = float(rng.uniform(0.5, math.pi))
         cols = int(rng.integers(64, 2000)); off = float(rng.choice([0.0, 0.5]))
         rmin = float(rng.uniform(0.0, 1.0)); rmax = float(rng.uniform(5.0, 40.0))
@@ -1854,6 +1855,10 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
         elif finder == 1:
             f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=md, normal_cos=nc)
             osp = po.slice_params(finder=po.FINDER_NN, max_distance=md, normal_cos=nc)
+        elif finder == 3:
+            lr = float(10.0 ** rng_kd.uniform(-3, 0)); lp = int(rng_kd.integers(1, 60))      # (a generator of their own: the other trials keep the parameter sequences of earlier rounds' soaks)
+            f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=md, normal_cos=nc, max_leaf_range=lr, min_leaf_points=lp, search="kdtree")
+            osp = po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=md, normal_cos=nc, kd_max_leaf_range=lr, kd_min_leaf_points=lp)
         else:
             f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=md, resolution=res, normal_cos=nc)
             osp = po.slice_params(finder=po.FINDER_DISTMAP, max_distance=md, resolution=res, normal_cos=nc)
@@ -1876,6 +1881,13 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
         rt = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, device_order=True), [osp], [scan], [m], x0)
         if only < 0:
             _assert_bitwise_equal_to_device_order_oracle(res_g, 0, rt, ("trial=%d" % trial, finder))       # EVERY trial, well-posed or not
+            if finder == 0:      # the batch kernel with its exact culling against the fixed canvas (the call above ran the latency kernel, which has none):
+                ctx.set_option("align_path", 1)      # random fields of view, column rounding and gates through chunk_may_matter
+                try:
+                    res_c = al.compute_batch([scan], [m], x0[None, :], want_stats=True)
+                finally:
+                    ctx.set_option("align_path", 0)
+                _assert_bitwise_equal_to_device_order_oracle(res_c, 0, rt, ("trial=%d culled" % trial, finder))
         if only >= 0:
             print("trial", trial, dict(finder=finder, n_map=n_map, beams=beams, cols=cols, off=off, a0=a0, a1=a1, rmin=rmin, rmax=rmax, pd=pd, nc=nc, md=md, res=res,
                                        cauchy=cauchy, tau=tau, mc=mc, S=S, its=its, min_inl=min_inl, x0=x0.tolist()))
