@@ -1602,7 +1602,13 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   // kernel (k_align_pair; bit-identical sums) -- 512 threads per slice, two slices' passes side by side instead of one after the
   // other, registers to spare for the serial solve step.  Measured against k_align on single-slice calls (tools/latency_kernel_ab.py):
   // 1 scan vs 10k points 0.163 -> 0.146 ms, vs a 700-point clipped scene with prior 0.063 -> 0.045, 256 candidates 0.172 -> 0.154
-  const size_t lds_pair = lds + (size_t) (ns - 1) * (sizeof(u64) * (size_t) cols_max + sizeof(float) * kAccumWords * (kAlignBlock / 64));
+  // its LDS: fixed winners and canvases as k_align, a moving canvas and a block of wave totals per slice, and -- room permitting --
+  // the moving clouds themselves (kPairMovCap points of 16 bytes per slice)
+  const size_t lds_pair0 = sizeof(float4) * (size_t) fcan_total + sizeof(u64) * (size_t) fcan_total +
+                           (size_t) ns * (sizeof(u64) * (size_t) cols_max + sizeof(float) * kPairRedStride * (kAlignBlock / 64));
+  const size_t lds_mov = (size_t) ns * kPairMovCap * sizeof(float4);
+  A.pair_mov_cap = (int) (lds_pair0 + lds_mov) + 512 <= ctx->max_dyn_lds ? kPairMovCap : 0;
+  const size_t lds_pair = lds_pair0 + (A.pair_mov_cap ? lds_mov : 0);
   const bool use_pair = !use_split && ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist && !has_kd &&
                         (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0 && (int) lds_pair + 512 <= ctx->max_dyn_lds;
 

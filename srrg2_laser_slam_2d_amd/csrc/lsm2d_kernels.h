@@ -661,6 +661,7 @@ struct AlignArgs {
   const int32_t* order;                     // alignment handled by workgroup b (nullptr: b itself) -- the balanced placement of k_balance_order
   int32_t cull_block;                       // steps per unit of the culled stream (0: automatic; tuning knob)
   int32_t cull;                             // 1: projective slices drop the chunks of the moving cloud that cannot yield a pair (chunk_may_matter), results unchanged
+  int32_t pair_mov_cap;                     // latency kernel: moving points per slice it may keep in LDS (kPairMovCap, or 0: no room)
   const float* init_pose;
   const PriorDev* prior;
   int32_t  host_polls;                      // results go to pinned host memory and the host polls the status words: release them to the system
@@ -1172,44 +1173,115 @@ __global__ __launch_bounds__(1024) void k_balance_order(const int32_t* __restric
 // ---- the latency kernel: one alignment per workgroup, tuned for calls that cannot fill the chip ------------------
 // (one or two projective slices; with two, side by side)
 // The live tracker's aligner has two laser slices (front and rear scanner, MULTI.json:396-401) and runs one alignment at a
-// time: with one workgroup per alignment the chip is empty and the call is a chain of latencies, so the two slices' passes
-// run next to each other instead of one after the other.  1024 threads: waves 0-7 own slice 0, waves 8-15 slice 1, every
-// thread keeps the role it has in k_align (thread = tid mod 512 of its slice), the per-wave sums are gathered in the same wave
-// order and the two slice totals are added in slice order -- the sums, hence the poses, have k_align's bits.
+// time: with one workgroup per alignment the chip is empty and the call is a chain of latencies on ONE compute unit, where sixteen
+// waves share four SIMDs -- so the kernel is built around (i) the number of instructions all waves issue per iteration and (ii) the
+// length of the stretch only one wave can run (sums -> 3x3 solve -> next transforms).  1024 threads: waves 0-7 own slice 0, waves
+// 8-15 slice 1; every thread keeps the COLUMNS it has in k_align (thread = tid mod 512 of its slice: col, col + 512, ...), the
+// per-wave sums are the same 64-leaf trees, gathered in the same wave order, the slice totals added in slice order, the prior's
+// terms and the solve are the same IEEE operations -- the sums, hence the poses, have k_align's bits (tests: fused == latency kernel).
+//   * a moving cloud of <= 1024 points (the tracker's clipped scene: one point per column) lives in LDS, coordinates and normal
+//     in one 16-byte row: the bin walk's gather of the moving winner is one LDS read instead of two dependent global loads; its
+//     coordinates also sit in registers, ONE point per thread (the few beyond 512 go to the highest lanes), so an iteration's
+//     projection is one point's chain per thread with no load in front;
+//   * wave totals: the eleven sums go through the DPP tree level by level (independent instructions back to back: no wait
+//     states between a VALU write and the DPP read of it), the three counts through ballots and scalar popcounts; counts travel
+//     as exact floats so that the gather is one add per word;
+//   * the serial stretch runs on wave 0 as a VECTOR: lane q owns quantity q (6 of H, 3 of b, 2 chi, 3 counts; lanes 32-40 the
+//     nine entries of the information matrix handed back), gathers it over waves and slices, adds ITS term of the prior -- which
+//     every lane computed for itself before the barrier, while the other waves were still summing -- and only the nine inputs of
+//     the 3x3 solve are broadcast (v_readlane).  The solve has no early exits (a failed pivot is a flag), the pose's sine and
+//     cosine are ready before the barrier, and lanes 0 / 1 turn the new pose into the slices' transforms side by side.
 static constexpr int kPairBlock = 2 * kAlignBlock;
-LSM2D_DEV void block_reduce_gather_pair(const float* red0, const float* red1, int nwaves, int lane, Accum& A0, Accum& A1) {
-  const int q = lane & 15;
-  const float* red = (lane & 16) ? red1 : red0;
-  float v = 0.0f; int vi = 0;
-  if (lane < 32) {
-    if (q < 11) { for (int w = 0; w < nwaves; ++w) v += red[w * kAccumWords + q]; }
-    else if (q < kAccumWords) { for (int w = 0; w < nwaves; ++w) vi += __float_as_int(red[w * kAccumWords + q]); }
-  }
-  const int b = __float_as_int(v);
-#define LSM2D_RL_F(k) __int_as_float(__builtin_amdgcn_readlane(b, k))
-  A0.h00 = LSM2D_RL_F(0); A0.h01 = LSM2D_RL_F(1); A0.h02 = LSM2D_RL_F(2); A0.h11 = LSM2D_RL_F(3); A0.h12 = LSM2D_RL_F(4); A0.h22 = LSM2D_RL_F(5);
-  A0.b0 = LSM2D_RL_F(6); A0.b1 = LSM2D_RL_F(7); A0.b2 = LSM2D_RL_F(8); A0.chi_in = LSM2D_RL_F(9); A0.chi_out = LSM2D_RL_F(10);
-  A1.h00 = LSM2D_RL_F(16); A1.h01 = LSM2D_RL_F(17); A1.h02 = LSM2D_RL_F(18); A1.h11 = LSM2D_RL_F(19); A1.h12 = LSM2D_RL_F(20); A1.h22 = LSM2D_RL_F(21);
-  A1.b0 = LSM2D_RL_F(22); A1.b1 = LSM2D_RL_F(23); A1.b2 = LSM2D_RL_F(24); A1.chi_in = LSM2D_RL_F(25); A1.chi_out = LSM2D_RL_F(26);
-#undef LSM2D_RL_F
-  A0.n_in = __builtin_amdgcn_readlane(vi, 11); A0.n_out = __builtin_amdgcn_readlane(vi, 12); A0.n_corr = __builtin_amdgcn_readlane(vi, 13);
-  A1.n_in = __builtin_amdgcn_readlane(vi, 27); A1.n_out = __builtin_amdgcn_readlane(vi, 28); A1.n_corr = __builtin_amdgcn_readlane(vi, 29);
+static constexpr int kPairMovCap = 2 * kAlignBlock;     // moving points per slice kept on chip
+static constexpr int kPairRedStride = 16;               // words per (slice, wave) record: 11 sums, n_in, n_out, n_corr (exact floats), 2 spare = one 64-byte row
+
+template <int N> LSM2D_DEV void wave_tree63(float (&f)[11]) {      // wave_sum63's tree for N values at once, level by level
+#define LSM2D_LVL(ctrl, rmask) _Pragma("unroll") for (int k = 0; k < N; ++k) f[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f[k]), ctrl, rmask, 0xF, false));
+  LSM2D_LVL(0x111, 0xF) LSM2D_LVL(0x112, 0xF) LSM2D_LVL(0x114, 0xF) LSM2D_LVL(0x118, 0xF) LSM2D_LVL(0x142, 0xA) LSM2D_LVL(0x143, 0xC)
+#undef LSM2D_LVL
 }
+// all threads of a slice call; afterwards red[wave][0..13] holds the wave's totals.  count_bits: bits a thread's counts can occupy
+// (a thread accumulates at most ceil(cols / 512) pairs).  A slice without robustifier has chi_out == +0 and n_in == n_corr in
+// every lane: nothing to add up.
+LSM2D_DEV void pair_wave_sums(const Accum& A, float* red, int tid, bool cauchy, int count_bits) {
+  const int lane = tid & 63, wave = tid >> 6;
+  float f[11] = {A.h00, A.h01, A.h02, A.h11, A.h12, A.h22, A.b0, A.b1, A.b2, A.chi_in, A.chi_out};
+  int nc = 0, ni = 0;
+  if (cauchy) {
+    wave_tree63<11>(f);
+    for (int b = 0; b < count_bits; ++b) {
+      nc += __builtin_popcountll(__ballot((A.n_corr >> b) & 1)) << b;
+      ni += __builtin_popcountll(__ballot((A.n_in >> b) & 1)) << b;
+    }
+  } else {
+    wave_tree63<10>(f);
+    for (int b = 0; b < count_bits; ++b) nc += __builtin_popcountll(__ballot((A.n_corr >> b) & 1)) << b;
+    ni = nc; f[10] = 0.0f;
+  }
+  if (lane == 63) {
+    float4* r = reinterpret_cast<float4*>(red + wave * kPairRedStride);
+    r[0] = make_float4(f[0], f[1], f[2], f[3]); r[1] = make_float4(f[4], f[5], f[6], f[7]);
+    r[2] = make_float4(f[8], f[9], f[10], (float) ni);
+    *reinterpret_cast<float2*>(r + 3) = make_float2((float) (nc - ni), (float) nc);
+  }
+}
+
+// ONE entry of the odometry prior's J^T Omega [J | e] (prior_apply's operations for that entry, in its order): row r in 0..2, column c in
+// 0..2 of the H term, c == 3 the b term.  J = [[cs, -sn, 0], [sn, cs, 0], [0, 0, 1]].
+LSM2D_DEV float prior_term_lane(const PriorDev& Pz, const float pose[3], int r, int c) {
+  float E[3]; compose(Pz.cz, Pz.sz, Pz.z_inv, pose, E);
+  float cs, sn; sincos_fixed(E[2], sn, cs);
+  const float msn = -sn;
+  const float x0 = c == 0 ? cs : (c == 1 ? msn : (c == 2 ? 0.0f : E[0]));
+  const float x1 = c == 0 ? sn : (c == 1 ? cs : (c == 2 ? 0.0f : E[1]));
+  const float x2 = c == 2 ? 1.0f : (c == 3 ? E[2] : 0.0f);
+  const float j0 = r == 0 ? cs : (r == 1 ? msn : 0.0f);
+  const float j1 = r == 0 ? sn : (r == 1 ? cs : 0.0f);
+  const float j2 = r == 2 ? 1.0f : 0.0f;
+  float oj[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { float v = 0.0f; v += Pz.omega[3 * k + 0] * x0; v += Pz.omega[3 * k + 1] * x1; v += Pz.omega[3 * k + 2] * x2; oj[k] = v; }
+  float v = 0.0f; v += j0 * oj[0]; v += j1 * oj[1]; v += j2 * oj[2];
+  return v;
+}
+
+// solve_update's LDL^T without early exits: the same operations on the same values whenever it succeeds; a failed pivot or a
+// non-finite step is reported at the end (what was computed behind it is discarded by the caller, as solve_update's return does)
+LSM2D_DEV bool solve_flat(float h00, float h01, float h02, float h11, float h12, float h22, float b0, float b1, float b2, float damping,
+                          float& dx, float& dy, float& dth) {
+  const double a00 = (double) h00 + (double) damping, a01 = h01, a02 = h02;
+  const double a11 = (double) h11 + (double) damping, a12 = h12, a22 = (double) h22 + (double) damping;
+  const double r0 = -(double) b0, r1 = -(double) b1, r2 = -(double) b2;
+  const double d0 = a00;
+  const double l10 = a01 / d0, l20 = a02 / d0;
+  const double d1 = a11 - l10 * a01;
+  const double l21 = (a12 - l20 * a01) / d1;
+  const double d2 = a22 - l20 * a02 - l21 * l21 * d1;
+  const double y0 = r0, y1 = r1 - l10 * y0, y2 = r2 - l20 * y0 - l21 * y1;
+  const double z2 = y2 / d2;
+  const double z1 = y1 / d1 - l21 * z2;
+  const double z0 = y0 / d0 - l10 * z1 - l20 * z2;
+  dx = (float) z0; dy = (float) z1; dth = (float) z2;
+  return (d0 > 0) & (d1 > 0) & (d2 > 0) & (bool) __builtin_isfinite(d0) & (bool) __builtin_isfinite(d1) & (bool) __builtin_isfinite(d2) &
+         (bool) __builtin_isfinite(z0) & (bool) __builtin_isfinite(z1) & (bool) __builtin_isfinite(z2);
+}
+
+#ifndef LSM2D_PAIR_READ_FIRST
+#define LSM2D_PAIR_READ_FIRST false      // z-buffer updates of the on-chip moving cloud: fire-and-forget (neighbouring lanes hold neighbouring columns' points)
+#endif
 
 __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
-  float4* fwin = reinterpret_cast<float4*>(smem);                  // 16-byte rows first (alignment), as in k_align
-  u64* mcan2 = reinterpret_cast<u64*>(fwin + A.fcan_total);        // [n_slices][cols_max]: one moving canvas per slice
+  constexpr int nwaves = kAlignBlock / 64;
+  float4* fwin = reinterpret_cast<float4*>(smem);                                 // 16-byte rows first (alignment)
+  float4* mwin2 = fwin + A.fcan_total;                                             // [n_slices][pair_mov_cap]: the moving clouds, (x, y, nx, ny)
+  float* red2 = reinterpret_cast<float*>(mwin2 + A.n_slices * A.pair_mov_cap);     // [n_slices][nwaves][kPairRedStride]
+  u64* mcan2 = reinterpret_cast<u64*>(red2 + A.n_slices * nwaves * kPairRedStride);      // [n_slices][cols_max]: one moving canvas per slice
   u64* fcan = mcan2 + A.n_slices * A.cols_max;
-  float* red2 = reinterpret_cast<float*>(fcan + A.fcan_total);     // [n_slices][nwaves][kAccumWords]
   __shared__ Iso   s_iso[2];
   __shared__ int   s_done;
-  float pose[3] = {0.0f, 0.0f, 0.0f}, Hlast[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // thread 0's: estimate and information matrix stay in registers
-  int status = LSM2D_RUNNING;
-  float prev_chi = 0.0f;            // thread 0's: total chi^2 of the previous iteration (termination_chi_epsilon)
   __shared__ PriorDev s_prior;
 
-  constexpr int nwaves = kAlignBlock / 64;
   const int a = blockIdx.x, gtid = threadIdx.x, nthr = kAlignBlock * A.n_slices;      // launched with 512 threads per slice (one or two slices)
 #ifdef LSM2D_PHASE_CLOCKS      // debug build: where one alignment's time goes (10 ns ticks), printed by thread 0
   unsigned long long pc_t = __builtin_amdgcn_s_memrealtime(), pc_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1218,37 +1290,56 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
 #define LSM2D_PC(k) do { } while (0)
 #endif
   const int half = __builtin_amdgcn_readfirstlane(gtid >> 9);      // wave-uniform: the slice this wave works for
-  const int tid = gtid & (kAlignBlock - 1);
+  const bool w0 = __builtin_amdgcn_readfirstlane(gtid >> 6) == 0;  // wave 0: the serial stretch
+  const int tid = gtid & (kAlignBlock - 1), lane = gtid & 63;
   u64* mcan = mcan2 + half * A.cols_max;
-  float* red = red2 + half * nwaves * kAccumWords;
+  float* red = red2 + half * nwaves * kPairRedStride;
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
   if (A.prior && gtid >= 64 && gtid < 64 + kPriorWords)
     ((float*) &s_prior)[gtid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[gtid - 64] : ((const float*) (A.prior + a))[gtid - 64];
   if (A.inline_n1 && A.s[half].unpack_src) unpack_fixed_set(A.s[half], tid, kAlignBlock);      // visible after the barrier below
   for (int i = gtid; i < A.fcan_total; i += nthr) fcan[i] = kEmptyCell;
   for (int i = gtid; i < A.n_slices * A.cols_max; i += nthr) mcan2[i] = kEmptyCell;
-  auto begin_iteration = [&]() {
-    for (int s = 0; s < A.n_slices; ++s) s_iso[s] = slice_iso(A.s[s], pose);
-  };
-  if (gtid == 0) {
+
+  // wave 0's state: the estimate (the same value in every lane), each lane's quantity and its entry of the prior, lanes 0 / 1 their slice's sensor offset
+  float pose[3] = {0.0f, 0.0f, 0.0f}, hl = 0.0f;
+  int status = LSM2D_RUNNING, last_n_in = 0;
+  float prev_chi = 0.0f;            // total chi^2 of the previous iteration (termination_chi_epsilon)
+  int q = 15, pr = 0, pc = 0; bool has_pterm = false;
+  float kS[3] = {0.0f, 0.0f, 0.0f}, kc = 1.0f, ks = 0.0f; int khs = 0;
+  if (w0) {
     if (A.inline_n1) { pose[0] = A.pose1[0]; pose[1] = A.pose1[1]; pose[2] = A.pose1[2]; }
     else { pose[0] = A.init_pose[3 * a + 0]; pose[1] = A.init_pose[3 * a + 1]; pose[2] = A.init_pose[3 * a + 2]; }
-    s_done = 0;
-    begin_iteration();
+    if (lane < 16) {
+      q = lane;
+      if (lane < 9) { has_pterm = true; pr = (int) ((0x210211000ull >> (4 * lane)) & 15); pc = (int) ((0x333221210ull >> (4 * lane)) & 15); }
+    } else if (lane >= 32 && lane < 41) {
+      const int k = lane - 32;
+      q = (int) ((0x542431210ull >> (4 * k)) & 15); has_pterm = true; pr = k / 3; pc = k - 3 * pr;
+    }
+    const SliceDev& Sa = A.s[0]; const SliceDev& Sb = A.s[A.n_slices - 1];
+    const bool second = lane == 1;
+    kS[0] = second ? Sb.Sinv[0] : Sa.Sinv[0]; kS[1] = second ? Sb.Sinv[1] : Sa.Sinv[1]; kS[2] = second ? Sb.Sinv[2] : Sa.Sinv[2];
+    kc = second ? Sb.cSinv : Sa.cSinv; ks = second ? Sb.sSinv : Sa.sSinv; khs = second ? Sb.has_sensor : Sa.has_sensor;
+    if (lane < A.n_slices) s_iso[lane] = slice_iso_of(khs, kc, ks, kS, pose);
+    if (lane == 0) s_done = 0;
   }
   __syncthreads();
+  PriorDev pz;                      // wave 0's copy of the prior, in registers
+  if (w0 && A.prior) pz = s_prior;
   const SliceDev& S = A.s[half];
   const int mc = pick_cloud(S.moving, a);
   const int mbase = S.moving.start[mc];
   const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
-  // a moving cloud of at most one pair of points per thread (the tracker's clipped scene: one point per column) is read once and
-  // kept in registers for all iterations (loaded here, ahead of the fixed cloud's passes: the two dependent loads overlap them)
+  // the moving cloud on chip (see the head comment); loaded here, ahead of the fixed cloud's passes: the loads overlap them
   const int m_count = S.moving.count[mc];
-  const bool m_in_regs = !S.moving.lane_xy && m_count <= 2 * kAlignBlock;
-  float4 m_pair = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float2 m_tail = make_float2(0.0f, 0.0f);
-  if (m_in_regs) {
-    if (tid < (m_count >> 1)) m_pair = reinterpret_cast<const float4*>(mp)[tid];
-    if ((m_count & 1) && tid == 0) m_tail = mp[m_count - 1];
+  const bool m_on_chip = !S.moving.lane_xy && m_count <= A.pair_mov_cap;      // pair_mov_cap: kPairMovCap, or 0 when LDS has no room
+  float4* mwin = mwin2 + half * A.pair_mov_cap;
+  const int j1 = kPairMovCap - 1 - tid;                   // this thread's second point, if the cloud has more than 512
+  float2 p0 = make_float2(0.0f, 0.0f), p1 = make_float2(0.0f, 0.0f);
+  if (m_on_chip) {
+    if (tid < m_count) { p0 = mp[tid]; const float2 n = mn[tid]; mwin[tid] = make_float4(p0.x, p0.y, n.x, n.y); }
+    if (j1 < m_count) { p1 = mp[j1]; const float2 n = mn[j1]; mwin[j1] = make_float4(p1.x, p1.y, n.x, n.y); }
   }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   const int fbase = S.fixed.start[pick_cloud(S.fixed, a)];
@@ -1262,19 +1353,21 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
       fwin[S.fcan_offset + col] = make_float4(p.x, p.y, n.x, n.y);
     }
   }
+  const int per_thread = (S.proj.cols + kAlignBlock - 1) / kAlignBlock;      // pairs a thread can accumulate
+  const int count_bits = 32 - __builtin_clz(per_thread | 1);
+  const bool cauchy = S.cauchy != 0;
   __syncthreads();
   LSM2D_PC(0);
 
   const u64* fcs = fcan + S.fcan_offset; const float4* fws = fwin + S.fcan_offset;
   int it = 0;
-  StatsDev last = {0, 0, 0, 0.0f, 0.0f};
   for (; it < A.max_it; ++it) {
     const Iso T = s_iso[half];
     Accum acc; accum_zero(acc);
     if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
-    else if (m_in_regs) {         // the same points every iteration: no load, no wait
-      if (tid < (m_count >> 1)) { project_point(T, S.proj, m_pair.x, m_pair.y, 2 * tid, mcan); project_point(T, S.proj, m_pair.z, m_pair.w, 2 * tid + 1, mcan); }
-      if ((m_count & 1) && tid == 0) project_point(T, S.proj, m_tail.x, m_tail.y, m_count - 1, mcan);
+    else if (m_on_chip) {         // the same points every iteration: no load, no wait
+      if (tid < m_count) project_point<LSM2D_PAIR_READ_FIRST>(T, S.proj, p0.x, p0.y, tid, mcan);
+      if (j1 < m_count) project_point<LSM2D_PAIR_READ_FIRST>(T, S.proj, p1.x, p1.y, j1, mcan);
     }
     else project_cloud(mp, m_count, T, S.proj, mcan, tid, kAlignBlock);
     __syncthreads();
@@ -1296,92 +1389,91 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
       const bool g0 = depth_gate(fk0, mk0), g1 = depth_gate(fk1, mk1);
       const int mi0 = g0 ? (int) (uint32_t) mk0 : 0, mi1 = g1 ? (int) (uint32_t) mk1 : 0;
       float2 nm0, pm0, nm1, pm1;
-      if (g0) { nm0 = mn[mi0]; pm0 = mp[mi0]; }
-      if (g1) { nm1 = mn[mi1]; pm1 = mp[mi1]; }
+      if (m_on_chip) {
+        if (g0) { const float4 m = mwin[mi0]; pm0 = make_float2(m.x, m.y); nm0 = make_float2(m.z, m.w); }
+        if (g1) { const float4 m = mwin[mi1]; pm1 = make_float2(m.x, m.y); nm1 = make_float2(m.z, m.w); }
+      } else {
+        if (g0) { nm0 = mn[mi0]; pm0 = mp[mi0]; }
+        if (g1) { nm1 = mn[mi1]; pm1 = mp[mi1]; }
+      }
       if (g0) {
         const float4 f = fws[col];
         float nqx, nqy; xf_normal(T, nm0.x, nm0.y, nqx, nqy);
         if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos))
-          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm0, nm0, S.cauchy != 0, S.tau, acc);
+          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm0, nm0, cauchy, S.tau, acc);
       }
       if (g1) {
         const float4 f = fws[col1];
         float nqx, nqy; xf_normal(T, nm1.x, nm1.y, nqx, nqy);
         if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos))
-          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm1, nm1, S.cauchy != 0, S.tau, acc);
+          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm1, nm1, cauchy, S.tau, acc);
       }
     }
     LSM2D_PC(6);                 // thread 0's wave: bin walk
-    block_reduce_store(acc, red, tid);
+    pair_wave_sums(acc, red, tid, cauchy, count_bits);
     LSM2D_PC(7);                 // its wave sums
-    // the odometry prior's terms depend on the pose alone: thread 0 computes them HERE, where its wave would otherwise wait ~0.5 us
-    // for the slowest of the sixteen (phase clocks: "wait"), instead of on the serial stretch behind the barrier
-    float Hp[9], bp[3];
-    if (gtid == 0 && A.prior) prior_terms(s_prior, pose, Hp, bp);
+    // what depends on the pose alone, computed by wave 0 HERE, where it would otherwise wait for the slowest of the sixteen: each
+    // lane's entry of the prior's terms, and the rotation of the update X <- X * v2t(dx)
+    float P = 0.0f, sp = 0.0f, cp = 1.0f;
+    if (w0) {
+      sincos_fixed(pose[2], sp, cp);
+      if (A.prior) P = prior_term_lane(pz, pose, pr, pc);
+    }
     LSM2D_PC(9);                 // prior
     __syncthreads();
     LSM2D_PC(2);                 // waiting for the other waves
-    if (gtid < 64) {
-      Accum t[2];
-      block_reduce_gather_pair(red2, red2 + (A.n_slices - 1) * nwaves * kAccumWords, nwaves, gtid, t[0], t[1]);      // one slice: t[1] repeats t[0], unused
+    if (w0) {
+      // gather: this lane's quantity over the waves (wave order, from +0 -- block_reduce_gather's sums), both slices
+      float v0 = 0.0f, v1 = 0.0f;
+#pragma unroll
+      for (int w = 0; w < nwaves; ++w) v0 += red2[w * kPairRedStride + q];
+      const bool two = A.n_slices == 2;
+      if (two) {
+#pragma unroll
+        for (int w = 0; w < nwaves; ++w) v1 += red2[(nwaves + w) * kPairRedStride + q];
+      }
       LSM2D_PC(3);
-      if (gtid == 0) {
-        // k_align's per-slice accumulation (zeroed sums, then slice 0, then slice 1) and its solve step, in its order
-        float Hs[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, bs[3] = {0.0f, 0.0f, 0.0f};
-        int n_in = 0, n_out = 0, n_corr = 0, active = 0; float chi_in = 0.0f, chi_out = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s >= A.n_slices) break;
-          n_corr += t[s].n_corr;
-          if (t[s].n_corr > A.s[s].min_corr) {
-            ++active;
-            Hs[0] += t[s].h00; Hs[1] += t[s].h01; Hs[2] += t[s].h02; Hs[3] += t[s].h01; Hs[4] += t[s].h11; Hs[5] += t[s].h12;
-            Hs[6] += t[s].h02; Hs[7] += t[s].h12; Hs[8] += t[s].h22;
-            bs[0] += t[s].b0; bs[1] += t[s].b1; bs[2] += t[s].b2;
-            n_in += t[s].n_in; n_out += t[s].n_out; chi_in += t[s].chi_in; chi_out += t[s].chi_out;
-          }
-        }
-        last.n_corr = n_corr; last.n_in = n_in; last.n_out = n_out; last.chi_in = chi_in; last.chi_out = chi_out;
-        if (A.out_stats) A.out_stats[(size_t) a * A.max_it + it] = last;
-        LSM2D_PC(8);               // sums of the slices, statistics
-        if (!active) { status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
+      // k_align's per-slice accumulation (zeroed sums, then slice 0, then slice 1; the pair count of every slice, the rest of active ones)
+      const int nc0 = (int) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), 13));
+      const int nc1 = (int) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), 13));
+      const bool act0 = nc0 > A.s[0].min_corr, act1 = two && nc1 > A.s[A.n_slices - 1].min_corr;
+      const bool always = lane == 13;
+      float tot = 0.0f;
+      tot += (act0 || always) ? v0 : 0.0f;        // (adding +0 to a sum that started from +0 changes nothing)
+      tot += (act1 || always) ? v1 : 0.0f;
+      last_n_in = (int) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 11));
+      if (A.out_stats && lane >= 9 && lane < 14) {      // StatsDev {n_corr, n_in, n_out, chi_in, chi_out} <- lanes 13, 11, 12, 9, 10
+        const int word = lane == 13 ? 0 : (lane == 11 ? 1 : (lane == 12 ? 2 : lane - 6));
+        reinterpret_cast<int32_t*>(A.out_stats + ((size_t) a * A.max_it + it))[word] = lane < 11 ? __float_as_int(tot) : (int) tot;
+      }
+      LSM2D_PC(8);               // sums of the slices, statistics
+      bool done_now = false;
+      if (!(act0 || act1)) { status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; done_now = true; }
+      else {
+        const float Hq = (A.prior && has_pterm) ? tot + P : tot;
+        hl = Hq;
+#define LSM2D_RL_F(k) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Hq), k))
+        float dx, dy, dth;
+        const bool ok = solve_flat(LSM2D_RL_F(0), LSM2D_RL_F(1), LSM2D_RL_F(2), LSM2D_RL_F(3), LSM2D_RL_F(4), LSM2D_RL_F(5),
+                                   LSM2D_RL_F(6), LSM2D_RL_F(7), LSM2D_RL_F(8), A.damping, dx, dy, dth);
+#undef LSM2D_RL_F
+        if (!ok) { status = LSM2D_SINGULAR_H; done_now = true; }
         else {
-          if (A.prior) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Hs[k] += Hp[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) bs[k] += bp[k];
+          const float nx = __builtin_fmaf(cp, dx, __builtin_fmaf(-sp, dy, pose[0]));
+          const float ny = __builtin_fmaf(sp, dx, __builtin_fmaf(cp, dy, pose[1]));
+          pose[0] = nx; pose[1] = ny; pose[2] = wrap_angle(pose[2] + dth);
+          if (A.term_eps > 0.0f) {       // as in k_align
+            const float chi_now = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 9)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 10));
+            if (it > 0 && __builtin_fabsf(prev_chi - chi_now) < A.term_eps * chi_now) done_now = true;
+            prev_chi = chi_now;
           }
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Hlast[k] = Hs[k];
-          float X[3] = {pose[0], pose[1], pose[2]};
-          if (!solve_update(Hs, bs, A.damping, X)) { status = LSM2D_SINGULAR_H; s_done = 1; }
-          else {
-            pose[0] = X[0]; pose[1] = X[1]; pose[2] = X[2];
-            if (A.term_eps > 0.0f) {       // as in k_align
-              const float chi_now = chi_in + chi_out;
-              if (it > 0 && __builtin_fabsf(prev_chi - chi_now) < A.term_eps * chi_now) s_done = 1;
-              prev_chi = chi_now;
-            }
-          }
-          LSM2D_PC(10);            // 3x3 solve and pose update
-        }
-        LSM2D_PC(4);               // (debug builds: the part of the transforms' time that is lane 0's alone is nil now)
-      }
-      // the next iteration's transforms: one slice per lane (lanes 0 and 1 of this wave), from the pose lane 0 has just written
-      {
-        float P3[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) P3[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pose[k]), 0));
-        if (!s_done && gtid < A.n_slices) {
-          const SliceDev& S0 = A.s[0]; const SliceDev& S1 = A.s[A.n_slices - 1];
-          const bool second = gtid == 1;
-          const float Sinv[3] = {second ? S1.Sinv[0] : S0.Sinv[0], second ? S1.Sinv[1] : S0.Sinv[1], second ? S1.Sinv[2] : S0.Sinv[2]};
-          s_iso[gtid] = slice_iso_of(second ? S1.has_sensor : S0.has_sensor, second ? S1.cSinv : S0.cSinv, second ? S1.sSinv : S0.sSinv, Sinv, P3);
         }
       }
+      LSM2D_PC(10);              // 3x3 solve and pose update
+      if (done_now) { if (lane == 0) s_done = 1; }
+      else if (lane < A.n_slices) s_iso[lane] = slice_iso_of(khs, kc, ks, kS, pose);      // the next iteration's transforms: one slice per lane
+      LSM2D_PC(4);
     }
-    LSM2D_PC(4);
     __syncthreads();
     LSM2D_PC(5);
     if (s_done) { ++it; break; }
@@ -1392,14 +1484,17 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   if (gtid == 0 && a == 0) printf("  solve = sums %llu + prior %llu + ldlt/update %llu + next transforms %llu\n", pc_acc[8], pc_acc[9], pc_acc[10], pc_acc[4]);
 #endif
 #undef LSM2D_PC
-  if (gtid == 0) {
+  if (w0) {
     int st = status;
-    if (st == LSM2D_RUNNING) st = (A.max_it > 0 && last.n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
-    A.out_pose[3 * a + 0] = pose[0]; A.out_pose[3 * a + 1] = pose[1]; A.out_pose[3 * a + 2] = pose[2];
-    if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = Hlast[k];
-    if (A.out_its) A.out_its[a] = it;
-    if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }    // status last (see k_align)
-    else A.out_status[a] = st;
+    if (st == LSM2D_RUNNING) st = (A.max_it > 0 && last_n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
+    if (lane < 3) A.out_pose[3 * a + lane] = lane == 0 ? pose[0] : (lane == 1 ? pose[1] : pose[2]);
+    if (A.out_H && lane >= 32 && lane < 41) A.out_H[9 * a + lane - 32] = hl;
+    if (A.out_its && lane == 0) A.out_its[a] = it;
+    if (A.host_polls) {      // status last (see k_align); the fence covers every lane's stores above
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(&A.out_status[a], st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    else if (lane == 0) A.out_status[a] = st;
   }
 }
 
