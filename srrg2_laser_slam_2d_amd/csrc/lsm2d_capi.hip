@@ -274,6 +274,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kd_levels")) { *out_value = ctx->last_kd_levels; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "max_dyn_lds")) { *out_value = ctx->max_dyn_lds; return LSM2D_SUCCESS; }      // bytes of LDS one workgroup may ask for
   if (!strcmp(key, "last_kd_nodes")) { *out_value = ctx->last_kd_nodes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "grid_big_threshold")) { *out_value = ctx->grid_big_threshold; return LSM2D_SUCCESS; }
   if (!strcmp(key, "find_path")) { *out_value = ctx->find_path; return LSM2D_SUCCESS; }

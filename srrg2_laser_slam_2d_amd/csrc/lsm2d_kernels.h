@@ -1353,6 +1353,15 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
       fwin[S.fcan_offset + col] = make_float4(p.x, p.y, n.x, n.y);
     }
   }
+  // what the serial stretch reads from the kernel arguments, fetched once (an s_load and its wait per use otherwise)
+  int min_corr0 = A.s[0].min_corr, min_corr1 = A.s[1].min_corr, n_slices = A.n_slices;
+  unsigned long long prior_ptr = reinterpret_cast<unsigned long long>(A.prior);
+  int term_eps_b = __float_as_int(A.term_eps), damping_b = __float_as_int(A.damping);
+  StatsDev* out_stats = A.out_stats ? A.out_stats + (size_t) a * A.max_it : nullptr;
+  asm volatile("" : "+s"(min_corr0), "+s"(min_corr1), "+s"(n_slices), "+s"(prior_ptr), "+s"(term_eps_b), "+s"(damping_b));
+  asm volatile("" : "+v"(out_stats));
+  const bool two_slices = n_slices == 2, has_prior = prior_ptr != 0;
+  const float term_eps = __int_as_float(term_eps_b), damping = __int_as_float(damping_b);
   const int per_thread = (S.proj.cols + kAlignBlock - 1) / kAlignBlock;      // pairs a thread can accumulate
   const int count_bits = 32 - __builtin_clz(per_thread | 1);
   const bool cauchy = S.cauchy != 0;
@@ -1417,7 +1426,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
     float P = 0.0f, sp = 0.0f, cp = 1.0f;
     if (w0) {
       sincos_fixed(pose[2], sp, cp);
-      if (A.prior) P = prior_term_lane(pz, pose, pr, pc);
+      if (has_prior) P = prior_term_lane(pz, pose, pr, pc);
     }
     LSM2D_PC(9);                 // prior
     __syncthreads();
@@ -1427,7 +1436,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
       float v0 = 0.0f, v1 = 0.0f;
 #pragma unroll
       for (int w = 0; w < nwaves; ++w) v0 += red2[w * kPairRedStride + q];
-      const bool two = A.n_slices == 2;
+      const bool two = two_slices;
       if (two) {
 #pragma unroll
         for (int w = 0; w < nwaves; ++w) v1 += red2[(nwaves + w) * kPairRedStride + q];
@@ -1436,35 +1445,35 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
       // k_align's per-slice accumulation (zeroed sums, then slice 0, then slice 1; the pair count of every slice, the rest of active ones)
       const int nc0 = (int) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), 13));
       const int nc1 = (int) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), 13));
-      const bool act0 = nc0 > A.s[0].min_corr, act1 = two && nc1 > A.s[A.n_slices - 1].min_corr;
+      const bool act0 = nc0 > min_corr0, act1 = two && nc1 > min_corr1;
       const bool always = lane == 13;
       float tot = 0.0f;
       tot += (act0 || always) ? v0 : 0.0f;        // (adding +0 to a sum that started from +0 changes nothing)
       tot += (act1 || always) ? v1 : 0.0f;
       last_n_in = (int) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 11));
-      if (A.out_stats && lane >= 9 && lane < 14) {      // StatsDev {n_corr, n_in, n_out, chi_in, chi_out} <- lanes 13, 11, 12, 9, 10
+      if (out_stats && lane >= 9 && lane < 14) {        // StatsDev {n_corr, n_in, n_out, chi_in, chi_out} <- lanes 13, 11, 12, 9, 10
         const int word = lane == 13 ? 0 : (lane == 11 ? 1 : (lane == 12 ? 2 : lane - 6));
-        reinterpret_cast<int32_t*>(A.out_stats + ((size_t) a * A.max_it + it))[word] = lane < 11 ? __float_as_int(tot) : (int) tot;
+        reinterpret_cast<int32_t*>(out_stats + it)[word] = lane < 11 ? __float_as_int(tot) : (int) tot;
       }
       LSM2D_PC(8);               // sums of the slices, statistics
       bool done_now = false;
       if (!(act0 || act1)) { status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; done_now = true; }
       else {
-        const float Hq = (A.prior && has_pterm) ? tot + P : tot;
+        const float Hq = (has_prior && has_pterm) ? tot + P : tot;
         hl = Hq;
 #define LSM2D_RL_F(k) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Hq), k))
         float dx, dy, dth;
         const bool ok = solve_flat(LSM2D_RL_F(0), LSM2D_RL_F(1), LSM2D_RL_F(2), LSM2D_RL_F(3), LSM2D_RL_F(4), LSM2D_RL_F(5),
-                                   LSM2D_RL_F(6), LSM2D_RL_F(7), LSM2D_RL_F(8), A.damping, dx, dy, dth);
+                                   LSM2D_RL_F(6), LSM2D_RL_F(7), LSM2D_RL_F(8), damping, dx, dy, dth);
 #undef LSM2D_RL_F
         if (!ok) { status = LSM2D_SINGULAR_H; done_now = true; }
         else {
           const float nx = __builtin_fmaf(cp, dx, __builtin_fmaf(-sp, dy, pose[0]));
           const float ny = __builtin_fmaf(sp, dx, __builtin_fmaf(cp, dy, pose[1]));
           pose[0] = nx; pose[1] = ny; pose[2] = wrap_angle(pose[2] + dth);
-          if (A.term_eps > 0.0f) {       // as in k_align
+          if (term_eps > 0.0f) {         // as in k_align
             const float chi_now = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 9)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 10));
-            if (it > 0 && __builtin_fabsf(prev_chi - chi_now) < A.term_eps * chi_now) done_now = true;
+            if (it > 0 && __builtin_fabsf(prev_chi - chi_now) < term_eps * chi_now) done_now = true;
             prev_chi = chi_now;
           }
         }
@@ -1909,6 +1918,22 @@ LSM2D_DEV int block_compact_offset(bool flag, int* s_wave_tot, int* s_base, int 
   return before + prefix;
 }
 
+// the same with ONE barrier per call: the per-wave totals alternate between two buffers (`parity`: 0, 1, 0, ... from call to call; the
+// barrier of call i + 1 separates the reads of call i from the writes of call i + 2), and every thread keeps the running base itself
+// (`base`, the same value in all threads; in: flagged elements so far, out: including this call's)
+LSM2D_DEV int block_compact_pos(bool flag, int* s_tot /* [2][nwaves] */, int parity, int& base, int tid, int nwaves) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const u64 bal = __ballot(flag);
+  const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+  int* t = s_tot + parity * nwaves;
+  if (lane == 0) t[wave] = __popcll(bal);
+  __syncthreads();
+  int before = base, total = 0;
+  for (int w = 0; w < nwaves; ++w) { const int v = t[w]; if (w < wave) before += v; total += v; }
+  base += total;
+  return before + prefix;
+}
+
 // SceneClipperProjective2D::compute tail (mapping/scene_clipper_projective_2d.cpp:53-63): filled cells in ascending
 // column -> transformed point (sensor frame), then moved to the robot frame by sensor_in_robot
 struct ClipEmitArgs {
@@ -1927,12 +1952,13 @@ __global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A);
 // n_dev: when non-null the scene's size is only known on the device (its set was last written by an asynchronous clip / merge)
 struct ClipSmallArgs { const float2* xy; const float2* nrm; int32_t n; const int32_t* n_dev; ProjK proj; ClipEmitArgs emit; };
 
-LSM2D_DEV void clip_emit_body(const ClipEmitArgs& A, const u64* canvas, int* s_wave_tot, int* s_base, int tid) {
-  for (int c0 = 0; c0 < A.cols; c0 += kFindBlock) {
+LSM2D_DEV void clip_emit_body(const ClipEmitArgs& A, const u64* canvas, int* s_tot /* [2][kFindBlock / 64] */, int tid) {
+  int base = 0, parity = 0;
+  for (int c0 = 0; c0 < A.cols; c0 += kFindBlock, parity ^= 1) {
     const int col = c0 + tid;
     const u64 k = col < A.cols ? canvas[col] : kEmptyCell;
     const bool ok = k != kEmptyCell;
-    const int pos = block_compact_offset(ok, s_wave_tot, s_base, tid, kFindBlock / 64);
+    const int pos = block_compact_pos(ok, s_tot, parity, base, tid, kFindBlock / 64);
     if (ok) {
       const int src = (int) (uint32_t) k;
       const float2 p = A.xy[src], n = A.nrm[src];
@@ -1950,30 +1976,25 @@ LSM2D_DEV void clip_emit_body(const ClipEmitArgs& A, const u64* canvas, int* s_w
   if (A.host_polls) {      // the count goes last, behind every thread's system-scope release of its rows: the synchronous form's host side polls it
     __threadfence_system();
     __syncthreads();
-    if (tid == 0) { *A.out_count_dev = *s_base; __hip_atomic_store(A.out_count, *s_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-  } else if (tid == 0) { *A.out_count = *s_base; *A.out_count_dev = *s_base; }
+    if (tid == 0) { *A.out_count_dev = base; __hip_atomic_store(A.out_count, base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  } else if (tid == 0) { *A.out_count = base; *A.out_count_dev = base; }
 }
 
 __global__ __launch_bounds__(kFindBlock) void k_clip_small(const ClipSmallArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64* can = reinterpret_cast<u64*>(smem);
-  __shared__ int s_wave_tot[kFindBlock / 64];
-  __shared__ int s_base;
+  __shared__ int s_tot[2 * (kFindBlock / 64)];
   const int tid = threadIdx.x;
   for (int i = tid; i < A.proj.cols; i += kFindBlock) can[i] = kEmptyCell;
-  if (tid == 0) s_base = 0;
   __syncthreads();
   project_cloud(A.xy, A.n_dev ? *A.n_dev : A.n, A.emit.T, A.proj, can, tid, kFindBlock);
   __syncthreads();
-  clip_emit_body(A.emit, can, s_wave_tot, &s_base, tid);
+  clip_emit_body(A.emit, can, s_tot, tid);
 }
 
 __global__ __launch_bounds__(kFindBlock) void k_clip_emit(const ClipEmitArgs A) {
-  __shared__ int s_wave_tot[kFindBlock / 64];
-  __shared__ int s_base;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  clip_emit_body(A, A.gcanvas, s_wave_tot, &s_base, threadIdx.x);
+  __shared__ int s_tot[2 * (kFindBlock / 64)];
+  clip_emit_body(A, A.gcanvas, s_tot, threadIdx.x);
 }
 
 // transform a cloud (measurement -> scene frame, mapping/merger_projective_2d.cpp:22-23)
@@ -2000,9 +2021,11 @@ struct MergeArgs {
 
 // mkT: when non-null the measurement is still in its own frame and is moved by *mkT on the fly (fused small-scene kernel);
 // the transform is the same operation sequence as k_transform_cloud, so both forms give the same bits
-LSM2D_DEV void merge_apply_body(const MergeArgs& A, const u64* scanvas, const u64* mcanvas, const Iso* mkT, int* s_wave_tot, int* s_cnt, int tid) {
-  // s_cnt: [0] appended, [1] new, [2] merged, [3] replaced
-  for (int c0 = 0; c0 < A.cols; c0 += kFindBlock) {
+// returns the number of appended points (the same value in every thread); s_tot: [2][kFindBlock / 64]; s_cnt: [1] new, [2] merged, [3] replaced,
+// zeroed by the caller, read here by thread 0 behind a barrier of its own
+LSM2D_DEV int merge_apply_body(const MergeArgs& A, const u64* scanvas, const u64* mcanvas, const Iso* mkT, int* s_tot, int* s_cnt, int tid) {
+  int appended = 0, parity = 0;
+  for (int c0 = 0; c0 < A.cols; c0 += kFindBlock, parity ^= 1) {
     const int col = c0 + tid;
     bool append = false; float2 mp = make_float2(0.f, 0.f), mn = mp;
     if (col < A.cols) {
@@ -2033,22 +2056,25 @@ LSM2D_DEV void merge_apply_body(const MergeArgs& A, const u64* scanvas, const u6
         }
       }
     }
-    const int pos = block_compact_offset(append, s_wave_tot, &s_cnt[0], tid, kFindBlock / 64);
+    const int pos = block_compact_pos(append, s_tot, parity, appended, tid, kFindBlock / 64);
     if (append) { A.sxy[A.n_scene + pos] = mp; A.snrm[A.n_scene + pos] = mn; }
   }
+  if (A.host_polls) __threadfence_system();      // every thread's rows, ahead of the size the host polls
+  __syncthreads();                                // the counters are final (and, with host_polls, every thread's rows are released)
   if (tid == 0) {      // the new size goes last; the synchronous form's host side polls it in pinned memory: released to the system then
-    A.out[1] = s_cnt[1]; A.out[2] = s_cnt[2]; A.out[3] = s_cnt[3]; *A.count_dev = A.n_scene + s_cnt[0];
-    if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out[0], A.n_scene + s_cnt[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-    else A.out[0] = A.n_scene + s_cnt[0];
+    A.out[1] = s_cnt[1]; A.out[2] = s_cnt[2]; A.out[3] = s_cnt[3]; *A.count_dev = A.n_scene + appended;
+    if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out[0], A.n_scene + appended, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    else A.out[0] = A.n_scene + appended;
   }
+  return appended;
 }
 
 __global__ __launch_bounds__(kFindBlock) void k_merge_apply(const MergeArgs A) {
-  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_tot[2 * (kFindBlock / 64)];
   __shared__ int s_cnt[4];
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  merge_apply_body(A, A.scanvas, A.mcanvas, nullptr, s_wave_tot, s_cnt, threadIdx.x);
+  merge_apply_body(A, A.scanvas, A.mcanvas, nullptr, s_tot, s_cnt, threadIdx.x);
 }
 
 // small scene: transform + both projections + column walk in one workgroup (mxy / mnrm hold the measurement in ITS frame)
@@ -2058,7 +2084,7 @@ __global__ __launch_bounds__(kFindBlock) void k_merge_small(const MergeSmallArgs
   extern __shared__ __align__(16) unsigned char smem[];
   u64* scan = reinterpret_cast<u64*>(smem);
   u64* mcan = scan + A.proj.cols;
-  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_tot[2 * (kFindBlock / 64)];
   __shared__ int s_cnt[4];
   const int tid = threadIdx.x;
   for (int i = tid; i < A.proj.cols; i += kFindBlock) { scan[i] = kEmptyCell; mcan[i] = kEmptyCell; }
@@ -2074,7 +2100,7 @@ __global__ __launch_bounds__(kFindBlock) void k_merge_small(const MergeSmallArgs
     project_point(A.Tinv, A.proj, x, y, i, mcan);
   }
   __syncthreads();
-  merge_apply_body(m, scan, mcan, &A.M, s_wave_tot, s_cnt, tid);
+  merge_apply_body(m, scan, mcan, &A.M, s_tot, s_cnt, tid);
 }
 
 // several measurements merged into the scene one after the other by ONE launch (lsm2d_merge_scenes: the live tracker's front and
@@ -2085,18 +2111,22 @@ __global__ __launch_bounds__(kFindBlock) void k_merge_multi(const MergeMultiArgs
   extern __shared__ __align__(16) unsigned char smem[];
   u64* scan = reinterpret_cast<u64*>(smem);
   u64* mcan = scan + A.a[0].proj.cols;                             // one projector for all of them
-  __shared__ int s_wave_tot[kFindBlock / 64];
+  __shared__ int s_tot[2 * (kFindBlock / 64)];
   __shared__ int s_cnt[4];
   const int tid = threadIdx.x;
-  int n_scene = 0;
+  // sizes only the device knows: all of them up front, the loads in flight together (not one round trip per measurement)
+  int n_scene = A.a[0].n_scene_dev ? *A.a[0].n_scene_dev : A.a[0].m.n_scene;
+  int n_meas_of[kMergeMulti];
+#pragma unroll
+  for (int k = 0; k < kMergeMulti; ++k) n_meas_of[k] = k < A.n ? (A.a[k].n_meas_dev ? *A.a[k].n_meas_dev : A.a[k].n_meas) : 0;
   for (int k = 0; k < A.n; ++k) {
     const MergeSmallArgs& S = A.a[k];
     for (int i = tid; i < S.proj.cols; i += kFindBlock) { scan[i] = kEmptyCell; mcan[i] = kEmptyCell; }
     if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
     MergeArgs m = S.m;
-    if (k == 0) { if (S.n_scene_dev) m.n_scene = *S.n_scene_dev; } else m.n_scene = n_scene;
-    const int n_meas = S.n_meas_dev ? *S.n_meas_dev : S.n_meas;
+    m.n_scene = n_scene;
+    const int n_meas = k == 0 ? n_meas_of[0] : (k == 1 ? n_meas_of[1] : (k == 2 ? n_meas_of[2] : n_meas_of[3]));
     project_cloud(m.sxy, m.n_scene, S.Tinv, S.proj, scan, tid, kFindBlock);
     for (int i = tid; i < n_meas; i += kFindBlock) {
       const float2 p = m.mxy[i];
@@ -2104,10 +2134,8 @@ __global__ __launch_bounds__(kFindBlock) void k_merge_multi(const MergeMultiArgs
       project_point(S.Tinv, S.proj, x, y, i, mcan);
     }
     __syncthreads();
-    merge_apply_body(m, scan, mcan, &S.M, s_wave_tot, s_cnt, tid);
-    __syncthreads();
-    n_scene = m.n_scene + s_cnt[0];          // what the next measurement is merged into (the body appended s_cnt[0] points)
-    __syncthreads();
+    n_scene = m.n_scene + merge_apply_body(m, scan, mcan, &S.M, s_tot, s_cnt, tid);      // what the next measurement is merged into
+    __syncthreads();                         // thread 0 has read the counters; rows and canvases are free for the next measurement
   }
 }
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 #include "lsm2d.h"
 
@@ -46,6 +47,15 @@ int main(int argc, char** argv) {
   const bool single_merges = getenv("LSM2D_TSB_SINGLE_MERGES") != nullptr;      // one lsm2d_merge_scene call per scan instead of one lsm2d_merge_scenes
   const bool timing = getenv("LSM2D_TSB_TIMING") != nullptr;        // kernel events cost ~30 us per step: off unless asked for
   if (timing) CK(lsm2d_set_option(ctx, "kernel_timing", 1));
+  if (const char* o = getenv("LSM2D_TSB_OPTIONS")) {                // "key=value,key=value": context options (A/B runs of tuning knobs)
+    std::string all(o); size_t at = 0;
+    while (at < all.size()) {
+      size_t e = all.find(',', at); if (e == std::string::npos) e = all.size();
+      const std::string kv = all.substr(at, e - at); const size_t q = kv.find('=');
+      if (q != std::string::npos) CK(lsm2d_set_option(ctx, kv.substr(0, q).c_str(), atoll(kv.c_str() + q + 1)));
+      at = e + 1;
+    }
+  }
   lsm2d_cloudset *local_map, *clipped, *m0, *m1;
   CK(lsm2d_cloudset_create_reserved(ctx, 60000, &local_map));
   CK(lsm2d_cloudset_create_reserved(ctx, 721, &clipped));
