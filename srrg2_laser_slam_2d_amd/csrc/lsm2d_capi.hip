@@ -1609,7 +1609,13 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
                            (size_t) ns * (sizeof(u64) * (size_t) cols_max + sizeof(float) * kPairRedStride * (kAlignBlock / 64));
   const size_t lds_mov = (size_t) ns * kPairMovCap * sizeof(float4);
   A.pair_mov_cap = (int) (lds_pair0 + lds_mov) + 512 <= ctx->max_dyn_lds ? kPairMovCap : 0;
-  const size_t lds_pair = lds_pair0 + (A.pair_mov_cap ? lds_mov : 0);
+  // ... and the fixed clouds (sizes the host knows, or upper bounds of sizes only the device knows: the kernel compares the real ones)
+  int max_fixed_rows = 0;
+  for (int s = 0; s < ns; ++s) { const lsm2d_cloudset* f = b->fixed[s]; for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > max_fixed_rows) max_fixed_rows = f->h_count[c]; }
+  max_fixed_rows = (max_fixed_rows + 63) & ~63;
+  const size_t lds_fix = (size_t) ns * (size_t) max_fixed_rows * sizeof(float4);
+  A.pair_fix_cap = max_fixed_rows <= 4096 && (int) (lds_pair0 + (A.pair_mov_cap ? lds_mov : 0) + lds_fix) + 512 <= ctx->max_dyn_lds ? max_fixed_rows : 0;
+  const size_t lds_pair = lds_pair0 + (A.pair_mov_cap ? lds_mov : 0) + (A.pair_fix_cap ? lds_fix : 0);
   const bool use_pair = !use_split && ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist && !has_kd &&
                         (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0 && (int) lds_pair + 512 <= ctx->max_dyn_lds;
 

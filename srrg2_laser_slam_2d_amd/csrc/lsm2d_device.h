@@ -453,7 +453,7 @@ LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, fl
     const float q = chi / tau;
     w = 1.0f / (1.0f + q);
     inlier = chi < tau;
-    kern = tau * (kInlineLog ? log_fixed_inline(1.0f + q) : log_fixed(1.0f + q));
+    if (!inlier) kern = tau * (kInlineLog ? log_fixed_inline(1.0f + q) : log_fixed(1.0f + q));      // only outliers' statistic uses it: waves of inliers skip the logarithm
   }
   A.n_in += inlier ? 1 : 0;
   A.n_out += inlier ? 0 : 1;

@@ -662,6 +662,7 @@ struct AlignArgs {
   int32_t cull_block;                       // steps per unit of the culled stream (0: automatic; tuning knob)
   int32_t cull;                             // 1: projective slices drop the chunks of the moving cloud that cannot yield a pair (chunk_may_matter), results unchanged
   int32_t pair_mov_cap;                     // latency kernel: moving points per slice it may keep in LDS (kPairMovCap, or 0: no room)
+  int32_t pair_fix_cap;                     // latency kernel: fixed points per slice it may keep in LDS (0: no room)
   const float* init_pose;
   const PriorDev* prior;
   int32_t  host_polls;                      // results go to pinned host memory and the host polls the status words: release them to the system
@@ -1275,7 +1276,8 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   constexpr int nwaves = kAlignBlock / 64;
   float4* fwin = reinterpret_cast<float4*>(smem);                                 // 16-byte rows first (alignment)
   float4* mwin2 = fwin + A.fcan_total;                                             // [n_slices][pair_mov_cap]: the moving clouds, (x, y, nx, ny)
-  float* red2 = reinterpret_cast<float*>(mwin2 + A.n_slices * A.pair_mov_cap);     // [n_slices][nwaves][kPairRedStride]
+  float4* fall2 = mwin2 + A.n_slices * A.pair_mov_cap;                             // [n_slices][pair_fix_cap]: the fixed clouds
+  float* red2 = reinterpret_cast<float*>(fall2 + A.n_slices * A.pair_fix_cap);     // [n_slices][nwaves][kPairRedStride]
   u64* mcan2 = reinterpret_cast<u64*>(red2 + A.n_slices * nwaves * kPairRedStride);      // [n_slices][cols_max]: one moving canvas per slice
   u64* fcan = mcan2 + A.n_slices * A.cols_max;
   __shared__ Iso   s_iso[2];
@@ -1294,10 +1296,36 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   const int tid = gtid & (kAlignBlock - 1), lane = gtid & 63;
   u64* mcan = mcan2 + half * A.cols_max;
   float* red = red2 + half * nwaves * kPairRedStride;
+  // ---- everything that comes from memory is asked for first: the clouds' places and sizes, then this thread's rows of both clouds (the
+  //      fixed one possibly still in the host's pinned upload buffer: SliceDev::unpack_src) -- in flight while the canvases are cleared
+  const SliceDev& S = A.s[half];
+  const int mc = pick_cloud(S.moving, a), fc = pick_cloud(S.fixed, a);
+  const bool unpack = A.inline_n1 && S.unpack_src;
+  const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
+  const int m_count = S.moving.count[mc], f_count = unpack ? S.unpack_n : S.fixed.count[fc];
+  const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
+  // clouds on chip (see the head comment): the moving one at most two points per thread (coordinates stay in registers), the fixed one as many rows as LDS has
+  const bool m_on_chip = !S.moving.lane_xy && m_count <= A.pair_mov_cap;      // pair_mov_cap: kPairMovCap, or 0 when LDS has no room
+  const bool f_on_chip = f_count <= A.pair_fix_cap;
+  float4* mwin = mwin2 + half * A.pair_mov_cap;
+  float4* fall = fall2 + half * A.pair_fix_cap;
+  const int j1 = kPairMovCap - 1 - tid;                   // this thread's second moving point, if the cloud has more than 512
+  float2 p0 = make_float2(0.0f, 0.0f), p1 = p0, n0 = p0, n1 = p0;
+  if (m_on_chip) {
+    if (tid < m_count) { p0 = mp[tid]; n0 = mn[tid]; }
+    if (j1 < m_count) { p1 = mp[j1]; n1 = mn[j1]; }
+  }
+  auto fixed_row = [&](int i) {
+    if (unpack) return S.unpack_src[i];
+    const float2 p = S.fixed.xy[fbase + i], n = S.fixed.nrm[fbase + i];
+    return make_float4(p.x, p.y, n.x, n.y);
+  };
+  float4 frow = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (f_on_chip && tid < f_count) frow = fixed_row(tid);
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
   if (A.prior && gtid >= 64 && gtid < 64 + kPriorWords)
     ((float*) &s_prior)[gtid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[gtid - 64] : ((const float*) (A.prior + a))[gtid - 64];
-  if (A.inline_n1 && A.s[half].unpack_src) unpack_fixed_set(A.s[half], tid, kAlignBlock);      // visible after the barrier below
+  if (unpack && !f_on_chip) unpack_fixed_set(S, tid, kAlignBlock);      // visible after the barrier below
   for (int i = gtid; i < A.fcan_total; i += nthr) fcan[i] = kEmptyCell;
   for (int i = gtid; i < A.n_slices * A.cols_max; i += nthr) mcan2[i] = kEmptyCell;
 
@@ -1324,33 +1352,36 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
     if (lane < A.n_slices) s_iso[lane] = slice_iso_of(khs, kc, ks, kS, pose);
     if (lane == 0) s_done = 0;
   }
-  __syncthreads();
+  __syncthreads();                  // canvases cleared, prior and first transforms in LDS
   PriorDev pz;                      // wave 0's copy of the prior, in registers
   if (w0 && A.prior) pz = s_prior;
-  const SliceDev& S = A.s[half];
-  const int mc = pick_cloud(S.moving, a);
-  const int mbase = S.moving.start[mc];
-  const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
-  // the moving cloud on chip (see the head comment); loaded here, ahead of the fixed cloud's passes: the loads overlap them
-  const int m_count = S.moving.count[mc];
-  const bool m_on_chip = !S.moving.lane_xy && m_count <= A.pair_mov_cap;      // pair_mov_cap: kPairMovCap, or 0 when LDS has no room
-  float4* mwin = mwin2 + half * A.pair_mov_cap;
-  const int j1 = kPairMovCap - 1 - tid;                   // this thread's second point, if the cloud has more than 512
-  float2 p0 = make_float2(0.0f, 0.0f), p1 = make_float2(0.0f, 0.0f);
   if (m_on_chip) {
-    if (tid < m_count) { p0 = mp[tid]; const float2 n = mn[tid]; mwin[tid] = make_float4(p0.x, p0.y, n.x, n.y); }
-    if (j1 < m_count) { p1 = mp[j1]; const float2 n = mn[j1]; mwin[j1] = make_float4(p1.x, p1.y, n.x, n.y); }
+    if (tid < m_count) mwin[tid] = make_float4(p0.x, p0.y, n0.x, n0.y);
+    if (j1 < m_count) mwin[j1] = make_float4(p1.x, p1.y, n1.x, n1.y);
   }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
-  const int fbase = S.fixed.start[pick_cloud(S.fixed, a)];
-  project_cloud(S.fixed.xy + fbase, (A.inline_n1 && S.unpack_src) ? S.unpack_n : S.fixed.count[pick_cloud(S.fixed, a)], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
-  __syncthreads();
-  for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
-    const u64 k = fcan[S.fcan_offset + col];
-    if (k != kEmptyCell) {
-      const int fi = (int) (uint32_t) k;
-      const float2 p = S.fixed.xy[fbase + fi], n = S.fixed.nrm[fbase + fi];
-      fwin[S.fcan_offset + col] = make_float4(p.x, p.y, n.x, n.y);
+  if (f_on_chip) {
+    // the fixed cloud: every row into LDS (the bin walk reads the winner's row there: no table of winners, no pass to fill it), a set that
+    // was still in the upload buffer also into its arrays (later consumers find them there), and into the z-buffer -- project_cloud's
+    // operations per point (project_point with the identity)
+    float2* oxy = const_cast<float2*>(S.fixed.xy) + fbase; float2* onr = const_cast<float2*>(S.fixed.nrm) + fbase;
+    for (int i = tid; i < f_count; i += kAlignBlock) {
+      if (i != tid) frow = fixed_row(i);
+      fall[i] = frow;
+      if (unpack) { oxy[i] = make_float2(frow.x, frow.y); onr[i] = make_float2(frow.z, frow.w); }
+      project_point(ident, S.proj, frow.x, frow.y, i, fcan + S.fcan_offset);
+    }
+    if (unpack && tid == 0) *const_cast<int32_t*>(S.fixed.count) = S.unpack_n;
+  } else {
+    project_cloud(S.fixed.xy + fbase, f_count, ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
+    __syncthreads();
+    for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
+      const u64 k = fcan[S.fcan_offset + col];
+      if (k != kEmptyCell) {
+        const int fi = (int) (uint32_t) k;
+        const float2 p = S.fixed.xy[fbase + fi], n = S.fixed.nrm[fbase + fi];
+        fwin[S.fcan_offset + col] = make_float4(p.x, p.y, n.x, n.y);
+      }
     }
   }
   // what the serial stretch reads from the kernel arguments, fetched once (an s_load and its wait per use otherwise)
@@ -1362,6 +1393,14 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   asm volatile("" : "+v"(out_stats));
   const bool two_slices = n_slices == 2, has_prior = prior_ptr != 0;
   const float term_eps = __int_as_float(term_eps_b), damping = __int_as_float(damping_b);
+  // ... and what every wave's projection and walk read, per slice
+  const bool on_chip = m_on_chip && f_on_chip;
+  ProjK Pk = S.proj;
+  int k00_b = __float_as_int(Pk.K00), k01_b = __float_as_int(Pk.K01), r2lo_b = __float_as_int(Pk.r2lo), r2hi_b = __float_as_int(Pk.r2hi), kcols = Pk.cols;
+  int pd_b = __float_as_int(S.point_distance), ncos_b = __float_as_int(S.normal_cos), tau_b = __float_as_int(S.tau);
+  asm volatile("" : "+s"(k00_b), "+s"(k01_b), "+s"(r2lo_b), "+s"(r2hi_b), "+s"(kcols), "+s"(pd_b), "+s"(ncos_b), "+s"(tau_b));
+  Pk.K00 = __int_as_float(k00_b); Pk.K01 = __int_as_float(k01_b); Pk.r2lo = __int_as_float(r2lo_b); Pk.r2hi = __int_as_float(r2hi_b); Pk.cols = kcols;
+  const float k_pd = __int_as_float(pd_b), k_ncos = __int_as_float(ncos_b), k_tau = __int_as_float(tau_b);
   const int per_thread = (S.proj.cols + kAlignBlock - 1) / kAlignBlock;      // pairs a thread can accumulate
   const int count_bits = 32 - __builtin_clz(per_thread | 1);
   const bool cauchy = S.cauchy != 0;
@@ -1373,6 +1412,25 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   for (; it < A.max_it; ++it) {
     const Iso T = s_iso[half];
     Accum acc; accum_zero(acc);
+    if (on_chip) {
+      // both clouds in LDS (the tracker's case): one point's z-buffer update per thread, then the walk one column at a time -- every gather is
+      // an LDS row, so there is no latency worth a second column in flight, and a wave without a second column does not walk through one
+      if (tid < m_count) project_point<LSM2D_PAIR_READ_FIRST>(T, Pk, p0.x, p0.y, tid, mcan);
+      if (j1 < m_count) project_point<LSM2D_PAIR_READ_FIRST>(T, Pk, p1.x, p1.y, j1, mcan);
+      __syncthreads();
+      LSM2D_PC(1);
+      for (int col = tid; col < Pk.cols; col += kAlignBlock) {
+        const u64 fk = fcs[col], mk = mcan[col];
+        mcan[col] = kEmptyCell;
+        const uint32_t fdb = (uint32_t) (fk >> 32), mdb = (uint32_t) (mk >> 32);       // an empty cell's depth bits are all ones, no depth's are
+        if (fdb != 0xFFFFFFFFu && mdb != 0xFFFFFFFFu && !(__builtin_fabsf(__uint_as_float(fdb) - __uint_as_float(mdb)) > k_pd)) {
+          const float4 m = mwin[(uint32_t) mk], f = fall[(uint32_t) fk];
+          float nqx, nqy; xf_normal(T, m.z, m.w, nqx, nqy);
+          if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < k_ncos))
+            accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), make_float2(m.x, m.y), make_float2(m.z, m.w), cauchy, k_tau, acc);
+        }
+      }
+    } else {
     if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
     else if (m_on_chip) {         // the same points every iteration: no load, no wait
       if (tid < m_count) project_point<LSM2D_PAIR_READ_FIRST>(T, S.proj, p0.x, p0.y, tid, mcan);
@@ -1406,17 +1464,18 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
         if (g1) { nm1 = mn[mi1]; pm1 = mp[mi1]; }
       }
       if (g0) {
-        const float4 f = fws[col];
+        const float4 f = f_on_chip ? fall[(uint32_t) fk0] : fws[col];
         float nqx, nqy; xf_normal(T, nm0.x, nm0.y, nqx, nqy);
         if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos))
           accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm0, nm0, cauchy, S.tau, acc);
       }
       if (g1) {
-        const float4 f = fws[col1];
+        const float4 f = f_on_chip ? fall[(uint32_t) fk1] : fws[col1];
         float nqx, nqy; xf_normal(T, nm1.x, nm1.y, nqx, nqy);
         if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos))
           accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm1, nm1, cauchy, S.tau, acc);
       }
+    }
     }
     LSM2D_PC(6);                 // thread 0's wave: bin walk
     pair_wave_sums(acc, red, tid, cauchy, count_bits);
