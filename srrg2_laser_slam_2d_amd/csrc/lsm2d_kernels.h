@@ -2231,7 +2231,7 @@ __global__ void k_pack_aos(const float2* __restrict__ xy, const float2* __restri
 static constexpr int kVoxBlock = 1024;
 static constexpr int kVoxMax = 2048;
 template <typename Emit>
-LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int k, float inv_rx, float inv_rn, int* s_wave_tot, int* s_base,
+LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int k, float inv_rx, float inv_rn, int* s_tot /* [2][kVoxBlock / 64] */,
                            int tid, Emit emit) {
   int np2 = 1; while (np2 < k) np2 <<= 1;
   for (int i = tid; i < np2; i += kVoxBlock) {
@@ -2267,13 +2267,12 @@ LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int
     }
   }
   __syncthreads();
-  if (tid == 0) *s_base = 0;
-  __syncthreads();
-  for (int t0 = 0; t0 < np2; t0 += kVoxBlock) {
+  int nv = 0, parity = 0;
+  for (int t0 = 0; t0 < np2; t0 += kVoxBlock, parity ^= 1) {
     const int t = t0 + tid;
     bool head = false; u64 key = ~0ull;
     if (t < np2) { key = s_key[t]; head = key != ~0ull && (t == 0 || (s_key[t - 1] >> 16) != (key >> 16)); }
-    const int pos = block_compact_offset(head, s_wave_tot, s_base, tid, kVoxBlock / 64);
+    const int pos = block_compact_pos(head, s_tot, parity, nv, tid, kVoxBlock / 64);
     if (head) {
       float ax = 0.0f, ay = 0.0f, anx = 0.0f, any_ = 0.0f; int cnt = 0;
       for (int e = t; e < np2 && (s_key[e] >> 16) == (key >> 16); ++e) {
@@ -2287,8 +2286,7 @@ LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int
       emit(pos, ax, ay, anx, any_);
     }
   }
-  __syncthreads();
-  return *s_base;
+  return nv;
 }
 
 // the clipper's voxelize_resolution > 0 branch (mapping/scene_clipper_projective_2d.cpp:36-48,60-62): the clipped cloud -- written
@@ -2303,13 +2301,12 @@ __global__ __launch_bounds__(kVoxBlock) void k_voxelize_clipped(const VoxArgs A)
   __shared__ float2 s_q[kVoxMax];
   __shared__ float2 s_n[kVoxMax];
   __shared__ u64 s_key[kVoxMax];
-  __shared__ int s_wave_tot[kVoxBlock / 64];
-  __shared__ int s_base;
+  __shared__ int s_tot[2 * (kVoxBlock / 64)];
   const int tid = threadIdx.x;
   int k = *A.count_dev; if (k > kVoxMax) k = kVoxMax;      // the host refuses canvases beyond kVoxMax columns
   for (int i = tid; i < k; i += kVoxBlock) { s_q[i] = A.xy[i]; s_n[i] = A.nrm[i]; }
   __syncthreads();
-  const int nv = voxelize_lds(s_q, s_n, s_key, k, A.inv_rx, A.inv_rn, s_wave_tot, &s_base, tid, [&](int pos, float x, float y, float nx, float ny) {
+  const int nv = voxelize_lds(s_q, s_n, s_key, k, A.inv_rx, A.inv_rn, s_tot, tid, [&](int pos, float x, float y, float nx, float ny) {
     if (!A.s_identity) {
       float tx, ty, tnx, tny;
       xf_point(A.S, x, y, tx, ty); xf_normal(A.S, nx, ny, tnx, tny);
@@ -2339,27 +2336,30 @@ LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
   __shared__ float2 s_q[kPrepMaxBeams];      // points that got a normal
   __shared__ float2 s_n[kPrepMaxBeams];      // their normals
   __shared__ u64 s_key[kPrepMaxBeams];       // (voxel key << 16) | index, bitonic-sorted
-  __shared__ int s_wave_tot[kPrepBlock / 64];
-  __shared__ int s_base;
+  __shared__ int s_tot[2 * (kPrepBlock / 64)];
   const int tid = threadIdx.x, nb = A.n_beams;
+#ifdef LSM2D_PHASE_CLOCKS
+  unsigned long long pc_t = __builtin_amdgcn_s_memrealtime(), pc_acc[6] = {0, 0, 0, 0, 0, 0};
+#define LSM2D_PC(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); pc_acc[k] += n_ - pc_t; pc_t = n_; } while (0)
+#else
+#define LSM2D_PC(k) do { } while (0)
+#endif
   const float* rg = A.ranges + (size_t) scan * nb;
   float2* oxy = A.out_xy + (size_t) scan * A.stride; float2* onr = A.out_nrm + (size_t) scan * A.stride;
   // ---- F2.1 unprojection, valid beams compacted in beam order
-  if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (int c0 = 0; c0 < nb; c0 += kPrepBlock) {
+  int m = 0, parity = 0;
+  for (int c0 = 0; c0 < nb; c0 += kPrepBlock, parity ^= 1) {
     const int c = c0 + tid;
-    float r = 0.0f; bool ok = false;
-    if (c < nb) { r = rg[c]; ok = r >= A.rmin && r <= A.rmax; }
-    const int pos = block_compact_offset(ok, s_wave_tot, &s_base, tid, kPrepBlock / 64);
-    if (ok) { const float2 d = A.beam_dir[c]; s_p[pos] = make_float2(r * d.x, r * d.y); }
+    float r = 0.0f; bool ok = false; float2 d = make_float2(0.0f, 0.0f);
+    if (c < nb) { r = rg[c]; d = A.beam_dir[c]; ok = r >= A.rmin && r <= A.rmax; }
+    const int pos = block_compact_pos(ok, s_tot, parity, m, tid, kPrepBlock / 64);
+    if (ok) s_p[pos] = make_float2(r * d.x, r * d.y);
   }
-  const int m = s_base;
   __syncthreads();
+  LSM2D_PC(0);
   // ---- F2.2 sliding-window normals
-  if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < m; i0 += kPrepBlock) {
+  int k = 0;
+  for (int i0 = 0; i0 < m; i0 += kPrepBlock, parity ^= 1) {
     const int i = i0 + tid;
     bool ok = false; float vx = 0.0f, vy = 0.0f; float2 pi = make_float2(0.0f, 0.0f);
     if (i < m) {
@@ -2392,20 +2392,26 @@ LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
         }
       }
     }
-    const int pos = block_compact_offset(ok, s_wave_tot, &s_base, tid, kPrepBlock / 64);
+    LSM2D_PC(1);
+    const int pos = block_compact_pos(ok, s_tot, parity, k, tid, kPrepBlock / 64);
     if (ok) { s_q[pos] = pi; s_n[pos] = make_float2(vx, vy); }
   }
-  const int k = s_base;
   __syncthreads();
+  LSM2D_PC(2);
   if (!(A.inv_res > 0.0f)) {                       // no voxelisation: every valid point, beam order
     for (int i = tid; i < k; i += kPrepBlock) { oxy[i] = s_q[i]; onr[i] = s_n[i]; }
     if (tid == 0) A.out_count[scan] = k;
     return;
   }
   // ---- F2.3 voxelisation: sort (key, index), average equal-key runs, ascending key order
-  const int nv = voxelize_lds(s_q, s_n, s_key, k, A.inv_res, 1.0f, s_wave_tot, &s_base, tid,
+  const int nv = voxelize_lds(s_q, s_n, s_key, k, A.inv_res, 1.0f, s_tot, tid,
                               [&](int pos, float x, float y, float nx, float ny) { oxy[pos] = make_float2(x, y); onr[pos] = make_float2(nx, ny); });
   if (tid == 0) A.out_count[scan] = nv;
+  LSM2D_PC(3);
+#ifdef LSM2D_PHASE_CLOCKS
+  if (tid == 0) printf("preprocess ticks(10ns): unproject %llu normals %llu compaction %llu voxelise %llu (beams %d valid %d normals %d voxels %d)\n", pc_acc[0], pc_acc[1], pc_acc[2], pc_acc[3], nb, m, k, nv);
+#endif
+#undef LSM2D_PC
 }
 __global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs A) { preprocess_scan_body(A, blockIdx.x); }
 // several scans, each with its own sensor geometry and its own output set, side by side (the live tracker's front and rear scanner:
