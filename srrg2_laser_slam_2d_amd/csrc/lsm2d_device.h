@@ -492,20 +492,50 @@ LSM2D_DEV int wave_sum63_i(int v) {
   return v;
 }
 
+// wave_sum63's tree for N values at once, level by level: independent instructions back to back (no wait states between a VALU write and
+// the DPP read of it), and the two levels across rows as ONE instruction per value -- v_add with a DPP operand and a row mask leaves the
+// masked-out rows' registers as they are (the builtin's form -- zero into those rows, then add -- costs a v_mov_dpp and a v_add each).
+// The same sums: rows 1 and 3 add lane 15 of the row below, then rows 2 and 3 add lane 31.  (s_nop: a DPP operand written by the VALU
+// instruction right before needs two wait states; inside the block the other values' instructions stand between a value's two levels.)
+template <int N> LSM2D_DEV void wave_tree63(float (&f)[11]) {
+  static_assert(N == 10 || N == 11, "one block of ten or eleven values");
+#define LSM2D_LVL(ctrl, rmask) _Pragma("unroll") for (int k = 0; k < N; ++k) f[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f[k]), ctrl, rmask, 0xF, false));
+  LSM2D_LVL(0x111, 0xF) LSM2D_LVL(0x112, 0xF) LSM2D_LVL(0x114, 0xF) LSM2D_LVL(0x118, 0xF)
+#undef LSM2D_LVL
+#define LSM2D_ROW(k, what) "v_add_f32_dpp %" #k ", %" #k ", %" #k " " what "\n\t"
+#define LSM2D_ROWS10(what) LSM2D_ROW(0, what) LSM2D_ROW(1, what) LSM2D_ROW(2, what) LSM2D_ROW(3, what) LSM2D_ROW(4, what) LSM2D_ROW(5, what) \
+                           LSM2D_ROW(6, what) LSM2D_ROW(7, what) LSM2D_ROW(8, what) LSM2D_ROW(9, what)
+  if constexpr (N == 11)
+    asm volatile("s_nop 1\n\t" LSM2D_ROWS10("row_bcast:15 row_mask:0xa") LSM2D_ROW(10, "row_bcast:15 row_mask:0xa")
+                 LSM2D_ROWS10("row_bcast:31 row_mask:0xc") LSM2D_ROW(10, "row_bcast:31 row_mask:0xc")
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]));
+  else
+    asm volatile("s_nop 1\n\t" LSM2D_ROWS10("row_bcast:15 row_mask:0xa") LSM2D_ROWS10("row_bcast:31 row_mask:0xc")
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
+#undef LSM2D_ROWS10
+#undef LSM2D_ROW
+}
+// a wave's total of a small per-lane count (at most 2^bits - 1): a ballot and a scalar popcount per bit
+LSM2D_DEV int wave_count(int v, int bits) {
+  int n = 0;
+  for (int b = 0; b < bits; ++b) n += __builtin_popcountll(__ballot((v >> b) & 1)) << b;
+  return n;
+}
+
 // all threads call; afterwards `red` (LDS, nwaves*kAccumWords words) holds per-wave totals.
-LSM2D_DEV void block_reduce_store(const Accum& A, float* red, int tid) {
+// count_bits: bits a thread's pair count can occupy (it accumulates at most ceil(cols / block) pairs); 0: unknown, counts go through the adder tree
+LSM2D_DEV void block_reduce_store(const Accum& A, float* red, int tid, int count_bits = 0) {
   const int lane = tid & 63, wave = tid >> 6;
   float f[11] = {A.h00, A.h01, A.h02, A.h11, A.h12, A.h22, A.b0, A.b1, A.b2, A.chi_in, A.chi_out};
-#pragma unroll
-  for (int k = 0; k < 11; ++k) {
-    const float s = wave_sum63(f[k]);
-    if (lane == 63) red[wave * kAccumWords + k] = s;
-  }
-  const int i0 = wave_sum63_i(A.n_in), i1 = wave_sum63_i(A.n_out), i2 = wave_sum63_i(A.n_corr);
+  wave_tree63<11>(f);
+  int i0, i1, i2;
+  if (count_bits > 0) { i0 = wave_count(A.n_in, count_bits); i2 = wave_count(A.n_corr, count_bits); i1 = i2 - i0; }      // n_out == n_corr - n_in in every lane
+  else { i0 = wave_sum63_i(A.n_in); i1 = wave_sum63_i(A.n_out); i2 = wave_sum63_i(A.n_corr); }
   if (lane == 63) {
-    red[wave * kAccumWords + 11] = __int_as_float(i0);
-    red[wave * kAccumWords + 12] = __int_as_float(i1);
-    red[wave * kAccumWords + 13] = __int_as_float(i2);
+    float* r = red + wave * kAccumWords;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) r[k] = f[k];
+    r[11] = __int_as_float(i0); r[12] = __int_as_float(i1); r[13] = __int_as_float(i2);
   }
 }
 // one thread: sum the per-wave totals in wave order

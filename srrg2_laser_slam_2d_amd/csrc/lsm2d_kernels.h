@@ -1051,7 +1051,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         else query_loop(std::integral_constant<int, 1>{});
       }
       LSM2D_PH(0);
-      block_reduce_store(acc, red, tid);
+      // (a projective slice's thread accumulates at most ceil(cols / block) pairs: its counts are a few bits, summed by ballots)
+      block_reduce_store(acc, red, tid, (kHasProj && !kHasNN && !kHasDist && !kHasKd) ? 32 - __builtin_clz(((S.proj.cols + kAlignBlock - 1) / kAlignBlock) | 1) : 0);
       __syncthreads();
       if (tid < 64) {
         // lanes 0..13 of wave 0 each add one quantity over the waves (wave order) and then into the iteration's sum themselves
@@ -1196,28 +1197,6 @@ static constexpr int kPairBlock = 2 * kAlignBlock;
 static constexpr int kPairMovCap = 2 * kAlignBlock;     // moving points per slice kept on chip
 static constexpr int kPairRedStride = 16;               // words per (slice, wave) record: 11 sums, n_in, n_out, n_corr (exact floats), 2 spare = one 64-byte row
 
-template <int N> LSM2D_DEV void wave_tree63(float (&f)[11]) {      // wave_sum63's tree for N values at once, level by level
-#define LSM2D_LVL(ctrl, rmask) _Pragma("unroll") for (int k = 0; k < N; ++k) f[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f[k]), ctrl, rmask, 0xF, false));
-  LSM2D_LVL(0x111, 0xF) LSM2D_LVL(0x112, 0xF) LSM2D_LVL(0x114, 0xF) LSM2D_LVL(0x118, 0xF)
-#undef LSM2D_LVL
-  // the two levels across rows as ONE instruction per value: v_add with a DPP operand and a row mask leaves the masked-out rows' registers as they
-  // are (the builtin's form -- zero into those rows, then add -- costs a v_mov_dpp and a v_add each).  Same sums: rows 1 and 3 add lane 15
-  // of the row below, then rows 2 and 3 add lane 31.  (s_nop: a DPP operand written by the VALU instruction right before needs two wait
-  // states; inside the block ten other instructions stand between a value's two levels.)
-  static_assert(N == 10 || N == 11, "one block of ten or eleven values");
-#define LSM2D_ROW(k, what) "v_add_f32_dpp %" #k ", %" #k ", %" #k " " what "\n\t"
-#define LSM2D_ROWS10(what) LSM2D_ROW(0, what) LSM2D_ROW(1, what) LSM2D_ROW(2, what) LSM2D_ROW(3, what) LSM2D_ROW(4, what) LSM2D_ROW(5, what) \
-                           LSM2D_ROW(6, what) LSM2D_ROW(7, what) LSM2D_ROW(8, what) LSM2D_ROW(9, what)
-  if constexpr (N == 11)
-    asm volatile("s_nop 1\n\t" LSM2D_ROWS10("row_bcast:15 row_mask:0xa") LSM2D_ROW(10, "row_bcast:15 row_mask:0xa")
-                 LSM2D_ROWS10("row_bcast:31 row_mask:0xc") LSM2D_ROW(10, "row_bcast:31 row_mask:0xc")
-                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]));
-  else
-    asm volatile("s_nop 1\n\t" LSM2D_ROWS10("row_bcast:15 row_mask:0xa") LSM2D_ROWS10("row_bcast:31 row_mask:0xc")
-                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
-#undef LSM2D_ROWS10
-#undef LSM2D_ROW
-}
 // all threads of a slice call; afterwards red[wave][0..13] holds the wave's totals.  count_bits: bits a thread's counts can occupy
 // (a thread accumulates at most ceil(cols / 512) pairs).  A slice without robustifier has chi_out == +0 and n_in == n_corr in
 // every lane: nothing to add up.
