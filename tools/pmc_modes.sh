@@ -1,7 +1,8 @@
 #!/bin/bash
 # Counters for the OTHER bench.py modes (finders / roles / map sizes): three rocprofv3 --pmc passes each (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU),
 # merged into profiles/counters.json under the mode's own key, so that every line of tools/bench_modes.sh carries a measured roofline.
-# usage on the GPU box, AFTER tools/profile_round.sh <tag> (which writes the headline's entry): bash tools/pmc_modes.sh <tag>
+# usage on the GPU box, AFTER tools/profile_round.sh <tag> (which writes the headline's entry) and in the SAME gpurun call -- or with that call's
+# profiles/counters.json copied into the tree first (a file stamped with another source hash is started afresh): bash tools/pmc_modes.sh <tag>
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; tag=${1:-round}; O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 mode() {      # name, write_counters flags, bench flags
