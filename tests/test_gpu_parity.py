@@ -2590,3 +2590,72 @@ def test_point_query_finders_against_the_reference_arithmetic_mode(ctx, po):
         assert worst[0] < POSE_TOL_M and worst[1] < POSE_TOL_RAD, (name, worst)
         report.append("%s: max pose delta %.1e m / %.1e rad, pairs differing at x0 %.3f %% (mean)" % (name, worst[0], worst[1], 100 * float(np.mean(differing))))
     print("HIP vs reference arithmetic, point-query finders, role B, 100k map: " + "; ".join(report))
+
+
+@pytest.mark.gpu
+def test_latency_kernel_every_cloud_placement_equals_the_fused_kernel(ctx, po):
+    """k_align_pair keeps a moving cloud of <= 1024 points and a fixed cloud of <= 4096 points per slice in LDS rows and has a walk of its
+    own when both are there; each of the four combinations (and the sizes around the limits: 512 / 513 / 1024 / 1025 moving points, one
+    and two slices, Cauchy, prior, a canvas with three columns per thread) must give k_align's bits -- poses, information matrices,
+    statuses, iteration counts and per-iteration statistics -- and the oracle's in the device's order."""
+    world = synth.make_world(11)
+    robot = synth.sample_poses(world, 1, seed=31)
+    big = synth.make_map(world, 20000, noise_sigma=0.003, seed=4)
+
+    def in_robot_frame(cloud, pose):          # world cloud -> the frame of `pose` (fp64 arithmetic, rounded once: just another input)
+        T = np.linalg.inv(synth.v2t(pose)); R = T[:2, :2]
+        out = np.empty_like(cloud)
+        out[:, :2] = (cloud[:, :2].astype(np.float64) @ R.T + T[:2, 2]).astype(np.float32)
+        out[:, 2:] = (cloud[:, 2:].astype(np.float64) @ R.T).astype(np.float32)
+        return np.ascontiguousarray(out)
+
+    def scan(n_beams, seed, dpose=(0.0, 0.0, 0.0)):
+        p = synth.compose_poses(robot, np.array([dpose]))
+        pts, _ = synth.make_scans(world, p, n_beams=n_beams, noise_sigma=0.004, seed=seed)
+        return pts
+
+    big_local = in_robot_frame(big, robot[0])
+    cases = []
+    for n_mov in (300, 512, 513, 1024, 1025):                                      # moving on chip up to 1024, one or two points per thread
+        mv = scan(1400, 7)[:n_mov]
+        assert len(mv) == n_mov
+        cases.append(("moving %d / fixed scan" % n_mov, [scan(900, 3)], [mv], 1))
+    cases.append(("moving scan / fixed 20000 (no room in LDS)", [big_local], [scan(700, 5)], 1))
+    cases.append(("moving 20000 / fixed scan", [scan(1000, 9)], [big_local], 1))
+    cases.append(("moving 20000 / fixed 20000", [big_local], [big_local[::-1].copy()], 1))
+    cases.append(("two slices: on chip + moving in memory", [scan(800, 13), scan(600, 14)], [scan(700, 15), big_local], 2))
+    cases.append(("two slices, both on chip", [scan(721, 16), scan(500, 17)], [scan(640, 18), scan(900, 19)], 2))
+    checked = 0
+    for name, fixed, moving, ns in cases:
+        for cols, use_prior in ((721, True), (1300, False)):
+            al = api.MultiAligner2D(ctx, max_iterations=7, min_num_inliers=5)
+            oslices = []
+            for s in range(ns):
+                proj = api.PointNormal2fProjectorPolar(cols + 60 * s, -math.pi, math.pi, 0.3, 25.0)
+                f = api.CorrespondenceFinderProjective2f(ctx, proj, 0.6, 0.7)
+                rob = api.RobustifierCauchy(0.02) if s == 0 else None
+                S = np.float32([0.1, -0.05, 0.2]) if s == 1 else np.zeros(3, np.float32)
+                sl = (api.AlignerSliceProcessorLaser2DWithSensor(f, sensor_in_robot=S, robustifier=rob, min_num_correspondences=3) if S.any()
+                      else api.AlignerSliceProcessorLaser2D(f, robustifier=rob, min_num_correspondences=3))
+                al.param_slice_processors.append(sl); oslices.append(_oracle_slice(po, sl.slice_params()))
+            x0 = np.float32([[0.03, -0.02, 0.01]])
+            pri = [(x0[0].copy(), np.diag([40.0, 30.0, 20.0]).astype(np.float32))] if use_prior else None
+            fs = [api.CloudSet(ctx, c) for c in fixed]; ms = [api.CloudSet(ctx, c) for c in moving]
+            res = {}
+            for path in (1, 3):
+                ctx.set_option("align_path", path)
+                try:
+                    res[path] = al.compute_batch(fs, ms, x0, priors=pri, want_stats=True)
+                    assert ctx.get_option("last_align_path") == path
+                finally:
+                    ctx.set_option("align_path", 0)
+            a, c = res[1], res[3]
+            assert np.array_equal(a.pose, c.pose) and np.array_equal(a.information, c.information) and np.array_equal(a.status, c.status) and \
+                np.array_equal(a.iterations, c.iterations), (name, cols)
+            assert np.array_equal(a.stats[0][: a.iterations[0]], c.stats[0][: c.iterations[0]]), (name, cols, "statistics")
+            assert a.stats[0]["n_correspondences"][0] > 20, (name, cols, "the case must form pairs")
+            kw = dict(prior_z=pri[0][0], prior_omega=pri[0][1]) if use_prior else {}
+            rt = po.align(po.aligner_params(7, min_num_inliers=5, device_order=True, **kw), oslices, fixed, moving, x0[0])
+            _assert_bitwise_equal_to_device_order_oracle(c, 0, rt, (name, cols))
+            checked += 1
+    print("latency kernel: %d placements x canvases equal to k_align and to the device-order oracle bit for bit" % checked)
