@@ -56,6 +56,7 @@ struct lsm2d_context {
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
   long long last_clock_khz = 0;       // in-kernel clock of the most recent timed k_align launch (median over the stamped workgroups), 0 = none
   long long last_wg_lifetime_ns = 0;  // median lifetime of its stamped workgroups
+  int last_query_cull = 0;     // the latest aligner call ran its point-query finder with the exact culling of the queries (k_align, tiles of 64 moving points)
   long long last_kd_levels = 0, last_kd_nodes = 0;      // shape of the most recently built KD-tree set (levels of the deepest tree, nodes in all of them)
   std::vector<lsm2d_cloudset*> live_sets;      // lsm2d_destroy orphans what is left (a set destroyed after its context must not touch it)
 };
@@ -115,6 +116,7 @@ struct lsm2d_cloudset {
   // lane-chunked copy of xy for k_align's streaming pass (built on first use, dropped when the contents change)
   mutable float4* d_lane_xy = nullptr; mutable long long* d_lane_start = nullptr; mutable int32_t* d_lane_T = nullptr;
   mutable float4* d_lane_bounds = nullptr;      // bounding circle of every thread's chunk of every cloud (k_lane_bounds): what the culling tests
+  mutable float4* d_tile_bounds = nullptr; mutable int32_t* d_tile_start = nullptr;      // bounding circles of the tiles of 64 points (k_tile_bounds): the point-query finders' culling
   int32_t n_clouds = 0;
   mutable int64_t total = 0;  // logical points
   int64_t padded_total = 0;   // device points incl. even-alignment padding
@@ -273,6 +275,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "last_query_cull")) { *out_value = ctx->last_query_cull; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kd_levels")) { *out_value = ctx->last_kd_levels; return LSM2D_SUCCESS; }
   if (!strcmp(key, "max_dyn_lds")) { *out_value = ctx->max_dyn_lds; return LSM2D_SUCCESS; }      // bytes of LDS one workgroup may ask for
   if (!strcmp(key, "last_kd_nodes")) { *out_value = ctx->last_kd_nodes; return LSM2D_SUCCESS; }
@@ -423,6 +426,8 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_lane_start) (void) hipFree(cs->d_lane_start);
   if (cs->d_lane_T) (void) hipFree(cs->d_lane_T);
   if (cs->d_lane_bounds) (void) hipFree(cs->d_lane_bounds);
+  if (cs->d_tile_bounds) (void) hipFree(cs->d_tile_bounds);
+  if (cs->d_tile_start) (void) hipFree(cs->d_tile_start);
   if (cs->ctx && cs->staged_epoch == cs->ctx->sync_epoch) (void) stream_sync(cs->ctx);      // a staged transfer may still be reading h_upload
   if (cs->h_upload) (void) hipHostFree(cs->h_upload);
   if (cs->ctx) { auto& v = cs->ctx->live_sets; for (size_t i = 0; i < v.size(); ++i) if (v[i] == cs) { v[i] = v.back(); v.pop_back(); break; } }
@@ -506,6 +511,8 @@ static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents 
   if (cs->d_lane_start) { (void) hipFree(cs->d_lane_start); cs->d_lane_start = nullptr; }
   if (cs->d_lane_T) { (void) hipFree(cs->d_lane_T); cs->d_lane_T = nullptr; }
   if (cs->d_lane_bounds) { (void) hipFree(cs->d_lane_bounds); cs->d_lane_bounds = nullptr; }
+  if (cs->d_tile_bounds) { (void) hipFree(cs->d_tile_bounds); cs->d_tile_bounds = nullptr; }
+  if (cs->d_tile_start) { (void) hipFree(cs->d_tile_start); cs->d_tile_start = nullptr; }
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   cs->dists.clear();
   for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block);
@@ -643,6 +650,7 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
   c.lane_xy = cs->d_lane_xy; c.lane_start = cs->d_lane_start; c.lane_T = cs->d_lane_T; c.lane_bounds = cs->d_lane_bounds;
+  c.tile_bounds = cs->d_tile_bounds; c.tile_start = cs->d_tile_start;
   c.grid = GridDev{nullptr, nullptr, nullptr, nullptr};
   c.dist = DistDev{nullptr, nullptr};
   c.kd = KdDev{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -797,6 +805,8 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   return LSM2D_SUCCESS;
 }
 
+static CloudDev cloud_dev_with_tiles(CloudDev c, const lsm2d_cloudset* cs) { c.tile_bounds = cs->d_tile_bounds; c.tile_start = cs->d_tile_start; return c; }
+
 // lane-chunked copy of every cloud for k_align's projective streaming pass (project_cloud_lanes in lsm2d_device.h)
 static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
   if (cs->d_lane_xy || cs->count_pending) return LSM2D_SUCCESS;     // a size-pending set is a clipped scene: small, and building needs a sync
@@ -834,6 +844,31 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, stream_sync(ctx));        // the host vectors above back the async copies
+  return LSM2D_SUCCESS;
+}
+
+// bounding circles of every cloud's tiles of 64 consecutive points: what k_align's point-query branch tests before it runs a tile's queries
+static int ensure_tile_bounds(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
+  if (cs->d_tile_bounds || cs->count_pending) return LSM2D_SUCCESS;
+  const int nc = cs->n_clouds;
+  std::vector<int32_t> tstart((size_t) nc);
+  long long tiles = 0; int max_tiles = 1;
+  for (int c = 0; c < nc; ++c) {
+    const int t = (cs->h_count[c] + 63) / 64;
+    tstart[c] = (int32_t) tiles; tiles += t; if (t > max_tiles) max_tiles = t;
+    if (tiles > 0x7fffffff) return LSM2D_SUCCESS;          // (no culling for such a set)
+  }
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_tile_bounds, sizeof(float4) * (size_t) (tiles > 0 ? tiles : 1)));
+  HIPCHK(ctx, hipMalloc((void**) &cs->d_tile_start, sizeof(int32_t) * (size_t) nc));
+  HIPCHK(ctx, hipMemcpyAsync(cs->d_tile_start, tstart.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  int gx = (max_tiles + 3) / 4; if (gx > 4096) gx = 4096; if (gx < 1) gx = 1;
+  for (int c0 = 0; c0 < nc; c0 += 32768) {
+    const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
+    hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned) gx, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy, (const int32_t*) cs->d_start,
+                       (const int32_t*) cs->d_count, (const int32_t*) cs->d_tile_start, cs->d_tile_bounds, c0);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, stream_sync(ctx));        // the host vector above backs the async copy
   return LSM2D_SUCCESS;
 }
 
@@ -1577,27 +1612,46 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   // one NN slice whose fixed clouds are scan-sized (one lane per query): stage each cloud's search tables in LDS.  Budget 38 KB
   // per workgroup keeps four workgroups on a CU; bigger clouds / grids search in global memory as before.  (Measured on configs[1]
   // role A: 3 sqrt(n) cells per side in 38 KB 9.6 ms; 4 sqrt(n) in 50 KB -- three workgroups per CU -- 12.2; 2 sqrt(n) 12.3.)
+  // one NN, KD-tree or distance-map slice in the tracker's wiring (scan-sized fixed clouds, a big moving cloud): exact culling of the queries (k_align,
+  // "point-query finders"): an occupancy bitmap of the fixed cloud (2 KB) and one keep bit per tile of 64 moving points, out of the same budget
+  A.pq_cull_off = 0; A.pq_keep_words = 0;
+  size_t pq_bytes = 0;
+  if (ns == 1 && ctx->cull && (b->slices[0].finder == LSM2D_FINDER_NN || b->slices[0].finder == LSM2D_FINDER_KDTREE || b->slices[0].finder == LSM2D_FINDER_DISTMAP) &&
+      !b->moving[0]->count_pending) {
+    const lsm2d_cloudset* f = b->fixed[0]; const lsm2d_cloudset* m = b->moving[0];
+    int mf = 0, mm = 0;
+    for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > mf) mf = f->h_count[c];
+    for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] > mm) mm = m->h_count[c];
+    const int keep_words = (((mm + 63) / 64 + kAlignBlock - 1) / kAlignBlock) * (kAlignBlock / 64);
+    if (mf <= 16384 && mm >= 4096 && mm > 2 * mf && keep_words <= 512) {
+      const int trc = ensure_tile_bounds(ctx, m); if (trc) return trc;
+      if (m->d_tile_bounds) { A.pq_keep_words = keep_words; pq_bytes = 128 * 5 * 4 + sizeof(u64) * (size_t) keep_words + 16; A.s[0].moving = cloud_dev_with_tiles(A.s[0].moving, m); }
+    }
+  }
+  const size_t lds_budget = 38 * 1024 - pq_bytes;
   A.nn_lds_points = 0; A.nn_lds_cells = 0;
   if (ns == 1 && b->slices[0].finder == LSM2D_FINDER_NN && A.s[0].nn_group == 1) {
     const lsm2d_cloudset* f = b->fixed[0];
     int mf = 0; for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > mf) mf = f->h_count[c];
     int cap = (int) ceil((mf >= 16384 ? 6.0 : 3.0) * sqrt((double) (mf > 0 ? mf : 1))); cap = cap < 16 ? 16 : cap;      // ensure_grid's rule
     const size_t need = sizeof(float2) * (size_t) mf + sizeof(uint16_t) * ((size_t) cap * cap + 4) + sizeof(uint16_t) * ((size_t) mf + 2);
-    if (mf > 0 && mf <= 65535 && need <= 38 * 1024 - lds) { A.nn_lds_points = mf; A.nn_lds_cells = cap * cap + 1; lds += need + 16; }
+    if (mf > 0 && mf <= 65535 && lds + need <= lds_budget) { A.nn_lds_points = mf; A.nn_lds_cells = cap * cap + 1; lds += need + 16; }
   }
   // one KD-tree slice: the top of the fixed cloud's tree (up to "kd_lds_nodes" nodes, 24 bytes each) rides in LDS -- same 38 KB budget
   A.kd_lds_nodes = 0; A.kd_lds_points = 0;
   if (ns == 1 && b->slices[0].finder == LSM2D_FINDER_KDTREE && kd_cache0 && ctx->kd_lds_nodes > 0) {
     int k = kd_cache0->max_nodes_per_cloud < ctx->kd_lds_nodes ? kd_cache0->max_nodes_per_cloud : ctx->kd_lds_nodes;
-    const size_t room = lds < 38 * 1024 ? (38 * 1024 - lds) / (sizeof(float4) + sizeof(int2)) : 0;
+    const size_t room = lds < lds_budget ? (lds_budget - lds) / (sizeof(float4) + sizeof(int2)) : 0;
     if ((size_t) k > room) k = (int) room;
     if (k > 0) { A.kd_lds_nodes = k; lds += (size_t) k * (sizeof(float4) + sizeof(int2)) + 16; }
     // scan-sized fixed clouds whose whole tree fits: the leaf arrays too (coordinates and normals: 16 bytes per point)
     const lsm2d_cloudset* f = b->fixed[0];
     int mf = 0; for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > mf) mf = f->h_count[c];
     const size_t need = (size_t) (mf + 2) * (sizeof(float2) + sizeof(float2)) + 32;
-    if (k > 0 && k == kd_cache0->max_nodes_per_cloud && mf > 0 && mf <= 65535 && lds + need <= 38 * 1024) { A.kd_lds_points = mf; lds += need; }
+    if (k > 0 && k == kd_cache0->max_nodes_per_cloud && mf > 0 && mf <= 65535 && lds + need <= lds_budget) { A.kd_lds_points = mf; lds += need; }
   }
+  if (pq_bytes) { lds = (lds + 15) & ~(size_t) 15; A.pq_cull_off = (int32_t) lds; lds += pq_bytes; }
+  ctx->last_query_cull = A.pq_cull_off > 0;
   if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
   // one or two projective slices and too few alignments to fill the chip (the live tracker: one alignment per scan): the latency
   // kernel (k_align_pair; bit-identical sums) -- 512 threads per slice, two slices' passes side by side instead of one after the

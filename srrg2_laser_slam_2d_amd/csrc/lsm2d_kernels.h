@@ -134,6 +134,8 @@ struct CloudDev {            // device view of a cloud set
   const long long* lane_start; // [n_clouds] first float4 slot of each cloud in lane_xy
   const int32_t* lane_T;     // [n_clouds] steps per thread
   const float4* lane_bounds; // [n_clouds][kAlignBlock] bounding circle (cx, cy, rho; rho < 0: no points) of the chunk each thread owns, or nullptr
+  const float4* tile_bounds; // bounding circle of every TILE of 64 consecutive points of every cloud (k_tile_bounds), or nullptr: what the point-query
+  const int32_t* tile_start; //   finders' culling tests; [n_clouds] first tile of each cloud
   GridDev grid;              // valid only when the slice uses the NN finder on this (fixed) cloud
   DistDev dist;              // valid only when the slice uses the distance-map finder on this (fixed) cloud
   KdDev kd;                  // valid only when the slice uses the KD-tree finder on this (fixed) cloud
@@ -661,6 +663,8 @@ struct AlignArgs {
   const int32_t* order;                     // alignment handled by workgroup b (nullptr: b itself) -- the balanced placement of k_balance_order
   int32_t cull_block;                       // steps per unit of the culled stream (0: automatic; tuning knob)
   int32_t cull;                             // 1: projective slices drop the chunks of the moving cloud that cannot yield a pair (chunk_may_matter), results unchanged
+  int32_t pq_cull_off;                      // > 0: byte offset in dynamic LDS of the point-query finders' culling state (occupancy bitmap of the fixed cloud, then
+  int32_t pq_keep_words;                    //   pq_keep_words 64-bit words of per-tile keep bits); single-slice NN / KD-tree batches with scan-sized fixed clouds
   int32_t pair_mov_cap;                     // latency kernel: moving points per slice it may keep in LDS (kPairMovCap, or 0: no room)
   int32_t pair_fix_cap;                     // latency kernel: fixed points per slice it may keep in LDS (0: no room)
   const float* init_pose;
@@ -815,6 +819,27 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   if (A.prior && tid >= 64 && tid < 64 + kPriorWords)
     ((float*) &s_prior)[tid - 64] = A.inline_n1 ? ((const float*) &A.prior1)[tid - 64] : ((const float*) (A.prior + a))[tid - 64];
 
+  // ---- point-query finders, tracker wiring (a scan-sized fixed cloud, every point of a big moving cloud a query): EXACT culling of the queries.
+  // A pair needs a fixed point within max_distance of the transformed moving point (the grid search's gate d2 <= md2, the tree's d2 < md2, the
+  // distance map's parent pixel within max_distance of the query's pixel), so a TILE of 64 consecutive moving points -- what one wave handles in
+  // one trip of the query loop -- can be skipped when no fixed point lies within rho + max_distance of its bounding circle's centre
+  // (k_tile_bounds: centre, rho).  The fixed cloud is rasterised ONCE per alignment into a 128 x 128 occupancy bitmap (cell side g: its extent
+  // / 125, at least a sixth of the reach); the test looks at the (2k + 1)^2 cells around the centre's, k = floor(reach / g) + 1: if they are
+  // clear, every fixed point is more than `reach` away.  The queries keep their threads and a skipped query could not have paired: every sum
+  // keeps its bits.  (Measured on configs[1], role A: 49 % of the tiles survive where an exact distance test would keep 32 %.)
+  constexpr int kPqRowWords = 5, kPqOccWords = 128 * kPqRowWords;      // rows of 128 bits and one word that stays zero: a row's window is read as two words
+  __shared__ unsigned s_pqbb[4];      // the fixed cloud's bounding box as order-preserving integers: min x, min y, max x, max y
+  __shared__ float s_pq[4];           // bitmap origin x, y, 1 / g, the reach beyond a tile's own radius (< 0: culling off for this alignment)
+  const bool pq_on = (kHasNN || kHasKd || kHasDist) && A.pq_cull_off > 0;
+  uint32_t* l_occ = reinterpret_cast<uint32_t*>(smem + (pq_on ? A.pq_cull_off : 0));
+  u64* l_keep = reinterpret_cast<u64*>(l_occ + kPqOccWords);
+  auto ordered = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+  auto unordered = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); };
+  if (pq_on) {
+    for (int i = tid; i < kPqOccWords; i += kAlignBlock) l_occ[i] = 0u;
+    if (tid < 4) s_pqbb[tid] = tid < 2 ? 0xFFFFFFFFu : 0u;
+  }
+
   if (kHasProj && !kHasNN && !kHasDist && !kHasKd && A.inline_n1)
     for (int s = 0; s < A.n_slices; ++s) if (A.s[s].unpack_src) unpack_fixed_set(A.s[s], tid, kAlignBlock);      // visible after the barrier below
   // ---- prologue: fixed canvases, camera at identity (correspondence_finder_projective_2d.cpp:37-44)
@@ -877,6 +902,17 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       if (kd_leaves_lds) for (int i = tid; i < nf; i += kAlignBlock) { l_kxy[i] = S.fixed.kd.leaf_xy[fb + i]; l_knr[i] = S.fixed.kd.leaf_nrm[fb + i]; }
     }
   }
+  if (pq_on) {      // bounding box of the fixed cloud (finite points only)
+    const SliceDev& S = A.s[0];
+    const int fc = pick_cloud(S.fixed, a), nf = S.fixed.count[fc];
+    const float2* fp = S.fixed.xy + S.fixed.start[fc];
+    for (int i = tid; i < nf; i += kAlignBlock) {
+      const float2 p = fp[i];
+      if (__builtin_fabsf(p.x) < 1e30f && __builtin_fabsf(p.y) < 1e30f) {
+        atomicMin(&s_pqbb[0], ordered(p.x)); atomicMin(&s_pqbb[1], ordered(p.y)); atomicMax(&s_pqbb[2], ordered(p.x)); atomicMax(&s_pqbb[3], ordered(p.y));
+      }
+    }
+  }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   for (int s = 0; s < A.n_slices; ++s) {
     const SliceDev& S = A.s[s];
@@ -886,6 +922,29 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     project_cloud(S.fixed.xy + S.fixed.start[fc], (A.inline_n1 && S.unpack_src) ? S.unpack_n : S.fixed.count[fc], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
   }
   __syncthreads();
+  if (pq_on) {      // the occupancy bitmap: every thread derives the same cell size and origin from the box, then stamps its points
+    const SliceDev& S = A.s[0];
+    const int fc = pick_cloud(S.fixed, a), nf = S.fixed.count[fc];
+    const float2* fp = S.fixed.xy + S.fixed.start[fc];
+    const unsigned k0 = s_pqbb[0], k1 = s_pqbb[1], k2 = s_pqbb[2], k3 = s_pqbb[3];
+    const float minx = unordered(k0), miny = unordered(k1), maxx = unordered(k2), maxy = unordered(k3);
+    const bool have = k0 <= k2 && k1 <= k3;                           // at least one finite point
+    // a skipped tile's points stay farther than max_distance from every fixed point; the distance map pairs a query with the point of a PIXEL whose
+    // centre is within max_distance of the query's pixel centre: two pixel diagonals more
+    float reach = S.max_distance * 1.002f + 2e-3f;
+    if (kHasDist && S.finder == LSM2D_FINDER_DISTMAP) reach += 3.0f / S.fixed.dist.meta[fc].inv_res;
+    const float ext = __builtin_fmaxf(maxx - minx, maxy - miny);
+    const float g = __builtin_fmaxf((reach + 0.1f) * (1.0f / 6.0f), ext * (1.0f / 125.0f));
+    const float ox = minx - g, oy = miny - g, inv_g = 1.0f / g;
+    const bool usable = have && g > 0.0f && g < 1e30f && S.max_distance >= 0.0f;
+    if (tid == 0) { s_pq[0] = ox; s_pq[1] = oy; s_pq[2] = inv_g; s_pq[3] = usable ? reach : -1.0f; }
+    if (usable) for (int i = tid; i < nf; i += kAlignBlock) {
+      const float2 p = fp[i];
+      if (!(__builtin_fabsf(p.x) < 1e30f && __builtin_fabsf(p.y) < 1e30f)) continue;
+      const int cx = (int) ((p.x - ox) * inv_g), cy = (int) ((p.y - oy) * inv_g);       // 1 .. 126 by construction
+      if ((unsigned) cx < 128u && (unsigned) cy < 128u) atomicOr(&l_occ[cy * kPqRowWords + (cx >> 5)], 1u << (cx & 31));
+    }
+  }
   for (int s = 0; s < A.n_slices; ++s) {      // cache the fixed winners' payload next to their keys
     const SliceDev& S = A.s[s];
     if (!kHasProj || S.finder != LSM2D_FINDER_PROJECTIVE) continue;
@@ -999,12 +1058,57 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         }
         const float md2 = S.max_distance * S.max_distance;
         const int nm_pts = S.moving.count[mc];
+        // cooperative search (kNNGroup lanes per query) when THIS alignment's fixed cloud is at least four times its moving one --
+        // decided per alignment from the device-side counts, so ragged batches get the right loop for each cloud (the oracle's
+        // device-order mode applies the same rule)
+        const bool coop = use_grid && (long long) S.fixed.count[fc] >= 4ll * nm_pts;
+        // this iteration's keep bits, one per tile of 64 moving points (see the prologue): bit t of l_keep <-> tile t
+        const int n_tiles = (nm_pts + 63) >> 6;
+        const bool pq_cull = pq_on && S.moving.tile_bounds && !coop && ((n_tiles + kAlignBlock - 1) / kAlignBlock) * (kAlignBlock / 64) <= A.pq_keep_words;
+        if (pq_cull) {
+          const float4* tb = S.moving.tile_bounds + S.moving.tile_start[mc];
+          const float ox = s_pq[0], oy = s_pq[1], inv_g = s_pq[2], reach = s_pq[3];
+          for (int t0 = 0; t0 < n_tiles; t0 += kAlignBlock) {
+            const int t = t0 + tid; bool keep = false;
+            if (t < n_tiles) {
+              const float4 b = tb[t];
+              keep = true;
+              const float kf = (b.z * 1.002f + reach) * inv_g;      // cells the tile's reach spans (rho = +inf, a tile with a non-finite point: no claim)
+              if (reach >= 0.0f && kf < 10.0f) {
+                float qx, qy; xf_point(T, b.x, b.y, qx, qy);
+                const float fx = __builtin_floorf((qx - ox) * inv_g), fy = __builtin_floorf((qy - oy) * inv_g);
+                if (fx > -64.0f && fx < 192.0f && fy > -64.0f && fy < 192.0f) {
+                  const int k = (int) kf + 1, cx = (int) fx, cy = (int) fy;
+                  const int x0 = cx - k < 0 ? 0 : cx - k, x1 = cx + k > 127 ? 127 : cx + k, y0 = cy - k < 0 ? 0 : cy - k, y1 = cy + k > 127 ? 127 : cy + k;
+                  keep = false;
+                  if (x0 <= x1) {
+                    const u64 mask = (~0ull >> (63 - (x1 - x0))) << (x0 & 31);      // at most 21 bits, from bit x0 of the two-word window
+                    for (int y = y0; y <= y1; ++y) {
+                      const uint32_t* row = l_occ + y * kPqRowWords + (x0 >> 5);
+                      if ((((u64) row[1] << 32) | (u64) row[0]) & mask) { keep = true; break; }
+                    }
+                  }
+                }
+                else keep = !(fx == fx && fy == fy);      // far beyond the bitmap: nothing within reach; not a number: no claim
+              }
+            }
+            const u64 bal = __ballot(keep);
+            if ((tid & 63) == 0) l_keep[(t0 >> 6) + (tid >> 6)] = bal;
+          }
+          __syncthreads();
+        }
         // the grid search is cooperative on dense fixed clouds (kNNGroup lanes per query); the distance map is one lookup
         auto query_loop = [&](auto group_tag) {
           constexpr int group = decltype(group_tag)::value;
           const int sub = tid & (group - 1);
           constexpr int per_step = kAlignBlock / group;
           for (int j0 = 0; j0 < nm_pts; j0 += per_step) {
+            if (group == 1 && pq_cull) {             // this wave's 64 queries of the trip are one tile
+              const int tile = (j0 >> 6) + __builtin_amdgcn_readfirstlane(tid >> 6);
+              const u64 w = l_keep[tile >> 6];
+              const unsigned half = (tile & 32) ? (unsigned) (w >> 32) : (unsigned) w;
+              if (!((__builtin_amdgcn_readfirstlane((int) half) >> (tile & 31)) & 1)) continue;
+            }
             const int j = j0 + tid / group;
             const bool live = j < nm_pts;                    // whole groups are live or not: the shuffles inside stay uniform
             const float2 pm = live ? mp[j] : make_float2(0.0f, 0.0f);
@@ -1035,12 +1139,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
             }
           }
         };
-        // cooperative search (kNNGroup lanes per query) when THIS alignment's fixed cloud is at least four times its moving one --
-        // decided per alignment from the device-side counts, so ragged batches get the right loop for each cloud (the oracle's
-        // device-order mode applies the same rule)
         // (the cooperative search on a scan-sized fixed cloud with its tables in LDS: 2 / 4 / 8 lanes per query take 21 / 41 / 90 ms against
         // 8.1 ms with one lane per query -- the time goes with the number of wave-queries, i.e. into the fixed cost of a query, not its candidates)
-        const bool coop = use_grid && (long long) S.fixed.count[fc] >= 4ll * nm_pts;
         // (several queries of a thread in flight together -- all points, then all pixels, then all parents -- measured with the registers
         // for it: 4 waves per SIMD and 3-4 trips tie with this loop at 8 waves per SIMD on role B and lose 10-50 % elsewhere; at 8 waves per SIMD
         // with only the parents' indices kept live, 2 / 3 trips take 0.29 / 0.38 ms against 0.21 on role B and lose on role A too; DESIGN App. A)
@@ -2448,6 +2548,30 @@ __global__ __launch_bounds__(256) void k_lane_bounds(const float2* __restrict__ 
     r = make_float4(cx, cy, (cx == cx && cy == cy) ? rho : __builtin_huge_valf(), 0.0f);
   }
   if (lane == 0) out[(size_t) c * nthreads + g] = r;
+}
+
+// bounding circle of every tile of 64 consecutive points (the point-query finders' culling, k_align): one wave per tile
+__global__ __launch_bounds__(256) void k_tile_bounds(const float2* __restrict__ xy, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
+                                                     const int32_t* __restrict__ tile_start, float4* __restrict__ out, int cloud0) {
+  const int c = cloud0 + blockIdx.y, lane = threadIdx.x & 63;
+  const int n = count[c], n_tiles = (n + 63) >> 6;
+  const float2* p = xy + start[c];
+  for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n_tiles; t += gridDim.x * 4) {
+    const int i = t * 64 + lane; const bool in = i < n;
+    const float2 v = in ? p[i] : make_float2(0.0f, 0.0f);
+    float mnx = in ? v.x : 3.402823466e+38f, mny = in ? v.y : 3.402823466e+38f, mxx = in ? v.x : -3.402823466e+38f, mxy = in ? v.y : -3.402823466e+38f;
+    for (int o = 32; o > 0; o >>= 1) {
+      mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+      mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+    }
+    const float cx = 0.5f * (mnx + mxx), cy = 0.5f * (mny + mxy);
+    const float dx = v.x - cx, dy = v.y - cy;
+    float d2 = in ? dx * dx + dy * dy : 0.0f;
+    bool bad = in && !(d2 == d2);                 // a non-finite point must not poison the circle: its tile is never skipped (rho = +inf)
+    for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o, 64));
+    bad = __ballot(bad) != 0ull || !(cx == cx && cy == cy);
+    if (lane == 0) out[(size_t) tile_start[c] + t] = make_float4(cx, cy, bad ? __builtin_huge_valf() : __builtin_sqrtf(d2) * 1.00001f + 1e-6f, 0.0f);
+  }
 }
 
 // ---- refill of a small single-cloud set straight from its pinned staging buffer (lsm2d_cloudset_upload): the kernel reads the

@@ -2559,6 +2559,30 @@ def test_culling_and_placement_change_no_bit(ctx, po):
         rt = po.align(po.aligner_params(10, device_order=True), [po.slice_params(), po.slice_params(canvas_cols=721, point_distance=0.3, normal_cos=0.9)],
                       [sc, sc], [wl.map_points, wl.map_points], wl.x0[i])
         _assert_bitwise_equal_to_device_order_oracle(got, i, rt, ("two slices culled", i))
+    # point-query finders in the tracker's wiring (a tree / grid per scan, every map point a query): tiles of 64 map points with no scan point
+    # within reach are skipped -- the same bits with and without, ordered and shuffled map, a map with non-finite points, a far-off start pose
+    broken = wl.map_points.copy(); broken[5000, 0] = np.nan; broken[20000:20003, 1] = np.inf
+    far = wl.x0.copy(); far[::7, 0] += 300.0
+    for finder in (api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=0.8, search="exact"),
+                   api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.25, normal_cos=0.8, search="kdtree"),
+                   api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.002, normal_cos=0.8, search="exact")):
+        al = api.MultiAligner2D(ctx, max_iterations=6, min_num_inliers=10)
+        al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10, robustifier=api.RobustifierCauchy(0.05)))
+        for name, mp, x0 in (("ordered", wl.map_points, wl.x0), ("shuffled", shuffled, wl.x0), ("non-finite", broken, wl.x0), ("far", wl.map_points, far)):
+            moving = api.CloudSet(ctx, mp)
+            res = {}
+            for cull in (0, 1):
+                ctx.set_option("cull", cull)
+                try:
+                    res[cull] = al.compute_batch([fixed], [moving], x0, want_stats=True)
+                    assert ctx.get_option("last_query_cull") == cull
+                finally:
+                    ctx.set_option("cull", 1)
+            a, c = res[0], res[1]
+            assert np.array_equal(a.pose, c.pose, equal_nan=True) and np.array_equal(a.information, c.information, equal_nan=True), (finder.search, name)
+            assert np.array_equal(a.status, c.status) and np.array_equal(a.iterations, c.iterations) and np.array_equal(a.stats, c.stats), (finder.search, name)
+            if name == "ordered" and finder.param_max_distance_m > 0.1:
+                assert (a.status == 0).mean() > 0.9, (finder.search, (a.status == 0).mean())
 
 
 def test_point_query_finders_against_the_reference_arithmetic_mode(ctx, po):
