@@ -217,6 +217,18 @@ def main() -> None:
     # with the collection between warm-up and timing, 20 timed steps ran entirely on the low clock.
     import gc
     gc.collect(); gc.freeze()
+    # N > 1: the ranks line up BEFORE the clock ramp, and the collectives the timed region is bracketed by run once here.  Measured on one
+    # rank with the RCCL path forced (LSM2D_BENCH_FORCE_DIST=1, --steps 20): without this the barrier in front of the timed region was the
+    # first of its kind -- it loaded RCCL's kernels while the GPU sat idle, the chip dropped its clock and the 20 timed steps ran 8 % slow
+    # (1.092 vs 0.996 ms per step, kernel 0.985 vs 0.913 ms); and ranks that start their ramp at different times reach that barrier at
+    # different times, the early ones idling there just as long.
+    if use_dist:
+        step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        warm = torch.zeros(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(warm, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
     # clock ramp, untimed: the same step for --spinup-s seconds (the count is printed as `spinup_steps`), then the W warm-up steps
     spinup_steps = 0
     t_spin = time.perf_counter()
