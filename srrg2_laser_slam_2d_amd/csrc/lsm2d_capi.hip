@@ -49,6 +49,7 @@ struct lsm2d_context {
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
   int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / k_balance_order); 0: workgroup b = alignment b
   int n_cu = 0;                // compute units of the device (hipDeviceProp_t.multiProcessorCount)
+  int nn_qcache = 1;           // grid NN over a map-sized fixed cloud: cache every query's cell ranges in LDS between iterations (0: off; A/B knob)
   int cull_block = 0;          // steps per unit of the culled stream (0: automatic, ~1/25 of a chunk; even; tuning knob)
   int cull = 1;                // k_align, projective slices: exact culling of the moving cloud against the fixed canvas (0: off; results do not depend on it)
   int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
@@ -93,7 +94,7 @@ struct GridCache {     // one search grid per (cloud set, max_distance), built o
   float max_distance = 0.0f;
   void* d_block = nullptr;      // ONE allocation (hipMalloc costs ~0.1 ms a call); the pointers below are views into it
   GridMeta* d_meta = nullptr; int32_t* d_cell_start = nullptr; int32_t* d_cursor = nullptr;
-  int32_t* d_sorted_idx = nullptr; float2* d_sorted_xy = nullptr;
+  int32_t* d_sorted_idx = nullptr; float2* d_sorted_xy = nullptr; float2* d_sorted_nrm = nullptr;
 };
 
 struct DistCache {     // one distance map per (cloud set, max_distance, resolution)
@@ -259,6 +260,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull must be 0, 1 or 2"); ctx->cull = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "nn_qcache")) { ctx->nn_qcache = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
@@ -272,6 +274,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "distmap_build")) { *out_value = ctx->distmap_build; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull")) { *out_value = ctx->cull; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { *out_value = ctx->cull_block; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "nn_qcache")) { *out_value = ctx->nn_qcache; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
@@ -651,7 +654,7 @@ static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
   c.lane_xy = cs->d_lane_xy; c.lane_start = cs->d_lane_start; c.lane_T = cs->d_lane_T; c.lane_bounds = cs->d_lane_bounds;
   c.tile_bounds = cs->d_tile_bounds; c.tile_start = cs->d_tile_start;
-  c.grid = GridDev{nullptr, nullptr, nullptr, nullptr};
+  c.grid = GridDev{nullptr, nullptr, nullptr, nullptr, nullptr};
   c.dist = DistDev{nullptr, nullptr};
   c.kd = KdDev{nullptr, nullptr, nullptr, nullptr, nullptr};
   return c;
@@ -660,7 +663,7 @@ static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
 // CorrespondenceFinderKDTree2D::reset() (registration/correspondence_finder_kd_tree_2d.cpp:31-38).
 static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_distance, GridDev* out) {
   for (const auto& g : cs->grids)
-    if (g.max_distance == max_distance) { *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy}; return LSM2D_SUCCESS; }
+    if (g.max_distance == max_distance) { *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy, g.d_sorted_nrm}; return LSM2D_SUCCESS; }
   const int nc = cs->n_clouds;
   std::vector<int32_t> cell_base(nc), gcap(nc);
   int64_t cells = 0;
@@ -678,19 +681,19 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
   const size_t o_meta = take(sizeof(GridMeta) * (size_t) nc), o_start = take(sizeof(int32_t) * (size_t) cells), o_cursor = take(sizeof(int32_t) * (size_t) cells);
-  const size_t o_sidx = take(sizeof(int32_t) * (size_t) cs->padded_total), o_sxy = take(sizeof(float2) * (size_t) cs->padded_total);
+  const size_t o_sidx = take(sizeof(int32_t) * (size_t) cs->padded_total), o_sxy = take(sizeof(float2) * (size_t) cs->padded_total), o_snr = take(sizeof(float2) * (size_t) cs->padded_total);
   const size_t o_base = take(sizeof(int32_t) * (size_t) nc), o_gcap = take(sizeof(int32_t) * (size_t) nc), o_tiles = take(sizeof(int32_t) * 2048);
   HIPCHK(ctx, hipMalloc(&t_block.p, off));
   char* blk = (char*) t_block.p;
   g.d_meta = (GridMeta*) (blk + o_meta); g.d_cell_start = (int32_t*) (blk + o_start); g.d_cursor = (int32_t*) (blk + o_cursor);
-  g.d_sorted_idx = (int32_t*) (blk + o_sidx); g.d_sorted_xy = (float2*) (blk + o_sxy);
+  g.d_sorted_idx = (int32_t*) (blk + o_sidx); g.d_sorted_xy = (float2*) (blk + o_sxy); g.d_sorted_nrm = (float2*) (blk + o_snr);
   int32_t* d_base = (int32_t*) (blk + o_base); int32_t* d_gcap = (int32_t*) (blk + o_gcap); int32_t* d_tiles = (int32_t*) (blk + o_tiles);
   HIPCHK(ctx, hipMemcpyAsync(d_base, cell_base.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_gcap, gcap.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   GridBuildArgs A;
   A.xy = cs->d_xy; A.start = cs->d_start; A.count = cs->d_count; A.n_clouds = nc; A.h_min = max_distance * 0.015625f;
   A.cell_base = d_base; A.gcap = d_gcap; A.meta = g.d_meta; A.cell_start = g.d_cell_start; A.cursor = g.d_cursor;
-  A.sorted_idx = g.d_sorted_idx; A.sorted_xy = g.d_sorted_xy;
+  A.sorted_idx = g.d_sorted_idx; A.sorted_xy = g.d_sorted_xy; A.nrm = cs->d_nrm; A.sorted_nrm = g.d_sorted_nrm;
   A.big_threshold = ctx->grid_big_threshold;
   hipLaunchKernelGGL(k_grid_build, dim3((unsigned) nc), dim3(1024), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
@@ -702,7 +705,7 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
     HIPCHK(ctx, hipMemsetAsync(g.d_cursor + cell_base[c], 0, sizeof(int32_t) * (size_t) cells_max, ctx->stream));
     GridBigArgs B;
     B.xy = cs->d_xy; B.start = cs->d_start; B.count = cs->d_count; B.cloud = c; B.meta = g.d_meta; B.cell_start = g.d_cell_start; B.cursor = g.d_cursor;
-    B.tile_sums = d_tiles; B.sorted_idx = g.d_sorted_idx; B.sorted_xy = g.d_sorted_xy;
+    B.tile_sums = d_tiles; B.sorted_idx = g.d_sorted_idx; B.sorted_xy = g.d_sorted_xy; B.nrm = cs->d_nrm; B.sorted_nrm = g.d_sorted_nrm;
     int pb = (cs->h_count[c] + 1023) / 1024; pb = pb < 1 ? 1 : (pb > 2048 ? 2048 : pb);
     hipLaunchKernelGGL(k_grid_big_hist, dim3((unsigned) pb), dim3(256), 0, ctx->stream, B);
     hipLaunchKernelGGL(k_grid_big_scan<0>, dim3((unsigned) n_tiles), dim3(1024), 0, ctx->stream, B);
@@ -714,7 +717,7 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
   HIPCHK(ctx, stream_sync(ctx));      // host vectors above must outlive the copies
   g.d_block = t_block.release();      // owned by the cache from here on
   cs->grids.push_back(g);
-  *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy};
+  *out = GridDev{g.d_meta, g.d_cell_start, g.d_sorted_idx, g.d_sorted_xy, g.d_sorted_nrm};
   return LSM2D_SUCCESS;
 }
 
@@ -1637,6 +1640,15 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     const size_t need = sizeof(float2) * (size_t) mf + sizeof(uint16_t) * ((size_t) cap * cap + 4) + sizeof(uint16_t) * ((size_t) mf + 2);
     if (mf > 0 && mf <= 65535 && lds + need <= lds_budget) { A.nn_lds_points = mf; A.nn_lds_cells = cap * cap + 1; lds += need + 16; }
   }
+  // one NN slice whose tables stay in global memory (the map is the fixed cloud): every query's cell and the candidate ranges of its 3 x 3 block are
+  // cached in LDS from one iteration to the next (32 bytes per query of the biggest moving cloud), same budget
+  A.nn_qcache = 0;
+  if (ns == 1 && b->slices[0].finder == LSM2D_FINDER_NN && A.nn_lds_points == 0 && ctx->nn_qcache) {
+    const lsm2d_cloudset* m = b->moving[0];
+    int mm = 0; for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] > mm) mm = m->h_count[c];
+    lds = (lds + 15) & ~(size_t) 15;
+    if (mm > 0 && lds + 32 * (size_t) mm + 16 <= lds_budget) { A.nn_qcache = mm; lds += 32 * (size_t) mm + 16; }
+  }
   // one KD-tree slice: the top of the fixed cloud's tree (up to "kd_lds_nodes" nodes, 24 bytes each) rides in LDS -- same 38 KB budget
   A.kd_lds_nodes = 0; A.kd_lds_points = 0;
   if (ns == 1 && b->slices[0].finder == LSM2D_FINDER_KDTREE && kd_cache0 && ctx->kd_lds_nodes > 0) {
@@ -1755,6 +1767,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     const dim3 grid((unsigned) n), block(kAlignBlock);
     if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3((unsigned) (kAlignBlock * ns)), lds_pair, ctx->stream, A);
     else if (has_proj && !has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
+    else if (!has_proj && has_nn && !has_dist && !has_kd && A.nn_lds_points == 0) hipLaunchKernelGGL((k_align<false, true, false, false, true>), grid, block, lds, ctx->stream, A);      // tables in global memory
     else if (!has_proj && has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && !has_nn && has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && !has_nn && !has_dist && has_kd) hipLaunchKernelGGL((k_align<false, false, false, true>), grid, block, lds, ctx->stream, A);

@@ -42,6 +42,7 @@ struct GridDev {
   const int32_t*  cell_start;  // per cloud: gw*gh+1 entries from meta.cell_base (positions relative to the cloud)
   const int32_t*  sorted_idx;  // [padded total] original point index, cloud-relative, grouped by cell
   const float2*   sorted_xy;   // [padded total] coordinates in the same order
+  const float2*   sorted_nrm;  // [padded total] normals in the same order: the fused aligner takes a match's normal from where the search found the point
 };
 
 // Distance map over every cloud of a set (CorrespondenceFinderNN2D, registration/correspondence_finder_nn_2d.cpp):
@@ -219,6 +220,81 @@ LSM2D_DEV int nn_query(const GridMeta& g, const CellT* __restrict__ cell_start, 
   return best;
 }
 
+// The same search keeping the winner's POSITION in the sorted arrays (-1: none), for tables in global memory (k_align<..., kNNGlobal>): a
+// candidate's original index is read only to break an exact tie of distances (ties -> lowest index) -- the one index read per improving
+// candidate of nn_query is gone -- and whoever needs the winner's coordinates or normal reads sorted_xy / sorted_nrm there once.  The group's
+// minimum goes through DPP moves inside the quad (no LDS crossbar).
+template <int o> LSM2D_DEV int quad_xor(int v) {      // lane ^ 1 or lane ^ 2 inside a quad
+  static_assert(o == 1 || o == 2, "inside a quad");
+  return __builtin_amdgcn_update_dpp(0, v, o == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true);
+}
+// qc: this query's cache row in LDS (8 words: cell x, y and the candidate ranges of the three rows of its 3 x 3 block), or nullptr.  Between two
+// iterations of an alignment a query moves by less than a cell more often than not: its block's ranges are then read from LDS instead of
+// six entries of the cell table (the one structure of this search that misses the L2s: 14 MB for a 100k-point map).
+template <int group>
+LSM2D_DEV int nn_query_pos(const GridMeta& g, const int32_t* __restrict__ cell_start, const int32_t* __restrict__ sidx,
+                           const float2* __restrict__ sxy, float qx, float qy, float md, float md2, int sub, int* qc = nullptr) {
+  static_assert(group == 1 || group == 2 || group == 4, "a group is (part of) a quad");
+  const float fx = __builtin_floorf((qx - g.minx) * g.inv_h), fy = __builtin_floorf((qy - g.miny) * g.inv_h);
+  const float reach = __builtin_ceilf(md * g.inv_h * 1.002f);
+  if (!(fx >= -reach && fx <= (float) g.gw + reach && fy >= -reach && fy <= (float) g.gh + reach)) return -1;
+  const int cx = (int) fx, cy = (int) fy, kmax = (int) reach;
+  int best = -1; float bd = 3.402823466e+38f;
+  for (int k = 1;; k *= 2) {
+    if (k > kmax) k = kmax;
+    const int x0 = cx - k < 0 ? 0 : cx - k, x1 = cx + k > g.gw - 1 ? g.gw - 1 : cx + k;
+    const int y0 = cy - k < 0 ? 0 : cy - k, y1 = cy + k > g.gh - 1 ? g.gh - 1 : cy + k;
+    if (x0 <= x1 && y0 <= y1) {
+      auto consider = [&](int t, float2 p) {
+        const float dx = p.x - qx, dy = p.y - qy;
+        const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+        if (d2 <= md2 && d2 <= bd) {
+          bool take = d2 < bd || best < 0;
+          if (!take && t != best) take = sidx[t] < sidx[best];      // an exact tie: the lower original index wins
+          if (take) { bd = d2; best = t; }
+        }
+      };
+      // (measured and dropped: two candidates per 16-byte load with the odd head and tail on one lane each, 1.91-1.93 ms against 1.81 for this form)
+      auto scan_row = [&](int s, int e) {
+        for (int t = s + sub; t < e; t += 2 * group) {
+          float2 p[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) { const int tu = t + u * group; p[u] = sxy[tu < e ? tu : t]; }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) { const int tu = t + u * group; if (tu < e) consider(tu, p[u]); }
+        }
+      };
+      if (qc && k == 1) {
+        const int4 c0 = *reinterpret_cast<const int4*>(qc), c1 = *reinterpret_cast<const int4*>(qc + 4);
+        int r[6] = {c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        if (!(c0.x == cx && c0.y == cy)) {                       // a new cell: read the table, remember what it said (every lane of the group reads the same entries)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int yy = y0 + i;
+            r[2 * i] = yy <= y1 ? cell_start[yy * g.gw + x0] : 0; r[2 * i + 1] = yy <= y1 ? cell_start[yy * g.gw + x1 + 1] : 0;
+          }
+          if (sub == 0) { *reinterpret_cast<int4*>(qc) = make_int4(cx, cy, r[0], r[1]); *reinterpret_cast<int4*>(qc + 4) = make_int4(r[2], r[3], r[4], r[5]); }
+        }
+        scan_row(r[0], r[1]); scan_row(r[2], r[3]); scan_row(r[4], r[5]);
+      }
+      else for (int yy = y0; yy <= y1; ++yy) scan_row(cell_start[yy * g.gw + x0], cell_start[yy * g.gw + x1 + 1]);
+    }
+    if (group > 1) {                                             // lexicographic (d2, index) minimum over the group
+      auto merge = [&](float od, int oi) {
+        bool take = oi >= 0 && (best < 0 || od < bd);
+        if (!take && oi >= 0 && best >= 0 && od == bd && oi != best) take = sidx[oi] < sidx[best];
+        if (take) { bd = od; best = oi; }
+      };
+      if (group >= 2) merge(__int_as_float(quad_xor<1>(__float_as_int(bd))), quad_xor<1>(best));
+      if (group >= 4) merge(__int_as_float(quad_xor<2>(__float_as_int(bd))), quad_xor<2>(best));
+    }
+    if (k >= kmax) break;
+    const float inside = (float) k * g.h * 0.998f;
+    if (best >= 0 && bd < inside * inside) break;
+  }
+  return best;
+}
+
 // bounding box per cloud as CorrespondenceFinderNN2D::_adjustSize computes it (correspondence_finder_nn_2d.cpp:28-43):
 // upper bounds start at the smallest positive float (the reference's numeric_limits<float>::min()).
 __global__ __launch_bounds__(256) void k_cloud_bbox(const float2* __restrict__ xy, const int32_t* __restrict__ start,
@@ -315,6 +391,7 @@ struct GridBuildArgs {
   const int32_t* cell_base;     // [n_clouds] host-computed: room for gcap^2 + 1 entries per cloud
   const int32_t* gcap;          // [n_clouds] max grid dimension per cloud
   GridMeta* meta; int32_t* cell_start; int32_t* cursor; int32_t* sorted_idx; float2* sorted_xy;
+  const float2* nrm; float2* sorted_nrm;      // the normals travel with the points
   int32_t big_threshold;        // clouds of at least this many points only get their bounding box and meta here; the chip-wide
                                 // kernels below (k_grid_big_*) do the rest -- one workgroup scanning 3.6 M cells took 5 ms for a 100k-point map
 };
@@ -387,7 +464,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(const GridBuildArgs A) {
   for (int i = tid; i < n; i += 1024) {
     const float2 p = xy[i];
     const int pos = atomicAdd(&cur[cell_of(p)], 1);
-    A.sorted_idx[base + pos] = i; A.sorted_xy[base + pos] = p;
+    A.sorted_idx[base + pos] = i; A.sorted_xy[base + pos] = p; A.sorted_nrm[base + pos] = A.nrm[base + i];
   }
 }
 
@@ -398,6 +475,7 @@ static constexpr int kGridTile = 4096;      // cells per workgroup of the scan: 
 struct GridBigArgs {
   const float2* xy; const int32_t* start; const int32_t* count; int32_t cloud;
   const GridMeta* meta; int32_t* cell_start; int32_t* cursor; int32_t* tile_sums; int32_t* sorted_idx; float2* sorted_xy;
+  const float2* nrm; float2* sorted_nrm;
 };
 
 __global__ __launch_bounds__(256) void k_grid_big_hist(const GridBigArgs A) {
@@ -460,7 +538,7 @@ __global__ __launch_bounds__(256) void k_grid_big_scatter(const GridBigArgs A) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float2 p = xy[i];
     const int pos = atomicAdd(&cur[grid_cell_of(g, p)], 1);
-    A.sorted_idx[base + pos] = i; A.sorted_xy[base + pos] = p;
+    A.sorted_idx[base + pos] = i; A.sorted_xy[base + pos] = p; A.sorted_nrm[base + pos] = A.nrm[base + i];
   }
 }
 
@@ -658,6 +736,7 @@ struct AlignArgs {
   float   term_eps;                         // lsm2d_aligner_params.termination_chi_epsilon (0 = run all iterations)
   int32_t cols_max, fcan_total;
   int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
+  int32_t nn_qcache;                        // > 0: single NN slice with its tables in global memory (kNNGlobal): room in LDS for this many queries' cached cell ranges (32 bytes each)
   int32_t kd_lds_nodes;                     // > 0: single KD-tree slice -- room in LDS for this many nodes of the fixed cloud's tree (its top levels)
   int32_t kd_lds_points;                    // > 0: ... and, for scan-sized fixed clouds, for this many leaf points (whole trees on chip)
   const int32_t* order;                     // alignment handled by workgroup b (nullptr: b itself) -- the balanced placement of k_balance_order
@@ -770,8 +849,12 @@ __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], 
 // projective hot loop does not carry the NN path's register pressure (and vice versa).
 // kHasDist: a slice uses the distance-map finder (compiled out otherwise so the NN search keeps its registers).
 // kHasKd: a slice uses the KD-tree finder (LSM2D_FINDER_KDTREE); compiled out otherwise.
-template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false>
+// kNNGlobal: a pure grid-NN batch whose search tables stay in global memory (the map is the fixed cloud: BASELINE's wording with the exact search) --
+// an instantiation of its own, so that its position-keeping search (nn_query_pos) does not share 64 registers with the LDS-table path of the
+// tracker's wiring (both forms in one kernel: scratch 16 -> 80 bytes, role A 7.2 -> 10.6 ms)
+template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, bool kNNGlobal = false>
 __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LSM2D_QUERY_MIN_WAVES)) void k_align(const AlignArgs A) {
+  static_assert(!kNNGlobal || (kHasNN && !kHasProj && !kHasDist && !kHasKd), "kNNGlobal: grid NN only");
   extern __shared__ __align__(16) unsigned char smem[];
   // the 16-byte rows first: behind the canvases they would sit on an odd 8-byte boundary whenever cols_max + fcan_total is odd
   float4* fwin = reinterpret_cast<float4*>(smem);                 // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
@@ -781,6 +864,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   // NN finder over a scan-sized fixed cloud (the tracker wiring: tree over the scan, every map point a query): the cloud's search
   // tables live in LDS for the whole alignment -- 20 iterations x N_m queries then touch global memory only for the query stream
   float2* l_sxy = reinterpret_cast<float2*>(red + (kAlignBlock / 64) * kAccumWords);
+  int* l_qc = reinterpret_cast<int*>(red + (kAlignBlock / 64) * kAccumWords);      // kNNGlobal: [nn_qcache][8] cached cell ranges per query (16-byte aligned: the host pads)
   uint16_t* l_cst = reinterpret_cast<uint16_t*>(l_sxy + A.nn_lds_points);
   uint16_t* l_sidx = l_cst + ((A.nn_lds_cells + 2) & ~1);
   // KD-tree finder: the top levels of the fixed cloud's tree (its first kd_lds_nodes nodes) live in LDS for the whole alignment -- every
@@ -869,8 +953,9 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     begin_iteration();
   }
   __syncthreads();
+  if (kNNGlobal) for (int i = tid; i < A.nn_qcache; i += kAlignBlock) l_qc[8 * i] = 0x7fffffff;      // no cell cached yet (visible after the barriers below)
   bool nn_lds = false;
-  if (kHasNN && A.nn_lds_points > 0) {
+  if (kHasNN && !kNNGlobal && A.nn_lds_points > 0) {
     const SliceDev& S = A.s[0];
     const int fc = pick_cloud(S.fixed, a), nf = S.fixed.count[fc];
     const GridMeta g0 = S.fixed.grid.meta[fc];
@@ -1053,6 +1138,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
           g.gw = __builtin_amdgcn_readfirstlane(g.gw); g.gh = __builtin_amdgcn_readfirstlane(g.gh); g.cell_base = __builtin_amdgcn_readfirstlane(g.cell_base);
           cst = S.fixed.grid.cell_start + g.cell_base;
           sidx = S.fixed.grid.sorted_idx + fbase; sxy = S.fixed.grid.sorted_xy + fbase;
+          if (kNNGlobal) knr = S.fixed.grid.sorted_nrm + fbase;
         } else {
           dm = S.fixed.dist.meta[fc];       // distance-map finder: one lookup per query (correspondence_finder_nn_2d.cpp:63-80)
         }
@@ -1124,6 +1210,15 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
                   const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
                   if (!(dot < S.normal_cos)) accumulate_pair(T, bxy, nf, pm, nm, S.cauchy != 0, S.tau, acc);
                 }
+              }
+            } else
+            if (kNNGlobal) {      // the match's point and normal come from where the search found it: no detour through the original index
+              const int pos = live ? nn_query_pos<group>(g, cst, sidx, sxy, qx, qy, S.max_distance, md2, sub, j < A.nn_qcache ? l_qc + 8 * j : nullptr) : -1;
+              if (pos >= 0 && sub == 0) {                    // one lane per query accumulates
+                const float2 nm = mn[j], nf = knr[pos], pf = sxy[pos];
+                float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+                const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
+                if (!(dot < S.normal_cos)) accumulate_pair(T, pf, nf, pm, nm, S.cauchy != 0, S.tau, acc);
               }
             } else
             if (use_grid) {
