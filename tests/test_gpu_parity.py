@@ -2688,3 +2688,41 @@ def test_latency_kernel_every_cloud_placement_equals_the_fused_kernel(ctx, po):
             _assert_bitwise_equal_to_device_order_oracle(c, 0, rt, (name, cols))
             checked += 1
     print("latency kernel: %d placements x canvases equal to k_align and to the device-order oracle bit for bit" % checked)
+
+
+@pytest.mark.gpu
+def test_grid_nn_over_the_map_position_search_ties_and_cell_cache(ctx, po):
+    """The grid NN with a map-sized fixed cloud runs in an instantiation of its own (k_align<0,1,0,0,1>): the search keeps the winner's position,
+    reads an original index only to break an exact tie, and caches every query's cell ranges in LDS between iterations.  A map with DUPLICATED
+    points (exact ties of distances on most queries: the lower original index must win, as in the oracle) aligned with the cache on and off,
+    ragged scans, Cauchy: the same bits both ways, and the device-order oracle's."""
+    wl = synth.make_workload(12, 40000, seed=12)
+    dup = np.concatenate([wl.map_points, wl.map_points[::3], wl.map_points[5000:9000]], 0)      # every third point twice, a stretch three times
+    x0_b = synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32)
+    scans = [wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]][: 1081 - 37 * i] for i in range(12)]
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in scans])]).astype(np.int32)
+    fixed = api.CloudSet(ctx, dup); moving = api.CloudSet(ctx, np.concatenate(scans, 0), offs)
+    al = api.MultiAligner2D(ctx, max_iterations=12, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.4, normal_cos=0.7, search="exact"),
+                                                                      min_num_correspondences=10, robustifier=api.RobustifierCauchy(0.03)))
+    res = {}
+    for cache in (1, 0):
+        ctx.set_option("nn_qcache", cache)
+        try:
+            res[cache] = al.compute_batch([fixed], [moving], x0_b, want_stats=True)
+        finally:
+            ctx.set_option("nn_qcache", 1)
+    a, c = res[1], res[0]
+    assert np.array_equal(a.pose, c.pose) and np.array_equal(a.information, c.information) and np.array_equal(a.status, c.status) and np.array_equal(a.stats, c.stats)
+    assert np.all(a.status == 0)
+    osp = po.slice_params(finder=po.FINDER_NN, max_distance=0.4, normal_cos=0.7, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.03, min_num_correspondences=10)
+    for i in (0, 5, 11):
+        rt = po.align(po.aligner_params(12, min_num_inliers=10, device_order=True), [osp], [dup], [scans[i]], x0_b[i])
+        _assert_bitwise_equal_to_device_order_oracle(a, i, rt, ("grid NN over the map", i))
+    # the finder-level call on the same clouds returns the oracle's pairs (lowest index on every tie)
+    f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.4, normal_cos=0.7, search="exact")
+    f.setFixed(dup); f.setMoving(scans[0]); f.setLocalMapInSensor(x0_b[0])
+    got = f.compute(); want = po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.4, normal_cos=0.7), dup, scans[0], x0_b[0])
+    assert np.array_equal(got, want) and len(want) > 500
+    tied = np.isin(want[:, 0], np.arange(0, len(wl.map_points), 3)).mean()
+    assert tied > 0.2, tied          # many winners ARE the lower-indexed copy of a duplicated point
