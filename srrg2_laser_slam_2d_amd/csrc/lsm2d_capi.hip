@@ -49,6 +49,7 @@ struct lsm2d_context {
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
   int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / k_balance_order); 0: workgroup b = alignment b
   int n_cu = 0;                // compute units of the device (hipDeviceProp_t.multiProcessorCount)
+  int nn_lds_only = 1;         // grid NN with every alignment's tables staged in LDS: the instantiation without the search in global memory (0: the shared one; A/B knob)
   int nn_qcache = 1;           // grid NN over a map-sized fixed cloud: cache every query's cell ranges in LDS between iterations (0: off; A/B knob)
   int cull_block = 0;          // steps per unit of the culled stream (0: automatic, ~1/25 of a chunk; even; tuning knob)
   int cull = 1;                // k_align, projective slices: exact culling of the moving cloud against the fixed canvas (0: off; results do not depend on it)
@@ -261,6 +262,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "cull")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull must be 0, 1 or 2"); ctx->cull = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_qcache")) { ctx->nn_qcache = value != 0; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "nn_lds_only")) { ctx->nn_lds_only = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
@@ -275,6 +277,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "cull")) { *out_value = ctx->cull; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { *out_value = ctx->cull_block; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_qcache")) { *out_value = ctx->nn_qcache; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "nn_lds_only")) { *out_value = ctx->nn_lds_only; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
@@ -1664,6 +1667,16 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   }
   if (pq_bytes) { lds = (lds + 15) & ~(size_t) 15; A.pq_cull_off = (int32_t) lds; lds += pq_bytes; }
   ctx->last_query_cull = A.pq_cull_off > 0;
+  // the NN instantiation without the search in global memory: the staging holds every alignment's tables (sized for the largest fixed cloud above), and no
+  // alignment takes the cooperative loop, which searches in global memory (the kernel's rule: fixed cloud >= 4 x moving cloud) -- whatever the pairing
+  bool nn_lds_for_all = false;
+  if (A.nn_lds_points > 0 && ctx->nn_lds_only && !b->moving[0]->count_pending && !b->fixed[0]->count_pending) {
+    const lsm2d_cloudset* f = b->fixed[0]; const lsm2d_cloudset* m = b->moving[0];
+    long long mf = 0, mn = 0x7fffffff;
+    for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > mf) mf = f->h_count[c];
+    for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] < mn) mn = m->h_count[c];
+    nn_lds_for_all = m->n_clouds > 0 && mf < 4 * mn;
+  }
   if ((int) lds + 512 > ctx->max_dyn_lds) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch: canvases do not fit LDS");
   // one or two projective slices and too few alignments to fill the chip (the live tracker: one alignment per scan): the latency
   // kernel (k_align_pair; bit-identical sums) -- 512 threads per slice, two slices' passes side by side instead of one after the
@@ -1767,7 +1780,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     const dim3 grid((unsigned) n), block(kAlignBlock);
     if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3((unsigned) (kAlignBlock * ns)), lds_pair, ctx->stream, A);
     else if (has_proj && !has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
-    else if (!has_proj && has_nn && !has_dist && !has_kd && A.nn_lds_points == 0) hipLaunchKernelGGL((k_align<false, true, false, false, true>), grid, block, lds, ctx->stream, A);      // tables in global memory
+    else if (!has_proj && has_nn && !has_dist && !has_kd && A.nn_lds_points == 0) hipLaunchKernelGGL((k_align<false, true, false, false, 1>), grid, block, lds, ctx->stream, A);      // tables in global memory
+    else if (!has_proj && has_nn && !has_dist && !has_kd && nn_lds_for_all) hipLaunchKernelGGL((k_align<false, true, false, false, 2>), grid, block, lds, ctx->stream, A);      // tables in LDS, every alignment
     else if (!has_proj && has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && !has_nn && has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && !has_nn && !has_dist && has_kd) hipLaunchKernelGGL((k_align<false, false, false, true>), grid, block, lds, ctx->stream, A);

@@ -852,9 +852,12 @@ __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], 
 // kNNGlobal: a pure grid-NN batch whose search tables stay in global memory (the map is the fixed cloud: BASELINE's wording with the exact search) --
 // an instantiation of its own, so that its position-keeping search (nn_query_pos) does not share 64 registers with the LDS-table path of the
 // tracker's wiring (both forms in one kernel: scratch 16 -> 80 bytes, role A 7.2 -> 10.6 ms)
-template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, bool kNNGlobal = false>
+// kNNMode 2: the counterpart -- a pure grid-NN batch whose tables the host has PROVED to fit the LDS staging for every alignment (nn_lds_points is the
+// largest fixed cloud, nn_lds_cells the grid ensure_grid() gives that size): the search in global memory and the cooperative loop are compiled out
+template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
 __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LSM2D_QUERY_MIN_WAVES)) void k_align(const AlignArgs A) {
-  static_assert(!kNNGlobal || (kHasNN && !kHasProj && !kHasDist && !kHasKd), "kNNGlobal: grid NN only");
+  constexpr bool kNNGlobal = kNNMode == 1, kNNLds = kNNMode == 2;
+  static_assert(kNNMode == 0 || (kHasNN && !kHasProj && !kHasDist && !kHasKd), "kNNMode: grid NN only");
   extern __shared__ __align__(16) unsigned char smem[];
   // the 16-byte rows first: behind the canvases they would sit on an odd 8-byte boundary whenever cols_max + fcan_total is odd
   float4* fwin = reinterpret_cast<float4*>(smem);                 // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
@@ -967,6 +970,15 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       for (int i = tid; i <= ncell; i += kAlignBlock) l_cst[i] = (uint16_t) cst[i];
       for (int i = tid; i < nf; i += kAlignBlock) { l_sxy[i] = S.fixed.grid.sorted_xy[fbase + i]; l_sidx[i] = (uint16_t) S.fixed.grid.sorted_idx[fbase + i]; }
     }
+  }
+  if (kNNLds && !nn_lds) {      // cannot happen (the host sized the staging for the set's largest cloud): refuse loudly rather than search tables that are not there
+    if (tid == 0) {
+      A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
+      if (A.out_its) A.out_its[a] = 0;
+      if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], (int) LSM2D_CAPACITY_EXCEEDED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+      else A.out_status[a] = LSM2D_CAPACITY_EXCEEDED;
+    }
+    return;
   }
   int kd_lds = 0;                            // nodes of this alignment's tree that were staged (workgroup-uniform)
   bool kd_leaves_lds = false;                // ... and its leaf arrays
@@ -1221,6 +1233,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
                 if (!(dot < S.normal_cos)) accumulate_pair(T, pf, nf, pm, nm, S.cauchy != 0, S.tau, acc);
               }
             } else
+            if (kNNLds) { if (live) best = nn_query<1, uint16_t, uint16_t>(g, l_cst, l_sidx, l_sxy, qx, qy, S.max_distance, md2, 0); }
+            else
             if (use_grid) {
               if (live) best = (group == 1 && nn_lds) ? nn_query<1, uint16_t, uint16_t>(g, l_cst, l_sidx, l_sxy, qx, qy, S.max_distance, md2, 0)
                                                       : nn_query<group>(g, cst, sidx, sxy, qx, qy, S.max_distance, md2, sub);
@@ -1242,7 +1256,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         // (matched pairs queued per wave in LDS and added up 64 at a time with every lane busy, instead of ~70 instructions of accumulate_pair on
         // every trip for the quarter of the lanes that matched: slower everywhere -- distance map role A 5.21 -> 5.87 ms, NN role A 7.95 -> 8.61,
         // distance map role B 0.21 -> 0.30: the ballot, the queue and the reloads cost more than the idle lanes; DESIGN App. A)
-        if (coop) query_loop(std::integral_constant<int, kNNGroup>{});
+        if (!kNNLds && coop) query_loop(std::integral_constant<int, kNNGroup>{});
         else query_loop(std::integral_constant<int, 1>{});
       }
       LSM2D_PH(0);

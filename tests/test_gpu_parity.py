@@ -2588,6 +2588,13 @@ def test_culling_and_placement_change_no_bit(ctx, po):
             assert np.array_equal(a.status, c.status) and np.array_equal(a.iterations, c.iterations) and np.array_equal(a.stats, c.stats), (finder.search, name)
             if name == "ordered" and finder.param_max_distance_m > 0.1:
                 assert (a.status == 0).mean() > 0.9, (finder.search, (a.status == 0).mean())
+            if finder.search == "exact" and name in ("ordered", "far"):      # the grid NN's instantiation without the search in global memory against the shared one
+                ctx.set_option("nn_lds_only", 0)
+                try:
+                    s0 = al.compute_batch([fixed], [moving], x0, want_stats=True)
+                finally:
+                    ctx.set_option("nn_lds_only", 1)
+                assert np.array_equal(s0.pose, c.pose, equal_nan=True) and np.array_equal(s0.information, c.information, equal_nan=True) and np.array_equal(s0.stats, c.stats), name
 
 
 def test_point_query_finders_against_the_reference_arithmetic_mode(ctx, po):
