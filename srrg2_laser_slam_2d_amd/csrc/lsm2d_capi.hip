@@ -49,6 +49,7 @@ struct lsm2d_context {
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
   int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / k_balance_order); 0: workgroup b = alignment b
   int n_cu = 0;                // compute units of the device (hipDeviceProp_t.multiProcessorCount)
+  int kd_modes = 1;            // KD-tree batches: the instantiations with one form of the descent only (0: the shared one; A/B knob)
   int nn_lds_only = 1;         // grid NN with every alignment's tables staged in LDS: the instantiation without the search in global memory (0: the shared one; A/B knob)
   int nn_qcache = 1;           // grid NN over a map-sized fixed cloud: cache every query's cell ranges in LDS between iterations (0: off; A/B knob)
   int cull_block = 0;          // steps per unit of the culled stream (0: automatic, ~1/25 of a chunk; even; tuning knob)
@@ -263,6 +264,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_qcache")) { ctx->nn_qcache = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_lds_only")) { ctx->nn_lds_only = value != 0; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_modes")) { ctx->kd_modes = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
@@ -278,6 +280,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "cull_block")) { *out_value = ctx->cull_block; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_qcache")) { *out_value = ctx->nn_qcache; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_lds_only")) { *out_value = ctx->nn_lds_only; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_modes")) { *out_value = ctx->kd_modes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
@@ -1784,6 +1787,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     else if (!has_proj && has_nn && !has_dist && !has_kd && nn_lds_for_all) hipLaunchKernelGGL((k_align<false, true, false, false, 2>), grid, block, lds, ctx->stream, A);      // tables in LDS, every alignment
     else if (!has_proj && has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && !has_nn && has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
+    else if (!has_proj && !has_nn && !has_dist && has_kd && ns == 1 && ctx->kd_modes && A.kd_lds_points > 0) hipLaunchKernelGGL((k_align<false, false, false, true, 3>), grid, block, lds, ctx->stream, A);      // whole trees in LDS
+    else if (!has_proj && !has_nn && !has_dist && has_kd && ns == 1 && ctx->kd_modes && A.kd_lds_points == 0) hipLaunchKernelGGL((k_align<false, false, false, true, 4>), grid, block, lds, ctx->stream, A);     // only their tops
     else if (!has_proj && !has_nn && !has_dist && has_kd) hipLaunchKernelGGL((k_align<false, false, false, true>), grid, block, lds, ctx->stream, A);
     else if (!has_kd) hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
     else hipLaunchKernelGGL((k_align<true, true, true, true>), grid, block, lds, ctx->stream, A);              // mixed finders, one of them the KD-tree

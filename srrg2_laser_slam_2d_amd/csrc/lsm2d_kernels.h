@@ -857,7 +857,10 @@ __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], 
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
 __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LSM2D_QUERY_MIN_WAVES)) void k_align(const AlignArgs A) {
   constexpr bool kNNGlobal = kNNMode == 1, kNNLds = kNNMode == 2;
-  static_assert(kNNMode == 0 || (kHasNN && !kHasProj && !kHasDist && !kHasKd), "kNNMode: grid NN only");
+  // the same for a pure KD-tree batch: 3 = every alignment's whole tree, leaf arrays included, is in LDS (the tracker's wiring: a tree per scan); 4 = only the
+  // top of the tree is (the map is the fixed cloud): the other form of the descent and of the leaf scan is compiled out
+  constexpr bool kKdAllLds = kNNMode == 3, kKdTop = kNNMode == 4;
+  static_assert(kNNMode == 0 || ((kNNMode <= 2) && kHasNN && !kHasProj && !kHasDist && !kHasKd) || ((kNNMode >= 3) && kHasKd && !kHasProj && !kHasDist && !kHasNN), "kNNMode: one point-query finder only");
   extern __shared__ __align__(16) unsigned char smem[];
   // the 16-byte rows first: behind the canvases they would sit on an odd 8-byte boundary whenever cols_max + fcan_total is odd
   float4* fwin = reinterpret_cast<float4*>(smem);                 // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     // tree is on chip and 20 iterations x N_m queries touch global memory for the query stream only
     if (A.kd_lds_points > 0) {
       const int fc = pick_cloud(S.fixed, a), nf = S.fixed.count[fc], fb = S.fixed.start[fc];
-      kd_leaves_lds = nf <= A.kd_lds_points && kd_lds == km.n_nodes;      // workgroup-uniform
+      kd_leaves_lds = !kKdTop && nf <= A.kd_lds_points && kd_lds == km.n_nodes;      // workgroup-uniform
       if (kd_leaves_lds) for (int i = tid; i < nf; i += kAlignBlock) { l_kxy[i] = S.fixed.kd.leaf_xy[fb + i]; l_knr[i] = S.fixed.kd.leaf_nrm[fb + i]; }
     }
   }
@@ -1009,6 +1012,15 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         atomicMin(&s_pqbb[0], ordered(p.x)); atomicMin(&s_pqbb[1], ordered(p.y)); atomicMax(&s_pqbb[2], ordered(p.x)); atomicMax(&s_pqbb[3], ordered(p.y));
       }
     }
+  }
+  if (kKdAllLds && !kd_leaves_lds) {      // cannot happen (the host sized the staging for the set's largest tree): refuse loudly, as above
+    if (tid == 0) {
+      A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
+      if (A.out_its) A.out_its[a] = 0;
+      if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], (int) LSM2D_CAPACITY_EXCEEDED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+      else A.out_status[a] = LSM2D_CAPACITY_EXCEEDED;
+    }
+    return;
   }
   const Iso ident = {1.0f, 0.0f, 0.0f, 0.0f};
   for (int s = 0; s < A.n_slices; ++s) {
@@ -1215,9 +1227,11 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
             if (use_kd) {      // the match's point and normal come from the leaf arrays, where the scan found it: the original index is never needed
               if (live) {
                 float2 bxy;
-                const int pos = kd_leaves_lds ? kd_query_pos<true>(knd, l_kxy, qx, qy, md2, bxy, l_kpl, l_klk, kd_lds) : kd_query_pos(knd, sxy, qx, qy, md2, bxy, l_kpl, l_klk, kd_lds);
+                const int pos = kKdAllLds ? kd_query_pos<true>(knd, l_kxy, qx, qy, md2, bxy, l_kpl, l_klk, kd_lds)
+                              : kKdTop ? kd_query_pos(knd, sxy, qx, qy, md2, bxy, l_kpl, l_klk, kd_lds)
+                              : kd_leaves_lds ? kd_query_pos<true>(knd, l_kxy, qx, qy, md2, bxy, l_kpl, l_klk, kd_lds) : kd_query_pos(knd, sxy, qx, qy, md2, bxy, l_kpl, l_klk, kd_lds);
                 if (pos >= 0) {
-                  const float2 nm = mn[j], nf = kd_leaves_lds ? l_knr[pos] : knr[pos];
+                  const float2 nm = mn[j], nf = kKdAllLds ? l_knr[pos] : (kKdTop ? knr[pos] : (kd_leaves_lds ? l_knr[pos] : knr[pos]));
                   float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
                   const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
                   if (!(dot < S.normal_cos)) accumulate_pair(T, bxy, nf, pm, nm, S.cauchy != 0, S.tau, acc);

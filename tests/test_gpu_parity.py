@@ -2318,10 +2318,10 @@ def test_aligner_kdtree_both_roles_bitwise(ctx, po):
     x0_b = synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32); xt_b = synth.invert_poses(wl.x_true)
     fixed = api.CloudSet(ctx, wl.map_points); moving = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
     results = []
-    for lds_nodes in (1024, 0, 37):
-        ctx.set_option("kd_lds_nodes", lds_nodes)
+    for lds_nodes, modes in ((1024, 1), (0, 1), (37, 1), (1024, 0)):      # (modes 0: the shared instantiation with both forms of the descent)
+        ctx.set_option("kd_lds_nodes", lds_nodes); ctx.set_option("kd_modes", modes)
         results.append(_kd_aligner(ctx).compute_batch([fixed], [moving], x0_b, want_stats=True))
-    ctx.set_option("kd_lds_nodes", 1024)
+    ctx.set_option("kd_lds_nodes", 1024); ctx.set_option("kd_modes", 1)
     res = results[0]
     for other in results[1:]:
         assert np.array_equal(res.pose, other.pose) and np.array_equal(res.information, other.information) and np.array_equal(res.status, other.status)
@@ -2337,6 +2337,12 @@ def test_aligner_kdtree_both_roles_bitwise(ctx, po):
     fixed2 = api.CloudSet(ctx, wl2.scan_points, wl2.scan_offsets); moving2 = api.CloudSet(ctx, wl2.map_points)
     al = _kd_aligner(ctx, md=0.3, leaf_range=0.03, leaf_points=10, robustifier=api.RobustifierCauchy(0.05))
     res2 = al.compute_batch([fixed2], [moving2], wl2.x0, want_stats=True)
+    ctx.set_option("kd_modes", 0)
+    try:
+        shared = al.compute_batch([fixed2], [moving2], wl2.x0, want_stats=True)
+    finally:
+        ctx.set_option("kd_modes", 1)
+    assert np.array_equal(res2.pose, shared.pose) and np.array_equal(res2.information, shared.information) and np.array_equal(res2.stats, shared.stats)
     osp2 = po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, kd_max_leaf_range=0.03, kd_min_leaf_points=10, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.05)
     for i in (0, 3, 5):
         s = wl2.scan_points[wl2.scan_offsets[i]:wl2.scan_offsets[i + 1]]
@@ -2588,12 +2594,12 @@ def test_culling_and_placement_change_no_bit(ctx, po):
             assert np.array_equal(a.status, c.status) and np.array_equal(a.iterations, c.iterations) and np.array_equal(a.stats, c.stats), (finder.search, name)
             if name == "ordered" and finder.param_max_distance_m > 0.1:
                 assert (a.status == 0).mean() > 0.9, (finder.search, (a.status == 0).mean())
-            if finder.search == "exact" and name in ("ordered", "far"):      # the grid NN's instantiation without the search in global memory against the shared one
-                ctx.set_option("nn_lds_only", 0)
+            if name in ("ordered", "far"):      # the instantiations with one form of the search only (grid NN without the search in global memory, KD-tree with the whole tree in LDS) against the shared ones
+                ctx.set_option("nn_lds_only", 0); ctx.set_option("kd_modes", 0)
                 try:
                     s0 = al.compute_batch([fixed], [moving], x0, want_stats=True)
                 finally:
-                    ctx.set_option("nn_lds_only", 1)
+                    ctx.set_option("nn_lds_only", 1); ctx.set_option("kd_modes", 1)
                 assert np.array_equal(s0.pose, c.pose, equal_nan=True) and np.array_equal(s0.information, c.information, equal_nan=True) and np.array_equal(s0.stats, c.stats), name
 
 
