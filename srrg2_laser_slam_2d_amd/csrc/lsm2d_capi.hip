@@ -49,6 +49,7 @@ struct lsm2d_context {
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
   int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / k_balance_order); 0: workgroup b = alignment b
   int n_cu = 0;                // compute units of the device (hipDeviceProp_t.multiProcessorCount)
+  int proj_modes = 1;          // projective batches against map-sized clouds: the instantiation with the culled stream only (0: the shared one; A/B knob)
   int kd_modes = 1;            // KD-tree batches: the instantiations with one form of the descent only (0: the shared one; A/B knob)
   int nn_lds_only = 1;         // grid NN with every alignment's tables staged in LDS: the instantiation without the search in global memory (0: the shared one; A/B knob)
   int nn_qcache = 1;           // grid NN over a map-sized fixed cloud: cache every query's cell ranges in LDS between iterations (0: off; A/B knob)
@@ -211,6 +212,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   c->max_dyn_lds = (int) prop.sharedMemPerBlock;
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align<true, false, false, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -265,6 +267,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "nn_qcache")) { ctx->nn_qcache = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_lds_only")) { ctx->nn_lds_only = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_modes")) { ctx->kd_modes = value != 0; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "proj_modes")) { ctx->proj_modes = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
@@ -281,6 +284,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "nn_qcache")) { *out_value = ctx->nn_qcache; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_lds_only")) { *out_value = ctx->nn_lds_only; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_modes")) { *out_value = ctx->kd_modes; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "proj_modes")) { *out_value = ctx->proj_modes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
@@ -1670,6 +1674,9 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   }
   if (pq_bytes) { lds = (lds + 15) & ~(size_t) 15; A.pq_cull_off = (int32_t) lds; lds += pq_bytes; }
   ctx->last_query_cull = A.pq_cull_off > 0;
+  // the projective instantiation with the culled stream only: every slice's moving set has its lane-chunked copy and chunk circles, and culling is on
+  bool proj_culled_for_all = has_proj && !has_nn && !has_dist && !has_kd && A.cull == 1 && ctx->proj_modes;
+  for (int s = 0; s < ns && proj_culled_for_all; ++s) proj_culled_for_all = A.s[s].moving.lane_xy != nullptr && A.s[s].moving.lane_bounds != nullptr;
   // the NN instantiation without the search in global memory: the staging holds every alignment's tables (sized for the largest fixed cloud above), and no
   // alignment takes the cooperative loop, which searches in global memory (the kernel's rule: fixed cloud >= 4 x moving cloud) -- whatever the pairing
   bool nn_lds_for_all = false;
@@ -1782,6 +1789,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   } else {
     const dim3 grid((unsigned) n), block(kAlignBlock);
     if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3((unsigned) (kAlignBlock * ns)), lds_pair, ctx->stream, A);
+    else if (has_proj && !has_nn && !has_dist && !has_kd && proj_culled_for_all) hipLaunchKernelGGL((k_align<true, false, false, false, 5>), grid, block, lds, ctx->stream, A);      // every slice: the culled stream
     else if (has_proj && !has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
     else if (!has_proj && has_nn && !has_dist && !has_kd && A.nn_lds_points == 0) hipLaunchKernelGGL((k_align<false, true, false, false, 1>), grid, block, lds, ctx->stream, A);      // tables in global memory
     else if (!has_proj && has_nn && !has_dist && !has_kd && nn_lds_for_all) hipLaunchKernelGGL((k_align<false, true, false, false, 2>), grid, block, lds, ctx->stream, A);      // tables in LDS, every alignment

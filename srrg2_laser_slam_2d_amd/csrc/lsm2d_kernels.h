@@ -860,7 +860,11 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   // the same for a pure KD-tree batch: 3 = every alignment's whole tree, leaf arrays included, is in LDS (the tracker's wiring: a tree per scan); 4 = only the
   // top of the tree is (the map is the fixed cloud): the other form of the descent and of the leaf scan is compiled out
   constexpr bool kKdAllLds = kNNMode == 3, kKdTop = kNNMode == 4;
-  static_assert(kNNMode == 0 || ((kNNMode <= 2) && kHasNN && !kHasProj && !kHasDist && !kHasKd) || ((kNNMode >= 3) && kHasKd && !kHasProj && !kHasDist && !kHasNN), "kNNMode: one point-query finder only");
+  // ... and for a pure projective batch: 5 = every slice streams a lane-chunked moving cloud through the exact culling in units (what a batch against a map
+  // does): the plain lane stream, the row-major variant and the per-pair stream of small clouds are compiled out
+  constexpr bool kProjCulled = kNNMode == 5;
+  static_assert(kNNMode == 0 || ((kNNMode <= 2) && kHasNN && !kHasProj && !kHasDist && !kHasKd) || ((kNNMode == 3 || kNNMode == 4) && kHasKd && !kHasProj && !kHasDist && !kHasNN) ||
+                (kNNMode == 5 && kHasProj && !kHasNN && !kHasDist && !kHasKd), "kNNMode: one finder only");
   extern __shared__ __align__(16) unsigned char smem[];
   // the 16-byte rows first: behind the canvases they would sit on an odd 8-byte boundary whenever cols_max + fcan_total is odd
   float4* fwin = reinterpret_cast<float4*>(smem);                 // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
@@ -1086,7 +1090,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
           // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
           const int mc = pick_cloud(S.moving, a);
           // clouds of at most one pair per thread (the tracker's clipped scenes) need no lane-chunked copy
-          if (S.moving.lane_xy && S.moving.lane_bounds && A.cull) {
+          if (kProjCulled || (S.moving.lane_xy && S.moving.lane_bounds && A.cull)) {
             // exact culling against the fixed canvas (chunk_may_matter): every thread tests the chunk it would stream, the survivors are
             // compacted (two barriers: counts, then the list) and their points spread evenly over the workgroup (project_cloud_units)
             const int lane = tid & 63, wave = tid >> 6;
@@ -1113,10 +1117,11 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
             // order, balanced to one step, 1.066: project_cloud_rows, "cull" 2)
             const int B = A.cull_block > 0 ? A.cull_block : 2 * ((Tm + 13) / 14), nb = (Tm + B - 1) / B;
             if (n_surv > 0) {
-              if (A.cull == 2) project_cloud_rows(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv);
+              if (!kProjCulled && A.cull == 2) project_cloud_rows(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv);
               else project_cloud_units(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv, B, nb);
             }
           }
+          else if (kProjCulled) { }
           else if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
           else project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
         }

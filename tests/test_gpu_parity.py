@@ -2546,14 +2546,15 @@ def test_culling_and_placement_change_no_bit(ctx, po):
         try:
             return al.compute_batch([fixed] * len(moving_sets), moving_sets, wl.x0, want_stats=True)
         finally:
-            ctx.set_option("cull", 1); ctx.set_option("balance", 1); ctx.set_option("cull_block", 0)
+            ctx.set_option("cull", 1); ctx.set_option("balance", 1); ctx.set_option("cull_block", 0); ctx.set_option("proj_modes", 1)
     for name, mp in (("ordered", wl.map_points), ("shuffled", shuffled)):
         moving = api.CloudSet(ctx, mp)
         for tag, al in (("plain", _aligner(ctx)), ("cauchy 270 deg", _aligner(ctx, robustifier=api.RobustifierCauchy(0.05)))):
             if tag != "plain":      # a partial field of view: columns outside the canvas never hold a fixed point
                 al.param_slice_processors[0].param_finder.param_projector = api.PointNormal2fProjectorPolar(811, -0.75 * math.pi, 0.75 * math.pi, 0.3, 25.0)
             ref = run(al, [moving], cull=0)
-            for opts in (dict(cull=1), dict(cull=1, balance=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98)):
+            # (proj_modes 0: the shared instantiation instead of the one with the culled stream only)
+            for opts in (dict(cull=1), dict(cull=1, balance=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98), dict(cull=1, proj_modes=0)):
                 got = run(al, [moving], **opts)
                 assert np.array_equal(got.pose, ref.pose) and np.array_equal(got.information, ref.information), (name, tag, opts)
                 assert np.array_equal(got.status, ref.status) and np.array_equal(got.iterations, ref.iterations) and np.array_equal(got.stats, ref.stats), (name, tag, opts)
