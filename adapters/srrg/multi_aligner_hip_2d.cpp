@@ -50,19 +50,22 @@ namespace srrg2_laser_slam_2d {
     if (!_fixed || !_moving) {
       throw std::runtime_error(std::string(who) + "| fixed / moving scene not set");
     }
-    // options of the upstream aligner that the device loop does not implement: refused, never silently dropped
-    // (MULTI.json:606-610,704-708: both 0 in the shipped aligners; :627-630,729-731: termination_criteria unset)
-    if (lsm2d_srrg::inlierOnlyRunsEnabled(*this)) {
-      throw std::runtime_error(std::string(who) + "| enable_inlier_only_runs is not supported on the device (the loop runs no inlier-only re-runs)");
-    }
-    if (lsm2d_srrg::keepOnlyInlierCorrespondences(*this)) {
-      throw std::runtime_error(std::string(who) + "| keep_only_inlier_correspondences is not supported on the device (every iteration searches afresh)");
+    // the upstream aligner's remaining options (MULTI.json:606-610,704-708,627-630,729-731) go to the device loop as they are
+    // (lsm2d_aligner_params; semantics in include/lsm2d.h).  A termination_criteria OBJECT is translated into the epsilon it carries
+    // (upstream_access.h: terminationCriteriaEpsilon); one without such a property is refused -- never silently dropped.
+    float chi_epsilon = param_termination_chi_epsilon.value();
+    if (!(chi_epsilon >= 0.f)) {
+      throw std::runtime_error(std::string(who) + "| termination_chi_epsilon must be >= 0");
     }
     if (lsm2d_srrg::terminationCriteriaSet(*this)) {
-      throw std::runtime_error(std::string(who) + "| a termination_criteria object cannot run on the device: unset it and use termination_chi_epsilon");
-    }
-    if (!(param_termination_chi_epsilon.value() >= 0.f)) {
-      throw std::runtime_error(std::string(who) + "| termination_chi_epsilon must be >= 0");
+      const float from_object = lsm2d_srrg::terminationCriteriaEpsilon(*this);
+      if (!(from_object >= 0.f)) {
+        throw std::runtime_error(std::string(who) + "| the termination_criteria object carries no float property 'epsilon': it cannot be translated for the device");
+      }
+      if (chi_epsilon > 0.f && chi_epsilon != from_object) {
+        throw std::runtime_error(std::string(who) + "| termination_chi_epsilon and the termination_criteria object's epsilon disagree");
+      }
+      chi_epsilon = from_object;
     }
     if (!_ctx) {
       throwOnError(lsm2d_create(param_device_id.value(), nullptr, &_ctx), std::string(who) + " create", nullptr);
@@ -168,30 +171,38 @@ namespace srrg2_laser_slam_2d {
     ap.max_iterations  = param_max_iterations.value();
     ap.min_num_inliers = param_min_num_inliers.value();
     ap.damping         = 0.f; // GN, MULTI.json:254-259
-    ap.termination_chi_epsilon = param_termination_chi_epsilon.value();
-    std::vector<lsm2d_iteration_stats> stats((size_t) (ap.max_iterations > 0 ? ap.max_iterations : 1));
-    throwOnError(lsm2d_align_batch(_ctx, &ap, &batch, pose, information, &status, &iterations, stats.data()), who, _ctx);
+    ap.termination_chi_epsilon          = chi_epsilon;
+    ap.enable_inlier_only_runs          = lsm2d_srrg::inlierOnlyRunsEnabled(*this) ? 1 : 0;
+    ap.keep_only_inlier_correspondences = lsm2d_srrg::keepOnlyInlierCorrespondences(*this) ? 1 : 0;
+    std::vector<lsm2d_iteration_stats> stats((size_t) lsm2d_stats_capacity(&ap));
+    // with publish_correspondences the call also hands back what the reference leaves in slice->correspondences(): the pairs of the last
+    // iteration (only its inliers under keep_only_inlier_correspondences)
+    std::vector<lsm2d_correspondence> pairs;
+    std::vector<int32_t> n_pairs(slices.size(), 0);
+    size_t pair_capacity = 0;
+    if (param_publish_correspondences.value()) {
+      for (size_t s = 0; s < slices.size(); ++s) {
+        const size_t need = slices[s].finder == LSM2D_FINDER_PROJECTIVE ? (size_t) slices[s].projector.canvas_cols : laser_slices[s].n_moving;
+        pair_capacity     = need > pair_capacity ? need : pair_capacity;
+      }
+      pair_capacity = pair_capacity > 0 ? pair_capacity : 1;
+      pairs.resize(pair_capacity * slices.size());
+    }
+    throwOnError(lsm2d_align_batch_pairs(_ctx, &ap, &batch, pose, information, &status, &iterations, stats.data(),
+                                         pairs.empty() ? nullptr : pairs.data(), (int32_t) pair_capacity, n_pairs.data()),
+                 who, _ctx);
     _last_status     = status;
     _last_iterations = iterations;
     setMovingInFixed(geometry2d::v2t(Vector3f(pose[0], pose[1], pose[2])));
     _writeBack(status, information, iterations, stats);
 
     if (param_publish_correspondences.value()) {
-      std::vector<lsm2d_correspondence> pairs;
       for (size_t s = 0; s < laser_slices.size(); ++s) {
-        // X_eff = S^-1 X is what the slice's finder saw in the last iteration
-        Isometry2f S = geometry2d::v2t(Vector3f(slices[s].sensor_in_robot[0], slices[s].sensor_in_robot[1], slices[s].sensor_in_robot[2]));
-        float xe[3];
-        lsm2d_srrg::poseToArray(S.inverse() * movingInFixed(), xe);
-        const size_t capacity = slices[s].finder == LSM2D_FINDER_PROJECTIVE ? (size_t) slices[s].projector.canvas_cols : laser_slices[s].n_moving;
-        pairs.resize(capacity > 0 ? capacity : 1);
-        int32_t k = 0;
-        throwOnError(lsm2d_find_correspondences(_ctx, &slices[s], fixed_sets[s], 0, moving_sets[s], 0, xe, pairs.data(), (int32_t) pairs.size(), &k),
-                     who, _ctx);
-        CorrespondenceVector& out = laser_slices[s].correspondences();
-        out.resize(k);
-        for (int32_t i = 0; i < k; ++i) {
-          out[i] = Correspondence(pairs[i].fixed_idx, pairs[i].moving_idx);
+        CorrespondenceVector& out          = laser_slices[s].correspondences();
+        const lsm2d_correspondence* mine   = pairs.data() + s * pair_capacity;
+        out.resize((size_t) n_pairs[s]);
+        for (int32_t i = 0; i < n_pairs[s]; ++i) {
+          out[i] = Correspondence(mine[i].fixed_idx, mine[i].moving_idx);
         }
       }
     }

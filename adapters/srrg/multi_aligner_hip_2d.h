@@ -4,8 +4,9 @@
 // call that runs the whole loop on the device.  It consumes the same configuration -- max_iterations, min_num_inliers,
 // slice_processors (configurations/stage_segway_double_config_MULTI.json:700-732): every AlignerSliceProcessorLaser2D[WithSensor]
 // becomes an lsm2d slice (finder, robustifier, min_num_correspondences, sensor extrinsics), the AlignerSliceOdom2DPrior
-// (MULTI.json:402-422) becomes the lsm2d_prior; a slice processor of any other type is an ERROR, never skipped, and so is a non-default
-// enable_inlier_only_runs / keep_only_inlier_correspondences / termination_criteria (MULTI.json:606-610,627-630).  After the call
+// (MULTI.json:402-422) becomes the lsm2d_prior; a slice processor of any other type is an ERROR, never skipped.  enable_inlier_only_runs /
+// keep_only_inlier_correspondences (MULTI.json:606-610) go to the device loop as they are, a termination_criteria object (:627-630) is
+// translated into the epsilon it carries (one that carries none is refused).  After the call
 // the pose, the status, the information matrix and the iteration statistics are written back into the base class.
 // Device clouds persist across calls (reserved sets, refilled), one per distinct host cloud.
 #pragma once
@@ -25,15 +26,16 @@ namespace srrg2_laser_slam_2d {
     PARAM(srrg2_core::PropertyInt, device_id, "HIP device ordinal", 0, 0);
     PARAM(srrg2_core::PropertyInt,
           publish_correspondences,
-          "1: after compute() every laser slice's correspondences() holds the pairs at the final estimate (one extra finder call per slice; "
-          "callers use them for drawing only: apps/visual_test_aligner_2d.cpp:129-143)",
+          "1: after compute() every laser slice's correspondences() holds the pairs of the last iteration, as the reference leaves them (only "
+          "its inliers with keep_only_inlier_correspondences; one extra finder pass per slice; callers use them for drawing only: "
+          "apps/visual_test_aligner_2d.cpp:129-143)",
           0,
           0);
     PARAM(srrg2_core::PropertyFloat,
           termination_chi_epsilon,
           "device-side termination criterion: stop after an iteration whose total chi2 differs from the previous one's by less than this "
-          "ratio (0: run max_iterations, what an unset termination_criteria means; a termination_criteria OBJECT cannot run on the device "
-          "and is refused)",
+          "ratio (0: run max_iterations, what an unset termination_criteria means; a termination_criteria OBJECT with a float property "
+          "'epsilon' is translated into this value)",
           0.f,
           0);
     virtual ~MultiAlignerHIP2D();

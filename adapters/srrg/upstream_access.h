@@ -66,10 +66,10 @@ namespace lsm2d_srrg {
   inline CorrespondenceVector& sliceCorrespondences(const SlicePtr_& slice_) {
     return slice_->_correspondences;
   }
-  // aligner options the shipped configurations carry (MULTI.json:606-610,627-630,704-708,729-731) and the device loop does not
-  // implement as objects: read here so that MultiAlignerHIP2D can REFUSE a non-default value instead of running another algorithm.
+  // aligner options the shipped configurations carry (MULTI.json:606-610,627-630,704-708,729-731), handed on to the device loop
+  // (lsm2d_aligner_params.enable_inlier_only_runs / keep_only_inlier_correspondences / termination_chi_epsilon).
   // UPSTREAM: the PARAM types behind "enable_inlier_only_runs" / "keep_only_inlier_correspondences" (bool or int) and the class behind
-  // "termination_criteria" -- only `.value()` and a conversion to bool are used.
+  // "termination_criteria" -- only `.value()`, a conversion to bool and a property looked up by name are used.
   template <typename Aligner_>
   inline bool inlierOnlyRunsEnabled(const Aligner_& aligner_) {
     return (bool) aligner_.param_enable_inlier_only_runs.value();
@@ -81,6 +81,20 @@ namespace lsm2d_srrg {
   template <typename Aligner_>
   inline bool terminationCriteriaSet(const Aligner_& aligner_) {
     return (bool) aligner_.param_termination_criteria.value();
+  }
+  // The criteria OBJECT as an epsilon.  The aligner-side class is not in the reference tree; the one in-tree trace of such a criterion is the
+  // solver's SimpleTerminationCriteria with its float property "epsilon" -- "ratio of decay of chi2 between iteration" (MULTI.json:218-223) --
+  // which is exactly what lsm2d_aligner_params.termination_chi_epsilon implements.  A criteria object that carries a float property of that
+  // name is translated; any other object returns a negative value and MultiAlignerHIP2D refuses it (it cannot know what it asks for).
+  // UPSTREAM: Configurable::property(name) and the PropertyFloat type behind it.
+  template <typename Aligner_>
+  inline float terminationCriteriaEpsilon(const Aligner_& aligner_) {
+    auto criteria = aligner_.param_termination_criteria.value();
+    if (!criteria) {
+      return 0.f;
+    }
+    auto* eps = dynamic_cast<srrg2_core::PropertyFloat*>(criteria->property("epsilon"));
+    return eps ? eps->value() : -1.f;
   }
   // information matrix of the odometry prior factor.  UPSTREAM: the prior slice's factor carries its own information matrix; the
   // shipped configuration sets none (MULTI.json:402-422), i.e. the factor's default, taken to be identity.

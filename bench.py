@@ -39,6 +39,8 @@ N_SIMD = 256 * 4             # same guide: 256 CUs x 4 SIMD-32; a wave64 VALU in
 SPEC_CLOCK_MHZ = 2400.0      # same guide: max clock (spec)
 L2_PEAK_GBS = 34500.0        # same guide: ~34.5 TB/s aggregate over the eight per-XCD L2s
 VALU_CYCLES = 2.0            # a transcendental (the stream's one v_rsq_f32 per point) over 4: one slot more than SQ_INSTS_VALU counts for it
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # same guide: fp32 vector (non-matrix) peak
+FLOPS_PER_POINT = 60.0       # "A ~ 60 N_m" algorithmic flops per projected point
 
 
 def algorithmic_bytes_per_alignment(role: str, finder: str, n_map: int, n_scan_mean: float, bins: int, iterations: int) -> float:
@@ -127,7 +129,26 @@ def main() -> None:
                     help="BASELINE configs[3]: a fixed sweep of this many candidate alignments sharded over the ranks (strong scaling); "
                          "overrides --scans with this rank's share and gathers the poses on every rank at the end")
     ap.add_argument("--unique-scans", type=int, default=0, help="ray-cast only this many scans; candidates reuse them through an index array (loop-closure sweep)")
+    ap.add_argument("--shard-by", choices=["work", "count"], default="work",
+                    help="--total-candidates: shard the sweep over the ranks by estimated work (lsm2d_estimate_work: chunks of the map each candidate's first "
+                         "iteration streams) or by candidate count")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): this process has not touched the GPU yet -- it becomes the
+    # launcher itself: N fresh rank processes through torch.distributed.run, exactly as the driver starts them, rank 0's JSON line relayed, its exit
+    # code ours.  (Until round 3 this case silently ran ONE rank and printed n_gpus: 1.)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        import torch                       # (importing torch / counting devices does not initialise the GPU)
+        n_dev = torch.cuda.device_count()
+        if os.environ.get("LSM2D_BENCH_BACKEND", "nccl") == "nccl" and n_dev < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d device(s) visible (RCCL wants one device per rank; LSM2D_BENCH_BACKEND=gloo lets ranks share a card)" % (args.gpus, n_dev))
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.run(cmd)        # stdout / stderr inherited: rank 0's line is the only JSON line
+        raise SystemExit(child.returncode)
 
     import torch
     import torch.distributed as dist
@@ -135,8 +156,8 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line's n_gpus must be the number of ranks that ran")
     # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (tests): LSM2D_BENCH_BACKEND=gloo lets several ranks share a card
     # (RCCL refuses two ranks on one device); the ranks then run the same kernels, shards and cross-rank check, only the transport differs
     backend = os.environ.get("LSM2D_BENCH_BACKEND", "nccl")
@@ -157,24 +178,28 @@ def main() -> None:
 
     strong = args.total_candidates > 0
     if strong:
-        lo, hi = distributed.shard_range(args.total_candidates, rank, world)
+        lo, hi = distributed.shard_range(args.total_candidates, rank, world)      # (refined below by estimated work: --shard-by)
         args.scans = hi - lo
 
     # ---- inputs: the shared local map comes from rank 0 (RCCL broadcast), each rank ray-casts its own scans
     world_geom = synth.make_world(args.seed)
     map_dev = distributed.broadcast_map(
         synth.make_map(world_geom, args.map_points, seed=args.seed) if rank == 0 else None, args.map_points, local_rank)
-    n_unique = args.unique_scans if 0 < args.unique_scans < args.scans else args.scans
-    wl = synth.make_workload(n_unique, args.map_points, seed=args.seed, n_beams=args.beams, pose_seed_offset=rank,
+    # strong scaling: ONE global candidate list (every rank derives the same one from the seed) cut into this rank's shard; weak: every rank its own scans
+    n_list = args.total_candidates if strong else args.scans
+    n_unique = args.unique_scans if 0 < args.unique_scans < n_list else n_list
+    wl = synth.make_workload(n_unique, args.map_points, seed=args.seed, n_beams=args.beams, pose_seed_offset=0 if strong else rank,
                              world=world_geom, map_points=np.zeros((0, 4), np.float32))
     scan_index = None
-    if n_unique < args.scans:      # candidate i = (scan i mod n_unique, its own perturbed initial guess)
-        scan_index = (np.arange(args.scans) % n_unique).astype(np.int32)
-        st = synth.Stream(args.seed + 1000 + rank, salt=9)
-        delta = st.uniform(3 * args.scans, -0.05, 0.05).reshape(args.scans, 3)
+    if n_unique < n_list:      # candidate i = (scan i mod n_unique, its own perturbed initial guess)
+        scan_index = (np.arange(n_list) % n_unique).astype(np.int32)
+        st = synth.Stream(args.seed + 1000 + (0 if strong else rank), salt=9)
+        delta = st.uniform(3 * n_list, -0.05, 0.05).reshape(n_list, 3)
         t_true = synth.invert_poses(wl.x_true)[scan_index]
         wl.x_true = wl.x_true[scan_index]
         wl.x0 = synth.invert_poses(synth.compose_poses(t_true, delta)).astype(np.float32)
+    elif strong:
+        scan_index = np.arange(n_list, dtype=np.int32)
     # a dedicated torch stream, made current: the kernels, the HIP events around them and torch's own view all sit on it
     # (the legacy default stream synchronises device-wide, which doubles the per-call latency of the single-scan config)
     torch.cuda.synchronize()
@@ -196,6 +221,23 @@ def main() -> None:
     aligner = api.MultiAligner2D(ctx, max_iterations=args.iterations, min_num_inliers=10)
     robust = api.RobustifierCauchy(args.cauchy) if args.cauchy > 0 else None
     aligner.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10, robustifier=robust))
+    shard_info = None
+    if strong:
+        # this rank's shard of the global list: by estimated work (lsm2d_estimate_work -- with the exact culling an alignment's time follows the number
+        # of map chunks it streams) or by count.  Every rank computes the same estimates, hence the same cuts: no collective.
+        shards = [distributed.shard_range(n_list, r, world) for r in range(world)]
+        if args.shard_by == "work" and args.role == "A" and args.finder == "projective":
+            work = aligner.estimate_work([scan_set], [map_set], wl.x0, fixed_index=scan_index[None, :])
+            shards = distributed.shard_by_work(work, world)
+            tot = [float(work[a:b].sum()) for a, b in shards]
+            shard_info = {"by": "work", "candidates_per_rank": [b - a for a, b in shards], "work_max_over_mean": max(tot) / (sum(tot) / world) if sum(tot) > 0 else 1.0,
+                          "work_max_over_mean_if_sharded_by_count": (lambda t: max(t) / (sum(t) / world))([float(work[a:b].sum()) for a, b in
+                                                                                                            [distributed.shard_range(n_list, r, world) for r in range(world)]])}
+        else:
+            shard_info = {"by": "count", "candidates_per_rank": [b - a for a, b in shards]}
+        lo, hi = shards[rank]
+        args.scans = hi - lo
+        wl.x0 = wl.x0[lo:hi]; wl.x_true = wl.x_true[lo:hi]; scan_index = scan_index[lo:hi]
     if args.role == "A":
         x0, x_true = wl.x0, wl.x_true
         idx = None if scan_index is None else scan_index[None, :]
@@ -251,8 +293,7 @@ def main() -> None:
     # candidate is PART OF THE STEP and is timed with it (round 2 gathered once, behind the timed region)
     gather_pad = 0
     if strong and use_dist:
-        counts = [distributed.shard_range(args.total_candidates, r, world) for r in range(world)]
-        gather_pad = max(h - l for l, h in counts)
+        gather_pad = max(h - l for l, h in shards)
         gather_buf = np.zeros((gather_pad, 3), np.float32)
     gathered = None
     for i_step in range(args.steps):
@@ -334,8 +375,9 @@ def main() -> None:
                 "hbm": {"effective_l2_served_GBs": effective, "effective_over_hbm_peak": effective / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": bytes_per_alignment * args.scans, "hbm_real_GBs": None, "hbm_real_frac": None,
                         "peak_GBs": HBM_PEAK_GBS},
-                "note": "the map is L2-resident (TCC hit > 99 %), so HBM does not bind: frac = VALU issue slots used / slots the 1024 SIMDs had at the "
-                        "clock measured inside the launch; hbm.* keeps the SURVEY 8(d) algorithmic figure and the counter-measured DRAM rate"}
+                "note": "the map is L2-resident (TCC hit > 99 %), so HBM does not bind: frac = VALU issue slots used / slots the 1024 SIMDs have at the "
+                        "2.4 GHz spec clock (frac_at_in_kernel_clock: at the clock measured inside the launch); hbm.* keeps the SURVEY 8(d) algorithmic figure "
+                        "and the counter-measured DRAM rate"}
         # what the L2s serve: the kernel's vector-memory read instructions x 1 KiB (16 bytes per lane) against the 34.5 TB/s of the eight L2s
         # (MI355X_MICROARCH.md, "L2 (per XCD)"); the instruction count is a committed counter like the VALU count (profiles/counters.json)
         if counters and counters.get("vmem_rd_insts_per_launch"):
@@ -350,10 +392,18 @@ def main() -> None:
             # ~12-18 cycles -- the stream_floor block below prices the launch with the measured costs instead.)
             slots = counters["valu_insts_per_launch"] + counters.get("trans_insts_per_launch", 0.0)
             roof["achieved"] = slots / (k_ms * 1e-3) / 1e9
+            # `frac` is priced against the SPEC clock (2.4 GHz) since round 4 -- the peak the guide prints; the chip holds 2.1-2.3 GHz under this load,
+            # so the figure against the clock measured inside the launch (the slots the SIMDs really had) reads ~7 % higher: kept beside it
+            roof["peak_at_in_kernel_clock"] = roof["peak"]
+            roof["peak"] = N_SIMD * SPEC_CLOCK_MHZ * 1e6 / VALU_CYCLES / 1e9
             roof["frac"] = roof["achieved"] / roof["peak"]
-            # the same slots against the SPEC clock (2.4 GHz): the chip holds 2.1-2.3 GHz under this load, so the in-kernel-clock figure above
-            # reads ~8 % higher than this one; both are printed, `frac` stays the in-kernel-clock one (the slots the SIMDs really had)
-            roof["frac_at_spec_clock"] = roof["achieved"] / (N_SIMD * SPEC_CLOCK_MHZ * 1e6 / VALU_CYCLES / 1e9)
+            roof["frac_at_spec_clock"] = roof["frac"]
+            roof["frac_at_in_kernel_clock"] = roof["achieved"] / roof["peak_at_in_kernel_clock"]
+            if counters.get("wave_points_per_launch"):
+                # what of that issue rate is the reference's arithmetic: SURVEY 8(d)'s 60 flop per projected point x the points the kernel really visits
+                # (counted: one v_rsq_f32 wave-instruction per 64 point visits) against the fp32 vector peak
+                uf = FLOPS_PER_POINT * counters["wave_points_per_launch"] * 64.0 / (k_ms * 1e-3) / 1e12
+                roof["useful_flops"] = {"TFLOPs": uf, "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS, "frac": uf / FP32_VECTOR_PEAK_TFLOPS, "flops_per_point_visit": FLOPS_PER_POINT}
             roof["counters_are"] = "SQ_INSTS_VALU / vmem / HBM bytes per launch are COMMITTED constants (profiles/counters.json, checked against a hash of the kernel sources); only the launch time and the clock are measured live"
             roof["valu_insts_per_launch"] = counters["valu_insts_per_launch"]
             roof["trans_insts_per_launch"] = counters.get("trans_insts_per_launch")
@@ -405,6 +455,9 @@ def main() -> None:
             out["cross_rank_check"] = cross
         if per_rank_ms is not None:
             out["ms_per_step_per_rank"] = per_rank_ms
+            out["ms_per_step_rank_max"] = max(per_rank_ms); out["ms_per_step_rank_min"] = min(per_rank_ms)
+        if shard_info is not None:
+            out["sharding"] = shard_info
         if gather_pad:
             out["strong_scaling_gather"] = "all_gather of %d x 12 B per rank inside every timed step" % gather_pad
         if world == 1 and not args.no_cpu_baseline:

@@ -29,14 +29,18 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 130 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
+#define LSM2D_VERSION 140 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
                              0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes;
                              0.2.0: + lsm2d_clip_scene_voxelized, lsm2d_sweep_* (multi-device loop-closure sweep), in-kernel clock options;
                              0.2.1: + lsm2d_cloudset_cloud_sizes, pinned / device-resident ranges in lsm2d_preprocess_scans, options
                                     "distmap_build", "grid_big_threshold", "find_path", "zero_copy_max";
                              0.3.0: + LSM2D_FINDER_KDTREE (the reference KD-tree's own build and single-leaf descent, honouring max_leaf_range /
                                     min_leaf_points: lsm2d_slice_params grew two fields), lsm2d_aligner_params.termination_chi_epsilon,
-                                    sweep option "peer_copy" */
+                                    sweep option "peer_copy";
+                             0.4.0: lsm2d_iteration_stats grew the order-independent digest of the iteration's correspondence set (pair_digest_lo / _hi);
+                                    lsm2d_aligner_params grew enable_inlier_only_runs / keep_only_inlier_correspondences (no longer refused);
+                                    + lsm2d_align_batch_pairs (the correspondences the aligner leaves in its slices), lsm2d_stats_capacity,
+                                    lsm2d_pair_hash, lsm2d_estimate_work (work-aware sharding of a candidate sweep) */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -107,7 +111,21 @@ typedef struct {
    * iteration"): 0 = off; > 0: the loop stops after an iteration whose total chi^2 (inliers + kernelised outliers) differs from the
    * previous iteration's by less than epsilon times itself.  The iteration that triggers the stop is still solved and applied. */
   float   termination_chi_epsilon;
+  /* MultiAligner2D's two remaining options (MULTI.json:606-610,704-708; both 0 in the shipped configurations).  The upstream class is not in
+   * the reference tree, so their semantics are RESTATED from the parameters' own doc strings (PARITY.md section 2, [UPSTREAM-MEMORY]):
+   * enable_inlier_only_runs ("toggles additional inlier only runs if sufficient inliers are available"): when the regular loop ended without
+   *   a failure and its last iteration counted n_inliers >= min_num_inliers, a second loop of up to max_iterations iterations follows in which
+   *   a pair whose factor is not an inlier under its slice's robustifier (chi^2 >= chi_threshold) contributes nothing and an inlier contributes
+   *   with weight 1 (no kernel); finders, gates, statistics, the termination criterion (afresh) and the status rules are those of the regular
+   *   loop.  An alignment then runs up to 2 * max_iterations iterations: see lsm2d_stats_capacity.
+   * keep_only_inlier_correspondences ("toggles removal of correspondences which factors are not inliers in the last iteration"): the
+   *   correspondences the aligner leaves in its slices (lsm2d_align_batch_pairs) hold only the pairs whose factor was an inlier in the last
+   *   iteration; poses, information matrices and statistics do not depend on it. */
+  int32_t enable_inlier_only_runs;
+  int32_t keep_only_inlier_correspondences;
 } lsm2d_aligner_params;
+/* iterations one alignment may run under `aligner`, i.e. the row length of out_stats: max_iterations, doubled with enable_inlier_only_runs (>= 1) */
+int32_t lsm2d_stats_capacity(const lsm2d_aligner_params* aligner);
 
 /* Optional odometry-prior cue (AlignerSliceOdom2DPrior, MULTI.json:402-422): e = t2v(Z^-1 X), information omega. */
 typedef struct {
@@ -122,7 +140,17 @@ typedef struct { int32_t fixed_idx, moving_idx; } lsm2d_correspondence;
 typedef struct {
   int32_t n_correspondences, n_inliers, n_outliers;
   float   chi_inliers, chi_outliers;
+  /* order-independent digest of the iteration's correspondence SET -- the pairs the reference aligner exposes per slice
+   * (apps/visual_test_aligner_2d.cpp:129-143): the wrapping 64-bit sum of lsm2d_pair_hash(slice, fixed_idx, moving_idx) over every pair counted
+   * in n_correspondences (all slices, skipped ones included).  Equal digests <=> the same pairs went into the iteration (up to a 2^-64 hash
+   * collision); tests use it to tell "same pairs, different summation order" from "different pairs".  Computed only when statistics are asked for. */
+  uint32_t pair_digest_lo, pair_digest_hi;
 } lsm2d_iteration_stats;
+/* the per-pair hash behind pair_digest -- plain 32-bit integer arithmetic, the same on the host, in the kernels and in the CPU oracle:
+ *   a = fixed_idx * 0x9E3779B1;  b = (moving_idx ^ (slice * 0x632BE5AB)) * 0x85EBCA77;
+ *   lo = a ^ rotl(b, 13);  hi = b ^ rotl(a, 19);  lo += rotl(lo, 17) ^ b;  hi += rotl(hi, 11) ^ a;  hash = hi << 32 | lo
+ * (so a caller holding a correspondence vector can form the digest it should see) */
+uint64_t lsm2d_pair_hash(uint32_t slice, uint32_t fixed_idx, uint32_t moving_idx);
 
 typedef struct lsm2d_context  lsm2d_context;
 typedef struct lsm2d_cloudset lsm2d_cloudset;
@@ -312,7 +340,26 @@ int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params* aligner, c
                       float* out_H,                     /* [n][9]  information matrix = H of the last iteration; may be NULL */
                       int32_t* out_status,              /* [n]     lsm2d_status >= 0 */
                       int32_t* out_iterations,          /* [n]     iterations started; may be NULL */
-                      lsm2d_iteration_stats* out_stats  /* [n][max_iterations]; may be NULL */);
+                      lsm2d_iteration_stats* out_stats  /* [n][lsm2d_stats_capacity(aligner)]; may be NULL */);
+
+/* What an alignment of `batch` will cost relative to the others, WITHOUT running it: for projective slices against a map-sized moving cloud the
+ * number of chunks of that cloud (of 512) that survive the exact culling against the alignment's fixed canvas at its start pose -- what its first
+ * iteration streams (k_cull_estimate: the quantity lsm2d_align_batch itself places a batch on the chip by); 1 for every alignment when there is
+ * no such slice.  A caller that shards a candidate sweep over several devices or processes (MultiLoopDetectorBruteForce2D's loop, MULTI.json:964-986)
+ * balances the shards by the SUM of these numbers instead of by candidate count: with the culling an alignment's time follows it (33-59 % of the
+ * chunks survive on configs[1]).  out_work: [n_alignments]. */
+int lsm2d_estimate_work(lsm2d_context* ctx, const lsm2d_batch* batch, int32_t* out_work);
+
+/* The same call, additionally handing back what aligner->compute() leaves in every slice's correspondence vector (the reference's
+ * slice->correspondences(), apps/visual_test_aligner_2d.cpp:129-143): the pairs of the LAST iteration each alignment started, in the finder's
+ * order (ascending column / ascending moving index) -- with keep_only_inlier_correspondences only those whose factor was an inlier in that
+ * iteration.  out_pairs: [n][n_slices][pair_capacity]; out_n_pairs: [n][n_slices].  pair_capacity must hold a slice's largest possible vector
+ * (canvas_cols of a projective slice, the largest moving cloud of a point-query slice) or the call returns LSM2D_CAPACITY_EXCEEDED.  The
+ * pairs are re-derived after the aligner kernel from the pose its last iteration started at (one finder pass per alignment and slice, same
+ * arithmetic, hence the same pairs: tests compare their digest with the in-kernel one); out_pairs == NULL is lsm2d_align_batch. */
+int lsm2d_align_batch_pairs(lsm2d_context* ctx, const lsm2d_aligner_params* aligner, const lsm2d_batch* batch,
+                            float* out_pose, float* out_H, int32_t* out_status, int32_t* out_iterations, lsm2d_iteration_stats* out_stats,
+                            lsm2d_correspondence* out_pairs, int32_t pair_capacity, int32_t* out_n_pairs);
 
 /* ---- the candidate loop of MultiLoopDetectorBruteForce2D / MultiRelocalizer2D (MULTI.json:964-986, :749-769) over the GPUs of one
  * node, in ONE process and without Python: a context per device, the submap uploaded to device_ids[0] once and replicated device to

@@ -21,6 +21,16 @@
  * (Round 1 used atan(min/max) with a degree-7 polynomial: one more transcendental per point on the device.) */
 static const float LSMO_ASIN_C[7] = {
   1.666723490e-01f, 7.478348911e-02f, 4.762428626e-02f, 1.043075230e-02f, 9.340071678e-02f, -1.153038889e-01f, 1.237212196e-01f};
+/* the per-pair term of lsmo_iter_stats.pair_digest: plain 32-bit integer arithmetic (restated here on its own; the tests hold it against the
+ * device's digest) */
+unsigned long long lsmo_pair_hash(unsigned int slice, unsigned int f, unsigned int m) {
+  const unsigned int a = f * 0x9E3779B1u, b = (m ^ (slice * 0x632BE5ABu)) * 0x85EBCA77u;
+  unsigned int lo = a ^ ((b << 13) | (b >> 19)), hi = b ^ ((a << 19) | (a >> 13));
+  lo += ((lo << 17) | (lo >> 15)) ^ b;
+  hi += ((hi << 11) | (hi >> 21)) ^ a;
+  return ((unsigned long long) hi << 32) | (unsigned long long) lo;
+}
+
 #define LSMO_PI_F      3.14159274101257324f
 #define LSMO_HALF_PI_F 1.57079637050628662f
 
@@ -319,7 +329,7 @@ typedef struct {
 
 static void* batch_worker(void* arg) {
   batch_job* j = (batch_job*) arg;
-  lsmo_iter_stats* st = (lsmo_iter_stats*) malloc(sizeof(lsmo_iter_stats) * (size_t) (j->ap->max_iterations > 0 ? j->ap->max_iterations : 1));
+  lsmo_iter_stats* st = (lsmo_iter_stats*) malloc(sizeof(lsmo_iter_stats) * (size_t) (j->ap->max_iterations > 0 ? j->ap->max_iterations : 1) * 2);
   for (int i = j->begin; i < j->end; ++i) {
     const lsmo_point* f = j->fixed_packed + j->offs[i];
     const int nf = j->offs[i + 1] - j->offs[i];

@@ -98,12 +98,27 @@ typedef struct {
                                          MULTI.json:218-223, documents its epsilon as the "ratio of decay of chi2 between iteration"): 0 = off;
                                          > 0: stop after an iteration whose total chi^2 (inliers + kernelised outliers) differs from the previous
                                          iteration's by less than epsilon times itself; that iteration is still solved and applied. */
+  /* MultiAligner2D's two remaining options (MULTI.json:606-610,704-708; both 0 in the shipped configurations).  The upstream class is not in the
+   * tree: semantics RESTATED from the parameters' doc strings (PARITY.md section 2, [UPSTREAM-MEMORY]).
+   * enable_inlier_only_runs ("toggles additional inlier only runs if sufficient inliers are available"): when the regular loop ended without a
+   *   failure and its last iteration counted n_in >= min_num_inliers, a second loop of up to max_iterations iterations follows in which a pair whose
+   *   factor is not an inlier under its slice's robustifier (chi^2 >= tau) contributes nothing to H and b and an inlier contributes with weight 1;
+   *   finders, gates, statistics, the termination criterion (afresh) and the status rules are the regular loop's.  stats then needs room for
+   *   2 * max_iterations entries.
+   * keep_only_inlier_correspondences ("toggles removal of correspondences which factors are not inliers in the last iteration"): the pairs handed
+   *   back by lsmo_align_pairs_* hold only the last iteration's inliers; nothing else depends on it. */
+  int   enable_inlier_only_runs;
+  int   keep_only_inlier_correspondences;
 } lsmo_aligner_params;
 
 typedef struct {
   int   n_corr, n_in, n_out;
   float chi_in, chi_out;
+  /* order-independent digest of the iteration's correspondence set (test instrument, not part of the reference): the wrapping 64-bit sum of
+   * lsmo_pair_hash(slice, fixed_idx, moving_idx) over every pair counted in n_corr, low and high word */
+  unsigned int pair_digest_lo, pair_digest_hi;
 } lsmo_iter_stats;
+unsigned long long lsmo_pair_hash(unsigned int slice, unsigned int fixed_idx, unsigned int moving_idx);
 
 /* ---- scalar helpers --------------------------------------------------------------------- */
 float lsmo_atan2f(float y, float x);     /* the fixed-polynomial atan2 both CPU and GPU evaluate */
@@ -171,6 +186,22 @@ int lsmo_align_d(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_p
                  const lsmo_point* const* moving, const int* n_moving,
                  const double x0[3], double x_out[3], double H_out[9],
                  lsmo_iter_stats* stats, int* iterations_done);
+/* the same, additionally handing back what the aligner leaves in every slice's correspondence vector (slice->correspondences(),
+ * apps/visual_test_aligner_2d.cpp:129-143): the pairs of the last iteration started, finder order; with keep_only_inlier_correspondences only
+ * that iteration's inliers.  out_pairs[s]: room for canvas_cols resp. n_moving[s] pairs; out_n_pairs[s]: how many.  stats: room for
+ * max_iterations * (1 + enable_inlier_only_runs) entries. */
+int lsmo_align_pairs_f(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_params* sp,
+                       const lsmo_point* const* fixed, const int* n_fixed, const lsmo_point* const* moving, const int* n_moving,
+                       const float x0[3], float x_out[3], float H_out[9], lsmo_iter_stats* stats, int* iterations_done,
+                       lsmo_corr* const* out_pairs, int* out_n_pairs);
+int lsmo_align_pairs_d(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_params* sp,
+                       const lsmo_point* const* fixed, const int* n_fixed, const lsmo_point* const* moving, const int* n_moving,
+                       const double x0[3], double x_out[3], double H_out[9], lsmo_iter_stats* stats, int* iterations_done,
+                       lsmo_corr* const* out_pairs, int* out_n_pairs);
+int lsmo_align_pairs_r(const lsmo_aligner_params* ap, int n_slices, const lsmo_slice_params* sp,
+                       const lsmo_point* const* fixed, const int* n_fixed, const lsmo_point* const* moving, const int* n_moving,
+                       const float x0[3], float x_out[3], float H_out[9], lsmo_iter_stats* stats, int* iterations_done,
+                       lsmo_corr* const* out_pairs, int* out_n_pairs);
 
 /* ---- sensor processing: RawDataPreprocessorProjective2D ----------------------------
  * sensor_processing/raw_data_preprocessor_projective_2d.cpp:13-51 (compute) and :77-104 (_processLaserMessage).

@@ -38,12 +38,17 @@ class SliceParams(C.Structure):
 class AlignerParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("min_num_inliers", C.c_int), ("damping", C.c_float),
                 ("has_prior", C.c_int), ("prior_z", C.c_float * 3), ("prior_omega", C.c_float * 9), ("device_order", C.c_int),
-                ("termination_chi_epsilon", C.c_float)]
+                ("termination_chi_epsilon", C.c_float), ("enable_inlier_only_runs", C.c_int), ("keep_only_inlier_correspondences", C.c_int)]
 
 
 class IterStats(C.Structure):
     _fields_ = [("n_corr", C.c_int), ("n_in", C.c_int), ("n_out", C.c_int),
-                ("chi_in", C.c_float), ("chi_out", C.c_float)]
+                ("chi_in", C.c_float), ("chi_out", C.c_float), ("pair_digest_lo", C.c_uint), ("pair_digest_hi", C.c_uint)]
+
+    @property
+    def pair_digest(self) -> int:
+        """order-independent 64-bit digest of the iteration's correspondence set (lsm2d_oracle.h)"""
+        return (int(self.pair_digest_hi) << 32) | int(self.pair_digest_lo)
 
 
 def _host_stamp() -> str:
@@ -90,7 +95,24 @@ def lib():
         _lib.lsmo_logf_fixed.argtypes = [C.c_float]
         _lib.lsmo_sincosf.restype = None
         _lib.lsmo_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib.lsmo_pair_hash.restype = C.c_ulonglong
+        _lib.lsmo_pair_hash.argtypes = [C.c_uint, C.c_uint, C.c_uint]
     return _lib
+
+
+def pair_digest(pairs, slice_index: int = 0) -> int:
+    """wrapping 64-bit sum of lsmo_pair_hash(slice, fixed_idx, moving_idx) over int32 pairs [k, 2] (numpy restatement of the hash; the C
+    definition is checked against it in tests/test_oracle.py)"""
+    p = np.ascontiguousarray(pairs, np.int64).reshape(-1, 2)
+    M = np.uint32
+    with np.errstate(over="ignore"):
+        f = p[:, 0].astype(np.uint32); m = p[:, 1].astype(np.uint32)
+        rot = lambda v, r: (v << M(r)) | (v >> M(32 - r))
+        a = f * M(0x9E3779B1); b = (m ^ M((slice_index * 0x632BE5AB) & 0xFFFFFFFF)) * M(0x85EBCA77)
+        lo = a ^ rot(b, 13); hi = b ^ rot(a, 19)
+        lo = lo + (rot(lo, 17) ^ b); hi = hi + (rot(hi, 11) ^ a)
+        tot = (hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)
+        return int(tot.sum(dtype=np.uint64)) & 0xFFFFFFFFFFFFFFFF
 
 
 def log_fixed(x):
@@ -123,11 +145,13 @@ def slice_params(finder=FINDER_PROJECTIVE, canvas_cols=1081, angle_min=-np.pi, a
 
 
 def aligner_params(max_iterations=20, min_num_inliers=10, damping=0.0, prior_z=None, prior_omega=None, device_order=False,
-                   termination_chi_epsilon=0.0) -> AlignerParams:
+                   termination_chi_epsilon=0.0, enable_inlier_only_runs=False, keep_only_inlier_correspondences=False) -> AlignerParams:
     """device_order: sum H, b and the statistics in the HIP kernels' order (fp32 mirror only) -> bit-identical to the device."""
     ap = AlignerParams()
     ap.device_order = 1 if device_order else 0
     ap.termination_chi_epsilon = termination_chi_epsilon
+    ap.enable_inlier_only_runs = 1 if enable_inlier_only_runs else 0
+    ap.keep_only_inlier_correspondences = 1 if keep_only_inlier_correspondences else 0
     ap.max_iterations, ap.min_num_inliers, ap.damping = max_iterations, min_num_inliers, damping
     ap.has_prior = 0 if prior_z is None else 1
     if prior_z is not None:
@@ -230,9 +254,10 @@ def solve_update(H, b, pose, damping=0.0, double=False):
     return rc, pose, dx
 
 
-def align(ap: AlignerParams, slices, fixed, moving, x0, double=False):
+def align(ap: AlignerParams, slices, fixed, moving, x0, double=False, want_pairs=False):
     """Multi-slice alignment. ``slices``: list of SliceParams; ``fixed``/``moving``: lists of clouds.
-    Returns dict(status, pose, H, stats[list of IterStats], iterations)."""
+    Returns dict(status, pose, H, stats[list of IterStats], iterations); with want_pairs also pairs = per slice the int32 [k, 2] correspondences
+    the aligner leaves behind (last iteration started; only its inliers under keep_only_inlier_correspondences)."""
     dt, sfx = _real(double)
     n = len(slices)
     sp = (SliceParams * n)(*slices)
@@ -240,10 +265,17 @@ def align(ap: AlignerParams, slices, fixed, moving, x0, double=False):
     pf = (C.c_void_p * n)(*[p for _, p in fx]); pm = (C.c_void_p * n)(*[p for _, p in mv])
     nf = (C.c_int * n)(*[len(a) for a, _ in fx]); nm = (C.c_int * n)(*[len(a) for a, _ in mv])
     x0 = np.ascontiguousarray(x0, dt); xo = np.empty(3, dt); H = np.empty(9, dt)
-    stats = (IterStats * max(ap.max_iterations, 1))(); its = C.c_int(0)
-    rc = getattr(lib(), "lsmo_align" + sfx)(C.byref(ap), n, sp, pf, nf, pm, nm, x0.ctypes.data_as(C.c_void_p),
-                                            xo.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p), stats, C.byref(its))
-    return dict(status=rc, pose=xo, H=H.reshape(3, 3), stats=[stats[i] for i in range(its.value)], iterations=its.value)
+    stats = (IterStats * (max(ap.max_iterations, 1) * (2 if ap.enable_inlier_only_runs else 1)))(); its = C.c_int(0)
+    if not want_pairs:
+        rc = getattr(lib(), "lsmo_align" + sfx)(C.byref(ap), n, sp, pf, nf, pm, nm, x0.ctypes.data_as(C.c_void_p),
+                                                xo.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p), stats, C.byref(its))
+        return dict(status=rc, pose=xo, H=H.reshape(3, 3), stats=[stats[i] for i in range(its.value)], iterations=its.value)
+    bufs = [np.empty((max(s_.projector.canvas_cols if s_.finder == FINDER_PROJECTIVE else len(m_[0]), 1), 2), np.int32) for s_, m_ in zip(slices, mv)]
+    pp = (C.c_void_p * n)(*[b.ctypes.data_as(C.c_void_p) for b in bufs]); npairs = (C.c_int * n)()
+    rc = getattr(lib(), "lsmo_align_pairs" + sfx)(C.byref(ap), n, sp, pf, nf, pm, nm, x0.ctypes.data_as(C.c_void_p),
+                                                  xo.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p), stats, C.byref(its), pp, npairs)
+    return dict(status=rc, pose=xo, H=H.reshape(3, 3), stats=[stats[i] for i in range(its.value)], iterations=its.value,
+                pairs=[bufs[s_][: npairs[s_]].copy() for s_ in range(n)])
 
 
 def align_batch(ap: AlignerParams, sp: SliceParams, fixed_packed, fixed_offsets, moving, x0, n_threads=1):

@@ -33,7 +33,8 @@ class SliceParams(C.Structure):
 
 class AlignerParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("min_num_inliers", C.c_int32), ("damping", C.c_float),
-                ("termination_chi_epsilon", C.c_float)]
+                ("termination_chi_epsilon", C.c_float), ("enable_inlier_only_runs", C.c_int32),
+                ("keep_only_inlier_correspondences", C.c_int32)]
 
 
 class Prior(C.Structure):
@@ -46,7 +47,11 @@ class Correspondence(C.Structure):
 
 class IterationStats(C.Structure):
     _fields_ = [("n_correspondences", C.c_int32), ("n_inliers", C.c_int32), ("n_outliers", C.c_int32),
-                ("chi_inliers", C.c_float), ("chi_outliers", C.c_float)]
+                ("chi_inliers", C.c_float), ("chi_outliers", C.c_float), ("pair_digest_lo", C.c_uint32), ("pair_digest_hi", C.c_uint32)]
+
+    @property
+    def pair_digest(self) -> int:
+        return (int(self.pair_digest_hi) << 32) | int(self.pair_digest_lo)
 
 
 class Preprocessor(C.Structure):
@@ -105,6 +110,10 @@ SYMBOLS = [
     ("lsm2d_linearize", C.c_int,
      [_P, C.POINTER(SliceParams), _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.POINTER(IterationStats)]),
     ("lsm2d_align_batch", C.c_int, [_P, C.POINTER(AlignerParams), C.POINTER(Batch), _P, _P, _P, _P, _P]),
+    ("lsm2d_align_batch_pairs", C.c_int, [_P, C.POINTER(AlignerParams), C.POINTER(Batch), _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    ("lsm2d_stats_capacity", C.c_int32, [C.POINTER(AlignerParams)]),
+    ("lsm2d_pair_hash", C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("lsm2d_estimate_work", C.c_int, [_P, C.POINTER(Batch), _P]),
 ]
 
 _lib = None

@@ -420,10 +420,11 @@ class BatchResult:
     information: np.ndarray   # [n, 3, 3]
     status: np.ndarray        # [n]
     iterations: np.ndarray    # [n]
-    stats: Optional[np.ndarray]  # structured [n, max_it] or None
+    stats: Optional[np.ndarray]  # structured [n, lsm2d_stats_capacity] or None
     kernel_ms: float
     kernel_clock_mhz: float = 0.0      # clock the chip held inside the k_align launch (in-kernel stamps; 0 when not timed / another kernel ran)
     workgroup_lifetime_ms: float = 0.0  # median lifetime of the stamped workgroups
+    pairs: Optional[list] = None        # want_pairs: pairs[i][s] = int32 [k, 2] (fixed_idx, moving_idx) the aligner leaves in slice s of alignment i
 
     def status_names(self):
         return [STATUS_NAMES.get(int(s), str(int(s))) for s in self.status]
@@ -450,7 +451,13 @@ class BatchResult:
 
 
 STATS_DTYPE = np.dtype([("n_correspondences", np.int32), ("n_inliers", np.int32), ("n_outliers", np.int32),
-                        ("chi_inliers", np.float32), ("chi_outliers", np.float32)])
+                        ("chi_inliers", np.float32), ("chi_outliers", np.float32),
+                        ("pair_digest_lo", np.uint32), ("pair_digest_hi", np.uint32)])
+
+
+def pair_digests(stats: np.ndarray) -> np.ndarray:
+    """uint64 digest of every iteration's correspondence set (lsm2d_iteration_stats.pair_digest_lo / _hi)."""
+    return (stats["pair_digest_hi"].astype(np.uint64) << np.uint64(32)) | stats["pair_digest_lo"].astype(np.uint64)
 
 
 class MultiAligner2D:
@@ -463,12 +470,13 @@ class MultiAligner2D:
         self.param_max_iterations = max_iterations
         self.param_min_num_inliers = min_num_inliers
         self.param_damping = damping
-        # the options both shipped aligners carry at their defaults (MULTI.json:606-610,627-630,704-708,729-731).  The device loop has no
-        # inlier-only re-runs and keeps every correspondence: a non-default value is REFUSED by compute(), never ignored.  The termination
-        # criterion exists as an epsilon on the relative decay of the total chi^2 (lsm2d.h); 0 = not set = max_iterations.
+        # the options both shipped aligners carry at their defaults (MULTI.json:606-610,627-630,704-708,729-731); semantics in include/lsm2d.h
+        # (restated from the parameters' doc strings: the upstream class is not in the reference tree).  The termination criterion exists as
+        # an epsilon on the relative decay of the total chi^2 (lsm2d.h); 0 = not set = max_iterations.
         self.param_enable_inlier_only_runs = False
         self.param_keep_only_inlier_correspondences = False
         self.param_termination_chi_epsilon = termination_chi_epsilon
+        self.store_correspondences = False      # compute() also fetches what the reference leaves in slice->correspondences()
         self.param_slice_processors: list[AlignerSliceProcessorLaser2D] = []
         self._fixed = {}
         self._moving = {}
@@ -497,8 +505,16 @@ class MultiAligner2D:
         fixed = [self._fixed[s.param_fixed_slice_name] for s in self.param_slice_processors]
         moving = [self._moving[s.param_moving_slice_name] for s in self.param_slice_processors]
         prior = None if self._prior is None else [self._prior]
-        self._result = self.compute_batch(fixed, moving, self._moving_in_fixed[None, :], priors=prior, want_stats=True)
+        self._result = self.compute_batch(fixed, moving, self._moving_in_fixed[None, :], priors=prior, want_stats=True,
+                                          want_pairs=self.store_correspondences)
         return self.status()
+
+    def correspondences(self, slice_index: int = 0) -> np.ndarray:
+        """slice->correspondences() after compute() (apps/visual_test_aligner_2d.cpp:129-143): int32 [k, 2] (fixed_idx, moving_idx).
+        Needs ``store_correspondences = True`` before compute(): the device loop keeps no pair lists, they cost a finder pass per slice."""
+        if self._result is None or self._result.pairs is None:
+            raise RuntimeError("MultiAligner2D::correspondences| set store_correspondences = True before compute()")
+        return self._result.pairs[0][slice_index]
 
     def movingInFixed(self) -> np.ndarray:
         return self._result.pose[0]
@@ -515,52 +531,89 @@ class MultiAligner2D:
 
     # --- batched surface ---------------------------------------------------------------------------
     def compute_batch(self, fixed: Sequence[CloudSet], moving: Sequence[CloudSet], init_poses, priors=None,
-                      fixed_index=None, moving_index=None, want_stats: bool = False) -> BatchResult:
+                      fixed_index=None, moving_index=None, want_stats: bool = False, want_pairs: bool = False) -> BatchResult:
         """``fixed[s]`` / ``moving[s]``: cloud set of slice ``s`` (one cloud = shared by the batch, else one per
-        alignment or chosen through ``*_index[s][i]``).  ``init_poses``: [n, 3]."""
+        alignment or chosen through ``*_index[s][i]``).  ``init_poses``: [n, 3].  want_pairs: also the correspondences the aligner
+        leaves in its slices (lsm2d_align_batch_pairs: one finder pass per alignment and slice after the aligner kernel)."""
         ctx, lib = self._ctx, self._ctx._lib
         slices = self.param_slice_processors
         ns = len(slices)
-        x0 = np.ascontiguousarray(init_poses, np.float32).reshape(-1, 3)
-        n = len(x0)
-        sp = (SliceParams * ns)(*[s.slice_params() for s in slices])
-        fixed_sets = [_as_cloudset(ctx, f) for f in fixed]          # keep host-array uploads alive for the duration of the call
-        moving_sets = [_as_cloudset(ctx, m) for m in moving]
-        fx = (C.c_void_p * ns)(*[f.handle.value for f in fixed_sets])
-        mv = (C.c_void_p * ns)(*[m.handle.value for m in moving_sets])
-        b = Batch()
-        b.n_alignments, b.n_slices = n, ns
-        b.slices = sp
-        b.fixed = C.cast(fx, C.POINTER(C.c_void_p)); b.moving = C.cast(mv, C.POINTER(C.c_void_p))
-        keep = []
-        if fixed_index is not None:
-            fi = np.ascontiguousarray(fixed_index, np.int32).reshape(ns, n); keep.append(fi)
-            b.fixed_index = fi.ctypes.data_as(C.POINTER(C.c_int32))
-        if moving_index is not None:
-            mi = np.ascontiguousarray(moving_index, np.int32).reshape(ns, n); keep.append(mi)
-            b.moving_index = mi.ctypes.data_as(C.POINTER(C.c_int32))
-        b.init_pose = x0.ctypes.data_as(C.POINTER(C.c_float))
-        if priors is not None:
-            pr = (Prior * n)()
-            for i, (z, om) in enumerate(priors):
-                pr[i].z = (C.c_float * 3)(*np.asarray(z, np.float32).ravel())
-                pr[i].omega = (C.c_float * 9)(*np.asarray(om, np.float32).ravel())
-            b.prior = pr
-        if self.param_enable_inlier_only_runs or self.param_keep_only_inlier_correspondences:
-            raise RuntimeError("MultiAligner2D::compute| enable_inlier_only_runs / keep_only_inlier_correspondences are not supported on the device")
-        ap = AlignerParams(self.param_max_iterations, self.param_min_num_inliers, self.param_damping, self.param_termination_chi_epsilon)
+        b, keep = self._batch(fixed, moving, init_poses, priors, fixed_index, moving_index)
+        n = b.n_alignments; moving_sets = keep[1]
+        ap = AlignerParams(self.param_max_iterations, self.param_min_num_inliers, self.param_damping, self.param_termination_chi_epsilon,
+                           1 if self.param_enable_inlier_only_runs else 0, 1 if self.param_keep_only_inlier_correspondences else 0)
         pose = np.empty((n, 3), np.float32); H = np.empty((n, 9), np.float32)
         status = np.empty(n, np.int32); its = np.empty(n, np.int32)
-        stats = np.zeros((n, max(self.param_max_iterations, 1)), STATS_DTYPE) if want_stats else None
-        check(lib.lsm2d_align_batch(ctx.handle, C.byref(ap), C.byref(b), pose.ctypes.data_as(C.c_void_p),
-                                    H.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
-                                    its.ctypes.data_as(C.c_void_p),
-                                    stats.ctypes.data_as(C.c_void_p) if want_stats else None),
-              "lsm2d_align_batch", ctx.handle)
-        timed = bool(n and ctx.kernel_timing)
+        stats = np.zeros((n, int(lib.lsm2d_stats_capacity(C.byref(ap)))), STATS_DTYPE) if want_stats else None
+        pairs = None
+        if want_pairs and n:
+            cap = 1
+            for s_, m_ in zip(slices, moving_sets):
+                sp_ = s_.slice_params()
+                cap = max(cap, sp_.projector.canvas_cols if sp_.finder == FINDER_PROJECTIVE else int(max(m_.counts)) if len(m_.counts) else 1)
+            pbuf = np.empty((n, ns, cap, 2), np.int32); pcnt = np.zeros((n, ns), np.int32)
+            check(lib.lsm2d_align_batch_pairs(ctx.handle, C.byref(ap), C.byref(b), pose.ctypes.data_as(C.c_void_p),
+                                              H.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p), its.ctypes.data_as(C.c_void_p),
+                                              stats.ctypes.data_as(C.c_void_p) if want_stats else None,
+                                              pbuf.ctypes.data_as(C.c_void_p), cap, pcnt.ctypes.data_as(C.c_void_p)),
+                  "lsm2d_align_batch_pairs", ctx.handle)
+            pairs = [[pbuf[i, s_, : pcnt[i, s_]].copy() for s_ in range(ns)] for i in range(n)]
+        else:
+            check(lib.lsm2d_align_batch(ctx.handle, C.byref(ap), C.byref(b), pose.ctypes.data_as(C.c_void_p),
+                                        H.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
+                                        its.ctypes.data_as(C.c_void_p),
+                                        stats.ctypes.data_as(C.c_void_p) if want_stats else None),
+                  "lsm2d_align_batch", ctx.handle)
+        timed = bool(n and ctx.kernel_timing) and not pairs      # (the finder passes behind a pairs call overwrite the timed events)
         return BatchResult(pose, H.reshape(n, 3, 3), status, its, stats, ctx.last_kernel_ms() if timed else 0.0,
                            ctx.get_option("last_kernel_clock_khz") * 1e-3 if timed else 0.0,
-                           ctx.get_option("last_workgroup_lifetime_ns") * 1e-6 if timed else 0.0)
+                           ctx.get_option("last_workgroup_lifetime_ns") * 1e-6 if timed else 0.0, pairs)
+
+
+def _batch_method(self, fixed, moving, init_poses, priors=None, fixed_index=None, moving_index=None):
+    """lsm2d_batch descriptor of a call (and everything it points to, to be kept alive by the caller)"""
+    ctx = self._ctx
+    slices = self.param_slice_processors
+    ns = len(slices)
+    x0 = np.ascontiguousarray(init_poses, np.float32).reshape(-1, 3)
+    n = len(x0)
+    sp = (SliceParams * ns)(*[s.slice_params() for s in slices])
+    fixed_sets = [_as_cloudset(ctx, f) for f in fixed]          # keep host-array uploads alive for the duration of the call
+    moving_sets = [_as_cloudset(ctx, m) for m in moving]
+    fx = (C.c_void_p * ns)(*[f.handle.value for f in fixed_sets])
+    mv = (C.c_void_p * ns)(*[m.handle.value for m in moving_sets])
+    b = Batch()
+    b.n_alignments, b.n_slices = n, ns
+    b.slices = sp
+    b.fixed = C.cast(fx, C.POINTER(C.c_void_p)); b.moving = C.cast(mv, C.POINTER(C.c_void_p))
+    keep = [fixed_sets, moving_sets, sp, fx, mv, x0]
+    if fixed_index is not None:
+        fi = np.ascontiguousarray(fixed_index, np.int32).reshape(ns, n); keep.append(fi)
+        b.fixed_index = fi.ctypes.data_as(C.POINTER(C.c_int32))
+    if moving_index is not None:
+        mi = np.ascontiguousarray(moving_index, np.int32).reshape(ns, n); keep.append(mi)
+        b.moving_index = mi.ctypes.data_as(C.POINTER(C.c_int32))
+    b.init_pose = x0.ctypes.data_as(C.POINTER(C.c_float))
+    if priors is not None:
+        pr = (Prior * n)()
+        for i, (z, om) in enumerate(priors):
+            pr[i].z = (C.c_float * 3)(*np.asarray(z, np.float32).ravel())
+            pr[i].omega = (C.c_float * 9)(*np.asarray(om, np.float32).ravel())
+        b.prior = pr; keep.append(pr)
+    return b, keep
+
+
+def _estimate_work_method(self, fixed, moving, init_poses, fixed_index=None, moving_index=None) -> np.ndarray:
+    """lsm2d_estimate_work: per alignment, what it will cost relative to the others (chunks of the moving cloud its first iteration streams),
+    without running it -- what a sweep sharded over devices or ranks balances its shards by (distributed.shard_by_work).  int32 [n]."""
+    b, keep = self._batch(fixed, moving, init_poses, None, fixed_index, moving_index)
+    work = np.empty(b.n_alignments, np.int32)
+    check(self._ctx._lib.lsm2d_estimate_work(self._ctx.handle, C.byref(b), work.ctypes.data_as(C.c_void_p)), "lsm2d_estimate_work", self._ctx.handle)
+    return work
+
+
+MultiAligner2D._batch = _batch_method
+MultiAligner2D.estimate_work = _estimate_work_method
 
 
 def linearize(ctx: Context, slice_params: SliceParams, fixed, moving, correspondences, pose,

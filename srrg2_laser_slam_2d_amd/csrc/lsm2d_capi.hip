@@ -1351,9 +1351,10 @@ extern "C" int lsm2d_project(lsm2d_context* ctx, const lsm2d_projector* pr, cons
 }
 
 // ---- plugin interface #1 ---------------------------------------------------------------------------------
-extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_params* sp, const lsm2d_cloudset* fixed,
-                                          int32_t fi, const lsm2d_cloudset* moving, int32_t mi, const float pose[3],
-                                          lsm2d_correspondence* out_pairs, int32_t capacity, int32_t* out_n) {
+// inl_tau > 0: only the pairs whose factor is an inlier under a Cauchy robustifier of that threshold (FindArgs::inl_tau)
+static int find_correspondences_impl(lsm2d_context* ctx, const lsm2d_slice_params* sp, const lsm2d_cloudset* fixed,
+                                     int32_t fi, const lsm2d_cloudset* moving, int32_t mi, const float pose[3],
+                                     lsm2d_correspondence* out_pairs, int32_t capacity, int32_t* out_n, float inl_tau) {
   if (!ctx || !sp || !pose || !out_n || !valid_cloud_index(fixed, fi) || !valid_cloud_index(moving, mi) || capacity < 0 ||
       (capacity > 0 && !out_pairs))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "find_correspondences: bad argument");
@@ -1371,7 +1372,7 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
                            : ensure_grid(ctx, fixed, sp->max_distance, &N.fixed.grid);
     if (rc) return rc;
     const size_t nm = (size_t) moving->h_count[mi], bytes = nm * 8 + 16;
-    N.max_distance = sp->max_distance; N.normal_cos = sp->normal_cos; N.T = make_iso(pose);
+    N.max_distance = sp->max_distance; N.normal_cos = sp->normal_cos; N.T = make_iso(pose); N.inl_tau = inl_tau;
     N.nn_group = fixed->h_count[fi] >= 4 * (int64_t) moving->h_count[mi] ? kNNGroup : 1;     // dense fixed cloud: cooperative search
     // more queries than one workgroup takes in a trip: one workgroup per trip's worth, two launches (search, then ordered compaction)
     const int per_step = kFindBlock / ((N.use_distmap || N.use_kd) ? 1 : N.nn_group);
@@ -1416,7 +1417,7 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
   int rc = ensure_scratch(ctx, o_can + 2 * cols * sizeof(u64)); if (rc) return rc;
   rc = ensure_stage(ctx, bytes); if (rc) return rc;
   A.fixed = cloud_dev(fixed, nullptr); A.moving = cloud_dev(moving, nullptr); A.fc = fi; A.mc = mi;
-  A.point_distance = sp->point_distance; A.normal_cos = sp->normal_cos; A.T = make_iso(pose);
+  A.point_distance = sp->point_distance; A.normal_cos = sp->normal_cos; A.T = make_iso(pose); A.inl_tau = inl_tau;
   char* dv = nullptr; rc = stage_device_view(ctx, &dv); if (rc) return rc;       // <= one pair per column: written straight to pinned host memory
   A.out_count = (int32_t*) dv; A.out_pairs = (int32_t*) (dv + 16);
   A.fcan_global = nullptr; A.mcan_global = nullptr;
@@ -1443,6 +1444,12 @@ extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_
   return LSM2D_SUCCESS;
 }
 
+extern "C" int lsm2d_find_correspondences(lsm2d_context* ctx, const lsm2d_slice_params* sp, const lsm2d_cloudset* fixed,
+                                          int32_t fi, const lsm2d_cloudset* moving, int32_t mi, const float pose[3],
+                                          lsm2d_correspondence* out_pairs, int32_t capacity, int32_t* out_n) {
+  return find_correspondences_impl(ctx, sp, fixed, fi, moving, mi, pose, out_pairs, capacity, out_n, 0.0f);
+}
+
 // ---- factor ---------------------------------------------------------------------------------------------------
 extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp, const lsm2d_cloudset* fixed, int32_t fi,
                                const lsm2d_cloudset* moving, int32_t mi, const lsm2d_correspondence* pairs, int32_t n_pairs,
@@ -1459,7 +1466,9 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   int blocks = (n_pairs + 255) / 256; if (blocks < 1) blocks = 1; if (blocks > 1024) blocks = 1024;
   const size_t pair_bytes = sizeof(lsm2d_correspondence) * (size_t) n_pairs;
   const size_t part_off = (pair_bytes + 255) & ~(size_t) 255, out_off = part_off + sizeof(float) * kAccumWords * (size_t) blocks;
-  const size_t bytes = out_off + sizeof(float) * kAccumWords;
+  const size_t dig_off = out_off + sizeof(float) * kAccumWords;      // 8-byte aligned: out_off is a multiple of 256, kAccumWords is even
+  static_assert(kAccumWords % 2 == 0, "the digest behind the sums must be 8-byte aligned");
+  const size_t bytes = dig_off + sizeof(unsigned long long);
   int rc = ensure_scratch(ctx, bytes); if (rc) return rc;
   rc = ensure_stage(ctx, bytes); if (rc) return rc;
   if (n_pairs) memcpy(ctx->h_stage, pairs, pair_bytes);
@@ -1473,6 +1482,9 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   A.pairs = (const int32_t*) dv; A.n_pairs = n_pairs; A.T = make_iso(pose);
   A.cauchy = sp->robustifier == LSM2D_ROBUST_CAUCHY; A.tau = sp->chi_threshold;
   A.partial = (float*) ((char*) ctx->d_scratch + part_off); A.out = (float*) (dv + out_off);
+  A.dig = (unsigned long long*) (dv + dig_off);
+  if (direct) *(unsigned long long*) ((char*) ctx->h_stage + dig_off) = 0ull;
+  else HIPCHK(ctx, hipMemsetAsync(A.dig, 0, sizeof(unsigned long long), ctx->stream));
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_linearize_partial, dim3(blocks), dim3(256), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_linearize_final, dim3(1), dim3(64), 0, ctx->stream, (const float*) A.partial, blocks, A.out);
@@ -1480,21 +1492,41 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = ctx->kernel_timing;
   float* h = (float*) ((char*) ctx->h_stage + out_off);
-  if (!direct) HIPCHK(ctx, hipMemcpyAsync(h, A.out, sizeof(float) * kAccumWords, hipMemcpyDeviceToHost, ctx->stream));
+  if (!direct) HIPCHK(ctx, hipMemcpyAsync(h, A.out, sizeof(float) * kAccumWords + sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, stream_sync(ctx));
   out_H[0] = h[0]; out_H[1] = h[1]; out_H[2] = h[2]; out_H[3] = h[1]; out_H[4] = h[3]; out_H[5] = h[4]; out_H[6] = h[2]; out_H[7] = h[4]; out_H[8] = h[5];
   out_b[0] = h[6]; out_b[1] = h[7]; out_b[2] = h[8];
   if (st) {
     int32_t iv[3]; memcpy(iv, h + 11, sizeof iv);
     st->n_inliers = iv[0]; st->n_outliers = iv[1]; st->n_correspondences = iv[2]; st->chi_inliers = h[9]; st->chi_outliers = h[10];
+    unsigned long long dg; memcpy(&dg, (char*) ctx->h_stage + dig_off, sizeof dg);
+    st->pair_digest_lo = (uint32_t) dg; st->pair_digest_hi = (uint32_t) (dg >> 32);
   }
   return LSM2D_SUCCESS;
 }
 
 // ---- plugin interface #2 ----------------------------------------------------------------------------------------
-extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params* ap, const lsm2d_batch* b, float* out_pose,
-                                 float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats) {
-  if (!ctx || !ap || !b || !out_pose || !out_status) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: null argument");
+extern "C" uint64_t lsm2d_pair_hash(uint32_t slice, uint32_t fixed_idx, uint32_t moving_idx) {      // the kernels' pair_hash_dev, on the host
+  const uint32_t a = fixed_idx * 0x9E3779B1u, b = (moving_idx ^ (slice * 0x632BE5ABu)) * 0x85EBCA77u;
+  uint32_t lo = a ^ ((b << 13) | (b >> 19)), hi = b ^ ((a << 19) | (a >> 13));
+  lo += ((lo << 17) | (lo >> 15)) ^ b;
+  hi += ((hi << 11) | (hi >> 21)) ^ a;
+  return ((uint64_t) hi << 32) | (uint64_t) lo;
+}
+
+extern "C" int32_t lsm2d_stats_capacity(const lsm2d_aligner_params* ap) {
+  if (!ap) return 1;
+  const long long c = (long long) (ap->max_iterations > 0 ? ap->max_iterations : 0) * (ap->enable_inlier_only_runs ? 2 : 1);
+  return (int32_t) (c < 1 ? 1 : (c > 0x7fffffff ? 0x7fffffff : c));
+}
+
+// out_last_pose [n][3] (may be NULL): the pose the last iteration every alignment started began at (what lsm2d_align_batch_pairs re-derives
+// that iteration's correspondences from)
+// out_work [n] (may be NULL): ONLY the work estimate of lsm2d_estimate_work is produced -- no alignment runs, the other outputs are not touched
+static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, const lsm2d_batch* b, float* out_pose,
+                            float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats, float* out_last_pose,
+                            int32_t* out_work = nullptr) {
+  if (!ctx || !ap || !b || ((!out_pose || !out_status) && !out_work)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: null argument");
   const int n = b->n_alignments, ns = b->n_slices;
   if (n < 0 || ns < 1 || ns > kMaxSlices || ap->max_iterations < 0 || !b->slices || !b->fixed || !b->moving || (n > 0 && !b->init_pose))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad batch descriptor");
@@ -1506,6 +1538,10 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   A.n_align = n; A.n_slices = ns; A.max_it = ap->max_iterations; A.min_inliers = ap->min_num_inliers; A.damping = ap->damping;
   if (!(ap->termination_chi_epsilon >= 0.0f)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: termination_chi_epsilon must be >= 0");
   A.term_eps = ap->termination_chi_epsilon;
+  if (ap->max_iterations > 0x3fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: max_iterations out of range");
+  A.inlier_runs = ap->enable_inlier_only_runs != 0;
+  const int stats_stride = lsm2d_stats_capacity(ap), it_cap = A.inlier_runs ? 2 * ap->max_iterations : ap->max_iterations;
+  A.stats_stride = stats_stride;
   // ---- device scratch layout: [init_pose | prior | indices | out_pose | out_H | status | its | stats]
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
@@ -1519,7 +1555,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   const size_t in_bytes = off;
   const size_t o_pose = take(sizeof(float) * 3 * (size_t) n), o_H = take(sizeof(float) * 9 * (size_t) n);
   const size_t o_status = take(sizeof(int32_t) * (size_t) n), o_its = take(sizeof(int32_t) * (size_t) n);
-  const size_t o_stats = out_stats ? take(sizeof(StatsDev) * (size_t) n * (size_t) (ap->max_iterations > 0 ? ap->max_iterations : 1)) : 0;
+  const size_t o_stats = out_stats ? take(sizeof(StatsDev) * (size_t) n * (size_t) stats_stride) : 0;
+  const size_t o_last_pose = out_last_pose ? take(sizeof(float) * 3 * (size_t) n) : 0;
   // in-kernel clock stamps of ~32 workgroups spread over the grid (timed k_align launches only)
   const int clock_stride = ctx->clock_stride > 0 ? ctx->clock_stride : (n / 32 > 1 ? n / 32 : 1), n_clock = (n + clock_stride - 1) / clock_stride;
   const size_t o_clock = ctx->kernel_timing ? take(sizeof(unsigned long long) * 4 * (size_t) n_clock) : 0;
@@ -1549,7 +1586,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   // (Not for big batches: with 1000 alignments reading their start poses and writing their results over the host link the step takes 1.485 ms
   // against 1.467 with the three small transfers; tools/zero_copy_ab.py.)
   // ("zero_copy_max" bounds every batch, so the A/B knob works below 256 too; batches that carry index arrays stay on the transfers above 256)
-  const bool zero_copy = !use_split && n <= ctx->zero_copy_max && (n <= 256 || (!b->fixed_index && !b->moving_index));
+  const bool zero_copy = !out_work && !use_split && n <= ctx->zero_copy_max && (n <= 256 || (!b->fixed_index && !b->moving_index));
   if (zero_copy) ds = (char*) ctx->h_stage_dev;
 
   // ---- slices
@@ -1726,6 +1763,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   A.init_pose = (const float*) (ds + o_pose_in);
   A.out_pose = (float*) (ds + o_pose); A.out_H = (float*) (ds + o_H); A.out_status = (int32_t*) (ds + o_status); A.out_its = (int32_t*) (ds + o_its);
   A.out_stats = out_stats ? (StatsDev*) (ds + o_stats) : nullptr;
+  A.out_last_pose = out_last_pose ? (float*) (ds + o_last_pose) : nullptr;
 
   ctx->last_clock_khz = 0; ctx->last_wg_lifetime_ns = 0;
   const bool stamps = ctx->kernel_timing && !use_split && !use_pair;
@@ -1740,6 +1778,18 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   ctx->last_align_path = use_split ? 2 : (use_pair ? 3 : 1);
   // culled batches that run in about one dispatch round: balanced placement (two small launches ahead of k_align; see k_cull_estimate)
   A.order = nullptr;
+  if (out_work) {      // lsm2d_estimate_work: the chunks of the moving cloud each alignment's FIRST iteration will stream (k_cull_estimate), or 1 everywhere
+    int bs = -1;
+    for (int s = 0; s < ns && bs < 0; ++s) if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].moving.lane_xy && A.s[s].moving.lane_bounds && A.cull) bs = s;
+    if (bs < 0) { for (int i = 0; i < n; ++i) out_work[i] = 1; return LSM2D_SUCCESS; }
+    int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work);
+    hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), sizeof(u64) * (size_t) A.s[bs].proj.cols, ctx->stream, A, bs, d_work);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(hs + o_work, d_work, sizeof(int32_t) * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, stream_sync(ctx));
+    memcpy(out_work, hs + o_work, sizeof(int32_t) * (size_t) n);
+    return LSM2D_SUCCESS;
+  }
   if (!use_split && !use_pair && !zero_copy && A.cull && ctx->balance && n > 256 && has_proj) {
     int bs = -1;
     for (int s = 0; s < ns && bs < 0; ++s) if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].moving.lane_xy && A.s[s].moving.lane_bounds) bs = s;
@@ -1757,7 +1807,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     const size_t can_bytes = sizeof(u64) * 2 * (size_t) fcan_total * (size_t) n;
     const size_t w_pose = (can_bytes + 255) & ~(size_t) 255, w_done = w_pose + (((sizeof(float) * 3 * (size_t) n) + 255) & ~(size_t) 255);
     const size_t w_H = w_done + (((sizeof(int32_t) * (size_t) n) + 255) & ~(size_t) 255), w_last = w_H + (((sizeof(float) * 9 * (size_t) n) + 255) & ~(size_t) 255);
-    const size_t w_total = w_last + sizeof(StatsDev) * (size_t) n;
+    const size_t w_phase = w_last + ((sizeof(StatsDev) * (size_t) n + 255) & ~(size_t) 255);
+    const size_t w_total = w_phase + sizeof(int32_t) * 3 * (size_t) n;
     if (w_total > ctx->d_split_bytes) {
       if (ctx->d_split) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipFree(ctx->d_split)); ctx->d_split = nullptr; ctx->d_split_bytes = 0; }
       HIPCHK(ctx, hipMalloc(&ctx->d_split, w_total + w_total / 2));
@@ -1766,8 +1817,10 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     char* w = (char*) ctx->d_split;
     SplitArgs SA; SA.A = A;
     SA.gcan = (u64*) w; SA.pose = (float*) (w + w_pose); SA.done = (int32_t*) (w + w_done); SA.H_last = (float*) (w + w_H); SA.last = (StatsDev*) (w + w_last);
+    SA.phase = (int32_t*) (w + w_phase);
     HIPCHK(ctx, hipMemsetAsync(SA.gcan, 0xFF, can_bytes, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(SA.done, 0, sizeof(int32_t) * (size_t) n, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(SA.phase, 0, sizeof(int32_t) * 3 * (size_t) n, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(SA.pose, A.init_pose, sizeof(float) * 3 * (size_t) n, hipMemcpyDeviceToDevice, ctx->stream));
     int max_fixed = 0;
     for (int s = 0; s < ns; ++s) { const lsm2d_cloudset* f = b->fixed[s]; for (int c = 0; c < f->n_clouds; ++c) if (f->h_count[c] > max_fixed) max_fixed = f->h_count[c]; }
@@ -1781,7 +1834,7 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
     SA.it = 0;
     hipLaunchKernelGGL((k_split_project<true>), dim3((unsigned) chunks_for(max_fixed), (unsigned) n, (unsigned) ns), dim3(512), clds, ctx->stream, SA);
     const int mchunks = chunks_for(max_moving);
-    for (int it = 0; it < ap->max_iterations; ++it) {
+    for (int it = 0; it < it_cap; ++it) {      // (alignments that are done leave their launches at once: S.done)
       SA.it = it;
       hipLaunchKernelGGL((k_split_project<false>), dim3((unsigned) mchunks, (unsigned) n, (unsigned) ns), dim3(512), clds, ctx->stream, SA);
       hipLaunchKernelGGL(k_split_finish, dim3((unsigned) n), dim3(kAlignBlock), 0, ctx->stream, SA);
@@ -1813,7 +1866,8 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
   if (out_H) memcpy(out_H, hs + o_H, sizeof(float) * 9 * (size_t) n);
   memcpy(out_status, hs + o_status, sizeof(int32_t) * (size_t) n);
   if (out_its) memcpy(out_its, hs + o_its, sizeof(int32_t) * (size_t) n);
-  if (out_stats) memcpy(out_stats, hs + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) ap->max_iterations);
+  if (out_stats) memcpy(out_stats, hs + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride);
+  if (out_last_pose) memcpy(out_last_pose, hs + o_last_pose, sizeof(float) * 3 * (size_t) n);
   if (stamps) {     // median over the stamped workgroups: shader cycles per 10 ns tick of the constant 100 MHz counter
     const unsigned long long* ck = (const unsigned long long*) (hs + o_clock);
     std::vector<double> khz; std::vector<unsigned long long> life;
@@ -1832,6 +1886,62 @@ extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params*
       std::nth_element(life.begin(), life.begin() + life.size() / 2, life.end()); ctx->last_wg_lifetime_ns = (long long) life[life.size() / 2];
     }
   }
+  return LSM2D_SUCCESS;
+}
+
+extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params* ap, const lsm2d_batch* b, float* out_pose,
+                                 float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats) {
+  return align_batch_impl(ctx, ap, b, out_pose, out_H, out_status, out_its, out_stats, nullptr);
+}
+
+extern "C" int lsm2d_estimate_work(lsm2d_context* ctx, const lsm2d_batch* b, int32_t* out_work) {
+  if (!out_work) return fail(ctx, LSM2D_BAD_ARGUMENT, "estimate_work: null argument");
+  lsm2d_aligner_params ap; memset(&ap, 0, sizeof ap); ap.max_iterations = 1;
+  return align_batch_impl(ctx, &ap, b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_work);
+}
+
+// MultiAligner2D::compute + what it leaves in the slices' correspondence vectors (apps/visual_test_aligner_2d.cpp:129-143).  The aligner kernels keep
+// no pair lists (their pairs live for one bin walk / one query); the vectors are re-derived from the pose the last started iteration began at by
+// the finder-level kernels -- the same arithmetic, hence the same pairs (tests: their digest equals the in-kernel one) -- one finder pass per
+// alignment and slice: an observability surface (40-90 us per pass), not a throughput path.
+extern "C" int lsm2d_align_batch_pairs(lsm2d_context* ctx, const lsm2d_aligner_params* ap, const lsm2d_batch* b, float* out_pose, float* out_H,
+                                       int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats,
+                                       lsm2d_correspondence* out_pairs, int32_t pair_capacity, int32_t* out_n_pairs) {
+  if (!out_pairs) return align_batch_impl(ctx, ap, b, out_pose, out_H, out_status, out_its, out_stats, nullptr);
+  if (!ctx || !ap || !b || !out_n_pairs || pair_capacity < 0) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch_pairs: bad argument");
+  const int n = b->n_alignments, ns = b->n_slices;
+  if (n < 0 || ns < 1 || ns > kMaxSlices || !b->slices || !b->fixed || !b->moving) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch_pairs: bad batch descriptor");
+  for (int s = 0; s < ns; ++s) {      // a slice's largest possible vector must fit
+    const lsm2d_cloudset* m = b->moving[s];
+    if (!m || !b->fixed[s]) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch_pairs: cloud set missing");
+    long long need = 0;
+    if (b->slices[s].finder == LSM2D_FINDER_PROJECTIVE) need = b->slices[s].projector.canvas_cols;
+    else { const int rc0 = resolve_count(m); if (rc0) return rc0; for (int c = 0; c < m->n_clouds; ++c) if (m->h_count[c] > need) need = m->h_count[c]; }
+    if (need > pair_capacity) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "align_batch_pairs: pair_capacity below a slice's largest possible correspondence vector");
+  }
+  std::vector<float> last_pose((size_t) 3 * (size_t) (n > 0 ? n : 1));
+  std::vector<int32_t> its_local;
+  int32_t* its = out_its;
+  if (!its) { its_local.assign((size_t) (n > 0 ? n : 1), 0); its = its_local.data(); }
+  int rc = align_batch_impl(ctx, ap, b, out_pose, out_H, out_status, its, out_stats, last_pose.data());
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i)
+    for (int s = 0; s < ns; ++s) {
+      const lsm2d_slice_params& sp = b->slices[s];
+      const lsm2d_cloudset* f = b->fixed[s]; const lsm2d_cloudset* m = b->moving[s];
+      int32_t* cnt = out_n_pairs + (size_t) i * ns + s;
+      lsm2d_correspondence* dst = out_pairs + ((size_t) i * ns + s) * (size_t) pair_capacity;
+      *cnt = 0;
+      if (its[i] < 1) continue;      // no iteration started: the vectors stay empty
+      const int fc = b->fixed_index ? b->fixed_index[(size_t) s * n + i] : (f->n_clouds == 1 ? 0 : i);
+      const int mc = b->moving_index ? b->moving_index[(size_t) s * n + i] : (m->n_clouds == 1 ? 0 : i);
+      float Xe[3] = {last_pose[3 * (size_t) i], last_pose[3 * (size_t) i + 1], last_pose[3 * (size_t) i + 2]};
+      const bool has_sensor = !(sp.sensor_in_robot[0] == 0.0f && sp.sensor_in_robot[1] == 0.0f && sp.sensor_in_robot[2] == 0.0f);
+      if (has_sensor) { float Sinv[3], X[3] = {Xe[0], Xe[1], Xe[2]}; inverse_host(sp.sensor_in_robot, Sinv); compose_host(Sinv, X, Xe); }      // X_eff = S^-1 X, the kernels' operations
+      const float inl_tau = (ap->keep_only_inlier_correspondences && sp.robustifier == LSM2D_ROBUST_CAUCHY) ? sp.chi_threshold : 0.0f;
+      rc = find_correspondences_impl(ctx, &sp, f, fc, m, mc, Xe, dst, pair_capacity, cnt, inl_tau);
+      if (rc) return rc;
+    }
   return LSM2D_SUCCESS;
 }
 
@@ -1970,7 +2080,7 @@ extern "C" int lsm2d_sweep_align(lsm2d_sweep* sw, const lsm2d_aligner_params* ap
       lsm2d_batch b; memset(&b, 0, sizeof b);
       b.n_alignments = n; b.n_slices = 1; b.slices = slice; b.fixed = &fx; b.moving = &mv; b.fixed_index = idx; b.init_pose = init_pose + 3 * lo;
       std::vector<lsm2d_iteration_stats> stats;
-      if (out_last_stats) stats.resize((size_t) n * (size_t) (ap->max_iterations > 0 ? ap->max_iterations : 1));
+      if (out_last_stats) stats.resize((size_t) n * (size_t) lsm2d_stats_capacity(ap));
       std::vector<int32_t> its((size_t) n);
       const int rc = lsm2d_align_batch(sw->ctx[(size_t) r], ap, &b, out_pose + 3 * lo, out_H ? out_H + 9 * lo : nullptr, out_status + lo, its.data(),
                                        out_last_stats ? stats.data() : nullptr);
@@ -1980,7 +2090,7 @@ extern "C" int lsm2d_sweep_align(lsm2d_sweep* sw, const lsm2d_aligner_params* ap
       if (out_last_stats)
         for (int i = 0; i < n; ++i) {
           lsm2d_iteration_stats z; memset(&z, 0, sizeof z);
-          out_last_stats[lo + i] = its[(size_t) i] > 0 ? stats[(size_t) i * (size_t) ap->max_iterations + (size_t) (its[(size_t) i] - 1)] : z;
+          out_last_stats[lo + i] = its[(size_t) i] > 0 ? stats[(size_t) i * (size_t) lsm2d_stats_capacity(ap) + (size_t) (its[(size_t) i] - 1)] : z;
         }
       } catch (const std::bad_alloc&) { rcs[(size_t) r] = LSM2D_OUT_OF_MEMORY; } catch (...) { rcs[(size_t) r] = LSM2D_DEVICE_ERROR; }
     });

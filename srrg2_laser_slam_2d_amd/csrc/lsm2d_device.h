@@ -432,9 +432,12 @@ LSM2D_DEV void accum_zero(Accum& a) {
 }
 
 // e = [ n_f.(q - p_f) ; n_q - n_f ],  J = [[ (R^T n_f)^T , n_f.(R J2 p_m) ], [ 0 , R J2 n_m ]]
+// inl_only: an iteration of the aligner's inlier-only runs (lsm2d_aligner_params.enable_inlier_only_runs): a pair that is not an inlier under
+// the slice's robustifier contributes nothing to H and b (weight +0: every fused add below then returns its addend), an inlier weight 1;
+// the statistics are formed as in a regular iteration.  false: the regular loop, bit for bit what it was.
 template <bool kInlineLog = false>
 LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, float2 nm, bool cauchy,
-                               float tau, Accum& A) {
+                               float tau, Accum& A, bool inl_only = false) {
   float qx, qy, nqx, nqy;
   xf_point(T, pm.x, pm.y, qx, qy);
   xf_normal(T, nm.x, nm.y, nqx, nqy);
@@ -454,6 +457,7 @@ LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, fl
     w = 1.0f / (1.0f + q);
     inlier = chi < tau;
     if (!inlier) kern = tau * (kInlineLog ? log_fixed_inline(1.0f + q) : log_fixed(1.0f + q));      // only outliers' statistic uses it: waves of inliers skip the logarithm
+    if (inl_only) w = inlier ? 1.0f : 0.0f;
   }
   A.n_in += inlier ? 1 : 0;
   A.n_out += inlier ? 0 : 1;
@@ -468,6 +472,18 @@ LSM2D_DEV void accumulate_pair(const Iso& T, float2 pf, float2 nf, float2 pm, fl
   A.h22 = __builtin_fmaf(wa2, a2, A.h22); A.h22 = __builtin_fmaf(w, dd, A.h22);
   A.b0 = __builtin_fmaf(wa0, e0, A.b0); A.b1 = __builtin_fmaf(wa1, e0, A.b1);
   A.b2 = __builtin_fmaf(wa2, e0, A.b2); A.b2 = __builtin_fmaf(w, de, A.b2);
+}
+
+// chi^2 of ONE pair: accumulate_pair's operations up to `chi`, in its order -- what decides "inlier" (chi < tau) when the aligner's
+// keep_only_inlier_correspondences filters the correspondences it hands back (lsm2d_align_batch_pairs)
+LSM2D_DEV float pair_chi(const Iso& T, float2 pf, float2 nf, float2 pm, float2 nm) {
+  float qx, qy, nqx, nqy;
+  xf_point(T, pm.x, pm.y, qx, qy);
+  xf_normal(T, nm.x, nm.y, nqx, nqy);
+  const float dx = qx - pf.x, dy = qy - pf.y;
+  const float e0 = __builtin_fmaf(nf.x, dx, nf.y * dy);
+  const float e1 = nqx - nf.x, e2 = nqy - nf.y;
+  return __builtin_fmaf(e0, e0, __builtin_fmaf(e1, e1, e2 * e2));
 }
 
 // ---- wave64 / workgroup reduction: shuffle butterfly, one LDS hop, fixed order => deterministic ----

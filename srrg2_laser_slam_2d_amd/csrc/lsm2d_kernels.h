@@ -728,12 +728,27 @@ struct SliceDev {
 };
 
 struct PriorDev { float z_inv[3], cz, sz, omega[9]; };   // Z^-1 and cos/sin of its angle, host-computed
-struct StatsDev { int32_t n_corr, n_in, n_out; float chi_in, chi_out; };
+struct StatsDev { int32_t n_corr, n_in, n_out; float chi_in, chi_out; uint32_t dig_lo, dig_hi; };
+
+// lsm2d_pair_hash (include/lsm2d.h) on the device: the per-pair term of lsm2d_iteration_stats.pair_digest.  slice_salt = slice * 0x632BE5AB
+// (wave-uniform).  Integer arithmetic only; tests hold the two definitions against each other through the oracle's digest.
+LSM2D_DEV u64 pair_hash_dev(uint32_t slice_salt, uint32_t f, uint32_t m) {
+  const uint32_t a = f * 0x9E3779B1u, b = (m ^ slice_salt) * 0x85EBCA77u;
+  uint32_t lo = a ^ __builtin_rotateleft32(b, 13), hi = b ^ __builtin_rotateleft32(a, 19);
+  lo += __builtin_rotateleft32(lo, 17) ^ b;
+  hi += __builtin_rotateleft32(hi, 11) ^ a;
+  return ((u64) hi << 32) | (u64) lo;
+}
+// one pair into the iteration's digest: a fire-and-forget 64-bit LDS add (order-independent: the sum wraps mod 2^64), no register held across the loops
+LSM2D_DEV void digest_add(u64* s_dig, uint32_t slice_salt, int f, int m) { atomicAdd(reinterpret_cast<unsigned long long*>(s_dig), (unsigned long long) pair_hash_dev(slice_salt, (uint32_t) f, (uint32_t) m)); }
 
 struct AlignArgs {
   int32_t n_align, n_slices, max_it, min_inliers;
   float   damping;
   float   term_eps;                         // lsm2d_aligner_params.termination_chi_epsilon (0 = run all iterations)
+  int32_t inlier_runs;                      // lsm2d_aligner_params.enable_inlier_only_runs: a second loop of up to max_it iterations over inliers only (lsm2d.h)
+  int32_t stats_stride;                     // iterations an alignment may run = row length of out_stats: max_it * (1 + inlier_runs), at least 1
+  float*  out_last_pose;                    // [n][3] or nullptr: the pose the LAST started iteration began at (lsm2d_align_batch_pairs re-derives that iteration's pairs from it)
   int32_t cols_max, fcan_total;
   int32_t nn_lds_points, nn_lds_cells;      // > 0: single NN slice over scan-sized fixed clouds -- their search tables are staged in LDS (room for this many)
   int32_t nn_qcache;                        // > 0: single NN slice with its tables in global memory (kNNGlobal): room in LDS for this many queries' cached cell ranges (32 bytes each)
@@ -892,6 +907,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   __shared__ float s_H[9], s_rhs[3], s_sum[kAccumWords + 2];
   __shared__ int   s_n_corr, s_active, s_done, s_status, s_last_n_in;
   __shared__ float s_prev_chi;      // total chi^2 of the previous iteration (termination_chi_epsilon)
+  __shared__ u64 s_dig;             // this iteration's pair digest (lsm2d_iteration_stats.pair_digest): every matched pair adds its hash; only when statistics go out
+  __shared__ int s_phase, s_phase_start, s_phase_end;      // 0: the regular loop, 1: the inlier-only runs (enable_inlier_only_runs); iterations [start, end) belong to the phase
   __shared__ uint16_t s_surv[kAlignBlock];      // culling: the chunks of the moving cloud that survived this iteration's test, compacted in thread order
   __shared__ int s_wcnt[kAlignBlock / 64];
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
@@ -954,11 +971,14 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     for (int k = 0; k < 11; ++k) s_sum[k] = zf;
     s_sum[11] = s_sum[12] = __int_as_float(zi);
     s_n_corr = s_active = zi;
+    s_dig = (u64) (unsigned) zi;
+    if (A.out_last_pose) { A.out_last_pose[3 * a + 0] = s_pose[0]; A.out_last_pose[3 * a + 1] = s_pose[1]; A.out_last_pose[3 * a + 2] = s_pose[2]; }
   };
   if (tid == 0) {
     if (A.inline_n1) { s_pose[0] = A.pose1[0]; s_pose[1] = A.pose1[1]; s_pose[2] = A.pose1[2]; }
     else { s_pose[0] = A.init_pose[3 * a + 0]; s_pose[1] = A.init_pose[3 * a + 1]; s_pose[2] = A.init_pose[3 * a + 2]; }
     s_done = 0; s_status = LSM2D_RUNNING; s_last_n_in = 0;
+    s_phase = 0; s_phase_start = 0; s_phase_end = A.max_it;
     for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
     begin_iteration();
   }
@@ -1074,7 +1094,10 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   __syncthreads();
 
   int it = 0;
-  for (; it < A.max_it; ++it) {
+  const int it_cap = A.inlier_runs ? 2 * A.max_it : A.max_it;
+  const bool want_dig = A.out_stats != nullptr;      // the digest leaves the kernel through the statistics only
+  for (; it < it_cap; ++it) {
+    const bool inl_only = A.inlier_runs && __builtin_amdgcn_readfirstlane(s_phase) != 0;
 #if LSM2D_PRIO_BY_PROGRESS == 1
     { const int q = (4 * it) / A.max_it; if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #elif LSM2D_PRIO_BY_PROGRESS == 2
@@ -1083,6 +1106,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     for (int s = 0; s < A.n_slices; ++s) {
       const SliceDev& S = A.s[s];
       const Iso T = s_iso[s];
+      const uint32_t salt = (uint32_t) s * 0x632BE5ABu;
       Accum acc; accum_zero(acc);
       LSM2D_PH(2);
       if (kHasProj && ((!kHasNN && !kHasDist && !kHasKd) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
@@ -1142,7 +1166,8 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
           const float4 f = fws[col];
           float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
           if (__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos) continue;
-          accumulate_pair(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, S.cauchy != 0, S.tau, acc);
+          if (want_dig) digest_add(&s_dig, salt, (int) (uint32_t) fk, mi);
+          accumulate_pair(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
         }
       } else if (kHasNN || kHasDist || kHasKd) {
         // NN finder fused with the factor (correspondence_finder_kd_tree_2d.cpp:12-27): every moving point is
@@ -1239,7 +1264,10 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
                   const float2 nm = mn[j], nf = kKdAllLds ? l_knr[pos] : (kKdTop ? knr[pos] : (kd_leaves_lds ? l_knr[pos] : knr[pos]));
                   float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
                   const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
-                  if (!(dot < S.normal_cos)) accumulate_pair(T, bxy, nf, pm, nm, S.cauchy != 0, S.tau, acc);
+                  if (!(dot < S.normal_cos)) {
+                    if (want_dig) digest_add(&s_dig, salt, S.fixed.kd.leaf_idx[fbase + pos], j);      // the original index: only the digest asks for it
+                    accumulate_pair(T, bxy, nf, pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
+                  }
                 }
               }
             } else
@@ -1249,7 +1277,10 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
                 const float2 nm = mn[j], nf = knr[pos], pf = sxy[pos];
                 float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
                 const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
-                if (!(dot < S.normal_cos)) accumulate_pair(T, pf, nf, pm, nm, S.cauchy != 0, S.tau, acc);
+                if (!(dot < S.normal_cos)) {
+                  if (want_dig) digest_add(&s_dig, salt, sidx[pos], j);
+                  accumulate_pair(T, pf, nf, pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
+                }
               }
             } else
             if (kNNLds) { if (live) best = nn_query<1, uint16_t, uint16_t>(g, l_cst, l_sidx, l_sxy, qx, qy, S.max_distance, md2, 0); }
@@ -1263,7 +1294,10 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
               const float2 nm = mn[j], nf = fn[best];
               float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
               const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
-              if (!(dot < S.normal_cos)) accumulate_pair(T, fp[best], nf, pm, nm, S.cauchy != 0, S.tau, acc);
+              if (!(dot < S.normal_cos)) {
+                if (want_dig) digest_add(&s_dig, salt, best, j);
+                accumulate_pair(T, fp[best], nf, pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
+              }
             }
           }
         };
@@ -1303,7 +1337,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       // (thread 0's serial state lives in LDS, not in registers every thread would carry -- and spill -- across the loops)
       StatsDev last; last.n_corr = s_n_corr; last.n_in = __float_as_int(s_sum[11]); last.n_out = __float_as_int(s_sum[12]); last.chi_in = s_sum[9]; last.chi_out = s_sum[10];
       s_last_n_in = last.n_in;
-      if (A.out_stats) A.out_stats[(size_t) a * A.max_it + it] = last;
+      if (A.out_stats) { const u64 dg = s_dig; last.dig_lo = (uint32_t) dg; last.dig_hi = (uint32_t) (dg >> 32); A.out_stats[(size_t) a * A.stats_stride + it] = last; }
       if (!s_active) { s_status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
       else {
         // information matrix = H of the last iteration: assembled, given its prior and solved where it lies
@@ -1314,10 +1348,18 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
         float dmp = A.damping;
         asm volatile("" : "+v"(dmp));      // (not a loop invariant to hoist -- as a double it was kept, and spilled, across the whole kernel)
         if (!solve_update(s_H, s_rhs, dmp, s_pose)) { s_status = LSM2D_SINGULAR_H; s_done = 1; }
-        else if (A.term_eps > 0.0f) {      // the aligner's termination criterion: relative decay of the total chi^2 (lsm2d.h)
-          const float chi_now = last.chi_in + last.chi_out;
-          if (it > 0 && __builtin_fabsf(s_prev_chi - chi_now) < A.term_eps * chi_now) s_done = 1;      // status stays RUNNING: decided below as after max_iterations
-          s_prev_chi = chi_now;
+        else {
+          bool phase_over = it + 1 >= s_phase_end;
+          if (A.term_eps > 0.0f) {      // the aligner's termination criterion: relative decay of the total chi^2 (lsm2d.h), afresh in every phase
+            const float chi_now = last.chi_in + last.chi_out;
+            if (it > s_phase_start && __builtin_fabsf(s_prev_chi - chi_now) < A.term_eps * chi_now) phase_over = true;      // status stays RUNNING: decided below as after max_iterations
+            s_prev_chi = chi_now;
+          }
+          if (phase_over) {
+            // enable_inlier_only_runs (lsm2d.h): the regular loop ended without a failure and with enough inliers -> up to max_it iterations over inliers only
+            if (A.inlier_runs && s_phase == 0 && last.n_in >= A.min_inliers) { s_phase = 1; s_phase_start = it + 1; s_phase_end = it + 1 + A.max_it; }
+            else s_done = 1;
+          }
         }
       }
       if (!s_done) begin_iteration();        // next iteration's transforms and zeroed sums, under the same barrier
@@ -1505,7 +1547,8 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   u64* mcan2 = reinterpret_cast<u64*>(red2 + A.n_slices * nwaves * kPairRedStride);      // [n_slices][cols_max]: one moving canvas per slice
   u64* fcan = mcan2 + A.n_slices * A.cols_max;
   __shared__ Iso   s_iso[2];
-  __shared__ int   s_done;
+  __shared__ int   s_done, s_inl;      // s_inl: the iteration about to run belongs to the inlier-only runs (enable_inlier_only_runs)
+  __shared__ u64   s_dig;              // the iteration's pair digest, as in k_align
   __shared__ PriorDev s_prior;
 
   const int a = blockIdx.x, gtid = threadIdx.x, nthr = kAlignBlock * A.n_slices;      // launched with 512 threads per slice (one or two slices)
@@ -1530,7 +1573,9 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
   // clouds on chip (see the head comment): the moving one at most two points per thread (coordinates stay in registers), the fixed one as many rows as LDS has
   const bool m_on_chip = !S.moving.lane_xy && m_count <= A.pair_mov_cap;      // pair_mov_cap: kPairMovCap, or 0 when LDS has no room
-  const bool f_on_chip = f_count <= A.pair_fix_cap;
+  // (workgroup-uniform: the branch below holds a barrier.  pair_fix_cap > 0 means the host sized the rows for the LARGEST fixed cloud of every slice, so
+  // both halves take the same side; with pair_fix_cap == 0 an empty fixed cloud must not count as "on chip" while the other slice's is not)
+  const bool f_on_chip = A.pair_fix_cap > 0 && f_count <= A.pair_fix_cap;
   float4* mwin = mwin2 + half * A.pair_mov_cap;
   float4* fall = fall2 + half * A.pair_fix_cap;
   const int j1 = kPairMovCap - 1 - tid;                   // this thread's second moving point, if the cloud has more than 512
@@ -1557,6 +1602,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   float pose[3] = {0.0f, 0.0f, 0.0f}, hl = 0.0f;
   int status = LSM2D_RUNNING, last_n_in = 0;
   float prev_chi = 0.0f;            // total chi^2 of the previous iteration (termination_chi_epsilon)
+  int phase = 0, phase_start = 0, phase_end = A.max_it;      // as in k_align
   int q = 15, pr = 0, pc = 0; bool has_pterm = false;
   float kS[3] = {0.0f, 0.0f, 0.0f}, kc = 1.0f, ks = 0.0f; int khs = 0;
   if (w0) {
@@ -1574,7 +1620,8 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
     kS[0] = second ? Sb.Sinv[0] : Sa.Sinv[0]; kS[1] = second ? Sb.Sinv[1] : Sa.Sinv[1]; kS[2] = second ? Sb.Sinv[2] : Sa.Sinv[2];
     kc = second ? Sb.cSinv : Sa.cSinv; ks = second ? Sb.sSinv : Sa.sSinv; khs = second ? Sb.has_sensor : Sa.has_sensor;
     if (lane < A.n_slices) s_iso[lane] = slice_iso_of(khs, kc, ks, kS, pose);
-    if (lane == 0) s_done = 0;
+    if (lane == 0) { s_done = 0; s_inl = 0; s_dig = 0ull; }
+    if (A.out_last_pose && lane < 3) A.out_last_pose[3 * a + lane] = lane == 0 ? pose[0] : (lane == 1 ? pose[1] : pose[2]);
   }
   __syncthreads();                  // canvases cleared, prior and first transforms in LDS
   PriorDev pz;                      // wave 0's copy of the prior, in registers
@@ -1612,7 +1659,7 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   int min_corr0 = A.s[0].min_corr, min_corr1 = A.s[1].min_corr, n_slices = A.n_slices;
   unsigned long long prior_ptr = reinterpret_cast<unsigned long long>(A.prior);
   int term_eps_b = __float_as_int(A.term_eps), damping_b = __float_as_int(A.damping);
-  StatsDev* out_stats = A.out_stats ? A.out_stats + (size_t) a * A.max_it : nullptr;
+  StatsDev* out_stats = A.out_stats ? A.out_stats + (size_t) a * A.stats_stride : nullptr;
   asm volatile("" : "+s"(min_corr0), "+s"(min_corr1), "+s"(n_slices), "+s"(prior_ptr), "+s"(term_eps_b), "+s"(damping_b));
   asm volatile("" : "+v"(out_stats));
   const bool two_slices = n_slices == 2, has_prior = prior_ptr != 0;
@@ -1628,13 +1675,17 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
   const int per_thread = (S.proj.cols + kAlignBlock - 1) / kAlignBlock;      // pairs a thread can accumulate
   const int count_bits = 32 - __builtin_clz(per_thread | 1);
   const bool cauchy = S.cauchy != 0;
+  const bool want_dig = A.out_stats != nullptr;
+  const uint32_t salt = (uint32_t) half * 0x632BE5ABu;
+  const int it_cap = A.inlier_runs ? 2 * A.max_it : A.max_it;
   __syncthreads();
   LSM2D_PC(0);
 
   const u64* fcs = fcan + S.fcan_offset; const float4* fws = fwin + S.fcan_offset;
   int it = 0;
-  for (; it < A.max_it; ++it) {
+  for (; it < it_cap; ++it) {
     const Iso T = s_iso[half];
+    const bool inl_only = A.inlier_runs && __builtin_amdgcn_readfirstlane(s_inl) != 0;
     Accum acc; accum_zero(acc);
     if (on_chip) {
       // both clouds in LDS (the tracker's case): one point's z-buffer update per thread, then the walk one column at a time -- every gather is
@@ -1650,8 +1701,10 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
         if (fdb != 0xFFFFFFFFu && mdb != 0xFFFFFFFFu && !(__builtin_fabsf(__uint_as_float(fdb) - __uint_as_float(mdb)) > k_pd)) {
           const float4 m = mwin[(uint32_t) mk], f = fall[(uint32_t) fk];
           float nqx, nqy; xf_normal(T, m.z, m.w, nqx, nqy);
-          if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < k_ncos))
-            accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), make_float2(m.x, m.y), make_float2(m.z, m.w), cauchy, k_tau, acc);
+          if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < k_ncos)) {
+            if (want_dig) digest_add(&s_dig, salt, (int) (uint32_t) fk, (int) (uint32_t) mk);
+            accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), make_float2(m.x, m.y), make_float2(m.z, m.w), cauchy, k_tau, acc, inl_only);
+          }
         }
       }
     } else {
@@ -1690,14 +1743,18 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
       if (g0) {
         const float4 f = f_on_chip ? fall[(uint32_t) fk0] : fws[col];
         float nqx, nqy; xf_normal(T, nm0.x, nm0.y, nqx, nqy);
-        if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos))
-          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm0, nm0, cauchy, S.tau, acc);
+        if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos)) {
+          if (want_dig) digest_add(&s_dig, salt, (int) (uint32_t) fk0, mi0);
+          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm0, nm0, cauchy, S.tau, acc, inl_only);
+        }
       }
       if (g1) {
         const float4 f = f_on_chip ? fall[(uint32_t) fk1] : fws[col1];
         float nqx, nqy; xf_normal(T, nm1.x, nm1.y, nqx, nqy);
-        if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos))
-          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm1, nm1, cauchy, S.tau, acc);
+        if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos)) {
+          if (want_dig) digest_add(&s_dig, salt, (int) (uint32_t) fk1, mi1);
+          accumulate_pair<true>(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm1, nm1, cauchy, S.tau, acc, inl_only);
+        }
       }
     }
     }
@@ -1738,6 +1795,10 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
         const int word = lane == 13 ? 0 : (lane == 11 ? 1 : (lane == 12 ? 2 : lane - 6));
         reinterpret_cast<int32_t*>(out_stats + it)[word] = lane < 11 ? __float_as_int(tot) : (int) tot;
       }
+      if (out_stats && lane == 0) {      // the iteration's pair digest (every pair's add landed before the barrier above); zeroed for the next iteration
+        const u64 dg = s_dig; s_dig = 0ull;
+        reinterpret_cast<uint32_t*>(out_stats + it)[5] = (uint32_t) dg; reinterpret_cast<uint32_t*>(out_stats + it)[6] = (uint32_t) (dg >> 32);
+      }
       LSM2D_PC(8);               // sums of the slices, statistics
       bool done_now = false;
       if (!(act0 || act1)) { status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; done_now = true; }
@@ -1754,16 +1815,24 @@ __global__ __launch_bounds__(kPairBlock) void k_align_pair(const AlignArgs A) {
           const float nx = __builtin_fmaf(cp, dx, __builtin_fmaf(-sp, dy, pose[0]));
           const float ny = __builtin_fmaf(sp, dx, __builtin_fmaf(cp, dy, pose[1]));
           pose[0] = nx; pose[1] = ny; pose[2] = wrap_angle(pose[2] + dth);
+          bool phase_over = it + 1 >= phase_end;
           if (term_eps > 0.0f) {         // as in k_align
             const float chi_now = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 9)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 10));
-            if (it > 0 && __builtin_fabsf(prev_chi - chi_now) < term_eps * chi_now) done_now = true;
+            if (it > phase_start && __builtin_fabsf(prev_chi - chi_now) < term_eps * chi_now) phase_over = true;
             prev_chi = chi_now;
+          }
+          if (phase_over) {              // as in k_align: the inlier-only runs follow a regular loop that ended well
+            if (A.inlier_runs && phase == 0 && last_n_in >= A.min_inliers) { phase = 1; phase_start = it + 1; phase_end = it + 1 + A.max_it; if (lane == 0) s_inl = 1; }
+            else done_now = true;
           }
         }
       }
       LSM2D_PC(10);              // 3x3 solve and pose update
       if (done_now) { if (lane == 0) s_done = 1; }
-      else if (lane < A.n_slices) s_iso[lane] = slice_iso_of(khs, kc, ks, kS, pose);      // the next iteration's transforms: one slice per lane
+      else {
+        if (lane < A.n_slices) s_iso[lane] = slice_iso_of(khs, kc, ks, kS, pose);      // the next iteration's transforms: one slice per lane
+        if (A.out_last_pose && lane < 3) A.out_last_pose[3 * a + lane] = lane == 0 ? pose[0] : (lane == 1 ? pose[1] : pose[2]);
+      }
       LSM2D_PC(4);
     }
     __syncthreads();
@@ -1802,6 +1871,7 @@ struct SplitArgs {
   int32_t* done;         // [n_align] 0 = running
   float* H_last;         // [n_align][9]
   StatsDev* last;        // [n_align]
+  int32_t* phase;        // [n_align][3]: phase (0 regular, 1 inlier-only runs), its first iteration, its end -- zero-filled means (0, 0, max_it)
   int32_t it;            // iteration this launch belongs to
 };
 
@@ -1847,11 +1917,16 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
   // solved where it lies (no private arrays, no scratch on the serial stretch)
   __shared__ float s_H[9], s_rhs[3], s_sum[kAccumWords + 2], s_pose[3];
   __shared__ int s_n_corr, s_active;
+  __shared__ u64 s_dig;
   const int a = blockIdx.x, tid = threadIdx.x;
   constexpr int nwaves = kAlignBlock / 64;
   if (S.done[a]) return;
+  const bool want_dig = A.out_stats != nullptr;
+  const bool inl_only = A.inlier_runs && S.phase[3 * a] != 0;
   if (tid == 0) {
+    s_dig = 0ull;
     s_pose[0] = S.pose[3 * a]; s_pose[1] = S.pose[3 * a + 1]; s_pose[2] = S.pose[3 * a + 2];
+    if (A.out_last_pose) { A.out_last_pose[3 * a] = s_pose[0]; A.out_last_pose[3 * a + 1] = s_pose[1]; A.out_last_pose[3 * a + 2] = s_pose[2]; }
     for (int s = 0; s < A.n_slices; ++s) s_iso[s] = slice_iso(A.s[s], s_pose);
     for (int k = 0; k < 11; ++k) s_sum[k] = 0.0f;
     s_sum[11] = s_sum[12] = __int_as_float(0);
@@ -1871,8 +1946,10 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
       const u64 mk = gM[SL.fcan_offset + col];
       gM[SL.fcan_offset + col] = kEmptyCell;                  // ready for the next iteration's projection
       int fi, mi; float2 nf, nm;
-      if (match_bin(gF[SL.fcan_offset + col], mk, SL, T, fn, mn, fi, mi, nf, nm))
-        accumulate_pair(T, fp[fi], nf, mp[mi], nm, SL.cauchy != 0, SL.tau, acc);
+      if (match_bin(gF[SL.fcan_offset + col], mk, SL, T, fn, mn, fi, mi, nf, nm)) {
+        if (want_dig) digest_add(&s_dig, (uint32_t) s * 0x632BE5ABu, fi, mi);
+        accumulate_pair(T, fp[fi], nf, mp[mi], nm, SL.cauchy != 0, SL.tau, acc, inl_only);
+      }
     }
     block_reduce_store(acc, red, tid);
     __syncthreads();
@@ -1890,9 +1967,10 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
   }
   if (tid == 0) {
     StatsDev last; last.n_corr = s_n_corr; last.n_in = __float_as_int(s_sum[11]); last.n_out = __float_as_int(s_sum[12]); last.chi_in = s_sum[9]; last.chi_out = s_sum[10];
-    if (A.out_stats) A.out_stats[(size_t) a * A.max_it + S.it] = last;
+    if (A.out_stats) { const u64 dg = s_dig; last.dig_lo = (uint32_t) dg; last.dig_hi = (uint32_t) (dg >> 32); A.out_stats[(size_t) a * A.stats_stride + S.it] = last; }
     int status = LSM2D_RUNNING;
     bool stop_now = false;
+    const int ph = A.inlier_runs ? S.phase[3 * a] : 0, ph_start = ph ? S.phase[3 * a + 1] : 0, ph_end = ph ? S.phase[3 * a + 2] : A.max_it;
     if (!s_active) {
       status = LSM2D_NOT_ENOUGH_CORRESPONDENCES;
       for (int k = 0; k < 9; ++k) s_H[k] = S.it == 0 ? 0.0f : S.H_last[9 * a + k];      // the information matrix stays the last solved iteration's
@@ -1907,12 +1985,15 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
         S.pose[3 * a] = s_pose[0]; S.pose[3 * a + 1] = s_pose[1]; S.pose[3 * a + 2] = s_pose[2];
         if (A.term_eps > 0.0f) {       // as in k_align; the previous iteration's statistics wait in S.last
           const float chi_now = last.chi_in + last.chi_out;
-          if (S.it > 0) { const StatsDev pv = S.last[a]; stop_now = __builtin_fabsf((pv.chi_in + pv.chi_out) - chi_now) < A.term_eps * chi_now; }
+          if (S.it > ph_start) { const StatsDev pv = S.last[a]; stop_now = __builtin_fabsf((pv.chi_in + pv.chi_out) - chi_now) < A.term_eps * chi_now; }
           S.last[a] = last;
         }
       }
     }
-    const bool last_it = S.it == A.max_it - 1 || stop_now;
+    bool last_it = S.it + 1 >= ph_end || stop_now;
+    if (status == LSM2D_RUNNING && last_it && A.inlier_runs && ph == 0 && last.n_in >= A.min_inliers) {      // as in k_align: on to the inlier-only runs
+      S.phase[3 * a] = 1; S.phase[3 * a + 1] = S.it + 1; S.phase[3 * a + 2] = S.it + 1 + A.max_it; last_it = false;
+    }
     if (status == LSM2D_RUNNING && last_it) status = last.n_in < A.min_inliers ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
     if (status != LSM2D_RUNNING) {
       S.done[a] = 1;
@@ -1932,6 +2013,8 @@ struct FindArgs {
   int32_t* out_pairs;  // [cols][2]
   int32_t* out_count;
   const u64* fcan_global; const u64* mcan_global;      // a map-sized cloud's canvas, projected over many workgroups beforehand (k_project_split), or nullptr
+  float inl_tau;         // > 0: only pairs whose factor is an inlier under a Cauchy robustifier of this threshold (chi^2 < tau) are emitted -- the aligner's
+                         // keep_only_inlier_correspondences (lsm2d_align_batch_pairs); 0: every pair
 };
 
 __global__ __launch_bounds__(kFindBlock) void k_find_projective(const FindArgs A) {
@@ -1957,6 +2040,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_projective(const FindArgs A
     const int col = c0 + tid;
     int fi = -1, mi = -1; float2 nf, nm; bool ok = false;
     if (col < A.proj.cols) ok = match_bin(fcan[col], mcan[col], S, A.T, A.fixed.nrm + fbase, A.moving.nrm + mbase, fi, mi, nf, nm);
+    if (ok && A.inl_tau > 0.0f) ok = pair_chi(A.T, A.fixed.xy[fbase + fi], nf, A.moving.xy[mbase + mi], nm) < A.inl_tau;
     // order-preserving compaction: ballot prefix inside the wave, wave totals through LDS
     const u64 bal = __ballot(ok);
     const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
@@ -1978,6 +2062,7 @@ struct FindNNArgs {
   float max_distance, normal_cos; Iso T; int32_t nn_group;
   int32_t* out_pairs; int32_t* out_count;
   int32_t* match; int32_t* block_count;      // k_find_nn_multi: per query the matched fixed index or -1; pairs per workgroup
+  float inl_tau;                              // as FindArgs::inl_tau
 };
 
 __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
@@ -2015,6 +2100,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn(const FindNNArgs A) {
         const float2 nm = A.moving.nrm[mbase + j], nf = A.fixed.nrm[fbase + best];
         float nqx, nqy; xf_normal(A.T, nm.x, nm.y, nqx, nqy);
         ok = !(__builtin_fmaf(nqx, nf.x, nqy * nf.y) < A.normal_cos);
+        if (ok && A.inl_tau > 0.0f) ok = pair_chi(A.T, A.fixed.xy[fbase + best], nf, pm, nm) < A.inl_tau;
       }
     }
     // lanes are in ascending query order (tid / group), so the ballot compaction keeps ascending moving index
@@ -2064,6 +2150,7 @@ __global__ __launch_bounds__(kFindBlock) void k_find_nn_multi(const FindNNArgs A
         const float2 nm = A.moving.nrm[mbase + j], nf = A.fixed.nrm[fbase + best];
         float nqx, nqy; xf_normal(A.T, nm.x, nm.y, nqx, nqy);
         ok = !(__builtin_fmaf(nqx, nf.x, nqy * nf.y) < A.normal_cos);
+        if (ok && A.inl_tau > 0.0f) ok = pair_chi(A.T, A.fixed.xy[fbase + best], nf, pm, nm) < A.inl_tau;
       }
       if (sub == 0) A.match[j] = ok ? best : -1;
     }
@@ -2129,21 +2216,29 @@ struct LinArgs {
   Iso T; int32_t cauchy; float tau;
   float* partial;     // [n_blocks][kAccumWords]
   float* out;         // [kAccumWords]
+  unsigned long long* dig;      // the pairs' digest (lsm2d_iteration_stats.pair_digest, slice 0), zeroed by the host: every workgroup adds its share
 };
 
 __global__ __launch_bounds__(256) void k_linearize_partial(const LinArgs A) {
   __shared__ float red[4 * kAccumWords];
+  __shared__ u64 s_dig;
   const int tid = threadIdx.x;
   const int fbase = A.fixed.start[A.fc], mbase = A.moving.start[A.mc];
   Accum acc; accum_zero(acc);
+  if (tid == 0) s_dig = 0ull;
+  __syncthreads();
+  u64 dg = 0ull;
   for (int k = blockIdx.x * 256 + tid; k < A.n_pairs; k += gridDim.x * 256) {
     const int fi = A.pairs[2 * k], mi = A.pairs[2 * k + 1];
+    dg += pair_hash_dev(0u, (uint32_t) fi, (uint32_t) mi);
     accumulate_pair(A.T, A.fixed.xy[fbase + fi], A.fixed.nrm[fbase + fi], A.moving.xy[mbase + mi], A.moving.nrm[mbase + mi],
                     A.cauchy != 0, A.tau, acc);
   }
+  if (dg) atomicAdd(reinterpret_cast<unsigned long long*>(&s_dig), (unsigned long long) dg);
   block_reduce_store(acc, red, tid);
   __syncthreads();
   if (tid == 0) {
+    if (A.dig && s_dig) atomicAdd(A.dig, (unsigned long long) s_dig);
     Accum t; block_reduce_gather(red, 4, t);
     float* p = A.partial + (size_t) blockIdx.x * kAccumWords;
     p[0] = t.h00; p[1] = t.h01; p[2] = t.h02; p[3] = t.h11; p[4] = t.h12; p[5] = t.h22; p[6] = t.b0; p[7] = t.b1; p[8] = t.b2;

@@ -282,9 +282,10 @@ class MultiAligner2D {
   explicit MultiAligner2D(Context& ctx) : _ctx(ctx) {}
   int param_max_iterations = 10, param_min_num_inliers = 10;             // MULTI.json:711,714
   float param_damping = 0.f;                                             // MULTI.json:254-259
-  // the options the shipped aligners carry at their defaults (MULTI.json:606-610,627-630): the device loop has no inlier-only re-runs and
-  // keeps every correspondence, so a non-default value is REFUSED, never ignored; the termination criterion exists as an epsilon (lsm2d.h)
+  // the options the shipped aligners carry at their defaults (MULTI.json:606-610,627-630); semantics in include/lsm2d.h (restated from the
+  // parameters' doc strings: the upstream class is not in the reference tree); the termination criterion exists as an epsilon (lsm2d.h)
   bool param_enable_inlier_only_runs = false, param_keep_only_inlier_correspondences = false;
+  bool store_correspondences = false;      // compute() also fetches what the reference leaves in slice->correspondences() (a finder pass per slice)
   float param_termination_chi_epsilon = 0.f;                             // 0 = "termination_criteria" not set = max_iterations
   std::vector<AlignerSliceProcessorLaser2DPtr> param_slice_processors;
 
@@ -308,14 +309,28 @@ class MultiAligner2D {
     }
     lsm2d_batch b{}; b.n_alignments = 1; b.n_slices = ns; b.slices = sp.data(); b.fixed = fx.data(); b.moving = mv.data();
     b.init_pose = _moving_in_fixed.data(); b.prior = _has_prior ? &_prior : nullptr;
-    if (param_enable_inlier_only_runs || param_keep_only_inlier_correspondences)
-      throw std::runtime_error("MultiAligner2D::compute| enable_inlier_only_runs / keep_only_inlier_correspondences are not supported on the device");
-    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, param_damping, param_termination_chi_epsilon};
-    _stats.assign((size_t) (param_max_iterations > 0 ? param_max_iterations : 1), lsm2d_iteration_stats{});
+    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, param_damping, param_termination_chi_epsilon,
+                            param_enable_inlier_only_runs ? 1 : 0, param_keep_only_inlier_correspondences ? 1 : 0};
+    _stats.assign((size_t) lsm2d_stats_capacity(&ap), lsm2d_iteration_stats{});
     int32_t st = 0, its = 0;
-    check(lsm2d_align_batch(_ctx.get(), &ap, &b, _moving_in_fixed.data(), _information.data(), &st, &its, _stats.data()), "lsm2d_align_batch", _ctx.get());
+    _pairs.assign((size_t) ns, {});
+    if (store_correspondences) {
+      size_t cap = 1;
+      for (int s = 0; s < ns; ++s) {
+        const size_t need = sp[(size_t) s].finder == LSM2D_FINDER_PROJECTIVE ? (size_t) sp[(size_t) s].projector.canvas_cols : (size_t) lsm2d_cloudset_num_points(mv[(size_t) s]);
+        cap = need > cap ? need : cap;
+      }
+      std::vector<lsm2d_correspondence> buf(cap * (size_t) ns); std::vector<int32_t> cnt((size_t) ns, 0);
+      check(lsm2d_align_batch_pairs(_ctx.get(), &ap, &b, _moving_in_fixed.data(), _information.data(), &st, &its, _stats.data(), buf.data(), (int32_t) cap, cnt.data()),
+            "lsm2d_align_batch_pairs", _ctx.get());
+      for (int s = 0; s < ns; ++s) _pairs[(size_t) s].assign(buf.begin() + (long) (cap * (size_t) s), buf.begin() + (long) (cap * (size_t) s) + cnt[(size_t) s]);
+    } else {
+      check(lsm2d_align_batch(_ctx.get(), &ap, &b, _moving_in_fixed.data(), _information.data(), &st, &its, _stats.data()), "lsm2d_align_batch", _ctx.get());
+    }
     _stats.resize((size_t) its); _status = st;
   }
+  // slice->correspondences() after compute() (apps/visual_test_aligner_2d.cpp:129-143); needs store_correspondences
+  const std::vector<lsm2d_correspondence>& correspondences(size_t slice = 0) const { return _pairs.at(slice); }
   const Vector3f& movingInFixed() const { return _moving_in_fixed; }
   const std::array<float, 9>& informationMatrix() const { return _information; }
   const std::vector<lsm2d_iteration_stats>& iterationStats() const { return _stats; }
@@ -326,6 +341,7 @@ class MultiAligner2D {
   Vector3f _moving_in_fixed{{0.f, 0.f, 0.f}};
   std::array<float, 9> _information{};
   std::vector<lsm2d_iteration_stats> _stats;
+  std::vector<std::vector<lsm2d_correspondence>> _pairs;
   lsm2d_prior _prior{}; bool _has_prior = false; int _status = 0;
 };
 
@@ -370,7 +386,7 @@ class LoopClosureSweep {
     const int n = (int) init_pose.size();
     if ((int) scan_index.size() != n) throw std::runtime_error("LoopClosureSweep::compute| one scan index per candidate");
     const lsm2d_slice_params sp = param_slice;
-    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, 0.f, 0.f};
+    lsm2d_aligner_params ap{param_max_iterations, param_min_num_inliers, 0.f, 0.f, 0, 0};
     pose.assign((size_t) n, Vector3f{{0.f, 0.f, 0.f}}); information.assign((size_t) n, std::array<float, 9>{});
     status.assign((size_t) n, 0); iterations.assign((size_t) n, 0); last_stats.assign((size_t) n, lsm2d_iteration_stats{});
     static_assert(sizeof(Vector3f) == 3 * sizeof(float), "poses are packed");

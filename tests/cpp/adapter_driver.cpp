@@ -122,23 +122,48 @@ int main(int argc, char** argv) {
     aligner->param_min_num_inliers.setValue(1000000); aligner->setMovingInFixed(geometry2d::v2t(x0)); aligner->compute();
     out << ",\"status_not_enough_inliers\":" << (int) aligner->status();
     aligner->param_min_num_inliers.setValue(10);
-    // aligner options the device loop does not implement (MULTI.json:606-610,627-630): each non-default value is REFUSED
+    // the aligner's remaining options (MULTI.json:606-610,627-630): a termination_criteria object WITHOUT an epsilon cannot be translated and is
+    // refused, one that carries the float property "epsilon" (as the solver's SimpleTerminationCriteria does, MULTI.json:218-223) is
     auto refuses = [&]() { try { aligner->setMovingInFixed(geometry2d::v2t(x0)); aligner->compute(); } catch (const std::runtime_error&) { return 1; } return 0; };
-    aligner->param_enable_inlier_only_runs.setValue(true);
-    out << ",\"threw_on_inlier_only_runs\":" << refuses();
-    aligner->param_enable_inlier_only_runs.setValue(false);
-    aligner->param_keep_only_inlier_correspondences.setValue(true);
-    out << ",\"threw_on_keep_only_inliers\":" << refuses();
-    aligner->param_keep_only_inlier_correspondences.setValue(false);
     aligner->param_termination_criteria.setValue(std::make_shared<AlignerTerminationCriteriaBase>());
-    out << ",\"threw_on_termination_criteria\":" << refuses();
+    out << ",\"threw_on_opaque_termination_criteria\":" << refuses();
+    struct ChiDecayCriteria : public AlignerTerminationCriteriaBase { PARAM(PropertyFloat, epsilon, "ratio of decay of chi2 between iteration", 1e-3f, 0); };
+    aligner->param_termination_criteria.setValue(std::make_shared<ChiDecayCriteria>());
+    out << ",\"refused_criteria_with_epsilon\":" << refuses();
+    out << ",\"iterations_with_criteria_object\":" << aligner->iterationStats().size() << ",\"pose_with_criteria_object\":" << f3(geometry2d::t2v(aligner->movingInFixed()));
     aligner->param_termination_criteria.setValue(std::shared_ptr<AlignerTerminationCriteriaBase>());
     aligner->param_termination_chi_epsilon.setValue(-1.f);
     out << ",\"threw_on_negative_epsilon\":" << refuses();
-    // ... and the criterion the device does implement: with an epsilon the loop stops early, at the same pose to the tolerance
+    // ... the same criterion through the adapter's own PARAM: with an epsilon the loop stops early, at the same pose to the tolerance
     aligner->param_termination_chi_epsilon.setValue(1e-3f);
     out << ",\"refused_after_reset\":" << refuses();
     out << ",\"iterations_with_epsilon\":" << aligner->iterationStats().size() << ",\"pose_with_epsilon\":" << f3(geometry2d::t2v(aligner->movingInFixed()));
+    aligner->param_termination_chi_epsilon.setValue(0.f);
+  }
+  {
+    // enable_inlier_only_runs / keep_only_inlier_correspondences (MULTI.json:606-610) on a robustified slice: the second loop runs (up to 2 x
+    // max_iterations statistics come back), and the slice is left with the last iteration's inliers only
+    auto aligner = std::make_shared<MultiAlignerHIP2D>();
+    aligner->param_max_iterations.setValue(iters); aligner->param_min_num_inliers.setValue(10);
+    auto slice = makeSlice(std::make_shared<AlignerSliceProcessorLaser2D>(), 0.8f, 0.05f);
+    aligner->param_slice_processors.pushBack(slice);
+    aligner->param_publish_correspondences.setValue(1);
+    aligner->setFixed(&fixed_scene); aligner->setMoving(&moving_scene);
+    // a start off by 15 cm / 3 degrees: the first iterations see outliers
+    const Vector3f x_off(x0.x() + 0.15f, x0.y() - 0.1f, x0.z() + 0.05f);
+    aligner->setMovingInFixed(geometry2d::v2t(x_off)); aligner->compute();
+    out << ",\"plain_iterations\":" << aligner->iterationStats().size() << ",\"plain_pairs\":" << slice->correspondences().size()
+        << ",\"plain_last_inliers\":" << aligner->iterationStats().back().num_inliers << ",\"plain_last_outliers\":" << aligner->iterationStats().back().num_outliers
+        << ",\"plain_pose\":" << f3(geometry2d::t2v(aligner->movingInFixed()));
+    aligner->param_keep_only_inlier_correspondences.setValue(true);
+    aligner->setMovingInFixed(geometry2d::v2t(x_off)); aligner->compute();
+    out << ",\"keep_pairs\":" << slice->correspondences().size() << ",\"keep_last_inliers\":" << aligner->iterationStats().back().num_inliers
+        << ",\"keep_pose\":" << f3(geometry2d::t2v(aligner->movingInFixed()));
+    aligner->param_enable_inlier_only_runs.setValue(true);
+    aligner->setMovingInFixed(geometry2d::v2t(x_off)); aligner->compute();
+    out << ",\"inlier_runs_iterations\":" << aligner->iterationStats().size() << ",\"inlier_runs_status\":" << aligner->lastDeviceStatus()
+        << ",\"inlier_runs_pairs\":" << slice->correspondences().size() << ",\"inlier_runs_last_inliers\":" << aligner->iterationStats().back().num_inliers
+        << ",\"inlier_runs_pose\":" << f3(geometry2d::t2v(aligner->movingInFixed()));
   }
   {
     // the tracker's configuration (MULTI.json:715-721): laser slice with sensor extrinsics + Cauchy, the odometry prior, a second laser slice

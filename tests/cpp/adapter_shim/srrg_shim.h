@@ -19,6 +19,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -114,12 +115,25 @@ namespace srrg2_core {
   using CorrespondenceVector = std::vector<Correspondence>;
 
   // ---- properties / configurables (srrg_property, srrg_config)
-  class Configurable { public: virtual ~Configurable() {} };
   class PropertyBase { public: virtual ~PropertyBase() {} };
+  // containers holding named properties: the dynamic ones of apps/visual_test_aligner_2d.cpp:108-118, and every Configurable (a PARAM
+  // registers itself with its owner under its name: what ConfigurableManager reads and writes a configuration file through)
+  class PropertyContainerBase {
+  public:
+    virtual ~PropertyContainerBase() {}
+    std::map<std::string, PropertyBase*> _props;
+    PropertyBase* property(const std::string& name_) const { auto it = _props.find(name_); return it == _props.end() ? nullptr : it->second; }
+  };
+  using PropertyContainerDynamic = PropertyContainerBase;
+  class Configurable : public PropertyContainerBase { public: virtual ~Configurable() {} };
   template <typename T>
   class Property_ : public PropertyBase {
   public:
     Property_(const char* name_, const char*, void*, const T& def_, bool* flag_ = nullptr) : _name(name_), _value(def_), _flag(flag_) {}
+    template <typename Owner_, typename = typename std::enable_if<std::is_base_of<PropertyContainerBase, Owner_>::value>::type>
+    Property_(const char* name_, const char*, Owner_* owner_, const T& def_, bool* flag_ = nullptr) : _name(name_), _value(def_), _flag(flag_) {
+      if (owner_) static_cast<PropertyContainerBase*>(owner_)->_props[_name] = this;
+    }
     Property_(const std::string& name_, const std::string&, class PropertyContainerBase* owner_);
     const T& value() const { return _value; }
     T& value() { return _value; }
@@ -153,14 +167,6 @@ namespace srrg2_core {
   protected:
     std::vector<std::shared_ptr<C>> _v;
   };
-  // dynamic containers holding named properties (apps/visual_test_aligner_2d.cpp:108-118)
-  class PropertyContainerBase {
-  public:
-    virtual ~PropertyContainerBase() {}
-    std::map<std::string, PropertyBase*> _props;
-    PropertyBase* property(const std::string& name_) const { auto it = _props.find(name_); return it == _props.end() ? nullptr : it->second; }
-  };
-  using PropertyContainerDynamic = PropertyContainerBase;
   template <typename T>
   Property_<T>::Property_(const std::string& name_, const std::string&, PropertyContainerBase* owner_) : _name(name_) { if (owner_) owner_->_props[name_] = this; }
 

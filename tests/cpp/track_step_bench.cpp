@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
     sl[i].robustifier = i ? LSM2D_ROBUST_NONE : LSM2D_ROBUST_CAUCHY; sl[i].chi_threshold = 0.01f; sl[i].min_num_correspondences = 5;
     memcpy(sl[i].sensor_in_robot, i ? S1 : S0, sizeof S0);
   }
-  lsm2d_aligner_params ap = {10, 10, 0.0f};
+  lsm2d_aligner_params ap = {10, 10, 0.0f, 0.0f, 0, 0};
   lsm2d_prior prior; memset(&prior, 0, sizeof prior); prior.omega[0] = prior.omega[4] = prior.omega[8] = 100.0f;
   const lsm2d_cloudset* fixed[2] = {m0, m1}; const lsm2d_cloudset* moving[2] = {clipped, clipped};
   const float x0[3] = {0, 0, 0};

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     bound = {s[0] for s in _capi.SYMBOLS}
     assert set(declared) == bound
     l = _capi.load()
-    assert l.lsm2d_version() == 130
+    assert l.lsm2d_version() == 140
     assert l.lsm2d_status_string(0) == b"Success" and l.lsm2d_status_string(-4) == b"CapacityExceeded"
 
 
@@ -55,10 +55,10 @@ def test_struct_layouts_match_header_sizes():
     from srrg2_laser_slam_2d_amd import _capi
     assert C.sizeof(_capi.Projector) == 24
     assert C.sizeof(_capi.SliceParams) == 4 + 24 + 16 + 4 + 4 + 4 + 12 + 4 + 4
-    assert C.sizeof(_capi.AlignerParams) == 16
+    assert C.sizeof(_capi.AlignerParams) == 24
     assert C.sizeof(_capi.Prior) == 48
     assert C.sizeof(_capi.Correspondence) == 8
-    assert C.sizeof(_capi.IterationStats) == 20
+    assert C.sizeof(_capi.IterationStats) == 28
 
 
 def test_struct_layouts_match_the_c_compiler(tmp_path):

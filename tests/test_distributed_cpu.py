@@ -91,3 +91,43 @@ def test_gloo_world_size_2_shards_align_and_cross_check(tmp_path):
     port = _free_port()
     mp.spawn(_align_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "aligned0").exists() and (tmp_path / "aligned1").exists()
+
+
+def test_shard_by_work_partitions_exactly_and_balances():
+    """distributed.shard_by_work: contiguous, exhaustive, deterministic; cumulative work per rank within one candidate's worth of the ideal."""
+    rng = np.random.default_rng(3)
+    for n in (1, 5, 1000, 65536):
+        w = rng.integers(150, 320, size=n)
+        for world in (1, 2, 3, 8):
+            sh = distributed.shard_by_work(w, world)
+            assert len(sh) == world and sh[0][0] == 0 and sh[-1][1] == n and all(a[1] == b[0] for a, b in zip(sh, sh[1:])) and all(lo <= hi for lo, hi in sh)
+            assert sh == distributed.shard_by_work(w.copy(), world)
+            if n >= 100 * world:
+                tot = [int(w[lo:hi].sum()) for lo, hi in sh]
+                assert max(tot) - w.sum() / world <= 2 * w.max()
+    # heavy candidates at one end: equal counts would give one rank most of the work
+    w = np.concatenate([np.full(500, 300), np.full(500, 100)])
+    sh = distributed.shard_by_work(w, 2)
+    by_count = [int(w[lo:hi].sum()) for lo, hi in (distributed.shard_range(1000, r, 2) for r in range(2))]
+    by_work = [int(w[lo:hi].sum()) for lo, hi in sh]
+    assert max(by_work) < max(by_count) and max(by_work) <= 100300
+    # no usable estimate: the count partition
+    assert distributed.shard_by_work(np.zeros(10), 3) == [distributed.shard_range(10, r, 3) for r in range(3)]
+    assert distributed.shard_by_work([], 2) == [(0, 0), (0, 0)]
+
+
+def test_bench_refuses_more_gpus_than_devices_without_a_launcher():
+    """`python bench.py --gpus 8` with no launcher in front must never print a line that claims one GPU: it starts its own ranks -- or, where the box
+    has fewer devices than ranks (this CPU container has none), exits non-zero before anything runs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LSM2D_BENCH_BACKEND")}
+    if torch.cuda.device_count() >= 8:
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "device(s) visible" in (r.stderr + r.stdout)
+    # a launcher's world that disagrees with --gpus is refused as well (it used to pass when WORLD_SIZE was 1)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout

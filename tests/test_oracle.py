@@ -496,3 +496,88 @@ def test_tracker_replay_1000_digests(po):
     got = tracker_chain.run_oracle(po, g["steps_total"], record_every=g["record_every"])
     assert got == g["steps"]
     assert len(got) == 20 and all(st["status"] == 0 for st in got)
+
+
+def test_pair_digest_definitions_agree_and_tell_sets_apart(po, small_workload):
+    """lsm2d_iteration_stats.pair_digest: the C oracle's hash, its numpy restatement and the product library's lsm2d_pair_hash (host code, no GPU
+    needed) are the same function; the digest of a correspondence set does not depend on the order of its pairs, and exchanging partners,
+    moving one index by one or swapping the slice changes it."""
+    from srrg2_laser_slam_2d_amd import _capi
+    L = po.lib(); lib = _capi.load()
+    rng = np.random.default_rng(5)
+    p = rng.integers(0, 2 ** 31 - 1, size=(2000, 2)); p[:50] = rng.integers(0, 40, size=(50, 2))
+    for sl in (0, 1, 2, 3):
+        c = 0
+        for f, m in p[:300]:
+            h = L.lsmo_pair_hash(sl, int(f), int(m))
+            assert h == lib.lsm2d_pair_hash(sl, int(f), int(m))
+            c = (c + h) & 0xFFFFFFFFFFFFFFFF
+        assert c == po.pair_digest(p[:300], sl)
+    base = po.pair_digest(p)
+    assert base == po.pair_digest(p[rng.permutation(len(p))])                      # order-independent
+    q = p.copy(); q[[10, 11], 1] = q[[11, 10], 1]; assert po.pair_digest(q) != base      # partners exchanged
+    q = p.copy(); q[7, 0] += 1; assert po.pair_digest(q) != base
+    q = p.copy(); q[7, 1] += 1; assert po.pair_digest(q) != base
+    assert po.pair_digest(p, 1) != base and po.pair_digest(p[:-1]) != base
+    # the aligner's statistics carry it: every iteration's digest is the digest of the finder's pairs at that iteration's pose, both summation orders
+    wl = small_workload
+    s = wl.scan_points[wl.scan_offsets[1]:wl.scan_offsets[2]]
+    for dev in (False, True):
+        r = po.align(po.aligner_params(6, device_order=dev), [po.slice_params()], [s], [wl.map_points], wl.x0[1], want_pairs=True)
+        assert r["stats"][0].pair_digest == po.pair_digest(po.find(po.slice_params(), s, wl.map_points, wl.x0[1]))
+        assert r["stats"][-1].pair_digest == po.pair_digest(r["pairs"][0]) and len(r["pairs"][0]) == r["stats"][-1].n_corr
+    # two slices: the second slice's pairs are salted with its index
+    r2 = po.align(po.aligner_params(3), [po.slice_params(), po.slice_params(normal_cos=0.9)], [s, s], [wl.map_points, wl.map_points], wl.x0[1], want_pairs=True)
+    assert r2["stats"][-1].pair_digest == (po.pair_digest(r2["pairs"][0], 0) + po.pair_digest(r2["pairs"][1], 1)) & 0xFFFFFFFFFFFFFFFF
+    assert r2["stats"][-1].n_corr == len(r2["pairs"][0]) + len(r2["pairs"][1])
+
+
+def test_inlier_only_runs_and_keep_only_inlier_correspondences_semantics(po, small_workload):
+    """MultiAligner2D's two remaining options as restated in lsm2d_oracle.h (MULTI.json:606-610; [UPSTREAM-MEMORY]):
+    enable_inlier_only_runs -- a second loop of up to max_iterations iterations when the regular loop ended well with enough inliers, in which
+    non-inliers weigh nothing and inliers 1; keep_only_inlier_correspondences -- the pairs handed back are the last iteration's inliers."""
+    wl = small_workload
+    s = wl.scan_points[wl.scan_offsets[2]:wl.scan_offsets[3]].copy()
+    s[:, :2] += np.random.default_rng(11).normal(0.0, 0.02, (len(s), 2)).astype(np.float32)      # range noise: outliers under a tight kernel, to the end
+    x_off = wl.x0[2] + np.float32([0.15, -0.1, 0.05])
+    tau = 5e-4
+    spc = po.slice_params(robustifier=po.ROBUST_CAUCHY, chi_threshold=tau)
+    for mode in (False, True, "ref"):
+        dt = np.float64 if mode is True else np.float32
+        kw = dict(double=mode)
+        plain = po.align(po.aligner_params(8), [spc], [s], [wl.map_points], x_off.astype(dt), want_pairs=True, **kw)
+        runs = po.align(po.aligner_params(8, enable_inlier_only_runs=True), [spc], [s], [wl.map_points], x_off.astype(dt), want_pairs=True, **kw)
+        assert plain["iterations"] == 8 and runs["iterations"] == 16 and runs["status"] == 0
+        # the regular loop is untouched by the option: its eight iterations are the plain run's, bit for bit
+        for k in range(8):
+            a, b = plain["stats"][k], runs["stats"][k]
+            assert (a.n_corr, a.n_in, a.n_out, a.chi_in, a.chi_out, a.pair_digest) == (b.n_corr, b.n_in, b.n_out, b.chi_in, b.chi_out, b.pair_digest)
+        # not enough inliers at the end of the regular loop: no second loop
+        few = po.align(po.aligner_params(8, min_num_inliers=10 ** 6, enable_inlier_only_runs=True), [spc], [s], [wl.map_points], x_off.astype(dt), **kw)
+        assert few["iterations"] == 8 and few["status"] == po.NOT_ENOUGH_INLIERS
+        # keep_only_inlier_correspondences: a subset of the unfiltered vector, as many as the last iteration's inliers; nothing else moves
+        keep = po.align(po.aligner_params(8, keep_only_inlier_correspondences=True), [spc], [s], [wl.map_points], x_off.astype(dt), want_pairs=True, **kw)
+        assert np.array_equal(keep["pose"], plain["pose"]) and np.array_equal(keep["H"], plain["H"])
+        assert len(keep["pairs"][0]) == plain["stats"][-1].n_in and plain["stats"][-1].n_out > 0
+        assert {tuple(p) for p in keep["pairs"][0].tolist()} < {tuple(p) for p in plain["pairs"][0].tolist()}
+    # a slice without robustifier has no outliers: the second loop is eight more regular iterations
+    sp = po.slice_params()
+    r16 = po.align(po.aligner_params(16), [sp], [s], [wl.map_points], wl.x0[2])
+    r8x2 = po.align(po.aligner_params(8, enable_inlier_only_runs=True), [sp], [s], [wl.map_points], wl.x0[2])
+    assert r8x2["iterations"] == 16 and np.array_equal(r16["pose"], r8x2["pose"]) and np.array_equal(r16["H"], r8x2["H"])
+    # the weights of the second loop by hand: H of its first iteration = sum over the INLIERS of J^T J at that iteration's pose (fp64 oracle)
+    runs = po.align(po.aligner_params(8, enable_inlier_only_runs=True), [spc], [s], [wl.map_points], x_off.astype(np.float64), double=True)
+    nine = po.align(po.aligner_params(1, enable_inlier_only_runs=True, min_num_inliers=0), [spc], [s], [wl.map_points], x_off.astype(np.float64), double=True)
+    assert nine["iterations"] == 2
+    first = po.align(po.aligner_params(1), [spc], [s], [wl.map_points], x_off.astype(np.float64), double=True)
+    pairs = po.find(spc, s, wl.map_points, first["pose"], double=True)
+    H = np.zeros((3, 3))
+    for fi, mi in pairs:
+        e, J = po.error_jacobian(s[fi], wl.map_points[mi], first["pose"])
+        if float(e @ e) < tau:
+            H += J.T @ J
+    assert np.allclose(nine["H"], H, rtol=1e-9, atol=1e-9)
+    # the termination criterion starts afresh in the second loop
+    te = po.align(po.aligner_params(12, termination_chi_epsilon=1e-2, enable_inlier_only_runs=True), [spc], [s], [wl.map_points], x_off)
+    k1 = po.align(po.aligner_params(12, termination_chi_epsilon=1e-2), [spc], [s], [wl.map_points], x_off)["iterations"]
+    assert k1 < 12 and k1 + 2 <= te["iterations"] <= k1 + 12

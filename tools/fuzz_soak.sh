@@ -1,0 +1,11 @@
+#!/bin/bash
+# Soak of the three randomised GPU tests over many seeds: bash tools/fuzz_soak.sh <out.log> [trials] [seed ...]
+# (the structure fuzz holds every alignment whose per-iteration pair digests equal the sequential-order oracle's to the 1e-4 m / 1e-4 rad bar)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; out=$1; trials=${2:-420}; shift 2
+seeds=${@:-"1 2 3 5 7 11 42 99 123 777 2024 5150 31337 65537"}
+cd $R; : > $out
+for s in $seeds; do
+  echo "== seed $s, $trials trials" >> $out
+  LSM2D_FUZZ_TRIALS=$trials LSM2D_FUZZ_SEED=$s timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "randomised" >> $out 2>&1 || { echo "FAILED seed $s" >> $out; tail -30 $out; exit 1; }
+done
+grep -c "3 passed" $out
