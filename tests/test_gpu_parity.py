@@ -2416,14 +2416,16 @@ def test_termination_chi_epsilon_all_aligner_paths(ctx, po, small_workload):
                 _assert_bitwise_equal_to_device_order_oracle(res, i, rt, ("eps", eps, i))
     with pytest.raises(api.Lsm2dError):
         _neg_eps(ctx, fixed, moving, wl)
+    # the two options round 3 refused run on the device since round 4 (test_pair_digest_inlier_only_runs_and_kept_correspondences_all_paths holds them
+    # to the oracle); on a slice without robustifier the second loop is five more regular iterations
     al = api.MultiAligner2D(ctx, max_iterations=5)
     al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector())))
-    al.param_enable_inlier_only_runs = True
-    with pytest.raises(RuntimeError):
-        al.compute_batch([fixed], [moving], wl.x0)
-    al.param_enable_inlier_only_runs = False; al.param_keep_only_inlier_correspondences = True
-    with pytest.raises(RuntimeError):
-        al.compute_batch([fixed], [moving], wl.x0)
+    al.param_enable_inlier_only_runs = True; al.param_keep_only_inlier_correspondences = True
+    r10 = al.compute_batch([fixed], [moving], wl.x0)
+    al2 = api.MultiAligner2D(ctx, max_iterations=10)
+    al2.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector())))
+    r10b = al2.compute_batch([fixed], [moving], wl.x0)
+    assert np.all(r10.iterations == 10) and np.array_equal(r10.pose, r10b.pose) and np.array_equal(r10.information, r10b.information)
 
 
 def _neg_eps(ctx, fixed, moving, wl):
