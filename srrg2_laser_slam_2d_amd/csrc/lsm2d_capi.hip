@@ -55,6 +55,9 @@ struct lsm2d_context {
   int nn_qcache = 1;           // grid NN over a map-sized fixed cloud: cache every query's cell ranges in LDS between iterations (0: off; A/B knob)
   int cull_block = 0;          // steps per unit of the culled stream (0: automatic, ~1/25 of a chunk; even; tuning knob)
   int cull = 1;                // k_align, projective slices: exact culling of the moving cloud against the fixed canvas (0: off; results do not depend on it)
+  int cull_keep = 1;           // ... the culled stream's unit lists are kept across iterations while the estimate stays within the margins they were built with (0: rebuilt every iteration; A/B knob)
+  int cull_margin_um = 10000;  // the translation margin in micrometres (10 mm) and
+  int cull_margin_urad = 2000; // the rotation margin in microradians (2 mrad): tuning knobs, results do not depend on them
   int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
   int kd_lds_nodes = 1536;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it; 512 / 1024 / 1536: 0.830 / 0.804 / 0.778 ms on configs[1] role B)
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
@@ -120,6 +123,8 @@ struct lsm2d_cloudset {
   // lane-chunked copy of xy for k_align's streaming pass (built on first use, dropped when the contents change)
   mutable float4* d_lane_xy = nullptr; mutable long long* d_lane_start = nullptr; mutable int32_t* d_lane_T = nullptr;
   mutable float4* d_lane_bounds = nullptr;      // bounding circle of every thread's chunk of every cloud (k_lane_bounds): what the culling tests
+  mutable float4* d_block_bounds = nullptr;     // ... and of every block of every chunk (k_block_bounds): the block-level test of the unit lists
+  mutable float4* d_aos = nullptr;              // (x, y, nx, ny) rows of the whole set (k_aos_rows): one gather per z-buffer winner in k_align's bin walk
   mutable float4* d_tile_bounds = nullptr; mutable int32_t* d_tile_start = nullptr;      // bounding circles of the tiles of 64 points (k_tile_bounds): the point-query finders' culling
   int32_t n_clouds = 0;
   mutable int64_t total = 0;  // logical points
@@ -264,6 +269,9 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull must be 0, 1 or 2"); ctx->cull = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_keep")) { ctx->cull_keep = value != 0; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_margin_um")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_margin_um: 0 .. 1e6"); ctx->cull_margin_um = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_margin_urad")) { if (value < 0 || value > 200000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_margin_urad: 0 .. 2e5"); ctx->cull_margin_urad = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_qcache")) { ctx->nn_qcache = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "nn_lds_only")) { ctx->nn_lds_only = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_modes")) { ctx->kd_modes = value != 0; return LSM2D_SUCCESS; }
@@ -286,6 +294,9 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "kd_modes")) { *out_value = ctx->kd_modes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "proj_modes")) { *out_value = ctx->proj_modes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_keep")) { *out_value = ctx->cull_keep; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_margin_um")) { *out_value = ctx->cull_margin_um; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_margin_urad")) { *out_value = ctx->cull_margin_urad; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_query_cull")) { *out_value = ctx->last_query_cull; return LSM2D_SUCCESS; }
@@ -439,6 +450,8 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_lane_start) (void) hipFree(cs->d_lane_start);
   if (cs->d_lane_T) (void) hipFree(cs->d_lane_T);
   if (cs->d_lane_bounds) (void) hipFree(cs->d_lane_bounds);
+  if (cs->d_block_bounds) (void) hipFree(cs->d_block_bounds);
+  if (cs->d_aos) (void) hipFree(cs->d_aos);
   if (cs->d_tile_bounds) (void) hipFree(cs->d_tile_bounds);
   if (cs->d_tile_start) (void) hipFree(cs->d_tile_start);
   if (cs->ctx && cs->staged_epoch == cs->ctx->sync_epoch) (void) stream_sync(cs->ctx);      // a staged transfer may still be reading h_upload
@@ -524,6 +537,8 @@ static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents 
   if (cs->d_lane_start) { (void) hipFree(cs->d_lane_start); cs->d_lane_start = nullptr; }
   if (cs->d_lane_T) { (void) hipFree(cs->d_lane_T); cs->d_lane_T = nullptr; }
   if (cs->d_lane_bounds) { (void) hipFree(cs->d_lane_bounds); cs->d_lane_bounds = nullptr; }
+  if (cs->d_block_bounds) { (void) hipFree(cs->d_block_bounds); cs->d_block_bounds = nullptr; }
+  if (cs->d_aos) { (void) hipFree(cs->d_aos); cs->d_aos = nullptr; }
   if (cs->d_tile_bounds) { (void) hipFree(cs->d_tile_bounds); cs->d_tile_bounds = nullptr; }
   if (cs->d_tile_start) { (void) hipFree(cs->d_tile_start); cs->d_tile_start = nullptr; }
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
@@ -663,6 +678,7 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
   c.lane_xy = cs->d_lane_xy; c.lane_start = cs->d_lane_start; c.lane_T = cs->d_lane_T; c.lane_bounds = cs->d_lane_bounds;
+  c.block_bounds = cs->d_block_bounds; c.aos = cs->d_aos;
   c.tile_bounds = cs->d_tile_bounds; c.tile_start = cs->d_tile_start;
   c.grid = GridDev{nullptr, nullptr, nullptr, nullptr, nullptr};
   c.dist = DistDev{nullptr, nullptr};
@@ -820,7 +836,10 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
 
 static CloudDev cloud_dev_with_tiles(CloudDev c, const lsm2d_cloudset* cs) { c.tile_bounds = cs->d_tile_bounds; c.tile_start = cs->d_tile_start; return c; }
 
-// lane-chunked copy of every cloud for k_align's projective streaming pass (project_cloud_lanes in lsm2d_device.h)
+// lane-chunked copy of every cloud for k_align's projective streaming pass (project_cloud_lanes in lsm2d_device.h), with the bounding circles of
+// every thread's chunk and of every block of it (the exact culling).  Everything is built into guarded temporaries and PUBLISHED to the set only
+// after the last launch has finished (round-3 advisor: a failure half-way used to leave d_lane_xy set and never filled -- the next call streamed
+// uninitialised memory).
 static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
   if (cs->d_lane_xy || cs->count_pending) return LSM2D_SUCCESS;     // a size-pending set is a clipped scene: small, and building needs a sync
   const int nc = cs->n_clouds;
@@ -839,24 +858,45 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
   }
   if (slots == 0) slots = 1;
   slots += 2 * kAlignBlock;      // two spare rows behind the last cloud: project_cloud_units' look-ahead load may read one row past a cloud's last
-  HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_xy, sizeof(float4) * (size_t) slots));
-  HIPCHK(ctx, hipMemsetAsync(cs->d_lane_xy + (slots - 2 * kAlignBlock), 0x7f, sizeof(float4) * 2 * kAlignBlock, ctx->stream));
-  HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_bounds, sizeof(float4) * (size_t) nc * kAlignBlock));
-  HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_start, sizeof(long long) * (size_t) nc));
-  HIPCHK(ctx, hipMalloc((void**) &cs->d_lane_T, sizeof(int32_t) * (size_t) nc));
-  HIPCHK(ctx, hipMemcpyAsync(cs->d_lane_start, lstart.data(), sizeof(long long) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(cs->d_lane_T, lT.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  DevTmp t_xy, t_bounds, t_blocks, t_start, t_T;
+  HIPCHK(ctx, hipMalloc(&t_xy.p, sizeof(float4) * (size_t) slots));
+  HIPCHK(ctx, hipMalloc(&t_bounds.p, sizeof(float4) * (size_t) nc * kAlignBlock));
+  HIPCHK(ctx, hipMalloc(&t_blocks.p, sizeof(float4) * (size_t) nc * kCullBlocks * kAlignBlock));
+  HIPCHK(ctx, hipMalloc(&t_start.p, sizeof(long long) * (size_t) nc));
+  HIPCHK(ctx, hipMalloc(&t_T.p, sizeof(int32_t) * (size_t) nc));
+  float4* d_xy = (float4*) t_xy.p; float4* d_bounds = (float4*) t_bounds.p; float4* d_blocks = (float4*) t_blocks.p;
+  long long* d_start = (long long*) t_start.p; int32_t* d_T = (int32_t*) t_T.p;
+  HIPCHK(ctx, hipMemsetAsync(d_xy + (slots - 2 * kAlignBlock), 0x7f, sizeof(float4) * 2 * kAlignBlock, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_start, lstart.data(), sizeof(long long) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_T, lT.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   long long per = (long long) maxT * kAlignBlock; int gx = (int) ((per + 255) / 256); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
   for (int c0 = 0; c0 < nc; c0 += 32768) {         // gridDim.y is limited to 65535
     const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
     hipLaunchKernelGGL(k_lane_layout, dim3((unsigned) gx, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
-                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const long long*) cs->d_lane_start,
-                       (const int32_t*) cs->d_lane_T, (int) kAlignBlock, cs->d_lane_xy, c0);
+                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const long long*) d_start,
+                       (const int32_t*) d_T, (int) kAlignBlock, d_xy, c0);
     hipLaunchKernelGGL(k_lane_bounds, dim3((unsigned) (kAlignBlock / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
-                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) cs->d_lane_T, (int) kAlignBlock, cs->d_lane_bounds, c0);
+                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) d_T, (int) kAlignBlock, d_bounds, c0);
+    hipLaunchKernelGGL(k_block_bounds, dim3((unsigned) (kAlignBlock * kCullBlocks / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) d_T, (int) kAlignBlock, d_blocks, c0);
   }
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, stream_sync(ctx));        // the host vectors above back the async copies
+  HIPCHK(ctx, stream_sync(ctx));        // the host vectors above back the async copies; and only a finished build is published
+  cs->d_lane_xy = (float4*) t_xy.release(); cs->d_lane_bounds = (float4*) t_bounds.release(); cs->d_block_bounds = (float4*) t_blocks.release();
+  cs->d_lane_start = (long long*) t_start.release(); cs->d_lane_T = (int32_t*) t_T.release();
+  return LSM2D_SUCCESS;
+}
+
+// (x, y, nx, ny) rows of the whole set: k_align's bin walk gathers a z-buffer winner's point and normal as one 16-byte row
+static int ensure_aos(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
+  if (cs->d_aos || cs->count_pending || cs->unpack_pending || cs->prep_pending) return LSM2D_SUCCESS;      // (a set still changing on the device is gathered from its split arrays)
+  DevTmp t;
+  HIPCHK(ctx, hipMalloc(&t.p, sizeof(float4) * (size_t) cs->padded_total));
+  long long blocks = (cs->padded_total + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_aos_rows, dim3((unsigned) blocks), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy, (const float2*) cs->d_nrm, (long long) cs->padded_total, (float4*) t.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, stream_sync(ctx));
+  cs->d_aos = (float4*) t.release();
   return LSM2D_SUCCESS;
 }
 
@@ -871,17 +911,19 @@ static int ensure_tile_bounds(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
     tstart[c] = (int32_t) tiles; tiles += t; if (t > max_tiles) max_tiles = t;
     if (tiles > 0x7fffffff) return LSM2D_SUCCESS;          // (no culling for such a set)
   }
-  HIPCHK(ctx, hipMalloc((void**) &cs->d_tile_bounds, sizeof(float4) * (size_t) (tiles > 0 ? tiles : 1)));
-  HIPCHK(ctx, hipMalloc((void**) &cs->d_tile_start, sizeof(int32_t) * (size_t) nc));
-  HIPCHK(ctx, hipMemcpyAsync(cs->d_tile_start, tstart.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  DevTmp t_bounds, t_start;      // published only when complete (see ensure_lane_layout)
+  HIPCHK(ctx, hipMalloc(&t_bounds.p, sizeof(float4) * (size_t) (tiles > 0 ? tiles : 1)));
+  HIPCHK(ctx, hipMalloc(&t_start.p, sizeof(int32_t) * (size_t) nc));
+  HIPCHK(ctx, hipMemcpyAsync(t_start.p, tstart.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   int gx = (max_tiles + 3) / 4; if (gx > 4096) gx = 4096; if (gx < 1) gx = 1;
   for (int c0 = 0; c0 < nc; c0 += 32768) {
     const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
     hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned) gx, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy, (const int32_t*) cs->d_start,
-                       (const int32_t*) cs->d_count, (const int32_t*) cs->d_tile_start, cs->d_tile_bounds, c0);
+                       (const int32_t*) cs->d_count, (const int32_t*) t_start.p, (float4*) t_bounds.p, c0);
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, stream_sync(ctx));        // the host vector above backs the async copy
+  cs->d_tile_bounds = (float4*) t_bounds.release(); cs->d_tile_start = (int32_t*) t_start.release();
   return LSM2D_SUCCESS;
 }
 
@@ -1635,6 +1677,13 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     if (!defer_unpack) { const int urc = flush_pending(f); if (urc) return urc; }
     { const int urc = flush_pending(m); if (urc) return urc; }
     if (sp.finder == LSM2D_FINDER_PROJECTIVE) { const int lrc = ensure_lane_layout(ctx, m); if (lrc) return lrc; }
+    // k_align's bin walk gathers both z-buffer winners as 16-byte rows of the sets' AoS copies (not for the calls the latency kernel or the split
+    // path will take: the live tracker's sets change every step)
+    const bool pair_candidate = ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist && !has_kd && (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0;
+    if (sp.finder == LSM2D_FINDER_PROJECTIVE && !use_split && !pair_candidate && !defer_unpack) {
+      int arc = ensure_aos(ctx, f); if (arc) return arc;
+      arc = ensure_aos(ctx, m); if (arc) return arc;
+    }
     S.fixed = cloud_dev(f, d_fi); S.moving = cloud_dev(m, d_mi);
     S.unpack_src = defer_unpack ? (const float4*) f->h_upload_dev : nullptr; S.unpack_n = defer_unpack ? f->h_count[0] : 0;
     if (sp.finder == LSM2D_FINDER_NN) { const int grc = ensure_grid(ctx, f, sp.max_distance, &S.fixed.grid); if (grc) return grc; }
@@ -1657,8 +1706,8 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   A.cull_block = ctx->cull_block;
   A.cull = ctx->cull;      // (the test's column loop wraps once: canvases below 64 columns are not worth it and would need a second wrap)
   for (int s = 0; s < ns; ++s) if (b->slices[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].proj.cols < 64) A.cull = 0;
-  size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total) + sizeof(float4) * (size_t) fcan_total +
-               sizeof(float) * kAccumWords * (kAlignBlock / 64);      // moving canvas, fixed canvases, fixed winners, reduction
+  size_t lds = sizeof(u64) * (size_t) (cols_max + fcan_total + ((cols_max + fcan_total) & 1)) +
+               sizeof(float) * kAccumWords * (kAlignBlock / 64);      // moving canvas, fixed canvases (padded to 16 bytes), reduction
   // one NN slice whose fixed clouds are scan-sized (one lane per query): stage each cloud's search tables in LDS.  Budget 38 KB
   // per workgroup keeps four workgroups on a CU; bigger clouds / grids search in global memory as before.  (Measured on configs[1]
   // role A: 3 sqrt(n) cells per side in 38 KB 9.6 ms; 4 sqrt(n) in 50 KB -- three workgroups per CU -- 12.2; 2 sqrt(n) 12.3.)
@@ -1712,8 +1761,17 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   if (pq_bytes) { lds = (lds + 15) & ~(size_t) 15; A.pq_cull_off = (int32_t) lds; lds += pq_bytes; }
   ctx->last_query_cull = A.pq_cull_off > 0;
   // the projective instantiation with the culled stream only: every slice's moving set has its lane-chunked copy and chunk circles, and culling is on
-  bool proj_culled_for_all = has_proj && !has_nn && !has_dist && !has_kd && A.cull == 1 && ctx->proj_modes;
-  for (int s = 0; s < ns && proj_culled_for_all; ++s) proj_culled_for_all = A.s[s].moving.lane_xy != nullptr && A.s[s].moving.lane_bounds != nullptr;
+  // (its unit lists -- kCullBlocks x 512 16-bit entries per slice, kept across iterations -- sit behind everything else in dynamic LDS; "cull_block" is the
+  // round-3 stream's tuning knob: a batch that sets it runs the shared instantiation)
+  bool proj_culled_for_all = has_proj && !has_nn && !has_dist && !has_kd && A.cull == 1 && ctx->proj_modes && ctx->cull_block == 0;
+  for (int s = 0; s < ns && proj_culled_for_all; ++s)
+    proj_culled_for_all = A.s[s].moving.lane_xy != nullptr && A.s[s].moving.lane_bounds != nullptr && A.s[s].moving.block_bounds != nullptr;
+  A.units_off = 0; A.cull_keep = ctx->cull_keep; A.cull_mt = 1e-6f * (float) ctx->cull_margin_um; A.cull_mth = 1e-6f * (float) ctx->cull_margin_urad;
+  if (proj_culled_for_all) {
+    const size_t at = (lds + 15) & ~(size_t) 15, need = sizeof(uint16_t) * (size_t) ns * kCullBlocks * kAlignBlock;
+    if ((int) (at + need) + 2048 <= ctx->max_dyn_lds && at + need + 2048 <= 40 * 1024) { A.units_off = (int32_t) at; lds = at + need; }      // four workgroups per CU must still fit (160 KB)
+    else proj_culled_for_all = false;
+  }
   // the NN instantiation without the search in global memory: the staging holds every alignment's tables (sized for the largest fixed cloud above), and no
   // alignment takes the cooperative loop, which searches in global memory (the kernel's rule: fixed cloud >= 4 x moving cloud) -- whatever the pairing
   bool nn_lds_for_all = false;

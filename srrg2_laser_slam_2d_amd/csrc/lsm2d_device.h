@@ -282,20 +282,32 @@ LSM2D_DEV void project_cloud_lanes_t(const float4* __restrict__ lane_xy, int T_s
 // bearing range can reach (empty fixed cells count as "no depth at all"), or the range gate, with margins far above fp32 rounding.
 // On configs[1] (a 270-degree scan in a room with pillars) 57 % of the chunks of a 100k-point map fall to it: blind sector 22 %, beyond
 // range_max 16 %, behind what the scan saw 19 %.
-LSM2D_DEV bool chunk_may_matter(const Iso& T, const ProjK& P, float4 bd /* cx, cy, rho (< 0: no points) */, const u64* fcan, float point_distance) {
+// Round 4: the test serves a NEIGHBOURHOOD of poses.  Seen from the sensor, a change of the estimate from T0 to T is a rotation about the sensor's
+// origin by dth followed by a translation d (q = R(dth) q0 + d, d = t - R(dth) t0).  With margins m_t >= |d| and m_th >= |dth| every point of the
+// circle is, under T, at least D - m_t - rho deep and within m_th + asin(m_t / (D - m_t)) + asin(rho / (D - m_t)) of the centre's bearing under T0:
+// a circle dropped with these margins cannot matter under any such T, so a survivor list built at T0 stays valid while the estimate stays within
+// (m_t, m_th) of T0 -- k_align rebuilds it a few times per alignment instead of testing every chunk every iteration.  m_t = m_th = 0 is the
+// round-3 test.  Keeping a circle that could have gone is always harmless (its points are the ones whose presence changes no pair).
+LSM2D_DEV bool chunk_may_matter(const Iso& T, const ProjK& P, float4 bd /* cx, cy, rho (< 0: no points) */, const u64* fcan, float point_distance,
+                                float m_t = 0.0f, float m_th = 0.0f) {
   if (bd.z < 0.0f) return false;
   float qx, qy;
   xf_point(T, bd.x, bd.y, qx, qy);
   const float r2 = __builtin_fmaf(qx, qx, qy * qy);
   if (!(r2 >= 1e-30f && r2 <= 1e37f)) return true;                  // degenerate: no claim
   float y0;
-  const float D = sqrt_rn_seed(r2, y0), rho = bd.z;
-  const float near = D - rho - (1e-3f + 1e-5f * D);                 // every point of the chunk is at least this deep (triangle inequality, minus slack)
+  const float Dc = sqrt_rn_seed(r2, y0), rho = bd.z;
+  const float D = Dc - m_t;                                          // the centre is at least this deep under every pose the answer serves
+  const float near = D - rho - (1e-3f + 1e-5f * Dc);                // every point of the chunk is at least this deep (triangle inequality, minus slack)
   if (near > P.rmax) return false;                                   // the range gate takes them all
-  if (!(D > 2.0f * rho + 0.05f)) return true;                       // the sensor is next to (or inside) the chunk: its bearings spread over more than 30 degrees
-  const float th = bearing<true>(qy, qx, D, y0);
+  if (!(D > 2.0f * (rho + m_t) + 0.05f)) return true;               // the sensor is next to (or inside) the chunk: its bearings spread over more than 30 degrees
+  const float th = bearing<true>(qy, qx, Dc, y0);
   const float u = __builtin_fmaf(P.K00, th, P.K01);
-  const float dc = P.K00 * (rho / D) * 1.06f + 1.5f;                // asin(x) <= 1.048 x on [0, 1/2]; 1.5 columns for the floors and the arithmetic
+  // asin(x) <= 1.048 x on [0, 1/2].  The columns the circle's points can fall into are floor(u - w) .. floor(u + w) for the true half-width w: the two
+  // floors below cover them, and what the arithmetic adds -- the bearing polynomial's 5e-8 rad, the roundings of u and of a point's own column -- is below
+  // 1e-3 columns at 16 384 of them: 0.05 columns of slack.  (Round 3 allowed 1.5 columns each side: at BLOCK level -- a block is about one column wide at
+  // 10 m -- that tripled every window; measured on configs[1]: 41 % of the point visits left with 1.5, 3x % with 0.05, the floor for 28-point blocks being 32 %.)
+  const float dc = P.K00 * (((rho + m_t) / D) * 1.06f + m_th) + 0.05f;
   if (!(dc <= 24.0f)) return true;
   const int c_lo = (int) __builtin_floorf(u - dc), c_hi = (int) __builtin_floorf(u + dc);
   float deepest = -__builtin_huge_valf();                            // deepest fixed cell among the columns in reach; empty cells (a NaN pattern) do not count
@@ -356,6 +368,58 @@ LSM2D_DEV void project_cloud_units_t(const float4* __restrict__ lane_xy, int T_s
     while (i >= s && blk < nb) { i -= s; ++blk; }
   }
 }
+// Round 4: the same stream over an explicit LIST of surviving units in LDS (k_align, kProjCulled): entry = (block << 9) | chunk, block-major -- the
+// lanes of a wave hold consecutive entries, i.e. neighbouring surviving chunks at the same block offset (the spacing that keeps a wave's ds_min_u64s
+// off each other's cells, as above) -- and every entry is a unit that survived the BLOCK-level test (a block = B steps = 2 B consecutive map points,
+// ~6 cm of wall on configs[1] and [4] alike), so a chunk that straddles the edge of what the scan saw is streamed in part only.  Thread u takes the
+// entries u, u + nthreads, ...: whole waves run out of work together.
+template <bool kGuarded>
+LSM2D_DEV void project_cloud_list_t(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin, u64* canvas, int tid, int nthreads,
+                                    const uint16_t* units, int n_units, int B) {
+  const Iso T = Tin; ProjK P = Pin;
+  asm volatile("" : "+v"(P.K01));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long pb = reinterpret_cast<unsigned long long>(lane_xy);
+  const unsigned pb_hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (pb >> 32));
+  const unsigned pb_lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) pb);
+  float4* ubase = reinterpret_cast<float4*>(((unsigned long long) pb_hi << 32) | (unsigned long long) pb_lo);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, (short) 0, 0x7fffffff, 0x00020000);
+  const int row_bytes = nthreads * (int) sizeof(float4);
+  for (int k = tid; k < n_units; k += nthreads) {
+    const int code = (int) units[k];
+    const int g = code & 511, t0 = (code >> 9) * B;
+    const int nsteps = T_steps - t0 < B ? T_steps - t0 : B;
+    const int voff = g * (int) sizeof(float4) + t0 * row_bytes;      // this lane's chunk and block; the step advances in the scalar offset
+    int idx = 2 * (g * T_steps + t0);
+    auto load = [&](int soff) {
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+      return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    };
+    auto pair = [&](const float4& v, int i) {
+      project_point_stream<kGuarded>(T, P, v.x, v.y, i, canvas);
+      project_point_stream<kGuarded>(T, P, v.z, v.w, i + 1, canvas);
+    };
+    // (two steps per trip, the two load buffers swapping roles; the scalar offset advances unconditionally and the last trip's look-ahead load reads
+    // one row past the block -- never used: project_cloud_units_t)
+    int t = 0, soff = 0;
+    float4 va = load(0);
+    for (; t + 2 <= nsteps; t += 2) {
+      const float4 vb = load(soff + row_bytes);
+      pair(va, idx);
+      soff += 2 * row_bytes;
+      va = load(soff);
+      pair(vb, idx + 2);
+      idx += 4;
+    }
+    if (t < nsteps) pair(va, idx);
+  }
+}
+LSM2D_DEV void project_cloud_list(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P, u64* canvas, int tid, int nthreads,
+                                  const uint16_t* units, int n_units, int B) {
+  if (P.tiny_ok) project_cloud_list_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
+  else project_cloud_list_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
+}
+
 // The same survivors, balanced to within one step: the s surviving chunks x T steps form a matrix (row = step t, column = survivor i);
 // thread u takes the elements u, u + nthreads, ... of its row-major order.  The lanes of a wave then hold consecutive survivors at the SAME
 // step -- their 16-byte loads fall into one row of the copy, and they stay a chunk apart along the map -- and every thread gets

@@ -19,6 +19,9 @@
 namespace lsm2d {
 
 static constexpr int kMaxSlices = 4;
+// exact culling of a projective slice's moving cloud (k_align): a thread's chunk of T steps is cut into at most kCullBlocks blocks of B steps
+static constexpr int kCullBlocks = 7;
+LSM2D_HD int cull_block_steps(int T) { return 2 * ((T + 13) / 14); }      // even; ceil(T / B) <= 7 for every T >= 1
 // Wave priority by progress.  The SIMD arbitrates by priority, then AGE: with equal priorities the oldest two waves of a SIMD run
 // at full single-wave speed and the younger workgroups of a CU wait (tools/occupancy_probe.py: lifetimes 0.97 .. 2.19 ms in one
 // launch), so the last workgroup of a CU ends up alone, with nobody to issue under its barriers, bin walks and solves.  A
@@ -44,6 +47,10 @@ struct GridDev {
   const float2*   sorted_xy;   // [padded total] coordinates in the same order
   const float2*   sorted_nrm;  // [padded total] normals in the same order: the fused aligner takes a match's normal from where the search found the point
 };
+// (Round 4, measured and dropped: the cell table COMPRESSED to its occupied cells -- a map's points lie on walls, 2 % of the 3.6 M cells of a 100k-point
+// map's grid hold one; per block of 64 cells a 16-byte record {occupancy mask, start, index} + one word per occupied cell, 1.3 MB instead of 14 MB, L2-resident --
+// took configs[1] role B from 1.72 to 2.12 ms: the record and the word behind it are two dependent requests to L2 where the dense table needs one line, and
+// this search is bound by the L2's request rate, not by the misses of the dense table: DESIGN App. A.)
 
 // Distance map over every cloud of a set (CorrespondenceFinderNN2D, registration/correspondence_finder_nn_2d.cpp):
 // parent[r*cols + c] = the nearest fixed point's pixel within max_distance as (squared pixel distance << gbits | lowest point index in
@@ -135,6 +142,8 @@ struct CloudDev {            // device view of a cloud set
   const long long* lane_start; // [n_clouds] first float4 slot of each cloud in lane_xy
   const int32_t* lane_T;     // [n_clouds] steps per thread
   const float4* lane_bounds; // [n_clouds][kAlignBlock] bounding circle (cx, cy, rho; rho < 0: no points) of the chunk each thread owns, or nullptr
+  const float4* block_bounds; // [n_clouds][kCullBlocks][kAlignBlock] the same per BLOCK of a chunk (block b of chunk g = its steps [b B, (b + 1) B), B = cull_block_steps(T)), or nullptr
+  const float4* aos;         // [padded total] (x, y, nx, ny) rows next to xy / nrm -- one 16-byte gather per z-buffer winner in k_align's bin walk -- or nullptr
   const float4* tile_bounds; // bounding circle of every TILE of 64 consecutive points of every cloud (k_tile_bounds), or nullptr: what the point-query
   const int32_t* tile_start; //   finders' culling tests; [n_clouds] first tile of each cloud
   GridDev grid;              // valid only when the slice uses the NN finder on this (fixed) cloud
@@ -757,6 +766,11 @@ struct AlignArgs {
   const int32_t* order;                     // alignment handled by workgroup b (nullptr: b itself) -- the balanced placement of k_balance_order
   int32_t cull_block;                       // steps per unit of the culled stream (0: automatic; tuning knob)
   int32_t cull;                             // 1: projective slices drop the chunks of the moving cloud that cannot yield a pair (chunk_may_matter), results unchanged
+  // kProjCulled (round 4): every slice keeps a LIST of the (block, chunk) units that survive the test at block level, in dynamic LDS at units_off
+  // (kCullBlocks * kAlignBlock 16-bit entries per slice), built with margins (cull_mt metres, cull_mth radians) and kept while the slice's transform
+  // stays within them of the one it was built at (cull_keep 0: rebuilt every iteration, zero margins -- A/B knob)
+  int32_t units_off, cull_keep;
+  float   cull_mt, cull_mth;
   int32_t pq_cull_off;                      // > 0: byte offset in dynamic LDS of the point-query finders' culling state (occupancy bitmap of the fixed cloud, then
   int32_t pq_keep_words;                    //   pq_keep_words 64-bit words of per-tile keep bits); single-slice NN / KD-tree batches with scan-sized fixed clouds
   int32_t pair_mov_cap;                     // latency kernel: moving points per slice it may keep in LDS (kPairMovCap, or 0: no room)
@@ -860,6 +874,8 @@ LSM2D_DEV void add_prior_inline(const PriorDev& Pz, const float pose[3], float H
 // k_align (64 VGPRs) and the split path call it: rarely taken, and out of the register allocation of their loops
 __device__ __noinline__ void add_prior(const PriorDev& Pz, const float pose[3], float H[9], float b[3]) { add_prior_inline(Pz, pose, H, b); }
 
+LSM2D_DEV int block_compact_pos(bool flag, int* s_tot, int parity, int& base, int tid, int nwaves);      // (defined with the mapping kernels below)
+
 // kHasProj / kHasNN: which finders the batch's slices use -- the unused one is compiled out so the
 // projective hot loop does not carry the NN path's register pressure (and vice versa).
 // kHasDist: a slice uses the distance-map finder (compiled out otherwise so the NN search keeps its registers).
@@ -881,11 +897,11 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   static_assert(kNNMode == 0 || ((kNNMode <= 2) && kHasNN && !kHasProj && !kHasDist && !kHasKd) || ((kNNMode == 3 || kNNMode == 4) && kHasKd && !kHasProj && !kHasDist && !kHasNN) ||
                 (kNNMode == 5 && kHasProj && !kHasNN && !kHasDist && !kHasKd), "kNNMode: one finder only");
   extern __shared__ __align__(16) unsigned char smem[];
-  // the 16-byte rows first: behind the canvases they would sit on an odd 8-byte boundary whenever cols_max + fcan_total is odd
-  float4* fwin = reinterpret_cast<float4*>(smem);                 // (x, y, nx, ny) of every fixed-canvas winner: the bin walk never gathers the fixed side
-  u64* mcan = reinterpret_cast<u64*>(fwin + A.fcan_total);
+  // (round 4: the fixed winners' payload no longer sits in LDS -- 16 bytes per column, 17 KB at 1081 -- the bin walk gathers it like the moving winner's,
+  // one 16-byte row of the cloud's AoS copy each, both in flight together; the room holds the culled stream's unit lists)
+  u64* mcan = reinterpret_cast<u64*>(smem);
   u64* fcan = mcan + A.cols_max;
-  float* red = reinterpret_cast<float*>(fcan + A.fcan_total);     // [nwaves][kAccumWords]
+  float* red = reinterpret_cast<float*>(fcan + A.fcan_total + ((A.cols_max + A.fcan_total) & 1));     // [nwaves][kAccumWords], 16-byte aligned
   // NN finder over a scan-sized fixed cloud (the tracker wiring: tree over the scan, every map point a query): the cloud's search
   // tables live in LDS for the whole alignment -- 20 iterations x N_m queries then touch global memory only for the query stream
   float2* l_sxy = reinterpret_cast<float2*>(red + (kAlignBlock / 64) * kAccumWords);
@@ -910,7 +926,10 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
   __shared__ u64 s_dig;             // this iteration's pair digest (lsm2d_iteration_stats.pair_digest): every matched pair adds its hash; only when statistics go out
   __shared__ int s_phase, s_phase_start, s_phase_end;      // 0: the regular loop, 1: the inlier-only runs (enable_inlier_only_runs); iterations [start, end) belong to the phase
   __shared__ uint16_t s_surv[kAlignBlock];      // culling: the chunks of the moving cloud that survived this iteration's test, compacted in thread order
-  __shared__ int s_wcnt[kAlignBlock / 64];
+  __shared__ int s_wcnt[2 * (kAlignBlock / 64)];
+  __shared__ int s_nunits[kMaxSlices], s_rebuild[kMaxSlices];      // kProjCulled: entries in a slice's unit list; the list must be rebuilt before it is streamed again
+  __shared__ Iso s_list_iso[kMaxSlices];                             // ... and the transform it was built at
+  uint16_t* l_units = reinterpret_cast<uint16_t*>(smem + A.units_off);      // [n_slices][kCullBlocks * kAlignBlock]
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   // (the alignment's index is wave-uniform: said so, or everything indexed by it would live in vector registers)
@@ -972,6 +991,14 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     s_sum[11] = s_sum[12] = __int_as_float(zi);
     s_n_corr = s_active = zi;
     s_dig = (u64) (unsigned) zi;
+    if (kProjCulled) for (int s = 0; s < A.n_slices; ++s) {
+      // has the slice's transform left the neighbourhood its unit list serves?  Seen from the sensor the change is a rotation by dth about the origin
+      // and a translation d = t - R(dth) t0 (chunk_may_matter): the list holds while |d| <= cull_mt and |dth| <= cull_mth
+      const Iso N = s_iso[s], L = s_list_iso[s];
+      const float cd = N.c * L.c + N.s * L.s, sd = N.s * L.c - N.c * L.s;
+      const float dx = N.tx - (cd * L.tx - sd * L.ty), dy = N.ty - (sd * L.tx + cd * L.ty);
+      s_rebuild[s] = (A.cull_keep && cd > 0.5f && __builtin_fabsf(sd) <= A.cull_mth && dx * dx + dy * dy <= A.cull_mt * A.cull_mt) ? zi : 1;
+    }
     if (A.out_last_pose) { A.out_last_pose[3 * a + 0] = s_pose[0]; A.out_last_pose[3 * a + 1] = s_pose[1]; A.out_last_pose[3 * a + 2] = s_pose[2]; }
   };
   if (tid == 0) {
@@ -979,8 +1006,10 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
     else { s_pose[0] = A.init_pose[3 * a + 0]; s_pose[1] = A.init_pose[3 * a + 1]; s_pose[2] = A.init_pose[3 * a + 2]; }
     s_done = 0; s_status = LSM2D_RUNNING; s_last_n_in = 0;
     s_phase = 0; s_phase_start = 0; s_phase_end = A.max_it;
+    for (int s = 0; s < kMaxSlices; ++s) { s_list_iso[s].c = 1.0f; s_list_iso[s].s = 0.0f; s_list_iso[s].tx = 0.0f; s_list_iso[s].ty = 0.0f; }
     for (int k = 0; k < 9; ++k) s_H[k] = 0.0f;
     begin_iteration();
+    for (int s = 0; s < kMaxSlices; ++s) s_rebuild[s] = 1;      // no list yet
   }
   __syncthreads();
   if (kNNGlobal) for (int i = tid; i < A.nn_qcache; i += kAlignBlock) l_qc[8 * i] = 0x7fffffff;      // no cell cached yet (visible after the barriers below)
@@ -1078,19 +1107,6 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       if ((unsigned) cx < 128u && (unsigned) cy < 128u) atomicOr(&l_occ[cy * kPqRowWords + (cx >> 5)], 1u << (cx & 31));
     }
   }
-  for (int s = 0; s < A.n_slices; ++s) {      // cache the fixed winners' payload next to their keys
-    const SliceDev& S = A.s[s];
-    if (!kHasProj || S.finder != LSM2D_FINDER_PROJECTIVE) continue;
-    const int fbase = S.fixed.start[pick_cloud(S.fixed, a)];
-    for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
-      const u64 k = fcan[S.fcan_offset + col];
-      if (k != kEmptyCell) {
-        const int fi = (int) (uint32_t) k;
-        const float2 p = S.fixed.xy[fbase + fi], n = S.fixed.nrm[fbase + fi];
-        fwin[S.fcan_offset + col] = make_float4(p.x, p.y, n.x, n.y);
-      }
-    }
-  }
   __syncthreads();
 
   int it = 0;
@@ -1114,7 +1130,60 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
           // HOT: every moving point, every iteration (correspondence_finder_projective_2d.cpp:47-48)
           const int mc = pick_cloud(S.moving, a);
           // clouds of at most one pair per thread (the tracker's clipped scenes) need no lane-chunked copy
-          if (kProjCulled || (S.moving.lane_xy && S.moving.lane_bounds && A.cull)) {
+          if (kProjCulled) {
+            // Round 4: the survivors of the BLOCK-level test as a list in LDS, kept across iterations (see AlignArgs::units_off).  Build, when thread 0 found the
+            // slice's transform outside the list's neighbourhood: (A) every thread tests the chunk it owns -- as the per-iteration test of round 3 did, with the
+            // margins -- and the surviving chunks are compacted; (B) the nb blocks of every surviving chunk are tested the same way, dealt to the threads in
+            // block-major order and compacted in that order: the list.  2 + ceil(nb s / 512) + 1 barriers, a few times per alignment.
+            const int lane = tid & 63, wave = tid >> 6;
+            uint16_t* units = l_units + s * (kCullBlocks * kAlignBlock);
+            const int Tm = S.moving.lane_T[mc];
+            const int B = cull_block_steps(Tm), nb = (Tm + B - 1) / B;
+            if (__builtin_amdgcn_readfirstlane(s_rebuild[s])) {
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              const float m_t = A.cull_keep ? A.cull_mt : 0.0f, m_th = A.cull_keep ? A.cull_mth : 0.0f;
+              const unsigned long long bb = reinterpret_cast<unsigned long long>(S.moving.lane_bounds + (size_t) mc * kAlignBlock);
+              float4* bbase = reinterpret_cast<float4*>(((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (bb >> 32)) << 32) |
+                                                        (unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) bb));
+              const u32x4 bw = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(bbase, (short) 0, kAlignBlock * 16, 0x00020000), tid * 16, 0, 0);
+              const bool keep = chunk_may_matter(T, S.proj, make_float4(__uint_as_float(bw.x), __uint_as_float(bw.y), __uint_as_float(bw.z), 0.0f), fcan + S.fcan_offset, S.point_distance, m_t, m_th);
+              const u64 bal = __ballot(keep);
+              if (lane == 0) s_wcnt[wave] = __popcll(bal);
+              __syncthreads();
+              int before = 0, n_surv = 0;
+#pragma unroll
+              for (int w = 0; w < nwaves; ++w) { const int cw = s_wcnt[w]; before += w < wave ? cw : 0; n_surv += cw; }
+              n_surv = __builtin_amdgcn_readfirstlane(n_surv);
+              if (keep) s_surv[before + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) bal, 0u))] = (uint16_t) tid;
+              __syncthreads();
+              // (B) test v = (block v / n_surv, survivor v mod n_surv), v = tid, tid + 512, ...; block_compact_pos: one barrier per round, buffers alternating
+              const unsigned long long kb = reinterpret_cast<unsigned long long>(S.moving.block_bounds + (size_t) mc * (kCullBlocks * kAlignBlock));
+              float4* kbase = reinterpret_cast<float4*>(((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (kb >> 32)) << 32) |
+                                                        (unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) kb));
+              const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(kbase, (short) 0, kCullBlocks * kAlignBlock * 16, 0x00020000);
+              int n_units = 0, parity = 1, i = tid, blk = 0;
+              while (n_surv > 0 && i >= n_surv && blk < nb) { i -= n_surv; ++blk; }
+              const int n_tests = nb * n_surv;
+              for (int v0 = 0; v0 < n_tests; v0 += kAlignBlock, parity ^= 1) {
+                bool k2 = false; int code = 0;
+                if (blk < nb) {
+                  const int g = (int) s_surv[i];
+                  code = (blk << 9) | g;
+                  const u32x4 w4 = __builtin_amdgcn_raw_buffer_load_b128(krs, code * 16, 0, 0);      // entry (blk * 512 + g) of the cloud's block circles
+                  k2 = chunk_may_matter(T, S.proj, make_float4(__uint_as_float(w4.x), __uint_as_float(w4.y), __uint_as_float(w4.z), 0.0f), fcan + S.fcan_offset, S.point_distance, m_t, m_th);
+                }
+                const int pos = block_compact_pos(k2, s_wcnt, parity, n_units, tid, nwaves);
+                if (k2) units[pos] = (uint16_t) code;
+                i += kAlignBlock;
+                while (n_surv > 0 && i >= n_surv && blk < nb) { i -= n_surv; ++blk; }
+              }
+              if (tid == 0) { s_nunits[s] = n_units; s_list_iso[s] = T; }
+              __syncthreads();
+            }
+            const int n_units = __builtin_amdgcn_readfirstlane(s_nunits[s]);
+            if (n_units > 0) project_cloud_list(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, units, n_units, B);
+          }
+          else if (S.moving.lane_xy && S.moving.lane_bounds && A.cull) {
             // exact culling against the fixed canvas (chunk_may_matter): every thread tests the chunk it would stream, the survivors are
             // compacted (two barriers: counts, then the list) and their points spread evenly over the workgroup (project_cloud_units)
             const int lane = tid & 63, wave = tid >> 6;
@@ -1145,28 +1214,31 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
               else project_cloud_units(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv, B, nb);
             }
           }
-          else if (kProjCulled) { }
           else if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
           else project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
         }
         __syncthreads();
         // bin walk (correspondence_finder_projective_2d.cpp:55-74): the fixed side comes from LDS, the two gathers of the
         // moving winner are issued together, and every cell read is reset for the next projection
-        const int mbase = S.moving.start[pick_cloud(S.moving, a)];
+        const int mbase = S.moving.start[pick_cloud(S.moving, a)], fbase = S.fixed.start[pick_cloud(S.fixed, a)];
         const float2* mn = S.moving.nrm + mbase; const float2* mp = S.moving.xy + mbase;
-        const u64* fcs = fcan + S.fcan_offset; const float4* fws = fwin + S.fcan_offset;
+        const float2* fnr = S.fixed.nrm + fbase; const float2* fpp = S.fixed.xy + fbase;
+        const float4* maos = S.moving.aos ? S.moving.aos + mbase : nullptr;      // (a set without its AoS copy -- sizes still pending on the device, or
+        const float4* faos = S.fixed.aos ? S.fixed.aos + fbase : nullptr;        //  unpacked by this launch -- is gathered from its split arrays)
+        const u64* fcs = fcan + S.fcan_offset;
         for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
           const u64 fk = fcs[col], mk = mcan[col];
           mcan[col] = kEmptyCell;
           if (mk == kEmptyCell || fk == kEmptyCell) continue;
           const float fd = __uint_as_float((uint32_t) (fk >> 32)), md = __uint_as_float((uint32_t) (mk >> 32));
           if (__builtin_fabsf(fd - md) > S.point_distance) continue;
-          const int mi = (int) (uint32_t) mk;
-          const float2 nm = mn[mi], pm = mp[mi];
-          const float4 f = fws[col];
+          const int mi = (int) (uint32_t) mk, fi = (int) (uint32_t) fk;
+          float2 nm, pm; float4 f;
+          if (maos) { const float4 m4 = maos[mi]; pm = make_float2(m4.x, m4.y); nm = make_float2(m4.z, m4.w); } else { nm = mn[mi]; pm = mp[mi]; }
+          if (faos) f = faos[fi]; else { const float2 p2 = fpp[fi], n2 = fnr[fi]; f = make_float4(p2.x, p2.y, n2.x, n2.y); }
           float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
           if (__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos) continue;
-          if (want_dig) digest_add(&s_dig, salt, (int) (uint32_t) fk, mi);
+          if (want_dig) digest_add(&s_dig, salt, fi, mi);
           accumulate_pair(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
         }
       } else if (kHasNN || kHasDist || kHasKd) {
@@ -1337,6 +1409,9 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
       // (thread 0's serial state lives in LDS, not in registers every thread would carry -- and spill -- across the loops)
       StatsDev last; last.n_corr = s_n_corr; last.n_in = __float_as_int(s_sum[11]); last.n_out = __float_as_int(s_sum[12]); last.chi_in = s_sum[9]; last.chi_out = s_sum[10];
       s_last_n_in = last.n_in;
+#ifdef LSM2D_DEBUG_UNITS      // diagnostics build: the culled stream's list length and whether it was rebuilt, in place of the outlier statistics
+      if (kProjCulled) { last.n_out = s_nunits[0]; last.chi_out = (float) s_rebuild[0]; }
+#endif
       if (A.out_stats) { const u64 dg = s_dig; last.dig_lo = (uint32_t) dg; last.dig_hi = (uint32_t) (dg >> 32); A.out_stats[(size_t) a * A.stats_stride + it] = last; }
       if (!s_active) { s_status = LSM2D_NOT_ENOUGH_CORRESPONDENCES; s_done = 1; }
       else {
@@ -2771,6 +2846,44 @@ __global__ __launch_bounds__(256) void k_lane_bounds(const float2* __restrict__ 
     r = make_float4(cx, cy, (cx == cx && cy == cy) ? rho : __builtin_huge_valf(), 0.0f);
   }
   if (lane == 0) out[(size_t) c * nthreads + g] = r;
+}
+
+// the same per BLOCK of a chunk (block b of chunk g = the points [2 (g T + b B), 2 (g T + min((b + 1) B, T))) of the cloud, B = cull_block_steps(T)): entry
+// (c * kCullBlocks + b) * nthreads + g; blocks beyond the chunk's last (or beyond the cloud's end) get rho < 0 = "no points".  One wave per block.
+__global__ __launch_bounds__(256) void k_block_bounds(const float2* __restrict__ xy, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
+                                                      const int32_t* __restrict__ lane_T, int nthreads, float4* __restrict__ out, int cloud0) {
+  const int c = cloud0 + blockIdx.y, w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= nthreads * kCullBlocks) return;
+  const int b = w / nthreads, g = w - b * nthreads;
+  const int n = count[c], T = lane_T[c], B = cull_block_steps(T);
+  const int t0 = b * B, t1 = t0 + B < T ? t0 + B : T;
+  long long lo = 2ll * ((long long) g * T + t0), hi = 2ll * ((long long) g * T + t1);
+  if (hi > n) hi = n;
+  const float2* p = xy + start[c];
+  float4 r = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
+  if (t0 < T && hi > lo) {
+    float mnx = 3.402823466e+38f, mny = mnx, mxx = -mnx, mxy = -mnx;
+    for (long long i = lo + lane; i < hi; i += 64) { const float2 v = p[i]; mnx = fminf(mnx, v.x); mxx = fmaxf(mxx, v.x); mny = fminf(mny, v.y); mxy = fmaxf(mxy, v.y); }
+    for (int o = 32; o > 0; o >>= 1) {
+      mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+      mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+    }
+    const float cx = 0.5f * (mnx + mxx), cy = 0.5f * (mny + mxy);
+    float d2 = 0.0f;
+    for (long long i = lo + lane; i < hi; i += 64) { const float2 v = p[i]; const float dx = v.x - cx, dy = v.y - cy; d2 = fmaxf(d2, dx * dx + dy * dy); }
+    for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o, 64));
+    const float rho = (d2 == d2) ? __builtin_sqrtf(d2) * 1.00001f + 1e-6f : __builtin_huge_valf();      // (a non-finite point: never culled, as in k_lane_bounds)
+    r = make_float4(cx, cy, (cx == cx && cy == cy) ? rho : __builtin_huge_valf(), 0.0f);
+  }
+  if (lane == 0) out[((size_t) c * kCullBlocks + b) * nthreads + g] = r;
+}
+
+// (x, y, nx, ny) rows of a whole set next to its split arrays (CloudDev::aos)
+__global__ void k_aos_rows(const float2* __restrict__ xy, const float2* __restrict__ nrm, long long n, float4* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+    const float2 p = xy[i], q = nrm[i];
+    out[i] = make_float4(p.x, p.y, q.x, q.y);
+  }
 }
 
 // bounding circle of every tile of 64 consecutive points (the point-query finders' culling, k_align): one wave per tile
