@@ -34,6 +34,7 @@ struct lsm2d_context {
   void* h_stage = nullptr; size_t h_stage_bytes = 0; void* h_stage_dev = nullptr;
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_split = nullptr; size_t d_split_bytes = 0;      // workspace of the split aligner path
+  void* d_kd_work = nullptr; size_t d_kd_work_bytes = 0;  // working set of the KD-tree build (ping-pong copies, queues, counters): kept, grown on demand
   void* h_flag = nullptr;                                 // 256 pinned bytes of its own for small read-backs inside a call (the KD-tree build's level counts)
   struct BeamDirs { int n_beams; float angle_min, angle_max; float2* d_dir; };
   std::vector<BeamDirs> beam_dirs;                        // (cos, sin) per beam of the sensors seen so far (lsm2d_preprocess_scan_into)
@@ -58,6 +59,7 @@ struct lsm2d_context {
   int cull_keep = 1;           // ... the culled stream's unit lists are kept across iterations while the estimate stays within the margins they were built with (0: rebuilt every iteration; A/B knob)
   int cull_margin_um = 10000;  // the translation margin in micrometres (10 mm) and
   int cull_margin_urad = 2000; // the rotation margin in microradians (2 mrad): tuning knobs, results do not depend on them
+  int kd_wg_max_points = 16384; // KD-tree build: clouds of at most this many points are built by ONE launch, a workgroup per cloud walking the levels itself (k_kd_build_wg); 0: the level loop for all (A/B knob; same trees)
   int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
   int kd_lds_nodes = 1536;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it; 512 / 1024 / 1536: 0.830 / 0.804 / 0.778 ms on configs[1] role B)
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
@@ -113,6 +115,9 @@ struct KdCache {       // one KD-tree per cloud of the set, per (max_leaf_range,
   void* d_block = nullptr;      // one allocation; the pointers below are views into it
   KdMeta* d_meta = nullptr; KdNode* d_nodes = nullptr; float2* d_leaf_xy = nullptr; int32_t* d_leaf_idx = nullptr; float2* d_leaf_nrm = nullptr;
   int levels = 0; long long total_nodes = 0; int max_nodes_per_cloud = 0;
+  // a reserved single-cloud set (the live tracker's scan, refilled every step) keeps the allocation when its contents change: the next reset() rebuilds
+  // into it -- a hipMalloc costs ~0.1 ms, more than the build of a scan's tree itself
+  bool valid = true; size_t block_bytes = 0;
 };
 
 struct lsm2d_cloudset {
@@ -244,6 +249,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->h_flag) (void) hipHostFree(c->h_flag);
   if (c->d_scratch) (void) hipFree(c->d_scratch);
   if (c->d_split) (void) hipFree(c->d_split);
+  if (c->d_kd_work) (void) hipFree(c->d_kd_work);
   for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
   if (c->ev1) (void) hipEventDestroy(c->ev1);
@@ -278,6 +284,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "proj_modes")) { ctx->proj_modes = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_wg_max_points")) { if (value < 0 || value > (1 << 20)) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_wg_max_points: 0 .. 2^20"); ctx->kd_wg_max_points = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
@@ -298,6 +305,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "cull_margin_um")) { *out_value = ctx->cull_margin_um; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_margin_urad")) { *out_value = ctx->cull_margin_urad; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_wg_max_points")) { *out_value = ctx->kd_wg_max_points; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_query_cull")) { *out_value = ctx->last_query_cull; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kd_levels")) { *out_value = ctx->last_kd_levels; return LSM2D_SUCCESS; }
@@ -543,8 +551,8 @@ static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents 
   if (cs->d_tile_start) { (void) hipFree(cs->d_tile_start); cs->d_tile_start = nullptr; }
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   cs->dists.clear();
-  for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block);
-  cs->kds.clear();
+  if (cs->capacity > 0 && cs->n_clouds == 1 && cs->kds.size() == 1) cs->kds[0].valid = false;      // a reserved set: the allocation is recycled by the next build (KdCache::valid)
+  else { for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block); cs->kds.clear(); }
 }
 
 extern "C" int lsm2d_cloudset_create_reserved(lsm2d_context* ctx, int64_t capacity, lsm2d_cloudset** out) {
@@ -754,7 +762,7 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   if (!(max_leaf_range > 0.0f)) max_leaf_range = 1e-2f;         // the class defaults (correspondence_finder_kd_tree_2d.h:26-33), as the oracle applies them
   if (min_leaf_points <= 0) min_leaf_points = 20;
   for (const auto& k : cs->kds)
-    if (k.max_leaf_range == max_leaf_range && k.min_leaf_points == min_leaf_points) {
+    if (k.valid && k.max_leaf_range == max_leaf_range && k.min_leaf_points == min_leaf_points) {
       *out = KdDev{k.d_meta, k.d_nodes, k.d_leaf_xy, k.d_leaf_idx, k.d_leaf_nrm}; if (out_cache) *out_cache = &k; return LSM2D_SUCCESS;
     }
   const int nc = cs->n_clouds;
@@ -763,18 +771,25 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   long long nodes = 0;
   for (int c = 0; c < nc; ++c) {
     meta[(size_t) c].node_base = (int32_t) nodes; meta[(size_t) c].n_nodes = 0; meta[(size_t) c].pad0 = meta[(size_t) c].pad1 = 0;
-    nodes += 2ll * cs->h_count[c] > 2 ? 2ll * cs->h_count[c] : 2;
+    const long long room = cs->capacity > 0 ? cs->capacity : cs->h_count[c];      // (a reserved set: for whatever it may hold later -- its allocation is recycled)
+    nodes += 2ll * room > 2 ? 2ll * room : 2;
     if (nodes > 0x7ffffff0ll) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "kdtree: too many nodes");
   }
   const size_t np = (size_t) cs->padded_total, nq = np / 2 + (size_t) nc + 2;
   constexpr int kMaxLevels = 8192;
   KdCache kc; kc.max_leaf_range = max_leaf_range; kc.min_leaf_points = min_leaf_points;
-  DevTmp t_block, t_work;
+  DevTmp t_block;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
   const size_t o_meta = take(sizeof(KdMeta) * (size_t) nc), o_nodes = take(sizeof(KdNode) * (size_t) nodes);
   const size_t o_lxy = take(sizeof(float2) * np), o_lidx = take(sizeof(int32_t) * np), o_lnr = take(sizeof(float2) * np);
-  HIPCHK(ctx, hipMalloc(&t_block.p, off));
+  const bool recycle = cs->kds.size() == 1 && !cs->kds[0].valid && cs->kds[0].d_block && cs->kds[0].block_bytes >= off;
+  kc.block_bytes = off;
+  if (recycle) { t_block.p = cs->kds[0].d_block; kc.block_bytes = cs->kds[0].block_bytes; cs->kds.clear(); }      // (owned by the guard again until the build has succeeded)
+  else {
+    if (cs->kds.size() == 1 && !cs->kds[0].valid) { if (cs->kds[0].d_block) (void) hipFree(cs->kds[0].d_block); cs->kds.clear(); }
+    HIPCHK(ctx, hipMalloc(&t_block.p, off));
+  }
   char* blk = (char*) t_block.p;
   kc.d_meta = (KdMeta*) (blk + o_meta); kc.d_nodes = (KdNode*) (blk + o_nodes);
   kc.d_leaf_xy = (float2*) (blk + o_lxy); kc.d_leaf_idx = (int32_t*) (blk + o_lidx); kc.d_leaf_nrm = (float2*) (blk + o_lnr);
@@ -782,51 +797,77 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   off = 0;
   const size_t w_xy0 = take(sizeof(float2) * np), w_xy1 = take(sizeof(float2) * np), w_ix0 = take(sizeof(int32_t) * np), w_ix1 = take(sizeof(int32_t) * np);
   const size_t w_q0 = take(sizeof(int4) * nq), w_q1 = take(sizeof(int4) * nq), w_nn = take(sizeof(int32_t) * (size_t) nc), w_cnt = take(sizeof(int32_t) * (size_t) (kMaxLevels + 1));
-  HIPCHK(ctx, hipMalloc(&t_work.p, off));
-  char* wk = (char*) t_work.p;
+  if (off > ctx->d_kd_work_bytes) {
+    if (ctx->d_kd_work) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipFree(ctx->d_kd_work)); ctx->d_kd_work = nullptr; ctx->d_kd_work_bytes = 0; }
+    HIPCHK(ctx, hipMalloc(&ctx->d_kd_work, off + off / 2));
+    ctx->d_kd_work_bytes = off + off / 2;
+  }
+  char* wk = (char*) ctx->d_kd_work;
   float2* xyb[2] = {(float2*) (wk + w_xy0), (float2*) (wk + w_xy1)}; int32_t* ixb[2] = {(int32_t*) (wk + w_ix0), (int32_t*) (wk + w_ix1)};
   int4* qb[2] = {(int4*) (wk + w_q0), (int4*) (wk + w_q1)};
   int32_t* d_nn = (int32_t*) (wk + w_nn); int32_t* d_cnt = (int32_t*) (wk + w_cnt);
   HIPCHK(ctx, hipMemcpyAsync(kc.d_meta, meta.data(), sizeof(KdMeta) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t) (kMaxLevels + 1), ctx->stream));
-  hipLaunchKernelGGL(k_kd_init, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) cs->d_count, nc, qb[0], d_nn);
-  HIPCHK(ctx, hipGetLastError());
   KdBuildArgs B;
   B.start = cs->d_start; B.meta = kc.d_meta; B.nodes = kc.d_nodes; B.n_nodes = d_nn;
   B.leaf_xy = kc.d_leaf_xy; B.leaf_idx = kc.d_leaf_idx; B.max_leaf_range = max_leaf_range; B.min_leaf_points = min_leaf_points;
-  long long n_items = nc; int level = 0;
-  volatile int32_t* h_cnt = (volatile int32_t*) ctx->h_flag;
-  while (n_items > 0) {
-    if (level >= kMaxLevels) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "kdtree: deeper than 8192 levels");
-    B.xy_in = level == 0 ? cs->d_xy : xyb[level & 1]; B.idx_in = level == 0 ? nullptr : ixb[level & 1];
-    B.xy_out = xyb[(level + 1) & 1]; B.idx_out = ixb[(level + 1) & 1];
-    B.q_in = qb[level & 1]; B.q_out = qb[(level + 1) & 1]; B.q_out_count = d_cnt + level + 1; B.n_items = (int32_t) n_items;
-    const unsigned blocks = (unsigned) ((n_items + 3) / 4);
-    if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_level<1>, dim3(blocks), dim3(256), 0, ctx->stream, B);
-    else hipLaunchKernelGGL(k_kd_level<0>, dim3(blocks), dim3(256), 0, ctx->stream, B);
+  B.xy_in = nullptr; B.idx_in = nullptr; B.xy_out = nullptr; B.idx_out = nullptr; B.q_in = nullptr; B.q_out = nullptr; B.q_out_count = nullptr; B.n_items = 0;
+  // Scan-sized clouds: ONE launch builds every such tree, a workgroup per cloud walking its levels itself (k_kd_build_wg) -- no host round trip per level.
+  // Map-sized clouds keep the level loop (a level of theirs fills the chip): their roots are queued here, the host learns every level's node count.
+  const int wg_max = ctx->kd_wg_max_points;
+  std::vector<int4> roots; std::vector<int32_t> ones((size_t) nc, 1);
+  int n_small = 0;
+  for (int c = 0; c < nc; ++c) { if (cs->h_count[c] <= wg_max) ++n_small; else roots.push_back(make_int4(c, 0, 0, cs->h_count[c])); }
+  HIPCHK(ctx, hipMemcpyAsync(d_nn, ones.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
+  if (n_small > 0) {
+    KdBuildWgArgs W; W.B = B; W.count = cs->d_count; W.xy0 = cs->d_xy; W.nrm0 = cs->d_nrm;
+    W.xy_buf[0] = xyb[0]; W.xy_buf[1] = xyb[1]; W.idx_buf[0] = ixb[0]; W.idx_buf[1] = ixb[1]; W.q_buf[0] = qb[0]; W.q_buf[1] = qb[1];
+    W.leaf_nrm = kc.d_leaf_nrm; W.meta_rw = kc.d_meta; W.max_points = wg_max;
+    if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_build_wg<1>, dim3((unsigned) nc), dim3(256), 0, ctx->stream, W);
+    else hipLaunchKernelGGL(k_kd_build_wg<0>, dim3((unsigned) nc), dim3(256), 0, ctx->stream, W);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync((void*) h_cnt, d_cnt + level + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, stream_sync(ctx));
-    n_items = h_cnt[0];
-    ++level;
   }
-  hipLaunchKernelGGL(k_kd_finish, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) d_nn, nc, kc.d_meta);
-  {
-    int max_pts = 1; for (int c = 0; c < nc; ++c) if (cs->h_count[c] > max_pts) max_pts = cs->h_count[c];
-    int gx = (max_pts + 255) / 256; if (gx > 1024) gx = 1024;
-    for (int c0 = 0; c0 < nc; c0 += 32768) {         // gridDim.y is limited to 65535
-      const int ny = nc - c0 < 32768 ? nc - c0 : 32768;
-      hipLaunchKernelGGL(k_kd_permute_normals, dim3((unsigned) gx, (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_nrm,
-                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) kc.d_leaf_idx, kc.d_leaf_nrm, c0);
+  long long n_items = (long long) roots.size(); int level = 0;
+  if (n_items > 0) {
+    // (the big clouds' items use the queue buffers from position 0: the small clouds' stretches -- start / 2 + c -- are theirs alone only while the
+    // workgroup build runs, and the stream orders the two)
+    HIPCHK(ctx, hipMemcpyAsync(qb[0], roots.data(), sizeof(int4) * roots.size(), hipMemcpyHostToDevice, ctx->stream));
+    volatile int32_t* h_cnt = (volatile int32_t*) ctx->h_flag;
+    while (n_items > 0) {
+      if (level >= kMaxLevels) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "kdtree: deeper than 8192 levels");
+      B.xy_in = level == 0 ? cs->d_xy : xyb[level & 1]; B.idx_in = level == 0 ? nullptr : ixb[level & 1];
+      B.xy_out = xyb[(level + 1) & 1]; B.idx_out = ixb[(level + 1) & 1];
+      B.q_in = qb[level & 1]; B.q_out = qb[(level + 1) & 1]; B.q_out_count = d_cnt + level + 1; B.n_items = (int32_t) n_items;
+      const unsigned blocks = (unsigned) ((n_items + 3) / 4);
+      if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_level<1>, dim3(blocks), dim3(256), 0, ctx->stream, B);
+      else hipLaunchKernelGGL(k_kd_level<0>, dim3(blocks), dim3(256), 0, ctx->stream, B);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipMemcpyAsync((void*) h_cnt, d_cnt + level + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, stream_sync(ctx));
+      n_items = h_cnt[0];
+      ++level;
     }
+    // the big clouds' sizes and leaf-order normals (the workgroup build wrote its own clouds')
+    hipLaunchKernelGGL(k_kd_finish, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) d_nn, nc, kc.d_meta);
+    for (int c = 0; c < nc; ++c) {
+      if (cs->h_count[c] <= wg_max) continue;
+      int gx = (cs->h_count[c] + 255) / 256; if (gx > 1024) gx = 1024;
+      hipLaunchKernelGGL(k_kd_permute_normals, dim3((unsigned) gx, 1u), dim3(256), 0, ctx->stream, (const float2*) cs->d_nrm,
+                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) kc.d_leaf_idx, kc.d_leaf_nrm, c);
+    }
+    HIPCHK(ctx, hipGetLastError());
   }
-  HIPCHK(ctx, hipGetLastError());
-  std::vector<int32_t> h_nn((size_t) nc);
-  HIPCHK(ctx, hipMemcpyAsync(h_nn.data(), d_nn, sizeof(int32_t) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
+  // what the host needs of the result: every tree's node count (and, of the workgroup builds, the depth): one read, one wait
+  std::vector<KdMeta> h_meta((size_t) nc);
+  HIPCHK(ctx, hipMemcpyAsync(h_meta.data(), kc.d_meta, sizeof(KdMeta) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, stream_sync(ctx));
   kc.levels = level; kc.total_nodes = 0; kc.max_nodes_per_cloud = 0;
-  for (int c = 0; c < nc; ++c) { kc.total_nodes += h_nn[(size_t) c]; if (h_nn[(size_t) c] > kc.max_nodes_per_cloud) kc.max_nodes_per_cloud = h_nn[(size_t) c]; }
-  ctx->last_kd_levels = level; ctx->last_kd_nodes = kc.total_nodes;
+  for (int c = 0; c < nc; ++c) {
+    const int nn = h_meta[(size_t) c].n_nodes;
+    kc.total_nodes += nn; if (nn > kc.max_nodes_per_cloud) kc.max_nodes_per_cloud = nn;
+    if (cs->h_count[c] <= wg_max && h_meta[(size_t) c].pad0 > kc.levels) kc.levels = h_meta[(size_t) c].pad0;
+  }
+  ctx->last_kd_levels = kc.levels; ctx->last_kd_nodes = kc.total_nodes;
   kc.d_block = t_block.release();      // owned by the cache from here on (the working set goes with its guard)
   cs->kds.push_back(kc);
   *out = KdDev{kc.d_meta, kc.d_nodes, kc.d_leaf_xy, kc.d_leaf_idx, kc.d_leaf_nrm};
@@ -1832,7 +1873,12 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     int32_t* st = (int32_t*) (hs + o_status);
     for (int i = 0; i < n; ++i) st[i] = kStatusNotWritten;          // the kernels write an alignment's status last (release, system scope)
   }
-  else HIPCHK(ctx, hipMemsetAsync(ds + o_pose, 0, out_bytes, ctx->stream));
+  else {
+    // every alignment's pose, information matrix, status and iteration count are written by its workgroup whatever happens to it; what a kernel may leave
+    // untouched are the statistics of iterations that never started: only those are cleared (the clock stamps of a timed launch are written by every
+    // stamping workgroup -- each alignment runs exactly once, wherever the placement puts it)
+    if (out_stats) HIPCHK(ctx, hipMemsetAsync(ds + o_stats, 0, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, ctx->stream));
+  }
   ctx->last_align_path = use_split ? 2 : (use_pair ? 3 : 1);
   // culled batches that run in about one dispatch round: balanced placement (two small launches ahead of k_align; see k_cull_estimate)
   A.order = nullptr;

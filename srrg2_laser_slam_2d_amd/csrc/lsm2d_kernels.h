@@ -586,12 +586,10 @@ struct SeqSum {      // one sequential fp32 sum over values that arrive 64 at a 
   LSM2D_DEV float total() const { return kChain == 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63)) : acc; }
 };
 
-template <int kChain>
-__global__ __launch_bounds__(256) void k_kd_level(const KdBuildArgs A) {
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= A.n_items) return;                     // whole waves leave: no workgroup barrier below
-  const int4 it = A.q_in[item];
+// one node of the build, by one wave: `it` = (cloud, node, begin, end).  push(n_next, item_left, item_right): lane 0 hands the children that must be split
+// again to the next level's queue (n_next of them: the left one first when both go)
+template <int kChain, typename Push>
+LSM2D_DEV void kd_node(const KdBuildArgs& A, const int4 it, const int lane, Push push) {
   const int c = __builtin_amdgcn_readfirstlane(it.x), node = __builtin_amdgcn_readfirstlane(it.y);
   const int begin = __builtin_amdgcn_readfirstlane(it.z), end = __builtin_amdgcn_readfirstlane(it.w);
   const int n = end - begin, base = A.start[c], nbase = A.meta[c].node_base;
@@ -677,9 +675,8 @@ __global__ __launch_bounds__(256) void k_kd_level(const KdBuildArgs A) {
     if (leaf_r) { KdNode nd = {0.0f, 0.0f, 0.0f, 0.0f, -1 - (begin + nl), end, 0, 0}; A.nodes[nbase + left_id + 1] = nd; }
     const int n_next = (leaf_l ? 0 : 1) + (leaf_r ? 0 : 1);
     if (n_next) {
-      int q = atomicAdd(A.q_out_count, n_next);
-      if (!leaf_l) A.q_out[q++] = make_int4(c, left_id, begin, begin + nl);
-      if (!leaf_r) A.q_out[q] = make_int4(c, left_id + 1, begin + nl, end);
+      const int4 il = make_int4(c, left_id, begin, begin + nl), ir = make_int4(c, left_id + 1, begin + nl, end);
+      push(n_next, leaf_l ? ir : il, ir);
     }
   }
   float2* oxy_l = (leaf_l ? A.leaf_xy : A.xy_out) + base + begin;  int32_t* oix_l = (leaf_l ? A.leaf_idx : A.idx_out) + base + begin;
@@ -698,6 +695,62 @@ __global__ __launch_bounds__(256) void k_kd_level(const KdBuildArgs A) {
     }
     cl += __popcll(bl); cr += __popcll(br);
   }
+}
+
+template <int kChain>
+__global__ __launch_bounds__(256) void k_kd_level(const KdBuildArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= A.n_items) return;                     // whole waves leave: no workgroup barrier below
+  kd_node<kChain>(A, A.q_in[item], lane, [&](int n_next, const int4& first, const int4& second) {
+    int q = atomicAdd(A.q_out_count, n_next);
+    A.q_out[q] = first;
+    if (n_next == 2) A.q_out[q + 1] = second;
+  });
+}
+
+// Round 4: the WHOLE build of a scan-sized cloud in ONE launch -- a workgroup per cloud walks its tree's levels itself (two barriers per level), its waves
+// take the nodes of a level in turn, the queue of the next level sits in the cloud's own stretch of the queue buffers, and the leaf-order normals are written
+// at the end.  CorrespondenceFinderKDTree2D::reset() runs whenever the fixed cloud changes (correspondence_finder_kd_tree_2d.cpp:6-8,31-38): for the live
+// tracker that is once per scan, and the level-by-level build of round 3 paid a host round trip per level (~7 for a 1081-point scan).  Same kd_node, same
+// order of every sequential sum, hence the same tree bit for bit (tests).  Clouds above max_points are left to the level loop (k_kd_level).
+struct KdBuildWgArgs {
+  KdBuildArgs B;                       // xy_in / idx_in / xy_out / idx_out / q_in / q_out are set per level by the kernel itself
+  const int32_t* count; const float2* xy0; const float2* nrm0;
+  float2* xy_buf[2]; int32_t* idx_buf[2]; int4* q_buf[2];
+  float2* leaf_nrm; KdMeta* meta_rw;
+  int32_t max_points;
+};
+template <int kChain>
+__global__ __launch_bounds__(256) void k_kd_build_wg(const KdBuildWgArgs W) {
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = W.count[c], base = W.B.start[c];
+  if (n > W.max_points) return;
+  __shared__ int s_cnt[2], s_levels;
+  const int qbase = (base >> 1) + c;                 // this cloud's stretch of the queue buffers: a level never holds more than n / 2 (+ 1) nodes
+  if (tid == 0) { W.q_buf[0][qbase] = make_int4(c, 0, 0, n); s_cnt[0] = 1; s_cnt[1] = 0; s_levels = 0; W.B.n_nodes[c] = 1; }
+  __syncthreads();
+  KdBuildArgs A = W.B;
+  for (int level = 0;; ++level) {
+    const int cur = level & 1, nxt = cur ^ 1;
+    const int items = s_cnt[cur];
+    if (items == 0) break;                           // (workgroup-uniform)
+    A.xy_in = level == 0 ? W.xy0 : W.xy_buf[cur]; A.idx_in = level == 0 ? nullptr : W.idx_buf[cur];
+    A.xy_out = W.xy_buf[nxt]; A.idx_out = W.idx_buf[nxt];
+    const int4* qin = W.q_buf[cur] + qbase; int4* qout = W.q_buf[nxt] + qbase;
+    for (int item = wave; item < items; item += 4)
+      kd_node<kChain>(A, qin[item], lane, [&](int n_next, const int4& first, const int4& second) {
+        const int q = atomicAdd(&s_cnt[nxt], n_next);
+        qout[q] = first;
+        if (n_next == 2) qout[q + 1] = second;
+      });
+    __syncthreads();                                 // the level's writes (children's points, queue, counter) are complete and visible to the workgroup
+    if (tid == 0) { s_cnt[cur] = 0; s_levels = level + 1; }
+    __syncthreads();
+  }
+  // the normals in leaf order (k_kd_permute_normals), and the tree's size
+  for (int i = tid; i < n; i += 256) W.leaf_nrm[base + i] = W.nrm0[base + W.B.leaf_idx[base + i]];
+  if (tid == 0) { W.meta_rw[c].n_nodes = W.B.n_nodes[c]; W.meta_rw[c].pad0 = s_levels; }
 }
 
 // roots of every cloud's tree: work item (c, 0, 0, count[c]); one node handed out per cloud

@@ -54,6 +54,19 @@ def main():
             if os.environ.get("LSM2D_TSB_DUMP"):          # debug builds (-DLSM2D_PHASE_CLOCKS) print from the kernel
                 sys.stderr.write(r.stdout)
             out[key] = json.loads(r.stdout.strip().splitlines()[-1])
+        # the same asynchronous step with the point-query finders in both slices: CorrespondenceFinderKDTree2D as the reference runs it (its tree REBUILT for
+        # every new scan, correspondence_finder_kd_tree_2d.cpp:6-8,31-38: since round 4 one launch per build), the exact grid search, the distance map
+        for fk in ("kdtree", "nn", "distmap"):
+            r = subprocess.run([exe, os.path.join(d, "map.bin"), os.path.join(d, "s0.bin"), os.path.join(d, "s1.bin"),
+                                repr(float(guess[0])), repr(float(guess[1])), repr(float(guess[2])), str(max(args.steps // 4, 50)), "1",
+                                os.path.join(d, "r0.bin"), os.path.join(d, "r1.bin"), repr(a0), repr(a1)],
+                               check=True, capture_output=True, text=True, timeout=300, env=dict(os.environ, LSM2D_TSB_FINDER=fk))
+            out["c_abi_async_finder_" + fk] = json.loads(r.stdout.strip().splitlines()[-1])
+        r = subprocess.run([exe, os.path.join(d, "map.bin"), os.path.join(d, "s0.bin"), os.path.join(d, "s1.bin"),
+                            repr(float(guess[0])), repr(float(guess[1])), repr(float(guess[2])), str(max(args.steps // 4, 50)), "1",
+                            os.path.join(d, "r0.bin"), os.path.join(d, "r1.bin"), repr(a0), repr(a1)],
+                           check=True, capture_output=True, text=True, timeout=300, env=dict(os.environ, LSM2D_TSB_FINDER="kdtree", LSM2D_TSB_OPTIONS="kd_wg_max_points=0"))
+        out["c_abi_async_finder_kdtree_level_loop_build"] = json.loads(r.stdout.strip().splitlines()[-1])
     # the same step on the CPU oracle
     osl = [po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.9, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.01, min_num_correspondences=5, sensor_in_robot=tuple(S[0])),
            po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.8, min_num_correspondences=5, sensor_in_robot=tuple(S[1]))]

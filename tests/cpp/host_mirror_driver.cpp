@@ -49,6 +49,25 @@ int main(int argc, char** argv) {
     aligner.setFixed(&fixed_props); aligner.setMoving(&moving_props); aligner.setMovingInFixed(pose);
     aligner.compute();
 
+    // round 4: what the reference leaves in slice->correspondences() (apps/visual_test_aligner_2d.cpp:129-143), the pair digest of the last
+    // iteration, and MultiAligner2D's inlier options (MULTI.json:606-610) on a robustified slice
+    size_t n_kept = 0, n_all = 0, its_runs = 0; unsigned long long dig_stats = 0, dig_pairs = 0; int last_inl = 0;
+    { AlignerSliceProcessorLaser2DPtr rs(new AlignerSliceProcessorLaser2D);
+      rs->param_finder = cf; rs->param_min_num_correspondences = 10;
+      rs->param_robustifier.reset(new RobustifierCauchy); rs->param_robustifier->param_chi_threshold = 2e-5f;
+      MultiAligner2D al2(ctx);
+      al2.param_max_iterations = its; al2.param_slice_processors.push_back(rs); al2.store_correspondences = true;
+      al2.setFixed(&fixed_props); al2.setMoving(&moving_props); al2.setMovingInFixed(pose);
+      al2.compute();
+      n_all = al2.correspondences(0).size();
+      const lsm2d_iteration_stats& st = al2.iterationStats().back();
+      dig_stats = ((unsigned long long) st.pair_digest_hi << 32) | st.pair_digest_lo;
+      for (const auto& p : al2.correspondences(0)) dig_pairs += lsm2d_pair_hash(0u, (uint32_t) p.fixed_idx, (uint32_t) p.moving_idx);
+      al2.param_keep_only_inlier_correspondences = true; al2.param_enable_inlier_only_runs = true;
+      al2.setMovingInFixed(pose); al2.compute();
+      n_kept = al2.correspondences(0).size(); its_runs = al2.iterationStats().size(); last_inl = al2.iterationStats().back().n_inliers;
+    }
+
     // the other two finders and the mapping steps, through their reference-named classes
     CorrespondenceVector nn_pairs, dm_pairs, kd_pairs;
     { CorrespondenceFinderKDTree2D kd(ctx, "exact"); kd.param_max_distance_m = 0.3f;      // the exact grid search
@@ -77,8 +96,10 @@ int main(int argc, char** argv) {
            threw, nn_pairs.size(), kd_pairs.size(), dm_pairs.size(), n_clipped, merged_size, merger.counts[0], merger.counts[1], merger.counts[2], correspondences.size());
     for (size_t i = 0; i < correspondences.size(); ++i) printf("%s[%d,%d]", i ? "," : "", correspondences[i].fixed_idx, correspondences[i].moving_idx);
     const Vector3f& x = aligner.movingInFixed();
-    printf("], \"status\": %d, \"pose\": [%.9g, %.9g, %.9g], \"iterations\": %zu, \"last_n_corr\": %d}\n", aligner.status(), x[0], x[1], x[2],
-           aligner.iterationStats().size(), aligner.iterationStats().empty() ? 0 : aligner.iterationStats().back().n_correspondences);
+    printf("], \"status\": %d, \"pose\": [%.9g, %.9g, %.9g], \"iterations\": %zu, \"last_n_corr\": %d, \"n_all\": %zu, \"digest_matches\": %d, \"n_kept\": %zu, "
+           "\"iterations_with_inlier_runs\": %zu, \"last_inliers_with_inlier_runs\": %d}\n", aligner.status(), x[0], x[1], x[2],
+           aligner.iterationStats().size(), aligner.iterationStats().empty() ? 0 : aligner.iterationStats().back().n_correspondences,
+           n_all, (int) (dig_stats == dig_pairs && dig_stats != 0), n_kept, its_runs, last_inl);
   } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
   return 0;
 }

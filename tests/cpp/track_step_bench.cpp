@@ -68,6 +68,13 @@ int main(int argc, char** argv) {
     sl[i].robustifier = i ? LSM2D_ROBUST_NONE : LSM2D_ROBUST_CAUCHY; sl[i].chi_threshold = 0.01f; sl[i].min_num_correspondences = 5;
     memcpy(sl[i].sensor_in_robot, i ? S1 : S0, sizeof S0);
   }
+  // LSM2D_TSB_FINDER=kdtree | nn | distmap: the same step with a point-query finder in both slices (CorrespondenceFinderKDTree2D as the reference
+  // runs it -- its tree rebuilt for every new scan, correspondence_finder_kd_tree_2d.cpp:6-8,31-38 --, the exact grid search, the distance map): what
+  // the live tracker pays for the finders' reset() at scan rate
+  if (const char* fk = getenv("LSM2D_TSB_FINDER")) {
+    const int kind = !strcmp(fk, "kdtree") ? LSM2D_FINDER_KDTREE : (!strcmp(fk, "nn") ? LSM2D_FINDER_NN : (!strcmp(fk, "distmap") ? LSM2D_FINDER_DISTMAP : LSM2D_FINDER_PROJECTIVE));
+    for (int i = 0; i < 2; ++i) { sl[i].finder = kind; sl[i].max_distance = 0.3f; sl[i].resolution = 0.05f; sl[i].kd_max_leaf_range = 0.01f; sl[i].kd_min_leaf_points = 20; }
+  }
   lsm2d_aligner_params ap = {10, 10, 0.0f, 0.0f, 0, 0};
   lsm2d_prior prior; memset(&prior, 0, sizeof prior); prior.omega[0] = prior.omega[4] = prior.omega[8] = 100.0f;
   const lsm2d_cloudset* fixed[2] = {m0, m1}; const lsm2d_cloudset* moving[2] = {clipped, clipped};

@@ -552,6 +552,12 @@ def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     o = po.align(po.aligner_params(20), [po.slice_params()], [f], [wl.map_points], x0)
     d = np.abs(np.array(r["pose"]) - o["pose"])
     assert r["status"] == 0 and r["iterations"] == 20 and d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
+    # round 4 through the C++ mirror: stored correspondences (their host-side digest equals the last iteration's), kept inliers, the second loop
+    spc = po.slice_params(robustifier=po.ROBUST_CAUCHY, chi_threshold=2e-5)
+    o_all = po.align(po.aligner_params(20, device_order=True), [spc], [f], [wl.map_points], x0, want_pairs=True)
+    o_run = po.align(po.aligner_params(20, device_order=True, enable_inlier_only_runs=True, keep_only_inlier_correspondences=True), [spc], [f], [wl.map_points], x0, want_pairs=True)
+    assert r["digest_matches"] == 1 and r["n_all"] == len(o_all["pairs"][0]) and r["iterations_with_inlier_runs"] == o_run["iterations"] == 40
+    assert r["n_kept"] == len(o_run["pairs"][0]) == r["last_inliers_with_inlier_runs"] == o_run["stats"][-1].n_in
     # the other finders and the mapping classes of the C++ mirror give the oracle's counts on the same inputs
     assert r["n_nn"] == len(po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.3), f, wl.map_points, x0))
     assert r["n_kdtree"] == len(po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, kd_max_leaf_range=0.02, kd_min_leaf_points=9), f, wl.map_points, x0))
@@ -2115,6 +2121,7 @@ def test_randomised_aligner_structure(ctx, po):
     maps = {n: synth.make_map(world, n, noise_sigma=0.003, seed=n + 3) for n in (4000, 30000)}
     poses = synth.sample_poses(world, 8, seed=17)
     checked = soft = paired = sets_differ = 0
+    worst_same = worst_same_strict = worst_diff = 0.0      # largest |device - sequential-order oracle| (m or rad): digest-equal alignments (all / those held to 1e-4), sets that part ways
     for trial in range(n_trials):
         ns = int(rng.integers(1, 4)); nb = int(rng.integers(1, 6)); its = int(rng.integers(1, 13)); m = maps[(4000, 30000)[trial % 2]]
         use_prior = bool(trial % 3 == 0)
@@ -2199,9 +2206,17 @@ def test_randomised_aligner_structure(ctx, po):
                           o_.n_corr, o_.n_in, o_.chi_in, t_.n_corr, t_.n_in, t_.chi_in))
                 print("  pose gpu", a.pose[i].tolist(), "f32", r["pose"].tolist(), "f64", rd["pose"].tolist())
             assert d.max() < tol, (trial, i, d, dd, same_sets)
+            if same_sets:
+                worst_same = max(worst_same, float(d.max()))
+                if tol <= POSE_TOL_M:
+                    worst_same_strict = max(worst_same_strict, float(d.max()))
+            else:
+                worst_diff = max(worst_diff, float(d.max()))
             checked += 1; soft += int(tol > POSE_TOL_M)
     print("structure fuzz: %d trials, %d alignments checked (%d against a bar above 1e-4, of which %d because the two summation orders' pair sets part ways -- digests), "
-          "split == fused in all, latency kernel == fused in all %d one- and two-slice trials" % (n_trials, checked, soft, sets_differ, paired))
+          "split == fused in all, latency kernel == fused in all %d one- and two-slice trials; largest pose difference: %.2e where every iteration's digest agrees and the bar is "
+          "1e-4, %.2e where it agrees and the fp32 / fp64 oracles themselves are further apart, %.2e where the sets part ways"
+          % (n_trials, checked, soft, sets_differ, paired, worst_same_strict, worst_same, worst_diff))
     assert checked >= n_trials // 2
 
 
@@ -2912,3 +2927,45 @@ def test_latency_kernel_two_slices_one_empty_fixed_cloud_and_one_beyond_the_lds_
         w = po.align(po.aligner_params(6, min_num_inliers=5, device_order=True), osl, fixed, [m, m], x0[0])
         _assert_bitwise_equal_to_device_order_oracle(c, 0, w, "one empty fixed cloud")
         assert c.status[0] == 0
+
+
+def test_kdtree_single_launch_build_equals_the_level_loop(ctx, po):
+    """Round 4: scan-sized clouds get their KD-tree from ONE launch (k_kd_build_wg: a workgroup per cloud walks the levels itself -- the reference
+    rebuilds the tree whenever the fixed cloud changes, correspondence_finder_kd_tree_2d.cpp:6-8,31-38, i.e. per scan in the live tracker); the
+    level-by-level build of round 3 stays for map-sized clouds ("kd_wg_max_points" 0 forces it).  Same kd_node, same order of every sequential sum:
+    the same trees -- node counts, depths, and every pair of every query -- and both equal the oracle's."""
+    world = synth.make_world(12)
+    robots = synth.sample_poses(world, 24, seed=3)
+    pts, offs = synth.make_scans(world, robots, n_beams=1081, noise_sigma=0.004, seed=2)
+    m = synth.make_map(world, 12000, noise_sigma=0.002, seed=4)
+    degenerate = [np.zeros((0, 4), np.float32), pts[:1], pts[:2], pts[:19], pts[:20], pts[:21], np.repeat(pts[:1], 50, 0)]
+    clouds = [pts[offs[i]:offs[i + 1]] for i in range(24)] + degenerate + [m]
+    offs_all = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    allp = np.concatenate(clouds, 0)
+    x0 = np.float32([0.02, -0.01, 0.01])
+    res = {}
+    try:
+        for wg in (16384, 0, 100):              # 100: the scans go through the level loop, the tiny clouds through the workgroup build (a mixed set)
+            ctx.set_option("kd_wg_max_points", wg)
+            cs = api.CloudSet(ctx, allp, offs_all)
+            out = []
+            for lr, lp in ((1e-2, 20), (0.05, 7)):
+                f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=0.5, max_leaf_range=lr, min_leaf_points=lp, search="kdtree")
+                for ci in range(len(clouds)):
+                    f.setFixed(cs, ci); f.setMoving(m[::7]); f.setLocalMapInSensor(x0)
+                    out.append(f.compute())
+                out.append(np.array([[ctx.get_option("last_kd_levels"), ctx.get_option("last_kd_nodes")]]))
+            res[wg] = out
+            cs.close()
+    finally:
+        ctx.set_option("kd_wg_max_points", 16384)
+    for wg in (0, 100):
+        assert len(res[wg]) == len(res[16384])
+        for a, b in zip(res[16384], res[wg]):
+            assert np.array_equal(a, b), wg
+    k = 0
+    for lr, lp in ((1e-2, 20), (0.05, 7)):
+        for ci in (0, 5, 23, 24, 27, 29, len(clouds) - 1):
+            want = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, normal_cos=0.5, kd_max_leaf_range=lr, kd_min_leaf_points=lp), clouds[ci], m[::7], x0)
+            assert np.array_equal(res[16384][k + ci], want), (lr, lp, ci)
+        k += len(clouds) + 1

@@ -22,6 +22,29 @@ def main():
     ctx = api.Context(0)
     wl = synth.make_workload(args.scans, 1000, seed=0)
     q = wl.scan_points[: wl.scan_offsets[1]]
+    # the live tracker's case: ONE scan's tree per call (a fresh cloud every time, as CorrespondenceFinderKDTree2D::reset() sees it), with the
+    # single-launch workgroup build (default) and with the level-by-level build of round 3 ("kd_wg_max_points" 0)
+    for wg in (16384, 0):
+        ctx.set_option("kd_wg_max_points", wg)
+        ts = []
+        for rep in range(30):
+            sc = wl.scan_points[wl.scan_offsets[rep]:wl.scan_offsets[rep + 1]]
+            cs = api.CloudSet(ctx, sc)
+            f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.5, search="kdtree")
+            f.setFixed(cs); f.setMoving(q); f.setLocalMapInSensor([0, 0, 0])
+            ctx.synchronize(); t0 = time.perf_counter(); f.compute(); t1 = time.perf_counter(); f.compute(); t2 = time.perf_counter()
+            ts.append(((t1 - t0) - (t2 - t1)) * 1e3)
+            cs.close()
+        print(json.dumps({"case": "one scan per call", "kd_wg_max_points": wg, "build_ms_median": float(np.median(ts[5:])), "build_ms_min": float(np.min(ts[5:])),
+                          "levels": ctx.get_option("last_kd_levels"), "nodes": ctx.get_option("last_kd_nodes")}), flush=True)
+        cs = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
+        f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.5, search="kdtree")
+        f.setFixed(cs, 0); f.setMoving(q); f.setLocalMapInSensor([0, 0, 0])
+        ctx.synchronize(); t0 = time.perf_counter(); f.compute(); t1 = time.perf_counter(); f.compute(); t2 = time.perf_counter()
+        print(json.dumps({"case": "scans", "clouds": args.scans, "kd_wg_max_points": wg, "build_ms": ((t1 - t0) - (t2 - t1)) * 1e3,
+                          "levels": ctx.get_option("last_kd_levels"), "nodes": ctx.get_option("last_kd_nodes")}), flush=True)
+        cs.close()
+    ctx.set_option("kd_wg_max_points", 16384)
     for chain in (1, 0):
         ctx.set_option("kd_chain", chain)
         for n in args.map_points:
