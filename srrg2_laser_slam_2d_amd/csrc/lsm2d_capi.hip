@@ -48,8 +48,11 @@ struct lsm2d_context {
   int find_path = 0;           // 0 auto (point-query finder calls with more queries than one trip of a workgroup: many workgroups), 1 one workgroup always
   int grid_big_threshold = 16384;   // clouds of at least this many points get their search grid built by the chip-wide kernels (k_grid_big_*)
   int distmap_build = 0;       // 0 auto (scatter build when it packs), 1 gather build always (the two agree bit for bit: tests)
-  int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / k_balance_order); 0: workgroup b = alignment b
+  int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / balance_order); 0: workgroup b = alignment b
   int n_cu = 0;                // compute units of the device (hipDeviceProp_t.multiProcessorCount)
+  int cull_est_um = 0, cull_est_urad = 40000;      // margins of the work estimate's chunk test ("cull_est_um", "cull_est_urad"; placement only)
+  int balance_notes = 1;       // ... group the workgroup ids by the CU the previous launch of the same shape ran them on (0: assume b, b + n_cu, ...; A/B knob)
+  int32_t* d_wg_place = nullptr; unsigned long long wg_place_shape = 0;      // the notes (one int per workgroup) and the launch shape they belong to
   int proj_modes = 1;          // projective batches against map-sized clouds: the instantiation with the culled stream only (0: the shared one; A/B knob)
   int kd_modes = 1;            // KD-tree batches: the instantiations with one form of the descent only (0: the shared one; A/B knob)
   int nn_lds_only = 1;         // grid NN with every alignment's tables staged in LDS: the instantiation without the search in global memory (0: the shared one; A/B knob)
@@ -250,6 +253,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->d_scratch) (void) hipFree(c->d_scratch);
   if (c->d_split) (void) hipFree(c->d_split);
   if (c->d_kd_work) (void) hipFree(c->d_kd_work);
+  if (c->d_wg_place) (void) hipFree(c->d_wg_place);
   for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
   if (c->ev1) (void) hipEventDestroy(c->ev1);
@@ -275,6 +279,9 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull must be 0, 1 or 2"); ctx->cull = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_est_um")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_est_um out of range"); ctx->cull_est_um = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_est_urad")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_est_urad out of range"); ctx->cull_est_urad = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "balance_notes")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance_notes must be 0 or 1"); ctx->balance_notes = (int) value; ctx->wg_place_shape = 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_keep")) { ctx->cull_keep = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_margin_um")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_margin_um: 0 .. 1e6"); ctx->cull_margin_um = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_margin_urad")) { if (value < 0 || value > 200000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_margin_urad: 0 .. 2e5"); ctx->cull_margin_urad = (int) value; return LSM2D_SUCCESS; }
@@ -301,6 +308,9 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "kd_modes")) { *out_value = ctx->kd_modes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "proj_modes")) { *out_value = ctx->proj_modes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_est_um")) { *out_value = ctx->cull_est_um; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "cull_est_urad")) { *out_value = ctx->cull_est_urad; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "balance_notes")) { *out_value = ctx->balance_notes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_keep")) { *out_value = ctx->cull_keep; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_margin_um")) { *out_value = ctx->cull_margin_um; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_margin_urad")) { *out_value = ctx->cull_margin_urad; return LSM2D_SUCCESS; }
@@ -1880,14 +1890,15 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     if (out_stats) HIPCHK(ctx, hipMemsetAsync(ds + o_stats, 0, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, ctx->stream));
   }
   ctx->last_align_path = use_split ? 2 : (use_pair ? 3 : 1);
-  // culled batches that run in about one dispatch round: balanced placement (two small launches ahead of k_align; see k_cull_estimate)
-  A.order = nullptr;
+  // culled batches that run in about one dispatch round: balanced placement (one small launch ahead of k_align; see k_cull_estimate)
+  A.order = nullptr; A.wg_place = nullptr;
+  A.cull_est_mt = 1e-6f * (float) ctx->cull_est_um; A.cull_est_mth = 1e-6f * (float) ctx->cull_est_urad;
   if (out_work) {      // lsm2d_estimate_work: the chunks of the moving cloud each alignment's FIRST iteration will stream (k_cull_estimate), or 1 everywhere
     int bs = -1;
     for (int s = 0; s < ns && bs < 0; ++s) if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].moving.lane_xy && A.s[s].moving.lane_bounds && A.cull) bs = s;
     if (bs < 0) { for (int i = 0; i < n; ++i) out_work[i] = 1; return LSM2D_SUCCESS; }
     int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work);
-    hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), sizeof(u64) * (size_t) A.s[bs].proj.cols, ctx->stream, A, bs, d_work);
+    hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), sizeof(u64) * (size_t) A.s[bs].proj.cols, ctx->stream, A, bs, d_work, (int32_t*) nullptr, (const int32_t*) nullptr, ctx->n_cu, (unsigned int*) nullptr);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(hs + o_work, d_work, sizeof(int32_t) * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, stream_sync(ctx));
@@ -1899,10 +1910,19 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     for (int s = 0; s < ns && bs < 0; ++s) if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].moving.lane_xy && A.s[s].moving.lane_bounds) bs = s;
     if (bs >= 0) {
       int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work); int32_t* d_order = (int32_t*) ((char*) ctx->d_scratch + o_order);
-      hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), sizeof(u64) * (size_t) A.s[bs].proj.cols, ctx->stream, A, bs, d_work);
-      hipLaunchKernelGGL(k_balance_order, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*) d_work, n, ctx->n_cu, 4, d_order);
+      // the workgroups of the previous launch of the same shape noted the CU they ran on (AlignArgs::wg_place): the placement groups by those notes
+      const unsigned long long shape = ((unsigned long long) (unsigned) n << 32) ^ ((unsigned long long) lds << 8) ^ (unsigned long long) (proj_culled_for_all ? 5 : 0);
+      if (!ctx->d_wg_place) {      // 1024 notes + the estimate's ticket counter
+        HIPCHK(ctx, hipMalloc(&ctx->d_wg_place, sizeof(int32_t) * 1025)); ctx->wg_place_shape = 0;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_wg_place, 0, sizeof(int32_t) * 1025, ctx->stream));
+      }
+      const bool notes = ctx->balance_notes && ctx->wg_place_shape == shape;
+      size_t est_lds = sizeof(u64) * (size_t) A.s[bs].proj.cols; if (est_lds < sizeof(BalanceLds)) est_lds = sizeof(BalanceLds);
+      hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), est_lds, ctx->stream, A, bs, d_work, d_order,
+                         notes ? (const int32_t*) ctx->d_wg_place : (const int32_t*) nullptr, ctx->n_cu, (unsigned int*) (ctx->d_wg_place + 1024));
       HIPCHK(ctx, hipGetLastError());
       A.order = d_order;
+      if (ctx->balance_notes && n <= 1024) { A.wg_place = ctx->d_wg_place; ctx->wg_place_shape = shape; }
     }
   }
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));

@@ -817,6 +817,8 @@ struct AlignArgs {
   int32_t kd_lds_nodes;                     // > 0: single KD-tree slice -- room in LDS for this many nodes of the fixed cloud's tree (its top levels)
   int32_t kd_lds_points;                    // > 0: ... and, for scan-sized fixed clouds, for this many leaf points (whole trees on chip)
   const int32_t* order;                     // alignment handled by workgroup b (nullptr: b itself) -- the balanced placement of k_balance_order
+  float cull_est_mt, cull_est_mth;          // margins of k_cull_estimate's chunk test (metres, radians)
+  int32_t* wg_place;                        // [grid] or nullptr: every workgroup notes the CU it ran on (place_key) for the next call's placement
   int32_t cull_block;                       // steps per unit of the culled stream (0: automatic; tuning knob)
   int32_t cull;                             // 1: projective slices drop the chunks of the moving cloud that cannot yield a pair (chunk_may_matter), results unchanged
   // kProjCulled (round 4): every slice keeps a LIST of the (block, chunk) units that survive the test at block level, in dynamic LDS at units_off
@@ -938,6 +940,12 @@ LSM2D_DEV int block_compact_pos(bool flag, int* s_tot, int parity, int& base, in
 // tracker's wiring (both forms in one kernel: scratch 16 -> 80 bytes, role A 7.2 -> 10.6 ms)
 // kNNMode 2: the counterpart -- a pure grid-NN batch whose tables the host has PROVED to fit the LDS staging for every alignment (nn_lds_points is the
 // largest fixed cloud, nn_lds_cells the grid ensure_grid() gives that size): the search in global memory and the cooperative loop are compiled out
+// where a workgroup runs: the key the balanced placement groups workgroup ids by (see k_balance_order)
+static constexpr int kPlaceKeys = 4096;      // XCC (4 bits) | SE (3) | SH (1) | CU (4)
+LSM2D_DEV int place_key() {
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);      // HW_REG_HW_ID, HW_REG_XCC_ID
+  return (int) (((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u));
+}
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
 __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LSM2D_QUERY_MIN_WAVES)) void k_align(const AlignArgs A) {
   constexpr bool kNNGlobal = kNNMode == 1, kNNLds = kNNMode == 2;
@@ -997,6 +1005,7 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
 #else
 #define LSM2D_PH(k) do { } while (0)
 #endif
+  if (A.wg_place && tid == 0) A.wg_place[blockIdx.x] = place_key();
   const bool stamp = A.clock_out && tid == 0 && a % A.clock_stride == 0;
   if (stamp) { s_clk[0] = __builtin_amdgcn_s_memtime(); s_clk[1] = __builtin_amdgcn_s_memrealtime(); }
   if (A.prior && tid >= 64 && tid < 64 + kPriorWords)
@@ -1525,15 +1534,171 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
 // ---- balanced placement for culled batches -------------------------------------------------------------------------------------------
 // With the exact culling an alignment's work depends on its pose and scan (33 .. 59 % of the map's chunks survive on configs[1]), and a
 // batch of about one workgroup per slot of the chip runs in ONE dispatch round: the CU that happens to get four heavy alignments ends the
-// launch (workgroup lifetimes 0.64 .. 1.07 ms in one launch, tools/occupancy_probe.py).  Two small launches ahead of k_align fix that:
-// k_cull_estimate counts, per alignment, the chunks that survive at the START pose (what the first iteration will stream; later iterations
-// move the pose by centimetres); k_balance_order ranks the alignments by that count and deals them to workgroup ids so that the ids which
-// share a CU -- b, b + n_cu, b + 2 n_cu, ... as the dispatcher deals them (same probe) -- get a heavy, a light, a heavy, a light one
-// (boustrophedon rows); beyond the first round the heaviest go first.  Only WHERE an alignment runs changes; every result is the same.
-__global__ __launch_bounds__(kAlignBlock) void k_cull_estimate(const AlignArgs A, int slice, int32_t* __restrict__ work) {
-  extern __shared__ __align__(16) unsigned char smem[];
+// launch (workgroup lifetimes 0.64 .. 1.07 ms in one launch, tools/occupancy_probe.py).  One small launch ahead of k_align fixes that:
+// k_cull_estimate counts, per alignment, the chunks that survive at the START pose under the margins A.cull_est_mt / cull_est_mth (what the
+// iterations will stream while the pose moves by centimetres), and the workgroup that finishes LAST (an agent-scope counter) ranks the
+// alignments by that count and deals them to workgroup ids (balance_order) so that the ids which share a CU carry about the same sum.
+//
+// Round 4.  WHICH workgroup ids share a CU is the dispatcher's business: the probe of round 3 saw b, b + n_cu, b + 2 n_cu, ...; with this round's
+// smaller LDS footprint the groups look irregular ([0, 394, 527, 763], ...) -- but they are THE SAME from launch to launch
+// (tools/mapping_stability_probe.py: 256 of 256 groups identical over six launches, although the CUs' names permute).  So every k_align workgroup
+// notes where it ran (place_key, one store per workgroup), and the next call of the same shape groups the first round's workgroup ids by what the
+// previous launch noted; no notes yet (first call of a shape): the round-3 assumption.  Within the groups the alignments are dealt level by level:
+// the k-th member of every group takes one of the next-lighter block of alignments, and the group whose PROJECTED sum (what it carries so far plus
+// the mean of the lighter levels for every member still to come -- groups differ in size when n is not a multiple of the slots) is largest takes
+// the lightest of the block; for equal loads this is the boustrophedon of round 3.  Beyond the first round the heaviest go first.
+// Only WHERE an alignment runs changes; every result is the same.
+// Measured on configs[1] (profiles/r04/balance_ab_r04n.txt; k_align alone / whole step): no placement 0.793 / 0.842 ms; round-3 grouping, margins 3 cm and
+// 0.02 rad 0.762 / 0.848; noted grouping, margins 0 and 0.04 rad (the defaults) 0.751 / 0.833.  The estimate's own launch is 35 us of the step.
+static constexpr int kBalMaxFirst = 1024, kBalMaxLevels = 8, kBalMaxGroups = 512;
+struct BalanceLds {                               // < 40 KB: four workgroups of k_cull_estimate per CU, the whole batch in one dispatch round
+  union { int bin[kAlignBlock + 2]; int gsize[kBalMaxGroups]; };      // (the bins are done with when the groups are formed)
+  int sorted[kBalMaxFirst];                       // the first round's alignments, heaviest first
+  unsigned short sw[kBalMaxFirst];                // ... and their counts
+  union {
+    unsigned short wall[2048];                    // the counts of alignments 0 .. 2047 (one agent-scope load each; beyond: loaded twice) -- until the ranks are out
+    unsigned short member[kBalMaxGroups * kBalMaxLevels];      // workgroup id of (group, slot) -- afterwards
+  };
+  unsigned int cnt[kPlaceKeys / 4];               // members per place key (8 bits each; more than 8 on a key: fallback)
+  unsigned short gid[kPlaceKeys];                 // the key's dense group id
+  unsigned short wg_key[kBalMaxFirst]; unsigned char wg_slot[kBalMaxFirst];
+  int gload[kBalMaxGroups];
+  __attribute__((aligned(16))) int gproj[kBalMaxGroups];
+  int grank[kBalMaxGroups];
+  int lvl[kBalMaxLevels + 1], lvl_work[kBalMaxLevels + 1];
+  int ngroups, bad;
+};
+static_assert(sizeof(BalanceLds) <= 39 * 1024, "k_cull_estimate: four workgroups per CU");
+LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu, int per_cu, int32_t* __restrict__ order, const int32_t* place, int tid, int nt) {
+  for (int i = tid; i < kAlignBlock + 2; i += nt) L.bin[i] = 0;
+  for (int i = tid; i < kPlaceKeys / 4; i += nt) L.cnt[i] = 0;
+  for (int i = tid; i < kBalMaxGroups; i += nt) L.gproj[i] = INT_MIN;
+  if (tid <= kBalMaxLevels) { L.lvl[tid] = 0; L.lvl_work[tid] = 0; }
+  if (tid == 0) { L.ngroups = 0; L.bad = 0; }
+  __syncthreads();
+  // (the counts were written by other workgroups, on other XCDs: agent-scope loads)
+  for (int a = tid; a < n; a += nt) {
+    const int w = __hip_atomic_load(&work[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a < 2048) L.wall[a] = (unsigned short) w;
+    atomicAdd(&L.bin[w], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {      // exclusive prefix over the bins, heaviest first: one wave, 9 bins per lane
+    constexpr int kPer = (kAlignBlock + 2 + 63) / 64;
+    int c[kPer], sum = 0;
+    #pragma unroll
+    for (int j = 0; j < kPer; ++j) { const int w = kAlignBlock + 1 - (tid * kPer + j); c[j] = w >= 0 ? L.bin[w] : 0; sum += c[j]; }
+    int incl = sum;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
+    int pos = incl - sum;
+    #pragma unroll
+    for (int j = 0; j < kPer; ++j) { const int w = kAlignBlock + 1 - (tid * kPer + j); if (w >= 0) L.bin[w] = pos; pos += c[j]; }
+  }
+  __syncthreads();
+  int first = n < n_cu * per_cu ? n : n_cu * per_cu;      // the ranks that go out in the first dispatch round
+  if (first > kBalMaxFirst) first = kBalMaxFirst;
+  for (int a = tid; a < n; a += nt) {
+    const int w = a < 2048 ? (int) L.wall[a] : __hip_atomic_load(&work[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int r = atomicAdd(&L.bin[w], 1);                      // rank among all alignments (ties in any order: placement only)
+    if (r < first) { L.sorted[r] = a; L.sw[r] = (unsigned short) w; } else order[r] = a;      // beyond the first round: the heaviest go first
+  }
+  // the groups of the first round's workgroup ids: by the previous launch's notes, or by the round-3 assumption
+  for (int b = tid; b < first; b += nt) {
+    const int key = place ? (place[b] & (kPlaceKeys - 1)) : (b % n_cu);
+    const unsigned int old = atomicAdd(&L.cnt[key >> 2], 1u << (8 * (key & 3)));
+    const int slot = (int) ((old >> (8 * (key & 3))) & 0xFFu);
+    if (slot >= kBalMaxLevels) L.bad = 1;      // (checked before anything reads a byte that overflowed into its neighbour)
+    L.wg_key[b] = (unsigned short) key; L.wg_slot[b] = (unsigned char) slot;
+  }
+  __syncthreads();
+  const bool bad = L.bad != 0;                      // (uniform: read after the barrier)
+  if (!bad) for (int kk = tid; kk < kPlaceKeys / 4; kk += nt) {
+    const unsigned int four = L.cnt[kk];
+    if (four) {
+      #pragma nounroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = (int) ((four >> (q * 8)) & 0xFFu);
+        if (c > 0) {
+          const int g = atomicAdd(&L.ngroups, 1);
+          if (g < kBalMaxGroups) {
+            L.gsize[g] = c; L.gload[g] = 0; L.gid[4 * kk + q] = (unsigned short) g;
+            #pragma nounroll
+            for (int k = 0; k < c; ++k) atomicAdd(&L.lvl[k + 1], 1);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int G = L.ngroups;
+  if (bad || G > kBalMaxGroups) {                // notes this cannot use (more than 8 workgroups on a CU, more than 512 CUs): the plain heaviest-first order
+    for (int r = tid; r < first; r += nt) order[r] = L.sorted[r];
+    return;
+  }
+  for (int b = tid; b < first; b += nt) L.member[(int) L.gid[L.wg_key[b]] * kBalMaxLevels + L.wg_slot[b]] = (unsigned short) b;
+  if (tid == 0) { for (int k = 0; k < kBalMaxLevels; ++k) L.lvl[k + 1] += L.lvl[k]; }      // lvl[k+1] held the groups with a k-th member: now level offsets
+  __syncthreads();
+  // work in every level (for the projected sums): a wave per level
+  if ((tid >> 6) < kBalMaxLevels) {
+    const int k = tid >> 6, lane = tid & 63;
+    int sum = 0;
+    for (int r = L.lvl[k] + lane; r < L.lvl[k + 1]; r += 64) sum += L.sw[r];
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) L.lvl_work[k] = sum;
+  }
+  __syncthreads();
+  // (this runs once per launch in ONE workgroup while the chip waits: measured with clock stamps, a rank loop of 256 tie-breaking compares per thread was
+  // 5.5 us per level; unique keys and the split between threads below: one compare per key.  The level loop stays a loop: unrolled it was 8200 instructions)
+  const int G4 = (G + 3) >> 2;
+  #pragma nounroll
+  for (int k = 0; k < kBalMaxLevels; ++k) {
+    const int base = L.lvl[k], m = L.lvl[k + 1] - base;
+    if (m == 0) break;
+    // what a group will carry: its sum so far plus the mean of every lighter level it still has a member in (x 16: integer means keep 4 fractional bits);
+    // made a UNIQUE key with the group's id below it (ties by id), so that a rank is a count of larger keys: one compare per key
+    if (tid < G) {
+      int p = INT_MIN;
+      if (L.gsize[tid] > k) {
+        p = 16 * L.gload[tid];
+        #pragma nounroll
+        for (int j = k + 1; j < L.gsize[tid] && j < kBalMaxLevels; ++j) { const int mj = L.lvl[j + 1] - L.lvl[j]; if (mj > 0) p += 16 * L.lvl_work[j] / mj; }
+        p = p * kBalMaxGroups + (kBalMaxGroups - 1 - tid);      // (< 2^31: sums stay below 8 x 512 x 16)
+      }
+      L.gproj[tid] = p; L.grank[tid] = 0;
+    }
+    __syncthreads();
+    {      // every group's rank: the keys are split between the threads that share a group (two halves at 256 groups and 512 threads); 128-bit LDS reads, a wave on one address
+      const int parts = G * 2 <= nt ? 2 : 1, per = nt / parts, g = tid % per, part = tid / per;
+      if (g < G && L.gsize[g] > k) {
+        const int mine = L.gproj[g];
+        const int4* gp = reinterpret_cast<const int4*>(L.gproj);
+        const int q0 = part * G4 / parts, q1 = (part + 1) * G4 / parts;
+        int r = 0;
+        #pragma unroll 2
+        for (int q = q0; q < q1; ++q) { const int4 v = gp[q]; r += (v.x > mine ? 1 : 0) + (v.y > mine ? 1 : 0) + (v.z > mine ? 1 : 0) + (v.w > mine ? 1 : 0); }
+        if (parts == 1) L.grank[g] = r; else atomicAdd(&L.grank[g], r);
+      }
+    }
+    __syncthreads();
+    int pick = -1, mine_w = 0;
+    if (tid < G && L.gsize[tid] > k) {
+      const int r = L.grank[tid];
+      pick = L.sorted[base + (m - 1 - r)];      // the group with the largest projected sum takes the lightest of the block
+      mine_w = L.sw[base + (m - 1 - r)];
+    }
+    if (pick >= 0) { order[L.member[tid * kBalMaxLevels + k]] = pick; L.gload[tid] += mine_w; }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kAlignBlock) void k_cull_estimate(const AlignArgs A, int slice, int32_t* __restrict__ work,
+                                                               int32_t* __restrict__ order /* or nullptr: counts only */, const int32_t* __restrict__ place, int n_cu, unsigned int* __restrict__ done_counter) {
+  extern __shared__ __align__(16) unsigned char smem[];      // the fixed canvas; the last workgroup's BalanceLds afterwards (the host sizes it for both)
   u64* fcan = reinterpret_cast<u64*>(smem);
   __shared__ Iso s_T;
+  __shared__ int s_last;
   const int a = blockIdx.x, tid = threadIdx.x;
   const SliceDev& S = A.s[slice];
   for (int i = tid; i < S.proj.cols; i += kAlignBlock) fcan[i] = kEmptyCell;
@@ -1543,31 +1708,21 @@ __global__ __launch_bounds__(kAlignBlock) void k_cull_estimate(const AlignArgs A
   const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
   project_cloud(S.fixed.xy + S.fixed.start[fc], S.fixed.count[fc], ident, S.proj, fcan, tid, kAlignBlock);
   __syncthreads();
-  const bool keep = chunk_may_matter(s_T, S.proj, S.moving.lane_bounds[(size_t) mc * kAlignBlock + tid], fcan, S.point_distance);
+  const bool keep = chunk_may_matter(s_T, S.proj, S.moving.lane_bounds[(size_t) mc * kAlignBlock + tid], fcan, S.point_distance, A.cull_est_mt, A.cull_est_mth);
   const int n_keep = __syncthreads_count(keep);
-  if (tid == 0) work[a] = n_keep;
-}
-
-__global__ __launch_bounds__(1024) void k_balance_order(const int32_t* __restrict__ work, int n, int n_cu, int per_cu, int32_t* __restrict__ order) {
-  __shared__ int s_bin[kAlignBlock + 2];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < kAlignBlock + 2; i += 1024) s_bin[i] = 0;
-  __syncthreads();
-  for (int a = tid; a < n; a += 1024) atomicAdd(&s_bin[work[a]], 1);
-  __syncthreads();
-  if (tid == 0) { int pos = 0; for (int w = kAlignBlock; w >= 0; --w) { const int c = s_bin[w]; s_bin[w] = pos; pos += c; } }      // heaviest first
-  __syncthreads();
-  const int first = n < n_cu * per_cu ? n : n_cu * per_cu;      // the ranks that go out in the first dispatch round
-  for (int a = tid; a < n; a += 1024) {
-    const int r = atomicAdd(&s_bin[work[a]], 1);                // rank among all alignments (ties in any order: placement only)
-    int b = r;
-    if (r < first) {
-      const int row = r / n_cu; int col = r - row * n_cu;
-      if (row & 1) { const int len = first - row * n_cu < n_cu ? first - row * n_cu : n_cu; col = len - 1 - col; }
-      b = row * n_cu + col;
-    }
-    order[b] = a;
+  if (!order) { if (tid == 0) work[a] = n_keep; return; }
+  if (tid == 0) {
+    // no fences (an agent-scope release writes the XCD's L2 back, a thousand times over): the count goes out as a RETURNING agent-scope exchange -- performed
+    // where all XCDs meet once its value is back -- and the ticket's increment depends on that value, so the ticket cannot be taken before the count is there
+    const int was = __hip_atomic_exchange(&work[a], n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int before = __hip_atomic_fetch_add(done_counter, 1u + (was == INT_MIN ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (counts are >= 0)
+    s_last = before + 1u == gridDim.x;
   }
+  __syncthreads();
+  if (!s_last) return;
+  // every other workgroup has published its count: this one deals the alignments out
+  balance_order(*reinterpret_cast<BalanceLds*>(smem), work, (int) gridDim.x, n_cu, 4, order, place, tid, kAlignBlock);
+  if (tid == 0) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next call
 }
 
 // ---- the latency kernel: one alignment per workgroup, tuned for calls that cannot fill the chip ------------------

@@ -2578,7 +2578,7 @@ def test_configs4_full_size_properties_1000_scans_vs_1m_map(ctx, po):
 
 def test_culling_and_placement_change_no_bit(ctx, po):
     """The exact culling of the moving cloud against the fixed canvas (chunk_may_matter), both forms of the culled stream (units /
-    row-major), and the balanced placement of a culled batch (k_cull_estimate / k_balance_order) change WHERE and WHETHER a map point is
+    row-major), and the balanced placement of a culled batch (k_cull_estimate / balance_order) change WHERE and WHETHER a map point is
     visited, never a result: poses, information matrices, iteration counts and every iteration's statistics are bit-identical to the
     plain stream -- on a batch that fills the chip, on a shuffled map (chunks without locality: nothing is culled), on a partial-FOV
     canvas, with the Cauchy kernel, and with a second slice."""
@@ -2591,7 +2591,8 @@ def test_culling_and_placement_change_no_bit(ctx, po):
         try:
             return al.compute_batch([fixed] * len(moving_sets), moving_sets, wl.x0, want_stats=True)
         finally:
-            ctx.set_option("cull", 1); ctx.set_option("balance", 1); ctx.set_option("cull_block", 0); ctx.set_option("proj_modes", 1)
+            ctx.set_option("cull", 1); ctx.set_option("balance", 1); ctx.set_option("cull_block", 0); ctx.set_option("proj_modes", 1); ctx.set_option("balance_notes", 1)
+            ctx.set_option("cull_est_um", 0); ctx.set_option("cull_est_urad", 40000)
     for name, mp in (("ordered", wl.map_points), ("shuffled", shuffled)):
         moving = api.CloudSet(ctx, mp)
         for tag, al in (("plain", _aligner(ctx)), ("cauchy 270 deg", _aligner(ctx, robustifier=api.RobustifierCauchy(0.05)))):
@@ -2599,7 +2600,9 @@ def test_culling_and_placement_change_no_bit(ctx, po):
                 al.param_slice_processors[0].param_finder.param_projector = api.PointNormal2fProjectorPolar(811, -0.75 * math.pi, 0.75 * math.pi, 0.3, 25.0)
             ref = run(al, [moving], cull=0)
             # (proj_modes 0: the shared instantiation instead of the one with the culled stream only)
-            for opts in (dict(cull=1), dict(cull=1, balance=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98), dict(cull=1, proj_modes=0)):
+            # (round 4: the placement groups workgroup ids by the CU the previous launch of the same shape ran them on -- the second and third plain
+            # runs below place by the first one's notes --, "balance_notes" 0: by the round-3 assumption; other margins in the work estimate)
+            for opts in (dict(cull=1), dict(cull=1), dict(cull=1, cull_est_um=60000, cull_est_urad=0), dict(cull=1, balance_notes=0), dict(cull=1, balance=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98), dict(cull=1, proj_modes=0)):
                 got = run(al, [moving], **opts)
                 assert np.array_equal(got.pose, ref.pose) and np.array_equal(got.information, ref.information), (name, tag, opts)
                 assert np.array_equal(got.status, ref.status) and np.array_equal(got.iterations, ref.iterations) and np.array_equal(got.stats, ref.stats), (name, tag, opts)
