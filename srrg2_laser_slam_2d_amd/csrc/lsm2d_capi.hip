@@ -63,6 +63,8 @@ struct lsm2d_context {
   int cull_margin_um = 10000;  // the translation margin in micrometres (10 mm) and
   int cull_margin_urad = 2000; // the rotation margin in microradians (2 mrad): tuning knobs, results do not depend on them
   int kd_wg_max_points = 16384; // KD-tree build: clouds of at most this many points are built by ONE launch, a workgroup per cloud walking the levels itself (k_kd_build_wg); 0: the level loop for all (A/B knob; same trees)
+  int kd_wide_min_points = 1024;   // KD-tree build of larger clouds: levels whose evenly split nodes would hold at least this many points run a workgroup per node (0: a wave per node always; A/B knob)
+  int kd_scan_max_clouds = 8;      // KD-tree build of a set of at most this many clouds of <= 1280 points each: the latency form with the working set in LDS (0: never; A/B knob)
   int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
   int kd_lds_nodes = 1536;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it; 512 / 1024 / 1536: 0.830 / 0.804 / 0.778 ms on configs[1] role B)
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
@@ -230,6 +232,8 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_cull_estimate, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_kd_build_scan<1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_kd_build_scan<0>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -291,6 +295,8 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "proj_modes")) { ctx->proj_modes = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_scan_max_clouds")) { if (value < 0) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_scan_max_clouds must be >= 0"); ctx->kd_scan_max_clouds = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_wide_min_points")) { if (value < 0) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_wide_min_points must be >= 0"); ctx->kd_wide_min_points = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_wg_max_points")) { if (value < 0 || value > (1 << 20)) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_wg_max_points: 0 .. 2^20"); ctx->kd_wg_max_points = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
@@ -316,6 +322,8 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "cull_margin_urad")) { *out_value = ctx->cull_margin_urad; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_wg_max_points")) { *out_value = ctx->kd_wg_max_points; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_scan_max_clouds")) { *out_value = ctx->kd_scan_max_clouds; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "kd_wide_min_points")) { *out_value = ctx->kd_wide_min_points; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_query_cull")) { *out_value = ctx->last_query_cull; return LSM2D_SUCCESS; }
   if (!strcmp(key, "last_kd_levels")) { *out_value = ctx->last_kd_levels; return LSM2D_SUCCESS; }
@@ -821,7 +829,7 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   KdBuildArgs B;
   B.start = cs->d_start; B.meta = kc.d_meta; B.nodes = kc.d_nodes; B.n_nodes = d_nn;
   B.leaf_xy = kc.d_leaf_xy; B.leaf_idx = kc.d_leaf_idx; B.max_leaf_range = max_leaf_range; B.min_leaf_points = min_leaf_points;
-  B.xy_in = nullptr; B.idx_in = nullptr; B.xy_out = nullptr; B.idx_out = nullptr; B.q_in = nullptr; B.q_out = nullptr; B.q_out_count = nullptr; B.n_items = 0;
+  B.xy_in = nullptr; B.idx_in = nullptr; B.xy_out = nullptr; B.idx_out = nullptr; B.q_in = nullptr; B.q_out = nullptr; B.q_out_count = nullptr; B.n_items = 0; B.n_items_ptr = nullptr; B.local_io = 0; B.io_base = 0; B.io_node_base = 0;
   // Scan-sized clouds: ONE launch builds every such tree, a workgroup per cloud walking its levels itself (k_kd_build_wg) -- no host round trip per level.
   // Map-sized clouds keep the level loop (a level of theirs fills the chip): their roots are queued here, the host learns every level's node count.
   const int wg_max = ctx->kd_wg_max_points;
@@ -829,7 +837,17 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   int n_small = 0;
   for (int c = 0; c < nc; ++c) { if (cs->h_count[c] <= wg_max) ++n_small; else roots.push_back(make_int4(c, 0, 0, cs->h_count[c])); }
   HIPCHK(ctx, hipMemcpyAsync(d_nn, ones.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
-  if (n_small > 0) {
+  // a handful of scan-sized clouds (the live tracker: one scan per reset()): the build with the cloud's working set in LDS (k_kd_build_scan)
+  int small_max = 0; for (int c = 0; c < nc; ++c) if (cs->h_count[c] <= wg_max && cs->h_count[c] > small_max) small_max = cs->h_count[c];
+  const int scan_cap = 1280;      // (58 KB of LDS: under the 64 KB a workgroup may ask for)
+  const bool scan_form = n_small > 0 && n_small == nc && nc <= ctx->kd_scan_max_clouds && small_max <= scan_cap && (int) kd_scan_lds_bytes(scan_cap) <= ctx->max_dyn_lds;
+  if (scan_form) {
+    KdBuildScanArgs W; W.B = B; W.count = cs->d_count; W.xy0 = cs->d_xy; W.nrm0 = cs->d_nrm; W.leaf_nrm = kc.d_leaf_nrm; W.meta_rw = kc.d_meta; W.cap = scan_cap;
+    if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_build_scan<1>, dim3((unsigned) nc), dim3(kKdScanThreads), kd_scan_lds_bytes(scan_cap), ctx->stream, W);
+    else hipLaunchKernelGGL(k_kd_build_scan<0>, dim3((unsigned) nc), dim3(kKdScanThreads), kd_scan_lds_bytes(scan_cap), ctx->stream, W);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  else if (n_small > 0) {
     KdBuildWgArgs W; W.B = B; W.count = cs->d_count; W.xy0 = cs->d_xy; W.nrm0 = cs->d_nrm;
     W.xy_buf[0] = xyb[0]; W.xy_buf[1] = xyb[1]; W.idx_buf[0] = ixb[0]; W.idx_buf[1] = ixb[1]; W.q_buf[0] = qb[0]; W.q_buf[1] = qb[1];
     W.leaf_nrm = kc.d_leaf_nrm; W.meta_rw = kc.d_meta; W.max_points = wg_max;
@@ -838,39 +856,63 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
     HIPCHK(ctx, hipGetLastError());
   }
   long long n_items = (long long) roots.size(); int level = 0;
+  std::vector<KdMeta> h_meta((size_t) nc);
   if (n_items > 0) {
     // (the big clouds' items use the queue buffers from position 0: the small clouds' stretches -- start / 2 + c -- are theirs alone only while the
     // workgroup build runs, and the stream orders the two)
     HIPCHK(ctx, hipMemcpyAsync(qb[0], roots.data(), sizeof(int4) * roots.size(), hipMemcpyHostToDevice, ctx->stream));
-    volatile int32_t* h_cnt = (volatile int32_t*) ctx->h_flag;
-    while (n_items > 0) {
-      if (level >= kMaxLevels) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "kdtree: deeper than 8192 levels");
-      B.xy_in = level == 0 ? cs->d_xy : xyb[level & 1]; B.idx_in = level == 0 ? nullptr : ixb[level & 1];
-      B.xy_out = xyb[(level + 1) & 1]; B.idx_out = ixb[(level + 1) & 1];
-      B.q_in = qb[level & 1]; B.q_out = qb[(level + 1) & 1]; B.q_out_count = d_cnt + level + 1; B.n_items = (int32_t) n_items;
-      const unsigned blocks = (unsigned) ((n_items + 3) / 4);
-      if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_level<1>, dim3(blocks), dim3(256), 0, ctx->stream, B);
-      else hipLaunchKernelGGL(k_kd_level<0>, dim3(blocks), dim3(256), 0, ctx->stream, B);
+    // Levels are launched back to back with an UPPER BOUND of their item count (a level cannot hold more items than roots x 2^level, nor more than
+    // there are groups of max(min_leaf_points, 2) points); the kernel reads the true count where the previous level left it, waves beyond it leave at
+    // once, a level with no items does nothing.  The host reads the counts after as many levels as a balanced tree would have, then every four levels.
+    long long big_points = 0; for (const int4& r : roots) big_points += r.w;
+    const long long per_item = min_leaf_points > 2 ? min_leaf_points : 2;
+    const long long cap_items = big_points / per_item + (long long) roots.size();
+    const int32_t n_roots = (int32_t) roots.size();
+    HIPCHK(ctx, hipMemcpyAsync(d_cnt, &n_roots, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));      // (pageable source: copied before the call returns)
+    int expect = 4; for (long long m = cap_items; m > 1; m >>= 1) ++expect;      // (a 100k-point map with 20-point leaves: 16 launches for its 15 levels)
+    std::vector<int32_t> h_counts;
+    bool more = true;
+    while (more) {
+      const int until = level == 0 ? expect : level + 4;
+      for (; level < until; ++level) {
+        if (level >= kMaxLevels) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "kdtree: deeper than 8192 levels");
+        B.xy_in = level == 0 ? cs->d_xy : xyb[level & 1]; B.idx_in = level == 0 ? nullptr : ixb[level & 1];
+        B.xy_out = xyb[(level + 1) & 1]; B.idx_out = ixb[(level + 1) & 1];
+        B.q_in = qb[level & 1]; B.q_out = qb[(level + 1) & 1]; B.q_out_count = d_cnt + level + 1; B.n_items = 0; B.n_items_ptr = d_cnt + level;
+        long long bound = level < 40 ? ((long long) n_roots << level) : cap_items; if (bound > cap_items) bound = cap_items;
+        // the top levels of a map-sized cloud -- while an evenly split node would still hold "kd_wide_min_points" points --: a workgroup per node (kd_node_wide)
+        const bool wide = ctx->kd_wide_min_points > 0 && level < 40 && (big_points / n_roots) >> level >= ctx->kd_wide_min_points;
+        if (wide) {
+          if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_level_wide<1>, dim3((unsigned) bound), dim3(256), 0, ctx->stream, B);
+          else hipLaunchKernelGGL(k_kd_level_wide<0>, dim3((unsigned) bound), dim3(256), 0, ctx->stream, B);
+        } else {
+          const unsigned blocks = (unsigned) ((bound + 3) / 4);
+          if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_level<1>, dim3(blocks), dim3(256), 0, ctx->stream, B);
+          else hipLaunchKernelGGL(k_kd_level<0>, dim3(blocks), dim3(256), 0, ctx->stream, B);
+        }
+      }
+      // the big clouds' sizes and leaf-order normals (the workgroup build wrote its own clouds') go out with every batch of levels -- they are right as soon
+      // as the last level has run, which is nearly always the first batch -- and the counts and the sizes come back with ONE wait
+      hipLaunchKernelGGL(k_kd_finish, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) d_nn, nc, kc.d_meta);
+      for (int c = 0; c < nc; ++c) {
+        if (cs->h_count[c] <= wg_max) continue;
+        int gx = (cs->h_count[c] + 255) / 256; if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(k_kd_permute_normals, dim3((unsigned) gx, 1u), dim3(256), 0, ctx->stream, (const float2*) cs->d_nrm,
+                           (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) kc.d_leaf_idx, kc.d_leaf_nrm, c);
+      }
       HIPCHK(ctx, hipGetLastError());
-      HIPCHK(ctx, hipMemcpyAsync((void*) h_cnt, d_cnt + level + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      h_counts.resize((size_t) level + 1);
+      HIPCHK(ctx, hipMemcpyAsync(h_counts.data(), d_cnt, sizeof(int32_t) * ((size_t) level + 1), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(h_meta.data(), kc.d_meta, sizeof(KdMeta) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, stream_sync(ctx));
-      n_items = h_cnt[0];
-      ++level;
+      more = h_counts[(size_t) level] > 0;
     }
-    // the big clouds' sizes and leaf-order normals (the workgroup build wrote its own clouds')
-    hipLaunchKernelGGL(k_kd_finish, dim3((unsigned) ((nc + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*) d_nn, nc, kc.d_meta);
-    for (int c = 0; c < nc; ++c) {
-      if (cs->h_count[c] <= wg_max) continue;
-      int gx = (cs->h_count[c] + 255) / 256; if (gx > 1024) gx = 1024;
-      hipLaunchKernelGGL(k_kd_permute_normals, dim3((unsigned) gx, 1u), dim3(256), 0, ctx->stream, (const float2*) cs->d_nrm,
-                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) kc.d_leaf_idx, kc.d_leaf_nrm, c);
-    }
-    HIPCHK(ctx, hipGetLastError());
+    level = 0; while ((size_t) level < h_counts.size() && h_counts[(size_t) level] > 0) ++level;      // levels that held items: what the level-by-level loop counted
   }
-  // what the host needs of the result: every tree's node count (and, of the workgroup builds, the depth): one read, one wait
-  std::vector<KdMeta> h_meta((size_t) nc);
-  HIPCHK(ctx, hipMemcpyAsync(h_meta.data(), kc.d_meta, sizeof(KdMeta) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, stream_sync(ctx));
+  else {      // what the host needs of the result: every tree's node count (and, of the workgroup builds, the depth): one read, one wait
+    HIPCHK(ctx, hipMemcpyAsync(h_meta.data(), kc.d_meta, sizeof(KdMeta) * (size_t) nc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, stream_sync(ctx));
+  }
   kc.levels = level; kc.total_nodes = 0; kc.max_nodes_per_cloud = 0;
   for (int c = 0; c < nc; ++c) {
     const int nn = h_meta[(size_t) c].n_nodes;

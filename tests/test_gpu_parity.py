@@ -2299,13 +2299,15 @@ def test_kdtree_finder_bit_exact_both_roles(ctx, po, n_map):
         for role, (fixed, moving, pose) in enumerate(((scan, wl.map_points, x), (wl.map_points, scan, xb))):     # role A (tracker wiring), role B (BASELINE wording)
             want = po.find(osp, fixed, moving, pose)
             assert len(want) > 300
-            for chain in (1, 0):
-                ctx.set_option("kd_chain", chain)
-                f = _kd_finder(ctx, 0.5, leaf_range, leaf_points)
-                f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
-                got = f.compute()
-                assert np.array_equal(got, want), (n_map, role, leaf_range, chain, len(got), len(want))
-            ctx.set_option("kd_chain", 1)
+            for chain, wide in ((1, 4096), (0, 4096), (1, 0)):      # (round 4: a workgroup per node on the top levels of a map-sized cloud, or a wave per node throughout)
+                ctx.set_option("kd_chain", chain); ctx.set_option("kd_wide_min_points", wide)
+                try:
+                    f = _kd_finder(ctx, 0.5, leaf_range, leaf_points)
+                    f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
+                    got = f.compute()
+                finally:
+                    ctx.set_option("kd_chain", 1); ctx.set_option("kd_wide_min_points", 4096)
+                assert np.array_equal(got, want), (n_map, role, leaf_range, chain, wide, len(got), len(want))
             # the tree is approximate by construction: it must NOT be the exact search (else this test would not tell the two apart)
             ex = po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.5, normal_cos=0.8), fixed, moving, pose)
             assert not np.array_equal(ex, want)
@@ -2948,8 +2950,10 @@ def test_kdtree_single_launch_build_equals_the_level_loop(ctx, po):
     x0 = np.float32([0.02, -0.01, 0.01])
     res = {}
     try:
-        for wg in (16384, 0, 100):              # 100: the scans go through the level loop, the tiny clouds through the workgroup build (a mixed set)
-            ctx.set_option("kd_wg_max_points", wg)
+        # 100: the scans go through the level loop, the tiny clouds through the workgroup build (a mixed set); the level loop with a WORKGROUP per node
+        # (kd_node_wide: "kd_wide_min_points", by default only the top levels of a map-sized cloud) on every level that holds 64 / 1000 points per node
+        for wg, wide in ((16384, 4096), (0, 0), (100, 0), (0, 64), (100, 1000)):
+            ctx.set_option("kd_wg_max_points", wg); ctx.set_option("kd_wide_min_points", wide)
             cs = api.CloudSet(ctx, allp, offs_all)
             out = []
             for lr, lp in ((1e-2, 20), (0.05, 7)):
@@ -2958,17 +2962,49 @@ def test_kdtree_single_launch_build_equals_the_level_loop(ctx, po):
                     f.setFixed(cs, ci); f.setMoving(m[::7]); f.setLocalMapInSensor(x0)
                     out.append(f.compute())
                 out.append(np.array([[ctx.get_option("last_kd_levels"), ctx.get_option("last_kd_nodes")]]))
-            res[wg] = out
+            res[(wg, wide)] = out
             cs.close()
     finally:
-        ctx.set_option("kd_wg_max_points", 16384)
-    for wg in (0, 100):
-        assert len(res[wg]) == len(res[16384])
-        for a, b in zip(res[16384], res[wg]):
-            assert np.array_equal(a, b), wg
+        ctx.set_option("kd_wg_max_points", 16384); ctx.set_option("kd_wide_min_points", 4096)
+    for key in res:
+        assert len(res[key]) == len(res[(16384, 4096)])
+        for a, b in zip(res[(16384, 4096)], res[key]):
+            assert np.array_equal(a, b), key
     k = 0
     for lr, lp in ((1e-2, 20), (0.05, 7)):
         for ci in (0, 5, 23, 24, 27, 29, len(clouds) - 1):
             want = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, normal_cos=0.5, kd_max_leaf_range=lr, kd_min_leaf_points=lp), clouds[ci], m[::7], x0)
-            assert np.array_equal(res[16384][k + ci], want), (lr, lp, ci)
+            assert np.array_equal(res[(16384, 4096)][k + ci], want), (lr, lp, ci)
         k += len(clouds) + 1
+    # the LATENCY form (k_kd_build_scan: a set of at most "kd_scan_max_clouds" clouds of <= 1280 points, working set in LDS, sixteen waves, groups of four
+    # waves on the levels with few nodes): one scan; eight clouds with the degenerate ones among them; both forms of the chains -- against the workgroup
+    # build ("kd_scan_max_clouds" 0) and the oracle
+    small_sets = ([clouds[0]], [clouds[3][:1280]], [clouds[1], clouds[2]] + degenerate[:6], [degenerate[6], clouds[7][:700], clouds[8][:65], clouds[9][:64], clouds[10][:129]])
+    try:
+        for cl in small_sets:
+            o = np.concatenate([[0], np.cumsum([len(q) for q in cl])]).astype(np.int32)
+            ap_ = np.concatenate(cl, 0)
+            got = {}
+            for scan_max, chain in ((8, 1), (8, 0), (0, 1)):
+                ctx.set_option("kd_scan_max_clouds", scan_max); ctx.set_option("kd_chain", chain)
+                cs = api.CloudSet(ctx, ap_, o)
+                out = []
+                for lr, lp in ((1e-2, 20), (0.05, 7)):
+                    f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=0.5, max_leaf_range=lr, min_leaf_points=lp, search="kdtree")
+                    for ci in range(len(cl)):
+                        f.setFixed(cs, ci); f.setMoving(m[::7]); f.setLocalMapInSensor(x0)
+                        out.append(f.compute())
+                    out.append(np.array([[ctx.get_option("last_kd_levels"), ctx.get_option("last_kd_nodes")]]))
+                got[(scan_max, chain)] = out
+                cs.close()
+            for key in got:
+                for a, b in zip(got[(0, 1)], got[key]):
+                    assert np.array_equal(a, b), (key, [len(q) for q in cl])
+            k = 0
+            for lr, lp in ((1e-2, 20), (0.05, 7)):
+                for ci in range(len(cl)):
+                    want = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, normal_cos=0.5, kd_max_leaf_range=lr, kd_min_leaf_points=lp), cl[ci], m[::7], x0)
+                    assert np.array_equal(got[(8, 1)][k + ci], want), (lr, lp, ci, len(cl[ci]))
+                k += len(cl) + 1
+    finally:
+        ctx.set_option("kd_scan_max_clouds", 8); ctx.set_option("kd_chain", 1)

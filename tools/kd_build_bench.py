@@ -18,8 +18,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--map-points", type=int, nargs="*", default=[10000, 100000, 1000000])
     ap.add_argument("--scans", type=int, default=1000)
+    ap.add_argument("--wide-min-points", type=int, default=-1, help="kd_wide_min_points (levels of a map-sized cloud built by a workgroup per node); -1: the default")
     args = ap.parse_args()
     ctx = api.Context(0)
+    if args.wide_min_points >= 0:
+        ctx.set_option("kd_wide_min_points", args.wide_min_points)
     wl = synth.make_workload(args.scans, 1000, seed=0)
     q = wl.scan_points[: wl.scan_offsets[1]]
     # the live tracker's case: ONE scan's tree per call (a fresh cloud every time, as CorrespondenceFinderKDTree2D::reset() sees it), with the
@@ -27,7 +30,7 @@ def main():
     for wg in (16384, 0):
         ctx.set_option("kd_wg_max_points", wg)
         ts = []
-        for rep in range(30):
+        for rep in range(min(30, args.scans)):
             sc = wl.scan_points[wl.scan_offsets[rep]:wl.scan_offsets[rep + 1]]
             cs = api.CloudSet(ctx, sc)
             f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.5, search="kdtree")
