@@ -48,8 +48,9 @@ def algorithmic_bytes_per_alignment(role: str, finder: str, n_map: int, n_scan_m
     A/projective  16*N_m (stream moving) + 48*Bins (canvas key write+read, fixed-cell read, winner gather) + 64; once 16*N_s
     A/nn          16*N_m + 28*C (C counted at N_m) + 64; once 16*N_s
     B/nn          16*N_s + N_s*(24*d + 8*L + 8) + 64 with L = 20, d = ceil(log2(N_m/L))"""
-    if role == "A" and finder == "projective":
-        return iterations * (16.0 * n_map + 48.0 * bins + 64.0) + 16.0 * n_scan_mean
+    if finder == "projective":      # the same row with the clouds' roles swapped (role B: the scan is streamed every iteration, the map projected once)
+        n_moving, n_fixed = (n_map, n_scan_mean) if role == "A" else (n_scan_mean, n_map)
+        return iterations * (16.0 * n_moving + 48.0 * bins + 64.0) + 16.0 * n_fixed
     if role == "A" and finder == "nn":
         return iterations * (16.0 * n_map + 28.0 * n_map + 64.0) + 16.0 * n_scan_mean
     if finder in ("nn", "kdtree"):      # SURVEY 8(d) row "B / NN": a descent of d nodes of 24 B + a leaf of L points of 8 B + the matched fixed point, per query

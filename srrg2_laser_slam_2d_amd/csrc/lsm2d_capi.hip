@@ -51,6 +51,9 @@ struct lsm2d_context {
   int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / balance_order); 0: workgroup b = alignment b
   int n_cu = 0;                // compute units of the device (hipDeviceProp_t.multiProcessorCount)
   int cull_est_um = 0, cull_est_urad = 40000;      // margins of the work estimate's chunk test ("cull_est_um", "cull_est_urad"; placement only)
+  int two_stage = 0;           // 1: ... in TWO launches: iteration 0 first (k_first_iteration), the rest placed by the length of iteration 1's unit lists.  Measured on configs[1]: the second
+                               // launch 0.698 ms with a tail of 7 % instead of 10, but the first costs 95 us (every workgroup in the same phase at the same time: nothing overlaps) and the ordering 16:
+                               // 0.861 vs 0.836 ms per step.  Off; kept as an A/B knob with its bit-identity test
   int balance_notes = 1;       // ... group the workgroup ids by the CU the previous launch of the same shape ran them on (0: assume b, b + n_cu, ...; A/B knob)
   int32_t* d_wg_place = nullptr; unsigned long long wg_place_shape = 0;      // the notes (one int per workgroup) and the launch shape they belong to
   int proj_modes = 1;          // projective batches against map-sized clouds: the instantiation with the culled stream only (0: the shared one; A/B knob)
@@ -64,6 +67,7 @@ struct lsm2d_context {
   int cull_margin_urad = 2000; // the rotation margin in microradians (2 mrad): tuning knobs, results do not depend on them
   int kd_wg_max_points = 16384; // KD-tree build: clouds of at most this many points are built by ONE launch, a workgroup per cloud walking the levels itself (k_kd_build_wg); 0: the level loop for all (A/B knob; same trees)
   int kd_wide_min_points = 1024;   // KD-tree build of larger clouds: levels whose evenly split nodes would hold at least this many points run a workgroup per node (0: a wave per node always; A/B knob)
+  int grid_big_cells_x10 = 50;     // exact NN grid over a map-sized cloud: cells per side = this / 10 x sqrt(points); role B / NN on configs[1]: 2.0 2.08 ms, 3.0 1.85, 4.0 1.67, 5.0 1.66, 6.0 (rounds 2-3) 1.72, 8.0 1.73 (tuning knob)
   int kd_scan_max_clouds = 8;      // KD-tree build of a set of at most this many clouds of <= 1280 points each: the latency form with the working set in LDS (0: never; A/B knob)
   int kd_chain = 1;            // KD-tree build: how a node's sequential sums run -- 1 systolic DPP pass (default), 0 one v_readlane + add per value (same bits: tests)
   int kd_lds_nodes = 1536;     // KD-tree finder inside k_align: nodes of the fixed cloud's tree staged in LDS (0: none; results do not depend on it; 512 / 1024 / 1536: 0.830 / 0.804 / 0.778 ms on configs[1] role B)
@@ -232,6 +236,8 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_cull_estimate, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_first_iteration, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_balance_only, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_kd_build_scan<1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_kd_build_scan<0>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -285,6 +291,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_est_um")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_est_um out of range"); ctx->cull_est_um = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_est_urad")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_est_urad out of range"); ctx->cull_est_urad = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "two_stage")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "two_stage must be 0 or 1"); ctx->two_stage = (int) value; ctx->wg_place_shape = 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance_notes")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance_notes must be 0 or 1"); ctx->balance_notes = (int) value; ctx->wg_place_shape = 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_keep")) { ctx->cull_keep = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_margin_um")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_margin_um: 0 .. 1e6"); ctx->cull_margin_um = (int) value; return LSM2D_SUCCESS; }
@@ -295,6 +302,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "proj_modes")) { ctx->proj_modes = value != 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "grid_big_cells_x10")) { if (value < 5 || value > 400) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_cells_x10: 5 .. 400"); ctx->grid_big_cells_x10 = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_scan_max_clouds")) { if (value < 0) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_scan_max_clouds must be >= 0"); ctx->kd_scan_max_clouds = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_wide_min_points")) { if (value < 0) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_wide_min_points must be >= 0"); ctx->kd_wide_min_points = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_wg_max_points")) { if (value < 0 || value > (1 << 20)) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_wg_max_points: 0 .. 2^20"); ctx->kd_wg_max_points = (int) value; return LSM2D_SUCCESS; }
@@ -316,12 +324,14 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_est_um")) { *out_value = ctx->cull_est_um; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_est_urad")) { *out_value = ctx->cull_est_urad; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "two_stage")) { *out_value = ctx->two_stage; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance_notes")) { *out_value = ctx->balance_notes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_keep")) { *out_value = ctx->cull_keep; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_margin_um")) { *out_value = ctx->cull_margin_um; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_margin_urad")) { *out_value = ctx->cull_margin_urad; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_wg_max_points")) { *out_value = ctx->kd_wg_max_points; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "grid_big_cells_x10")) { *out_value = ctx->grid_big_cells_x10; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_scan_max_clouds")) { *out_value = ctx->kd_scan_max_clouds; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_wide_min_points")) { *out_value = ctx->kd_wide_min_points; return LSM2D_SUCCESS; }
   if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
@@ -723,7 +733,7 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
     // cells per side: ~3 sqrt(n) for scan-sized clouds (their queries mostly find empty blocks; finer cells only add block
     // levels), ~6 sqrt(n) for map-sized ones (dense walls: the 3x3 block of a converged query holds 3x fewer candidates).
     // Measured on configs[1], role B: 3 sqrt(n) 3.12 ms, 6 sqrt(n) 2.95 ms, 12 sqrt(n) 3.24 ms (cell table out of L2).
-    int cap = (int) ceil((cs->h_count[c] >= 16384 ? 6.0 : 3.0) * sqrt((double) cs->h_count[c]));
+    int cap = (int) ceil((cs->h_count[c] >= 16384 ? 0.1 * (double) ctx->grid_big_cells_x10 : 3.0) * sqrt((double) cs->h_count[c]));
     cap = cap < 16 ? 16 : (cap > 2048 ? 2048 : cap);       // 4096 buys 13 % on a 1M-point map for 4x the cell table: not taken
     gcap[c] = cap; cell_base[c] = (int32_t) cells; cells += (int64_t) cap * cap + 1;
     if (cells > 0x7fffffff) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "grid: too many cells");
@@ -1695,8 +1705,10 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   // in-kernel clock stamps of ~32 workgroups spread over the grid (timed k_align launches only)
   const int clock_stride = ctx->clock_stride > 0 ? ctx->clock_stride : (n / 32 > 1 ? n / 32 : 1), n_clock = (n + clock_stride - 1) / clock_stride;
   const size_t o_clock = ctx->kernel_timing ? take(sizeof(unsigned long long) * 4 * (size_t) n_clock) : 0;
+  const size_t out_bytes = off - o_pose;      // what travels back to the host
   const size_t o_work = take(sizeof(int32_t) * (size_t) n), o_order = take(sizeof(int32_t) * (size_t) n);      // balanced placement (device only)
-  const size_t total_bytes = off, out_bytes = total_bytes - o_pose;
+  const size_t o_resume = take(sizeof(ResumeDev) * (size_t) n);                                                // the state between the two launches of a batch (device only)
+  const size_t total_bytes = off;
   int rc = ensure_scratch(ctx, total_bytes); if (rc) return rc;
   rc = ensure_stage(ctx, total_bytes); if (rc) return rc;
   char* hs = (char*) ctx->h_stage; char* ds = (char*) ctx->d_scratch;
@@ -1947,7 +1959,27 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     memcpy(out_work, hs + o_work, sizeof(int32_t) * (size_t) n);
     return LSM2D_SUCCESS;
   }
-  if (!use_split && !use_pair && !zero_copy && A.cull && ctx->balance && n > 256 && has_proj) {
+  A.stage = 0; A.stage_split = 0; A.resume = nullptr; A.stage_work = nullptr;
+  // a culled batch of about one dispatch round, two launches: iteration 0 anywhere (k_first_iteration), then the rest placed by what iteration 1's lists hold
+  const bool two_stage = !use_split && !use_pair && !zero_copy && A.cull && ctx->balance && ctx->two_stage && n > 256 && n <= 1024 && proj_culled_for_all &&
+                         has_proj && !has_nn && !has_dist && !has_kd && ap->max_iterations >= 4;
+  if (two_stage) {
+    int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work); int32_t* d_order = (int32_t*) ((char*) ctx->d_scratch + o_order);
+    const unsigned long long shape = ((unsigned long long) (unsigned) n << 32) ^ ((unsigned long long) lds << 8) ^ 6ull;
+    if (!ctx->d_wg_place) {
+      HIPCHK(ctx, hipMalloc(&ctx->d_wg_place, sizeof(int32_t) * 1025)); ctx->wg_place_shape = 0;
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_wg_place, 0, sizeof(int32_t) * 1025, ctx->stream));
+    }
+    const bool notes = ctx->balance_notes && ctx->wg_place_shape == shape;
+    A.stage = 1; A.stage_split = 1; A.resume = (ResumeDev*) ((char*) ctx->d_scratch + o_resume); A.stage_work = d_work;
+    hipLaunchKernelGGL(k_first_iteration, dim3((unsigned) n), dim3(kAlignBlock), lds, ctx->stream, A);
+    hipLaunchKernelGGL(k_balance_only, dim3(1), dim3(kAlignBlock), sizeof(BalanceLds), ctx->stream, (const int32_t*) d_work, n, ctx->n_cu, d_order,
+                       notes ? (const int32_t*) ctx->d_wg_place : (const int32_t*) nullptr);
+    HIPCHK(ctx, hipGetLastError());
+    A.stage = 2; A.order = d_order;
+    if (ctx->balance_notes) { A.wg_place = ctx->d_wg_place; ctx->wg_place_shape = shape; }
+  }
+  else if (!use_split && !use_pair && !zero_copy && A.cull && ctx->balance && n > 256 && has_proj) {
     int bs = -1;
     for (int s = 0; s < ns && bs < 0; ++s) if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].moving.lane_xy && A.s[s].moving.lane_bounds) bs = s;
     if (bs >= 0) {

@@ -2593,7 +2593,7 @@ def test_culling_and_placement_change_no_bit(ctx, po):
         try:
             return al.compute_batch([fixed] * len(moving_sets), moving_sets, wl.x0, want_stats=True)
         finally:
-            ctx.set_option("cull", 1); ctx.set_option("balance", 1); ctx.set_option("cull_block", 0); ctx.set_option("proj_modes", 1); ctx.set_option("balance_notes", 1)
+            ctx.set_option("cull", 1); ctx.set_option("balance", 1); ctx.set_option("cull_block", 0); ctx.set_option("proj_modes", 1); ctx.set_option("balance_notes", 1); ctx.set_option("two_stage", 0)
             ctx.set_option("cull_est_um", 0); ctx.set_option("cull_est_urad", 40000)
     for name, mp in (("ordered", wl.map_points), ("shuffled", shuffled)):
         moving = api.CloudSet(ctx, mp)
@@ -2604,7 +2604,7 @@ def test_culling_and_placement_change_no_bit(ctx, po):
             # (proj_modes 0: the shared instantiation instead of the one with the culled stream only)
             # (round 4: the placement groups workgroup ids by the CU the previous launch of the same shape ran them on -- the second and third plain
             # runs below place by the first one's notes --, "balance_notes" 0: by the round-3 assumption; other margins in the work estimate)
-            for opts in (dict(cull=1), dict(cull=1), dict(cull=1, cull_est_um=60000, cull_est_urad=0), dict(cull=1, balance_notes=0), dict(cull=1, balance=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98), dict(cull=1, proj_modes=0)):
+            for opts in (dict(cull=1), dict(cull=1), dict(cull=1, two_stage=1), dict(cull=1, cull_est_um=60000, cull_est_urad=0), dict(cull=1, balance_notes=0), dict(cull=1, two_stage=1, balance_notes=0), dict(cull=1, balance=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98), dict(cull=1, proj_modes=0)):
                 got = run(al, [moving], **opts)
                 assert np.array_equal(got.pose, ref.pose) and np.array_equal(got.information, ref.information), (name, tag, opts)
                 assert np.array_equal(got.status, ref.status) and np.array_equal(got.iterations, ref.iterations) and np.array_equal(got.stats, ref.stats), (name, tag, opts)
@@ -2652,6 +2652,48 @@ def test_culling_and_placement_change_no_bit(ctx, po):
                 finally:
                     ctx.set_option("nn_lds_only", 1); ctx.set_option("kd_modes", 1)
                 assert np.array_equal(s0.pose, c.pose, equal_nan=True) and np.array_equal(s0.information, c.information, equal_nan=True) and np.array_equal(s0.stats, c.stats), name
+
+
+def test_two_launches_for_one_batch_change_no_bit(ctx, po):
+    """Round 4 (late): a culled batch of about one dispatch round CAN run as two launches ("two_stage" 1; measured, slower, off by default: DESIGN
+    App. A) -- iteration 0 of every alignment anywhere on the chip (k_first_iteration), then the remaining iterations placed by the length of
+    iteration 1's unit lists -- with pose, information matrix, phase and termination state carried in memory between them.  Against the single
+    launch, bit for bit: poses, information matrices, statuses,
+    iteration counts, every iteration's statistics and digest -- with the termination criterion, the inlier-only runs, the Cauchy kernel, two slices, the
+    shortest loop that is split at all (4 iterations), start poses that fail in iteration 0 (they finish in the first launch) -- and the oracle agrees."""
+    wl = synth.make_workload(300, 60000, seed=21)
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    x0 = wl.x0.copy(); x0[::11, 0] += 250.0; x0[5::17, 2] += 1.2      # some alignments start beyond the map / badly rotated
+    cases = []
+    al = _aligner(ctx, its=20); cases.append(("plain 20", al, 1, dict()))
+    al = _aligner(ctx, its=4); cases.append(("4 iterations", al, 1, dict()))
+    al = _aligner(ctx, its=12, robustifier=api.RobustifierCauchy(0.02)); al.param_termination_chi_epsilon = 1e-3
+    al.param_enable_inlier_only_runs = True; al.param_keep_only_inlier_correspondences = True
+    cases.append(("Cauchy + epsilon + inlier runs", al, 1, dict(robustifier=po.ROBUST_CAUCHY, chi_threshold=0.02)))
+    al = _aligner(ctx, its=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector(721), 0.3, 0.9), min_num_correspondences=10))
+    cases.append(("two slices", al, 2, dict()))
+    for name, al, ns, okw in cases:
+        got = {}
+        for ts in (1, 0):
+            ctx.set_option("two_stage", ts)
+            try:
+                got[ts] = al.compute_batch([fixed] * ns, [moving] * ns, x0, want_stats=True)
+                if ts == 1:
+                    assert ctx.get_option("last_align_path") == 1
+            finally:
+                ctx.set_option("two_stage", 0)
+        a, b = got[1], got[0]
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.information, b.information), name
+        assert np.array_equal(a.status, b.status) and np.array_equal(a.iterations, b.iterations) and np.array_equal(a.stats, b.stats), name
+        assert (a.status != 0).any() and (a.status == 0).mean() > 0.6, (name, (a.status == 0).mean())
+        if name in ("plain 20", "Cauchy + epsilon + inlier runs"):
+            ap_ = po.aligner_params(al.param_max_iterations, device_order=True, termination_chi_epsilon=al.param_termination_chi_epsilon,
+                                    enable_inlier_only_runs=al.param_enable_inlier_only_runs, keep_only_inlier_correspondences=al.param_keep_only_inlier_correspondences)
+            for i in (0, 5, 11, 150, 299):
+                sc = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
+                rt = po.align(ap_, [po.slice_params(**okw)], [sc], [wl.map_points], x0[i])
+                _assert_bitwise_equal_to_device_order_oracle(a, i, rt, (name, i))
 
 
 def test_point_query_finders_against_the_reference_arithmetic_mode(ctx, po):
