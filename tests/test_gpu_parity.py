@@ -2654,6 +2654,24 @@ def test_culling_and_placement_change_no_bit(ctx, po):
                 assert np.array_equal(s0.pose, c.pose, equal_nan=True) and np.array_equal(s0.information, c.information, equal_nan=True) and np.array_equal(s0.stats, c.stats), name
 
 
+def test_prepared_batch_equals_compute_batch(ctx, small_workload):
+    """MultiAligner2D.prepare_batch: the descriptor and the result arrays built once, lsm2d_align_batch called again and again (what bench.py times) --
+    the same results as compute_batch, call after call, also after new start poses were written in place."""
+    wl = small_workload
+    al = _aligner(ctx)
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    want = al.compute_batch([fixed], [moving], wl.x0, want_stats=True)
+    prep = al.prepare_batch([fixed], [moving], wl.x0, want_stats=True)
+    for _ in range(3):
+        got = prep.run()
+        assert np.array_equal(got.pose, want.pose) and np.array_equal(got.information, want.information) and np.array_equal(got.status, want.status)
+        assert np.array_equal(got.iterations, want.iterations) and np.array_equal(got.stats, want.stats)
+    x1 = wl.x0.copy(); x1[:, 0] += 0.01
+    prep.set_init_poses(x1)
+    got = prep.run(); want1 = al.compute_batch([fixed], [moving], x1, want_stats=True)
+    assert np.array_equal(got.pose, want1.pose) and np.array_equal(got.stats, want1.stats) and not np.array_equal(want1.pose, want.pose)
+
+
 def test_two_launches_for_one_batch_change_no_bit(ctx, po):
     """Round 4 (late): a culled batch of about one dispatch round CAN run as two launches ("two_stage" 1; measured, slower, off by default: DESIGN
     App. A) -- iteration 0 of every alignment anywhere on the chip (k_first_iteration), then the remaining iterations placed by the length of
