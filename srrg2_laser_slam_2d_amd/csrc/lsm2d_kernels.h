@@ -1246,6 +1246,7 @@ struct AlignArgs {
   int32_t stage, stage_split;
   struct ResumeDev* resume;                 // [n]
   int32_t* stage_work;                      // [n] 0 .. 512: the units the alignment will stream per iteration (0: it finished in the first stage)
+  float cull_mt2;                           // cull_mt squared (host)
   int32_t* wg_place;                        // [grid] or nullptr: every workgroup notes the CU it ran on (place_key) for the next call's placement
   int32_t cull_block;                       // steps per unit of the culled stream (0: automatic; tuning knob)
   int32_t cull;                             // 1: projective slices drop the chunks of the moving cloud that cannot yield a pair (chunk_may_matter), results unchanged
@@ -1488,7 +1489,8 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
       const Iso N = s_iso[s], L = s_list_iso[s];
       const float cd = N.c * L.c + N.s * L.s, sd = N.s * L.c - N.c * L.s;
       const float dx = N.tx - (cd * L.tx - sd * L.ty), dy = N.ty - (sd * L.tx + cd * L.ty);
-      s_rebuild[s] = (A.cull_keep && cd > 0.5f && __builtin_fabsf(sd) <= A.cull_mth && dx * dx + dy * dy <= A.cull_mt * A.cull_mt) ? zi : 1;
+      s_rebuild[s] = (A.cull_keep && cd > 0.5f && __builtin_fabsf(sd) <= A.cull_mth && dx * dx + dy * dy <= A.cull_mt2) ? zi : 1;      // (the square comes with the arguments: formed here it was a
+      // loop invariant in a vector register, kept -- and spilled -- across the whole iteration for thread 0's sake)
     }
     if (A.out_last_pose) { A.out_last_pose[3 * a + 0] = s_pose[0]; A.out_last_pose[3 * a + 1] = s_pose[1]; A.out_last_pose[3 * a + 2] = s_pose[2]; }
   };
