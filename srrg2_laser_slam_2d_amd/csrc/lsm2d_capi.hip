@@ -1871,7 +1871,8 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   bool proj_culled_for_all = has_proj && !has_nn && !has_dist && !has_kd && A.cull == 1 && ctx->proj_modes && ctx->cull_block == 0;
   for (int s = 0; s < ns && proj_culled_for_all; ++s)
     proj_culled_for_all = A.s[s].moving.lane_xy != nullptr && A.s[s].moving.lane_bounds != nullptr && A.s[s].moving.block_bounds != nullptr;
-  A.units_off = 0; A.cull_keep = ctx->cull_keep; A.cull_mt = 1e-6f * (float) ctx->cull_margin_um; A.cull_mth = 1e-6f * (float) ctx->cull_margin_urad; A.cull_mt2 = A.cull_mt * A.cull_mt;
+  A.units_off = 0; A.cull_keep = ctx->cull_keep;
+  A.cull_mt = ctx->cull_keep ? 1e-6f * (float) ctx->cull_margin_um : 0.0f; A.cull_mth = ctx->cull_keep ? 1e-6f * (float) ctx->cull_margin_urad : 0.0f; A.cull_mt2 = A.cull_mt * A.cull_mt;      // (lists rebuilt every iteration: no margins)
   if (proj_culled_for_all) {
     const size_t at = (lds + 15) & ~(size_t) 15, need = sizeof(uint16_t) * (size_t) ns * kCullBlocks * kAlignBlock;
     if ((int) (at + need) + 2048 <= ctx->max_dyn_lds && at + need + 2048 <= 40 * 1024) { A.units_off = (int32_t) at; lds = at + need; }      // four workgroups per CU must still fit (160 KB)

@@ -1377,6 +1377,7 @@ LSM2D_DEV int place_key() {
 }
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0, bool kFirstStage = false>
 LSM2D_DEV void align_body(const AlignArgs& A) {
+  __builtin_assume(A.n_slices >= 1 && A.n_slices <= kMaxSlices);      // (the host refuses anything else: the slice loops need no guard -- which, as a flag, was kept in a vector register and spilled)
   constexpr bool kNNGlobal = kNNMode == 1, kNNLds = kNNMode == 2;
   // the same for a pure KD-tree batch: 3 = every alignment's whole tree, leaf arrays included, is in LDS (the tracker's wiring: a tree per scan); 4 = only the
   // top of the tree is (the map is the fixed cloud): the other form of the descent and of the leaf scan is compiled out
@@ -1613,7 +1614,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
   __syncthreads();
 
   int it = __builtin_amdgcn_readfirstlane(s_it0);
-  const int it_cap = A.inlier_runs ? 2 * A.max_it : A.max_it;
+  const int it_cap = __builtin_amdgcn_readfirstlane(A.inlier_runs ? 2 * A.max_it : A.max_it);      // (a scalar: as a select and a shift it lived in a vector register, spilled for the loop's back edge)
   const bool want_dig = A.out_stats != nullptr;      // the digest leaves the kernel through the statistics only
   for (; it < it_cap; ++it) {
     const bool lists_only = kFirstStage && it == A.stage_split;      // the first of two launches enters this iteration for the LENGTH of its unit lists alone
@@ -1645,14 +1646,14 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
             const int B = cull_block_steps(Tm), nb = (Tm + B - 1) / B;
             if (__builtin_amdgcn_readfirstlane(s_rebuild[s]) || lists_only) {      // (lists_only: the list the second launch will build first, whatever the kept one covers)
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-              const float m_t = A.cull_keep ? A.cull_mt : 0.0f, m_th = A.cull_keep ? A.cull_mth : 0.0f;
+              const float m_t = A.cull_mt, m_th = A.cull_mth;      // (0 when the lists are not kept: the host sees to that -- a select made here was a vector register held across the iteration)
               const unsigned long long bb = reinterpret_cast<unsigned long long>(S.moving.lane_bounds + (size_t) mc * kAlignBlock);
               float4* bbase = reinterpret_cast<float4*>(((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (bb >> 32)) << 32) |
                                                         (unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) bb));
               const u32x4 bw = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(bbase, (short) 0, kAlignBlock * 16, 0x00020000), tid * 16, 0, 0);
               const bool keep = chunk_may_matter(T, S.proj, make_float4(__uint_as_float(bw.x), __uint_as_float(bw.y), __uint_as_float(bw.z), 0.0f), fcan + S.fcan_offset, S.point_distance, m_t, m_th);
               const u64 bal = __ballot(keep);
-              if (lane == 0) s_wcnt[wave] = __popcll(bal);
+              { int wv = tid >> 6; asm volatile("" : "+v"(wv)); if (lane == 0) s_wcnt[wv] = __popcll(bal); }      // (the address made here, not in front of the iteration loop and kept)
               __syncthreads();
               int before = 0, n_surv = 0;
 #pragma unroll
@@ -1899,8 +1900,9 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
         const int n_corr = __builtin_amdgcn_readlane(vi, 13);
         if (tid == 0) s_n_corr += n_corr;
         if (n_corr > S.min_corr) {     // slices with #pairs <= min_num_correspondences are skipped
-          if (tid < 11) s_sum[tid] += v;
-          else if (tid < 13) s_sum[tid] = __int_as_float(__float_as_int(s_sum[tid]) + vi);
+          int ts = tid; asm volatile("" : "+v"(ts));      // (s_sum's address for this lane made here: hoisted, it was spilled across the iteration)
+          if (tid < 11) s_sum[ts] += v;
+          else if (tid < 13) s_sum[ts] = __int_as_float(__float_as_int(s_sum[ts]) + vi);
           if (tid == 0) ++s_active;
         }
       }
@@ -1946,7 +1948,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
         else {
           bool phase_over = it + 1 >= s_phase_end;
           if (A.term_eps > 0.0f) {      // the aligner's termination criterion: relative decay of the total chi^2 (lsm2d.h), afresh in every phase
-            const float chi_now = last.chi_in + last.chi_out;
+            const float chi_now = s_sum[9] + s_sum[10];      // (= last.chi_in + last.chi_out, read again: kept in registers across the solve they were spilled)
             if (it > s_phase_start && __builtin_fabsf(s_prev_chi - chi_now) < A.term_eps * chi_now) phase_over = true;      // status stays RUNNING: decided below as after max_iterations
             s_prev_chi = chi_now;
           }
