@@ -51,6 +51,7 @@ struct lsm2d_context {
   int balance = 1;             // culled batches of more than 256 alignments: place them on the chip by estimated work (k_cull_estimate / balance_order); 0: workgroup b = alignment b
   int n_cu = 0;                // compute units of the device (hipDeviceProp_t.multiProcessorCount)
   int cull_est_um = 0, cull_est_urad = 40000;      // margins of the work estimate's chunk test ("cull_est_um", "cull_est_urad"; placement only)
+  int results_to_host = 1;     // batches that travel by copies: poses, information matrices, statuses, iteration counts and clock stamps written straight to pinned host memory (0: to the device and copied; A/B knob)
   int two_stage = 0;           // 1: ... in TWO launches: iteration 0 first (k_first_iteration), the rest placed by the length of iteration 1's unit lists.  Measured on configs[1]: the second
                                // launch 0.698 ms with a tail of 7 % instead of 10, but the first costs 95 us (every workgroup in the same phase at the same time: nothing overlaps) and the ordering 16:
                                // 0.861 vs 0.836 ms per step.  Off; kept as an A/B knob with its bit-identity test
@@ -291,6 +292,7 @@ extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t val
   if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_est_um")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_est_um out of range"); ctx->cull_est_um = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_est_urad")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_est_urad out of range"); ctx->cull_est_urad = (int) value; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "results_to_host")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "results_to_host must be 0 or 1"); ctx->results_to_host = (int) value; return LSM2D_SUCCESS; }
   if (!strcmp(key, "two_stage")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "two_stage must be 0 or 1"); ctx->two_stage = (int) value; ctx->wg_place_shape = 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance_notes")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance_notes must be 0 or 1"); ctx->balance_notes = (int) value; ctx->wg_place_shape = 0; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_keep")) { ctx->cull_keep = value != 0; return LSM2D_SUCCESS; }
@@ -324,6 +326,7 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
   if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_est_um")) { *out_value = ctx->cull_est_um; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_est_urad")) { *out_value = ctx->cull_est_urad; return LSM2D_SUCCESS; }
+  if (!strcmp(key, "results_to_host")) { *out_value = ctx->results_to_host; return LSM2D_SUCCESS; }
   if (!strcmp(key, "two_stage")) { *out_value = ctx->two_stage; return LSM2D_SUCCESS; }
   if (!strcmp(key, "balance_notes")) { *out_value = ctx->balance_notes; return LSM2D_SUCCESS; }
   if (!strcmp(key, "cull_keep")) { *out_value = ctx->cull_keep; return LSM2D_SUCCESS; }
@@ -1925,13 +1928,18 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   if (A.inline_n1) { memcpy(A.pose1, b->init_pose, sizeof A.pose1); if (b->prior) memcpy(&A.prior1, hs + o_prior, sizeof A.prior1); }
   if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   A.init_pose = (const float*) (ds + o_pose_in);
-  A.out_pose = (float*) (ds + o_pose); A.out_H = (float*) (ds + o_H); A.out_status = (int32_t*) (ds + o_status); A.out_its = (int32_t*) (ds + o_its);
+  // the SMALL results of a batch that travels by copies (56 bytes per alignment + the clock stamps) are written by the kernels straight into the pinned
+  // staging buffer: the device-to-host copy behind the launch -- a hand-over to the copy engine, 9 us of gap + 6 us of copy on the timeline of a
+  // 1000-alignment step -- is gone, the stream wait ends with the kernel.  The statistics (28 bytes per iteration and alignment) stay on the device and are copied.
+  const bool host_results = !zero_copy && !use_split && ctx->results_to_host && n > 0;
+  char* ro = host_results ? (char*) ctx->h_stage_dev : ds;
+  A.out_pose = (float*) (ro + o_pose); A.out_H = (float*) (ro + o_H); A.out_status = (int32_t*) (ro + o_status); A.out_its = (int32_t*) (ro + o_its);
   A.out_stats = out_stats ? (StatsDev*) (ds + o_stats) : nullptr;
-  A.out_last_pose = out_last_pose ? (float*) (ds + o_last_pose) : nullptr;
+  A.out_last_pose = out_last_pose ? (float*) (ro + o_last_pose) : nullptr;
 
   ctx->last_clock_khz = 0; ctx->last_wg_lifetime_ns = 0;
   const bool stamps = ctx->kernel_timing && !use_split && !use_pair;
-  if (stamps) { A.clock_out = (unsigned long long*) (ds + o_clock); A.clock_stride = clock_stride; }
+  if (stamps) { A.clock_out = (unsigned long long*) ((host_results ? (char*) ctx->h_stage_dev : ds) + o_clock); A.clock_stride = clock_stride; }
   A.host_polls = zero_copy;
   if (zero_copy) {
     memset(hs + o_pose, 0, out_bytes);
@@ -2058,7 +2066,8 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     if (A.s[s].unpack_src) { b->fixed[s]->unpack_pending = false; b->fixed[s]->staged_epoch = ctx->sync_epoch; }
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->have_timing = ctx->kernel_timing;
-  if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (host_results) { if (out_stats) HIPCHK(ctx, hipMemcpyAsync(hs + o_stats, ds + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, hipMemcpyDeviceToHost, ctx->stream)); }
+  else if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (zero_copy) HIPCHK(ctx, wait_for_statuses(ctx, (const int32_t*) (hs + o_status), n));
   else HIPCHK(ctx, stream_sync(ctx));
   memcpy(out_pose, hs + o_pose, sizeof(float) * 3 * (size_t) n);
