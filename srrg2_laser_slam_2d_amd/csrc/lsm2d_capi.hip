@@ -241,6 +241,8 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_balance_only, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_kd_build_scan<1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_kd_build_scan<0>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_kd_build_scan_multi<1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_kd_build_scan_multi<0>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_find_projective, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_canvas, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_project_split, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -789,13 +791,103 @@ static int ensure_grid(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_d
 // KD-tree finder: CorrespondenceFinderKDTree2D::reset() (registration/correspondence_finder_kd_tree_2d.cpp:31-38) for every cloud of the
 // (fixed) set, cached per (max_leaf_range, min_leaf_points).  Built on the device, level by level (k_kd_level: one wave per node); the
 // host only learns, after each level, how many nodes the next one has.
-static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_leaf_range, int min_leaf_points, KdDev* out, const KdCache** out_cache = nullptr) {
-  if (!(max_leaf_range > 0.0f)) max_leaf_range = 1e-2f;         // the class defaults (correspondence_finder_kd_tree_2d.h:26-33), as the oracle applies them
+// ---- the latency form of the KD-tree build (k_kd_build_scan): a handful of scan-sized clouds, working set in LDS.  Nothing is uploaded or cleared ahead of
+// the kernel (it writes the set's KdMeta itself), and the fixed sets of an aligner call's KD-tree slices -- the live tracker: one scan per laser -- are built
+// side by side by ONE launch with ONE wait for the trees' sizes (kd_scan_launch).
+static constexpr int kKdScanCap = 1280;      // points per cloud the LDS layout is sized for (58 KB)
+struct KdScanPrep {
+  const lsm2d_cloudset* cs = nullptr; KdCache kc; DevTmp block; KdBuildScanArgs W; std::vector<KdMeta> h_meta;
+};
+static void kd_defaults(float& max_leaf_range, int& min_leaf_points) {      // the class defaults (correspondence_finder_kd_tree_2d.h:26-33), as the oracle applies them
+  if (!(max_leaf_range > 0.0f)) max_leaf_range = 1e-2f;
   if (min_leaf_points <= 0) min_leaf_points = 20;
-  for (const auto& k : cs->kds)
-    if (k.valid && k.max_leaf_range == max_leaf_range && k.min_leaf_points == min_leaf_points) {
-      *out = KdDev{k.d_meta, k.d_nodes, k.d_leaf_xy, k.d_leaf_idx, k.d_leaf_nrm}; if (out_cache) *out_cache = &k; return LSM2D_SUCCESS;
-    }
+}
+static const KdCache* kd_cached(const lsm2d_cloudset* cs, float max_leaf_range, int min_leaf_points) {
+  for (const auto& k : cs->kds) if (k.valid && k.max_leaf_range == max_leaf_range && k.min_leaf_points == min_leaf_points) return &k;
+  return nullptr;
+}
+static bool kd_scan_eligible(const lsm2d_context* ctx, const lsm2d_cloudset* cs) {
+  const int nc = cs->n_clouds;
+  if (nc < 1 || nc > ctx->kd_scan_max_clouds || nc > 8 || cs->count_pending || (int) kd_scan_lds_bytes(kKdScanCap) > ctx->max_dyn_lds) return false;
+  for (int c = 0; c < nc; ++c) if (cs->h_count[c] > kKdScanCap || cs->h_count[c] > ctx->kd_wg_max_points) return false;
+  return true;
+}
+// the set's block (recycled for a reserved single-cloud set) and the kernel's arguments; no GPU work
+static int kd_scan_prepare(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_leaf_range, int min_leaf_points, KdScanPrep& P) {
+  const int nc = cs->n_clouds;
+  P.cs = cs; P.kc = KdCache(); P.kc.max_leaf_range = max_leaf_range; P.kc.min_leaf_points = min_leaf_points;
+  long long nodes = 0;
+  for (int c = 0; c < nc; ++c) {
+    P.W.node_base[c] = (int32_t) nodes;
+    const long long room = cs->capacity > 0 ? cs->capacity : cs->h_count[c];      // (a reserved set: for whatever it may hold later -- its allocation is recycled)
+    nodes += 2ll * room > 2 ? 2ll * room : 2;
+  }
+  const size_t np = (size_t) cs->padded_total;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t) 255; return o; };
+  const size_t o_meta = take(sizeof(KdMeta) * (size_t) nc), o_nodes = take(sizeof(KdNode) * (size_t) nodes);
+  const size_t o_lxy = take(sizeof(float2) * np), o_lidx = take(sizeof(int32_t) * np), o_lnr = take(sizeof(float2) * np);
+  const bool recycle = cs->kds.size() == 1 && !cs->kds[0].valid && cs->kds[0].d_block && cs->kds[0].block_bytes >= off;
+  P.kc.block_bytes = off;
+  if (recycle) { P.block.p = cs->kds[0].d_block; P.kc.block_bytes = cs->kds[0].block_bytes; cs->kds.clear(); }      // (owned by the guard again until the build has succeeded)
+  else {
+    if (cs->kds.size() == 1 && !cs->kds[0].valid) { if (cs->kds[0].d_block) (void) hipFree(cs->kds[0].d_block); cs->kds.clear(); }
+    HIPCHK(ctx, hipMalloc(&P.block.p, off));
+  }
+  char* blk = (char*) P.block.p;
+  KdCache& kc = P.kc;
+  kc.d_meta = (KdMeta*) (blk + o_meta); kc.d_nodes = (KdNode*) (blk + o_nodes);
+  kc.d_leaf_xy = (float2*) (blk + o_lxy); kc.d_leaf_idx = (int32_t*) (blk + o_lidx); kc.d_leaf_nrm = (float2*) (blk + o_lnr);
+  KdBuildArgs B;
+  B.start = cs->d_start; B.meta = kc.d_meta; B.nodes = kc.d_nodes; B.n_nodes = nullptr;
+  B.leaf_xy = kc.d_leaf_xy; B.leaf_idx = kc.d_leaf_idx; B.max_leaf_range = max_leaf_range; B.min_leaf_points = min_leaf_points;
+  B.xy_in = nullptr; B.idx_in = nullptr; B.xy_out = nullptr; B.idx_out = nullptr; B.q_in = nullptr; B.q_out = nullptr; B.q_out_count = nullptr; B.n_items = 0; B.n_items_ptr = nullptr; B.local_io = 0; B.io_base = 0; B.io_node_base = 0;
+  P.W.B = B; P.W.count = cs->d_count; P.W.xy0 = cs->d_xy; P.W.nrm0 = cs->d_nrm; P.W.leaf_nrm = kc.d_leaf_nrm; P.W.meta_rw = kc.d_meta; P.W.cap = kKdScanCap; P.W.n_clouds = nc;
+  P.h_meta.resize((size_t) nc);
+  return LSM2D_SUCCESS;
+}
+// one launch for all prepared sets, one wait for their trees' sizes; the caches are published to their sets
+static int kd_scan_launch(lsm2d_context* ctx, KdScanPrep* P, int count) {
+  if (count <= 0) return LSM2D_SUCCESS;
+  const size_t lds = kd_scan_lds_bytes(kKdScanCap);
+  if (count == 1) {
+    if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_build_scan<1>, dim3((unsigned) P[0].W.n_clouds), dim3(kKdScanThreads), lds, ctx->stream, P[0].W);
+    else hipLaunchKernelGGL(k_kd_build_scan<0>, dim3((unsigned) P[0].W.n_clouds), dim3(kKdScanThreads), lds, ctx->stream, P[0].W);
+  } else {
+    KdBuildScanMulti M; int widest = 1;
+    for (int i = 0; i < kMaxSlices; ++i) { M.w[i] = P[i < count ? i : 0].W; if (i >= count) M.w[i].n_clouds = 0; }
+    for (int i = 0; i < count; ++i) if (P[i].W.n_clouds > widest) widest = P[i].W.n_clouds;
+    if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_build_scan_multi<1>, dim3((unsigned) widest, (unsigned) count), dim3(kKdScanThreads), lds, ctx->stream, M);
+    else hipLaunchKernelGGL(k_kd_build_scan_multi<0>, dim3((unsigned) widest, (unsigned) count), dim3(kKdScanThreads), lds, ctx->stream, M);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  for (int i = 0; i < count; ++i)
+    HIPCHK(ctx, hipMemcpyAsync(P[i].h_meta.data(), P[i].kc.d_meta, sizeof(KdMeta) * P[i].h_meta.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, stream_sync(ctx));
+  for (int i = 0; i < count; ++i) {
+    KdCache& kc = P[i].kc;
+    kc.levels = 0; kc.total_nodes = 0; kc.max_nodes_per_cloud = 0;
+    for (const KdMeta& m : P[i].h_meta) { kc.total_nodes += m.n_nodes; if (m.n_nodes > kc.max_nodes_per_cloud) kc.max_nodes_per_cloud = m.n_nodes; if (m.pad0 > kc.levels) kc.levels = m.pad0; }
+    ctx->last_kd_levels = kc.levels; ctx->last_kd_nodes = kc.total_nodes;
+    kc.d_block = P[i].block.release();      // owned by the cache from here on
+    P[i].cs->kds.push_back(kc);
+  }
+  return LSM2D_SUCCESS;
+}
+
+static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max_leaf_range, int min_leaf_points, KdDev* out, const KdCache** out_cache = nullptr) {
+  kd_defaults(max_leaf_range, min_leaf_points);
+  if (const KdCache* k = kd_cached(cs, max_leaf_range, min_leaf_points)) {
+    *out = KdDev{k->d_meta, k->d_nodes, k->d_leaf_xy, k->d_leaf_idx, k->d_leaf_nrm}; if (out_cache) *out_cache = k; return LSM2D_SUCCESS;
+  }
+  if (kd_scan_eligible(ctx, cs)) {      // a handful of scan-sized clouds: the latency form
+    KdScanPrep P;
+    int rc = kd_scan_prepare(ctx, cs, max_leaf_range, min_leaf_points, P); if (rc) return rc;
+    rc = kd_scan_launch(ctx, &P, 1); if (rc) return rc;
+    const KdCache& k = cs->kds.back();
+    *out = KdDev{k.d_meta, k.d_nodes, k.d_leaf_xy, k.d_leaf_idx, k.d_leaf_nrm}; if (out_cache) *out_cache = &k;
+    return LSM2D_SUCCESS;
+  }
   const int nc = cs->n_clouds;
   // a cloud of n points has at most 2 n - 1 nodes (every split leaves both children non-empty); an empty cloud still has its root
   std::vector<KdMeta> meta((size_t) nc);
@@ -850,17 +942,7 @@ static int ensure_kdtree(lsm2d_context* ctx, const lsm2d_cloudset* cs, float max
   int n_small = 0;
   for (int c = 0; c < nc; ++c) { if (cs->h_count[c] <= wg_max) ++n_small; else roots.push_back(make_int4(c, 0, 0, cs->h_count[c])); }
   HIPCHK(ctx, hipMemcpyAsync(d_nn, ones.data(), sizeof(int32_t) * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
-  // a handful of scan-sized clouds (the live tracker: one scan per reset()): the build with the cloud's working set in LDS (k_kd_build_scan)
-  int small_max = 0; for (int c = 0; c < nc; ++c) if (cs->h_count[c] <= wg_max && cs->h_count[c] > small_max) small_max = cs->h_count[c];
-  const int scan_cap = 1280;      // (58 KB of LDS: under the 64 KB a workgroup may ask for)
-  const bool scan_form = n_small > 0 && n_small == nc && nc <= ctx->kd_scan_max_clouds && small_max <= scan_cap && (int) kd_scan_lds_bytes(scan_cap) <= ctx->max_dyn_lds;
-  if (scan_form) {
-    KdBuildScanArgs W; W.B = B; W.count = cs->d_count; W.xy0 = cs->d_xy; W.nrm0 = cs->d_nrm; W.leaf_nrm = kc.d_leaf_nrm; W.meta_rw = kc.d_meta; W.cap = scan_cap;
-    if (ctx->kd_chain == 1) hipLaunchKernelGGL(k_kd_build_scan<1>, dim3((unsigned) nc), dim3(kKdScanThreads), kd_scan_lds_bytes(scan_cap), ctx->stream, W);
-    else hipLaunchKernelGGL(k_kd_build_scan<0>, dim3((unsigned) nc), dim3(kKdScanThreads), kd_scan_lds_bytes(scan_cap), ctx->stream, W);
-    HIPCHK(ctx, hipGetLastError());
-  }
-  else if (n_small > 0) {
+  if (n_small > 0) {
     KdBuildWgArgs W; W.B = B; W.count = cs->d_count; W.xy0 = cs->d_xy; W.nrm0 = cs->d_nrm;
     W.xy_buf[0] = xyb[0]; W.xy_buf[1] = xyb[1]; W.idx_buf[0] = ixb[0]; W.idx_buf[1] = ixb[1]; W.q_buf[0] = qb[0]; W.q_buf[1] = qb[1];
     W.leaf_nrm = kc.d_leaf_nrm; W.meta_rw = kc.d_meta; W.max_points = wg_max;
@@ -1747,6 +1829,26 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     const lsm2d_cloudset* rd[2 * kMaxSlices]; int nr = 0;
     for (int s = 0; s < ns; ++s) { rd[nr++] = b->fixed[s]; rd[nr++] = b->moving[s]; }
     const int prc = flush_preprocessing_together(ctx, rd, nr); if (prc) return prc;
+  }
+  {   // KD-tree slices over scan-sized fixed sets whose trees are not there yet (the live tracker: a new scan per laser and step -- the reference's reset(),
+      // correspondence_finder_kd_tree_2d.cpp:6-8,31-38): ALL of them in one launch, side by side, with one wait (kd_scan_launch)
+    KdScanPrep preps[kMaxSlices]; int np_ = 0;
+    for (int s = 0; s < ns; ++s) {
+      const lsm2d_slice_params& sp = b->slices[s];
+      if (sp.finder != LSM2D_FINDER_KDTREE) continue;
+      const lsm2d_cloudset* f = b->fixed[s];
+      float mlr = sp.kd_max_leaf_range; int mlp = sp.kd_min_leaf_points; kd_defaults(mlr, mlp);
+      int rc0 = resolve_count(f); if (rc0) return rc0;
+      if (kd_cached(f, mlr, mlp) || !kd_scan_eligible(ctx, f)) continue;
+      bool dup = false;
+      for (int i = 0; i < np_; ++i) dup = dup || preps[i].cs == f;
+      if (dup) continue;      // (one set in two slices: built once here; with other parameters the second goes through ensure_kdtree)
+      rc0 = flush_pending(f); if (rc0) return rc0;
+      rc0 = kd_scan_prepare(ctx, f, mlr, mlp, preps[np_]); if (rc0) return rc0;
+      ++np_;
+    }
+    if (np_ >= 2) { const int rc0 = kd_scan_launch(ctx, preps, np_); if (rc0) return rc0; }
+    else if (np_ == 1) { const int rc0 = kd_scan_launch(ctx, preps, 1); if (rc0) return rc0; }
   }
   int cols_max = 0, fcan_total = 0;
   const KdCache* kd_cache0 = nullptr;      // the KD-tree set of the (last) KD-tree slice

@@ -1105,7 +1105,10 @@ struct KdBuildScanArgs {
   const int32_t* count; const float2* xy0; const float2* nrm0;
   float2* leaf_nrm; KdMeta* meta_rw;
   int32_t cap;                         // points the LDS layout is sized for (the host launches this kernel only for clouds that fit)
+  int32_t n_clouds;                    // clouds of THIS set (a launch over several sets is as wide as the largest)
+  int32_t node_base[8];                // first node of every cloud's region (the kernel writes the set's KdMeta itself: nothing is uploaded ahead of it)
 };
+struct KdBuildScanMulti { KdBuildScanArgs w[kMaxSlices]; };      // the fixed sets of an aligner call's KD-tree slices, built side by side by ONE launch (grid.y = set)
 static constexpr int kKdScanThreads = 1024, kKdScanGroups = kKdScanThreads / 256;
 LSM2D_HD size_t kd_scan_lds_bytes(int cap) {      // (cap <= 32767: a queue entry packs begin and end into 16 bits each)
   const size_t q = (size_t) (cap / 2 + 2);
@@ -1113,9 +1116,10 @@ LSM2D_HD size_t kd_scan_lds_bytes(int cap) {      // (cap <= 32767: a queue entr
        + kKdScanGroups * (32 * sizeof(float) + 8 * sizeof(int32_t)) + (kKdScanThreads / 64) * 256 * sizeof(float) + 64;
 }
 template <int kChain>
-__global__ __launch_bounds__(kKdScanThreads) void k_kd_build_scan(const KdBuildScanArgs W) {
+LSM2D_DEV void kd_build_scan_body(const KdBuildScanArgs& W, const int c) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, group = tid >> 8, gtid = tid & 255;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, group = tid >> 8, gtid = tid & 255;
+  if (c >= W.n_clouds) return;         // (a launch over several sets: this one has fewer clouds)
   const int n = W.count[c], base = W.B.start[c], cap = W.cap;
   if (n > cap) return;                 // (never: the host checked every cloud of the launch)
   const int qcap = cap / 2 + 2;
@@ -1131,7 +1135,7 @@ __global__ __launch_bounds__(kKdScanThreads) void k_kd_build_scan(const KdBuildS
   if (tid == 0) { qb[0][0] = make_int2(0, n << 16); s_ctl[0] = 1; s_ctl[1] = 0; s_ctl[2] = 1; s_ctl[3] = 0; }
   __syncthreads();
   KdBuildArgs A = W.B;
-  A.local_io = 1; A.n_nodes = s_ctl + 2; A.io_base = base; A.io_node_base = W.B.meta[c].node_base;
+  A.local_io = 1; A.n_nodes = s_ctl + 2; A.io_base = base; A.io_node_base = W.node_base[c];
   for (int level = 0;; ++level) {
     const int cur = level & 1, nxt = cur ^ 1;
     const int items = s_ctl[cur];
@@ -1169,8 +1173,12 @@ __global__ __launch_bounds__(kKdScanThreads) void k_kd_build_scan(const KdBuildS
   __syncthreads();                                   // ... and the leaf arrays in global memory, for the pass below
   // the normals in leaf order (k_kd_permute_normals), and the tree's size
   for (int i = tid; i < n; i += kKdScanThreads) W.leaf_nrm[base + i] = W.nrm0[base + W.B.leaf_idx[base + i]];
-  if (tid == 0) { W.B.n_nodes[c] = s_ctl[2]; W.meta_rw[c].n_nodes = s_ctl[2]; W.meta_rw[c].pad0 = s_ctl[3]; }
+  if (tid == 0) { KdMeta km; km.node_base = W.node_base[c]; km.n_nodes = s_ctl[2]; km.pad0 = s_ctl[3]; km.pad1 = 0; W.meta_rw[c] = km; }
 }
+template <int kChain>
+__global__ __launch_bounds__(kKdScanThreads) void k_kd_build_scan(const KdBuildScanArgs W) { kd_build_scan_body<kChain>(W, (int) blockIdx.x); }
+template <int kChain>
+__global__ __launch_bounds__(kKdScanThreads) void k_kd_build_scan_multi(const KdBuildScanMulti M) { kd_build_scan_body<kChain>(M.w[blockIdx.y], (int) blockIdx.x); }
 
 // roots of every cloud's tree: work item (c, 0, 0, count[c]); one node handed out per cloud
 __global__ void k_kd_init(const int32_t* __restrict__ count, int n_clouds, int4* __restrict__ q, int32_t* __restrict__ n_nodes) {
