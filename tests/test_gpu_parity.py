@@ -2654,6 +2654,40 @@ def test_culling_and_placement_change_no_bit(ctx, po):
                 assert np.array_equal(s0.pose, c.pose, equal_nan=True) and np.array_equal(s0.information, c.information, equal_nan=True) and np.array_equal(s0.stats, c.stats), name
 
 
+def test_two_kdtree_slices_build_their_scans_trees_in_one_launch(ctx, po):
+    """The live tracker with the reference's KD-tree finder: one alignment, two slices, each with its own NEW scan as the fixed cloud (a tree per scan and
+    step: CorrespondenceFinderKDTree2D::reset, correspondence_finder_kd_tree_2d.cpp:6-8,31-38), the same scene as the moving cloud.  The aligner call
+    builds both trees side by side in one launch (k_kd_build_scan_multi) -- the same poses, information matrices and statistics as with each tree built by
+    the workgroup build of its own call ("kd_scan_max_clouds" 0), step after step with refilled reserved sets, and the oracle's bits."""
+    wl = synth.make_workload(8, 20000, seed=15)
+    scene = wl.map_points[::25][:700].copy()
+    m0 = api.CloudSet.reserved(ctx, 1400); m1 = api.CloudSet.reserved(ctx, 1400); sc = api.CloudSet(ctx, scene)
+    f0 = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.3, normal_cos=0.8, max_leaf_range=0.01, min_leaf_points=20, search="kdtree")
+    f1 = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.25, normal_cos=0.7, max_leaf_range=0.02, min_leaf_points=12, search="kdtree")
+    al = api.MultiAligner2D(ctx, max_iterations=8, min_num_inliers=5)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(f0, min_num_correspondences=5))
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(f1, min_num_correspondences=5, robustifier=api.RobustifierCauchy(0.05)))
+    osp = [po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, normal_cos=0.8, kd_max_leaf_range=0.01, kd_min_leaf_points=20, min_num_correspondences=5),
+           po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.25, normal_cos=0.7, kd_max_leaf_range=0.02, kd_min_leaf_points=12, min_num_correspondences=5,
+                           robustifier=po.ROBUST_CAUCHY, chi_threshold=0.05)]
+    try:
+        for step in range(4):
+            a = wl.scan_points[wl.scan_offsets[2 * step]:wl.scan_offsets[2 * step + 1]]
+            b2 = wl.scan_points[wl.scan_offsets[2 * step + 1]:wl.scan_offsets[2 * step + 2]]
+            x0 = wl.x0[2 * step][None, :]
+            got = {}
+            for scan_max in (8, 0):
+                ctx.set_option("kd_scan_max_clouds", scan_max)
+                m0.upload(a); m1.upload(b2)           # new scans: both trees are rebuilt
+                got[scan_max] = al.compute_batch([m0, m1], [sc, sc], x0, want_stats=True)
+            g, h = got[8], got[0]
+            assert np.array_equal(g.pose, h.pose) and np.array_equal(g.information, h.information) and np.array_equal(g.status, h.status) and np.array_equal(g.stats, h.stats), step
+            rt = po.align(po.aligner_params(8, min_num_inliers=5, device_order=True), osp, [a, b2], [scene, scene], x0[0])
+            _assert_bitwise_equal_to_device_order_oracle(g, 0, rt, ("two kd slices", step))
+    finally:
+        ctx.set_option("kd_scan_max_clouds", 8)
+
+
 def test_prepared_batch_equals_compute_batch(ctx, small_workload):
     """MultiAligner2D.prepare_batch: the descriptor and the result arrays built once, lsm2d_align_batch called again and again (what bench.py times) --
     the same results as compute_batch, call after call, also after new start poses were written in place."""
