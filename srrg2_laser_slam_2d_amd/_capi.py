@@ -120,7 +120,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return _build.LIB_PATH
+    """liblsm2d_hip.so -- or, with LSM2D_EXPERIMENTS=1 in the environment, the experiments build of the same sources (tests / tuning only)."""
+    return _build.lib_path()
 
 
 def _preload_torch_hip_runtime():

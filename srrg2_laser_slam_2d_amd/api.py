@@ -575,7 +575,7 @@ def _batch_method(self, fixed, moving, init_poses, priors=None, fixed_index=None
     ctx = self._ctx
     slices = self.param_slice_processors
     ns = len(slices)
-    x0 = np.ascontiguousarray(init_poses, np.float32).reshape(-1, 3)
+    x0 = np.array(init_poses, dtype=np.float32, order="C", copy=True).reshape(-1, 3)      # the descriptor's OWN copy (round-4 advisor: PreparedBatch.set_init_poses wrote into the caller's array)
     n = len(x0)
     sp = (SliceParams * ns)(*[s.slice_params() for s in slices])
     fixed_sets = [_as_cloudset(ctx, f) for f in fixed]          # keep host-array uploads alive for the duration of the call
@@ -616,7 +616,9 @@ class PreparedBatch:
     """A batch whose descriptor, parameters and result arrays are built ONCE and handed to lsm2d_align_batch again and again -- what a host loop in the
     reference's own language does with its vectors (a candidate sweep re-aligns the same sets from new poses; the bench times the call, not the
     interpreter's marshalling of it: ~25 us of ctypes / numpy per call otherwise).  ``set_init_poses`` overwrites the start poses in place; every
-    ``run()`` overwrites the result arrays of the BatchResult it returns."""
+    ``run()`` overwrites the result arrays of the BatchResult it returns: the results of successive runs SHARE their arrays (``run(copy=True)`` hands back
+    arrays of their own).  The library keeps the placement of a batch it has seen before -- a run with unchanged sets and start poses launches no estimate
+    (``Context.get_option("last_cull_estimate")`` tells)."""
 
     def __init__(self, aligner, fixed, moving, init_poses, priors=None, fixed_index=None, moving_index=None, want_stats: bool = False):
         self._aligner = aligner
@@ -638,12 +640,13 @@ class PreparedBatch:
     def set_init_poses(self, init_poses) -> None:
         self._x0[...] = np.asarray(init_poses, np.float32).reshape(self._x0.shape)
 
-    def run(self) -> BatchResult:
+    def run(self, copy: bool = False) -> BatchResult:
         ctx = self._ctx
         check(self._fn(*self._args), "lsm2d_align_batch", ctx.handle)
         n = self._b.n_alignments
         timed = bool(n and ctx.kernel_timing)
-        return BatchResult(self.pose, self._H.reshape(n, 3, 3), self.status, self.iterations, self.stats, ctx.last_kernel_ms() if timed else 0.0,
+        c = (lambda a: None if a is None else a.copy()) if copy else (lambda a: a)
+        return BatchResult(c(self.pose), c(self._H).reshape(n, 3, 3), c(self.status), c(self.iterations), c(self.stats), ctx.last_kernel_ms() if timed else 0.0,
                            ctx.get_option("last_kernel_clock_khz") * 1e-3 if timed else 0.0,
                            ctx.get_option("last_workgroup_lifetime_ns") * 1e-6 if timed else 0.0, None)
 

@@ -15,6 +15,9 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblsm2d_hip.so")
+# The same sources with -DLSM2D_EXPERIMENTS: the measured-and-rejected alternatives of DESIGN App. A (second launch form, row-major culled stream, the A/B
+# option keys) compiled in.  NOT the product: only tests/test_gpu_experiments.py and tuning scripts load it, by LSM2D_EXPERIMENTS=1 in the environment.
+LIB_PATH_EXPERIMENTS = os.path.join(LIB_DIR, "liblsm2d_hip_experiments.so")
 SOURCES = [os.path.join(CSRC, "lsm2d_capi.hip")]
 HEADERS = [os.path.join(CSRC, "lsm2d_device.h"), os.path.join(CSRC, "lsm2d_kernels.h"),
            os.path.join(ROOT, "include", "lsm2d.h")]
@@ -50,18 +53,34 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def experiments_selected() -> bool:
+    return os.environ.get("LSM2D_EXPERIMENTS", "0") not in ("", "0")
+
+
+def lib_path(experiments: bool | None = None) -> str:
+    if experiments is None:
+        experiments = experiments_selected()
+    return LIB_PATH_EXPERIMENTS if experiments else LIB_PATH
+
+
+def is_stale(experiments: bool | None = None) -> bool:
+    path = lib_path(experiments)
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
+def build(force: bool = False, verbose: bool = False, experiments: bool | None = None) -> str:
+    if experiments is None:
+        experiments = experiments_selected()
+    LIB_PATH = lib_path(experiments)
+    if not force and not is_stale(experiments):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     extra = os.environ.get("LSM2D_EXTRA_HIPCC_FLAGS", "").split()      # tuning experiments only
+    if experiments:
+        extra = ["-DLSM2D_EXPERIMENTS"] + extra
     # compile next to the target and rename: several ranks of one job may get here together (torchrun), and none of them must
     # ever dlopen a half-written file
     tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
@@ -78,4 +97,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments=True if "--experiments" in sys.argv else None))

@@ -18,6 +18,7 @@ using lsm2d::LSM2D_RUNNING;
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <atomic>
 
 using namespace lsm2d;
 
@@ -41,7 +42,7 @@ struct lsm2d_context {
   int max_dyn_lds = 0;
   unsigned long long sync_epoch = 1;   // bumped by every stream_sync()
   int align_path = 0;          // 0 auto, 1 fused, 2 split, 3 slice pair
-  bool kernel_timing = false;  // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
+  int kernel_timing = 0;       // record HIP events around the hot-path launches (lsm2d_last_kernel_ms).  Off by default: two timed events per
                                // operation cost the live tracker 30 us of its 165 us step (they are API calls AND pipeline drains)
   int last_align_path = 0;     // what the most recent lsm2d_align_batch used (1, 2 or 3)
   int zero_copy_max = 256;     // largest batch whose arguments and results travel through pinned host memory directly ("zero_copy_max" option, A/B knob)
@@ -57,6 +58,7 @@ struct lsm2d_context {
                                // 0.861 vs 0.836 ms per step.  Off; kept as an A/B knob with its bit-identity test
   int balance_notes = 1;       // ... group the workgroup ids by the CU the previous launch of the same shape ran them on (0: assume b, b + n_cu, ...; A/B knob)
   int32_t* d_wg_place = nullptr; unsigned long long wg_place_shape = 0;      // the notes (one int per workgroup) and the launch shape they belong to
+  int32_t* d_order = nullptr;                                                // [4096] the placement the latest estimate made: kept for the next run of the SAME batch (order_valid / order_key / order_poses)
   int proj_modes = 1;          // projective batches against map-sized clouds: the instantiation with the culled stream only (0: the shared one; A/B knob)
   int kd_modes = 1;            // KD-tree batches: the instantiations with one form of the descent only (0: the shared one; A/B knob)
   int nn_lds_only = 1;         // grid NN with every alignment's tables staged in LDS: the instantiation without the search in global memory (0: the shared one; A/B knob)
@@ -75,6 +77,18 @@ struct lsm2d_context {
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
   long long last_clock_khz = 0;       // in-kernel clock of the most recent timed k_align launch (median over the stamped workgroups), 0 = none
   long long last_wg_lifetime_ns = 0;  // median lifetime of its stamped workgroups
+  int xcd_window = 0;          // (set below) big-map batches: the workgroups of an XCD walk the map's blocks within this many blocks of each other ("xcd_window"; 0: free-running)
+  int uploads = 0;             // host-to-device cloud uploads queued so far ("uploads", read-only: the adapters' upload-once test reads it)
+  long long last_h2d_bytes = 0; // bytes the most recent cloud upload moved over the host link
+  int experiments =
+#ifdef LSM2D_EXPERIMENTS
+      1;
+#else
+      0;
+#endif
+  int estimate_reuse = 1;      // a prepared batch run again with unchanged start poses keeps its placement (no k_cull_estimate launch); experiments build: 0 switches that off
+  int last_cull_estimate = 0;  // what the latest aligner call did about the placement's estimate ("last_cull_estimate")
+  bool order_valid = false; unsigned long long order_key = 0; std::vector<float> order_poses;      // the placement d_order holds: which batch it was made for
   int last_query_cull = 0;     // the latest aligner call ran its point-query finder with the exact culling of the queries (k_align, tiles of 64 moving points)
   long long last_kd_levels = 0, last_kd_nodes = 0;      // shape of the most recently built KD-tree set (levels of the deepest tree, nodes in all of them)
   std::vector<lsm2d_cloudset*> live_sets;      // lsm2d_destroy orphans what is left (a set destroyed after its context must not touch it)
@@ -130,8 +144,11 @@ struct KdCache {       // one KD-tree per cloud of the set, per (max_leaf_range,
   bool valid = true; size_t block_bytes = 0;
 };
 
+static unsigned long long next_cloudset_uid() { static std::atomic<unsigned long long> n{1}; return n.fetch_add(1, std::memory_order_relaxed); }
 struct lsm2d_cloudset {
   lsm2d_context* ctx = nullptr;
+  const unsigned long long uid = next_cloudset_uid();      // never reused: what a context remembers about a batch (the kept placement) names its sets by uid + version
+  mutable unsigned long long version = 0;                   // bumped whenever the contents change (cloudset_drop_grids)
   mutable std::vector<GridCache> grids;
   mutable std::vector<DistCache> dists;
   mutable std::vector<KdCache> kds;
@@ -237,8 +254,10 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_cull_estimate, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+#ifdef LSM2D_EXPERIMENTS
   (void) hipFuncSetAttribute((const void*) k_first_iteration, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_balance_only, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+#endif
   (void) hipFuncSetAttribute((const void*) k_kd_build_scan<1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_kd_build_scan<0>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_kd_build_scan_multi<1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -267,6 +286,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->d_split) (void) hipFree(c->d_split);
   if (c->d_kd_work) (void) hipFree(c->d_kd_work);
   if (c->d_wg_place) (void) hipFree(c->d_wg_place);
+  if (c->d_order) (void) hipFree(c->d_order);
   for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
   if (c->ev1) (void) hipEventDestroy(c->ev1);
@@ -281,75 +301,92 @@ extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
   return LSM2D_SUCCESS;
 }
 
+// ---- options ---------------------------------------------------------------------------------------------------------------------------
+// ONE table (round 5; 39 strcmp lines before).  Public keys are the ones include/lsm2d.h documents: what a caller may legitimately choose.  The A/B knobs of
+// measured-and-rejected or always-on alternatives (DESIGN App. A) exist only in a -DLSM2D_EXPERIMENTS build of the library: the shipped one answers
+// "unknown option" to them, and "experiments" reads 0 there.
+namespace {
+enum : int { kOptBool = 1, kOptEven = 2, kOptResetsNotes = 4, kOptReadOnly = 8, kOptExperiment = 16 };
+struct OptionDesc { const char* key; int lsm2d_context::* field; long long lo, hi; int flags; };
+struct OptionDescLL { const char* key; long long lsm2d_context::* field; };
+#ifdef LSM2D_EXPERIMENTS
+constexpr int kCullMax = 2, kBuiltWithExperiments = 1;
+#else
+constexpr int kCullMax = 1, kBuiltWithExperiments = 0;
+#endif
+const OptionDesc kOptions[] = {
+  // ---- public (include/lsm2d.h)
+  {"kernel_timing",      &lsm2d_context::kernel_timing,      0, 1,          kOptBool},
+  {"clock_stride",       &lsm2d_context::clock_stride,       0, 0x7fffffff, 0},
+  {"align_path",         &lsm2d_context::align_path,         0, 3,          0},
+  {"find_path",          &lsm2d_context::find_path,          0, 1,          0},
+  {"zero_copy_max",      &lsm2d_context::zero_copy_max,      0, 65536,      0},
+  {"cull",               &lsm2d_context::cull,               0, kCullMax,   0},
+  {"balance",            &lsm2d_context::balance,            0, 1,          0},
+  {"xcd_window",         &lsm2d_context::xcd_window,         0, 64,         0},
+  {"cull_margin_um",     &lsm2d_context::cull_margin_um,     0, 1000000,    0},
+  {"cull_margin_urad",   &lsm2d_context::cull_margin_urad,   0, 50000,      0},      // (the kept lists' proof compares |sin dth| with the margin: asin(x) - x stays below the test's 0.05-column slack up to here)
+  {"grid_big_threshold", &lsm2d_context::grid_big_threshold, 1, 0x7fffffff, 0},
+  {"distmap_build",      &lsm2d_context::distmap_build,      0, 1,          0},
+  {"kd_lds_nodes",       &lsm2d_context::kd_lds_nodes,       0, 4096,       0},
+  // ---- read-only
+  {"last_align_path",    &lsm2d_context::last_align_path,    0, 0, kOptReadOnly},
+  {"last_query_cull",    &lsm2d_context::last_query_cull,    0, 0, kOptReadOnly},
+  {"max_dyn_lds",        &lsm2d_context::max_dyn_lds,        0, 0, kOptReadOnly},      // bytes of LDS one workgroup may ask for
+  {"uploads",            &lsm2d_context::uploads,            0, 0, kOptReadOnly},      // host-to-device cloud uploads this context has queued so far (lsm2d_cloudset_create / _upload)
+  {"last_cull_estimate", &lsm2d_context::last_cull_estimate, 0, 0, kOptReadOnly},      // 1: the latest aligner call launched the placement's estimate; 0: it reused the order of an unchanged prepared batch, or needed none
+  {"experiments",        &lsm2d_context::experiments,        0, 0, kOptReadOnly},
+#ifdef LSM2D_EXPERIMENTS
+  // ---- A/B knobs of the experiments build (tests/test_gpu_experiments.py; each one's measurement: DESIGN App. A)
+  {"cull_est_um",        &lsm2d_context::cull_est_um,        0, 1000000, kOptExperiment},
+  {"cull_est_urad",      &lsm2d_context::cull_est_urad,      0, 1000000, kOptExperiment},
+  {"results_to_host",    &lsm2d_context::results_to_host,    0, 1,       kOptExperiment},
+  {"two_stage",          &lsm2d_context::two_stage,          0, 1,       kOptExperiment | kOptResetsNotes},
+  {"balance_notes",      &lsm2d_context::balance_notes,      0, 1,       kOptExperiment | kOptResetsNotes},
+  {"cull_keep",          &lsm2d_context::cull_keep,          0, 1,       kOptExperiment | kOptBool},
+  {"nn_qcache",          &lsm2d_context::nn_qcache,          0, 1,       kOptExperiment | kOptBool},
+  {"nn_lds_only",        &lsm2d_context::nn_lds_only,        0, 1,       kOptExperiment | kOptBool},
+  {"kd_modes",           &lsm2d_context::kd_modes,           0, 1,       kOptExperiment | kOptBool},
+  {"proj_modes",         &lsm2d_context::proj_modes,         0, 1,       kOptExperiment | kOptBool},
+  {"cull_block",         &lsm2d_context::cull_block,         0, 4096,    kOptExperiment | kOptEven},
+  {"kd_chain",           &lsm2d_context::kd_chain,           0, 1,       kOptExperiment},
+  {"grid_big_cells_x10", &lsm2d_context::grid_big_cells_x10, 5, 400,     kOptExperiment},
+  {"kd_scan_max_clouds", &lsm2d_context::kd_scan_max_clouds, 0, 0x7fffffff, kOptExperiment},
+  {"kd_wide_min_points", &lsm2d_context::kd_wide_min_points, 0, 0x7fffffff, kOptExperiment},
+  {"kd_wg_max_points",   &lsm2d_context::kd_wg_max_points,   0, 1 << 20, kOptExperiment},
+  {"estimate_reuse",     &lsm2d_context::estimate_reuse,     0, 1,       kOptExperiment},
+#endif
+};
+const OptionDescLL kOptionsLL[] = {      // read-only, 64-bit
+  {"last_kd_levels", &lsm2d_context::last_kd_levels}, {"last_kd_nodes", &lsm2d_context::last_kd_nodes},
+  {"last_kernel_clock_khz", &lsm2d_context::last_clock_khz}, {"last_workgroup_lifetime_ns", &lsm2d_context::last_wg_lifetime_ns},
+  {"last_h2d_bytes", &lsm2d_context::last_h2d_bytes},
+};
+}  // namespace
+
 extern "C" int lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return LSM2D_BAD_ARGUMENT;
-  if (!strcmp(key, "clock_stride")) { if (value < 0 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "clock_stride: out of range"); ctx->clock_stride = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kernel_timing")) { ctx->kernel_timing = value != 0; if (!ctx->kernel_timing) ctx->have_timing = false; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "align_path")) { if (value < 0 || value > 3) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_path must be 0, 1, 2 or 3"); ctx->align_path = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "zero_copy_max")) { if (value < 0 || value > 65536) return fail(ctx, LSM2D_BAD_ARGUMENT, "zero_copy_max: out of range"); ctx->zero_copy_max = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "find_path")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "find_path must be 0 or 1"); ctx->find_path = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "grid_big_threshold")) { if (value < 1 || value > 0x7fffffff) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_threshold: out of range"); ctx->grid_big_threshold = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "distmap_build")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "distmap_build must be 0 or 1"); ctx->distmap_build = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull")) { if (value < 0 || value > 2) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull must be 0, 1 or 2"); ctx->cull = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "balance")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance must be 0 or 1"); ctx->balance = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_est_um")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_est_um out of range"); ctx->cull_est_um = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_est_urad")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_est_urad out of range"); ctx->cull_est_urad = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "results_to_host")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "results_to_host must be 0 or 1"); ctx->results_to_host = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "two_stage")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "two_stage must be 0 or 1"); ctx->two_stage = (int) value; ctx->wg_place_shape = 0; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "balance_notes")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "balance_notes must be 0 or 1"); ctx->balance_notes = (int) value; ctx->wg_place_shape = 0; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_keep")) { ctx->cull_keep = value != 0; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_margin_um")) { if (value < 0 || value > 1000000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_margin_um: 0 .. 1e6"); ctx->cull_margin_um = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_margin_urad")) { if (value < 0 || value > 200000) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_margin_urad: 0 .. 2e5"); ctx->cull_margin_urad = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "nn_qcache")) { ctx->nn_qcache = value != 0; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "nn_lds_only")) { ctx->nn_lds_only = value != 0; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_modes")) { ctx->kd_modes = value != 0; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "proj_modes")) { ctx->proj_modes = value != 0; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_block")) { if (value < 0 || value > 4096 || (value & 1)) return fail(ctx, LSM2D_BAD_ARGUMENT, "cull_block must be even, 0 .. 4096"); ctx->cull_block = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_chain")) { if (value < 0 || value > 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_chain must be 0 or 1"); ctx->kd_chain = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "grid_big_cells_x10")) { if (value < 5 || value > 400) return fail(ctx, LSM2D_BAD_ARGUMENT, "grid_big_cells_x10: 5 .. 400"); ctx->grid_big_cells_x10 = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_scan_max_clouds")) { if (value < 0) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_scan_max_clouds must be >= 0"); ctx->kd_scan_max_clouds = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_wide_min_points")) { if (value < 0) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_wide_min_points must be >= 0"); ctx->kd_wide_min_points = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_wg_max_points")) { if (value < 0 || value > (1 << 20)) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_wg_max_points: 0 .. 2^20"); ctx->kd_wg_max_points = (int) value; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_lds_nodes")) { if (value < 0 || value > 4096) return fail(ctx, LSM2D_BAD_ARGUMENT, "kd_lds_nodes: out of range"); ctx->kd_lds_nodes = (int) value; return LSM2D_SUCCESS; }
+  for (const OptionDesc& o : kOptions) {
+    if (strcmp(key, o.key)) continue;
+    if (o.flags & kOptReadOnly) return fail(ctx, LSM2D_BAD_ARGUMENT, "set_option: this key is read-only");
+    if (o.flags & kOptBool) value = value != 0;
+    if (value < o.lo || value > o.hi || ((o.flags & kOptEven) && (value & 1))) {
+      char buf[160]; snprintf(buf, sizeof buf, "set_option: %s must be %sin %lld .. %lld", o.key, (o.flags & kOptEven) ? "even and " : "", o.lo, o.hi);
+      return fail(ctx, LSM2D_BAD_ARGUMENT, buf);
+    }
+    ctx->*(o.field) = (int) value;
+    if (o.flags & kOptResetsNotes) ctx->wg_place_shape = 0;
+    if (o.field == &lsm2d_context::kernel_timing && !value) ctx->have_timing = false;
+    ctx->order_valid = false;      // whatever changed may change what a batch launches: the next call makes its placement afresh
+    return LSM2D_SUCCESS;
+  }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
 
 extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* out_value) {
   if (!ctx || !key || !out_value) return LSM2D_BAD_ARGUMENT;
-  if (!strcmp(key, "kernel_timing")) { *out_value = ctx->kernel_timing ? 1 : 0; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "align_path")) { *out_value = ctx->align_path; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "distmap_build")) { *out_value = ctx->distmap_build; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull")) { *out_value = ctx->cull; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_block")) { *out_value = ctx->cull_block; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "nn_qcache")) { *out_value = ctx->nn_qcache; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "nn_lds_only")) { *out_value = ctx->nn_lds_only; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_modes")) { *out_value = ctx->kd_modes; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "proj_modes")) { *out_value = ctx->proj_modes; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "balance")) { *out_value = ctx->balance; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_est_um")) { *out_value = ctx->cull_est_um; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_est_urad")) { *out_value = ctx->cull_est_urad; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "results_to_host")) { *out_value = ctx->results_to_host; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "two_stage")) { *out_value = ctx->two_stage; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "balance_notes")) { *out_value = ctx->balance_notes; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_keep")) { *out_value = ctx->cull_keep; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_margin_um")) { *out_value = ctx->cull_margin_um; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "cull_margin_urad")) { *out_value = ctx->cull_margin_urad; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_chain")) { *out_value = ctx->kd_chain; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_wg_max_points")) { *out_value = ctx->kd_wg_max_points; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "grid_big_cells_x10")) { *out_value = ctx->grid_big_cells_x10; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_scan_max_clouds")) { *out_value = ctx->kd_scan_max_clouds; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_wide_min_points")) { *out_value = ctx->kd_wide_min_points; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "kd_lds_nodes")) { *out_value = ctx->kd_lds_nodes; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "last_query_cull")) { *out_value = ctx->last_query_cull; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "last_kd_levels")) { *out_value = ctx->last_kd_levels; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "max_dyn_lds")) { *out_value = ctx->max_dyn_lds; return LSM2D_SUCCESS; }      // bytes of LDS one workgroup may ask for
-  if (!strcmp(key, "last_kd_nodes")) { *out_value = ctx->last_kd_nodes; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "grid_big_threshold")) { *out_value = ctx->grid_big_threshold; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "find_path")) { *out_value = ctx->find_path; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "zero_copy_max")) { *out_value = ctx->zero_copy_max; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "last_align_path")) { *out_value = ctx->last_align_path; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "last_kernel_clock_khz")) { *out_value = ctx->last_clock_khz; return LSM2D_SUCCESS; }
-  if (!strcmp(key, "last_workgroup_lifetime_ns")) { *out_value = ctx->last_wg_lifetime_ns; return LSM2D_SUCCESS; }
+  for (const OptionDesc& o : kOptions) if (!strcmp(key, o.key)) { *out_value = ctx->*(o.field); return LSM2D_SUCCESS; }
+  for (const OptionDescLL& o : kOptionsLL) if (!strcmp(key, o.key)) { *out_value = ctx->*(o.field); return LSM2D_SUCCESS; }
   return fail(ctx, LSM2D_BAD_ARGUMENT, "unknown option");
 }
 
@@ -572,6 +609,7 @@ extern "C" int32_t lsm2d_cloudset_cloud_sizes(const lsm2d_cloudset* cs, int32_t*
 }
 
 static void cloudset_drop_grids(const lsm2d_cloudset* cs) {     // the contents changed: cached NN grids are stale
+  ++cs->version;
   for (auto& g : cs->grids) if (g.d_block) (void) hipFree(g.d_block);
   cs->grids.clear();
   if (cs->d_lane_xy) { (void) hipFree(cs->d_lane_xy); cs->d_lane_xy = nullptr; }
@@ -1046,10 +1084,14 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
   }
   if (slots == 0) slots = 1;
   slots += 2 * kAlignBlock;      // two spare rows behind the last cloud: project_cloud_units' look-ahead load may read one row past a cloud's last
+  // block circles: 57 KB per cloud.  They are what the kept unit lists are built from -- worth it for a map or a few thousand big clouds, not for tens of
+  // thousands of scan-sized moving clouds (round-4 advisor: several GB there): beyond 256 MB the set goes without them and its batches run the chunk-level
+  // stream of the shared instantiation (proj_culled_for_all needs block_bounds)
+  const bool want_blocks = sizeof(float4) * (size_t) nc * kCullBlocks * kAlignBlock <= ((size_t) 256 << 20);
   DevTmp t_xy, t_bounds, t_blocks, t_start, t_T;
   HIPCHK(ctx, hipMalloc(&t_xy.p, sizeof(float4) * (size_t) slots));
   HIPCHK(ctx, hipMalloc(&t_bounds.p, sizeof(float4) * (size_t) nc * kAlignBlock));
-  HIPCHK(ctx, hipMalloc(&t_blocks.p, sizeof(float4) * (size_t) nc * kCullBlocks * kAlignBlock));
+  if (want_blocks) HIPCHK(ctx, hipMalloc(&t_blocks.p, sizeof(float4) * (size_t) nc * kCullBlocks * kAlignBlock));
   HIPCHK(ctx, hipMalloc(&t_start.p, sizeof(long long) * (size_t) nc));
   HIPCHK(ctx, hipMalloc(&t_T.p, sizeof(int32_t) * (size_t) nc));
   float4* d_xy = (float4*) t_xy.p; float4* d_bounds = (float4*) t_bounds.p; float4* d_blocks = (float4*) t_blocks.p;
@@ -1065,8 +1107,9 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
                        (const int32_t*) d_T, (int) kAlignBlock, d_xy, c0);
     hipLaunchKernelGGL(k_lane_bounds, dim3((unsigned) (kAlignBlock / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
                        (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) d_T, (int) kAlignBlock, d_bounds, c0);
-    hipLaunchKernelGGL(k_block_bounds, dim3((unsigned) (kAlignBlock * kCullBlocks / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
-                       (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) d_T, (int) kAlignBlock, d_blocks, c0);
+    if (want_blocks)
+      hipLaunchKernelGGL(k_block_bounds, dim3((unsigned) (kAlignBlock * kCullBlocks / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) d_T, (int) kAlignBlock, d_blocks, c0);
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, stream_sync(ctx));        // the host vectors above back the async copies; and only a finished build is published
@@ -1750,6 +1793,17 @@ extern "C" int32_t lsm2d_stats_capacity(const lsm2d_aligner_params* ap) {
   return (int32_t) (c < 1 ? 1 : (c > 0x7fffffff ? 0x7fffffff : c));
 }
 
+// ---- the instantiations of k_align a batch can be launched as
+typedef void (*AlignKernel)(const AlignArgs);
+enum : unsigned { kFProj = 1, kFNN = 2, kFDist = 4, kFKd = 8 };
+struct AlignVariant { unsigned finders; int mode; AlignKernel fn; };
+static const AlignVariant kAlignVariants[] = {
+  {kFProj, 5, k_align<true, false, false, false, 5>}, {kFProj, 0, k_align<true, false, false>},
+  {kFNN, 1, k_align<false, true, false, false, 1>},   {kFNN, 2, k_align<false, true, false, false, 2>}, {kFNN, 0, k_align<false, true, false>},
+  {kFDist, 0, k_align<false, false, true>},
+  {kFKd, 3, k_align<false, false, false, true, 3>},   {kFKd, 4, k_align<false, false, false, true, 4>}, {kFKd, 0, k_align<false, false, false, true>},
+};
+
 // out_last_pose [n][3] (may be NULL): the pose the last iteration every alignment started began at (what lsm2d_align_batch_pairs re-derives
 // that iteration's correspondences from)
 // out_work [n] (may be NULL): ONLY the work estimate of lsm2d_estimate_work is produced -- no alignment runs, the other outputs are not touched
@@ -2053,6 +2107,10 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     // untouched are the statistics of iterations that never started: only those are cleared (the clock stamps of a timed launch are written by every
     // stamping workgroup -- each alignment runs exactly once, wherever the placement puts it)
     if (out_stats) HIPCHK(ctx, hipMemsetAsync(ds + o_stats, 0, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, ctx->stream));
+    // ... and "exactly once" is checked, not assumed (round-4 advisor): the status words start as kStatusNotWritten -- in the pinned buffer the kernels write to, a
+    // host memset of 4 n bytes; on the device for the paths that copy -- and one that is still unwritten after the wait turns the call into LSM2D_DEVICE_ERROR
+    if (host_results) memset(hs + o_status, 0xFF, sizeof(int32_t) * (size_t) n);
+    else HIPCHK(ctx, hipMemsetAsync(ds + o_status, 0xFF, sizeof(int32_t) * (size_t) n, ctx->stream));
   }
   ctx->last_align_path = use_split ? 2 : (use_pair ? 3 : 1);
   // culled batches that run in about one dispatch round: balanced placement (one small launch ahead of k_align; see k_cull_estimate)
@@ -2072,8 +2130,13 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   }
   A.stage = 0; A.stage_split = 0; A.resume = nullptr; A.stage_work = nullptr;
   // a culled batch of about one dispatch round, two launches: iteration 0 anywhere (k_first_iteration), then the rest placed by what iteration 1's lists hold
+#ifdef LSM2D_EXPERIMENTS
   const bool two_stage = !use_split && !use_pair && !zero_copy && A.cull && ctx->balance && ctx->two_stage && n > 256 && n <= 1024 && proj_culled_for_all &&
                          has_proj && !has_nn && !has_dist && !has_kd && ap->max_iterations >= 4;
+#else
+  constexpr bool two_stage = false;
+#endif
+#ifdef LSM2D_EXPERIMENTS
   if (two_stage) {
     int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work); int32_t* d_order = (int32_t*) ((char*) ctx->d_scratch + o_order);
     const unsigned long long shape = ((unsigned long long) (unsigned) n << 32) ^ ((unsigned long long) lds << 8) ^ 6ull;
@@ -2090,25 +2153,53 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     A.stage = 2; A.order = d_order;
     if (ctx->balance_notes) { A.wg_place = ctx->d_wg_place; ctx->wg_place_shape = shape; }
   }
+  else
+#endif
   // (a batch of many dispatch rounds balances itself, and the estimate of 65 536 alignments costs more than its heaviest-first order saves:
   // configs[3] 47.6 vs 47.2 ms per step -- the placement is for batches of up to four rounds)
-  else if (!use_split && !use_pair && !zero_copy && A.cull && ctx->balance && n > 256 && n <= 4096 && has_proj) {
+  ctx->last_cull_estimate = 0;
+  if (!use_split && !use_pair && !zero_copy && A.cull && ctx->balance && n > 256 && n <= 4096 && has_proj) {
     int bs = -1;
     for (int s = 0; s < ns && bs < 0; ++s) if (A.s[s].finder == LSM2D_FINDER_PROJECTIVE && A.s[s].moving.lane_xy && A.s[s].moving.lane_bounds) bs = s;
     if (bs >= 0) {
-      int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work); int32_t* d_order = (int32_t*) ((char*) ctx->d_scratch + o_order);
+      int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work);
       // the workgroups of the previous launch of the same shape noted the CU they ran on (AlignArgs::wg_place): the placement groups by those notes
       const unsigned long long shape = ((unsigned long long) (unsigned) n << 32) ^ ((unsigned long long) lds << 8) ^ (unsigned long long) (proj_culled_for_all ? 5 : 0);
       if (!ctx->d_wg_place) {      // 1024 notes + the estimate's ticket counter
         HIPCHK(ctx, hipMalloc(&ctx->d_wg_place, sizeof(int32_t) * 1025)); ctx->wg_place_shape = 0;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_wg_place, 0, sizeof(int32_t) * 1025, ctx->stream));
       }
+      if (!ctx->d_order) { HIPCHK(ctx, hipMalloc(&ctx->d_order, sizeof(int32_t) * 4096)); ctx->order_valid = false; }
       const bool notes = ctx->balance_notes && ctx->wg_place_shape == shape;
-      size_t est_lds = sizeof(u64) * (size_t) A.s[bs].proj.cols; if (est_lds < sizeof(BalanceLds)) est_lds = sizeof(BalanceLds);
-      hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), est_lds, ctx->stream, A, bs, d_work, d_order,
-                         notes ? (const int32_t*) ctx->d_wg_place : (const int32_t*) nullptr, ctx->n_cu, (unsigned int*) (ctx->d_wg_place + 1024));
-      HIPCHK(ctx, hipGetLastError());
-      A.order = d_order;
+      // Round 5: the order lives in a buffer of its own and is KEPT.  A caller that runs the same batch again -- the same sets (uid and version), index arrays,
+      // slice parameters, launch shape and START POSES: a candidate sweep re-scored, bench.py's resident step -- gets the placement made for it the first time
+      // with notes, and no estimate launch (33 us of a 0.8 ms step).  Anything that differs makes it afresh; only where alignments run depends on it, never a result.
+      unsigned long long key = 1469598103934665603ull;
+      auto mix = [&](const void* p, size_t bytes) { const unsigned char* q = (const unsigned char*) p; for (size_t i = 0; i < bytes; ++i) { key ^= q[i]; key *= 1099511628211ull; } };
+      mix(&shape, sizeof shape); mix(&bs, sizeof bs); mix(&A.cull_est_mt, 4); mix(&A.cull_est_mth, 4); mix(&ns, sizeof ns);
+      for (int s = 0; s < ns; ++s) {
+        const unsigned long long id[4] = {b->fixed[s]->uid, b->fixed[s]->version, b->moving[s]->uid, b->moving[s]->version};
+        mix(id, sizeof id); mix(&b->slices[s], sizeof(lsm2d_slice_params));
+        if (b->fixed_index) mix(b->fixed_index + (size_t) s * n, sizeof(int32_t) * (size_t) n);
+        if (b->moving_index) mix(b->moving_index + (size_t) s * n, sizeof(int32_t) * (size_t) n);
+      }
+      const bool reuse = ctx->estimate_reuse && notes && ctx->order_valid && ctx->order_key == key && ctx->order_poses.size() == 3 * (size_t) n &&
+                         !memcmp(ctx->order_poses.data(), b->init_pose, sizeof(float) * 3 * (size_t) n);
+      if (!reuse) {
+        size_t est_lds = sizeof(u64) * (size_t) A.s[bs].proj.cols; if (est_lds < sizeof(BalanceLds)) est_lds = sizeof(BalanceLds);
+        hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), est_lds, ctx->stream, A, bs, d_work, ctx->d_order,
+                           notes ? (const int32_t*) ctx->d_wg_place : (const int32_t*) nullptr, ctx->n_cu, (unsigned int*) (ctx->d_wg_place + 1024));
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {      // (round-4 advisor) a launch that failed may have left the ticket counter mid-count: the next call must not start mis-counted
+          (void) hipMemsetAsync(ctx->d_wg_place + 1024, 0, sizeof(int32_t), ctx->stream); ctx->order_valid = false;
+          HIPCHK(ctx, le);
+        }
+        ctx->last_cull_estimate = 1;
+        // (kept only once it was made WITH notes: the first call of a shape orders by the round-3 assumption, the second by what the first really did)
+        ctx->order_valid = notes; ctx->order_key = key;
+        if (notes) ctx->order_poses.assign(b->init_pose, b->init_pose + 3 * (size_t) n);
+      }
+      A.order = ctx->d_order;
       if (ctx->balance_notes && n <= 1024) { A.wg_place = ctx->d_wg_place; ctx->wg_place_shape = shape; }
     }
   }
@@ -2153,17 +2244,19 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   } else {
     const dim3 grid((unsigned) n), block(kAlignBlock);
     if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3((unsigned) (kAlignBlock * ns)), lds_pair, ctx->stream, A);
-    else if (has_proj && !has_nn && !has_dist && !has_kd && proj_culled_for_all) hipLaunchKernelGGL((k_align<true, false, false, false, 5>), grid, block, lds, ctx->stream, A);      // every slice: the culled stream
-    else if (has_proj && !has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<true, false, false>), grid, block, lds, ctx->stream, A);
-    else if (!has_proj && has_nn && !has_dist && !has_kd && A.nn_lds_points == 0) hipLaunchKernelGGL((k_align<false, true, false, false, 1>), grid, block, lds, ctx->stream, A);      // tables in global memory
-    else if (!has_proj && has_nn && !has_dist && !has_kd && nn_lds_for_all) hipLaunchKernelGGL((k_align<false, true, false, false, 2>), grid, block, lds, ctx->stream, A);      // tables in LDS, every alignment
-    else if (!has_proj && has_nn && !has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, true, false>), grid, block, lds, ctx->stream, A);
-    else if (!has_proj && !has_nn && has_dist && !has_kd) hipLaunchKernelGGL((k_align<false, false, true>), grid, block, lds, ctx->stream, A);
-    else if (!has_proj && !has_nn && !has_dist && has_kd && ns == 1 && ctx->kd_modes && A.kd_lds_points > 0) hipLaunchKernelGGL((k_align<false, false, false, true, 3>), grid, block, lds, ctx->stream, A);      // whole trees in LDS
-    else if (!has_proj && !has_nn && !has_dist && has_kd && ns == 1 && ctx->kd_modes && A.kd_lds_points == 0) hipLaunchKernelGGL((k_align<false, false, false, true, 4>), grid, block, lds, ctx->stream, A);     // only their tops
-    else if (!has_proj && !has_nn && !has_dist && has_kd) hipLaunchKernelGGL((k_align<false, false, false, true>), grid, block, lds, ctx->stream, A);
-    else if (!has_kd) hipLaunchKernelGGL((k_align<true, true, true>), grid, block, lds, ctx->stream, A);      // mixed finders
-    else hipLaunchKernelGGL((k_align<true, true, true, true>), grid, block, lds, ctx->stream, A);              // mixed finders, one of them the KD-tree
+    else {
+      // which instantiation: the finders the batch's slices use, and -- for a batch of ONE finder kind -- the form of its inner loop the host could prove
+      // serves every alignment (kNNMode of align_body).  One table (round 5; a 12-way ladder before); the mixed instantiations take whatever is left.
+      const unsigned finders = (has_proj ? kFProj : 0u) | (has_nn ? kFNN : 0u) | (has_dist ? kFDist : 0u) | (has_kd ? kFKd : 0u);
+      int mode = 0;
+      if (finders == kFProj) mode = proj_culled_for_all ? 5 : 0;                                                    // every slice: the culled stream over kept unit lists
+      else if (finders == kFNN) mode = A.nn_lds_points == 0 ? 1 : (nn_lds_for_all ? 2 : 0);                        // tables in global memory / in LDS for every alignment
+      else if (finders == kFKd && ns == 1 && ctx->kd_modes) mode = A.kd_lds_points > 0 ? 3 : 4;                    // whole trees in LDS / only their tops
+      AlignKernel fn = nullptr;
+      for (const AlignVariant& v : kAlignVariants) if (v.finders == finders && v.mode == mode) { fn = v.fn; break; }
+      if (!fn) fn = has_kd ? (AlignKernel) k_align<true, true, true, true> : (AlignKernel) k_align<true, true, true>;      // mixed finders
+      hipLaunchKernelGGL(fn, grid, block, lds, ctx->stream, A);
+    }
   }
   HIPCHK(ctx, hipGetLastError());
   for (int s = 0; s < ns; ++s)                  // sets the kernel's prologue unpacks (SliceDev::unpack_src)
@@ -2174,6 +2267,11 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   else if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (zero_copy) HIPCHK(ctx, wait_for_statuses(ctx, (const int32_t*) (hs + o_status), n));
   else HIPCHK(ctx, stream_sync(ctx));
+  {
+    static_assert(kStatusNotWritten == -1, "the memsets above write 0xFF bytes");
+    const int32_t* st = (const int32_t*) (hs + o_status);
+    for (int i = 0; i < n; ++i) if (st[i] == kStatusNotWritten) { ctx->order_valid = false; return fail(ctx, LSM2D_DEVICE_ERROR, "align_batch: an alignment's workgroup never reported (placement or launch fault)"); }
+  }
   memcpy(out_pose, hs + o_pose, sizeof(float) * 3 * (size_t) n);
   if (out_H) memcpy(out_H, hs + o_H, sizeof(float) * 9 * (size_t) n);
   memcpy(out_status, hs + o_status, sizeof(int32_t) * (size_t) n);

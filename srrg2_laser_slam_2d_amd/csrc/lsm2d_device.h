@@ -420,6 +420,7 @@ LSM2D_DEV void project_cloud_list(const float4* __restrict__ lane_xy, int T_step
   else project_cloud_list_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
 }
 
+#ifdef LSM2D_EXPERIMENTS      // ("cull" 2: measured 3 % slower than the block units, DESIGN App. A; compiled into the experiments build only)
 // The same survivors, balanced to within one step: the s surviving chunks x T steps form a matrix (row = step t, column = survivor i);
 // thread u takes the elements u, u + nthreads, ... of its row-major order.  The lanes of a wave then hold consecutive survivors at the SAME
 // step -- their 16-byte loads fall into one row of the copy, and they stay a chunk apart along the map -- and every thread gets
@@ -472,6 +473,7 @@ LSM2D_DEV void project_cloud_rows(const float4* __restrict__ lane_xy, int T_step
   if (P.tiny_ok) project_cloud_rows_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads, surv, s);
   else project_cloud_rows_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads, surv, s);
 }
+#endif
 
 LSM2D_DEV void project_cloud_units(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P, u64* canvas, int tid, int nthreads,
                                    const uint16_t* surv, int s, int B, int nb) {

@@ -19,6 +19,14 @@
 namespace lsm2d {
 
 static constexpr int kMaxSlices = 4;
+// Measured-and-rejected experiments (DESIGN App. A) are compiled only into a -DLSM2D_EXPERIMENTS build of the library (round 5): the second launch form of
+// a culled batch (k_first_iteration / k_balance_only), the row-major culled stream ("cull" 2), the round-3 stream's block-length knob ("cull_block") and the
+// A/B option keys of lsm2d_capi.hip.  The shipped library carries none of them; their bit-identity tests run against the experiments build only.
+#ifdef LSM2D_EXPERIMENTS
+static constexpr bool kExperiments = true;
+#else
+static constexpr bool kExperiments = false;
+#endif
 // exact culling of a projective slice's moving cloud (k_align): a thread's chunk of T steps is cut into at most kCullBlocks blocks of B steps
 static constexpr int kCullBlocks = 7;
 LSM2D_HD int cull_block_steps(int T) { return 2 * ((T + 13) / 14); }      // even; ceil(T / B) <= 7 for every T >= 1
@@ -1503,7 +1511,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
     }
     if (A.out_last_pose) { A.out_last_pose[3 * a + 0] = s_pose[0]; A.out_last_pose[3 * a + 1] = s_pose[1]; A.out_last_pose[3 * a + 2] = s_pose[2]; }
   };
-  const bool resumed = kProjCulled && !kFirstStage && A.stage == 2;      // the second of two launches: the alignment goes on where k_first_iteration left it
+  const bool resumed = kExperiments && kProjCulled && !kFirstStage && A.stage == 2;      // the second of two launches: the alignment goes on where k_first_iteration left it
   if (tid == 0) {
     if (resumed) {
       const ResumeDev R = A.resume[a];
@@ -1542,6 +1550,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
   if (kNNLds && !nn_lds) {      // cannot happen (the host sized the staging for the set's largest cloud): refuse loudly rather than search tables that are not there
     if (tid == 0) {
       A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
+      if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = 0.0f;      // (no iteration ran: the information matrix is the zero the regular path would hand back)
       if (A.out_its) A.out_its[a] = 0;
       if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], (int) LSM2D_CAPACITY_EXCEEDED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
       else A.out_status[a] = LSM2D_CAPACITY_EXCEEDED;
@@ -1581,6 +1590,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
   if (kKdAllLds && !kd_leaves_lds) {      // cannot happen (the host sized the staging for the set's largest tree): refuse loudly, as above
     if (tid == 0) {
       A.out_pose[3 * a + 0] = s_pose[0]; A.out_pose[3 * a + 1] = s_pose[1]; A.out_pose[3 * a + 2] = s_pose[2];
+      if (A.out_H) for (int k = 0; k < 9; ++k) A.out_H[9 * a + k] = 0.0f;      // (no iteration ran: the information matrix is the zero the regular path would hand back)
       if (A.out_its) A.out_its[a] = 0;
       if (A.host_polls) { __threadfence_system(); __hip_atomic_store(&A.out_status[a], (int) LSM2D_CAPACITY_EXCEEDED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
       else A.out_status[a] = LSM2D_CAPACITY_EXCEEDED;
@@ -1722,10 +1732,13 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
             // blocks of an even number of steps, 7 per chunk (measured on configs[1], T = 98: blocks of 2 / 4 / 6 / 8 / 14 steps 1.098 / 1.017 /
             // 0.991 / 0.983 / 0.969 ms -- what a unit costs to set up outweighs the better balance of smaller ones; element-wise row-major
             // order, balanced to one step, 1.066: project_cloud_rows, "cull" 2)
-            const int B = A.cull_block > 0 ? A.cull_block : 2 * ((Tm + 13) / 14), nb = (Tm + B - 1) / B;
+            const int B = (kExperiments && A.cull_block > 0) ? A.cull_block : cull_block_steps(Tm), nb = (Tm + B - 1) / B;
             if (n_surv > 0) {
+#ifdef LSM2D_EXPERIMENTS
               if (!kProjCulled && A.cull == 2) project_cloud_rows(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv);
-              else project_cloud_units(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv, B, nb);
+              else
+#endif
+              project_cloud_units(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, s_surv, n_surv, B, nb);
             }
           }
           else if (S.moving.lane_xy) project_cloud_lanes(S.moving.lane_xy + S.moving.lane_start[mc], S.moving.lane_T[mc], T, S.proj, mcan, tid, kAlignBlock);
@@ -1999,8 +2012,21 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
     else A.out_status[a] = st;
   }
 }
+// Registers: 8 waves per SIMD (64 VGPRs, four workgroups per CU) for every single-finder instantiation.  The MIXED instantiations (a projective slice next to a
+// point-query slice in one aligner: all forms of all finders in one body) spilled 176 bytes per thread at that budget; they are given 4 waves per SIMD
+// (128 VGPRs, two workgroups per CU) and have no private segment -- a configuration no BASELINE workload uses (round 5; tools/isa_dump.sh prints every kernel's frame).
+#ifndef LSM2D_MIXED_MIN_WAVES
+#define LSM2D_MIXED_MIN_WAVES 4
+#endif
+#ifndef LSM2D_NNGLOBAL_MIN_WAVES
+#define LSM2D_NNGLOBAL_MIN_WAVES LSM2D_QUERY_MIN_WAVES      // k_align<0,1,0,0,1>: A/B knob (6: 80 VGPRs, no frame, three workgroups per CU)
+#endif
+template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd, int kNNMode>
+constexpr int align_min_waves() {
+  return (kHasProj && (kHasNN || kHasDist || kHasKd)) ? LSM2D_MIXED_MIN_WAVES : kHasProj ? LSM2D_ALIGN_MIN_WAVES : kNNMode == 1 ? LSM2D_NNGLOBAL_MIN_WAVES : LSM2D_QUERY_MIN_WAVES;
+}
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
-__global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LSM2D_QUERY_MIN_WAVES)) void k_align(const AlignArgs A) {
+__global__ __launch_bounds__(kAlignBlock, (align_min_waves<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode>())) void k_align(const AlignArgs A) {
   align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false>(A);
 }
 // Round 4 (late): TWO launches for a culled batch of about one dispatch round.  The placement of such a batch decides its tail (the launch lasts as long as
@@ -2013,9 +2039,11 @@ __global__ __launch_bounds__(kAlignBlock, (kHasProj ? LSM2D_ALIGN_MIN_WAVES : LS
 // instead of 0.745 -- but a twentieth of that is the iteration it no longer runs, its tail is still 7 % (the length of a list is not the whole of an
 // alignment's cost), and this kernel takes 95 us for its twentieth of the work: all thousand workgroups are in the same phase at the same time, and the
 // phases that wait (prologue, list building, barriers) have no other workgroup's stream to hide under.  0.861 vs 0.836 ms per step.
+#ifdef LSM2D_EXPERIMENTS
 __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_first_iteration(const AlignArgs A) {
   align_body<true, false, false, false, 5, true>(A);
 }
+#endif
 
 // ---- balanced placement for culled batches -------------------------------------------------------------------------------------------
 // With the exact culling an alignment's work depends on its pose and scan (33 .. 59 % of the map's chunks survive on configs[1]), and a
@@ -2184,8 +2212,12 @@ __global__ __launch_bounds__(kAlignBlock) void k_cull_estimate(const AlignArgs A
   if (tid == 0) {
     // no fences (an agent-scope release writes the XCD's L2 back, a thousand times over): the count goes out as a RETURNING agent-scope exchange -- performed
     // where all XCDs meet once its value is back -- and the ticket's increment depends on that value, so the ticket cannot be taken before the count is there
+    // (round 5: the dependence is on the exchange's ARRIVAL, never on what it returned -- work[] is scratch nobody clears, and an increment computed from its stale
+    // contents (round 4: `1 + (was == INT_MIN)`, -0.0f of an earlier call's pose is exactly that pattern) could jump the ticket past a workgroup that had not published yet)
     const int was = __hip_atomic_exchange(&work[a], n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int before = __hip_atomic_fetch_add(done_counter, 1u + (was == INT_MIN ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (counts are >= 0)
+    unsigned int inc = 1u;
+    asm volatile("" : "+v"(inc) : "v"(was));      // `inc` cannot be formed before `was` is in its register: the ticket waits for the exchange, whatever value came back
+    const unsigned int before = __hip_atomic_fetch_add(done_counter, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = before + 1u == gridDim.x;
   }
   __syncthreads();
@@ -2195,10 +2227,12 @@ __global__ __launch_bounds__(kAlignBlock) void k_cull_estimate(const AlignArgs A
   if (tid == 0) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next call
 }
 
+#ifdef LSM2D_EXPERIMENTS
 __global__ __launch_bounds__(kAlignBlock) void k_balance_only(const int32_t* __restrict__ work, int n, int n_cu, int32_t* __restrict__ order, const int32_t* __restrict__ place) {
   extern __shared__ __align__(16) unsigned char smem[];      // BalanceLds
   balance_order(*reinterpret_cast<BalanceLds*>(smem), work, n, n_cu, 4, order, place, threadIdx.x, kAlignBlock);
 }
+#endif
 
 // ---- the latency kernel: one alignment per workgroup, tuned for calls that cannot fill the chip ------------------
 // (one or two projective slices; with two, side by side)

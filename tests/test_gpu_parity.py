@@ -12,7 +12,7 @@ import math
 import numpy as np
 import pytest
 
-from conftest import golden_path
+from conftest import golden_path, has_experiments, need_experiments, xset
 from srrg2_laser_slam_2d_amd import api, synth
 
 pytestmark = pytest.mark.gpu
@@ -2299,14 +2299,17 @@ def test_kdtree_finder_bit_exact_both_roles(ctx, po, n_map):
         for role, (fixed, moving, pose) in enumerate(((scan, wl.map_points, x), (wl.map_points, scan, xb))):     # role A (tracker wiring), role B (BASELINE wording)
             want = po.find(osp, fixed, moving, pose)
             assert len(want) > 300
-            for chain, wide in ((1, 4096), (0, 4096), (1, 0)):      # (round 4: a workgroup per node on the top levels of a map-sized cloud, or a wave per node throughout)
-                ctx.set_option("kd_chain", chain); ctx.set_option("kd_wide_min_points", wide)
+            # (round 4: a workgroup per node on the top levels of a map-sized cloud, or a wave per node throughout; the first pair is what the library ships with,
+            # the others are forced through knobs of the experiments build)
+            for chain, wide in ((1, 1024), (1, 4096), (0, 4096), (1, 0)):
                 try:
+                    if not xset(ctx, kd_chain=chain, kd_wide_min_points=wide):
+                        continue
                     f = _kd_finder(ctx, 0.5, leaf_range, leaf_points)
                     f.setFixed(fixed); f.setMoving(moving); f.setLocalMapInSensor(pose)
                     got = f.compute()
                 finally:
-                    ctx.set_option("kd_chain", 1); ctx.set_option("kd_wide_min_points", 4096)
+                    xset(ctx, kd_chain=1, kd_wide_min_points=1024)
                 assert np.array_equal(got, want), (n_map, role, leaf_range, chain, wide, len(got), len(want))
             # the tree is approximate by construction: it must NOT be the exact search (else this test would not tell the two apart)
             ex = po.find(po.slice_params(finder=po.FINDER_NN, max_distance=0.5, normal_cos=0.8), fixed, moving, pose)
@@ -2363,10 +2366,10 @@ def test_aligner_kdtree_both_roles_bitwise(ctx, po):
     x0_b = synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32); xt_b = synth.invert_poses(wl.x_true)
     fixed = api.CloudSet(ctx, wl.map_points); moving = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
     results = []
-    for lds_nodes, modes in ((1024, 1), (0, 1), (37, 1), (1024, 0)):      # (modes 0: the shared instantiation with both forms of the descent)
-        ctx.set_option("kd_lds_nodes", lds_nodes); ctx.set_option("kd_modes", modes)
-        results.append(_kd_aligner(ctx).compute_batch([fixed], [moving], x0_b, want_stats=True))
-    ctx.set_option("kd_lds_nodes", 1024); ctx.set_option("kd_modes", 1)
+    for lds_nodes, modes in ((1024, 1), (0, 1), (37, 1), (1024, 0)):      # (modes 0: the shared instantiation with both forms of the descent -- experiments build)
+        if xset(ctx, kd_lds_nodes=lds_nodes, kd_modes=modes):
+            results.append(_kd_aligner(ctx).compute_batch([fixed], [moving], x0_b, want_stats=True))
+    xset(ctx, kd_lds_nodes=1536, kd_modes=1)
     res = results[0]
     for other in results[1:]:
         assert np.array_equal(res.pose, other.pose) and np.array_equal(res.information, other.information) and np.array_equal(res.status, other.status)
@@ -2382,12 +2385,12 @@ def test_aligner_kdtree_both_roles_bitwise(ctx, po):
     fixed2 = api.CloudSet(ctx, wl2.scan_points, wl2.scan_offsets); moving2 = api.CloudSet(ctx, wl2.map_points)
     al = _kd_aligner(ctx, md=0.3, leaf_range=0.03, leaf_points=10, robustifier=api.RobustifierCauchy(0.05))
     res2 = al.compute_batch([fixed2], [moving2], wl2.x0, want_stats=True)
-    ctx.set_option("kd_modes", 0)
-    try:
-        shared = al.compute_batch([fixed2], [moving2], wl2.x0, want_stats=True)
-    finally:
-        ctx.set_option("kd_modes", 1)
-    assert np.array_equal(res2.pose, shared.pose) and np.array_equal(res2.information, shared.information) and np.array_equal(res2.stats, shared.stats)
+    if xset(ctx, kd_modes=0):
+        try:
+            shared = al.compute_batch([fixed2], [moving2], wl2.x0, want_stats=True)
+        finally:
+            xset(ctx, kd_modes=1)
+        assert np.array_equal(res2.pose, shared.pose) and np.array_equal(res2.information, shared.information) and np.array_equal(res2.stats, shared.stats)
     osp2 = po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, kd_max_leaf_range=0.03, kd_min_leaf_points=10, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.05)
     for i in (0, 3, 5):
         s = wl2.scan_points[wl2.scan_offsets[i]:wl2.scan_offsets[i + 1]]
@@ -2587,14 +2590,13 @@ def test_culling_and_placement_change_no_bit(ctx, po):
     wl = synth.make_workload(600, 60000, seed=8)
     shuffled = wl.map_points[np.argsort(synth.Stream(3).uniform(len(wl.map_points)))]
     fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
-    def run(al, moving_sets, **opts):
-        for k, v in opts.items():
-            ctx.set_option(k, v)
+    def run(al, moving_sets, **opts):      # None: a variant only the experiments build of the library has
         try:
+            if not xset(ctx, **opts):
+                return None
             return al.compute_batch([fixed] * len(moving_sets), moving_sets, wl.x0, want_stats=True)
         finally:
-            ctx.set_option("cull", 1); ctx.set_option("balance", 1); ctx.set_option("cull_block", 0); ctx.set_option("proj_modes", 1); ctx.set_option("balance_notes", 1); ctx.set_option("two_stage", 0)
-            ctx.set_option("cull_est_um", 0); ctx.set_option("cull_est_urad", 40000)
+            xset(ctx, cull=1, balance=1, xcd_window=0, cull_block=0, proj_modes=1, balance_notes=1, two_stage=0, cull_est_um=0, cull_est_urad=40000, estimate_reuse=1, cull_keep=1)
     for name, mp in (("ordered", wl.map_points), ("shuffled", shuffled)):
         moving = api.CloudSet(ctx, mp)
         for tag, al in (("plain", _aligner(ctx)), ("cauchy 270 deg", _aligner(ctx, robustifier=api.RobustifierCauchy(0.05)))):
@@ -2604,8 +2606,14 @@ def test_culling_and_placement_change_no_bit(ctx, po):
             # (proj_modes 0: the shared instantiation instead of the one with the culled stream only)
             # (round 4: the placement groups workgroup ids by the CU the previous launch of the same shape ran them on -- the second and third plain
             # runs below place by the first one's notes --, "balance_notes" 0: by the round-3 assumption; other margins in the work estimate)
-            for opts in (dict(cull=1), dict(cull=1), dict(cull=1, two_stage=1), dict(cull=1, cull_est_um=60000, cull_est_urad=0), dict(cull=1, balance_notes=0), dict(cull=1, two_stage=1, balance_notes=0), dict(cull=1, balance=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98), dict(cull=1, proj_modes=0)):
+            # (round 5: the third plain run finds the second one's batch unchanged and keeps its placement -- no estimate launch; "estimate_reuse" 0: made afresh;
+            # "xcd_window": the workgroups of an XCD walk the map's blocks in step; everything from "two_stage" on lives in the experiments build only)
+            for opts in (dict(cull=1), dict(cull=1), dict(cull=1), dict(cull=1, xcd_window=1), dict(cull=1, xcd_window=3, balance=0), dict(cull=1, balance=0), dict(cull=1, estimate_reuse=0),
+                         dict(cull=1, two_stage=1), dict(cull=1, cull_est_um=60000, cull_est_urad=0), dict(cull=1, balance_notes=0),
+                         dict(cull=1, two_stage=1, balance_notes=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98), dict(cull=1, proj_modes=0), dict(cull=1, cull_keep=0)):
                 got = run(al, [moving], **opts)
+                if got is None:
+                    continue
                 assert np.array_equal(got.pose, ref.pose) and np.array_equal(got.information, ref.information), (name, tag, opts)
                 assert np.array_equal(got.status, ref.status) and np.array_equal(got.iterations, ref.iterations) and np.array_equal(got.stats, ref.stats), (name, tag, opts)
     # two projective slices (the same clouds twice, different gates): culling per slice
@@ -2646,12 +2654,12 @@ def test_culling_and_placement_change_no_bit(ctx, po):
             if name == "ordered" and finder.param_max_distance_m > 0.1:
                 assert (a.status == 0).mean() > 0.9, (finder.search, (a.status == 0).mean())
             if name in ("ordered", "far"):      # the instantiations with one form of the search only (grid NN without the search in global memory, KD-tree with the whole tree in LDS) against the shared ones
-                ctx.set_option("nn_lds_only", 0); ctx.set_option("kd_modes", 0)
-                try:
-                    s0 = al.compute_batch([fixed], [moving], x0, want_stats=True)
-                finally:
-                    ctx.set_option("nn_lds_only", 1); ctx.set_option("kd_modes", 1)
-                assert np.array_equal(s0.pose, c.pose, equal_nan=True) and np.array_equal(s0.information, c.information, equal_nan=True) and np.array_equal(s0.stats, c.stats), name
+                if xset(ctx, nn_lds_only=0, kd_modes=0):
+                    try:
+                        s0 = al.compute_batch([fixed], [moving], x0, want_stats=True)
+                    finally:
+                        xset(ctx, nn_lds_only=1, kd_modes=1)
+                    assert np.array_equal(s0.pose, c.pose, equal_nan=True) and np.array_equal(s0.information, c.information, equal_nan=True) and np.array_equal(s0.stats, c.stats), name
 
 
 def test_two_kdtree_slices_build_their_scans_trees_in_one_launch(ctx, po):
@@ -2676,16 +2684,17 @@ def test_two_kdtree_slices_build_their_scans_trees_in_one_launch(ctx, po):
             b2 = wl.scan_points[wl.scan_offsets[2 * step + 1]:wl.scan_offsets[2 * step + 2]]
             x0 = wl.x0[2 * step][None, :]
             got = {}
-            for scan_max in (8, 0):
-                ctx.set_option("kd_scan_max_clouds", scan_max)
+            for scan_max in (8, 0):      # (0: each tree by the workgroup build of its own call -- a knob of the experiments build)
+                if not xset(ctx, kd_scan_max_clouds=scan_max):
+                    continue
                 m0.upload(a); m1.upload(b2)           # new scans: both trees are rebuilt
                 got[scan_max] = al.compute_batch([m0, m1], [sc, sc], x0, want_stats=True)
-            g, h = got[8], got[0]
+            g, h = got[8], got.get(0, got[8])
             assert np.array_equal(g.pose, h.pose) and np.array_equal(g.information, h.information) and np.array_equal(g.status, h.status) and np.array_equal(g.stats, h.stats), step
             rt = po.align(po.aligner_params(8, min_num_inliers=5, device_order=True), osp, [a, b2], [scene, scene], x0[0])
             _assert_bitwise_equal_to_device_order_oracle(g, 0, rt, ("two kd slices", step))
     finally:
-        ctx.set_option("kd_scan_max_clouds", 8)
+        xset(ctx, kd_scan_max_clouds=8)
 
 
 def test_prepared_batch_equals_compute_batch(ctx, small_workload):
@@ -2713,6 +2722,7 @@ def test_two_launches_for_one_batch_change_no_bit(ctx, po):
     launch, bit for bit: poses, information matrices, statuses,
     iteration counts, every iteration's statistics and digest -- with the termination criterion, the inlier-only runs, the Cauchy kernel, two slices, the
     shortest loop that is split at all (4 iterations), start poses that fail in iteration 0 (they finish in the first launch) -- and the oracle agrees."""
+    need_experiments(ctx)
     wl = synth.make_workload(300, 60000, seed=21)
     fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
     x0 = wl.x0.copy(); x0[::11, 0] += 250.0; x0[5::17, 2] += 1.2      # some alignments start beyond the map / badly rotated
@@ -2864,13 +2874,13 @@ def test_grid_nn_over_the_map_position_search_ties_and_cell_cache(ctx, po):
     al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=0.4, normal_cos=0.7, search="exact"),
                                                                       min_num_correspondences=10, robustifier=api.RobustifierCauchy(0.03)))
     res = {}
-    for cache in (1, 0):
-        ctx.set_option("nn_qcache", cache)
+    for cache in (1, 0):      # (0: without the per-query cell cache -- a knob of the experiments build)
         try:
-            res[cache] = al.compute_batch([fixed], [moving], x0_b, want_stats=True)
+            if xset(ctx, nn_qcache=cache):
+                res[cache] = al.compute_batch([fixed], [moving], x0_b, want_stats=True)
         finally:
-            ctx.set_option("nn_qcache", 1)
-    a, c = res[1], res[0]
+            xset(ctx, nn_qcache=1)
+    a, c = res[1], res.get(0, res[1])
     assert np.array_equal(a.pose, c.pose) and np.array_equal(a.information, c.information) and np.array_equal(a.status, c.status) and np.array_equal(a.stats, c.stats)
     assert np.all(a.status == 0)
     osp = po.slice_params(finder=po.FINDER_NN, max_distance=0.4, normal_cos=0.7, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.03, min_num_correspondences=10)
@@ -3046,8 +3056,10 @@ def test_kdtree_single_launch_build_equals_the_level_loop(ctx, po):
     try:
         # 100: the scans go through the level loop, the tiny clouds through the workgroup build (a mixed set); the level loop with a WORKGROUP per node
         # (kd_node_wide: "kd_wide_min_points", by default only the top levels of a map-sized cloud) on every level that holds 64 / 1000 points per node
-        for wg, wide in ((16384, 4096), (0, 0), (100, 0), (0, 64), (100, 1000)):
-            ctx.set_option("kd_wg_max_points", wg); ctx.set_option("kd_wide_min_points", wide)
+        # (the first pair is what the library ships with; the others force the other forms of the build through knobs of the experiments build)
+        for wg, wide in ((16384, 1024), (16384, 4096), (0, 0), (100, 0), (0, 64), (100, 1000)):
+            if not xset(ctx, kd_wg_max_points=wg, kd_wide_min_points=wide):
+                continue
             cs = api.CloudSet(ctx, allp, offs_all)
             out = []
             for lr, lp in ((1e-2, 20), (0.05, 7)):
@@ -3059,16 +3071,16 @@ def test_kdtree_single_launch_build_equals_the_level_loop(ctx, po):
             res[(wg, wide)] = out
             cs.close()
     finally:
-        ctx.set_option("kd_wg_max_points", 16384); ctx.set_option("kd_wide_min_points", 4096)
+        xset(ctx, kd_wg_max_points=16384, kd_wide_min_points=1024)
     for key in res:
-        assert len(res[key]) == len(res[(16384, 4096)])
-        for a, b in zip(res[(16384, 4096)], res[key]):
+        assert len(res[key]) == len(res[(16384, 1024)])
+        for a, b in zip(res[(16384, 1024)], res[key]):
             assert np.array_equal(a, b), key
     k = 0
     for lr, lp in ((1e-2, 20), (0.05, 7)):
         for ci in (0, 5, 23, 24, 27, 29, len(clouds) - 1):
             want = po.find(po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=0.3, normal_cos=0.5, kd_max_leaf_range=lr, kd_min_leaf_points=lp), clouds[ci], m[::7], x0)
-            assert np.array_equal(res[(16384, 4096)][k + ci], want), (lr, lp, ci)
+            assert np.array_equal(res[(16384, 1024)][k + ci], want), (lr, lp, ci)
         k += len(clouds) + 1
     # the LATENCY form (k_kd_build_scan: a set of at most "kd_scan_max_clouds" clouds of <= 1280 points, working set in LDS, sixteen waves, groups of four
     # waves on the levels with few nodes): one scan; eight clouds with the degenerate ones among them; both forms of the chains -- against the workgroup
@@ -3080,7 +3092,8 @@ def test_kdtree_single_launch_build_equals_the_level_loop(ctx, po):
             ap_ = np.concatenate(cl, 0)
             got = {}
             for scan_max, chain in ((8, 1), (8, 0), (0, 1)):
-                ctx.set_option("kd_scan_max_clouds", scan_max); ctx.set_option("kd_chain", chain)
+                if not xset(ctx, kd_scan_max_clouds=scan_max, kd_chain=chain):
+                    continue
                 cs = api.CloudSet(ctx, ap_, o)
                 out = []
                 for lr, lp in ((1e-2, 20), (0.05, 7)):
@@ -3092,7 +3105,7 @@ def test_kdtree_single_launch_build_equals_the_level_loop(ctx, po):
                 got[(scan_max, chain)] = out
                 cs.close()
             for key in got:
-                for a, b in zip(got[(0, 1)], got[key]):
+                for a, b in zip(got[(8, 1)], got[key]):
                     assert np.array_equal(a, b), (key, [len(q) for q in cl])
             k = 0
             for lr, lp in ((1e-2, 20), (0.05, 7)):
@@ -3101,4 +3114,4 @@ def test_kdtree_single_launch_build_equals_the_level_loop(ctx, po):
                     assert np.array_equal(got[(8, 1)][k + ci], want), (lr, lp, ci, len(cl[ci]))
                 k += len(cl) + 1
     finally:
-        ctx.set_option("kd_scan_max_clouds", 8); ctx.set_option("kd_chain", 1)
+        xset(ctx, kd_scan_max_clouds=8, kd_chain=1)
