@@ -207,9 +207,10 @@ def main() -> None:
     side = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(side)
     ctx = api.Context(local_rank, stream=side.cuda_stream)
-    for kv in filter(None, os.environ.get("LSM2D_BENCH_OPTIONS", "").split(",")):      # tuning experiments: context options as key=value pairs
+    options_set = {}
+    for kv in filter(None, os.environ.get("LSM2D_BENCH_OPTIONS", "").split(",")):      # tuning experiments: context options as key=value pairs (printed in the line)
         k_opt, _, v_opt = kv.partition("=")
-        ctx.set_option(k_opt.strip(), int(v_opt))
+        ctx.set_option(k_opt.strip(), int(v_opt)); options_set[k_opt.strip()] = int(v_opt)
     map_set = api.CloudSet(ctx, map_dev)                      # stays in HBM, no host copy
     scan_set = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets)
     if args.finder == "projective":
@@ -456,6 +457,8 @@ def main() -> None:
             "parity_ok": ok, "max_pose_err_m": float(err[:, :2].max()), "max_pose_err_rad": float(err[:, 2].max()),
             "roofline": roof,
         }
+        if options_set:
+            out["options"] = options_set
         if cross:
             out["cross_rank_check"] = cross
         if per_rank_ms is not None:

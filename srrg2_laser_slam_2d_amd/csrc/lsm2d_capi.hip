@@ -58,6 +58,7 @@ struct lsm2d_context {
                                // 0.861 vs 0.836 ms per step.  Off; kept as an A/B knob with its bit-identity test
   int balance_notes = 1;       // ... group the workgroup ids by the CU the previous launch of the same shape ran them on (0: assume b, b + n_cu, ...; A/B knob)
   int32_t* d_wg_place = nullptr; unsigned long long wg_place_shape = 0;      // the notes (one int per workgroup) and the launch shape they belong to
+  uint32_t* d_xcd = nullptr; size_t d_xcd_bytes = 0;                         // the XCD window's counters (AlignArgs::xcd_sync), cleared per launch
   int32_t* d_order = nullptr;                                                // [4096] the placement the latest estimate made: kept for the next run of the SAME batch (order_valid / order_key / order_poses)
   int proj_modes = 1;          // projective batches against map-sized clouds: the instantiation with the culled stream only (0: the shared one; A/B knob)
   int kd_modes = 1;            // KD-tree batches: the instantiations with one form of the descent only (0: the shared one; A/B knob)
@@ -87,6 +88,7 @@ struct lsm2d_context {
       0;
 #endif
   int estimate_reuse = 1;      // a prepared batch run again with unchanged start poses keeps its placement (no k_cull_estimate launch); experiments build: 0 switches that off
+  int last_xcd_window = 0;     // the window the latest aligner call ran with (0: free-running)
   int last_cull_estimate = 0;  // what the latest aligner call did about the placement's estimate ("last_cull_estimate")
   bool order_valid = false; unsigned long long order_key = 0; std::vector<float> order_poses;      // the placement d_order holds: which batch it was made for
   int last_query_cull = 0;     // the latest aligner call ran its point-query finder with the exact culling of the queries (k_align, tiles of 64 moving points)
@@ -156,6 +158,7 @@ struct lsm2d_cloudset {
   mutable float4* d_lane_xy = nullptr; mutable long long* d_lane_start = nullptr; mutable int32_t* d_lane_T = nullptr;
   mutable float4* d_lane_bounds = nullptr;      // bounding circle of every thread's chunk of every cloud (k_lane_bounds): what the culling tests
   mutable float4* d_block_bounds = nullptr;     // ... and of every block of every chunk (k_block_bounds): the block-level test of the unit lists
+  mutable int32_t block_stride = kCullBlocks;   // blocks per chunk in d_block_bounds: kCullBlocksMax for a set that holds a map-sized cloud (cull_blocks_for)
   mutable float4* d_aos = nullptr;              // (x, y, nx, ny) rows of the whole set (k_aos_rows): one gather per z-buffer winner in k_align's bin walk
   mutable float4* d_tile_bounds = nullptr; mutable int32_t* d_tile_start = nullptr;      // bounding circles of the tiles of 64 points (k_tile_bounds): the point-query finders' culling
   int32_t n_clouds = 0;
@@ -250,6 +253,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align<true, false, false, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -287,6 +291,7 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->d_kd_work) (void) hipFree(c->d_kd_work);
   if (c->d_wg_place) (void) hipFree(c->d_wg_place);
   if (c->d_order) (void) hipFree(c->d_order);
+  if (c->d_xcd) (void) hipFree(c->d_xcd);
   for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
   if (c->ev1) (void) hipEventDestroy(c->ev1);
@@ -335,6 +340,7 @@ const OptionDesc kOptions[] = {
   {"max_dyn_lds",        &lsm2d_context::max_dyn_lds,        0, 0, kOptReadOnly},      // bytes of LDS one workgroup may ask for
   {"uploads",            &lsm2d_context::uploads,            0, 0, kOptReadOnly},      // host-to-device cloud uploads this context has queued so far (lsm2d_cloudset_create / _upload)
   {"last_cull_estimate", &lsm2d_context::last_cull_estimate, 0, 0, kOptReadOnly},      // 1: the latest aligner call launched the placement's estimate; 0: it reused the order of an unchanged prepared batch, or needed none
+  {"last_xcd_window",    &lsm2d_context::last_xcd_window,    0, 0, kOptReadOnly},
   {"experiments",        &lsm2d_context::experiments,        0, 0, kOptReadOnly},
 #ifdef LSM2D_EXPERIMENTS
   // ---- A/B knobs of the experiments build (tests/test_gpu_experiments.py; each one's measurement: DESIGN App. A)
@@ -757,7 +763,7 @@ static bool make_projk(const lsm2d_projector& p, ProjK* k) {
 static CloudDev cloud_dev(const lsm2d_cloudset* cs, const int32_t* d_index) {
   CloudDev c; c.xy = cs->d_xy; c.nrm = cs->d_nrm; c.start = cs->d_start; c.count = cs->d_count; c.index = d_index; c.n_clouds = cs->n_clouds;
   c.lane_xy = cs->d_lane_xy; c.lane_start = cs->d_lane_start; c.lane_T = cs->d_lane_T; c.lane_bounds = cs->d_lane_bounds;
-  c.block_bounds = cs->d_block_bounds; c.aos = cs->d_aos;
+  c.block_bounds = cs->d_block_bounds; c.block_stride = cs->block_stride; c.aos = cs->d_aos;
   c.tile_bounds = cs->d_tile_bounds; c.tile_start = cs->d_tile_start;
   c.grid = GridDev{nullptr, nullptr, nullptr, nullptr, nullptr};
   c.dist = DistDev{nullptr, nullptr};
@@ -1087,11 +1093,12 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
   // block circles: 57 KB per cloud.  They are what the kept unit lists are built from -- worth it for a map or a few thousand big clouds, not for tens of
   // thousands of scan-sized moving clouds (round-4 advisor: several GB there): beyond 256 MB the set goes without them and its batches run the chunk-level
   // stream of the shared instantiation (proj_culled_for_all needs block_bounds)
-  const bool want_blocks = sizeof(float4) * (size_t) nc * kCullBlocks * kAlignBlock <= ((size_t) 256 << 20);
+  const int nbs = cull_blocks_for(maxT);      // 7 blocks per chunk, 14 when the set holds a map-sized cloud (lsm2d_kernels.h)
+  const bool want_blocks = sizeof(float4) * (size_t) nc * nbs * kAlignBlock <= ((size_t) 256 << 20);
   DevTmp t_xy, t_bounds, t_blocks, t_start, t_T;
   HIPCHK(ctx, hipMalloc(&t_xy.p, sizeof(float4) * (size_t) slots));
   HIPCHK(ctx, hipMalloc(&t_bounds.p, sizeof(float4) * (size_t) nc * kAlignBlock));
-  if (want_blocks) HIPCHK(ctx, hipMalloc(&t_blocks.p, sizeof(float4) * (size_t) nc * kCullBlocks * kAlignBlock));
+  if (want_blocks) HIPCHK(ctx, hipMalloc(&t_blocks.p, sizeof(float4) * (size_t) nc * nbs * kAlignBlock));
   HIPCHK(ctx, hipMalloc(&t_start.p, sizeof(long long) * (size_t) nc));
   HIPCHK(ctx, hipMalloc(&t_T.p, sizeof(int32_t) * (size_t) nc));
   float4* d_xy = (float4*) t_xy.p; float4* d_bounds = (float4*) t_bounds.p; float4* d_blocks = (float4*) t_blocks.p;
@@ -1108,13 +1115,14 @@ static int ensure_lane_layout(lsm2d_context* ctx, const lsm2d_cloudset* cs) {
     hipLaunchKernelGGL(k_lane_bounds, dim3((unsigned) (kAlignBlock / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
                        (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) d_T, (int) kAlignBlock, d_bounds, c0);
     if (want_blocks)
-      hipLaunchKernelGGL(k_block_bounds, dim3((unsigned) (kAlignBlock * kCullBlocks / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
-                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) d_T, (int) kAlignBlock, d_blocks, c0);
+      hipLaunchKernelGGL(k_block_bounds, dim3((unsigned) (kAlignBlock * nbs / 4), (unsigned) ny), dim3(256), 0, ctx->stream, (const float2*) cs->d_xy,
+                         (const int32_t*) cs->d_start, (const int32_t*) cs->d_count, (const int32_t*) d_T, (int) kAlignBlock, d_blocks, c0, nbs);
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, stream_sync(ctx));        // the host vectors above back the async copies; and only a finished build is published
   cs->d_lane_xy = (float4*) t_xy.release(); cs->d_lane_bounds = (float4*) t_bounds.release(); cs->d_block_bounds = (float4*) t_blocks.release();
   cs->d_lane_start = (long long*) t_start.release(); cs->d_lane_T = (int32_t*) t_T.release();
+  cs->block_stride = nbs;
   return LSM2D_SUCCESS;
 }
 
@@ -1798,7 +1806,7 @@ typedef void (*AlignKernel)(const AlignArgs);
 enum : unsigned { kFProj = 1, kFNN = 2, kFDist = 4, kFKd = 8 };
 struct AlignVariant { unsigned finders; int mode; AlignKernel fn; };
 static const AlignVariant kAlignVariants[] = {
-  {kFProj, 5, k_align<true, false, false, false, 5>}, {kFProj, 0, k_align<true, false, false>},
+  {kFProj, 5, k_align<true, false, false, false, 5>}, {kFProj, 6, k_align<true, false, false, false, 6>}, {kFProj, 0, k_align<true, false, false>},
   {kFNN, 1, k_align<false, true, false, false, 1>},   {kFNN, 2, k_align<false, true, false, false, 2>}, {kFNN, 0, k_align<false, true, false>},
   {kFDist, 0, k_align<false, false, true>},
   {kFKd, 3, k_align<false, false, false, true, 3>},   {kFKd, 4, k_align<false, false, false, true, 4>}, {kFKd, 0, k_align<false, false, false, true>},
@@ -2033,9 +2041,22 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   A.units_off = 0; A.cull_keep = ctx->cull_keep;
   A.cull_mt = ctx->cull_keep ? 1e-6f * (float) ctx->cull_margin_um : 0.0f; A.cull_mth = ctx->cull_keep ? 1e-6f * (float) ctx->cull_margin_urad : 0.0f; A.cull_mt2 = A.cull_mt * A.cull_mt;      // (lists rebuilt every iteration: no margins)
   if (proj_culled_for_all) {
-    const size_t at = (lds + 15) & ~(size_t) 15, need = sizeof(uint16_t) * (size_t) ns * kCullBlocks * kAlignBlock;
+    int nb_max = kCullBlocks;
+    for (int s = 0; s < ns; ++s) if (b->moving[s]->block_stride > nb_max) nb_max = b->moving[s]->block_stride;
+    A.units_stride = nb_max * kAlignBlock;
+    const size_t at = (lds + 15) & ~(size_t) 15, need = sizeof(uint16_t) * (size_t) ns * (size_t) A.units_stride;
     if ((int) (at + need) + 2048 <= ctx->max_dyn_lds && at + need + 2048 <= 40 * 1024) { A.units_off = (int32_t) at; lds = at + need; }      // four workgroups per CU must still fit (160 KB)
     else proj_culled_for_all = false;
+  }
+  // the XCD window (AlignArgs::xcd_sync): a big-map batch of ONE dispatch round -- every workgroup resident from the start (64 VGPRs, <= 40 KB of LDS: four per
+  // CU) -- whose position space fits the counters
+  A.xcd_sync = nullptr; A.xcd_window = 0; A.xcd_stride = 0; A.xcd_positions = 0;
+  bool xcd_on = false;
+  if (proj_culled_for_all && ctx->xcd_window > 0 && n > 1 && n <= 4 * ctx->n_cu && !out_work) {
+    bool big = false;
+    for (int s = 0; s < ns; ++s) big = big || b->moving[s]->block_stride == kCullBlocksMax;
+    const long long positions = (long long) it_cap * ns * kCullBlocksMax;
+    if (big && positions > 0 && positions <= 65536) { xcd_on = true; A.xcd_positions = (int32_t) positions; A.xcd_stride = (int32_t) ((16 + positions + 63) & ~63ll); A.xcd_window = ctx->xcd_window; }
   }
   // the NN instantiation without the search in global memory: the staging holds every alignment's tables (sized for the largest fixed cloud above), and no
   // alignment takes the cooperative loop, which searches in global memory (the kernel's rule: fixed cloud >= 4 x moving cloud) -- whatever the pairing
@@ -2084,6 +2105,16 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   if (A.inline_n1) { memcpy(A.pose1, b->init_pose, sizeof A.pose1); if (b->prior) memcpy(&A.prior1, hs + o_prior, sizeof A.prior1); }
   if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   A.init_pose = (const float*) (ds + o_pose_in);
+  if (xcd_on && !use_split && !use_pair && !zero_copy) {
+    const size_t xb = sizeof(uint32_t) * 16 * (size_t) A.xcd_stride;
+    if (xb > ctx->d_xcd_bytes) {
+      if (ctx->d_xcd) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipFree(ctx->d_xcd)); ctx->d_xcd = nullptr; ctx->d_xcd_bytes = 0; }
+      HIPCHK(ctx, hipMalloc((void**) &ctx->d_xcd, xb)); ctx->d_xcd_bytes = xb;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_xcd, 0, xb, ctx->stream));
+    A.xcd_sync = ctx->d_xcd;
+  }
+  ctx->last_xcd_window = A.xcd_sync ? A.xcd_window : 0;
   // the SMALL results of a batch that travels by copies (56 bytes per alignment + the clock stamps) are written by the kernels straight into the pinned
   // staging buffer: the device-to-host copy behind the launch -- a hand-over to the copy engine, 9 us of gap + 6 us of copy on the timeline of a
   // 1000-alignment step -- is gone, the stream wait ends with the kernel.  The statistics (28 bytes per iteration and alignment) stay on the device and are copied.
@@ -2249,7 +2280,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
       // serves every alignment (kNNMode of align_body).  One table (round 5; a 12-way ladder before); the mixed instantiations take whatever is left.
       const unsigned finders = (has_proj ? kFProj : 0u) | (has_nn ? kFNN : 0u) | (has_dist ? kFDist : 0u) | (has_kd ? kFKd : 0u);
       int mode = 0;
-      if (finders == kFProj) mode = proj_culled_for_all ? 5 : 0;                                                    // every slice: the culled stream over kept unit lists
+      if (finders == kFProj) mode = proj_culled_for_all ? (A.xcd_sync ? 6 : 5) : 0;                                                    // every slice: the culled stream over kept unit lists
       else if (finders == kFNN) mode = A.nn_lds_points == 0 ? 1 : (nn_lds_for_all ? 2 : 0);                        // tables in global memory / in LDS for every alignment
       else if (finders == kFKd && ns == 1 && ctx->kd_modes) mode = A.kd_lds_points > 0 ? 3 : 4;                    // whole trees in LDS / only their tops
       AlignKernel fn = nullptr;

@@ -29,7 +29,13 @@ static constexpr bool kExperiments = false;
 #endif
 // exact culling of a projective slice's moving cloud (k_align): a thread's chunk of T steps is cut into at most kCullBlocks blocks of B steps
 static constexpr int kCullBlocks = 7;
-LSM2D_HD int cull_block_steps(int T) { return 2 * ((T + 13) / 14); }      // even; ceil(T / B) <= 7 for every T >= 1
+// Round 5: a MAP-SIZED chunk (T >= kCullBigT steps: a cloud of half a million points and more) is cut into 14 blocks instead of 7 -- the unit of the XCD window
+// below is a block, and the L2 of an XCD (4 MiB) should hold a few of them: 1M points = 8 MB of lane copy = 0.57 MB per block.  Which count a SET uses
+// (CloudDev::block_stride, the stride of its block_bounds) is decided once, by its largest cloud; every cloud of the set is cut into that many.
+static constexpr int kCullBlocksMax = 14, kCullBigT = 512;
+static_assert(kCullBlocksMax == kListBlocksMax, "positions per slice and iteration (lsm2d_device.h)");
+LSM2D_HD int cull_blocks_for(int maxT) { return maxT >= kCullBigT ? kCullBlocksMax : kCullBlocks; }
+LSM2D_HD int cull_block_steps(int T, int nbs = kCullBlocks) { return 2 * ((T + 2 * nbs - 1) / (2 * nbs)); }      // even; ceil(T / B) <= nbs for every T >= 1
 // Wave priority by progress.  The SIMD arbitrates by priority, then AGE: with equal priorities the oldest two waves of a SIMD run
 // at full single-wave speed and the younger workgroups of a CU wait (tools/occupancy_probe.py: lifetimes 0.97 .. 2.19 ms in one
 // launch), so the last workgroup of a CU ends up alone, with nobody to issue under its barriers, bin walks and solves.  A
@@ -150,7 +156,8 @@ struct CloudDev {            // device view of a cloud set
   const long long* lane_start; // [n_clouds] first float4 slot of each cloud in lane_xy
   const int32_t* lane_T;     // [n_clouds] steps per thread
   const float4* lane_bounds; // [n_clouds][kAlignBlock] bounding circle (cx, cy, rho; rho < 0: no points) of the chunk each thread owns, or nullptr
-  const float4* block_bounds; // [n_clouds][kCullBlocks][kAlignBlock] the same per BLOCK of a chunk (block b of chunk g = its steps [b B, (b + 1) B), B = cull_block_steps(T)), or nullptr
+  const float4* block_bounds; // [n_clouds][block_stride][kAlignBlock] the same per BLOCK of a chunk (block b of chunk g = its steps [b B, (b + 1) B), B = cull_block_steps(T, block_stride)), or nullptr
+  int32_t block_stride;       // blocks per chunk of this set: kCullBlocks, or kCullBlocksMax when it holds a map-sized cloud (cull_blocks_for)
   const float4* aos;         // [padded total] (x, y, nx, ny) rows next to xy / nrm -- one 16-byte gather per z-buffer winner in k_align's bin walk -- or nullptr
   const float4* tile_bounds; // bounding circle of every TILE of 64 consecutive points of every cloud (k_tile_bounds), or nullptr: what the point-query
   const int32_t* tile_start; //   finders' culling tests; [n_clouds] first tile of each cloud
@@ -1270,7 +1277,19 @@ struct AlignArgs {
   // (kCullBlocks * kAlignBlock 16-bit entries per slice), built with margins (cull_mt metres, cull_mth radians) and kept while the slice's transform
   // stays within them of the one it was built at (cull_keep 0: rebuilt every iteration, zero margins -- A/B knob)
   int32_t units_off, cull_keep;
+  int32_t units_stride;                     // entries per slice of the unit lists: the largest block_stride of the batch's moving sets x kAlignBlock
   float   cull_mt, cull_mth;
+  // Round 5, big maps (kProjCulled): the workgroups of one XCD walk the map's blocks IN STEP.  A 1M-point map's lane copy (8 MB) does not fit an XCD's 4 MiB L2,
+  // and 128 workgroups streaming different parts of it at the same time missed on 43 % of their requests (40 GB of fabric reads per 1000-alignment launch for
+  // 50 MB of data, the chip at 1.8 GHz under that load: profiles/r04/pmc_k_align_cfg4_r04m.csv).  All workgroups of a one-round launch start together and walk
+  // their unit lists in the same block-major order; what pulls them apart is only that their lists differ in length.  So every WAVE publishes the position it
+  // has reached -- (iteration, slice, block) as one number g -- by counting itself into done[q] for every position q it has left behind, and before it starts a
+  // unit of position g it waits until every wave registered on ITS XCD has left position g - xcd_window - 1 (or has gone).  The counters of an XCD are touched
+  // by that XCD only: plain L2 atomics, no fabric traffic, no fence.  Waiting waves sleep; their issue slots go to the CU's other waves.  Nothing but the
+  // ORDER IN TIME of the z-buffer updates changes: every result keeps its bits.  xcd_sync == nullptr: free-running (the host offers the window only to
+  // launches of one dispatch round, whose workgroups are all resident from the start).
+  uint32_t* xcd_sync;                       // [16 XCC ids][xcd_stride]: word 0 waves registered, word 1 waves gone, word 16 + q: waves that have left position q
+  int32_t xcd_stride, xcd_window, xcd_positions;
   int32_t pq_cull_off;                      // > 0: byte offset in dynamic LDS of the point-query finders' culling state (occupancy bitmap of the fixed cloud, then
   int32_t pq_keep_words;                    //   pq_keep_words 64-bit words of per-tile keep bits); single-slice NN / KD-tree batches with scan-sized fixed clouds
   int32_t pair_mov_cap;                     // latency kernel: moving points per slice it may keep in LDS (kPairMovCap, or 0: no room)
@@ -1400,9 +1419,11 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
   constexpr bool kKdAllLds = kNNMode == 3, kKdTop = kNNMode == 4;
   // ... and for a pure projective batch: 5 = every slice streams a lane-chunked moving cloud through the exact culling in units (what a batch against a map
   // does): the plain lane stream, the row-major variant and the per-pair stream of small clouds are compiled out
-  constexpr bool kProjCulled = kNNMode == 5;
+  // 6 = 5 with the XCD window (AlignArgs::xcd_sync: big maps, one dispatch round): an instantiation of its own, so that the headline's loop does not carry the
+  // window's state (in one body: 16 bytes of scratch in the kernel that had none)
+  constexpr bool kProjCulled = kNNMode == 5 || kNNMode == 6, kXcdWindow = kNNMode == 6;
   static_assert(kNNMode == 0 || ((kNNMode <= 2) && kHasNN && !kHasProj && !kHasDist && !kHasKd) || ((kNNMode == 3 || kNNMode == 4) && kHasKd && !kHasProj && !kHasDist && !kHasNN) ||
-                (kNNMode == 5 && kHasProj && !kHasNN && !kHasDist && !kHasKd), "kNNMode: one finder only");
+                ((kNNMode == 5 || kNNMode == 6) && kHasProj && !kHasNN && !kHasDist && !kHasKd), "kNNMode: one finder only");
   extern __shared__ __align__(16) unsigned char smem[];
   // (round 4: the fixed winners' payload no longer sits in LDS -- 16 bytes per column, 17 KB at 1081 -- the bin walk gathers it like the moving winner's,
   // one 16-byte row of the cloud's AoS copy each, both in flight together; the room holds the culled stream's unit lists)
@@ -1453,6 +1474,13 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
 #define LSM2D_PH(k) do { } while (0)
 #endif
   if (A.wg_place && tid == 0) A.wg_place[blockIdx.x] = place_key();
+  // the XCD window (AlignArgs::xcd_sync): this wave's counters are its XCD's; it counts itself in before anything else
+  uint32_t* xsync = nullptr; int xs_prog = 0;      // (both wave-uniform: SGPRs)
+  if (kXcdWindow && !kFirstStage && A.xcd_sync) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) & 15u;      // HW_REG_XCC_ID
+    xsync = A.xcd_sync + (size_t) xcc * A.xcd_stride;
+    if (xcd_first_lane()) __hip_atomic_fetch_add(&xsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   const bool stamp = A.clock_out && tid == 0 && a % A.clock_stride == 0;
   if (stamp) { s_clk[0] = __builtin_amdgcn_s_memtime(); s_clk[1] = __builtin_amdgcn_s_memrealtime(); }
   if (A.prior && tid >= 64 && tid < 64 + kPriorWords)
@@ -1659,9 +1687,10 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
             // margins -- and the surviving chunks are compacted; (B) the nb blocks of every surviving chunk are tested the same way, dealt to the threads in
             // block-major order and compacted in that order: the list.  2 + ceil(nb s / 512) + 1 barriers, a few times per alignment.
             const int lane = tid & 63, wave = tid >> 6;
-            uint16_t* units = l_units + s * (kCullBlocks * kAlignBlock);
+            uint16_t* units = l_units + s * A.units_stride;
             const int Tm = S.moving.lane_T[mc];
-            const int B = cull_block_steps(Tm), nb = (Tm + B - 1) / B;
+            const int nbs = __builtin_amdgcn_readfirstlane(S.moving.block_stride);
+            const int B = cull_block_steps(Tm, nbs), nb = (Tm + B - 1) / B;
             if (__builtin_amdgcn_readfirstlane(s_rebuild[s]) || lists_only) {      // (lists_only: the list the second launch will build first, whatever the kept one covers)
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
               const float m_t = A.cull_mt, m_th = A.cull_mth;      // (0 when the lists are not kept: the host sees to that -- a select made here was a vector register held across the iteration)
@@ -1680,10 +1709,10 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
               if (keep) s_surv[before + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) bal, 0u))] = (uint16_t) tid;
               __syncthreads();
               // (B) test v = (block v / n_surv, survivor v mod n_surv), v = tid, tid + 512, ...; block_compact_pos: one barrier per round, buffers alternating
-              const unsigned long long kb = reinterpret_cast<unsigned long long>(S.moving.block_bounds + (size_t) mc * (kCullBlocks * kAlignBlock));
+              const unsigned long long kb = reinterpret_cast<unsigned long long>(S.moving.block_bounds + (size_t) mc * nbs * kAlignBlock);
               float4* kbase = reinterpret_cast<float4*>(((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (kb >> 32)) << 32) |
                                                         (unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) kb));
-              const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(kbase, (short) 0, kCullBlocks * kAlignBlock * 16, 0x00020000);
+              const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(kbase, (short) 0, nbs * kAlignBlock * 16, 0x00020000);
               int n_units = 0, parity = 1, i = tid, blk = 0;
               while (n_surv > 0 && i >= n_surv && blk < nb) { i -= n_surv; ++blk; }
               const int n_tests = nb * n_surv;
@@ -1705,7 +1734,10 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
             }
             if (lists_only) continue;
             const int n_units = __builtin_amdgcn_readfirstlane(s_nunits[s]);
-            if (n_units > 0) project_cloud_list(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, units, n_units, B);
+            {
+              XcdWindow xw; xw.sync = kXcdWindow ? xsync : nullptr; xw.window = A.xcd_window; xw.g0 = (it * A.n_slices + s) * kCullBlocksMax; xw.limit = A.xcd_positions;
+              project_cloud_list(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, units, n_units, B, xw, xs_prog);
+            }
           }
           else if (S.moving.lane_xy && S.moving.lane_bounds && A.cull) {
             // exact culling against the fixed canvas (chunk_may_matter): every thread tests the chunk it would stream, the survivors are
@@ -1986,6 +2018,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
     __syncthreads();
     if (s_done) { ++it; break; }
   }
+  if (kXcdWindow && xsync && xcd_first_lane()) __hip_atomic_fetch_add(&xsync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // gone: nobody waits for this wave any more
   if (tid == 0) {
     int st = s_status;
     if (st == LSM2D_RUNNING) st = (A.max_it > 0 && s_last_n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;
@@ -3566,13 +3599,13 @@ __global__ __launch_bounds__(256) void k_lane_bounds(const float2* __restrict__ 
 }
 
 // the same per BLOCK of a chunk (block b of chunk g = the points [2 (g T + b B), 2 (g T + min((b + 1) B, T))) of the cloud, B = cull_block_steps(T)): entry
-// (c * kCullBlocks + b) * nthreads + g; blocks beyond the chunk's last (or beyond the cloud's end) get rho < 0 = "no points".  One wave per block.
+// (c * nbs + b) * nthreads + g (nbs = the set's block_stride); blocks beyond the chunk's last (or beyond the cloud's end) get rho < 0 = "no points".  One wave per block.
 __global__ __launch_bounds__(256) void k_block_bounds(const float2* __restrict__ xy, const int32_t* __restrict__ start, const int32_t* __restrict__ count,
-                                                      const int32_t* __restrict__ lane_T, int nthreads, float4* __restrict__ out, int cloud0) {
+                                                      const int32_t* __restrict__ lane_T, int nthreads, float4* __restrict__ out, int cloud0, int nbs) {
   const int c = cloud0 + blockIdx.y, w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (w >= nthreads * kCullBlocks) return;
+  if (w >= nthreads * nbs) return;
   const int b = w / nthreads, g = w - b * nthreads;
-  const int n = count[c], T = lane_T[c], B = cull_block_steps(T);
+  const int n = count[c], T = lane_T[c], B = cull_block_steps(T, nbs);
   const int t0 = b * B, t1 = t0 + B < T ? t0 + B : T;
   long long lo = 2ll * ((long long) g * T + t0), hi = 2ll * ((long long) g * T + t1);
   if (hi > n) hi = n;
@@ -3592,7 +3625,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(const float2* __restrict__
     const float rho = (d2 == d2) ? __builtin_sqrtf(d2) * 1.00001f + 1e-6f : __builtin_huge_valf();      // (a non-finite point: never culled, as in k_lane_bounds)
     r = make_float4(cx, cy, (cx == cx && cy == cy) ? rho : __builtin_huge_valf(), 0.0f);
   }
-  if (lane == 0) out[((size_t) c * kCullBlocks + b) * nthreads + g] = r;
+  if (lane == 0) out[((size_t) c * nbs + b) * nthreads + g] = r;
 }
 
 // (x, y, nx, ny) rows of a whole set next to its split arrays (CloudDev::aos)

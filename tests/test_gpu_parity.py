@@ -2575,6 +2575,24 @@ def test_configs4_full_size_properties_1000_scans_vs_1m_map(ctx, po):
     finally:
         ctx.set_option("cull", 1)
     assert np.array_equal(plain.pose, res.pose) and np.array_equal(plain.information, res.information) and np.array_equal(plain.iterations, res.iterations)
+    # round 5: the XCD window (the workgroups of an XCD walk the map's blocks within "xcd_window" blocks of each other: AlignArgs::xcd_sync) changes WHEN a map
+    # point is visited, never a result -- windows 1 and 3, with a termination criterion that ends alignments at different iterations (waves that go early), and with
+    # start poses that fail at once (workgroups that are gone before the others have started)
+    al_eps = _aligner(ctx); al_eps.param_termination_chi_epsilon = 1e-3
+    x_bad = wl.x0.copy(); x_bad[::9, 0] += 400.0
+    for al_w, x0_w in ((al, wl.x0), (al_eps, wl.x0), (al, x_bad)):
+        got = {}
+        for w in (0, 1, 3):
+            ctx.set_option("xcd_window", w)
+            try:
+                got[w] = al_w.compute_batch([fixed], [moving], x0_w, want_stats=True)
+                assert ctx.get_option("last_xcd_window") == w
+            finally:
+                ctx.set_option("xcd_window", 0)
+        for w in (1, 3):
+            assert np.array_equal(got[w].pose, got[0].pose) and np.array_equal(got[w].information, got[0].information) and np.array_equal(got[w].status, got[0].status), w
+            assert np.array_equal(got[w].iterations, got[0].iterations) and np.array_equal(got[w].stats, got[0].stats), w
+    assert (got[0].status[::9] != 0).all() and (got[0].status == 0).sum() > 800
     for i in (0, 499, 999):
         sc = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
         rt = po.align(po.aligner_params(20, device_order=True), [po.slice_params()], [sc], [wl.map_points], wl.x0[i])
