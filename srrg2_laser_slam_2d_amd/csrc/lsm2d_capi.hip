@@ -78,7 +78,8 @@ struct lsm2d_context {
   int clock_stride = 0;               // 0: ~32 stamped workgroups per launch; > 0: every clock_stride-th ("clock_stride" option, diagnostics)
   long long last_clock_khz = 0;       // in-kernel clock of the most recent timed k_align launch (median over the stamped workgroups), 0 = none
   long long last_wg_lifetime_ns = 0;  // median lifetime of its stamped workgroups
-  int xcd_window = 0;          // (set below) big-map batches: the workgroups of an XCD walk the map's blocks within this many blocks of each other ("xcd_window"; 0: free-running)
+  int xcd_lockstep = 0;        // big-map batches of one dispatch round: the workgroups of an XCD walk the map in step, pass by pass ("xcd_lockstep": 0 free-running, 1 nobody starts
+                               // a pass before everybody on its XCD has finished the previous one, 2 .. : the one before that, ...)
   int uploads = 0;             // host-to-device cloud uploads queued so far ("uploads", read-only: the adapters' upload-once test reads it)
   long long last_h2d_bytes = 0; // bytes the most recent cloud upload moved over the host link
   int experiments =
@@ -88,7 +89,7 @@ struct lsm2d_context {
       0;
 #endif
   int estimate_reuse = 1;      // a prepared batch run again with unchanged start poses keeps its placement (no k_cull_estimate launch); experiments build: 0 switches that off
-  int last_xcd_window = 0;     // the window the latest aligner call ran with (0: free-running)
+  int last_xcd_lockstep = 0;   // what the latest aligner call ran with (0: free-running)
   int last_cull_estimate = 0;  // what the latest aligner call did about the placement's estimate ("last_cull_estimate")
   bool order_valid = false; unsigned long long order_key = 0; std::vector<float> order_poses;      // the placement d_order holds: which batch it was made for
   int last_query_cull = 0;     // the latest aligner call ran its point-query finder with the exact culling of the queries (k_align, tiles of 64 moving points)
@@ -253,7 +254,9 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+#ifdef LSM2D_EXPERIMENTS
   (void) hipFuncSetAttribute((const void*) k_align<true, false, false, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+#endif
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
@@ -328,7 +331,6 @@ const OptionDesc kOptions[] = {
   {"zero_copy_max",      &lsm2d_context::zero_copy_max,      0, 65536,      0},
   {"cull",               &lsm2d_context::cull,               0, kCullMax,   0},
   {"balance",            &lsm2d_context::balance,            0, 1,          0},
-  {"xcd_window",         &lsm2d_context::xcd_window,         0, 64,         0},
   {"cull_margin_um",     &lsm2d_context::cull_margin_um,     0, 1000000,    0},
   {"cull_margin_urad",   &lsm2d_context::cull_margin_urad,   0, 50000,      0},      // (the kept lists' proof compares |sin dth| with the margin: asin(x) - x stays below the test's 0.05-column slack up to here)
   {"grid_big_threshold", &lsm2d_context::grid_big_threshold, 1, 0x7fffffff, 0},
@@ -340,7 +342,7 @@ const OptionDesc kOptions[] = {
   {"max_dyn_lds",        &lsm2d_context::max_dyn_lds,        0, 0, kOptReadOnly},      // bytes of LDS one workgroup may ask for
   {"uploads",            &lsm2d_context::uploads,            0, 0, kOptReadOnly},      // host-to-device cloud uploads this context has queued so far (lsm2d_cloudset_create / _upload)
   {"last_cull_estimate", &lsm2d_context::last_cull_estimate, 0, 0, kOptReadOnly},      // 1: the latest aligner call launched the placement's estimate; 0: it reused the order of an unchanged prepared batch, or needed none
-  {"last_xcd_window",    &lsm2d_context::last_xcd_window,    0, 0, kOptReadOnly},
+  {"last_xcd_lockstep",  &lsm2d_context::last_xcd_lockstep,  0, 0, kOptReadOnly},
   {"experiments",        &lsm2d_context::experiments,        0, 0, kOptReadOnly},
 #ifdef LSM2D_EXPERIMENTS
   // ---- A/B knobs of the experiments build (tests/test_gpu_experiments.py; each one's measurement: DESIGN App. A)
@@ -361,6 +363,7 @@ const OptionDesc kOptions[] = {
   {"kd_wide_min_points", &lsm2d_context::kd_wide_min_points, 0, 0x7fffffff, kOptExperiment},
   {"kd_wg_max_points",   &lsm2d_context::kd_wg_max_points,   0, 1 << 20, kOptExperiment},
   {"estimate_reuse",     &lsm2d_context::estimate_reuse,     0, 1,       kOptExperiment},
+  {"xcd_lockstep",       &lsm2d_context::xcd_lockstep,       0, 64,      kOptExperiment},
 #endif
 };
 const OptionDescLL kOptionsLL[] = {      // read-only, 64-bit
@@ -1806,7 +1809,10 @@ typedef void (*AlignKernel)(const AlignArgs);
 enum : unsigned { kFProj = 1, kFNN = 2, kFDist = 4, kFKd = 8 };
 struct AlignVariant { unsigned finders; int mode; AlignKernel fn; };
 static const AlignVariant kAlignVariants[] = {
-  {kFProj, 5, k_align<true, false, false, false, 5>}, {kFProj, 6, k_align<true, false, false, false, 6>}, {kFProj, 0, k_align<true, false, false>},
+  {kFProj, 5, k_align<true, false, false, false, 5>}, {kFProj, 0, k_align<true, false, false>},
+#ifdef LSM2D_EXPERIMENTS
+  {kFProj, 6, k_align<true, false, false, false, 6>},      // 5 with the XCD lockstep ("xcd_lockstep": measured, 2x slower on configs[4] for 65 % less fabric traffic: DESIGN App. A)
+#endif
   {kFNN, 1, k_align<false, true, false, false, 1>},   {kFNN, 2, k_align<false, true, false, false, 2>}, {kFNN, 0, k_align<false, true, false>},
   {kFDist, 0, k_align<false, false, true>},
   {kFKd, 3, k_align<false, false, false, true, 3>},   {kFKd, 4, k_align<false, false, false, true, 4>}, {kFKd, 0, k_align<false, false, false, true>},
@@ -2052,11 +2058,11 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   // CU) -- whose position space fits the counters
   A.xcd_sync = nullptr; A.xcd_window = 0; A.xcd_stride = 0; A.xcd_positions = 0;
   bool xcd_on = false;
-  if (proj_culled_for_all && ctx->xcd_window > 0 && n > 1 && n <= 4 * ctx->n_cu && !out_work) {
+  if (kExperiments && proj_culled_for_all && ctx->xcd_lockstep > 0 && n > 1 && n <= 4 * ctx->n_cu && !out_work) {
     bool big = false;
     for (int s = 0; s < ns; ++s) big = big || b->moving[s]->block_stride == kCullBlocksMax;
-    const long long positions = (long long) it_cap * ns * kCullBlocksMax;
-    if (big && positions > 0 && positions <= 65536) { xcd_on = true; A.xcd_positions = (int32_t) positions; A.xcd_stride = (int32_t) ((16 + positions + 63) & ~63ll); A.xcd_window = ctx->xcd_window; }
+    const long long positions = (long long) it_cap * ns;      // one per (iteration, slice) pass
+    if (big && positions > 0 && positions <= 65536) { xcd_on = true; A.xcd_positions = (int32_t) positions; A.xcd_stride = (int32_t) ((16 + positions + 63) & ~63ll); A.xcd_window = ctx->xcd_lockstep - 1; }
   }
   // the NN instantiation without the search in global memory: the staging holds every alignment's tables (sized for the largest fixed cloud above), and no
   // alignment takes the cooperative loop, which searches in global memory (the kernel's rule: fixed cloud >= 4 x moving cloud) -- whatever the pairing
@@ -2114,7 +2120,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     HIPCHK(ctx, hipMemsetAsync(ctx->d_xcd, 0, xb, ctx->stream));
     A.xcd_sync = ctx->d_xcd;
   }
-  ctx->last_xcd_window = A.xcd_sync ? A.xcd_window : 0;
+  ctx->last_xcd_lockstep = A.xcd_sync ? A.xcd_window + 1 : 0;
   // the SMALL results of a batch that travels by copies (56 bytes per alignment + the clock stamps) are written by the kernels straight into the pinned
   // staging buffer: the device-to-host copy behind the launch -- a hand-over to the copy engine, 9 us of gap + 6 us of copy on the timeline of a
   // 1000-alignment step -- is gone, the stream wait ends with the kernel.  The statistics (28 bytes per iteration and alignment) stay on the device and are copied.
@@ -2309,6 +2315,20 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   if (out_its) memcpy(out_its, hs + o_its, sizeof(int32_t) * (size_t) n);
   if (out_stats) memcpy(out_stats, hs + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride);
   if (out_last_pose) memcpy(out_last_pose, hs + o_last_pose, sizeof(float) * 3 * (size_t) n);
+  if (A.xcd_sync) if (const char* dump = getenv("LSM2D_DUMP_XCD")) {      // diagnostics: the XCD window's counters after the launch, one line per XCC that took part
+    std::vector<uint32_t> h((size_t) 16 * A.xcd_stride);
+    if (hipMemcpy(h.data(), A.xcd_sync, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) if (FILE* f = fopen(dump, "a")) {
+      fprintf(f, "# launch n=%d lockstep=%d passes=%d\n", n, A.xcd_window + 1, A.xcd_positions);
+      for (int x = 0; x < 16; ++x) {
+        const uint32_t* c = h.data() + (size_t) x * A.xcd_stride;
+        if (!c[0]) continue;
+        fprintf(f, "xcc %2d registered %u gone %u watchdog %u (last: need %u saw %u reg %u gone %u at g %u) done:", x, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+        for (int q = 0; q < A.xcd_positions && q < 48; ++q) fprintf(f, " %u", c[16 + q]);
+        fprintf(f, " ... %u\n", c[16 + A.xcd_positions - 1]);
+      }
+      fclose(f);
+    }
+  }
   if (stamps) {     // median over the stamped workgroups: shader cycles per 10 ns tick of the constant 100 MHz counter
     const unsigned long long* ck = (const unsigned long long*) (hs + o_clock);
     std::vector<double> khz; std::vector<unsigned long long> life;

@@ -373,44 +373,32 @@ LSM2D_DEV void project_cloud_units_t(const float4* __restrict__ lane_xy, int T_s
 // off each other's cells, as above) -- and every entry is a unit that survived the BLOCK-level test (a block = B steps = 2 B consecutive map points,
 // ~6 cm of wall on configs[1] and [4] alike), so a chunk that straddles the edge of what the scan saw is streamed in part only.  Thread u takes the
 // entries u, u + nthreads, ...: whole waves run out of work together.
-// Round 5: the XCD window (AlignArgs::xcd_sync in lsm2d_kernels.h).  sync: this XCD's counters, or nullptr.  A wave's position g = g0 + block of its next unit.
-// leave(g): the wave counts itself into done[q] for every position q < g it had not left yet (prog: what it has published, wave-uniform, kept by the caller
-// across slices and iterations).  enter(g): wait until done[g - window - 1] + gone >= registered.  Every counter only grows and the wave with the smallest
-// position never waits (everybody has left what lies behind it), so every wait ends; a wave that ends early counts itself `gone`.  Lane 0 talks to the L2,
-// the answer travels by v_readfirstlane; a waiting wave sleeps ~1 us between looks.
-static constexpr int kListBlocksMax = 14;      // = kCullBlocksMax (lsm2d_kernels.h): positions per slice and iteration
-struct XcdWindow { uint32_t* sync; int window, g0, limit; };
-// "am I the wave's first lane", formed afresh where it is asked (two v_mbcnt): as `(tid & 63) == 0` the lane id was a value the compiler kept -- and spilled --
-// across the whole iteration loop for the sake of one atomic at the kernel's end
-LSM2D_DEV bool xcd_first_lane() { unsigned m = ~0u; asm volatile("" : "+s"(m)); return __builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u)) == 0u; }
-LSM2D_DEV void xcd_leave(const XcdWindow& w, int g, int& prog) {
-  if (g > w.limit) g = w.limit;
-  if (g <= prog) return;
-  if (xcd_first_lane()) for (int q = prog; q < g; ++q) __hip_atomic_fetch_add(&w.sync[16 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  prog = g;
+// Round 5: the XCD lockstep of k_align<1,0,0,0,6> (AlignArgs::xcd_sync in lsm2d_kernels.h) -- how a workgroup LOOKS at its XCD's counters: a SCALAR load with glc
+// (past the scalar cache, served by the L2, where the other CUs' atomic adds are performed; tools/l2_poll_probe.hip: it sees them within a poll, a plain or
+// sc0 vector load -- which is what the compiler makes of an atomic add of zero -- never does).  One request, no lane, no vector register, and a READ.
+LSM2D_DEV unsigned xcd_look(const uint32_t* p) {
+  unsigned v;
+  asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(p) : "memory");
+  return v;
 }
-LSM2D_DEV void xcd_enter(const XcdWindow& w, int g) {
-  const int need = g - w.window - 1;
-  if (need < 0 || need >= w.limit) return;
+// wait until every workgroup registered on this XCD has counted itself into done[need] (or has gone).  Called by ONE thread of a workgroup while the others
+// stand at a barrier.  The counters only grow, and the workgroup that is furthest behind waits for nobody, so every wait ends; should that reasoning ever be
+// wrong, ~100 ms end it too (the lockstep changes no result: giving up on it is always safe) -- counted in word 2 of the XCD's counters (LSM2D_DUMP_XCD).
+LSM2D_DEV void xcd_wait(uint32_t* sync, int need, int limit) {
+  if (need < 0 || need >= limit) return;
+  int polls = 0;
+#pragma nounroll
   for (;;) {
-    int ok = 1;
-    if (xcd_first_lane()) {
-      // three RETURNING atomics, performed in this XCD's L2, where the other CUs' adds are (a load -- which is what the compiler makes of an atomic add of
-      // zero -- may be served from this CU's own vector cache and never see them): spelled out, in flight together, one wait
-      unsigned d, reg, gone; const unsigned zero = 0u;
-      uint32_t* pd = w.sync + 16 + need;
-      asm volatile("global_atomic_add %0, %3, %5, off sc0\n\tglobal_atomic_add %1, %4, %5, off sc0\n\tglobal_atomic_add %2, %4, %5, off offset:4 sc0\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(d), "=&v"(reg), "=&v"(gone) : "v"(pd), "v"(w.sync), "v"(zero) : "memory");
-      ok = d + gone >= reg ? 1 : 0;
-    }
-    if (__builtin_amdgcn_readfirstlane(ok)) break;
-    __builtin_amdgcn_s_sleep(32);
+    const unsigned d = xcd_look(sync + 16 + need), reg = xcd_look(sync), gone = xcd_look(sync + 1);
+    if ((int) (d + gone - reg) >= 0) return;
+    if (polls < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(48);      // ~0.25 us at first, ~1.3 us later: 125 workgroups per XCD, one looking thread each
+    if (++polls > 60000) { __hip_atomic_fetch_add(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); sync[3] = (unsigned) need; sync[4] = d; sync[5] = reg; sync[6] = gone; return; }
   }
 }
 
 template <bool kGuarded>
 LSM2D_DEV void project_cloud_list_t(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin, u64* canvas, int tid, int nthreads,
-                                    const uint16_t* units, int n_units, int B, const XcdWindow& xw, int& xs_prog) {
+                                    const uint16_t* units, int n_units, int B) {
   const Iso T = Tin; ProjK P = Pin;
   asm volatile("" : "+v"(P.K01));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -420,13 +408,8 @@ LSM2D_DEV void project_cloud_list_t(const float4* __restrict__ lane_xy, int T_st
   float4* ubase = reinterpret_cast<float4*>(((unsigned long long) pb_hi << 32) | (unsigned long long) pb_lo);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, (short) 0, 0x7fffffff, 0x00020000);
   const int row_bytes = nthreads * (int) sizeof(float4);
-  int entered = -1;      // the last position this wave was let into (wave-uniform)
   for (int k = tid; k < n_units; k += nthreads) {
     const int code = (int) units[k];
-    if (xw.sync) {      // (wave-uniform branch) the wave's position: the block of its first lane's unit -- the list is block-major, its other lanes are at most a block on
-      const int gpos = xw.g0 + (__builtin_amdgcn_readfirstlane(code) >> 9);
-      if (gpos != entered) { xcd_leave(xw, gpos, xs_prog); xcd_enter(xw, gpos); entered = gpos; }
-    }
     const int g = code & 511, t0 = (code >> 9) * B;
     const int nsteps = T_steps - t0 < B ? T_steps - t0 : B;
     const int voff = g * (int) sizeof(float4) + t0 * row_bytes;      // this lane's chunk and block; the step advances in the scalar offset
@@ -453,12 +436,11 @@ LSM2D_DEV void project_cloud_list_t(const float4* __restrict__ lane_xy, int T_st
     }
     if (t < nsteps) pair(va, idx);
   }
-  if (xw.sync) xcd_leave(xw, xw.g0 + kListBlocksMax, xs_prog);      // this slice's pass is behind the wave, whether or not it had a unit in it
 }
 LSM2D_DEV void project_cloud_list(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P, u64* canvas, int tid, int nthreads,
-                                  const uint16_t* units, int n_units, int B, const XcdWindow& xw, int& xs_prog) {
-  if (P.tiny_ok) project_cloud_list_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B, xw, xs_prog);
-  else project_cloud_list_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B, xw, xs_prog);
+                                  const uint16_t* units, int n_units, int B) {
+  if (P.tiny_ok) project_cloud_list_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
+  else project_cloud_list_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
 }
 
 #ifdef LSM2D_EXPERIMENTS      // ("cull" 2: measured 3 % slower than the block units, DESIGN App. A; compiled into the experiments build only)

@@ -29,12 +29,11 @@ static constexpr bool kExperiments = false;
 #endif
 // exact culling of a projective slice's moving cloud (k_align): a thread's chunk of T steps is cut into at most kCullBlocks blocks of B steps
 static constexpr int kCullBlocks = 7;
-// Round 5: a MAP-SIZED chunk (T >= kCullBigT steps: a cloud of half a million points and more) is cut into 14 blocks instead of 7 -- the unit of the XCD window
-// below is a block, and the L2 of an XCD (4 MiB) should hold a few of them: 1M points = 8 MB of lane copy = 0.57 MB per block.  Which count a SET uses
-// (CloudDev::block_stride, the stride of its block_bounds) is decided once, by its largest cloud; every cloud of the set is cut into that many.
+// Round 5 (experiments build only; measured, no gain: DESIGN App. A): a MAP-SIZED chunk (T >= kCullBigT steps: a cloud of half a million points and more) cut
+// into 14 blocks instead of 7 -- the same point visits on configs[4] to four digits, 14 KB more LDS.  Which count a SET uses (CloudDev::block_stride, the
+// stride of its block_bounds) is decided once, by its largest cloud; every cloud of the set is cut into that many.  The shipped library: 7 everywhere.
 static constexpr int kCullBlocksMax = 14, kCullBigT = 512;
-static_assert(kCullBlocksMax == kListBlocksMax, "positions per slice and iteration (lsm2d_device.h)");
-LSM2D_HD int cull_blocks_for(int maxT) { return maxT >= kCullBigT ? kCullBlocksMax : kCullBlocks; }
+LSM2D_HD int cull_blocks_for(int maxT) { return (kExperiments && maxT >= kCullBigT) ? kCullBlocksMax : kCullBlocks; }
 LSM2D_HD int cull_block_steps(int T, int nbs = kCullBlocks) { return 2 * ((T + 2 * nbs - 1) / (2 * nbs)); }      // even; ceil(T / B) <= nbs for every T >= 1
 // Wave priority by progress.  The SIMD arbitrates by priority, then AGE: with equal priorities the oldest two waves of a SIMD run
 // at full single-wave speed and the younger workgroups of a CU wait (tools/occupancy_probe.py: lifetimes 0.97 .. 2.19 ms in one
@@ -1279,16 +1278,17 @@ struct AlignArgs {
   int32_t units_off, cull_keep;
   int32_t units_stride;                     // entries per slice of the unit lists: the largest block_stride of the batch's moving sets x kAlignBlock
   float   cull_mt, cull_mth;
-  // Round 5, big maps (kProjCulled): the workgroups of one XCD walk the map's blocks IN STEP.  A 1M-point map's lane copy (8 MB) does not fit an XCD's 4 MiB L2,
-  // and 128 workgroups streaming different parts of it at the same time missed on 43 % of their requests (40 GB of fabric reads per 1000-alignment launch for
-  // 50 MB of data, the chip at 1.8 GHz under that load: profiles/r04/pmc_k_align_cfg4_r04m.csv).  All workgroups of a one-round launch start together and walk
-  // their unit lists in the same block-major order; what pulls them apart is only that their lists differ in length.  So every WAVE publishes the position it
-  // has reached -- (iteration, slice, block) as one number g -- by counting itself into done[q] for every position q it has left behind, and before it starts a
-  // unit of position g it waits until every wave registered on ITS XCD has left position g - xcd_window - 1 (or has gone).  The counters of an XCD are touched
-  // by that XCD only: plain L2 atomics, no fabric traffic, no fence.  Waiting waves sleep; their issue slots go to the CU's other waves.  Nothing but the
-  // ORDER IN TIME of the z-buffer updates changes: every result keeps its bits.  xcd_sync == nullptr: free-running (the host offers the window only to
-  // launches of one dispatch round, whose workgroups are all resident from the start).
-  uint32_t* xcd_sync;                       // [16 XCC ids][xcd_stride]: word 0 waves registered, word 1 waves gone, word 16 + q: waves that have left position q
+  // Round 5, big maps (k_align<1,0,0,0,6>): the workgroups of one XCD walk the map IN STEP, pass by pass.  A 1M-point map's lane copy (8 MB) does not fit an
+  // XCD's 4 MiB L2, and 125 workgroups streaming different parts of it at the same time missed on 44 % of their requests (41 GB of fabric reads per
+  // 1000-alignment launch for 50 MB of data, the chip at 1.83 GHz under that load: profiles/r05/size_sweep_r05a.txt).  All workgroups of a one-round launch start
+  // together and walk their unit lists in the same block-major order -- what pulls them apart is only that their lists differ in length, a quarter of a pass per
+  // iteration.  So every workgroup counts itself into done[g] when ITS pass g = (iteration, slice) is over, and its thread 0 -- at the end of the serial solve,
+  // while the other threads stand at the iteration's closing barrier anyway -- waits until every workgroup registered on ITS XCD has finished the pass that
+  // lies xcd_window passes back (0: the one just finished) or has gone.  One atomic add and a handful of scalar looks per workgroup and iteration; the counters
+  // of an XCD are touched by that XCD only (plain L2 atomics, no fabric traffic, no fence).  Nothing but the ORDER IN TIME of the z-buffer updates changes:
+  // every result keeps its bits.  xcd_sync == nullptr: free-running (the host offers the lockstep only to launches of one dispatch round, whose workgroups
+  // are all resident from the start).  What was tried before this form -- per wave and per BLOCK of the map -- and what it cost: DESIGN App. A.
+  uint32_t* xcd_sync;                       // [16 XCC ids][xcd_stride]: word 0 workgroups registered, word 1 workgroups gone, words 2..6 the watchdog's notes, word 16 + g: workgroups that have finished pass g
   int32_t xcd_stride, xcd_window, xcd_positions;
   int32_t pq_cull_off;                      // > 0: byte offset in dynamic LDS of the point-query finders' culling state (occupancy bitmap of the fixed cloud, then
   int32_t pq_keep_words;                    //   pq_keep_words 64-bit words of per-tile keep bits); single-slice NN / KD-tree batches with scan-sized fixed clouds
@@ -1474,12 +1474,12 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
 #define LSM2D_PH(k) do { } while (0)
 #endif
   if (A.wg_place && tid == 0) A.wg_place[blockIdx.x] = place_key();
-  // the XCD window (AlignArgs::xcd_sync): this wave's counters are its XCD's; it counts itself in before anything else
-  uint32_t* xsync = nullptr; int xs_prog = 0;      // (both wave-uniform: SGPRs)
+  // the XCD lockstep (AlignArgs::xcd_sync): this workgroup's counters are its XCD's; it counts itself in before anything else
+  uint32_t* xsync = nullptr;      // (wave-uniform: SGPRs)
   if (kXcdWindow && !kFirstStage && A.xcd_sync) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) & 15u;      // HW_REG_XCC_ID
     xsync = A.xcd_sync + (size_t) xcc * A.xcd_stride;
-    if (xcd_first_lane()) __hip_atomic_fetch_add(&xsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (tid == 0) __hip_atomic_fetch_add(&xsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   const bool stamp = A.clock_out && tid == 0 && a % A.clock_stride == 0;
   if (stamp) { s_clk[0] = __builtin_amdgcn_s_memtime(); s_clk[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -1734,10 +1734,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
             }
             if (lists_only) continue;
             const int n_units = __builtin_amdgcn_readfirstlane(s_nunits[s]);
-            {
-              XcdWindow xw; xw.sync = kXcdWindow ? xsync : nullptr; xw.window = A.xcd_window; xw.g0 = (it * A.n_slices + s) * kCullBlocksMax; xw.limit = A.xcd_positions;
-              project_cloud_list(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, units, n_units, B, xw, xs_prog);
-            }
+            if (n_units > 0) project_cloud_list(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, units, n_units, B);
           }
           else if (S.moving.lane_xy && S.moving.lane_bounds && A.cull) {
             // exact culling against the fixed canvas (chunk_may_matter): every thread tests the chunk it would stream, the survivors are
@@ -1777,6 +1774,8 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
           else project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
         }
         __syncthreads();
+        if (kXcdWindow && xsync && tid == 0 && it * A.n_slices + s < A.xcd_positions)      // this workgroup's pass (it, s) over the map is behind all its waves
+          __hip_atomic_fetch_add(&xsync[16 + it * A.n_slices + s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // bin walk (correspondence_finder_projective_2d.cpp:55-74): the fixed side comes from LDS, the two gathers of the
         // moving winner are issued together, and every cell read is reset for the next projection
         const int mbase = S.moving.start[pick_cloud(S.moving, a)], fbase = S.fixed.start[pick_cloud(S.fixed, a)];
@@ -2013,12 +2012,14 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
         }
       }
       if (!s_done) begin_iteration();        // next iteration's transforms and zeroed sums, under the same barrier
+      // the XCD lockstep: nobody starts its next pass before everybody on this XCD has finished the pass xcd_window back (the others stand at the barrier below anyway)
+      if (kXcdWindow && xsync && !s_done) xcd_wait(xsync, (it + 1) * A.n_slices - 1 - A.xcd_window * A.n_slices, A.xcd_positions);
     }
     LSM2D_PH(2);
     __syncthreads();
     if (s_done) { ++it; break; }
   }
-  if (kXcdWindow && xsync && xcd_first_lane()) __hip_atomic_fetch_add(&xsync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // gone: nobody waits for this wave any more
+  if (kXcdWindow && xsync && tid == 0) __hip_atomic_fetch_add(&xsync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // gone: nobody waits for this workgroup any more
   if (tid == 0) {
     int st = s_status;
     if (st == LSM2D_RUNNING) st = (A.max_it > 0 && s_last_n_in < A.min_inliers) ? LSM2D_NOT_ENOUGH_INLIERS : LSM2D_SUCCESS;

@@ -2575,24 +2575,26 @@ def test_configs4_full_size_properties_1000_scans_vs_1m_map(ctx, po):
     finally:
         ctx.set_option("cull", 1)
     assert np.array_equal(plain.pose, res.pose) and np.array_equal(plain.information, res.information) and np.array_equal(plain.iterations, res.iterations)
-    # round 5: the XCD window (the workgroups of an XCD walk the map's blocks within "xcd_window" blocks of each other: AlignArgs::xcd_sync) changes WHEN a map
-    # point is visited, never a result -- windows 1 and 3, with a termination criterion that ends alignments at different iterations (waves that go early), and with
-    # start poses that fail at once (workgroups that are gone before the others have started)
-    al_eps = _aligner(ctx); al_eps.param_termination_chi_epsilon = 1e-3
-    x_bad = wl.x0.copy(); x_bad[::9, 0] += 400.0
-    for al_w, x0_w in ((al, wl.x0), (al_eps, wl.x0), (al, x_bad)):
-        got = {}
-        for w in (0, 1, 3):
-            ctx.set_option("xcd_window", w)
-            try:
-                got[w] = al_w.compute_batch([fixed], [moving], x0_w, want_stats=True)
-                assert ctx.get_option("last_xcd_window") == w
-            finally:
-                ctx.set_option("xcd_window", 0)
-        for w in (1, 3):
-            assert np.array_equal(got[w].pose, got[0].pose) and np.array_equal(got[w].information, got[0].information) and np.array_equal(got[w].status, got[0].status), w
-            assert np.array_equal(got[w].iterations, got[0].iterations) and np.array_equal(got[w].stats, got[0].stats), w
-    assert (got[0].status[::9] != 0).all() and (got[0].status == 0).sum() > 800
+    # round 5 (experiments build; measured and not shipped, DESIGN App. A): the XCD lockstep -- the workgroups of an XCD walk the map in step, pass by pass
+    # ("xcd_lockstep" k: nobody starts a pass before everybody on its XCD has finished the pass k - 1 back) -- changes WHEN a map point is visited, never a result:
+    # with a termination criterion that ends alignments at different iterations (workgroups that go early) and with start poses that fail at once (workgroups
+    # that are gone before the others have started)
+    if has_experiments(ctx):
+        al_eps = _aligner(ctx); al_eps.param_termination_chi_epsilon = 1e-3
+        x_bad = wl.x0.copy(); x_bad[::9, 0] += 400.0
+        for al_w, x0_w in ((al, wl.x0), (al_eps, wl.x0), (al, x_bad)):
+            got = {}
+            for w in (0, 1, 3):
+                try:
+                    xset(ctx, xcd_lockstep=w)
+                    got[w] = al_w.compute_batch([fixed], [moving], x0_w, want_stats=True)
+                    assert ctx.get_option("last_xcd_lockstep") == w
+                finally:
+                    xset(ctx, xcd_lockstep=0)
+            for w in (1, 3):
+                assert np.array_equal(got[w].pose, got[0].pose) and np.array_equal(got[w].information, got[0].information) and np.array_equal(got[w].status, got[0].status), w
+                assert np.array_equal(got[w].iterations, got[0].iterations) and np.array_equal(got[w].stats, got[0].stats), w
+        assert (got[0].status[::9] != 0).all() and (got[0].status == 0).sum() > 800
     for i in (0, 499, 999):
         sc = wl.scan_points[wl.scan_offsets[i]:wl.scan_offsets[i + 1]]
         rt = po.align(po.aligner_params(20, device_order=True), [po.slice_params()], [sc], [wl.map_points], wl.x0[i])
@@ -2614,7 +2616,7 @@ def test_culling_and_placement_change_no_bit(ctx, po):
                 return None
             return al.compute_batch([fixed] * len(moving_sets), moving_sets, wl.x0, want_stats=True)
         finally:
-            xset(ctx, cull=1, balance=1, xcd_window=0, cull_block=0, proj_modes=1, balance_notes=1, two_stage=0, cull_est_um=0, cull_est_urad=40000, estimate_reuse=1, cull_keep=1)
+            xset(ctx, cull=1, balance=1, xcd_lockstep=0, cull_block=0, proj_modes=1, balance_notes=1, two_stage=0, cull_est_um=0, cull_est_urad=40000, estimate_reuse=1, cull_keep=1)
     for name, mp in (("ordered", wl.map_points), ("shuffled", shuffled)):
         moving = api.CloudSet(ctx, mp)
         for tag, al in (("plain", _aligner(ctx)), ("cauchy 270 deg", _aligner(ctx, robustifier=api.RobustifierCauchy(0.05)))):
@@ -2625,8 +2627,8 @@ def test_culling_and_placement_change_no_bit(ctx, po):
             # (round 4: the placement groups workgroup ids by the CU the previous launch of the same shape ran them on -- the second and third plain
             # runs below place by the first one's notes --, "balance_notes" 0: by the round-3 assumption; other margins in the work estimate)
             # (round 5: the third plain run finds the second one's batch unchanged and keeps its placement -- no estimate launch; "estimate_reuse" 0: made afresh;
-            # "xcd_window": the workgroups of an XCD walk the map's blocks in step; everything from "two_stage" on lives in the experiments build only)
-            for opts in (dict(cull=1), dict(cull=1), dict(cull=1), dict(cull=1, xcd_window=1), dict(cull=1, xcd_window=3, balance=0), dict(cull=1, balance=0), dict(cull=1, estimate_reuse=0),
+            # everything from "estimate_reuse" on lives in the experiments build only)
+            for opts in (dict(cull=1), dict(cull=1), dict(cull=1), dict(cull=1, balance=0), dict(cull=1, estimate_reuse=0), dict(cull=1, xcd_lockstep=1),
                          dict(cull=1, two_stage=1), dict(cull=1, cull_est_um=60000, cull_est_urad=0), dict(cull=1, balance_notes=0),
                          dict(cull=1, two_stage=1, balance_notes=0), dict(cull=2), dict(cull=1, cull_block=6), dict(cull=1, cull_block=98), dict(cull=1, proj_modes=0), dict(cull=1, cull_keep=0)):
                 got = run(al, [moving], **opts)
