@@ -39,6 +39,8 @@ N_SIMD = 256 * 4             # same guide: 256 CUs x 4 SIMD-32; a wave64 VALU in
 SPEC_CLOCK_MHZ = 2400.0      # same guide: max clock (spec)
 L2_PEAK_GBS = 34500.0        # same guide: ~34.5 TB/s aggregate over the eight per-XCD L2s
 VALU_CYCLES = 2.0            # a transcendental (the stream's one v_rsq_f32 per point) over 4: one slot more than SQ_INSTS_VALU counts for it
+L3_BYTES = 256 * 2 ** 20     # same guide: Infinity Cache (L3), die-level
+L3_GATHER_PEAK_GBS = 8600.0  # same guide, "Indexed rows": a cached random gather out of the Infinity Cache reads at 8.6 TB/s chip-wide
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # same guide: fp32 vector (non-matrix) peak
 FLOPS_PER_POINT = 60.0       # "A ~ 60 N_m" algorithmic flops per projected point
 
@@ -104,6 +106,255 @@ def load_counters(cfg_key: str):
     return ent, None
 
 
+def working_set_bytes(role: str, finder: str, scans: int, map_points: int, n_scan_mean: float) -> float:
+    """What one launch of the projective role-A batch touches: the map's lane-chunked copy (8 B per point), its AoS rows (16 B per point: one gather per z-buffer
+    winner), chunk / block circles (65 KB), the scans' AoS rows.  Against the 256 MiB Infinity Cache this says whether L2 misses can be served on-die."""
+    if finder == "projective" and role == "A":
+        return 8.0 * map_points + 16.0 * map_points + 8 * 512 * 16 + 16.0 * scans * n_scan_mean
+    return 32.0 * map_points + 32.0 * scans * n_scan_mean
+
+
+def build_roofline(role, finder, scans, map_points, iterations, beams, cauchy, n_unique, n_scan_mean, k_ms, k_samples, clk, wg_ms):
+    """The roofline block of one measured workload (the headline line and every entry of `also`)."""
+    cfg_key = "role%s/%s/scans%d/map%d/it%d/beams%d" % (role, finder, scans, map_points, iterations, beams)
+    if cauchy > 0:                       # a robustified run is another instruction stream (the log, the weights): its own counters
+        cfg_key += "/cauchy%g" % cauchy
+    if n_unique != scans:                # scans shared through the index array: another memory pattern
+        cfg_key += "/unique%d" % n_unique
+    bytes_per_alignment = algorithmic_bytes_per_alignment(role, finder, map_points, n_scan_mean, beams, iterations)
+    counters, warn = load_counters(cfg_key)
+    effective = bytes_per_alignment * scans / (k_ms * 1e-3) / 1e9
+    ws = working_set_bytes(role, finder, scans, map_points, n_scan_mean)
+    roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave64-VALU issue slots/s", "frac": None, "traffic": None,
+            "kernel": "k_align", "kernel_ms": k_ms, "kernel_ms_samples": k_samples, "clock_mhz_in_kernel": clk, "workgroup_lifetime_ms": wg_ms,
+            "hbm": {"effective_l2_served_GBs": effective, "effective_over_hbm_peak": effective / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": bytes_per_alignment * scans, "peak_GBs": HBM_PEAK_GBS},
+            # Round 5: what the memory-side counters of this pool CAN tell.  FETCH_SIZE / TCC_EA0_RDREQ count the L2s' MISSES going out on the fabric; whether the
+            # Infinity Cache (256 MiB) or the DRAM behind it served them they do not say -- TCC_EA0_RDREQ_DRAM counts the same requests to four digits at 1M, 4M
+            # and 16M map points (profiles/r05/pmc_k_align_map*_r05a.csv): it names the address space, not the level that answered.  So the line carries the fabric
+            # rate, says whether the launch's working set fits the Infinity Cache, and claims NO DRAM figure.
+            "fabric_GBs": None, "dram_GBs": None, "working_set_MB": ws / 1e6, "l3_resident": bool(ws < 0.9 * L3_BYTES),
+            "note": "frac = VALU issue slots used / slots the 1024 SIMDs have at the 2.4 GHz spec clock (frac_at_in_kernel_clock: at the clock measured inside the "
+                    "launch).  fabric_GBs = the L2s' miss traffic (2 x FETCH_SIZE + WRITE_SIZE per launch / launch time): Infinity Cache or DRAM, the counters cannot "
+                    "tell which (dram_GBs stays null); l3_resident says whether the working set fits the 256 MiB Infinity Cache.  hbm.* keeps the SURVEY 8(d) algorithmic figure"}
+    # what the L2s serve: the kernel's vector-memory read instructions x 1 KiB (16 bytes per lane) against the 34.5 TB/s of the eight L2s
+    # (MI355X_MICROARCH.md, "L2 (per XCD)"); the instruction count is a committed counter like the VALU count (profiles/counters.json)
+    if counters and counters.get("vmem_rd_insts_per_launch"):
+        l2_bytes = counters["vmem_rd_insts_per_launch"] * 1024.0
+        roof["l2_served"] = {"bytes_per_launch": l2_bytes, "GBs": l2_bytes / (k_ms * 1e-3) / 1e9, "peak_GBs": L2_PEAK_GBS,
+                             "frac": l2_bytes / (k_ms * 1e-3) / 1e9 / L2_PEAK_GBS}
+    if clk:
+        roof["peak"] = N_SIMD * clk * 1e6 / VALU_CYCLES / 1e9
+    if counters and clk:
+        # nominal costs (MI355X_MICROARCH.md): a wave64 VALU instruction issues over 2 cycles, a transcendental (one v_rsq_f32 per point
+        # slot of the stream) over 4, i.e. one slot more than SQ_INSTS_VALU counts for it.  (Measured, tools/valu_issue_probe.hip: 2.15 and
+        # ~12-18 cycles -- the stream_floor block below prices the launch with the measured costs instead.)
+        slots = counters["valu_insts_per_launch"] + counters.get("trans_insts_per_launch", 0.0)
+        roof["achieved"] = slots / (k_ms * 1e-3) / 1e9
+        # `frac` is priced against the SPEC clock (2.4 GHz) since round 4 -- the peak the guide prints; the chip holds 2.1-2.3 GHz under this load,
+        # so the figure against the clock measured inside the launch (the slots the SIMDs really had) reads ~7 % higher: kept beside it
+        roof["peak_at_in_kernel_clock"] = roof["peak"]
+        roof["peak"] = N_SIMD * SPEC_CLOCK_MHZ * 1e6 / VALU_CYCLES / 1e9
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["frac_at_spec_clock"] = roof["frac"]
+        roof["frac_at_in_kernel_clock"] = roof["achieved"] / roof["peak_at_in_kernel_clock"]
+        if counters.get("wave_points_per_launch"):
+            # what of that issue rate is the reference's arithmetic: SURVEY 8(d)'s 60 flop per projected point x the points the kernel really visits
+            # (counted: one v_rsq_f32 wave-instruction per 64 point visits) against the fp32 vector peak
+            uf = FLOPS_PER_POINT * counters["wave_points_per_launch"] * 64.0 / (k_ms * 1e-3) / 1e12
+            roof["useful_flops"] = {"TFLOPs": uf, "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS, "frac": uf / FP32_VECTOR_PEAK_TFLOPS, "flops_per_point_visit": FLOPS_PER_POINT}
+        roof["counters_are"] = "SQ_INSTS_VALU / vmem / fabric bytes per launch are COMMITTED constants (profiles/counters.json, checked against a hash of the kernel sources); only the launch time and the clock are measured live"
+        roof["valu_insts_per_launch"] = counters["valu_insts_per_launch"]
+        roof["trans_insts_per_launch"] = counters.get("trans_insts_per_launch")
+        roof["traffic"] = counters.get("hbm_bytes_per_launch")      # (the key's name is round 1's; what it holds is the FABRIC traffic: see the note)
+        if roof["traffic"]:
+            roof["fabric_GBs"] = roof["traffic"] / (k_ms * 1e-3) / 1e9
+            # which level that traffic could be bound by: an on-die gather (8.6 TB/s measured in the guide) while the working set fits the Infinity Cache, the HBM peak beyond
+            fabric_peak = L3_GATHER_PEAK_GBS if roof["l3_resident"] else HBM_PEAK_GBS
+            roof["fabric_frac"] = roof["fabric_GBs"] / fabric_peak
+            if roof["fabric_frac"] > roof["frac_at_in_kernel_clock"]:
+                # a mode whose fabric traffic is the larger fraction of its ceiling than its VALU issue is AT THE CLOCK THE CHIP HELD (a distance map per scan:
+                # 3 GB of maps gathered at random; the projective stream over a 4M-point map and beyond: L2 hit rate 17 % and falling)
+                roof["valu_issue"] = {"achieved": roof["achieved"], "peak": roof["peak"], "frac": roof["frac"], "frac_at_in_kernel_clock": roof["frac_at_in_kernel_clock"], "unit": roof["unit"]}
+                roof.update(bound="fabric (Infinity Cache)" if roof["l3_resident"] else "fabric (Infinity Cache + HBM)", achieved=roof["fabric_GBs"], peak=fabric_peak, unit="GB/s",
+                            frac=roof["fabric_frac"])
+        if counters.get("point_visits_frac") is not None:
+            # the exact culling against the fixed canvas (round 3): which fraction of the (point, iteration) visits of the plain stream the
+            # kernel still makes -- counted (v_rsq_f32 wave-instructions), not modelled; the results are bit-identical either way
+            roof["culling"] = {"point_visits_frac": counters["point_visits_frac"], "wave_point_visits_per_launch": counters.get("wave_points_per_launch"),
+                               "wave_point_visits_without_culling": counters.get("wave_points_full")}
+        roof["counters_source"] = counters.get("source")
+        if counters.get("stream_cycles_per_wave_point") and counters.get("wave_points_per_launch"):
+            # the second, sharper yardstick: what the 1024 SIMDs need for THIS instruction stream when nothing else is in the way
+            # (tools/valu_issue_probe.hip runs csrc's project_point_stream on register-resident points: cycles per point of a wave)
+            cyc = counters["stream_cycles_per_wave_point"] * counters["wave_points_per_launch"] / N_SIMD
+            floor_ms = cyc / (clk * 1e6) * 1e3
+            roof["stream_floor"] = {"cycles_per_wave_point": counters["stream_cycles_per_wave_point"], "floor_ms_at_measured_clock": floor_ms,
+                                    "frac": floor_ms / k_ms,
+                                    "note": "kernel time / (point visits x the stream's own measured issue cost): bin walk, reductions, 3x3 solves and "
+                                            "barriers of the other workgroups on a CU run underneath the stream when this is ~1 (the probe is a launch of its own: "
+                                            "+-2 % between passes, so values just above 1 are its error, not a faster-than-floor kernel)"}
+    if warn:
+        roof["warning"] = warn
+        print("bench.py: " + warn, file=sys.stderr)
+    return roof
+
+
+def measure_also(ctx, api, synth, world_geom, wl, scan_set, args) -> list:
+    """The other single-GPU BASELINE configurations, timed ONCE inside the default run so that the driver's record holds them: each entry has
+    its own parity gate (noise-free data: the generating pose within 1e-4 m / 1e-4 rad), wall ms per step, kernel ms by HIP events, the in-kernel clock and a
+    roofline block built like the headline's."""
+    import time as _t
+    entries = []
+
+    def timed(prepared, warm, steps):
+        for _ in range(warm):
+            prepared.run()
+        k, c, w = [], [], []
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            r = prepared.run(); k.append(r.kernel_ms); c.append(r.kernel_clock_mhz); w.append(r.workgroup_lifetime_ms)
+        wall = (_t.perf_counter() - t0) / steps * 1e3
+        clk = float(np.median([x for x in c if x > 0])) if any(x > 0 for x in c) else None
+        return r, wall, float(np.mean(k)), clk, float(np.median(w))
+
+    def gate(res, x_true):
+        err = np.abs(res.pose - x_true); err[:, 2] = np.abs((err[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+        return bool(np.all(res.status == 0) and err[:, :2].max() < 1e-4 and err[:, 2].max() < 1e-4), float(err[:, :2].max()), float(err[:, 2].max())
+
+    ctx.set_option("kernel_timing", 1)
+    n_scan_mean = float(np.diff(wl.scan_offsets).mean())
+    proj = api.PointNormal2fProjectorPolar(args.beams, -np.pi, np.pi, 0.3, 30.0)
+    # ---- configs[4]: the same 1000 scans against a 1M-point map of the same world
+    map1m = api.CloudSet(ctx, synth.make_map(world_geom, 1000000, seed=args.seed))
+    al = api.MultiAligner2D(ctx, max_iterations=args.iterations, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, proj, point_distance=0.5, normal_cos=0.8), min_num_correspondences=10))
+    res, wall, k_ms, clk, wg = timed(al.prepare_batch([scan_set], [map1m], wl.x0), 2, 3)
+    ok, em, er = gate(res, wl.x_true)
+    entries.append({"config": "configs[4]: %d scans x %d-beam vs one 1000000-pt map, %d GN iters, role A, projective finder" % (args.scans, args.beams, args.iterations),
+                    "value": args.scans / (wall * 1e-3), "unit": "alignments/s", "steps": 3, "warmup": 2, "ms_per_step": wall, "parity_ok": ok, "max_pose_err_m": em, "max_pose_err_rad": er,
+                    "roofline": build_roofline("A", "projective", args.scans, 1000000, args.iterations, args.beams, 0.0, args.scans, n_scan_mean, k_ms, 3, clk, wg)})
+    map1m.close()
+    # ---- configs[3]: 65 536 loop-closure candidates = 2 048 distinct scans x 32 perturbed guesses each, Cauchy 0.05 (MULTI.json:957-962), against the 100k-point submap
+    n_unique, n_cand = 2048, 65536
+    wl3 = synth.make_workload(n_unique, args.map_points, seed=args.seed, n_beams=args.beams, world=world_geom, map_points=np.zeros((0, 4), np.float32))
+    idx = (np.arange(n_cand) % n_unique).astype(np.int32)
+    delta = synth.Stream(args.seed + 1000, salt=9).uniform(3 * n_cand, -0.05, 0.05).reshape(n_cand, 3)
+    x_true3 = wl3.x_true[idx]
+    x03 = synth.invert_poses(synth.compose_poses(synth.invert_poses(wl3.x_true)[idx], delta)).astype(np.float32)
+    scans3 = api.CloudSet(ctx, wl3.scan_points, wl3.scan_offsets)
+    map100k = api.CloudSet(ctx, synth.make_map(world_geom, args.map_points, seed=args.seed))
+    al3 = api.MultiAligner2D(ctx, max_iterations=args.iterations, min_num_inliers=10)
+    al3.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, proj, point_distance=0.5, normal_cos=0.8), min_num_correspondences=10,
+                                                                       robustifier=api.RobustifierCauchy(0.05)))
+    res, wall, k_ms, clk, wg = timed(al3.prepare_batch([scans3], [map100k], x03, fixed_index=idx[None, :]), 1, 1)
+    ok, em, er = gate(res, x_true3)
+    entries.append({"config": "configs[3] (one GPU's view): %d candidates over %d scans x %d-beam vs one %d-pt submap, Cauchy 0.05, %d GN iters" % (n_cand, n_unique, args.beams, args.map_points, args.iterations),
+                    "value": n_cand / (wall * 1e-3), "unit": "alignments/s", "steps": 1, "warmup": 1, "ms_per_step": wall, "parity_ok": ok, "max_pose_err_m": em, "max_pose_err_rad": er,
+                    "roofline": build_roofline("A", "projective", n_cand, args.map_points, args.iterations, args.beams, 0.05, n_unique, float(np.diff(wl3.scan_offsets).mean()), k_ms, 1, clk, wg)})
+    scans3.close(); map100k.close()
+    return entries
+
+
+def run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, args, side) -> None:
+    """bench.py --stream: ranges in -> poses out, new scans every step, one step in flight.  See the option's help; DESIGN.md section 5 'fresh data'."""
+    import gc
+    a0, a1 = -0.75 * np.pi, 0.75 * np.pi                      # the 270-degree scanner of synth.make_scans
+    nb, n, nbatch = args.beams, args.scans, max(2, args.stream_batches)
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=30.0, voxelize_resolution=0.02, normal_point_distance=0.3, normal_min_points=5)   # MULTI.json:496-521, 845-853
+    data = []
+    for k in range(nbatch):
+        poses = synth.sample_poses(world_geom, n, seed=args.seed + 7919 * (k + 1))
+        rg = synth.make_scan_ranges(world_geom, poses, n_beams=nb, angle_min=a0, angle_max=a1, seed=args.seed + k)
+        x_true, x0 = synth.initial_guesses(poses, seed=args.seed + k)
+        data.append({"ranges": torch.from_numpy(np.ascontiguousarray(rg, np.float32)).pin_memory(), "x0": x0.astype(np.float32), "x_true": x_true})
+    # the synchronous path on every distinct batch: what each streamed step must reproduce BIT FOR BIT
+    for d in data:
+        pre.setRawData(d["ranges"], a0, a1, 0.0, 30.0)
+        fx = pre.compute()
+        d["want"] = aligner.compute_batch([fx], [map_set], d["x0"])
+        d["points"] = int(fx.n_points)
+        fx.close()
+    sets = []
+    for k in range(2):
+        pre.setRawData(data[k]["ranges"], a0, a1, 0.0, 30.0); sets.append(pre.compute())
+    prep = [aligner.prepare_batch([sets[k]], [map_set], data[k]["x0"]) for k in range(2)]
+    state = {"i": 0, "bad": 0, "checked": 0, "last": None}
+
+    def check(step_i, res):
+        d = data[step_i % nbatch]
+        same = np.array_equal(res.pose, d["want"].pose) and np.array_equal(res.information, d["want"].information) and np.array_equal(res.status, d["want"].status)
+        state["checked"] += 1; state["bad"] += 0 if same else 1
+
+    def step(timed=False):
+        i = state["i"]; d = data[i % nbatch]
+        pre.setRawData(d["ranges"], a0, a1, 0.0, 30.0)
+        pre.refill(sets[i % 2])
+        prep[i % 2].set_init_poses(d["x0"])
+        prep[i % 2].begin()
+        res = None
+        if i > 0:
+            res = prep[(i - 1) % 2].wait()
+            check(i - 1, res)
+        state["i"] = i + 1
+        return res
+
+    gc.collect(); gc.freeze()
+    spin = 0; t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup_s:
+        step(); spin += 1
+    for _ in range(args.warmup):
+        step()
+    gc.disable()
+    kernel_ms, clock_mhz, wg_ms = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):      # every pass begins one batch and retires one: K batches per K steps, one in flight across the region's edges
+        res = step()
+        if res is not None:
+            kernel_ms.append(res.kernel_ms); clock_mhz.append(res.kernel_clock_mhz); wg_ms.append(res.workgroup_lifetime_ms)
+    elapsed = time.perf_counter() - t0
+    last_i = state["i"] - 1
+    res = prep[last_i % 2].wait(); check(last_i, res)
+    gc.enable()
+    # the resident-input step of the default line, same process, same clock state: the ratio the verdict asks for
+    d0 = data[0]
+    pre.setRawData(d0["ranges"], a0, a1, 0.0, 30.0); fx = pre.compute()
+    resident = aligner.prepare_batch([fx], [map_set], d0["x0"])
+    for _ in range(20):
+        resident.run()
+    t1 = time.perf_counter()
+    n_res = max(20, args.steps)
+    for _ in range(n_res):
+        r0 = resident.run()
+    resident_ms = (time.perf_counter() - t1) / n_res * 1e3
+    est_skipped = not bool(ctx.get_option("last_cull_estimate"))
+    # gates: every streamed step bit-identical to the synchronous path; poses near the generating ones (PCA normals on 2 cm voxels: centimetres, not 1e-4: DESIGN 5)
+    w = data[last_i % nbatch]["want"]; xt = data[last_i % nbatch]["x_true"]
+    ok_mask = w.status == 0
+    err = np.abs(w.pose - xt); err[:, 2] = np.abs((err[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+    near = bool(ok_mask.mean() > 0.98 and err[ok_mask][:, :2].max() < 3e-2 and err[ok_mask][:, 2].max() < 1e-2)
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
+    clk = float(np.median([c for c in clock_mhz if c > 0])) if any(c > 0 for c in clock_mhz) else None
+    ms = elapsed / args.steps * 1e3
+    rbytes = 4.0 * nb * n
+    out = {"metric": "scan-to-map alignments/sec (1081-beam vs 100k-pt map, 20 GN iters)", "value": n * args.steps / elapsed, "unit": "alignments/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "spinup_steps": spin, "ms_per_step": ms, "timed_region_s": elapsed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "STREAM: every step %d NEW %d-beam range vectors (pinned host memory) -> preprocessed on the device (2 cm voxels, sliding-window normals) -> aligned vs one "
+                                  "%d-pt map, %d GN iters, role A, projective finder; one step in flight" % (n, nb, args.map_points, args.iterations),
+                      "alignments_per_gpu": n, "map_points": args.map_points, "beams": nb, "iterations": args.iterations, "distinct_batches": nbatch,
+                      "points_per_batch_after_preprocessing": data[0]["points"]},
+           "parity_ok": bool(state["bad"] == 0 and near), "steps_checked_bitwise_against_the_synchronous_calls": state["checked"], "steps_that_differed": state["bad"],
+           "max_pose_err_m": float(err[ok_mask][:, :2].max()), "max_pose_err_rad": float(err[ok_mask][:, 2].max()), "alignments_succeeded_frac": float(ok_mask.mean()),
+           "stream": {"h2d_bytes_per_step": rbytes, "h2d_GBs_sustained": rbytes / (ms * 1e-3) / 1e9, "resident_input_ms_per_step_same_scans": resident_ms,
+                      "resident_step_skips_the_estimate": est_skipped, "sustained_over_resident": resident_ms / ms,
+                      "note": "resident = the same preprocessed scans already in HBM, lsm2d_align_batch per step (what the default line times); sustained_over_resident = its ms per step / "
+                              "the streamed ms per step"},
+           # (no committed counters for this workload -- the preprocessed scans are other clouds than the resident line's: the PMC-derived fields stay null)
+           "roofline": build_roofline("A", "projective", n, args.map_points, args.iterations, nb, 0.0, 0, data[0]["points"] / float(n), k_ms or float("nan"), len(kernel_ms), clk,
+                                      float(np.median(wg_ms)) if wg_ms else None)}
+    print(json.dumps(out), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +368,13 @@ def main() -> None:
     ap.add_argument("--beams", type=int, default=1081)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="alignments timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream", action="store_true",
+                    help="fresh data every step (VERDICT r4 item 3): each step uploads a NEW batch of raw range vectors (pinned host memory, 4 bytes per beam), preprocesses "
+                         "them on the device into one of two alternating scan sets (lsm2d_preprocess_scans_refill) and aligns them (lsm2d_align_batch_begin / _wait) "
+                         "while the previous step's batch is still in flight; value = alignments/s sustained from ranges to poses")
+    ap.add_argument("--stream-batches", type=int, default=4, help="--stream: distinct range batches cycled through (each has its own truth; every step is gated)")
+    ap.add_argument("--no-also", action="store_true", help="the default N=1 line carries an `also` block -- BASELINE configs[4] (1000 scans vs a 1M-point map, 3 steps) and "
+                                                              "configs[3] (65 536 candidates over 2 048 scans, Cauchy 0.05, 1 step), each with its own parity gate, kernel ms, clock and roofline; this skips it")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--role", choices=["A", "B"], default="A", help="A: fixed=scan, moving=map (reference tracker wiring); B: fixed=map, moving=scan")
     ap.add_argument("--finder", choices=["projective", "nn", "kdtree", "distmap"], default="projective",
@@ -223,6 +481,12 @@ def main() -> None:
     aligner = api.MultiAligner2D(ctx, max_iterations=args.iterations, min_num_inliers=10)
     robust = api.RobustifierCauchy(args.cauchy) if args.cauchy > 0 else None
     aligner.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(finder, min_num_correspondences=10, robustifier=robust))
+    if args.stream:
+        if world != 1 or args.role != "A" or args.finder != "projective" or strong:
+            raise SystemExit("--stream: one GPU, role A, projective finder")
+        run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, args, side)
+        ctx.close()
+        return
     shard_info = None
     if strong:
         # this rank's shard of the global list: by estimated work (lsm2d_estimate_work -- with the exact culling an alignment's time follows the number
@@ -374,73 +638,8 @@ def main() -> None:
             cfg_key += "/cauchy%g" % args.cauchy
         if n_unique != args.scans:                # scans shared through the index array: another memory pattern
             cfg_key += "/unique%d" % n_unique
-        counters, warn = load_counters(cfg_key)
-        effective = bytes_per_alignment * args.scans / (k_ms * 1e-3) / 1e9
-        roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave64-VALU issue slots/s", "frac": None, "traffic": None,
-                "kernel": "k_align", "kernel_ms": k_ms, "kernel_ms_samples": len(kernel_ms), "clock_mhz_in_kernel": clk, "workgroup_lifetime_ms": float(np.median(wg_ms)) if wg_ms else None,
-                "hbm": {"effective_l2_served_GBs": effective, "effective_over_hbm_peak": effective / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_launch": bytes_per_alignment * args.scans, "hbm_real_GBs": None, "hbm_real_frac": None,
-                        "peak_GBs": HBM_PEAK_GBS},
-                "note": "the map is L2-resident (TCC hit > 99 %), so HBM does not bind: frac = VALU issue slots used / slots the 1024 SIMDs have at the "
-                        "2.4 GHz spec clock (frac_at_in_kernel_clock: at the clock measured inside the launch); hbm.* keeps the SURVEY 8(d) algorithmic figure "
-                        "and the counter-measured DRAM rate"}
-        # what the L2s serve: the kernel's vector-memory read instructions x 1 KiB (16 bytes per lane) against the 34.5 TB/s of the eight L2s
-        # (MI355X_MICROARCH.md, "L2 (per XCD)"); the instruction count is a committed counter like the VALU count (profiles/counters.json)
-        if counters and counters.get("vmem_rd_insts_per_launch"):
-            l2_bytes = counters["vmem_rd_insts_per_launch"] * 1024.0
-            roof["l2_served"] = {"bytes_per_launch": l2_bytes, "GBs": l2_bytes / (k_ms * 1e-3) / 1e9, "peak_GBs": L2_PEAK_GBS,
-                                 "frac": l2_bytes / (k_ms * 1e-3) / 1e9 / L2_PEAK_GBS}
-        if clk:
-            roof["peak"] = N_SIMD * clk * 1e6 / VALU_CYCLES / 1e9
-        if counters and clk:
-            # nominal costs (MI355X_MICROARCH.md): a wave64 VALU instruction issues over 2 cycles, a transcendental (one v_rsq_f32 per point
-            # slot of the stream) over 4, i.e. one slot more than SQ_INSTS_VALU counts for it.  (Measured, tools/valu_issue_probe.hip: 2.15 and
-            # ~12-18 cycles -- the stream_floor block below prices the launch with the measured costs instead.)
-            slots = counters["valu_insts_per_launch"] + counters.get("trans_insts_per_launch", 0.0)
-            roof["achieved"] = slots / (k_ms * 1e-3) / 1e9
-            # `frac` is priced against the SPEC clock (2.4 GHz) since round 4 -- the peak the guide prints; the chip holds 2.1-2.3 GHz under this load,
-            # so the figure against the clock measured inside the launch (the slots the SIMDs really had) reads ~7 % higher: kept beside it
-            roof["peak_at_in_kernel_clock"] = roof["peak"]
-            roof["peak"] = N_SIMD * SPEC_CLOCK_MHZ * 1e6 / VALU_CYCLES / 1e9
-            roof["frac"] = roof["achieved"] / roof["peak"]
-            roof["frac_at_spec_clock"] = roof["frac"]
-            roof["frac_at_in_kernel_clock"] = roof["achieved"] / roof["peak_at_in_kernel_clock"]
-            if counters.get("wave_points_per_launch"):
-                # what of that issue rate is the reference's arithmetic: SURVEY 8(d)'s 60 flop per projected point x the points the kernel really visits
-                # (counted: one v_rsq_f32 wave-instruction per 64 point visits) against the fp32 vector peak
-                uf = FLOPS_PER_POINT * counters["wave_points_per_launch"] * 64.0 / (k_ms * 1e-3) / 1e12
-                roof["useful_flops"] = {"TFLOPs": uf, "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS, "frac": uf / FP32_VECTOR_PEAK_TFLOPS, "flops_per_point_visit": FLOPS_PER_POINT}
-            roof["counters_are"] = "SQ_INSTS_VALU / vmem / HBM bytes per launch are COMMITTED constants (profiles/counters.json, checked against a hash of the kernel sources); only the launch time and the clock are measured live"
-            roof["valu_insts_per_launch"] = counters["valu_insts_per_launch"]
-            roof["trans_insts_per_launch"] = counters.get("trans_insts_per_launch")
-            roof["traffic"] = counters.get("hbm_bytes_per_launch")
-            if roof["traffic"]:
-                roof["hbm"]["hbm_real_GBs"] = roof["traffic"] / (k_ms * 1e-3) / 1e9
-                roof["hbm"]["hbm_real_frac"] = roof["hbm"]["hbm_real_GBs"] / HBM_PEAK_GBS
-                if roof["hbm"]["hbm_real_frac"] > roof["frac"]:
-                    # a mode whose counter-measured DRAM traffic is the larger fraction (a distance map per scan: 3 GB of maps gathered at random)
-                    roof["valu_issue"] = {"achieved": roof["achieved"], "peak": roof["peak"], "frac": roof["frac"], "unit": roof["unit"]}
-                    roof.update(bound="hbm", achieved=roof["hbm"]["hbm_real_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roof["hbm"]["hbm_real_frac"],
-                                note="counter-measured DRAM traffic (2 x FETCH_SIZE + WRITE_SIZE) / launch time against the HBM peak; valu_issue keeps the other yardstick")
-            if counters.get("point_visits_frac") is not None:
-                # the exact culling against the fixed canvas (round 3): which fraction of the (point, iteration) visits of the plain stream the
-                # kernel still makes -- counted (v_rsq_f32 wave-instructions), not modelled; the results are bit-identical either way
-                roof["culling"] = {"point_visits_frac": counters["point_visits_frac"], "wave_point_visits_per_launch": counters.get("wave_points_per_launch"),
-                                   "wave_point_visits_without_culling": counters.get("wave_points_full")}
-            roof["counters_source"] = counters.get("source")
-            if counters.get("stream_cycles_per_wave_point") and counters.get("wave_points_per_launch"):
-                # the second, sharper yardstick: what the 1024 SIMDs need for THIS instruction stream when nothing else is in the way
-                # (tools/valu_issue_probe.hip runs csrc's project_point_stream on register-resident points: cycles per point of a wave)
-                cyc = counters["stream_cycles_per_wave_point"] * counters["wave_points_per_launch"] / N_SIMD
-                floor_ms = cyc / (clk * 1e6) * 1e3
-                roof["stream_floor"] = {"cycles_per_wave_point": counters["stream_cycles_per_wave_point"], "floor_ms_at_measured_clock": floor_ms,
-                                        "frac": floor_ms / k_ms,
-                                        "note": "kernel time / (point visits x the stream's own measured issue cost): bin walk, reductions, 3x3 solves and "
-                                                "barriers of the other workgroups on a CU run underneath the stream when this is ~1 (the probe is a launch of its own: "
-                                                "+-2 % between passes, so values just above 1 are its error, not a faster-than-floor kernel)"}
-        if warn:
-            roof["warning"] = warn
-            print("bench.py: " + warn, file=sys.stderr)
+        roof = build_roofline(args.role, args.finder, args.scans, args.map_points, args.iterations, args.beams, args.cauchy, n_unique, n_scan_mean,
+                              k_ms, len(kernel_ms), clk, float(np.median(wg_ms)) if wg_ms else None)
         out = {
             "metric": "scan-to-map alignments/sec (1081-beam vs 100k-pt map, 20 GN iters)",
             "value": n_total / elapsed, "unit": "alignments/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup_steps,
@@ -459,6 +658,13 @@ def main() -> None:
         }
         if options_set:
             out["options"] = options_set
+        # what the timed steps did about the placement of the batch: the library keeps the order it made for a batch and launches no estimate (k_cull_estimate, ~33 us)
+        # when the SAME batch -- sets, indices, parameters, start poses -- is run again, which is what this resident-input step does; `--stream` (fresh scans
+        # every step) pays it every time
+        out["placement"] = {"estimate_launched_in_last_step": bool(ctx.get_option("last_cull_estimate")),
+                            "note": "a batch run again with unchanged sets and start poses keeps its placement (lsm2d.h, option last_cull_estimate)"}
+        if world == 1 and default_cfg and not args.no_also and not options_set:
+            out["also"] = measure_also(ctx, api, synth, world_geom, wl, scan_set, args)
         if cross:
             out["cross_rank_check"] = cross
         if per_rank_ms is not None:

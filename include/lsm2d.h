@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 140 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
+#define LSM2D_VERSION 150 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
                              0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes;
                              0.2.0: + lsm2d_clip_scene_voxelized, lsm2d_sweep_* (multi-device loop-closure sweep), in-kernel clock options;
                              0.2.1: + lsm2d_cloudset_cloud_sizes, pinned / device-resident ranges in lsm2d_preprocess_scans, options
@@ -40,7 +40,10 @@ extern "C" {
                              0.4.0: lsm2d_iteration_stats grew the order-independent digest of the iteration's correspondence set (pair_digest_lo / _hi);
                                     lsm2d_aligner_params grew enable_inlier_only_runs / keep_only_inlier_correspondences (no longer refused);
                                     + lsm2d_align_batch_pairs (the correspondences the aligner leaves in its slices), lsm2d_stats_capacity,
-                                    lsm2d_pair_hash, lsm2d_estimate_work (work-aware sharding of a candidate sweep) */
+                                    lsm2d_pair_hash, lsm2d_estimate_work (work-aware sharding of a candidate sweep);
+                             0.5.0: + lsm2d_align_batch_begin / _wait (a batch in flight while the host prepares the next one), lsm2d_preprocess_scans_refill
+                                    (fresh scans into an existing set: no allocation, nothing waits); the option keys below are the WHOLE public set (the A/B
+                                    knobs of rounds 1-4 exist only in a -DLSM2D_EXPERIMENTS build); read-only keys "uploads", "last_cull_estimate", "experiments" */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -166,25 +169,36 @@ int  lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out_ctx);
 void lsm2d_destroy(lsm2d_context* ctx);
 /* blocks until everything queued on the context's stream has finished */
 int  lsm2d_synchronize(lsm2d_context* ctx);
-/* tuning / test knobs.  "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align),
- * 2 = always the split path (k_split_project + k_split_finish per iteration; projective slices only), 3 = the latency
- * kernel whenever the batch has one or two projective slices (k_align_pair: 512 threads per slice, two slices' passes side by
- * side in one workgroup; automatic for <= 256 alignments).  All paths return bit-identical results; the split path is for a
- * handful of alignments against a large cloud, the latency kernel for calls that cannot fill the chip (the live tracker).
- * "kernel_timing": 1 records HIP events around the hot-path launches so that lsm2d_last_kernel_ms can report them; 0 (default)
- * does not -- the two timed events per operation cost a latency-critical caller such as the live tracker ~20 % of its step --
- * and lsm2d_last_kernel_ms returns LSM2D_BAD_ARGUMENT.
- * "distmap_build": 0 = automatic (default: the distance maps of CorrespondenceFinderNN2D are built from the points' side, one disc of
- * atomic minima per point, whenever squared pixel distance and point index pack into 31 bits), 1 = always the per-pixel gather build;
- * the two produce identical correspondences.
- * "grid_big_threshold" (default 16384): fixed clouds of at least this many points get the NN finder's search grid built by chip-wide
- * kernels (histogram / scan / scatter over many workgroups) instead of one workgroup per cloud; results do not depend on it.
- * "find_path": 0 = automatic (default: a point-query lsm2d_find_correspondences call with more queries than one workgroup takes in a trip
- * runs on many workgroups, two launches; the projective finder z-buffers a cloud of more than 32768 points over many workgroups first),
- * 1 = always one workgroup; same pairs, same order.
- * "zero_copy_max" (default 256): batches of at most this many alignments read their arguments from, and write their results to, pinned
- * host memory directly (no transfers, status words polled) -- above 256 alignments only when the batch carries no index arrays; measured
- * slower than the transfers at 1000 alignments.  0 switches the zero-copy form off. */
+/* Options: the WHOLE public set (13 keys; anything else is LSM2D_BAD_ARGUMENT "unknown option").  Results never depend on any of them.
+ * "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align), 2 = always the split path (k_split_project +
+ *   k_split_finish per iteration; projective slices only), 3 = the latency kernel whenever the batch has one or two projective slices
+ *   (k_align_pair: 512 threads per slice, two slices' passes side by side in one workgroup; automatic for <= 256 alignments).  All paths return
+ *   bit-identical results; the split path is for a handful of alignments against a large cloud, the latency kernel for calls that cannot fill
+ *   the chip (the live tracker).
+ * "kernel_timing": 1 records HIP events around the hot-path launches so that lsm2d_last_kernel_ms can report them; 0 (default) does not -- the
+ *   two timed events per operation cost a latency-critical caller such as the live tracker ~20 % of its step -- and lsm2d_last_kernel_ms
+ *   returns LSM2D_BAD_ARGUMENT.  "clock_stride" (default 0 = ~32 per launch): with kernel timing on, every clock_stride-th workgroup of a k_align
+ *   launch stamps its shader-cycle and 100 MHz counters (get: "last_kernel_clock_khz", "last_workgroup_lifetime_ns").
+ * "find_path": 0 = automatic (default: a point-query lsm2d_find_correspondences call with more queries than one workgroup takes in a trip runs on
+ *   many workgroups, two launches; the projective finder z-buffers a cloud of more than 32768 points over many workgroups first), 1 = always one
+ *   workgroup; same pairs, same order.
+ * "zero_copy_max" (default 256): batches of at most this many alignments read their arguments from, and write their results to, pinned host memory
+ *   directly (no transfers, status words polled) -- above 256 alignments only when the batch carries no index arrays; measured slower than the
+ *   transfers at 1000 alignments.  0 switches the zero-copy form off.
+ * "cull" (default 1): the aligner's projective slices drop, exactly, the parts of a map-sized moving cloud that cannot yield a pair (and its
+ *   point-query slices the tiles of queries nobody is near); 0 streams everything.  "cull_margin_um" (10000) / "cull_margin_urad" (2000, at most
+ *   50000): how far a pose may move before the kept survivor lists of the projective culling are rebuilt.
+ * "balance" (default 1): batches of 257 .. 4096 culled alignments are placed on the chip by estimated work (one small launch ahead of k_align; a
+ *   batch run again with unchanged sets and start poses keeps its placement: get "last_cull_estimate"); 0: workgroup i runs alignment i.
+ * "grid_big_threshold" (default 16384): fixed clouds of at least this many points get the NN finder's search grid built by chip-wide kernels
+ *   (histogram / scan / scatter over many workgroups) instead of one workgroup per cloud.
+ * "distmap_build": 0 = automatic (default: the distance maps of CorrespondenceFinderNN2D are built from the points' side, one disc of atomic minima
+ *   per point, whenever squared pixel distance and point index pack into 31 bits), 1 = always the per-pixel gather build; identical maps.
+ * "kd_lds_nodes" (default 1536): nodes of the fixed cloud's KD-tree a k_align workgroup keeps in LDS (its top levels).
+ * Read-only (lsm2d_get_option): "last_align_path" (1 k_align, 2 split, 3 slice pair), "last_query_cull", "last_cull_estimate", "last_kd_levels",
+ *   "last_kd_nodes", "last_kernel_clock_khz", "last_workgroup_lifetime_ns", "max_dyn_lds", "uploads" (host-to-device cloud uploads queued so far:
+ *   lsm2d_cloudset_create / _upload / lsm2d_preprocess_scans_refill), "last_h2d_bytes", "experiments" (1: this library was built with
+ *   -DLSM2D_EXPERIMENTS and also knows the A/B knobs of DESIGN.md App. A; the shipped library: 0). */
 int  lsm2d_set_option(lsm2d_context* ctx, const char* key, int64_t value);
 /* reads a knob back; also "last_align_path": what the most recent lsm2d_align_batch ran (1 k_align, 2 split, 3 slice pair) */
 int  lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* out_value);
@@ -250,6 +264,11 @@ typedef struct {
  * ORDERING note at lsm2d_cloudset_create_from_device: the producer's stream must have been synchronised with). */
 int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges,
                            int32_t n_scans, lsm2d_cloudset** out_set);
+/* The same operation INTO a set that lsm2d_preprocess_scans made for the same number of scans and beams: no allocation, nothing waits (RawDataPreprocessorProjective2D::compute
+ * per incoming message, sensor_processing/raw_data_preprocessor_projective_2d.cpp:13-51, for a BATCH of fresh messages per step).  Pinned `ranges` are fetched by an
+ * asynchronous copy, pageable ones staged first, device-resident ones read in place; the clouds' sizes stay on the device (lsm2d_cloudset_cloud_size asks for them: a wait).
+ * Same kernel, same bits as lsm2d_preprocess_scans.  The caller keeps `ranges` untouched until the batch that reads the set has been waited for. */
+int lsm2d_preprocess_scans_refill(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges, int32_t n_scans, lsm2d_cloudset* set);
 /* The live tracker's form of the same operation: ONE scan into an existing reserved single-cloud set (capacity >= n_beams) --
  * no allocation, nothing waits: the ranges are staged in the set's pinned buffer, the cloud's size stays on the device until
  * somebody asks (see lsm2d_clip_scene).  Same kernel, same bits as lsm2d_preprocess_scans with n_scans = 1.  Unless kernel timing is
@@ -349,6 +368,19 @@ int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params* aligner, c
  * balances the shards by the SUM of these numbers instead of by candidate count: with the culling an alignment's time follows it (33-59 % of the
  * chunks survive on configs[1]).  out_work: [n_alignments]. */
 int lsm2d_estimate_work(lsm2d_context* ctx, const lsm2d_batch* batch, int32_t* out_work);
+
+/* lsm2d_align_batch in two halves: what a host that feeds the aligner batch after batch does between launching one and needing its poses
+ * (the reference's candidate loop, MULTI.json:964-986, and its per-scan tracker, apps/visual_test_aligner_2d.cpp:123-156, are synchronous: this is
+ * what a pipelined host puts in their place).  begin() queues everything -- start poses, placement, kernels, the copies of the results -- and returns;
+ * the batch descriptor and what it points to may be reused as soon as it has.  wait() blocks until THAT batch is done (a younger one may be queued
+ * behind it) and fills the outputs exactly as lsm2d_align_batch would have: begin + wait == lsm2d_align_batch, bit for bit.  While a batch is in flight,
+ * the NEXT batch's lsm2d_preprocess_scans_refill and the pre-kernels of its begin() run on a second stream, in the slots the launch in flight leaves
+ * free.  At most two batches are in flight per context; they are waited for in the order they were begun; every begun batch must be waited for.
+ * The cloud sets a batch in flight reads must not be modified (a pipeline alternates between two scan sets).
+ * want_stats != 0: the batch keeps per-iteration statistics (wait's out_stats may then be non-NULL). */
+typedef struct lsm2d_pending lsm2d_pending;
+int lsm2d_align_batch_begin(lsm2d_context* ctx, const lsm2d_aligner_params* aligner, const lsm2d_batch* batch, int32_t want_stats, lsm2d_pending** out_pending);
+int lsm2d_align_batch_wait(lsm2d_pending* pending, float* out_pose, float* out_H, int32_t* out_status, int32_t* out_iterations, lsm2d_iteration_stats* out_stats);
 
 /* The same call, additionally handing back what aligner->compute() leaves in every slice's correspondence vector (the reference's
  * slice->correspondences(), apps/visual_test_aligner_2d.cpp:129-143): the pairs of the LAST iteration each alignment started, in the finder's

@@ -114,6 +114,9 @@ SYMBOLS = [
     ("lsm2d_stats_capacity", C.c_int32, [C.POINTER(AlignerParams)]),
     ("lsm2d_pair_hash", C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
     ("lsm2d_estimate_work", C.c_int, [_P, C.POINTER(Batch), _P]),
+    ("lsm2d_align_batch_begin", C.c_int, [_P, C.POINTER(AlignerParams), C.POINTER(Batch), C.c_int32, C.POINTER(_P)]),
+    ("lsm2d_align_batch_wait", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("lsm2d_preprocess_scans_refill", C.c_int, [_P, C.POINTER(Preprocessor), _P, C.c_int32, _P]),
 ]
 
 _lib = None

@@ -640,6 +640,29 @@ class PreparedBatch:
     def set_init_poses(self, init_poses) -> None:
         self._x0[...] = np.asarray(init_poses, np.float32).reshape(self._x0.shape)
 
+    def begin(self) -> None:
+        """lsm2d_align_batch_begin: queue the batch and return; ``wait()`` hands its results over.  At most two batches of a context may be in flight, waited for in
+        the order they were begun -- two PreparedBatch objects alternating (each keeps its own result arrays)."""
+        if getattr(self, "_pending", None) is not None:
+            raise RuntimeError("PreparedBatch.begin: this batch is in flight already")
+        h = C.c_void_p()
+        check(self._ctx._lib.lsm2d_align_batch_begin(self._ctx.handle, C.byref(self._ap), C.byref(self._b), 1 if self.stats is not None else 0, C.byref(h)),
+              "lsm2d_align_batch_begin", self._ctx.handle)
+        self._pending = h
+
+    def wait(self, copy: bool = False) -> BatchResult:
+        if getattr(self, "_pending", None) is None:
+            raise RuntimeError("PreparedBatch.wait: nothing in flight")
+        h, self._pending = self._pending, None
+        ctx = self._ctx
+        check(ctx._lib.lsm2d_align_batch_wait(h, self._args[3], self._args[4], self._args[5], self._args[6], self._args[7]), "lsm2d_align_batch_wait", ctx.handle)
+        n = self._b.n_alignments
+        timed = bool(n and ctx.kernel_timing)
+        c = (lambda a: None if a is None else a.copy()) if copy else (lambda a: a)
+        return BatchResult(c(self.pose), c(self._H).reshape(n, 3, 3), c(self.status), c(self.iterations), c(self.stats), ctx.last_kernel_ms() if timed else 0.0,
+                           ctx.get_option("last_kernel_clock_khz") * 1e-3 if timed else 0.0,
+                           ctx.get_option("last_workgroup_lifetime_ns") * 1e-6 if timed else 0.0, None)
+
     def run(self, copy: bool = False) -> BatchResult:
         ctx = self._ctx
         check(self._fn(*self._args), "lsm2d_align_batch", ctx.handle)
@@ -868,6 +891,21 @@ class RawDataPreprocessorProjective2D:
         cs.counts = sizes.astype(np.int64)
         self._meas = cs
         return cs
+
+    def refill(self, out: CloudSet) -> CloudSet:
+        """The streaming form: the batch of messages set with setRawData goes into ``out`` -- a set an earlier ``compute()`` made for the same number of scans
+        and beams -- with no allocation and no wait (lsm2d_preprocess_scans_refill): the ranges are fetched by an asynchronous copy (keep them untouched until
+        the batch that reads ``out`` has been waited for), the clouds' sizes stay on the device.  Same kernel, same bits as ``compute()``."""
+        if self._msg is None:
+            raise RuntimeError("RawDataPreprocessorProjective2D::compute| no raw data")
+        r, a0, a1, m_rmin, m_rmax = self._msg
+        pp = _capi.Preprocessor(r.shape[1], a0, a1, max(m_rmin, self.param_range_min), min(m_rmax, self.param_range_max),
+                                self.param_normal_point_distance, self.param_normal_min_points, self.param_voxelize_resolution)
+        _producer_stream_wait(r)
+        check(self._ctx._lib.lsm2d_preprocess_scans_refill(self._ctx.handle, C.byref(pp), _data_pointer(r), r.shape[0], out.handle),
+              "lsm2d_preprocess_scans_refill", self._ctx.handle)
+        self._meas = out
+        return out
 
     def compute_into(self, out: CloudSet) -> CloudSet:
         """The live tracker's form: the ONE scan set with setRawData goes into the reserved set ``out`` -- no allocation,

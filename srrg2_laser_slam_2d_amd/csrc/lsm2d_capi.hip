@@ -29,6 +29,7 @@ struct lsm2d_context {
   hipStream_t stream = nullptr;
   bool owns_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t last_ev0 = nullptr, last_ev1 = nullptr;      // the events lsm2d_last_kernel_ms reads: the current lane's, or those of the batch most recently waited for
   bool have_timing = false;
   std::string last_error;
   // pinned host staging + device scratch, grown on demand
@@ -95,7 +96,48 @@ struct lsm2d_context {
   int last_query_cull = 0;     // the latest aligner call ran its point-query finder with the exact culling of the queries (k_align, tiles of 64 moving points)
   long long last_kd_levels = 0, last_kd_nodes = 0;      // shape of the most recently built KD-tree set (levels of the deepest tree, nodes in all of them)
   std::vector<lsm2d_cloudset*> live_sets;      // lsm2d_destroy orphans what is left (a set destroyed after its context must not touch it)
+  // ---- batches in flight (lsm2d_align_batch_begin / _wait, round 5).  Everything a batch keeps between its launch and its results -- the pinned staging buffer its
+  // results land in, the device scratch its arguments and statistics live in, the placement the estimate made for it, its timing events -- forms a LANE; the
+  // context has two: the members above (h_stage, d_scratch, d_order, order_*, ev0, ev1) are the CURRENT lane's, `parked` holds the other one's.  begin() works
+  // on the current lane, marks it busy and swaps: whatever is called next (the refill and the begin of the FOLLOWING batch) finds a free lane; wait() frees
+  // the lane its batch was begun on.  At most two batches are in flight.
+  struct Lane {
+    void* h_stage = nullptr; size_t h_stage_bytes = 0; void* h_stage_dev = nullptr; void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
+    int32_t* d_order = nullptr; bool order_valid = false; unsigned long long order_key = 0; std::vector<float> order_poses;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr; bool busy = false; int id = 1;
+  } parked;
+  int lane_id = 0; bool lane_busy = false; hipEvent_t ev_done = nullptr;      // the current lane's id / busy flag / "this batch's last operation has run"
+  int inflight = 0;                        // batches begun and not yet waited for
+  // the SECOND stream: while a batch is in flight, what the next one needs ahead of its k_align -- its scans' preprocessing (lsm2d_preprocess_scans_refill), its
+  // start poses' upload, its placement's estimate -- is queued here, so the chip runs it in the slots the launch in flight leaves free (its tail), and k_align
+  // on the first stream waits for an event behind it
+  hipStream_t stream_b = nullptr; hipEvent_t ev_b = nullptr, ev_a_est = nullptr; bool b_dirty = false, a_est_recorded = false;
 };
+static void swap_lanes(lsm2d_context* c) {
+  lsm2d_context::Lane& p = c->parked;
+  std::swap(c->h_stage, p.h_stage); std::swap(c->h_stage_bytes, p.h_stage_bytes); std::swap(c->h_stage_dev, p.h_stage_dev);
+  std::swap(c->d_scratch, p.d_scratch); std::swap(c->d_scratch_bytes, p.d_scratch_bytes);
+  std::swap(c->d_order, p.d_order); std::swap(c->order_valid, p.order_valid); std::swap(c->order_key, p.order_key); c->order_poses.swap(p.order_poses);
+  std::swap(c->ev0, p.ev0); std::swap(c->ev1, p.ev1); std::swap(c->ev_done, p.ev_done); std::swap(c->lane_busy, p.busy); std::swap(c->lane_id, p.id);
+}
+// the stream a batch's PRE-kernels go to: the second one while another batch is in flight (created on first use), else the context's own
+static hipStream_t pre_stream(lsm2d_context* ctx) {
+  if (ctx->inflight <= 0) return ctx->stream;
+  if (!ctx->stream_b) {
+    if (hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); ctx->stream_b = nullptr; return ctx->stream; }
+    if (hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); (void) hipStreamDestroy(ctx->stream_b); ctx->stream_b = nullptr; return ctx->stream; }
+  }
+  ctx->b_dirty = true;
+  return ctx->stream_b;
+}
+// k_align (first stream) must see what the second stream was given for it
+static hipError_t join_pre_stream(lsm2d_context* ctx) {
+  if (!ctx->b_dirty || !ctx->stream_b) return hipSuccess;
+  hipError_t e = hipEventRecord(ctx->ev_b, ctx->stream_b);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_b, 0);
+  ctx->b_dirty = false;
+  return e;
+}
 
 // every wait for the context's stream goes through here: the epoch lets a set know that a transfer it queued from its pinned
 // staging buffer has certainly run (some wait happened since) without an event of its own
@@ -168,6 +210,7 @@ struct lsm2d_cloudset {
   int64_t capacity = 0;       // > 0: a reserved single growable cloud (lsm2d_cloudset_create_reserved)
   float2* d_xy = nullptr; float2* d_nrm = nullptr;
   int32_t* d_start = nullptr; int32_t* d_count = nullptr;
+  float* d_ranges = nullptr;      // lsm2d_preprocess_scans_refill: the device copy of the ranges the set was last refilled from
   std::vector<int32_t> h_start; mutable std::vector<int32_t> h_count;
   // Asynchronous clip / merge leave the size of a reserved set known to the device only: h_count[0] is then an UPPER BOUND
   // and count_pending is set; kernels read d_count, and whatever needs the exact number calls resolve_count() (one sync).
@@ -245,6 +288,11 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   else if (e == hipSuccess) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); c->owns_stream = true; }
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e == hipSuccess) e = hipEventCreate(&c->parked.ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->parked.ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->parked.ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_a_est, hipEventDisableTiming);
   if (e == hipSuccess) e = hipHostMalloc(&c->h_flag, 256, hipHostMallocDefault);
   if (e != hipSuccess) { g_last_error = hipGetErrorString(e); delete c; return LSM2D_DEVICE_ERROR; }
   // allow the big-canvas configurations to use the whole 160 KiB LDS of a CDNA4 CU
@@ -294,6 +342,12 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->d_kd_work) (void) hipFree(c->d_kd_work);
   if (c->d_wg_place) (void) hipFree(c->d_wg_place);
   if (c->d_order) (void) hipFree(c->d_order);
+  if (c->stream_b) (void) hipStreamSynchronize(c->stream_b);
+  if (c->parked.h_stage) (void) hipHostFree(c->parked.h_stage);
+  if (c->parked.d_scratch) (void) hipFree(c->parked.d_scratch);
+  if (c->parked.d_order) (void) hipFree(c->parked.d_order);
+  for (hipEvent_t e : {c->parked.ev0, c->parked.ev1, c->parked.ev_done, c->ev_done, c->ev_b, c->ev_a_est}) if (e) (void) hipEventDestroy(e);
+  if (c->stream_b) (void) hipStreamDestroy(c->stream_b);
   if (c->d_xcd) (void) hipFree(c->d_xcd);
   for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
@@ -402,8 +456,9 @@ extern "C" int lsm2d_get_option(lsm2d_context* ctx, const char* key, int64_t* ou
 extern "C" int lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms) {
   if (!ctx || !out_ms) return LSM2D_BAD_ARGUMENT;
   if (!ctx->have_timing) return fail(ctx, LSM2D_BAD_ARGUMENT, "no timed launch yet");
-  HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
-  HIPCHK(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+  hipEvent_t e0 = ctx->last_ev0 ? ctx->last_ev0 : ctx->ev0, e1 = ctx->last_ev1 ? ctx->last_ev1 : ctx->ev1;
+  HIPCHK(ctx, hipEventSynchronize(e1));
+  HIPCHK(ctx, hipEventElapsedTime(out_ms, e0, e1));
   return LSM2D_SUCCESS;
 }
 
@@ -530,6 +585,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_nrm) (void) hipFree(cs->d_nrm);
   if (cs->d_start) (void) hipFree(cs->d_start);
   if (cs->d_count) (void) hipFree(cs->d_count);
+  if (cs->d_ranges) (void) hipFree(cs->d_ranges);
   for (auto& g : cs->grids) if (g.d_block) (void) hipFree(g.d_block);
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block);
@@ -554,6 +610,13 @@ static int resolve_count(const lsm2d_cloudset* cs) {
   lsm2d_context* ctx = cs->ctx;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, stream_sync(ctx));
+  if (ctx->stream_b) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_b));      // (a refill queued on the second stream)
+  if (cs->n_clouds > 1) {      // a refilled set of scans (lsm2d_preprocess_scans_refill): every cloud's size
+    HIPCHK(ctx, hipMemcpy(cs->h_count.data(), cs->d_count, sizeof(int32_t) * (size_t) cs->n_clouds, hipMemcpyDeviceToHost));
+    cs->total = 0; for (int c = 0; c < cs->n_clouds; ++c) cs->total += cs->h_count[c];
+    cs->count_pending = false;
+    return LSM2D_SUCCESS;
+  }
   int32_t n = 0;
   HIPCHK(ctx, hipMemcpy(&n, cs->d_count, sizeof(int32_t), hipMemcpyDeviceToHost));
   cs->h_count[0] = n; cs->total = n; cs->count_pending = false;
@@ -1330,6 +1393,65 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   return LSM2D_SUCCESS;
 }
 
+// The same operation INTO an existing set of lsm2d_preprocess_scans (same number of scans and beams): no allocation, nothing waits -- the streaming form (a batch of
+// fresh scans per step while the previous batch aligns).  The ranges are copied to a device buffer of the set's own (pinned host memory: an asynchronous DMA;
+// pageable: staged through the set's pinned buffer; device memory: read in place) and preprocessed by one launch, both on the stream a batch's pre-kernels go to
+// (pre_stream: the second stream while a batch is in flight).  The clouds' sizes stay on the device (the host keeps the upper bound n_beams per scan) until
+// somebody asks; the set's AoS rows, if it has them, are rewritten by the same launch.
+extern "C" int lsm2d_preprocess_scans_refill(lsm2d_context* ctx, const lsm2d_preprocessor* pp, const float* ranges, int32_t n_scans, lsm2d_cloudset* set) {
+  if (!ctx || !pp || !ranges || !set || set->ctx != ctx || n_scans < 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scans_refill: bad argument");
+  const int nb = pp->n_beams;
+  if (nb < 1 || nb > kPrepMaxBeams) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "preprocess_scans_refill: n_beams must be in [1, 2048]");
+  if (!(pp->angle_max > pp->angle_min) || pp->normal_min_points < 1 || !(pp->normal_point_distance >= 0.0f))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scans_refill: bad parameters");
+  const int stride = nb + (nb & 1);
+  if (set->n_clouds != n_scans || set->capacity > 0 || set->padded_total != (int64_t) stride * n_scans + 2 || (n_scans > 1 && set->h_start[1] != stride))
+    return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scans_refill: the set must come from lsm2d_preprocess_scans with the same number of scans and beams");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rdev = -1;
+  const PtrKind kind = pointer_kind(ranges, &rdev);
+  if (kind == PtrKind::device && rdev != ctx->device) return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scans_refill: device-resident ranges must live on the context's device");
+  const size_t rbytes = sizeof(float) * (size_t) nb * (size_t) n_scans;
+  // everything derived from the old contents goes -- except the AoS rows, which this launch rewrites in place (hipFree is a device-wide wait)
+  float4* keep_aos = set->d_aos; set->d_aos = nullptr;
+  cloudset_drop_grids(set);
+  set->d_aos = keep_aos;
+  if (kind != PtrKind::device && !set->d_ranges) HIPCHK(ctx, hipMalloc((void**) &set->d_ranges, rbytes));
+  // beam directions with the host libm (the oracle does the same), once per sensor geometry
+  const float2* d_dir = nullptr;
+  for (const auto& bd : ctx->beam_dirs) if (bd.n_beams == nb && bd.angle_min == pp->angle_min && bd.angle_max == pp->angle_max) d_dir = bd.d_dir;
+  if (!d_dir) {
+    std::vector<float2> hd((size_t) nb);
+    const float sensor_res = (pp->angle_max - pp->angle_min) / (float) nb, k01 = (float) nb * 0.5f;
+    for (int c = 0; c < nb; ++c) { const float a = ((float) c - k01) * sensor_res; hd[c] = make_float2(cosf(a), sinf(a)); }
+    float2* d = nullptr;
+    HIPCHK(ctx, hipMalloc((void**) &d, sizeof(float2) * (size_t) nb));
+    hipError_t e = hipMemcpy(d, hd.data(), sizeof(float2) * (size_t) nb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void) hipFree(d); HIPCHK(ctx, e); }
+    ctx->beam_dirs.push_back({nb, pp->angle_min, pp->angle_max, d}); d_dir = d;
+  }
+  const hipStream_t pre = pre_stream(ctx);
+  if (kind == PtrKind::pageable) {
+    const int rc = acquire_upload_stage(set, rbytes + 16); if (rc) return rc;
+    memcpy(set->h_upload, ranges, rbytes);
+    HIPCHK(ctx, hipMemcpyAsync(set->d_ranges, set->h_upload, rbytes, hipMemcpyHostToDevice, pre));
+    set->staged_epoch = ctx->sync_epoch;
+  }
+  else if (kind == PtrKind::pinned) HIPCHK(ctx, hipMemcpyAsync(set->d_ranges, ranges, rbytes, hipMemcpyHostToDevice, pre));
+  ++ctx->uploads; ctx->last_h2d_bytes = kind == PtrKind::device ? 0 : (long long) rbytes;
+  PrepArgs A;
+  A.ranges = kind == PtrKind::device ? ranges : (const float*) set->d_ranges; A.beam_dir = d_dir;
+  A.n_beams = nb; A.stride = stride; A.rmin = pp->range_min; A.rmax = pp->range_max;
+  A.d2max = pp->normal_point_distance * pp->normal_point_distance; A.min_points = pp->normal_min_points;
+  A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
+  A.out_xy = set->d_xy; A.out_nrm = set->d_nrm; A.out_count = set->d_count; A.out_aos = set->d_aos;
+  hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, pre, A);
+  HIPCHK(ctx, hipGetLastError());
+  for (int c = 0; c < n_scans; ++c) set->h_count[c] = nb;      // upper bounds: the real sizes are on the device
+  set->total = (int64_t) nb * n_scans; set->count_pending = true; set->unpack_pending = false; set->prep_pending = false;
+  return LSM2D_SUCCESS;
+}
+
 // the live tracker's form: ONE scan into an existing reserved set, no allocation, no wait (size pending on the device)
 extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_preprocessor* pp, const float* ranges, lsm2d_cloudset* out) {
   if (!ctx || !pp || !ranges || !out || out->ctx != ctx || out->n_clouds != 1) return fail(ctx, LSM2D_BAD_ARGUMENT, "preprocess_scan_into: bad argument");
@@ -1818,13 +1940,31 @@ static const AlignVariant kAlignVariants[] = {
   {kFKd, 3, k_align<false, false, false, true, 3>},   {kFKd, 4, k_align<false, false, false, true, 4>}, {kFKd, 0, k_align<false, false, false, true>},
 };
 
+// What a batch that has been LAUNCHED keeps until its results are asked for (lsm2d_align_batch_begin / _wait; the synchronous calls go through the same two halves)
+struct lsm2d_pending {
+  lsm2d_context* ctx = nullptr;
+  int lane_id = 0; hipEvent_t ev_done = nullptr, ev0 = nullptr, ev1 = nullptr;
+  char* hs = nullptr;                       // the lane's pinned staging buffer: where the results are (or are copied to)
+  size_t o_pose = 0, o_H = 0, o_status = 0, o_its = 0, o_stats = 0, o_last_pose = 0, o_clock = 0;
+  int n = 0, stats_stride = 0, n_clock = 0, clock_stride = 0;
+  bool zero_copy = false, want_stats = false, want_last_pose = false, stamps = false, timed = false, async = false;
+  uint32_t* xcd_sync = nullptr; int xcd_stride = 0, xcd_window = 0, xcd_positions = 0;
+};
+static int align_batch_finish(lsm2d_pending& P, float* out_pose, float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats, float* out_last_pose);
+
 // out_last_pose [n][3] (may be NULL): the pose the last iteration every alignment started began at (what lsm2d_align_batch_pairs re-derives
 // that iteration's correspondences from)
 // out_work [n] (may be NULL): ONLY the work estimate of lsm2d_estimate_work is produced -- no alignment runs, the other outputs are not touched
+// pend != NULL: lsm2d_align_batch_begin -- the call returns once everything is queued; the output pointers only say WHICH outputs are wanted (non-null), nothing is
+// written through them; lsm2d_align_batch_wait -> align_batch_finish hands the results over.
 static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, const lsm2d_batch* b, float* out_pose,
                             float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats, float* out_last_pose,
-                            int32_t* out_work = nullptr) {
+                            int32_t* out_work = nullptr, lsm2d_pending* pend = nullptr) {
   if (!ctx || !ap || !b || ((!out_pose || !out_status) && !out_work)) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: null argument");
+  if (ctx->lane_busy) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: two batches are in flight on this context: wait for the older one first (lsm2d_align_batch_wait)");
+  const bool async = pend != nullptr;
+  // what goes AHEAD of k_align (start poses, the placement's estimate): on the second stream while another batch is in flight
+  const hipStream_t pre = (async && !out_work) ? pre_stream(ctx) : ctx->stream;
   const int n = b->n_alignments, ns = b->n_slices;
   if (n < 0 || ns < 1 || ns > kMaxSlices || ap->max_iterations < 0 || !b->slices || !b->fixed || !b->moving || (n > 0 && !b->init_pose))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad batch descriptor");
@@ -2109,7 +2249,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   // wait for a read of host memory
   A.inline_n1 = n == 1 && !use_split;
   if (A.inline_n1) { memcpy(A.pose1, b->init_pose, sizeof A.pose1); if (b->prior) memcpy(&A.prior1, hs + o_prior, sizeof A.prior1); }
-  if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, pre));
   A.init_pose = (const float*) (ds + o_pose_in);
   if (xcd_on && !use_split && !use_pair && !zero_copy) {
     const size_t xb = sizeof(uint32_t) * 16 * (size_t) A.xcd_stride;
@@ -2224,9 +2364,12 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
                          !memcmp(ctx->order_poses.data(), b->init_pose, sizeof(float) * 3 * (size_t) n);
       if (!reuse) {
         size_t est_lds = sizeof(u64) * (size_t) A.s[bs].proj.cols; if (est_lds < sizeof(BalanceLds)) est_lds = sizeof(BalanceLds);
-        hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), est_lds, ctx->stream, A, bs, d_work, ctx->d_order,
+        // (estimates share ONE ticket counter: one queued on the second stream waits for the latest one queued on the first)
+        if (pre != ctx->stream && ctx->a_est_recorded) HIPCHK(ctx, hipStreamWaitEvent(pre, ctx->ev_a_est, 0));
+        hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), est_lds, pre, A, bs, d_work, ctx->d_order,
                            notes ? (const int32_t*) ctx->d_wg_place : (const int32_t*) nullptr, ctx->n_cu, (unsigned int*) (ctx->d_wg_place + 1024));
         const hipError_t le = hipGetLastError();
+        if (le == hipSuccess && pre == ctx->stream) { HIPCHK(ctx, hipEventRecord(ctx->ev_a_est, ctx->stream)); ctx->a_est_recorded = true; }
         if (le != hipSuccess) {      // (round-4 advisor) a launch that failed may have left the ticket counter mid-count: the next call must not start mis-counted
           (void) hipMemsetAsync(ctx->d_wg_place + 1024, 0, sizeof(int32_t), ctx->stream); ctx->order_valid = false;
           HIPCHK(ctx, le);
@@ -2240,6 +2383,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
       if (ctx->balance_notes && n <= 1024) { A.wg_place = ctx->d_wg_place; ctx->wg_place_shape = shape; }
     }
   }
+  HIPCHK(ctx, join_pre_stream(ctx));      // whatever the second stream holds for this batch (its scans' preprocessing, its start poses, its estimate) comes first
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   if (use_split) {
     // workspace: global canvases + running pose / flags, grown on demand and kept by the context
@@ -2302,12 +2446,46 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   ctx->have_timing = ctx->kernel_timing;
   if (host_results) { if (out_stats) HIPCHK(ctx, hipMemcpyAsync(hs + o_stats, ds + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, hipMemcpyDeviceToHost, ctx->stream)); }
   else if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  if (zero_copy) HIPCHK(ctx, wait_for_statuses(ctx, (const int32_t*) (hs + o_status), n));
+  // ---- the batch is queued.  What its results need: kept in a lsm2d_pending (the caller's for an asynchronous begin, a local one otherwise)
+  lsm2d_pending local; lsm2d_pending& P = pend ? *pend : local;
+  P.ctx = ctx; P.lane_id = ctx->lane_id; P.ev_done = ctx->ev_done; P.ev0 = ctx->ev0; P.ev1 = ctx->ev1; P.hs = hs;
+  P.o_pose = o_pose; P.o_H = o_H; P.o_status = o_status; P.o_its = o_its; P.o_stats = o_stats; P.o_last_pose = o_last_pose; P.o_clock = o_clock;
+  P.n = n; P.stats_stride = stats_stride; P.n_clock = n_clock; P.clock_stride = clock_stride;
+  P.zero_copy = zero_copy; P.want_stats = out_stats != nullptr; P.want_last_pose = out_last_pose != nullptr; P.stamps = stamps; P.timed = ctx->kernel_timing != 0; P.async = async;
+  P.xcd_sync = A.xcd_sync; P.xcd_stride = A.xcd_stride; P.xcd_window = A.xcd_window; P.xcd_positions = A.xcd_positions;
+  if (async) {
+    if (!zero_copy) HIPCHK(ctx, hipEventRecord(ctx->ev_done, ctx->stream));
+    ctx->lane_busy = true; ++ctx->inflight;
+    swap_lanes(ctx);      // whatever is called next works on the other lane
+    return LSM2D_SUCCESS;
+  }
+  return align_batch_finish(P, out_pose, out_H, out_status, out_its, out_stats, out_last_pose);
+}
+
+// the second half: wait for the batch, check that every alignment reported, hand the results over
+static int align_batch_finish(lsm2d_pending& P, float* out_pose, float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats, float* out_last_pose) {
+  lsm2d_context* ctx = P.ctx;
+  char* hs = P.hs; const int n = P.n;
+  const size_t o_pose = P.o_pose, o_H = P.o_H, o_status = P.o_status, o_its = P.o_its, o_stats = P.o_stats, o_last_pose = P.o_last_pose, o_clock = P.o_clock;
+  const int stats_stride = P.stats_stride, n_clock = P.n_clock, clock_stride = P.clock_stride;
+  const bool zero_copy = P.zero_copy, stamps = P.stamps;
+  if (P.async) {
+    // (an event of the batch's own, not a wait for the stream: the NEXT batch may be queued behind it already.  The stream's epoch does not move: work queued
+    // after this batch has not necessarily run)
+    hipError_t we = hipSuccess;
+    if (zero_copy) { we = wait_for_statuses(ctx, (const int32_t*) (hs + o_status), n); --ctx->sync_epoch; }
+    else we = hipEventSynchronize(P.ev_done);
+    if (ctx->lane_id == P.lane_id) ctx->lane_busy = false; else if (ctx->parked.id == P.lane_id) ctx->parked.busy = false;
+    if (ctx->inflight > 0) --ctx->inflight;
+    HIPCHK(ctx, we);
+  }
+  else if (zero_copy) HIPCHK(ctx, wait_for_statuses(ctx, (const int32_t*) (hs + o_status), n));
   else HIPCHK(ctx, stream_sync(ctx));
+  ctx->last_ev0 = P.ev0; ctx->last_ev1 = P.ev1; ctx->have_timing = P.timed;
   {
     static_assert(kStatusNotWritten == -1, "the memsets above write 0xFF bytes");
     const int32_t* st = (const int32_t*) (hs + o_status);
-    for (int i = 0; i < n; ++i) if (st[i] == kStatusNotWritten) { ctx->order_valid = false; return fail(ctx, LSM2D_DEVICE_ERROR, "align_batch: an alignment's workgroup never reported (placement or launch fault)"); }
+    for (int i = 0; i < n; ++i) if (st[i] == kStatusNotWritten) { ctx->order_valid = false; ctx->parked.order_valid = false; return fail(ctx, LSM2D_DEVICE_ERROR, "align_batch: an alignment's workgroup never reported (placement or launch fault)"); }
   }
   memcpy(out_pose, hs + o_pose, sizeof(float) * 3 * (size_t) n);
   if (out_H) memcpy(out_H, hs + o_H, sizeof(float) * 9 * (size_t) n);
@@ -2315,16 +2493,16 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   if (out_its) memcpy(out_its, hs + o_its, sizeof(int32_t) * (size_t) n);
   if (out_stats) memcpy(out_stats, hs + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride);
   if (out_last_pose) memcpy(out_last_pose, hs + o_last_pose, sizeof(float) * 3 * (size_t) n);
-  if (A.xcd_sync) if (const char* dump = getenv("LSM2D_DUMP_XCD")) {      // diagnostics: the XCD window's counters after the launch, one line per XCC that took part
-    std::vector<uint32_t> h((size_t) 16 * A.xcd_stride);
-    if (hipMemcpy(h.data(), A.xcd_sync, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) if (FILE* f = fopen(dump, "a")) {
-      fprintf(f, "# launch n=%d lockstep=%d passes=%d\n", n, A.xcd_window + 1, A.xcd_positions);
+  if (P.xcd_sync) if (const char* dump = getenv("LSM2D_DUMP_XCD")) {      // diagnostics: the XCD window's counters after the launch, one line per XCC that took part
+    std::vector<uint32_t> h((size_t) 16 * P.xcd_stride);
+    if (hipMemcpy(h.data(), P.xcd_sync, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) if (FILE* f = fopen(dump, "a")) {
+      fprintf(f, "# launch n=%d lockstep=%d passes=%d\n", n, P.xcd_window + 1, P.xcd_positions);
       for (int x = 0; x < 16; ++x) {
-        const uint32_t* c = h.data() + (size_t) x * A.xcd_stride;
+        const uint32_t* c = h.data() + (size_t) x * P.xcd_stride;
         if (!c[0]) continue;
         fprintf(f, "xcc %2d registered %u gone %u watchdog %u (last: need %u saw %u reg %u gone %u at g %u) done:", x, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
-        for (int q = 0; q < A.xcd_positions && q < 48; ++q) fprintf(f, " %u", c[16 + q]);
-        fprintf(f, " ... %u\n", c[16 + A.xcd_positions - 1]);
+        for (int q = 0; q < P.xcd_positions && q < 48; ++q) fprintf(f, " %u", c[16 + q]);
+        fprintf(f, " ... %u\n", c[16 + P.xcd_positions - 1]);
       }
       fclose(f);
     }
@@ -2353,6 +2531,38 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
 extern "C" int lsm2d_align_batch(lsm2d_context* ctx, const lsm2d_aligner_params* ap, const lsm2d_batch* b, float* out_pose,
                                  float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats) {
   return align_batch_impl(ctx, ap, b, out_pose, out_H, out_status, out_its, out_stats, nullptr);
+}
+
+// ---- a batch in flight: MultiAligner2D::compute over a batch, split where the host would otherwise sleep.  begin() queues everything -- inputs, placement,
+// kernels, the copies of the results -- and returns; wait() blocks until THAT batch's last operation has run (an event of its own: a younger batch may be
+// queued behind it) and hands the results over.  While one batch is in flight, the next one's pre-kernels go to a second stream (pre_stream) and fill the
+// slots its tail leaves free.  Two lanes of staging / scratch: at most two batches in flight, waited for in the order they were begun.
+extern "C" int lsm2d_align_batch_begin(lsm2d_context* ctx, const lsm2d_aligner_params* ap, const lsm2d_batch* b, int32_t want_stats, lsm2d_pending** out_pending) {
+  if (!ctx || !out_pending) return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch_begin: null argument");
+  *out_pending = nullptr;
+  lsm2d_pending* P = new (std::nothrow) lsm2d_pending;
+  if (!P) return LSM2D_OUT_OF_MEMORY;
+  static float dummy_pose; static int32_t dummy_status; static lsm2d_iteration_stats dummy_stats;      // (only their being non-null is looked at)
+  const int rc = align_batch_impl(ctx, ap, b, &dummy_pose, nullptr, &dummy_status, nullptr, want_stats ? &dummy_stats : nullptr, nullptr, nullptr, P);
+  if (rc != LSM2D_SUCCESS || !P->ctx) { const bool empty = rc == LSM2D_SUCCESS; delete P; if (!empty) return rc; P = new (std::nothrow) lsm2d_pending; if (!P) return LSM2D_OUT_OF_MEMORY; }      // (n == 0: an empty batch, nothing in flight)
+  *out_pending = P;
+  return LSM2D_SUCCESS;
+}
+extern "C" int lsm2d_align_batch_wait(lsm2d_pending* pending, float* out_pose, float* out_H, int32_t* out_status, int32_t* out_its, lsm2d_iteration_stats* out_stats) {
+  if (!pending) return LSM2D_BAD_ARGUMENT;
+  if (!pending->ctx) { delete pending; return LSM2D_SUCCESS; }      // an empty batch
+  lsm2d_context* ctx = pending->ctx;
+  int rc = LSM2D_SUCCESS;
+  if (!out_pose || !out_status || (out_stats && !pending->want_stats)) {
+    // the batch must still be retired: its lane stays busy otherwise
+    float* p = (float*) malloc(sizeof(float) * 3 * (size_t) (pending->n > 0 ? pending->n : 1)); int32_t* st = (int32_t*) malloc(sizeof(int32_t) * (size_t) (pending->n > 0 ? pending->n : 1));
+    if (p && st) (void) align_batch_finish(*pending, p, nullptr, st, nullptr, nullptr, nullptr);
+    free(p); free(st);
+    rc = fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch_wait: out_pose / out_status missing, or statistics asked for that the batch was not begun with");
+  }
+  else rc = align_batch_finish(*pending, out_pose, out_H, out_status, out_its, out_stats, nullptr);
+  delete pending;
+  return rc;
 }
 
 extern "C" int lsm2d_estimate_work(lsm2d_context* ctx, const lsm2d_batch* b, int32_t* out_work) {

@@ -3459,6 +3459,7 @@ struct PrepArgs {
   int32_t n_beams, stride;                           // stride: points reserved per output cloud (even)
   float rmin, rmax, d2max; int32_t min_points; float inv_res;   // inv_res <= 0: no voxelisation
   float2* out_xy; float2* out_nrm; int32_t* out_count;
+  float4* out_aos = nullptr;                         // the set's (x, y, nx, ny) rows, rewritten in place by a refill (lsm2d_preprocess_scans_refill), or nullptr
 };
 
 LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
@@ -3476,6 +3477,7 @@ LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
 #endif
   const float* rg = A.ranges + (size_t) scan * nb;
   float2* oxy = A.out_xy + (size_t) scan * A.stride; float2* onr = A.out_nrm + (size_t) scan * A.stride;
+  float4* oaos = A.out_aos ? A.out_aos + (size_t) scan * A.stride : nullptr;
   // ---- F2.1 unprojection, valid beams compacted in beam order
   int m = 0, parity = 0;
   for (int c0 = 0; c0 < nb; c0 += kPrepBlock, parity ^= 1) {
@@ -3529,13 +3531,13 @@ LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
   __syncthreads();
   LSM2D_PC(2);
   if (!(A.inv_res > 0.0f)) {                       // no voxelisation: every valid point, beam order
-    for (int i = tid; i < k; i += kPrepBlock) { oxy[i] = s_q[i]; onr[i] = s_n[i]; }
+    for (int i = tid; i < k; i += kPrepBlock) { oxy[i] = s_q[i]; onr[i] = s_n[i]; if (oaos) oaos[i] = make_float4(s_q[i].x, s_q[i].y, s_n[i].x, s_n[i].y); }
     if (tid == 0) A.out_count[scan] = k;
     return;
   }
   // ---- F2.3 voxelisation: sort (key, index), average equal-key runs, ascending key order
   const int nv = voxelize_lds(s_q, s_n, s_key, k, A.inv_res, 1.0f, s_tot, tid,
-                              [&](int pos, float x, float y, float nx, float ny) { oxy[pos] = make_float2(x, y); onr[pos] = make_float2(nx, ny); });
+                              [&](int pos, float x, float y, float nx, float ny) { oxy[pos] = make_float2(x, y); onr[pos] = make_float2(nx, ny); if (oaos) oaos[pos] = make_float4(x, y, nx, ny); });
   if (tid == 0) A.out_count[scan] = nv;
   LSM2D_PC(3);
 #ifdef LSM2D_PHASE_CLOCKS

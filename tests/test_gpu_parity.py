@@ -2717,6 +2717,85 @@ def test_two_kdtree_slices_build_their_scans_trees_in_one_launch(ctx, po):
         xset(ctx, kd_scan_max_clouds=8)
 
 
+def test_stream_pipeline_begin_wait_and_refill_equal_the_synchronous_calls(ctx, po):
+    """Round 5: the streaming form of the path -- fresh LaserMessage batches every step (raw_data_preprocessor_projective_2d.cpp:13-51 feeding the aligner of
+    apps/visual_test_aligner_2d.cpp:123-156) -- lsm2d_preprocess_scans_refill into one of two alternating scan sets, lsm2d_align_batch_begin for step i while
+    step i - 1 is still in flight (its pre-kernels on the context's second stream), lsm2d_align_batch_wait one step behind.  Every step's poses, information
+    matrices, statuses, iteration counts and statistics are BITWISE those of the synchronous calls on the same ranges (lsm2d_preprocess_scans +
+    lsm2d_align_batch), the refilled clouds are the oracle's, and the oracle's aligner (device order) reproduces sampled alignments bit for bit.  Also: the
+    third batch in flight is refused, a batch of another size can follow, and the context is clean afterwards (a synchronous call still works)."""
+    world = synth.make_world(5)
+    a0, a1 = -2.34747, 2.35619
+    n, beams, n_batches = 300, 721, 3
+    m = synth.make_map(world, 60000)
+    mset = api.CloudSet(ctx, m)
+    pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+    pp = po.Preprocessor(beams, a0, a1, 0.3, 20.0, 0.3, 5, 0.02)
+    al = api.MultiAligner2D(ctx, max_iterations=12, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(
+        api.CorrespondenceFinderProjective2f(ctx, api.PointNormal2fProjectorPolar(beams, -math.pi, math.pi, 0.3, 20.0)), min_num_correspondences=10))
+    batches = []
+    for k in range(n_batches):
+        poses = synth.sample_poses(world, n, seed=40 + k)
+        rg = synth.make_scan_ranges(world, poses, n_beams=beams, angle_min=a0, angle_max=a1, noise_sigma=0.003, seed=k)
+        if k == 1:
+            rg[7, :] = 0.01; rg[11, 200:400] = np.inf      # an empty cloud and a gap: ragged sizes that stay on the device
+        x_true, x0 = synth.initial_guesses(poses, seed=50 + k)
+        pre.setRawData(rg, a0, a1, 0.0, 30.0)
+        fixed = pre.compute()
+        want = al.compute_batch([fixed], [mset], x0.astype(np.float32), want_stats=True)
+        batches.append((rg, x0.astype(np.float32), x_true, want, fixed.counts.copy()))
+        fixed.close()
+    # the pipeline: two scan sets, two prepared batches, one step in flight
+    pre.setRawData(batches[0][0], a0, a1, 0.0, 30.0); set_a = pre.compute()
+    pre.setRawData(batches[1][0], a0, a1, 0.0, 30.0); set_b = pre.compute()
+    sets = (set_a, set_b)
+    prep = (al.prepare_batch([set_a], [mset], batches[0][1], want_stats=True), al.prepare_batch([set_b], [mset], batches[1][1], want_stats=True))
+    uploads0 = ctx.get_option("uploads")
+    steps, got = 7, {}
+    for i in range(steps):
+        k = i % n_batches
+        pre.setRawData(batches[k][0], a0, a1, 0.0, 30.0)
+        pre.refill(sets[i % 2])
+        prep[i % 2].set_init_poses(batches[k][1])
+        prep[i % 2].begin()
+        if i > 0 and (i - 1) not in got:
+            got[i - 1] = prep[(i - 1) % 2].wait(copy=True)
+        if i == 2:      # two batches in flight (step 2 and one more reading the OTHER set, which holds step 1's scans); a third is refused; waits in the order of the begins
+            extra = al.prepare_batch([sets[1]], [mset], batches[1][1], want_stats=True)
+            extra.begin()
+            third = al.prepare_batch([sets[1]], [mset], batches[1][1])
+            with pytest.raises(Exception):
+                third.begin()
+            got[2] = prep[0].wait(copy=True)
+            ex = extra.wait(copy=True)
+            assert np.array_equal(ex.pose, batches[1][3].pose) and np.array_equal(ex.stats, batches[1][3].stats)
+    got[steps - 1] = prep[(steps - 1) % 2].wait(copy=True)
+    assert ctx.get_option("uploads") - uploads0 == steps
+    for i in range(steps):
+        rg, x0, x_true, want, counts = batches[i % n_batches]
+        g = got[i]
+        assert np.array_equal(g.pose, want.pose) and np.array_equal(g.information, want.information), i
+        assert np.array_equal(g.status, want.status) and np.array_equal(g.iterations, want.iterations) and np.array_equal(g.stats, want.stats), i
+    # what the last refill left in its set: the oracle's clouds, sizes read from the device on demand
+    last = sets[(steps - 1) % 2]; rg, x0, x_true, want, counts = batches[(steps - 1) % n_batches]
+    for c in (0, 7, 11, n - 1):
+        assert np.array_equal(last.download(c), po.preprocess_scan(pp, rg[c])), c
+    # ... and the oracle's aligner on the oracle's clouds, device order: bit for bit
+    for c in (0, 150, n - 1):
+        sc = po.preprocess_scan(pp, rg[c])
+        rt = po.align(po.aligner_params(12, device_order=True), [po.slice_params(canvas_cols=beams, range_max=20.0)], [sc], [m], x0[c])
+        assert np.array_equal(want.pose[c], rt["pose"]) and np.array_equal(want.information[c], rt["H"]), c
+    ok = want.status == 0
+    err = np.abs(want.pose - x_true)[ok]
+    assert ok.mean() > 0.95 and err[:, :2].max() < 3e-2 and err[:, 2].max() < 1e-2
+    # the context is as it was: a synchronous call, another size
+    small = al.compute_batch([last], [mset], x0, want_stats=True)
+    assert np.array_equal(small.pose, want.pose) and np.array_equal(small.stats, want.stats)
+    for s_ in sets:
+        s_.close()
+
+
 def test_prepared_batch_equals_compute_batch(ctx, small_workload):
     """MultiAligner2D.prepare_batch: the descriptor and the result arrays built once, lsm2d_align_batch called again and again (what bench.py times) --
     the same results as compute_batch, call after call, also after new start poses were written in place."""
