@@ -9,8 +9,16 @@ namespace srrg2_laser_slam_2d {
   using lsm2d_srrg::throwOnError;
 
   CorrespondenceFinderHIPBase::~CorrespondenceFinderHIPBase() {
-    // the device clouds (members) go after this body; a set may outlive its context (lsm2d.h), so the order is safe either way
-    lsm2d_destroy(_ctx);
+    // the context is shared (lsm2d_srrg::sharedContext) or a HipContext configurable's: whoever holds it last destroys it.  The device clouds (members) go
+    // after this body; a set may outlive its context (lsm2d.h), so the order is safe either way
+  }
+
+  int64_t CorrespondenceFinderHIPBase::contextUploads() const {
+    int64_t v = 0;
+    if (_ctx) {
+      lsm2d_get_option(_ctx, "uploads", &v);
+    }
+    return v;
   }
 
   void CorrespondenceFinderHIPBase::compute() {
@@ -28,17 +36,22 @@ namespace srrg2_laser_slam_2d {
     lsm2d_slice_params sp{};
     fillSliceParams(&sp); // throws on a missing projector / bad parameters, before anything touches the device
     if (!_ctx) {
-      throwOnError(lsm2d_create(param_device_id.value(), nullptr, &_ctx), who + " create", nullptr);
+      if (param_context.value()) {
+        _ctx = param_context.value()->handle(who);
+      } else {
+        _shared = lsm2d_srrg::sharedContext(param_device_id.value(), who);
+        _ctx    = _shared->ctx;
+      }
     }
     // fixed: behind the base class's dirty flag, like the reference's cached canvas / tree (:37-44; kd_tree_2d.cpp:6-9)
     if (_fixed_changed_flag || !_fixed_dev.set() || _fixed_dev.host() != _fixed) {
       _fixed_dev.upload(_ctx, *_fixed, className());
       _fixed_changed_flag = false;
     }
-    // moving: ALWAYS refilled.  The tracker's clipped scene is one object, cleared and refilled every step and often the same
-    // size; the base class has no dirty flag for it, and pointer + size say nothing about its contents.  The refill is a copy
-    // into pinned memory -- the kernel that reads the set unpacks it.
-    _moving_dev.upload(_ctx, *_moving, className());
+    // moving: behind a CONTENT check (round 5).  The base class has no dirty flag for it as far as the reference's tree shows, and pointer + size say nothing
+    // about contents -- the tracker's clipped scene is one object, cleared and refilled every step, often to the same size -- so the packed floats are hashed
+    // while they are packed: an unchanged cloud (the reference's own aligner loop: twenty compute() calls on one local map) is not copied again, a changed one is.
+    _moving_dev.uploadIfChanged(_ctx, *_moving, className());
 
     float pose[3];
     lsm2d_srrg::poseToArray(_local_map_in_sensor, pose);

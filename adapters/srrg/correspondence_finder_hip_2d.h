@@ -21,12 +21,18 @@ namespace srrg2_laser_slam_2d {
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
     using BaseType = CorrespondenceFinderNormal2f;
     PARAM(srrg2_core::PropertyInt, device_id, "HIP device ordinal", 0, 0);
+    // unset (the default): the ONE context every HIP module of this process shares on that device (lsm2d_srrg::sharedContext); set: the context of that
+    // configurable -- the finder siblings of one aligner share a stream and their staging buffers either way
+    PARAM(srrg2_core::PropertyConfigurable_<lsm2d_srrg::HipContext>, context, "device context shared with other HIP modules (unset: one per process and device)", nullptr, 0);
     virtual ~CorrespondenceFinderHIPBase();
+    // host-to-device cloud uploads the finder's context has queued so far (lsm2d option "uploads"): what the upload-once test of the adapter driver reads
+    int64_t contextUploads() const;
     void compute() override;
 
   protected:
     virtual const char* className() const = 0;
-    lsm2d_context* _ctx = nullptr;
+    lsm2d_context* _ctx = nullptr;                               // borrowed: _shared or param_context own it
+    std::shared_ptr<lsm2d_srrg::SharedContext> _shared;
     lsm2d_srrg::DeviceCloud _fixed_dev, _moving_dev;
     std::vector<lsm2d_correspondence> _pairs;
   };

@@ -9,7 +9,10 @@
 #include <srrg_pcl/point_projector_types.h>
 #include <srrg_solver/solver_core/robustifier.h>
 
+#include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 namespace lsm2d_srrg {
@@ -20,6 +23,47 @@ namespace lsm2d_srrg {
       throw std::runtime_error(where_ + "| " + lsm2d_status_string(rc_) + ": " + lsm2d_last_error(ctx_));
     }
   }
+
+  // The device context the HIP modules of one process share: ONE device context -- one HIP stream, one set of staging buffers -- per device ordinal, created by the
+  // first module that needs it and destroyed with the last one.  (Round 4: every finder sibling owned a context and a stream of its own -- a two-laser MULTI
+  // configuration created three.)  A context is not thread-safe; the reference's compute path is single-threaded (finding 1), and so are its modules.
+  struct SharedContext {
+    lsm2d_context* ctx = nullptr;
+    ~SharedContext() {
+      lsm2d_destroy(ctx);
+    }
+  };
+  inline std::shared_ptr<SharedContext> sharedContext(int device_id_, const std::string& who_) {
+    static std::mutex mutex;
+    static std::map<int, std::weak_ptr<SharedContext>> registry;
+    std::lock_guard<std::mutex> lock(mutex);
+    if (auto alive = registry[device_id_].lock()) {
+      return alive;
+    }
+    auto fresh = std::make_shared<SharedContext>();
+    throwOnError(lsm2d_create(device_id_, nullptr, &fresh->ctx), who_ + " create", nullptr);
+    registry[device_id_] = fresh;
+    return fresh;
+  }
+  // A context of its own, as a configurable: modules whose `context` PARAM points at the same HipContext share IT instead of the process-wide one
+  // (a configuration that wants two independent streams on one device writes two of these).
+  class HipContext : public srrg2_core::Configurable {
+  public:
+    PARAM(srrg2_core::PropertyInt, device_id, "HIP device ordinal", 0, 0);
+    ~HipContext() {
+      lsm2d_destroy(_ctx);
+    }
+    lsm2d_context* handle(const std::string& who_) {
+      if (!_ctx) {
+        throwOnError(lsm2d_create(param_device_id.value(), nullptr, &_ctx), who_ + " create", nullptr);
+      }
+      return _ctx;
+    }
+
+  private:
+    lsm2d_context* _ctx = nullptr;
+  };
+  using HipContextPtr = std::shared_ptr<HipContext>;
 
   // One PointNormal2fVectorCloud on the device, in a reserved set that is REFILLED (lsm2d_cloudset_upload: a copy into pinned
   // memory, unpacked by the kernel that reads it) instead of being created and destroyed per call.  Owns the set.
@@ -34,25 +78,47 @@ namespace lsm2d_srrg {
     }
     // PointNormal2f -> (x, y, nx, ny).  The preprocessor never emits invalid points
     // (sensor_processing/raw_data_preprocessor_projective_2d.cpp:42-47), so indices are the host cloud's.
+    // uploadIfChanged: the same, unless the device already holds exactly these values -- same object, same size, same 64-bit hash of the packed floats (formed
+    // while they are packed: one pass over the cloud either way).  The reference's own finders re-PROJECT the moving cloud every compute() but never re-copy it
+    // (registration/correspondence_finder_projective_2d.cpp:37-48); under its aligner loop -- twenty compute() calls on an unchanged local map -- this sibling
+    // now uploads once too (round 4: 1.6 MB over the host link per iteration at 100k points).  A cloud changed IN PLACE has another hash and is uploaded.
+    // Returns true when an upload was queued.
+    bool uploadIfChanged(lsm2d_context* ctx_, const PointNormal2fVectorCloud& cloud_, const char* who_) {
+      return uploadImpl(ctx_, cloud_, who_, true);
+    }
     void upload(lsm2d_context* ctx_, const PointNormal2fVectorCloud& cloud_, const char* who_) {
+      uploadImpl(ctx_, cloud_, who_, false);
+    }
+
+  private:
+    bool uploadImpl(lsm2d_context* ctx_, const PointNormal2fVectorCloud& cloud_, const char* who_, bool skip_if_same_) {
       const size_t n = cloud_.size();
-      if (!_set || n > _capacity) {
+      _staging.resize(4 * n);
+      size_t k       = 0;
+      uint64_t hash  = 0x9E3779B97F4A7C15ull ^ (uint64_t) n;
+      for (const auto& p : cloud_) {
+        const float v[4] = {p.coordinates().x(), p.coordinates().y(), p.normal().x(), p.normal().y()};
+        uint64_t w[2];
+        memcpy(w, v, sizeof w);
+        hash = (hash ^ w[0]) * 0xFF51AFD7ED558CCDull; hash ^= hash >> 32;
+        hash = (hash ^ w[1]) * 0xC4CEB9FE1A85EC53ull; hash ^= hash >> 29;
+        _staging[k++] = v[0]; _staging[k++] = v[1]; _staging[k++] = v[2]; _staging[k++] = v[3];
+      }
+      if (skip_if_same_ && _set && _ctx == ctx_ && _host == &cloud_ && _n == n && _hash == hash) {
+        return false;
+      }
+      if (!_set || _ctx != ctx_ || n > _capacity) {
         lsm2d_cloudset_destroy(_set);
         _set      = nullptr;
         _capacity = n + n / 2 + 1024;
         throwOnError(lsm2d_cloudset_create_reserved(ctx_, (int64_t) _capacity, &_set), std::string(who_) + " reserve", ctx_);
       }
-      _staging.resize(4 * n);
-      size_t k = 0;
-      for (const auto& p : cloud_) {
-        _staging[k++] = p.coordinates().x();
-        _staging[k++] = p.coordinates().y();
-        _staging[k++] = p.normal().x();
-        _staging[k++] = p.normal().y();
-      }
       throwOnError(lsm2d_cloudset_upload(_set, _staging.data(), (int64_t) n), std::string(who_) + " upload", ctx_);
-      _host = &cloud_;
+      _host = &cloud_; _ctx = ctx_; _n = n; _hash = hash;
+      return true;
     }
+
+  public:
     lsm2d_cloudset* set() const {
       return _set;
     }
@@ -64,6 +130,9 @@ namespace lsm2d_srrg {
     lsm2d_cloudset* _set                  = nullptr;
     size_t _capacity                      = 0;
     const PointNormal2fVectorCloud* _host = nullptr;
+    const lsm2d_context* _ctx             = nullptr;
+    size_t _n                             = 0;
+    uint64_t _hash                        = 0;
     std::vector<float> _staging;
   };
 

@@ -88,6 +88,35 @@ def host_cpu() -> dict:
     return {"model": model, "physical_cores": len(cores) or None, "threads_allowed": len(os.sched_getaffinity(0))}
 
 
+def rank_affinity(allowed, local_rank: int, world: int):
+    """The cores rank `local_rank` of `world` pins itself to: a contiguous slice of the cores the process may use (the remainder goes to the first ranks); everybody
+    keeps the whole set when there are fewer cores than ranks.  (A step is a 0.8 ms launch loop: a rank whose host thread migrates between sockets shows it.)"""
+    allowed = sorted(allowed)
+    if world <= 1 or len(allowed) < world:
+        return allowed
+    per, extra = divmod(len(allowed), world)
+    lo = local_rank * per + min(local_rank, extra)
+    return allowed[lo: lo + per + (1 if local_rank < extra else 0)]
+
+
+_RANK_NOTE = {"path": None, "data": {}}
+
+
+def rank_note(stage: str, **kw) -> None:
+    """Every rank of an N > 1 run keeps a JSON file of its own up to date -- gpurun_out/bench_rank<r>.json, or under LSM2D_BENCH_RANK_DIR -- with the stage it has
+    reached (init / inputs / warmup / timed / done) and what it measured: a rank that hangs or dies is visible from outside by the stage its file stopped at."""
+    if not _RANK_NOTE["path"]:
+        return
+    _RANK_NOTE["data"].update(kw, stage=stage, t=time.time())
+    tmp = _RANK_NOTE["path"] + ".tmp"
+    try:
+        with open(tmp, "w") as f:
+            json.dump(_RANK_NOTE["data"], f)
+        os.replace(tmp, _RANK_NOTE["path"])
+    except OSError:
+        pass
+
+
 def load_counters(cfg_key: str):
     """profiles/counters.json (written by tools/write_counters.py from the rocprofv3 --pmc passes) if it was taken on the
     kernels that are running now, else None."""
@@ -421,6 +450,19 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line's n_gpus must be the number of ranks that ran")
+    # N > 1: pin this rank's host thread to its own slice of the allowed cores BEFORE anything touches the GPU (the runtime's helper threads inherit the mask),
+    # and start its note file
+    affinity = sorted(os.sched_getaffinity(0))
+    if world > 1:
+        mine = rank_affinity(affinity, local_rank, world)
+        try:
+            os.sched_setaffinity(0, mine); affinity = mine
+        except OSError:
+            pass
+        note_dir = os.environ.get("LSM2D_BENCH_RANK_DIR") or (os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+        if note_dir:
+            _RANK_NOTE["path"] = os.path.join(note_dir, "bench_rank%d.json" % rank)
+        rank_note("init", rank=rank, local_rank=local_rank, world=world, pid=os.getpid(), cpu_affinity=affinity, argv=sys.argv[1:])
     # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (tests): LSM2D_BENCH_BACKEND=gloo lets several ranks share a card
     # (RCCL refuses two ranks on one device); the ranks then run the same kernels, shards and cross-rank check, only the transport differs
     backend = os.environ.get("LSM2D_BENCH_BACKEND", "nccl")
@@ -532,6 +574,7 @@ def main() -> None:
     # (tools/clock_trace.py, profiles/r02/clock_trace_r02k.txt: 2.06 GHz for the first 25 steps after a pause, 2.19 GHz from then on) --
     # with the collection between warm-up and timing, 20 timed steps ran entirely on the low clock.
     import gc
+    rank_note("inputs", alignments=int(args.scans))
     gc.collect(); gc.freeze()
     # N > 1: the ranks line up BEFORE the clock ramp, and the collectives the timed region is bracketed by run once here.  Measured on one
     # rank with the RCCL path forced (LSM2D_BENCH_FORCE_DIST=1, --steps 20): without this the barrier in front of the timed region was the
@@ -553,9 +596,11 @@ def main() -> None:
     for _ in range(args.warmup):
         res = step()
     torch.cuda.synchronize()
+    rank_note("warmup", spinup_steps=spinup_steps)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    rank_note("timed")
     gc_was_on = gc.isenabled()
     if os.environ.get("LSM2D_BENCH_GC_OFF", "1") != "0":
         gc.disable()                 # as timeit does: the collector's pauses are the interpreter's, not the measured path's (re-enabled below)
@@ -589,6 +634,7 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_note("timed_done", ms_per_step=elapsed / args.steps * 1e3, steps=args.steps)
     if gc_was_on:
         gc.enable()
     if gather_pad:
@@ -671,6 +717,9 @@ def main() -> None:
             out["also"] = measure_also(ctx, api, synth, world_geom, wl, scan_set, args)
         if cross:
             out["cross_rank_check"] = cross
+        if world > 1:
+            out["cpu_affinity_rank0"] = affinity
+            out["rank_notes"] = _RANK_NOTE["path"] and os.path.join(os.path.dirname(_RANK_NOTE["path"]), "bench_rank<r>.json")
         if per_rank_ms is not None:
             out["ms_per_step_per_rank"] = per_rank_ms
             out["ms_per_step_rank_max"] = max(per_rank_ms); out["ms_per_step_rank_min"] = min(per_rank_ms)
@@ -719,6 +768,7 @@ def main() -> None:
             if all_cores:
                 out["cpu_baseline"]["all_cores"] = all_cores
         print(json.dumps(out), flush=True)
+    rank_note("done", parity_ok=bool(ok), max_pose_err_m=float(err[:, :2].max()))
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

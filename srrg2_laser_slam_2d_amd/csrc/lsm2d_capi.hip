@@ -547,6 +547,7 @@ static int cloudset_create_impl(lsm2d_context* ctx, const void* points, bool on_
     const int32_t* h_off = offsets ? offsets : one.data();
     hipError_t e = hipSuccess;
     if (!on_device) {
+      ++ctx->uploads; ctx->last_h2d_bytes = (long long) pts_bytes;
       e = hipMalloc(&d_src, pts_bytes);
       if (e == hipSuccess) e = hipMemcpyAsync(d_src, points, pts_bytes, hipMemcpyHostToDevice, ctx->stream);
     }
@@ -742,6 +743,7 @@ extern "C" int lsm2d_cloudset_upload(lsm2d_cloudset* cs, const float* pts, int64
   if (n > cap) return fail(ctx, LSM2D_CAPACITY_EXCEEDED, "cloudset_upload: does not fit the allocation");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   cloudset_drop_grids(cs);
+  ++ctx->uploads; ctx->last_h2d_bytes = (long long) (sizeof(float) * 4 * (size_t) n);
   // no allocation and no wait for the stream -- only for this set's PREVIOUS upload (an event), whose source the staging buffer
   // still is until it ran
   { const int rc0 = acquire_upload_stage(cs, sizeof(float) * 4 * (size_t) (n > 0 ? n : 1) + 16); if (rc0) return rc0; }

@@ -70,6 +70,47 @@ int main(int argc, char** argv) {
     for (size_t i = 0; same && i < corr.size(); ++i) same = corr[i].fixed_idx == corr2[i].fixed_idx && corr[i].moving_idx == corr2[i].moving_idx;
     out << ",\"in_place_change_seen\":" << (same ? 1 : 0) << ",\"pairs_before_change\":" << n_before << ",\"pairs_after_change\":" << corr.size();
 
+    // the reference's own aligner loop around plugin interface #1 (apps/visual_test_aligner_2d.cpp:123-156 drives MultiAligner2D, which calls the slice's finder
+    // once per iteration with a new local_map_in_sensor): twenty compute() calls, a moving cloud of map size that never changes -- ONE upload of it (round 5:
+    // content check), the pairs those of a finder that uploads every time would give; and the siblings of one process share ONE device context
+    {
+      PointNormal2fVectorCloud big(100000);
+      for (size_t i = 0; i < big.size(); ++i) {
+        const auto& src = moving[i % moving.size()];
+        const float shift = 1e-4f * (float) (i / moving.size());
+        big[i].coordinates() = Vector2f(src.coordinates().x() + shift, src.coordinates().y()); big[i].normal() = src.normal();
+      }
+      auto loop = std::make_shared<CorrespondenceFinderHIP2D>(); CorrespondenceVector cl;
+      loop->param_projector.setValue(projector);
+      loop->setFixed(&fixed); loop->setMoving(&big); loop->setCorrespondences(&cl);
+      loop->setLocalMapInSensor(geometry2d::v2t(x0)); loop->compute();
+      const long long up0 = (long long) loop->contextUploads();
+      size_t checksum = 0;
+      for (int it = 0; it < 20; ++it) {
+        const Vector3f xi(x0.x() + 0.002f * (float) it, x0.y() - 0.001f * (float) it, x0.z() + 0.0005f * (float) it);
+        loop->setLocalMapInSensor(geometry2d::v2t(xi)); loop->compute();
+        for (const auto& c : cl) checksum = checksum * 1000003u + (size_t) c.fixed_idx * 131u + (size_t) c.moving_idx;
+      }
+      const long long uploads_in_loop = (long long) loop->contextUploads() - up0;
+      // the same twenty calls by a finder on a context of its own whose moving cloud is a NEW object every call (always uploaded)
+      auto own = std::make_shared<lsm2d_srrg::HipContext>();
+      auto every = std::make_shared<CorrespondenceFinderHIP2D>(); CorrespondenceVector ce;
+      every->param_projector.setValue(projector); every->param_context.setValue(own);
+      every->setFixed(&fixed); every->setCorrespondences(&ce);
+      size_t checksum2 = 0; long long up1 = 0;
+      for (int it = 0; it < 20; ++it) {
+        PointNormal2fVectorCloud copy = big;
+        const Vector3f xi(x0.x() + 0.002f * (float) it, x0.y() - 0.001f * (float) it, x0.z() + 0.0005f * (float) it);
+        every->setMoving(&copy); every->setLocalMapInSensor(geometry2d::v2t(xi)); every->compute();
+        if (it == 0) up1 = (long long) every->contextUploads();
+        for (const auto& c : ce) checksum2 = checksum2 * 1000003u + (size_t) c.fixed_idx * 131u + (size_t) c.moving_idx;
+      }
+      out << ",\"aligner_loop_moving_uploads\":" << uploads_in_loop << ",\"aligner_loop_same_pairs\":" << (checksum == checksum2 ? 1 : 0)
+          << ",\"aligner_loop_pairs_last\":" << cl.size() << ",\"every_call_uploads\":" << ((long long) every->contextUploads() - up1 + 1)
+          << ",\"siblings_share_a_context\":" << (fp->contextUploads() == loop->contextUploads() ? 1 : 0)
+          << ",\"own_context_is_separate\":" << (every->contextUploads() != loop->contextUploads() ? 1 : 0);
+    }
+
     auto fk = std::make_shared<CorrespondenceFinderKDTreeHIP2D>(); CorrespondenceVector ck;
     fk->param_max_distance_m.setValue(0.3f);
     fk->param_search.setValue("exact");                                                       // the exact grid search

@@ -61,7 +61,7 @@ def _align_worker(rank, world, port, out_dir):
     world_geom = synth.make_world(0)
     m = synth.make_map(world_geom, 4000) if rank == 0 else None
     map_pts = distributed.broadcast_map(m, 4000, device="cpu").numpy()
-    n_total, n_beams = 10, 181
+    n_total, n_beams = 5 * world, 181      # five candidates per rank
     lo, hi = distributed.shard_range(n_total, rank, world)
     wl = synth.make_workload(hi - lo, 4000, seed=0, n_beams=n_beams, pose_seed_offset=rank, world=world_geom, map_points=np.zeros((0, 4), np.float32))
     sp = po.slice_params(canvas_cols=n_beams)
@@ -91,6 +91,28 @@ def test_gloo_world_size_2_shards_align_and_cross_check(tmp_path):
     port = _free_port()
     mp.spawn(_align_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "aligned0").exists() and (tmp_path / "aligned1").exists()
+
+
+def test_gloo_world_size_8_shards_align_and_cross_check(tmp_path):
+    """The node the driver's scaling run uses has EIGHT ranks: the same flow -- map broadcast from rank 0, per-rank shards aligned, the cross-rank bit check with a
+    tampered rank caught, the sweep's gather in candidate order -- at world size 8 (gloo on the CPU, five candidates per rank)."""
+    port = _free_port()
+    mp.spawn(_align_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all((tmp_path / ("aligned%d" % r)).exists() for r in range(8))
+
+
+def test_rank_affinity_masks_partition_the_allowed_cores():
+    """bench.py pins every rank to its own slice of the cores the process may use (by LOCAL_RANK, before anything touches the GPU): disjoint slices that cover
+    the allowed set when there are at least as many cores as ranks, the whole set for everybody otherwise."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    allowed = list(range(3, 67))
+    masks = [bench.rank_affinity(allowed, r, 8) for r in range(8)]
+    assert all(len(m) == 8 for m in masks) and sorted(c for m in masks for c in m) == allowed
+    assert bench.rank_affinity([5, 9], 1, 8) == [5, 9] and bench.rank_affinity(allowed, 0, 1) == allowed
+    masks = [bench.rank_affinity(list(range(10)), r, 3) for r in range(3)]
+    assert sorted(c for m in masks for c in m) == list(range(10)) and all(len(m) >= 3 for m in masks)
 
 
 def test_shard_by_work_partitions_exactly_and_balances():
