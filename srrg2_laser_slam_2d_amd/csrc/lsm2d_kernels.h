@@ -1784,6 +1784,43 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
         const float4* maos = S.moving.aos ? S.moving.aos + mbase : nullptr;      // (a set without its AoS copy -- sizes still pending on the device, or
         const float4* faos = S.fixed.aos ? S.fixed.aos + fbase : nullptr;        //  unpacked by this launch -- is gathered from its split arrays)
         const u64* fcs = fcan + S.fcan_offset;
+#ifndef LSM2D_BINWALK_BATCHED
+#define LSM2D_BINWALK_BATCHED 1
+#endif
+        if (LSM2D_BINWALK_BATCHED && kProjCulled && maos && faos) {
+          // Round 5: the walk as a two-deep pipeline -- the NEXT column's cells are read and gated (LDS) and its winners' two 16-byte rows asked for BEFORE this
+          // column's factor terms are formed; the terms are added in the same column order as before (the sums keep their bits).  A trip used to end in two
+          // dependent gathers from L2 that nothing covered: three exposed round trips per thread, iteration and slice; now the second and third travel under
+          // the arithmetic of the one before.  (All three trips asked for up front needed 24 registers more than the kernel has: 96 bytes of scratch.)
+          auto gate = [&](int col, int& fi, int& mi) -> bool {
+            if (col >= S.proj.cols) return false;
+            const u64 fk = fcs[col], mk = mcan[col];
+            mcan[col] = kEmptyCell;
+            if (mk == kEmptyCell || fk == kEmptyCell) return false;
+            const float fd = __uint_as_float((uint32_t) (fk >> 32)), md = __uint_as_float((uint32_t) (mk >> 32));
+            if (__builtin_fabsf(fd - md) > S.point_distance) return false;
+            mi = (int) (uint32_t) mk; fi = (int) (uint32_t) fk;
+            return true;
+          };
+          int fi_a = 0, mi_a = 0, fi_b = 0, mi_b = 0;
+          float4 m_a = make_float4(0.f, 0.f, 0.f, 0.f), f_a = m_a, m_b = m_a, f_b = m_a;
+          bool ok_a = gate(tid, fi_a, mi_a);
+          if (ok_a) { m_a = maos[mi_a]; f_a = faos[fi_a]; }
+          for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
+            const bool ok_b = gate(col + kAlignBlock, fi_b, mi_b);
+            if (ok_b) { m_b = maos[mi_b]; f_b = faos[fi_b]; }
+            if (ok_a) {
+              const float2 pm = make_float2(m_a.x, m_a.y), nm = make_float2(m_a.z, m_a.w);
+              float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+              if (!(__builtin_fmaf(nqx, f_a.z, nqy * f_a.w) < S.normal_cos)) {
+                if (want_dig) digest_add(&s_dig, salt, fi_a, mi_a);
+                accumulate_pair(T, make_float2(f_a.x, f_a.y), make_float2(f_a.z, f_a.w), pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
+              }
+            }
+            ok_a = ok_b; fi_a = fi_b; mi_a = mi_b; m_a = m_b; f_a = f_b;
+          }
+        }
+        else
         for (int col = tid; col < S.proj.cols; col += kAlignBlock) {
           const u64 fk = fcs[col], mk = mcan[col];
           mcan[col] = kEmptyCell;

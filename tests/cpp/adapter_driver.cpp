@@ -92,16 +92,16 @@ int main(int argc, char** argv) {
         for (const auto& c : cl) checksum = checksum * 1000003u + (size_t) c.fixed_idx * 131u + (size_t) c.moving_idx;
       }
       const long long uploads_in_loop = (long long) loop->contextUploads() - up0;
-      // the same twenty calls by a finder on a context of its own whose moving cloud is a NEW object every call (always uploaded)
+      // the same twenty calls by a finder on a context of its own whose moving cloud is ANOTHER object every call (two copies taking turns: always uploaded)
       auto own = std::make_shared<lsm2d_srrg::HipContext>();
       auto every = std::make_shared<CorrespondenceFinderHIP2D>(); CorrespondenceVector ce;
       every->param_projector.setValue(projector); every->param_context.setValue(own);
       every->setFixed(&fixed); every->setCorrespondences(&ce);
       size_t checksum2 = 0; long long up1 = 0;
+      PointNormal2fVectorCloud copies[2] = {big, big};
       for (int it = 0; it < 20; ++it) {
-        PointNormal2fVectorCloud copy = big;
         const Vector3f xi(x0.x() + 0.002f * (float) it, x0.y() - 0.001f * (float) it, x0.z() + 0.0005f * (float) it);
-        every->setMoving(&copy); every->setLocalMapInSensor(geometry2d::v2t(xi)); every->compute();
+        every->setMoving(&copies[it & 1]); every->setLocalMapInSensor(geometry2d::v2t(xi)); every->compute();
         if (it == 0) up1 = (long long) every->contextUploads();
         for (const auto& c : ce) checksum2 = checksum2 * 1000003u + (size_t) c.fixed_idx * 131u + (size_t) c.moving_idx;
       }

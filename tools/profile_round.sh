@@ -2,10 +2,10 @@
 # Full evidence pass for bench.py on the GPU box: kernel-trace stats + PMC passes + plain bench line.
 # usage: bash tools/profile_round.sh <tag>   -> gpurun_out/<tag>/...
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; tag=${1:-round}; O=$R/gpurun_out/$tag; mkdir -p $O
-cd $R && python bench.py --steps 100 > $O/bench_pre.json 2> $O/bench.err; tail -c 300 $O/bench_pre.json
+cd $R && python bench.py --steps 100 --no-also > $O/bench_pre.json 2> $O/bench.err; tail -c 300 $O/bench_pre.json
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $O/trace.log 2>&1; echo "trace rc=$?"
-run() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/$name.log 2>&1; echo "$name rc=$?"; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --no-cpu-baseline --no-also > $O/trace.log 2>&1; echo "trace rc=$?"
+run() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > $O/$name.log 2>&1; echo "$name rc=$?"; }
 run fetch FETCH_SIZE && run write WRITE_SIZE \
  && run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU \
  && run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVES \
