@@ -153,7 +153,7 @@ def build_roofline(role, finder, scans, map_points, iterations, beams, cauchy, n
     bytes_per_alignment = algorithmic_bytes_per_alignment(role, finder, map_points, n_scan_mean, beams, iterations)
     counters, warn = load_counters(cfg_key)
     effective = bytes_per_alignment * scans / (k_ms * 1e-3) / 1e9
-    ws = working_set_bytes(role, finder, scans, map_points, n_scan_mean)
+    ws = working_set_bytes(role, finder, n_unique if 0 < n_unique < scans else scans, map_points, n_scan_mean)      # (candidates that share scans through an index array: the distinct scans)
     roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave64-VALU issue slots/s", "frac": None, "traffic": None,
             "kernel": "k_align", "kernel_ms": k_ms, "kernel_ms_samples": k_samples, "clock_mhz_in_kernel": clk, "workgroup_lifetime_ms": wg_ms,
             "hbm": {"effective_l2_served_GBs": effective, "effective_over_hbm_peak": effective / HBM_PEAK_GBS,

@@ -18,5 +18,6 @@ mode nnB   "--role B --finder nn"       --role B --finder nn \
 && mode nnA   "--role A --finder nn"       --role A --finder nn --max-distance 0.3 \
 && mode distA "--role A --finder distmap"  --role A --finder distmap --max-distance 0.5 \
 && mode distB "--role B --finder distmap"  --role B --finder distmap --max-distance 0.5 \
-&& mode map1M "--map-points 1000000"       --map-points 1000000
+&& mode map1M "--map-points 1000000"       --map-points 1000000 \
+&& mode cfg3  "--scans 65536 --unique-scans 2048 --cauchy 0.05" --scans 65536 --unique-scans 2048 --cauchy 0.05
 cp $R/profiles/counters.json $O/counters.json

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--role", default="A"); ap.add_argument("--finder", default="projective")
     ap.add_argument("--scans", type=int, default=1000); ap.add_argument("--map-points", type=int, default=100000)
     ap.add_argument("--iterations", type=int, default=20); ap.add_argument("--beams", type=int, default=1081)
+    ap.add_argument("--cauchy", type=float, default=0.0); ap.add_argument("--unique-scans", type=int, default=0)
     ap.add_argument("--tag", default="")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "counters.json"))
     a = ap.parse_args()
@@ -46,6 +47,10 @@ def main():
     if "SQ_INSTS_VALU" not in m:
         raise SystemExit("no SQ_INSTS_VALU for %s under %s" % (a.kernel, a.root))
     key = "role%s/%s/scans%d/map%d/it%d/beams%d" % (a.role, a.finder, a.scans, a.map_points, a.iterations, a.beams)
+    if a.cauchy > 0:
+        key += "/cauchy%g" % a.cauchy
+    if a.unique_scans and a.unique_scans != a.scans:
+        key += "/unique%d" % a.unique_scans
     ent = {"valu_insts_per_launch": m["SQ_INSTS_VALU"], "launches_averaged": cnt["SQ_INSTS_VALU"], "pmc_means": m}
     if a.role == "A" and a.finder == "projective":
         # ONE transcendental (v_rsq_f32) per point slot of the lane-chunked stream since round 2's bearing = asin(min / r) (padding slots
@@ -60,6 +65,8 @@ def main():
         ent["wave_points_per_launch"] = visits
         ent["point_visits_frac"] = visits / full
         probe = os.path.join(a.root, "valu_issue_probe.txt")      # tools/valu_issue_probe.hip run in the same pass: the stream's own issue rate
+        if not os.path.exists(probe):                              # (a mode's passes live one level below the headline's: tools/pmc_modes.sh)
+            probe = os.path.join(os.path.dirname(os.path.abspath(a.root)), "valu_issue_probe.txt")
         if os.path.exists(probe):
             import re
             mm = re.search(r"k_align's point stream.*?:\s*([0-9.]+) cycles of a SIMD per point", open(probe).read())
