@@ -304,10 +304,12 @@ def run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, ar
         d["want"] = aligner.compute_batch([fx], [map_set], d["x0"])
         d["points"] = int(fx.n_points)
         fx.close()
+    ahead = 1 if args.stream_ahead else 0      # 1: the scans of step i + 1 are refilled (a third scan set) behind begin(i): their preprocessing has a whole launch to hide under
+    nsets = 2 + ahead
     sets = []
-    for k in range(2):
-        pre.setRawData(data[k]["ranges"], a0, a1, 0.0, 30.0); sets.append(pre.compute())
-    prep = [aligner.prepare_batch([sets[k]], [map_set], data[k]["x0"]) for k in range(2)]
+    for k in range(nsets):
+        pre.setRawData(data[k % nbatch]["ranges"], a0, a1, 0.0, 30.0); sets.append(pre.compute())
+    prep = [aligner.prepare_batch([sets[k]], [map_set], data[k % nbatch]["x0"]) for k in range(nsets)]
     state = {"i": 0, "bad": 0, "checked": 0, "last": None}
 
     def check(step_i, res):
@@ -317,13 +319,17 @@ def run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, ar
 
     def step(timed=False):
         i = state["i"]; d = data[i % nbatch]
-        pre.setRawData(d["ranges"], a0, a1, 0.0, 30.0)
-        pre.refill(sets[i % 2])
-        prep[i % 2].set_init_poses(d["x0"])
-        prep[i % 2].begin()
+        if not ahead or i == 0:
+            pre.setRawData(d["ranges"], a0, a1, 0.0, 30.0)
+            pre.refill(sets[i % nsets])
+        prep[i % nsets].set_init_poses(d["x0"])
+        prep[i % nsets].begin()
+        if ahead:                    # (the set batch i - 2 read: waited for in the previous step)
+            pre.setRawData(data[(i + 1) % nbatch]["ranges"], a0, a1, 0.0, 30.0)
+            pre.refill(sets[(i + 1) % nsets])
         res = None
         if i > 0:
-            res = prep[(i - 1) % 2].wait()
+            res = prep[(i - 1) % nsets].wait()
             check(i - 1, res)
         state["i"] = i + 1
         return res
@@ -343,7 +349,7 @@ def run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, ar
             kernel_ms.append(res.kernel_ms); clock_mhz.append(res.kernel_clock_mhz); wg_ms.append(res.workgroup_lifetime_ms)
     elapsed = time.perf_counter() - t0
     last_i = state["i"] - 1
-    res = prep[last_i % 2].wait(); check(last_i, res)
+    res = prep[last_i % nsets].wait(); check(last_i, res)
     gc.enable()
     # the resident-input step of the default line, same process, same clock state: the ratio the verdict asks for
     d0 = data[0]
@@ -370,8 +376,9 @@ def run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, ar
     out = {"metric": "scan-to-map alignments/sec (1081-beam vs 100k-pt map, 20 GN iters)", "value": n * args.steps / elapsed, "unit": "alignments/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "spinup_steps": spin, "ms_per_step": ms, "timed_region_s": elapsed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "STREAM: every step %d NEW %d-beam range vectors (pinned host memory) -> preprocessed on the device (2 cm voxels, sliding-window normals) -> aligned vs one "
-                                  "%d-pt map, %d GN iters, role A, projective finder; one step in flight" % (n, nb, args.map_points, args.iterations),
-                      "alignments_per_gpu": n, "map_points": args.map_points, "beams": nb, "iterations": args.iterations, "distinct_batches": nbatch,
+                                  "%d-pt map, %d GN iters, role A, projective finder; one step in flight, %s" % (
+                                      n, nb, args.map_points, args.iterations, "scans refilled a step ahead (three sets)" if ahead else "two scan sets"),
+                      "alignments_per_gpu": n, "map_points": args.map_points, "beams": nb, "iterations": args.iterations, "distinct_batches": nbatch, "refill_ahead": ahead,
                       "points_per_batch_after_preprocessing": data[0]["points"]},
            "parity_ok": bool(state["bad"] == 0 and near), "steps_checked_bitwise_against_the_synchronous_calls": state["checked"], "steps_that_differed": state["bad"],
            "max_pose_err_m": float(err[ok_mask][:, :2].max()), "max_pose_err_rad": float(err[ok_mask][:, 2].max()), "p99_pose_err_m": p99_m, "p99_pose_err_rad": p99_rad,
@@ -403,8 +410,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream", action="store_true",
                     help="fresh data every step (VERDICT r4 item 3): each step uploads a NEW batch of raw range vectors (pinned host memory, 4 bytes per beam), preprocesses "
-                         "them on the device into one of two alternating scan sets (lsm2d_preprocess_scans_refill) and aligns them (lsm2d_align_batch_begin / _wait) "
+                         "them on the device into one of three scan sets in rotation (lsm2d_preprocess_scans_refill) and aligns them (lsm2d_align_batch_begin / _wait) "
                          "while the previous step's batch is still in flight; value = alignments/s sustained from ranges to poses")
+    ap.add_argument("--stream-ahead", type=int, default=1, help="--stream: 1 (default) = three scan sets, the NEXT step's scans are refilled right behind this step's begin (their "
+                                                                "preprocessing has a whole launch to hide under: include/lsm2d.h at lsm2d_align_batch_begin); 0 = two sets, refill just before begin")
     ap.add_argument("--stream-batches", type=int, default=4, help="--stream: distinct range batches cycled through (each has its own truth; every step is gated)")
     ap.add_argument("--no-also", action="store_true", help="the default N=1 line carries an `also` block -- BASELINE configs[4] (1000 scans vs a 1M-point map, 3 steps) and "
                                                               "configs[3] (65 536 candidates over 2 048 scans, Cauchy 0.05, 1 step), each with its own parity gate, kernel ms, clock and roofline; this skips it")

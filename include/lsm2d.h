@@ -267,7 +267,9 @@ int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* params,
 /* The same operation INTO a set that lsm2d_preprocess_scans made for the same number of scans and beams: no allocation, nothing waits (RawDataPreprocessorProjective2D::compute
  * per incoming message, sensor_processing/raw_data_preprocessor_projective_2d.cpp:13-51, for a BATCH of fresh messages per step).  Pinned `ranges` are fetched by an
  * asynchronous copy, pageable ones staged first, device-resident ones read in place; the clouds' sizes stay on the device (lsm2d_cloudset_cloud_size asks for them: a wait).
- * Same kernel, same bits as lsm2d_preprocess_scans.  The caller keeps `ranges` untouched until the batch that reads the set has been waited for. */
+ * Same kernel, same bits as lsm2d_preprocess_scans.  The caller keeps `ranges` untouched until the batch that reads the set has been waited for.
+ * While a batch is in flight the refill runs on a stream of its own, ordered before the next aligner call on this context (and before lsm2d_cloudset_cloud_size /
+ * lsm2d_synchronize); other entry points that read a set refilled while a batch was in flight: lsm2d_synchronize first. */
 int lsm2d_preprocess_scans_refill(lsm2d_context* ctx, const lsm2d_preprocessor* params, const float* ranges, int32_t n_scans, lsm2d_cloudset* set);
 /* The live tracker's form of the same operation: ONE scan into an existing reserved single-cloud set (capacity >= n_beams) --
  * no allocation, nothing waits: the ranges are staged in the set's pinned buffer, the cloud's size stays on the device until
@@ -374,9 +376,14 @@ int lsm2d_estimate_work(lsm2d_context* ctx, const lsm2d_batch* batch, int32_t* o
  * what a pipelined host puts in their place).  begin() queues everything -- start poses, placement, kernels, the copies of the results -- and returns;
  * the batch descriptor and what it points to may be reused as soon as it has.  wait() blocks until THAT batch is done (a younger one may be queued
  * behind it) and fills the outputs exactly as lsm2d_align_batch would have: begin + wait == lsm2d_align_batch, bit for bit.  While a batch is in flight,
- * the NEXT batch's lsm2d_preprocess_scans_refill and the pre-kernels of its begin() run on a second stream, in the slots the launch in flight leaves
+ * the NEXT batch's lsm2d_preprocess_scans_refill and the pre-kernels of its begin() run on side streams, in the slots the launch in flight leaves
  * free.  At most two batches are in flight per context; they are waited for in the order they were begun; every begun batch must be waited for.
- * The cloud sets a batch in flight reads must not be modified (a pipeline alternates between two scan sets).
+ * While TWO are in flight the context's staging buffers are theirs: lsm2d_preprocess_scans_refill, lsm2d_align_batch_wait, the option calls and
+ * lsm2d_synchronize work, every other call that moves data returns LSM2D_BAD_ARGUMENT (with one in flight everything works).
+ * The cloud sets a batch in flight reads must not be modified: a pipeline alternates between two scan sets -- or, better, between THREE, refilling a step
+ * ahead: per step  begin(i) ; refill(set of step i + 1) ; wait(i - 1).  The launch in flight holds every wave slot of the chip, so a preprocessing launch
+ * queued beside it finishes only after it; queued a step ahead it is done before begin(i + 1) queues the estimate that reads its clouds, and batch i + 1
+ * starts where batch i ends (tests/cpp/stream_step_bench.cpp, bench.py --stream).
  * want_stats != 0: the batch keeps per-iteration statistics (wait's out_stats may then be non-NULL). */
 typedef struct lsm2d_pending lsm2d_pending;
 int lsm2d_align_batch_begin(lsm2d_context* ctx, const lsm2d_aligner_params* aligner, const lsm2d_batch* batch, int32_t want_stats, lsm2d_pending** out_pending);

@@ -112,6 +112,8 @@ struct lsm2d_context {
   // start poses' upload, its placement's estimate -- is queued here, so the chip runs it in the slots the launch in flight leaves free (its tail), and k_align
   // on the first stream waits for an event behind it
   hipStream_t stream_b = nullptr; hipEvent_t ev_b = nullptr, ev_a_est = nullptr; bool b_dirty = false, a_est_recorded = false;
+  hipStream_t stream_c = nullptr; hipEvent_t ev_c = nullptr; bool c_dirty = false;      // lsm2d_preprocess_scans_refill while a batch is in flight: a stream of its own (refill_stream)
+  hipStream_t stream_h = nullptr; hipEvent_t ev_h = nullptr;                            // ... and one for its host-to-device copy (the copy engine's; nothing it waits for)
 };
 static void swap_lanes(lsm2d_context* c) {
   lsm2d_context::Lane& p = c->parked;
@@ -120,15 +122,46 @@ static void swap_lanes(lsm2d_context* c) {
   std::swap(c->d_order, p.d_order); std::swap(c->order_valid, p.order_valid); std::swap(c->order_key, p.order_key); c->order_poses.swap(p.order_poses);
   std::swap(c->ev0, p.ev0); std::swap(c->ev1, p.ev1); std::swap(c->ev_done, p.ev_done); std::swap(c->lane_busy, p.busy); std::swap(c->lane_id, p.id);
 }
-// the stream a batch's PRE-kernels go to: the second one while another batch is in flight (created on first use), else the context's own
+// Side streams, created on first use with the highest priority the device has: what they carry is short, and the launch in flight holds every wave slot of the
+// chip -- the slots that come free at its end should go to the next batches' pre-kernels first, not to the 1000 long-lived workgroups of the launch queued behind it.
+static bool make_side_stream(hipStream_t* st, hipEvent_t* ev) {
+  int prio_least = 0, prio_greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void) hipGetLastError(); prio_greatest = 0; }
+  if (hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest) != hipSuccess) { (void) hipGetLastError(); *st = nullptr; return false; }
+  if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); (void) hipStreamDestroy(*st); *st = nullptr; *ev = nullptr; return false; }
+  return true;
+}
+// the stream a batch's PRE-kernels go to (its start poses, its estimate): the second one while another batch is in flight, else the context's own
 static hipStream_t pre_stream(lsm2d_context* ctx) {
   if (ctx->inflight <= 0) return ctx->stream;
-  if (!ctx->stream_b) {
-    if (hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); ctx->stream_b = nullptr; return ctx->stream; }
-    if (hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); (void) hipStreamDestroy(ctx->stream_b); ctx->stream_b = nullptr; return ctx->stream; }
-  }
+  if (!ctx->stream_b && !make_side_stream(&ctx->stream_b, &ctx->ev_b)) return ctx->stream;
   ctx->b_dirty = true;
   return ctx->stream_b;
+}
+// ... and the stream lsm2d_preprocess_scans_refill goes to while a batch is in flight: a THIRD one.  On the second stream a refill queued a step ahead of its
+// batch would sit between two estimates, and every estimate behind a preprocessing launch that the launch in flight starves of wave slots: the chain
+// preprocessing -> estimate -> k_align ran in the gap between two launches however early the host queued it (rocprofv3 trace).
+static hipStream_t refill_stream(lsm2d_context* ctx) {
+  if (ctx->inflight <= 0) return ctx->stream;
+  if (!ctx->stream_c && !make_side_stream(&ctx->stream_c, &ctx->ev_c)) return ctx->stream;
+  return ctx->stream_c;
+}
+// The refill's host-to-device copy depends on nothing the device does (the batch that read the set's previous contents has been waited for: the caller's side of
+// the contract), but in order on the refill stream it sat BETWEEN two preprocessing launches: 82 us of copy after the previous launch had ended, the next one
+// starting just as the next k_align took every wave slot -- a steady state in which every preprocessing launch finished after the launch it was meant to hide
+// under (trace in DESIGN.md section 5).  On a stream of its own the copy runs when the host queues it.
+static hipStream_t refill_copy_stream(lsm2d_context* ctx, hipStream_t refill) {
+  if (refill == ctx->stream) return refill;
+  if (!ctx->stream_h && !make_side_stream(&ctx->stream_h, &ctx->ev_h)) return refill;
+  return ctx->stream_h;
+}
+// what was queued on the refill stream comes before whatever `st` (and the context's own stream) is given next
+static hipError_t join_refill_stream(lsm2d_context* ctx, hipStream_t st) {
+  if (!ctx->c_dirty || !ctx->stream_c) return hipSuccess;
+  hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev_c, 0);
+  if (e == hipSuccess && st != ctx->stream) e = hipStreamWaitEvent(st, ctx->ev_c, 0);
+  ctx->c_dirty = false;
+  return e;
 }
 // k_align (first stream) must see what the second stream was given for it
 static hipError_t join_pre_stream(lsm2d_context* ctx) {
@@ -203,6 +236,7 @@ struct lsm2d_cloudset {
   mutable float4* d_block_bounds = nullptr;     // ... and of every block of every chunk (k_block_bounds): the block-level test of the unit lists
   mutable int32_t block_stride = kCullBlocks;   // blocks per chunk in d_block_bounds: kCullBlocksMax for a set that holds a map-sized cloud (cull_blocks_for)
   mutable float4* d_aos = nullptr;              // (x, y, nx, ny) rows of the whole set (k_aos_rows): one gather per z-buffer winner in k_align's bin walk
+  hipEvent_t ev_prep = nullptr;                 // behind the set's latest preprocessing launch on the refill stream: its NEXT refill's copy (another stream) overwrites what that launch reads
   mutable float4* d_tile_bounds = nullptr; mutable int32_t* d_tile_start = nullptr;      // bounding circles of the tiles of 64 points (k_tile_bounds): the point-query finders' culling
   int32_t n_clouds = 0;
   mutable int64_t total = 0;  // logical points
@@ -343,11 +377,15 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->d_wg_place) (void) hipFree(c->d_wg_place);
   if (c->d_order) (void) hipFree(c->d_order);
   if (c->stream_b) (void) hipStreamSynchronize(c->stream_b);
+  if (c->stream_c) (void) hipStreamSynchronize(c->stream_c);
+  if (c->stream_h) (void) hipStreamSynchronize(c->stream_h);
   if (c->parked.h_stage) (void) hipHostFree(c->parked.h_stage);
   if (c->parked.d_scratch) (void) hipFree(c->parked.d_scratch);
   if (c->parked.d_order) (void) hipFree(c->parked.d_order);
-  for (hipEvent_t e : {c->parked.ev0, c->parked.ev1, c->parked.ev_done, c->ev_done, c->ev_b, c->ev_a_est}) if (e) (void) hipEventDestroy(e);
+  for (hipEvent_t e : {c->parked.ev0, c->parked.ev1, c->parked.ev_done, c->ev_done, c->ev_b, c->ev_c, c->ev_h, c->ev_a_est}) if (e) (void) hipEventDestroy(e);
   if (c->stream_b) (void) hipStreamDestroy(c->stream_b);
+  if (c->stream_c) (void) hipStreamDestroy(c->stream_c);
+  if (c->stream_h) (void) hipStreamDestroy(c->stream_h);
   if (c->d_xcd) (void) hipFree(c->d_xcd);
   for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
@@ -360,6 +398,9 @@ extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
   if (!ctx) return LSM2D_BAD_ARGUMENT;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, stream_sync(ctx));
+  if (ctx->stream_b) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_b));      // (the side streams of the streamed pipeline: "everything" includes them)
+  if (ctx->stream_h) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_h));
+  if (ctx->stream_c) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_c));
   return LSM2D_SUCCESS;
 }
 
@@ -474,7 +515,11 @@ static PtrKind pointer_kind(const void* p, int* device = nullptr) {
   return PtrKind::pageable;                      // unregistered; managed memory is treated as host memory the runtime can page
 }
 
+// (both lanes taken by batches in flight: the "current" staging buffers are the older batch's -- its arguments, its results.  Every entry point that stages
+// anything comes through here and fails loudly instead of writing over them; lsm2d_align_batch_begin says the same before it gets here)
+static const char* const kBothLanesBusy = "two batches are in flight on this context and its staging buffers are theirs: wait for the older one first (lsm2d_align_batch_wait)";
 static int ensure_stage(lsm2d_context* ctx, size_t bytes) {
+  if (ctx->lane_busy) return fail(ctx, LSM2D_BAD_ARGUMENT, kBothLanesBusy);
   if (bytes <= ctx->h_stage_bytes) return LSM2D_SUCCESS;
   if (ctx->h_stage) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipHostFree(ctx->h_stage)); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
   size_t cap = bytes + bytes / 2 + 4096;
@@ -490,6 +535,7 @@ static int stage_device_view(lsm2d_context* ctx, char** out) {
 }
 
 static int ensure_scratch(lsm2d_context* ctx, size_t bytes) {
+  if (ctx->lane_busy) return fail(ctx, LSM2D_BAD_ARGUMENT, kBothLanesBusy);
   if (bytes <= ctx->d_scratch_bytes) return LSM2D_SUCCESS;
   if (ctx->d_scratch) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->d_scratch_bytes = 0; }
   size_t cap = bytes + bytes / 2 + 4096;
@@ -587,6 +633,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_start) (void) hipFree(cs->d_start);
   if (cs->d_count) (void) hipFree(cs->d_count);
   if (cs->d_ranges) (void) hipFree(cs->d_ranges);
+  if (cs->ev_prep) (void) hipEventDestroy(cs->ev_prep);
   for (auto& g : cs->grids) if (g.d_block) (void) hipFree(g.d_block);
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block);
@@ -611,7 +658,9 @@ static int resolve_count(const lsm2d_cloudset* cs) {
   lsm2d_context* ctx = cs->ctx;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, stream_sync(ctx));
-  if (ctx->stream_b) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_b));      // (a refill queued on the second stream)
+  if (ctx->stream_b) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_b));
+  if (ctx->stream_h) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_h));
+  if (ctx->stream_c) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_c));      // (a refill queued on the refill stream)
   if (cs->n_clouds > 1) {      // a refilled set of scans (lsm2d_preprocess_scans_refill): every cloud's size
     HIPCHK(ctx, hipMemcpy(cs->h_count.data(), cs->d_count, sizeof(int32_t) * (size_t) cs->n_clouds, hipMemcpyDeviceToHost));
     cs->total = 0; for (int c = 0; c < cs->n_clouds; ++c) cs->total += cs->h_count[c];
@@ -1432,14 +1481,16 @@ extern "C" int lsm2d_preprocess_scans_refill(lsm2d_context* ctx, const lsm2d_pre
     if (e != hipSuccess) { (void) hipFree(d); HIPCHK(ctx, e); }
     ctx->beam_dirs.push_back({nb, pp->angle_min, pp->angle_max, d}); d_dir = d;
   }
-  const hipStream_t pre = pre_stream(ctx);
+  const hipStream_t pre = refill_stream(ctx), cpy = refill_copy_stream(ctx, pre);
+  if (set->ev_prep) HIPCHK(ctx, hipStreamWaitEvent(cpy, set->ev_prep, 0));      // (the same set refilled twice in a row: its previous launch, on the refill stream, may still read d_ranges and write the clouds)
   if (kind == PtrKind::pageable) {
     const int rc = acquire_upload_stage(set, rbytes + 16); if (rc) return rc;
     memcpy(set->h_upload, ranges, rbytes);
-    HIPCHK(ctx, hipMemcpyAsync(set->d_ranges, set->h_upload, rbytes, hipMemcpyHostToDevice, pre));
+    HIPCHK(ctx, hipMemcpyAsync(set->d_ranges, set->h_upload, rbytes, hipMemcpyHostToDevice, cpy));
     set->staged_epoch = ctx->sync_epoch;
   }
-  else if (kind == PtrKind::pinned) HIPCHK(ctx, hipMemcpyAsync(set->d_ranges, ranges, rbytes, hipMemcpyHostToDevice, pre));
+  else if (kind == PtrKind::pinned) HIPCHK(ctx, hipMemcpyAsync(set->d_ranges, ranges, rbytes, hipMemcpyHostToDevice, cpy));
+  if (cpy != pre && kind != PtrKind::device) { HIPCHK(ctx, hipEventRecord(ctx->ev_h, cpy)); HIPCHK(ctx, hipStreamWaitEvent(pre, ctx->ev_h, 0)); }
   ++ctx->uploads; ctx->last_h2d_bytes = kind == PtrKind::device ? 0 : (long long) rbytes;
   PrepArgs A;
   A.ranges = kind == PtrKind::device ? ranges : (const float*) set->d_ranges; A.beam_dir = d_dir;
@@ -1449,6 +1500,12 @@ extern "C" int lsm2d_preprocess_scans_refill(lsm2d_context* ctx, const lsm2d_pre
   A.out_xy = set->d_xy; A.out_nrm = set->d_nrm; A.out_count = set->d_count; A.out_aos = set->d_aos;
   hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, pre, A);
   HIPCHK(ctx, hipGetLastError());
+  if (pre != ctx->stream) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_c, pre)); ctx->c_dirty = true;      // the next aligner call waits for it (join_refill_stream)
+    if (!set->ev_prep && hipEventCreateWithFlags(&set->ev_prep, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); set->ev_prep = nullptr; }
+    if (set->ev_prep) HIPCHK(ctx, hipEventRecord(set->ev_prep, pre));
+    else HIPCHK(ctx, hipStreamSynchronize(pre));      // (no event to be had: the only safe order left)
+  }
   for (int c = 0; c < n_scans; ++c) set->h_count[c] = nb;      // upper bounds: the real sizes are on the device
   set->total = (int64_t) nb * n_scans; set->count_pending = true; set->unpack_pending = false; set->prep_pending = false;
   return LSM2D_SUCCESS;
@@ -1967,6 +2024,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   const bool async = pend != nullptr;
   // what goes AHEAD of k_align (start poses, the placement's estimate): on the second stream while another batch is in flight
   const hipStream_t pre = (async && !out_work) ? pre_stream(ctx) : ctx->stream;
+  HIPCHK(ctx, join_refill_stream(ctx, pre));      // scans refilled while a batch was in flight: their preprocessing comes before anything this call queues
   const int n = b->n_alignments, ns = b->n_slices;
   if (n < 0 || ns < 1 || ns > kMaxSlices || ap->max_iterations < 0 || !b->slices || !b->fixed || !b->moving || (n > 0 && !b->init_pose))
     return fail(ctx, LSM2D_BAD_ARGUMENT, "align_batch: bad batch descriptor");

@@ -3533,19 +3533,47 @@ LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
     bool ok = false; float vx = 0.0f, vy = 0.0f; float2 pi = make_float2(0.0f, 0.0f);
     if (i < m) {
       pi = s_p[i];
+      // Round 5: the window walks and the two sums were one LDS round trip per step (load -> compare -> branch; load -> add), 13-33 us of a scan's ~35 -- the
+      // longest window of the workgroup (hundreds of points at close range) sets the pace.  Four neighbours per trip now: the loads of a trip are independent, the
+      // tests and the additions keep the reference's order (first neighbour that fails ends the walk; sums run j = lo .. hi one after the other): same bits.
+      const auto within = [&](int j) { const float2 q = s_p[j]; const float dx = q.x - pi.x, dy = q.y - pi.y; return __builtin_fmaf(dx, dx, dy * dy) <= A.d2max; };
       int lo = i, hi = i;
-      while (lo > 0) { const float dx = s_p[lo - 1].x - pi.x, dy = s_p[lo - 1].y - pi.y; if (!(__builtin_fmaf(dx, dx, dy * dy) <= A.d2max)) break; --lo; }
-      while (hi < m - 1) { const float dx = s_p[hi + 1].x - pi.x, dy = s_p[hi + 1].y - pi.y; if (!(__builtin_fmaf(dx, dx, dy * dy) <= A.d2max)) break; ++hi; }
+      while (lo > 0) {
+        const int j1 = lo - 1, j2 = lo >= 2 ? lo - 2 : 0, j3 = lo >= 3 ? lo - 3 : 0, j4 = lo >= 4 ? lo - 4 : 0;      // (clamped: the extra loads are of valid cells and never counted)
+        const bool f1 = within(j1), f2 = within(j2), f3 = within(j3), f4 = within(j4);
+        const int room = lo < 4 ? lo : 4;
+        const int adv = !f1 ? 0 : (room < 2 || !f2) ? 1 : (room < 3 || !f3) ? 2 : (room < 4 || !f4) ? 3 : 4;
+        lo -= adv;
+        if (adv < 4) break;
+      }
+      while (hi < m - 1) {
+        const int last = m - 1, j1 = hi + 1, j2 = hi + 2 <= last ? hi + 2 : last, j3 = hi + 3 <= last ? hi + 3 : last, j4 = hi + 4 <= last ? hi + 4 : last;
+        const bool f1 = within(j1), f2 = within(j2), f3 = within(j3), f4 = within(j4);
+        const int room = last - hi < 4 ? last - hi : 4;
+        const int adv = !f1 ? 0 : (room < 2 || !f2) ? 1 : (room < 3 || !f3) ? 2 : (room < 4 || !f4) ? 3 : 4;
+        hi += adv;
+        if (adv < 4) break;
+      }
       const int cnt = hi - lo + 1;
       if (cnt >= A.min_points) {
         float sx = 0.0f, sy = 0.0f;
-        for (int j = lo; j <= hi; ++j) { sx += s_p[j].x; sy += s_p[j].y; }
+        int j = lo;
+        for (; j + 3 <= hi; j += 4) {
+          const float2 a = s_p[j], b = s_p[j + 1], c = s_p[j + 2], d = s_p[j + 3];
+          sx += a.x; sy += a.y; sx += b.x; sy += b.y; sx += c.x; sy += c.y; sx += d.x; sy += d.y;
+        }
+        for (; j <= hi; ++j) { sx += s_p[j].x; sy += s_p[j].y; }
         const float inv = 1.0f / (float) cnt, mx = sx * inv, my = sy * inv;
         float sxx = 0.0f, sxy = 0.0f, syy = 0.0f;
-        for (int j = lo; j <= hi; ++j) {
-          const float dx = s_p[j].x - mx, dy = s_p[j].y - my;
+        const auto cov = [&](const float2 q) {
+          const float dx = q.x - mx, dy = q.y - my;
           sxx = __builtin_fmaf(dx, dx, sxx); sxy = __builtin_fmaf(dx, dy, sxy); syy = __builtin_fmaf(dy, dy, syy);
+        };
+        for (j = lo; j + 3 <= hi; j += 4) {
+          const float2 a = s_p[j], b = s_p[j + 1], c = s_p[j + 2], d = s_p[j + 3];
+          cov(a); cov(b); cov(c); cov(d);
         }
+        for (; j <= hi; ++j) cov(s_p[j]);
         const float tr = sxx + syy, df = sxx - syy;
         const float disc = __builtin_sqrtf(__builtin_fmaf(df, df, 4.0f * (sxy * sxy)));
         const float lmin = 0.5f * (tr - disc);

@@ -7,6 +7,8 @@
 //   MultiAligner2D                     upstream, driven as in apps/visual_test_aligner_2d.cpp:123-156
 //       param_slice_processors / setFixed / setMoving / setMovingInFixed / compute / movingInFixed /
 //       iterationStats / status
+//   LaserMessageBatchStream            batches of fresh LaserMessages through preprocessor + aligner, pipelined over three scan sets
+//       (lsm2d_preprocess_scans_refill, lsm2d_align_batch_begin / _wait)
 // This header depends on nothing but the C ABI and the standard library, so it compiles with plain g++;
 // the SRRG-side adapter (adapters/srrg/) is the same code expressed with srrg2_core types.
 #pragma once
@@ -343,6 +345,62 @@ class MultiAligner2D {
   std::vector<lsm2d_iteration_stats> _stats;
   std::vector<std::vector<lsm2d_correspondence>> _pairs;
   lsm2d_prior _prior{}; bool _has_prior = false; int _status = 0;
+};
+
+// Batches of FRESH LaserMessages against one device-resident map, pipelined: per incoming message RawDataPreprocessorProjective2D::compute
+// (sensor_processing/raw_data_preprocessor_projective_2d.cpp:13-51) feeding MultiAligner2D::compute (apps/visual_test_aligner_2d.cpp:123-156), for n_scans
+// messages per push().  THREE scan sets in rotation, the order include/lsm2d.h recommends at lsm2d_align_batch_begin:  push(k) begins batch k - 1 (whose scans
+// were preprocessed by the previous push), refills a set with the ranges of batch k (lsm2d_preprocess_scans_refill: their preprocessing has the whole launch of
+// batch k - 1 to hide under), and waits for batch k - 2.  It returns true when pose / information / status / iterations hold a finished batch's results --
+// retired() says which push they belong to -- bit for bit those of lsm2d_preprocess_scans + lsm2d_align_batch on the same ranges.
+// At the end of the sequence:  while (stream.flush()) { ...results of one more batch... }.
+// The caller keeps a pushed `ranges` buffer untouched until the results of ITS batch have come out (pinned memory is fetched asynchronously).
+class LaserMessageBatchStream {
+ public:
+  LaserMessageBatchStream(Context& ctx, const lsm2d_preprocessor& pre, const CloudSet& map, const lsm2d_slice_params& slice, const lsm2d_aligner_params& aligner, int n_scans)
+      : _ctx(ctx), _pre(pre), _map(map), _slice(slice), _aligner(aligner), _n(n_scans) {
+    if (n_scans < 1) throw std::runtime_error("LaserMessageBatchStream| n_scans < 1");
+    pose.resize((size_t) n_scans); information.resize((size_t) n_scans); status.resize((size_t) n_scans); iterations.resize((size_t) n_scans);
+    _start.resize((size_t) n_scans);
+  }
+  ~LaserMessageBatchStream() {
+    try { while (flush()) {} } catch (...) {}
+    for (auto* s : _sets) if (s) lsm2d_cloudset_destroy(s);
+  }
+  LaserMessageBatchStream(const LaserMessageBatchStream&) = delete; LaserMessageBatchStream& operator=(const LaserMessageBatchStream&) = delete;
+  bool push(const float* ranges /* [n_scans][n_beams] */, const Vector3f* init_pose /* [n_scans] */) {
+    if (_pushed > _begun) begin_next();                                   // batch k - 1: its scans are on the device (or on their way)
+    if (!_sets[0])                                                        // the first push makes the three sets (allocation; nothing is in flight yet), every later one refills
+      for (auto& s : _sets) check(lsm2d_preprocess_scans(_ctx.get(), &_pre, ranges, _n, &s), "lsm2d_preprocess_scans", _ctx.get());
+    else                                                                  // (the set batch k - 3 read: retired by the previous push)
+      check(lsm2d_preprocess_scans_refill(_ctx.get(), &_pre, ranges, _n, _sets[_pushed % 3]), "lsm2d_preprocess_scans_refill", _ctx.get());
+    _start.assign(init_pose, init_pose + _n);
+    ++_pushed;
+    return _begun - _retired >= 2 ? retire() : false;                     // batch k - 2
+  }
+  bool flush() {                      // ONE more batch per call, oldest first; false when none is left
+    if (_pushed > _begun) begin_next();
+    return _begun > _retired ? retire() : false;
+  }
+  long retired() const { return _retired - 1; }                           // the push (0-based) whose results the members hold; -1: none yet
+  std::vector<Vector3f> pose; std::vector<std::array<float, 9>> information; std::vector<int32_t> status, iterations;
+ private:
+  void begin_next() {
+    const lsm2d_cloudset* fx[1] = {_sets[_begun % 3]}; const lsm2d_cloudset* mv[1] = {_map.get()};
+    lsm2d_batch b{}; b.n_alignments = _n; b.n_slices = 1; b.slices = &_slice; b.fixed = fx; b.moving = mv; b.init_pose = _start[0].data();
+    check(lsm2d_align_batch_begin(_ctx.get(), &_aligner, &b, 0, &_pending[_begun & 1]), "lsm2d_align_batch_begin", _ctx.get());
+    ++_begun;
+  }
+  bool retire() {
+    lsm2d_pending* p = _pending[_retired & 1]; _pending[_retired & 1] = nullptr;     // wait() consumes the handle whatever it returns
+    ++_retired;
+    check(lsm2d_align_batch_wait(p, pose[0].data(), information[0].data(), status.data(), iterations.data(), nullptr), "lsm2d_align_batch_wait", _ctx.get());
+    return true;
+  }
+  Context& _ctx; lsm2d_preprocessor _pre; const CloudSet& _map; lsm2d_slice_params _slice; lsm2d_aligner_params _aligner; int _n;
+  lsm2d_cloudset* _sets[3] = {nullptr, nullptr, nullptr}; lsm2d_pending* _pending[2] = {nullptr, nullptr};
+  std::vector<Vector3f> _start;                                             // the start poses of the batch pushed last (begun by the next push)
+  long _pushed = 0, _begun = 0, _retired = 0;
 };
 
 // The candidate loop of MultiLoopDetectorBruteForce2D / MultiRelocalizer2D (MULTI.json:964-986, :749-769) over the GPUs of one node,

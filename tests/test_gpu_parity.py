@@ -597,6 +597,22 @@ def test_sweep_api_error_paths_and_index_defaults(ctx, small_workload):
         lib.lsm2d_sweep_destroy(sw)
 
 
+def test_cpp_stream_step_through_the_bare_c_abi_and_the_mirror_class(ctx):
+    """tests/cpp/stream_step_bench.cpp: the streamed pipeline (lsm2d_preprocess_scans_refill -> lsm2d_align_batch_begin -> lsm2d_align_batch_wait one step behind,
+    ranges in pinned host memory) driven from C++ -- the reference's host language -- through the bare C ABI, and again through the C++ mirror's
+    LaserMessageBatchStream (host/lsm2d.hpp) on a context of its own: every batch that comes out is BITWISE the synchronous calls' on the same ranges."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("stream_step_bench", os.path.join(ROOT, "tests", "bench", "stream_step_bench.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    for ahead in (1, 0):      # three scan sets, the next step's scans refilled behind this step's begin (what include/lsm2d.h recommends); two sets, refill just before begin
+        r = mod.run(steps=14, warmup=5, scans=96, map_points=20000, iterations=10, beams=721, batches=3, seed=5, ahead=ahead)
+        assert r["refill_ahead"] == ahead and r["steps_checked_bitwise"] == 14 + 5 - 1 and r["steps_that_differed"] == 0
+        assert r["mirror_batches_checked"] == 2 * 3 + 1 and r["mirror_batches_that_differed"] == 0
+        assert r["status_ok_batch0"] >= 90 and r["alignments"] == 96
+
+
 def test_cpp_host_mirror_driver(ctx, po, small_workload, tmp_path):
     """The header-only C++ mirror (srrg2_laser_slam_2d_amd/host/lsm2d.hpp), built with plain g++ and driven like
     apps/visual_test_correspondence_finder_projective_2d.cpp / apps/visual_test_aligner_2d.cpp."""
@@ -2840,6 +2856,8 @@ def test_stream_pipeline_begin_wait_and_refill_equal_the_synchronous_calls(ctx, 
             third = al.prepare_batch([sets[1]], [mset], batches[1][1])
             with pytest.raises(Exception):
                 third.begin()
+            with pytest.raises(Exception):      # ... and so is anything else that would stage data through the context: both lanes' buffers belong to the batches in flight
+                pre.compute()
             got[2] = prep[0].wait(copy=True)
             ex = extra.wait(copy=True)
             assert np.array_equal(ex.pose, batches[1][3].pose) and np.array_equal(ex.stats, batches[1][3].stats)
@@ -2866,7 +2884,32 @@ def test_stream_pipeline_begin_wait_and_refill_equal_the_synchronous_calls(ctx, 
     # the context is as it was: a synchronous call, another size
     small = al.compute_batch([last], [mset], x0, want_stats=True)
     assert np.array_equal(small.pose, want.pose) and np.array_equal(small.stats, want.stats)
-    for s_ in sets:
+    # the order include/lsm2d.h recommends: THREE scan sets, per step  begin(i) ; refill(set of step i + 1) ; wait(i - 1)  -- while a batch is in flight the refill's
+    # copy and its preprocessing run on streams of their own, joined by the begin() that reads the set.  Step 4 refills its set TWICE (other ranges first): the
+    # second copy must wait for the first launch, which still reads the set's range buffer (the set's own event)
+    pre.setRawData(batches[2][0], a0, a1, 0.0, 30.0); set_c = pre.compute()
+    sets3 = (set_a, set_b, set_c)
+    prep3 = [al.prepare_batch([s_], [mset], batches[0][1], want_stats=True) for s_ in sets3]
+    steps3, got3 = 8, {}
+    pre.setRawData(batches[0][0], a0, a1, 0.0, 30.0); pre.refill(sets3[0])
+    for i in range(steps3):
+        prep3[i % 3].set_init_poses(batches[i % n_batches][1])
+        prep3[i % 3].begin()
+        if i + 1 < steps3:
+            if i + 1 == 4:
+                pre.setRawData(batches[(i + 2) % n_batches][0], a0, a1, 0.0, 30.0); pre.refill(sets3[(i + 1) % 3])
+            pre.setRawData(batches[(i + 1) % n_batches][0], a0, a1, 0.0, 30.0); pre.refill(sets3[(i + 1) % 3])
+        if i > 0:
+            got3[i - 1] = prep3[(i - 1) % 3].wait(copy=True)
+    got3[steps3 - 1] = prep3[(steps3 - 1) % 3].wait(copy=True)
+    for i in range(steps3):
+        want_i = batches[i % n_batches][3]; g = got3[i]
+        assert np.array_equal(g.pose, want_i.pose) and np.array_equal(g.information, want_i.information) and np.array_equal(g.status, want_i.status), i
+        assert np.array_equal(g.iterations, want_i.iterations) and np.array_equal(g.stats, want_i.stats), i
+    ctx.synchronize()
+    for c in (0, 7, 11, n - 1):      # (lsm2d_synchronize covers the side streams; the last refill's clouds are the oracle's)
+        assert np.array_equal(sets3[(steps3 - 1) % 3].download(c), po.preprocess_scan(pp, batches[(steps3 - 1) % n_batches][0][c])), c
+    for s_ in sets3:
         s_.close()
 
 

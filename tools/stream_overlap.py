@@ -16,7 +16,14 @@ aligns = [r for r in rows if "k_align" in r[2]]
 pres = [r for r in rows if "k_preprocess_scans" in r[2] or "k_cull_estimate" in r[2]]
 if len(aligns) < 10:
     raise SystemExit("too few k_align launches in the trace")
-aligns = aligns[len(aligns) // 2:]                      # the steady state: the second half of the run
+# the streamed steps: launches with a k_preprocess_scans launch since the previous one (bench.py --stream ends with a loop of resident-input steps: not those),
+# and of them the second half (steady state)
+prep_starts = sorted(p0 for p0, _, name, _ in pres if "k_preprocess_scans" in name)
+import bisect
+streamed = [a for k, a in enumerate(aligns) if k > 0 and bisect.bisect_left(prep_starts, aligns[k - 1][0]) < bisect.bisect_left(prep_starts, a[0])]
+if len(streamed) >= 10:
+    aligns = streamed
+aligns = aligns[len(aligns) // 2:]
 t_first = aligns[0][0]
 tot_in, tot_pre, n_inside, gaps = 0, 0, 0, []
 for i, (a0, a1, _, _) in enumerate(aligns):
@@ -36,5 +43,15 @@ print("pre-kernels of the NEXT batch running inside a k_align launch: %d launche
     n_inside, tot_in / len(aligns) / 1e3, tot_pre / len(aligns) / 1e3))
 print("gap between the end of one k_align and the start of the next: mean %.1f us, median %.1f us" % (sum(gaps) / len(gaps) / 1e3, sorted(gaps)[len(gaps) // 2] / 1e3))
 print("step = launch + gap: %.1f us" % ((sum(dur) / len(dur) + sum(gaps) / len(gaps)) / 1e3))
-for (s0, s1, name, q) in rows[-14:]:
-    print("  %10.1f us  %8.1f us  q=%s  %s" % ((s0 - t_first) / 1e3, (s1 - s0) / 1e3, q, name[:60]))
+g = sorted(gaps)
+print("gap percentiles [us]: p10 %.1f  p50 %.1f  p90 %.1f  max %.1f" % (g[len(g) // 10] / 1e3, g[len(g) // 2] / 1e3, g[len(g) * 9 // 10] / 1e3, g[-1] / 1e3))
+# three steps of the steady state, every launch on every queue (and the copies, if the trace has them)
+copies = []
+for path in sorted(glob.glob(os.path.join(root, "**", "*memory_copy_trace.csv"), recursive=True)):
+    for r in csv.DictReader(open(path)):
+        copies.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "?"), "-"))
+k = len(aligns) // 2
+w0, w1 = aligns[k][0] - 50000, aligns[min(k + 3, len(aligns) - 1)][1]
+for (s0, s1, name, q) in sorted(rows + copies):
+    if s0 >= w0 and s0 <= w1:
+        print("  %10.1f us  -> %10.1f  (%8.1f us)  q=%s  %s" % ((s0 - w0) / 1e3, (s1 - w0) / 1e3, (s1 - s0) / 1e3, q, name[:60]))
