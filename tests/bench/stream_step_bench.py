@@ -17,7 +17,7 @@ def build(exe):
                     "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
 
 
-def run(steps=300, warmup=300, scans=1000, map_points=100000, iterations=20, beams=1081, batches=4, seed=0, ahead=1):
+def run(steps=300, warmup=300, scans=1000, map_points=100000, iterations=20, beams=1081, batches=4, seed=0, ahead=1, workdir=None):
     world = synth.make_world(seed)
     m = synth.make_map(world, map_points, seed=seed)
     a0, a1 = -0.75 * np.pi, 0.75 * np.pi
@@ -26,14 +26,21 @@ def run(steps=300, warmup=300, scans=1000, map_points=100000, iterations=20, bea
         poses = synth.sample_poses(world, scans, seed=seed + 7919 * (k + 1))
         rg.append(synth.make_scan_ranges(world, poses, n_beams=beams, angle_min=a0, angle_max=a1, seed=seed + k))
         x0.append(synth.initial_guesses(poses, seed=seed + k)[1].astype(np.float32))
-    with tempfile.TemporaryDirectory() as d:
+    import contextlib
+    if workdir:
+        os.makedirs(workdir, exist_ok=True)
+    with (contextlib.nullcontext(workdir) if workdir else tempfile.TemporaryDirectory()) as d:
         exe = os.path.join(d, "stream_step_bench")
         build(exe)
         np.ascontiguousarray(m, np.float32).tofile(os.path.join(d, "map.bin"))
         np.ascontiguousarray(np.stack(rg), np.float32).tofile(os.path.join(d, "ranges.bin"))
         np.ascontiguousarray(np.stack(x0), np.float32).tofile(os.path.join(d, "x0.bin"))
-        r = subprocess.run([exe, os.path.join(d, "map.bin"), os.path.join(d, "ranges.bin"), os.path.join(d, "x0.bin"), str(scans), str(beams), str(batches),
-                            str(steps), str(warmup), str(iterations), repr(float(np.float32(a0))), repr(float(np.float32(a1))), str(ahead)], capture_output=True, text=True, timeout=600)
+        cmd = [exe, os.path.join(d, "map.bin"), os.path.join(d, "ranges.bin"), os.path.join(d, "x0.bin"), str(scans), str(beams), str(batches),
+               str(steps), str(warmup), str(iterations), repr(float(np.float32(a0))), repr(float(np.float32(a1))), str(ahead)]
+        if workdir:      # (kept: the driver, its inputs and the command line -- what a rocprofv3 kernel trace of the C++ host runs)
+            with open(os.path.join(d, "cmd.txt"), "w") as f:
+                f.write(" ".join(cmd) + "\n")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         raise RuntimeError("stream_step_bench failed (%d): %s | %s" % (r.returncode, r.stderr[-2000:], r.stdout[-1000:]))
     out = json.loads(r.stdout.strip().splitlines()[-1])
@@ -46,6 +53,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=300); ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--scans", type=int, default=1000); ap.add_argument("--map-points", type=int, default=100000)
     ap.add_argument("--iterations", type=int, default=20); ap.add_argument("--beams", type=int, default=1081); ap.add_argument("--batches", type=int, default=4)
+    ap.add_argument("--workdir", default=None, help="keep the built driver, its inputs and cmd.txt (its command line) here")
     ap.add_argument("--ahead", type=int, default=1, help="1: three scan sets, the next step's scans refilled behind this step's begin; 0: two sets, refill just before begin")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.warmup, a.scans, a.map_points, a.iterations, a.beams, a.batches, ahead=a.ahead)))
+    print(json.dumps(run(a.steps, a.warmup, a.scans, a.map_points, a.iterations, a.beams, a.batches, ahead=a.ahead, workdir=a.workdir)))
