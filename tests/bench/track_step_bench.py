@@ -38,7 +38,7 @@ def main():
     with (contextlib.nullcontext(args.workdir) if args.workdir else tempfile.TemporaryDirectory()) as d:
         exe = os.path.join(d, "track_step_bench"); lib = os.path.join(ROOT, "srrg2_laser_slam_2d_amd", "lib")
         subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "track_step_bench.cpp"),
-                        "-L" + lib, "-llsm2d_hip", "-Wl,-rpath," + lib, "-o", exe], check=True)
+                        "-L" + lib, "-llsm2d_hip_experiments" if os.environ.get("LSM2D_EXPERIMENTS", "0") not in ("", "0") else "-llsm2d_hip", "-Wl,-rpath," + lib, "-o", exe], check=True)
         host_map.tofile(os.path.join(d, "map.bin")); scans[0].tofile(os.path.join(d, "s0.bin")); scans[1].tofile(os.path.join(d, "s1.bin"))
         out = {"local_map_points": int(len(host_map)), "scan_points": [int(len(s)) for s in scans]}
         ranges[0].tofile(os.path.join(d, "r0.bin")); ranges[1].tofile(os.path.join(d, "r1.bin"))
@@ -62,11 +62,12 @@ def main():
                                 os.path.join(d, "r0.bin"), os.path.join(d, "r1.bin"), repr(a0), repr(a1)],
                                check=True, capture_output=True, text=True, timeout=300, env=dict(os.environ, LSM2D_TSB_FINDER=fk))
             out["c_abi_async_finder_" + fk] = json.loads(r.stdout.strip().splitlines()[-1])
-        r = subprocess.run([exe, os.path.join(d, "map.bin"), os.path.join(d, "s0.bin"), os.path.join(d, "s1.bin"),
-                            repr(float(guess[0])), repr(float(guess[1])), repr(float(guess[2])), str(max(args.steps // 4, 50)), "1",
-                            os.path.join(d, "r0.bin"), os.path.join(d, "r1.bin"), repr(a0), repr(a1)],
-                           check=True, capture_output=True, text=True, timeout=300, env=dict(os.environ, LSM2D_TSB_FINDER="kdtree", LSM2D_TSB_OPTIONS="kd_wg_max_points=0"))
-        out["c_abi_async_finder_kdtree_level_loop_build"] = json.loads(r.stdout.strip().splitlines()[-1])
+        if os.environ.get("LSM2D_EXPERIMENTS", "0") not in ("", "0"):      # ("kd_wg_max_points" is an A/B knob of the experiments build: the shipped library builds a scan's tree in one launch)
+            r = subprocess.run([exe, os.path.join(d, "map.bin"), os.path.join(d, "s0.bin"), os.path.join(d, "s1.bin"),
+                                repr(float(guess[0])), repr(float(guess[1])), repr(float(guess[2])), str(max(args.steps // 4, 50)), "1",
+                                os.path.join(d, "r0.bin"), os.path.join(d, "r1.bin"), repr(a0), repr(a1)],
+                               check=True, capture_output=True, text=True, timeout=300, env=dict(os.environ, LSM2D_TSB_FINDER="kdtree", LSM2D_TSB_OPTIONS="kd_wg_max_points=0"))
+            out["c_abi_async_finder_kdtree_level_loop_build"] = json.loads(r.stdout.strip().splitlines()[-1])
     # the same step on the CPU oracle
     osl = [po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.9, robustifier=po.ROBUST_CAUCHY, chi_threshold=0.01, min_num_correspondences=5, sensor_in_robot=tuple(S[0])),
            po.slice_params(canvas_cols=721, range_max=20.0, normal_cos=0.8, min_num_correspondences=5, sensor_in_robot=tuple(S[1]))]
