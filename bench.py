@@ -229,6 +229,40 @@ def build_roofline(role, finder, scans, map_points, iterations, beams, cauchy, n
     return roof
 
 
+def measure_pipelined(ctx, prep_a, prep_b, want, args, roof) -> dict:
+    """The SAME resident-input step with two batches in flight (lsm2d_align_batch_begin / _wait: begin(k) ; wait(k - 1), two prepared batches alternating): each
+    asynchronously begun batch launches on its lane's own stream, so the younger launch's workgroups fill the slots the older one's tail leaves free (the mean
+    workgroup ends 10 % before its launch).  Every run's results are compared bit for bit with the synchronous step's.  The headline `value` stays the synchronous
+    step (one launch at a time: the roofline block's launch duration is that of a launch alone); this block is what a host with a queue of batches gets."""
+    want_pose, want_status = want.pose.copy(), want.status.copy()
+    pair = (prep_a, prep_b)
+    steps = max(250, min(args.steps, 2000)); warm = 30      # (its own length: the driver's 20 timed steps are too few for a pipeline to settle; ~0.2 s)
+    kt = ctx.get_option("kernel_timing"); ctx.set_option("kernel_timing", 0)      # (events around two overlapping launches time nothing meaningful)
+    bad = 0
+    try:
+        t0 = None
+        for k in range(warm + steps):
+            if k == warm:
+                t0 = time.perf_counter()
+            pair[k & 1].begin()
+            if k:
+                r = pair[(k - 1) & 1].wait()
+                bad += 0 if (np.array_equal(r.pose, want_pose) and np.array_equal(r.status, want_status)) else 1
+        r = pair[(warm + steps - 1) & 1].wait()
+        elapsed = time.perf_counter() - t0
+        bad += 0 if (np.array_equal(r.pose, want_pose) and np.array_equal(r.status, want_status)) else 1
+    finally:
+        ctx.set_option("kernel_timing", kt)
+    n = int(want_pose.shape[0]); ms = elapsed / steps * 1e3
+    out = {"value": n * steps / elapsed, "unit": "alignments/s", "ms_per_step": ms, "steps": steps, "batches_in_flight": 2,
+           "runs_that_differed_from_the_synchronous_step": bad, "parity_ok": bad == 0,
+           "note": "begin(k) ; wait(k - 1) over the same resident batch: launches of two lanes overlap on two streams; results bitwise those of the synchronous step"}
+    v, t = roof.get("valu_insts_per_launch"), roof.get("trans_insts_per_launch")
+    if v and roof.get("peak"):      # the chip's VALU issue rate over the whole region: committed counters x launches / wall time, against the same peak as roofline.frac
+        out["valu_issue_frac_at_spec_clock"] = (v + (t or 0.0)) / (ms * 1e-3) / 1e9 / roof["peak"]
+    return out
+
+
 def measure_also(ctx, api, synth, world_geom, wl, scan_set, args) -> list:
     """The other single-GPU BASELINE configurations, timed ONCE inside the default run so that the driver's record holds them: each entry has
     its own parity gate (noise-free data: the generating pose within 1e-4 m / 1e-4 rad), wall ms per step, kernel ms by HIP events, the in-kernel clock and a
@@ -415,6 +449,7 @@ def main() -> None:
     ap.add_argument("--stream-ahead", type=int, default=1, help="--stream: 1 (default) = three scan sets, the NEXT step's scans are refilled right behind this step's begin (their "
                                                                 "preprocessing has a whole launch to hide under: include/lsm2d.h at lsm2d_align_batch_begin); 0 = two sets, refill just before begin")
     ap.add_argument("--stream-batches", type=int, default=4, help="--stream: distinct range batches cycled through (each has its own truth; every step is gated)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the `pipelined` block (the same resident step with two batches in flight, after the timed region)")
     ap.add_argument("--no-also", action="store_true", help="the default N=1 line carries an `also` block -- BASELINE configs[4] (1000 scans vs a 1M-point map, 3 steps) and "
                                                               "configs[3] (65 536 candidates over 2 048 scans, Cauchy 0.05, 1 step), each with its own parity gate, kernel ms, clock and roofline; this skips it")
     ap.add_argument("--seed", type=int, default=0)
@@ -563,7 +598,9 @@ def main() -> None:
         x0, x_true = wl.x0, wl.x_true
         idx = None if scan_index is None else scan_index[None, :]
 
-        prepared = aligner.prepare_batch([scan_set], [map_set], x0, fixed_index=idx)      # descriptor and result arrays built once: the step is the C-ABI call
+        def make_prepared():
+            return aligner.prepare_batch([scan_set], [map_set], x0, fixed_index=idx)      # descriptor and result arrays built once: the step is the C-ABI call
+        prepared = make_prepared()
 
         def step():
             return prepared.run()
@@ -571,7 +608,9 @@ def main() -> None:
         x0 = synth.invert_poses(wl.x0.astype(np.float64)).astype(np.float32); x_true = synth.invert_poses(wl.x_true)
         idx = None if scan_index is None else scan_index[None, :]
 
-        prepared = aligner.prepare_batch([map_set], [scan_set], x0, moving_index=idx)
+        def make_prepared():
+            return aligner.prepare_batch([map_set], [scan_set], x0, moving_index=idx)
+        prepared = make_prepared()
 
         def step():
             return prepared.run()
@@ -722,6 +761,8 @@ def main() -> None:
         # every step) pays it every time
         out["placement"] = {"estimate_launched_in_last_step": bool(ctx.get_option("last_cull_estimate")),
                             "note": "a batch run again with unchanged sets and start poses keeps its placement (lsm2d.h, option last_cull_estimate)"}
+        if world == 1 and default_cfg and not args.no_also and not args.no_pipelined and not options_set:      # (with the `also` block: the extras of the default line; profiler passes run --no-also)
+            out["pipelined"] = measure_pipelined(ctx, prepared, make_prepared(), res, args, roof)
         if world == 1 and default_cfg and not args.no_also and not options_set:
             out["also"] = measure_also(ctx, api, synth, world_geom, wl, scan_set, args)
         if cross:

@@ -89,6 +89,7 @@ struct lsm2d_context {
 #else
       0;
 #endif
+  int lane_streams = 1;        // asynchronously begun batches launch on their lane's own stream (lane_stream); experiments build: 0 = in order on the context's stream, as first built
   int estimate_reuse = 1;      // a prepared batch run again with unchanged start poses keeps its placement (no k_cull_estimate launch); experiments build: 0 switches that off
   int last_xcd_lockstep = 0;   // what the latest aligner call ran with (0: free-running)
   int last_cull_estimate = 0;  // what the latest aligner call did about the placement's estimate ("last_cull_estimate")
@@ -114,6 +115,9 @@ struct lsm2d_context {
   hipStream_t stream_b = nullptr; hipEvent_t ev_b = nullptr, ev_a_est = nullptr; bool b_dirty = false, a_est_recorded = false;
   hipStream_t stream_c = nullptr; hipEvent_t ev_c = nullptr; bool c_dirty = false;      // lsm2d_preprocess_scans_refill while a batch is in flight: a stream of its own (refill_stream)
   hipStream_t stream_h = nullptr; hipEvent_t ev_h = nullptr;                            // ... and one for its host-to-device copy (the copy engine's; nothing it waits for)
+  // a batch begun asynchronously launches on ITS LANE's stream: two batches in flight are two streams, and the second one's workgroups fill the slots the first
+  // one's tail leaves free instead of waiting for its last workgroup (lane_stream)
+  hipStream_t k_stream[2] = {nullptr, nullptr}; hipEvent_t ev_main = nullptr;
 };
 static void swap_lanes(lsm2d_context* c) {
   lsm2d_context::Lane& p = c->parked;
@@ -158,6 +162,17 @@ static hipStream_t refill_copy_stream(lsm2d_context* ctx, hipStream_t refill) {
   if (!ctx->stream_h && !make_side_stream(&ctx->stream_h, &ctx->ev_h)) return refill;
   return ctx->stream_h;
 }
+// The stream an asynchronously begun batch's OWN operations go to (its memsets, k_align, its results' copies, its events): one per lane.  In order on the
+// context's stream the younger batch's 1000 workgroups waited for the older launch's LAST workgroup while a tenth of the chip's slot-time stood empty in its tail
+// (the mean workgroup ends 10 % before its launch); on two streams they start as slots come free.  The context's own stream keeps the synchronous calls and
+// everything that prepares sets; an event recorded on it at begin() orders the lane's stream (and the pre-kernels' stream) behind what it holds.
+static hipStream_t lane_stream(lsm2d_context* ctx) {
+  if (!ctx->lane_streams) return ctx->stream;
+  hipStream_t& st = ctx->k_stream[ctx->lane_id & 1];
+  if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); st = nullptr; return ctx->stream; }
+  if (!ctx->ev_main && hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); ctx->ev_main = nullptr; return ctx->stream; }
+  return st;
+}
 // what was queued on the refill stream comes before whatever `st` (and the context's own stream) is given next
 static hipError_t join_refill_stream(lsm2d_context* ctx, hipStream_t st) {
   if (!ctx->c_dirty || !ctx->stream_c) return hipSuccess;
@@ -167,10 +182,10 @@ static hipError_t join_refill_stream(lsm2d_context* ctx, hipStream_t st) {
   return e;
 }
 // k_align (first stream) must see what the second stream was given for it
-static hipError_t join_pre_stream(lsm2d_context* ctx) {
+static hipError_t join_pre_stream(lsm2d_context* ctx, hipStream_t ks) {
   if (!ctx->b_dirty || !ctx->stream_b) return hipSuccess;
   hipError_t e = hipEventRecord(ctx->ev_b, ctx->stream_b);
-  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_b, 0);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ks, ctx->ev_b, 0);
   ctx->b_dirty = false;
   return e;
 }
@@ -382,13 +397,15 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->stream_b) (void) hipStreamSynchronize(c->stream_b);
   if (c->stream_c) (void) hipStreamSynchronize(c->stream_c);
   if (c->stream_h) (void) hipStreamSynchronize(c->stream_h);
+  for (hipStream_t st : c->k_stream) if (st) (void) hipStreamSynchronize(st);
   if (c->parked.h_stage) (void) hipHostFree(c->parked.h_stage);
   if (c->parked.d_scratch) (void) hipFree(c->parked.d_scratch);
   if (c->parked.d_order) (void) hipFree(c->parked.d_order);
-  for (hipEvent_t e : {c->parked.ev0, c->parked.ev1, c->parked.ev_done, c->ev_done, c->ev_b, c->ev_c, c->ev_h, c->ev_a_est}) if (e) (void) hipEventDestroy(e);
+  for (hipEvent_t e : {c->parked.ev0, c->parked.ev1, c->parked.ev_done, c->ev_done, c->ev_b, c->ev_c, c->ev_h, c->ev_main, c->ev_a_est}) if (e) (void) hipEventDestroy(e);
   if (c->stream_b) (void) hipStreamDestroy(c->stream_b);
   if (c->stream_c) (void) hipStreamDestroy(c->stream_c);
   if (c->stream_h) (void) hipStreamDestroy(c->stream_h);
+  for (hipStream_t st : c->k_stream) if (st) (void) hipStreamDestroy(st);
   if (c->d_xcd) (void) hipFree(c->d_xcd);
   for (auto& bd : c->beam_dirs) if (bd.d_dir) (void) hipFree(bd.d_dir);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
@@ -404,6 +421,7 @@ extern "C" int lsm2d_synchronize(lsm2d_context* ctx) {
   if (ctx->stream_b) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_b));      // (the side streams of the streamed pipeline: "everything" includes them)
   if (ctx->stream_h) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_h));
   if (ctx->stream_c) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_c));
+  for (hipStream_t st : ctx->k_stream) if (st) HIPCHK(ctx, hipStreamSynchronize(st));
   return LSM2D_SUCCESS;
 }
 
@@ -461,6 +479,7 @@ const OptionDesc kOptions[] = {
   {"kd_wide_min_points", &lsm2d_context::kd_wide_min_points, 0, 0x7fffffff, kOptExperiment},
   {"kd_wg_max_points",   &lsm2d_context::kd_wg_max_points,   0, 1 << 20, kOptExperiment},
   {"estimate_reuse",     &lsm2d_context::estimate_reuse,     0, 1,       kOptExperiment},
+  {"lane_streams",       &lsm2d_context::lane_streams,       0, 1,       kOptExperiment},
   {"xcd_lockstep",       &lsm2d_context::xcd_lockstep,       0, 64,      kOptExperiment},
 #endif
 };
@@ -2312,6 +2331,14 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   // wait for a read of host memory
   A.inline_n1 = n == 1 && !use_split;
   if (A.inline_n1) { memcpy(A.pose1, b->init_pose, sizeof A.pose1); if (b->prior) memcpy(&A.prior1, hs + o_prior, sizeof A.prior1); }
+  // the stream this batch's own operations go to: its lane's when it was begun asynchronously (lane_stream) -- not for the split path (one workspace per context)
+  // nor the experiments' XCD counters.  Everything queued so far went to the context's stream (set preparation: pending preprocessing, trees, lane copies): an
+  // event behind it orders the lane's stream and the pre-kernels' stream
+  const hipStream_t ks = (async && !out_work && !use_split && !xcd_on) ? lane_stream(ctx) : ctx->stream;
+  if (ks != ctx->stream && pre != ctx->stream) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(pre, ctx->ev_main, 0));
+  }
   if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, pre));
   A.init_pose = (const float*) (ds + o_pose_in);
   if (xcd_on && !use_split && !use_pair && !zero_copy) {
@@ -2346,11 +2373,11 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     // every alignment's pose, information matrix, status and iteration count are written by its workgroup whatever happens to it; what a kernel may leave
     // untouched are the statistics of iterations that never started: only those are cleared (the clock stamps of a timed launch are written by every
     // stamping workgroup -- each alignment runs exactly once, wherever the placement puts it)
-    if (out_stats) HIPCHK(ctx, hipMemsetAsync(ds + o_stats, 0, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, ctx->stream));
+    if (out_stats) HIPCHK(ctx, hipMemsetAsync(ds + o_stats, 0, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, ks));
     // ... and "exactly once" is checked, not assumed (round-4 advisor): the status words start as kStatusNotWritten -- in the pinned buffer the kernels write to, a
     // host memset of 4 n bytes; on the device for the paths that copy -- and one that is still unwritten after the wait turns the call into LSM2D_DEVICE_ERROR
     if (host_results) memset(hs + o_status, 0xFF, sizeof(int32_t) * (size_t) n);
-    else HIPCHK(ctx, hipMemsetAsync(ds + o_status, 0xFF, sizeof(int32_t) * (size_t) n, ctx->stream));
+    else HIPCHK(ctx, hipMemsetAsync(ds + o_status, 0xFF, sizeof(int32_t) * (size_t) n, ks));
   }
   ctx->last_align_path = use_split ? 2 : (use_pair ? 3 : 1);
   // culled batches that run in about one dispatch round: balanced placement (one small launch ahead of k_align; see k_cull_estimate)
@@ -2407,7 +2434,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
       const unsigned long long shape = ((unsigned long long) (unsigned) n << 32) ^ ((unsigned long long) lds << 8) ^ (unsigned long long) (proj_culled_for_all ? 5 : 0);
       if (!ctx->d_wg_place) {      // 1024 notes + the estimate's ticket counter
         HIPCHK(ctx, hipMalloc(&ctx->d_wg_place, sizeof(int32_t) * 1025)); ctx->wg_place_shape = 0;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_wg_place, 0, sizeof(int32_t) * 1025, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_wg_place, 0, sizeof(int32_t) * 1025, pre));      // (on the stream the estimate that reads the ticket is queued on)
       }
       if (!ctx->d_order) { HIPCHK(ctx, hipMalloc(&ctx->d_order, sizeof(int32_t) * 4096)); ctx->order_valid = false; }
       const bool notes = ctx->balance_notes && ctx->wg_place_shape == shape;
@@ -2425,6 +2452,13 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
       }
       const bool reuse = ctx->estimate_reuse && notes && ctx->order_valid && ctx->order_key == key && ctx->order_poses.size() == 3 * (size_t) n &&
                          !memcmp(ctx->order_poses.data(), b->init_pose, sizeof(float) * 3 * (size_t) n);
+      // A batch begun while another one is in flight starts on the slots that one's tail leaves free -- wherever they are: the launch balances itself as a batch
+      // of many dispatch rounds does, and what is left of the placement's gain (2 % with a kept order) is less than the estimate's own chip time when it has to be made
+      // afresh (streamed pipeline 0.685 against 0.696 ms per step): no estimate then, workgroup b = alignment b.  A kept order is still used -- and a batch this
+      // lane has seen before (same sets, versions, parameters: a caller that runs it again and again) gets its estimate once, to be kept from then on.
+      const bool joins_a_batch_in_flight = ks != ctx->stream && ctx->inflight >= 1 && ctx->lane_streams;
+      if (!reuse && joins_a_batch_in_flight && !(ctx->estimate_reuse && ctx->order_key == key)) { ctx->order_valid = false; ctx->order_key = key; }
+      else {
       if (!reuse) {
         size_t est_lds = sizeof(u64) * (size_t) A.s[bs].proj.cols; if (est_lds < sizeof(BalanceLds)) est_lds = sizeof(BalanceLds);
         // (estimates share ONE ticket counter: one queued on the second stream waits for the latest one queued on the first)
@@ -2444,10 +2478,15 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
       }
       A.order = ctx->d_order;
       if (ctx->balance_notes && n <= 1024) { A.wg_place = ctx->d_wg_place; ctx->wg_place_shape = shape; }
+      }
     }
   }
-  HIPCHK(ctx, join_pre_stream(ctx));      // whatever the second stream holds for this batch (its scans' preprocessing, its start poses, its estimate) comes first
-  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ks != ctx->stream) {      // ... and the lane's stream behind everything the context's own stream was given up to here (set preparation; with nothing in flight also this batch's start poses and estimate)
+    HIPCHK(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_main, 0));
+  }
+  HIPCHK(ctx, join_pre_stream(ctx, ks));      // whatever the second stream holds for this batch (its start poses, its estimate) comes first
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ks));
   if (use_split) {
     // workspace: global canvases + running pose / flags, grown on demand and kept by the context
     const size_t can_bytes = sizeof(u64) * 2 * (size_t) fcan_total * (size_t) n;
@@ -2487,7 +2526,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     }
   } else {
     const dim3 grid((unsigned) n), block(kAlignBlock);
-    if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3((unsigned) (kAlignBlock * ns)), lds_pair, ctx->stream, A);
+    if (use_pair) hipLaunchKernelGGL(k_align_pair, grid, dim3((unsigned) (kAlignBlock * ns)), lds_pair, ks, A);
     else {
       // which instantiation: the finders the batch's slices use, and -- for a batch of ONE finder kind -- the form of its inner loop the host could prove
       // serves every alignment (kNNMode of align_body).  One table (round 5; a 12-way ladder before); the mixed instantiations take whatever is left.
@@ -2499,16 +2538,16 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
       AlignKernel fn = nullptr;
       for (const AlignVariant& v : kAlignVariants) if (v.finders == finders && v.mode == mode) { fn = v.fn; break; }
       if (!fn) fn = has_kd ? (AlignKernel) k_align<true, true, true, true> : (AlignKernel) k_align<true, true, true>;      // mixed finders
-      hipLaunchKernelGGL(fn, grid, block, lds, ctx->stream, A);
+      hipLaunchKernelGGL(fn, grid, block, lds, ks, A);
     }
   }
   HIPCHK(ctx, hipGetLastError());
   for (int s = 0; s < ns; ++s)                  // sets the kernel's prologue unpacks (SliceDev::unpack_src)
     if (A.s[s].unpack_src) { b->fixed[s]->unpack_pending = false; b->fixed[s]->staged_epoch = ctx->sync_epoch; }
-  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ks));
   ctx->have_timing = ctx->kernel_timing;
-  if (host_results) { if (out_stats) HIPCHK(ctx, hipMemcpyAsync(hs + o_stats, ds + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, hipMemcpyDeviceToHost, ctx->stream)); }
-  else if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (host_results) { if (out_stats) HIPCHK(ctx, hipMemcpyAsync(hs + o_stats, ds + o_stats, sizeof(StatsDev) * (size_t) n * (size_t) stats_stride, hipMemcpyDeviceToHost, ks)); }
+  else if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(hs + o_pose, ds + o_pose, out_bytes, hipMemcpyDeviceToHost, ks));
   // ---- the batch is queued.  What its results need: kept in a lsm2d_pending (the caller's for an asynchronous begin, a local one otherwise)
   lsm2d_pending local; lsm2d_pending& P = pend ? *pend : local;
   P.ctx = ctx; P.lane_id = ctx->lane_id; P.ev_done = ctx->ev_done; P.ev0 = ctx->ev0; P.ev1 = ctx->ev1; P.hs = hs;
@@ -2517,7 +2556,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   P.zero_copy = zero_copy; P.want_stats = out_stats != nullptr; P.want_last_pose = out_last_pose != nullptr; P.stamps = stamps; P.timed = ctx->kernel_timing != 0; P.async = async;
   P.xcd_sync = A.xcd_sync; P.xcd_stride = A.xcd_stride; P.xcd_window = A.xcd_window; P.xcd_positions = A.xcd_positions;
   if (async) {
-    if (!zero_copy) HIPCHK(ctx, hipEventRecord(ctx->ev_done, ctx->stream));
+    if (!zero_copy) HIPCHK(ctx, hipEventRecord(ctx->ev_done, ks));
     ctx->lane_busy = true; ++ctx->inflight;
     swap_lanes(ctx);      // whatever is called next works on the other lane
     return LSM2D_SUCCESS;

@@ -2913,6 +2913,62 @@ def test_stream_pipeline_begin_wait_and_refill_equal_the_synchronous_calls(ctx, 
         s_.close()
 
 
+def test_first_call_of_a_fresh_context_is_an_asynchronous_begin_and_two_batches_overlap(small_workload):
+    """Round 5: an asynchronously begun batch launches on its LANE's own stream, so that the younger of two batches in flight fills the slots the older one's tail
+    leaves free.  With nothing in flight a batch's start poses and estimate are queued on the context's own stream: the lane's stream must wait for them (the first
+    build did not: on a fresh context -- nothing valid in the lane's scratch yet -- four alignments in five never reported).  A context of its own, first call a
+    begin(); then two batches of 320 alignments (index arrays over six scans, other poses) alternating, two in flight: every result BITWISE the synchronous call's."""
+    wl = small_workload
+    c = api.Context(0)
+    try:
+        al = _aligner(c)
+        fixed = api.CloudSet(c, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(c, wl.map_points)
+        n = 320
+        fi = (np.arange(n, dtype=np.int32) % len(wl.x0)).reshape(1, n)
+        rng = np.random.default_rng(17)
+        xa = (wl.x0[fi[0]] + rng.normal(0, [0.02, 0.02, 0.005], (n, 3))).astype(np.float32)
+        xb = (wl.x0[fi[0]] + rng.normal(0, [0.02, 0.02, 0.005], (n, 3))).astype(np.float32)
+        pa = al.prepare_batch([fixed], [moving], xa, fixed_index=fi, want_stats=True)
+        pb = al.prepare_batch([fixed], [moving], xb, fixed_index=fi, want_stats=True)
+        pa.begin()                                  # the context's very first aligner call
+        pb.begin()                                  # ... and a second one behind it: two lanes, two streams
+        ra = pa.wait(copy=True); rb = pb.wait(copy=True)
+        wa = al.compute_batch([fixed], [moving], xa, fixed_index=fi, want_stats=True)
+        wb = al.compute_batch([fixed], [moving], xb, fixed_index=fi, want_stats=True)
+        for g, w in ((ra, wa), (rb, wb)):
+            assert np.array_equal(g.pose, w.pose) and np.array_equal(g.information, w.information) and np.array_equal(g.status, w.status)
+            assert np.array_equal(g.iterations, w.iterations) and np.array_equal(g.stats, w.stats)
+        assert (wa.status == 0).all() and not np.array_equal(wa.pose, wb.pose)
+        for k in range(6):                          # a pipeline of them: begin(k) ; wait(k - 1)
+            (pa, pb)[k & 1].begin()
+            if k:
+                g = (pa, pb)[(k - 1) & 1].wait(copy=True); w = (wa, wb)[(k - 1) & 1]
+                assert np.array_equal(g.pose, w.pose) and np.array_equal(g.stats, w.stats), k
+        g = pb.wait(copy=True)
+        assert np.array_equal(g.pose, wb.pose) and np.array_equal(g.stats, wb.stats)
+        fixed.close(); moving.close()
+    finally:
+        c.close()
+
+
+def test_start_poses_that_are_not_numbers_fail_their_alignment_not_the_call(ctx, small_workload):
+    """NaN / infinite start poses (a caller's bug, a diverged odometry) must cost THEIR alignments a failure status -- every workgroup still reports, the call succeeds,
+    the alignments next to them are untouched -- on the batch kernel (with its placement estimate) and on the latency kernel."""
+    wl = small_workload
+    al = _aligner(ctx)
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    for n in (len(wl.x0), 300):
+        fi = (np.arange(n, dtype=np.int32) % len(wl.x0)).reshape(1, n)
+        x = wl.x0[fi[0]].astype(np.float32).copy()
+        good = al.compute_batch([fixed], [moving], x, fixed_index=fi)
+        bad = x.copy(); bad[1, 0] = np.nan; bad[3, 2] = np.inf; bad[4, :] = np.nan
+        r = al.compute_batch([fixed], [moving], bad, fixed_index=fi)
+        ok = np.ones(n, bool); ok[[1, 3, 4]] = False
+        assert (r.status[[1, 3, 4]] != 0).all(), r.status[:6]
+        assert np.array_equal(r.pose[ok], good.pose[ok]) and np.array_equal(r.status[ok], good.status[ok])
+    fixed.close(); moving.close()
+
+
 def test_prepared_batch_equals_compute_batch(ctx, small_workload):
     """MultiAligner2D.prepare_batch: the descriptor and the result arrays built once, lsm2d_align_batch called again and again (what bench.py times) --
     the same results as compute_batch, call after call, also after new start poses were written in place."""
