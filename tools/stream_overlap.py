@@ -43,6 +43,12 @@ print("pre-kernels of the NEXT batch running inside a k_align launch: %d launche
     n_inside, tot_in / len(aligns) / 1e3, tot_pre / len(aligns) / 1e3))
 print("gap between the end of one k_align and the start of the next: mean %.1f us, median %.1f us" % (sum(gaps) / len(gaps) / 1e3, sorted(gaps)[len(gaps) // 2] / 1e3))
 print("step = launch + gap: %.1f us" % ((sum(dur) / len(dur) + sum(gaps) / len(gaps)) / 1e3))
+# (since the lane streams two k_align launches OVERLAP: a launch's own duration and the end-to-start "gap" say little -- the step is the start-to-start interval)
+starts = [a0 for a0, _, _, _ in aligns]
+iv = sorted(starts[i + 1] - starts[i] for i in range(len(starts) - 1))
+both = sum(max(0, min(aligns[i][1], aligns[i + 1][1]) - aligns[i + 1][0]) for i in range(len(aligns) - 1))
+print("start of one k_align to the start of the next: mean %.1f us, median %.1f us; two launches on the chip together %.0f %% of the time" % (
+    sum(iv) / len(iv) / 1e3, iv[len(iv) // 2] / 1e3, 100.0 * both / max(1, aligns[-1][1] - aligns[0][0])))
 g = sorted(gaps)
 print("gap percentiles [us]: p10 %.1f  p50 %.1f  p90 %.1f  max %.1f" % (g[len(g) // 10] / 1e3, g[len(g) // 2] / 1e3, g[len(g) * 9 // 10] / 1e3, g[-1] / 1e3))
 # three steps of the steady state, every launch on every queue (and the copies, if the trace has them)
