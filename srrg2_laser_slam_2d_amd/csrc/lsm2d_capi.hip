@@ -1413,6 +1413,12 @@ static int project_split(lsm2d_context* ctx, const float2* d_xy, int n, const Is
   return LSM2D_SUCCESS;
 }
 
+// a BATCH of scans: the small form of the kernel (512 threads, 37 KB: the footprint of one k_align workgroup) whenever the beams fit it -- it runs beside a launch in
+// flight in single slots as they come free, four to a CU when the chip is idle; a handful of scans keep one beam per thread (a scan's latency, the tracker's concern)
+static void launch_preprocess_scans(const PrepArgs& A, int n_scans, hipStream_t st) {
+  if (n_scans >= 8 && A.n_beams <= kPrepSmallBeams) hipLaunchKernelGGL(k_preprocess_scans_small, dim3((unsigned) n_scans), dim3(kPrepSmallBlock), 0, st, A);
+  else hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, st, A);
+}
 // ---- RawDataPreprocessorProjective2D, batched -------------------------------------------------------------------
 extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocessor* pp, const float* ranges, int32_t n_scans,
                                       lsm2d_cloudset** out) {
@@ -1455,7 +1461,7 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   hipError_t e = hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, kind == PtrKind::pageable ? o_rng + rbytes : dbytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && kind == PtrKind::pinned) e = hipMemcpyAsync((char*) ctx->d_scratch + o_rng, ranges, rbytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && ctx->kernel_timing) e = hipEventRecord(ctx->ev0, ctx->stream);
-  if (e == hipSuccess) { hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, ctx->stream, A); e = hipGetLastError(); }
+  if (e == hipSuccess) { launch_preprocess_scans(A, n_scans, ctx->stream); e = hipGetLastError(); }
   if (e == hipSuccess && ctx->kernel_timing) e = hipEventRecord(ctx->ev1, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(cs->h_count.data(), cs->d_count, sizeof(int32_t) * (size_t) n_scans, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = stream_sync(ctx);
@@ -1520,7 +1526,7 @@ extern "C" int lsm2d_preprocess_scans_refill(lsm2d_context* ctx, const lsm2d_pre
   A.d2max = pp->normal_point_distance * pp->normal_point_distance; A.min_points = pp->normal_min_points;
   A.inv_res = pp->voxelize_resolution > 0.0f ? 1.0f / pp->voxelize_resolution : 0.0f;
   A.out_xy = set->d_xy; A.out_nrm = set->d_nrm; A.out_count = set->d_count; A.out_aos = set->d_aos;
-  hipLaunchKernelGGL(k_preprocess_scans, dim3((unsigned) n_scans), dim3(kPrepBlock), 0, pre, A);
+  launch_preprocess_scans(A, n_scans, pre);
   HIPCHK(ctx, hipGetLastError());
   if (pre != ctx->stream) {
     HIPCHK(ctx, hipEventRecord(ctx->ev_c, pre)); ctx->c_dirty = true;      // the next aligner call waits for it (join_refill_stream)

@@ -3397,11 +3397,11 @@ __global__ void k_pack_aos(const float2* __restrict__ xy, const float2* __restri
 // kVoxBlock threads, k <= kVoxMax; emit(pos, x, y, nx, ny) is called once per voxel; returns the number of voxels (every thread).
 static constexpr int kVoxBlock = 1024;
 static constexpr int kVoxMax = 2048;
-template <typename Emit>
-LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int k, float inv_rx, float inv_rn, int* s_tot /* [2][kVoxBlock / 64] */,
+template <int kBlock = kVoxBlock, typename Emit>
+LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int k, float inv_rx, float inv_rn, int* s_tot /* [2][kBlock / 64] */,
                            int tid, Emit emit) {
   int np2 = 1; while (np2 < k) np2 <<= 1;
-  for (int i = tid; i < np2; i += kVoxBlock) {
+  for (int i = tid; i < np2; i += kBlock) {
     u64 key = ~0ull;
     if (i < k) {
       const float kx = __builtin_floorf(s_q[i].x * inv_rx), ky = __builtin_floorf(s_q[i].y * inv_rx);
@@ -3418,11 +3418,13 @@ LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int
   // aligned 128-element block of its wave whenever stride <= 64, so those steps need no workgroup barrier -- LDS operations
   // of one wave complete in order -- only the compiler must keep them in order (wavefront fence).  6 of the 55 steps of a
   // 1024-key sort cross waves.
-  static_assert(kVoxMax / 2 <= kVoxBlock, "one compare-exchange per thread");
+  // (a smaller workgroup -- the batch preprocessor's 512 threads -- takes its pairs t = tid, tid + kBlock, ...: pair t of a wave still lies in ONE aligned
+  // 128-element block, the same one in every step, so the wave-local ordering holds per trip)
+  static_assert(kVoxMax / 2 <= kVoxBlock && kBlock % 64 == 0, "one compare-exchange per thread at the full block size");
   for (int size = 2; size <= np2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const int t = tid;
-      if (t < (np2 >> 1)) {
+#pragma nounroll
+      for (int t = tid; t < (np2 >> 1); t += kBlock) {
         const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
         const bool up = (lo & size) == 0;
         const u64 a = s_key[lo], b = s_key[hi];
@@ -3435,11 +3437,11 @@ LSM2D_DEV int voxelize_lds(const float2* s_q, const float2* s_n, u64* s_key, int
   }
   __syncthreads();
   int nv = 0, parity = 0;
-  for (int t0 = 0; t0 < np2; t0 += kVoxBlock, parity ^= 1) {
+  for (int t0 = 0; t0 < np2; t0 += kBlock, parity ^= 1) {
     const int t = t0 + tid;
     bool head = false; u64 key = ~0ull;
     if (t < np2) { key = s_key[t]; head = key != ~0ull && (t == 0 || (s_key[t - 1] >> 16) != (key >> 16)); }
-    const int pos = block_compact_pos(head, s_tot, parity, nv, tid, kVoxBlock / 64);
+    const int pos = block_compact_pos(head, s_tot, parity, nv, tid, kBlock / 64);
     if (head) {
       float ax = 0.0f, ay = 0.0f, anx = 0.0f, any_ = 0.0f; int cnt = 0;
       for (int e = t; e < np2 && (s_key[e] >> 16) == (key >> 16); ++e) {
@@ -3499,11 +3501,21 @@ struct PrepArgs {
   float4* out_aos = nullptr;                         // the set's (x, y, nx, ny) rows, rewritten in place by a refill (lsm2d_preprocess_scans_refill), or nullptr
 };
 
+// kBlock threads, room for kCap beams.  (1024, 2048): one beam per thread, what a scan alone on the chip wants (the live tracker).  (512, 1152), round 5: a
+// BATCH of scans preprocessed beside a k_align launch in flight -- a workgroup of 512 threads and 37 KB is exactly what one retiring k_align workgroup leaves
+// free, where the 1024-thread, 64 KB form had to wait for two slots of one CU to come free together; four of them per CU when the chip is theirs.
+template <int kBlock, int kCap>
 LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
-  __shared__ float2 s_p[kPrepMaxBeams];      // unprojected points, beam order
-  __shared__ float2 s_q[kPrepMaxBeams];      // points that got a normal
-  __shared__ float2 s_n[kPrepMaxBeams];      // their normals
-  __shared__ u64 s_key[kPrepMaxBeams];       // (voxel key << 16) | index, bitonic-sorted
+  constexpr int kPrepBlock = kBlock;         // (shadows the full-size constant: every loop below strides by the workgroup's own size)
+  // (the sort pads to a power of two: its keys need 2048 entries as soon as more than 1024 points carry a normal.  The small form cannot afford them beside the
+  // three point arrays -- so its keys LIVE where the unprojected points were: those are dead once the normals are out, a barrier before the first key is written)
+  constexpr int kKeyCap = kCap <= 1024 ? 1024 : 2048;
+  constexpr bool kKeysOverPoints = kCap < kPrepMaxBeams;
+  __shared__ u64 s_key[kKeyCap];             // (voxel key << 16) | index, bitonic-sorted
+  __shared__ float2 s_p_own[kKeysOverPoints ? 1 : kCap];
+  float2* const s_p = kKeysOverPoints ? reinterpret_cast<float2*>(s_key) : s_p_own;      // unprojected points, beam order
+  __shared__ float2 s_q[kCap];               // points that got a normal
+  __shared__ float2 s_n[kCap];               // their normals
   __shared__ int s_tot[2 * (kPrepBlock / 64)];
   const int tid = threadIdx.x, nb = A.n_beams;
 #ifdef LSM2D_PHASE_CLOCKS
@@ -3601,8 +3613,8 @@ LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
     return;
   }
   // ---- F2.3 voxelisation: sort (key, index), average equal-key runs, ascending key order
-  const int nv = voxelize_lds(s_q, s_n, s_key, k, A.inv_res, 1.0f, s_tot, tid,
-                              [&](int pos, float x, float y, float nx, float ny) { oxy[pos] = make_float2(x, y); onr[pos] = make_float2(nx, ny); if (oaos) oaos[pos] = make_float4(x, y, nx, ny); });
+  const int nv = voxelize_lds<kPrepBlock>(s_q, s_n, s_key, k, A.inv_res, 1.0f, s_tot, tid,
+                                          [&](int pos, float x, float y, float nx, float ny) { oxy[pos] = make_float2(x, y); onr[pos] = make_float2(nx, ny); if (oaos) oaos[pos] = make_float4(x, y, nx, ny); });
   if (tid == 0) A.out_count[scan] = nv;
   LSM2D_PC(3);
 #ifdef LSM2D_PHASE_CLOCKS
@@ -3610,12 +3622,14 @@ LSM2D_DEV void preprocess_scan_body(const PrepArgs& A, const int scan) {
 #endif
 #undef LSM2D_PC
 }
-__global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs A) { preprocess_scan_body(A, blockIdx.x); }
+__global__ __launch_bounds__(kPrepBlock) void k_preprocess_scans(const PrepArgs A) { preprocess_scan_body<kPrepBlock, kPrepMaxBeams>(A, blockIdx.x); }
+static constexpr int kPrepSmallBlock = 512, kPrepSmallBeams = 1152;      // 4 x 8 B x 1152 = 36 KB + the wave totals: beside three k_align workgroups of a CU
+__global__ __launch_bounds__(kPrepSmallBlock) void k_preprocess_scans_small(const PrepArgs A) { preprocess_scan_body<kPrepSmallBlock, kPrepSmallBeams>(A, blockIdx.x); }
 // several scans, each with its own sensor geometry and its own output set, side by side (the live tracker's front and rear scanner:
 // lsm2d_preprocess_scan_into defers its launch, the aligner call that reads both sets queues them together)
 static constexpr int kPrepMulti = 4;
 struct PrepMultiArgs { PrepArgs a[kPrepMulti]; };
-__global__ __launch_bounds__(kPrepBlock) void k_preprocess_multi(const PrepMultiArgs M) { preprocess_scan_body(M.a[blockIdx.x], 0); }
+__global__ __launch_bounds__(kPrepBlock) void k_preprocess_multi(const PrepMultiArgs M) { preprocess_scan_body<kPrepBlock, kPrepMaxBeams>(M.a[blockIdx.x], 0); }
 
 // ---- lane-chunked copy of every cloud of a set for k_align's streaming pass (project_cloud_lanes) -------------
 // slot t*nthreads + g of cloud c  <-  pair g*T_c + t of the cloud (two points), +inf where the cloud has ended
