@@ -77,11 +77,16 @@ class _Envelope:
     envelope takes those runs in.  An alignment that only passes with them is tallied apart (needs_perturbed).
     Tallies: ok (within 1e-4 of fp64 outright), needs_factor (within 3 x the two evaluations' distance), needs_perturbed (within 3 x the distance of the
     one-ulp-perturbed runs), no_oracle (the fp64 oracle, or every fp32 one, did not succeed: nothing to compare with), status_differs (fp64 and an fp32 oracle
-    succeed, the device's mirror does not), violation (outside all of it)."""
+    succeed, the device's mirror does not), ill_conditioned (the REFERENCE arithmetic has no answer: its own evaluations, or its runs from one-ulp-moved start poses,
+    end more than 1e-2 m / 1e-2 rad -- a hundred bars -- from the fp64 oracle: an alignment that diverges chaotically (seed 4711 / trial 219 of the parameter fuzz:
+    one ulp on the start pose moves the sequential oracle by 0.74 m, the device's tree sums by 5 m).  Three times a four-sample spread bounds nothing there; such
+    alignments are counted, listed and bounded in number, and keep the bitwise device-order check like every other one), violation (outside all of it)."""
+    ILL = 1e-2
 
     def __init__(self):
-        self.tally = dict(ok=0, needs_factor=0, needs_perturbed=0, no_oracle=0, status_differs=0, violation=0)
+        self.tally = dict(ok=0, needs_factor=0, needs_perturbed=0, no_oracle=0, status_differs=0, ill_conditioned=0, violation=0)
         self.violations = []
+        self.ill = []
         self.worst = dict(ok=0.0, needs_factor=0.0, needs_perturbed=0.0)
 
     @staticmethod
@@ -114,6 +119,10 @@ class _Envelope:
                 pm = max(_pose_diff(o["pose"], rd["pose"])[0] for o in more); pr_ = max(_pose_diff(o["pose"], rd["pose"])[1] for o in more)
             if dm <= max(POSE_TOL_M, 3.0 * em, 3.0 * pm) and dr <= max(POSE_TOL_RAD, 3.0 * er, 3.0 * pr_):
                 self.tally["needs_perturbed"] += 1; self.worst["needs_perturbed"] = max(self.worst["needs_perturbed"], dm, dr); return "needs_perturbed"
+        if max(em, pm) > self.ILL or max(er, pr_) > self.ILL:
+            self.tally["ill_conditioned"] += 1
+            self.ill.append((where, dict(device_vs_fp64=(dm, dr), oracles_vs_fp64=(em, er), one_ulp_runs_vs_fp64=(pm, pr_))))
+            return "ill_conditioned"
         self.tally["violation"] += 1
         self.violations.append((where, dict(device_vs_fp64=(dm, dr), oracles_vs_fp64=(em, er), one_ulp_runs_vs_fp64=(pm, pr_), device=np.asarray(dev_pose).tolist(), fp64=np.asarray(rd["pose"]).tolist())))
         return "violation"
@@ -122,8 +131,9 @@ class _Envelope:
         t = self.tally
         return ("envelope class: %d within 1e-4 of the fp64 oracle outright (worst %.2e), %d within 3 x the reference arithmetic's own distance from it (worst %.2e), "
                 "%d within 3 x what ONE ULP on the start pose does to the reference arithmetic (worst %.2e), %d with no oracle to compare with, %d where only the "
-                "device-order evaluation fails, %d OUTSIDE the envelope"
-                % (t["ok"], self.worst["ok"], t["needs_factor"], self.worst["needs_factor"], t["needs_perturbed"], self.worst["needs_perturbed"], t["no_oracle"], t["status_differs"], t["violation"]))
+                "device-order evaluation fails, %d ill-conditioned (the reference arithmetic itself spreads over more than 1e-2), %d OUTSIDE the envelope"
+                % (t["ok"], self.worst["ok"], t["needs_factor"], self.worst["needs_factor"], t["needs_perturbed"], self.worst["needs_perturbed"], t["no_oracle"], t["status_differs"],
+                   t["ill_conditioned"], t["violation"]))
 
 
 def _projector(cols=1081, rmin=0.3, rmax=30.0, off=0.0):
@@ -2045,11 +2055,14 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
     checked_total = checked_poses
     for v in env.violations:
         print("OUTSIDE THE ENVELOPE", v)
-    # Fourteen seeds x 420 trials (profiles/r05/fuzz_soak_r05k.log): 3 of 22 535 alignments end outside the envelope -- 1.1e-4, 2.3e-4 and 2.5e-4 m from the fp64 oracle
+    # Eighteen seeds x 420 trials (profiles/r05/fuzz_soak_r05r_*.log): 5 of 28 972 alignments end outside the envelope -- 1.1e-4 ... 2.8e-4 m from the fp64 oracle
     # where the sequential-order evaluations sit within 2e-5 of it: the device's TREE sums pick another pair at a gate, and one pair in a few hundred moves the
     # optimum by that much.  Counted and bounded, not hidden: at most one alignment per two thousand checked (one per run at least), none beyond 5e-4 m / 5e-4 rad.
+    for v in env.ill:
+        print("ILL-CONDITIONED (the reference arithmetic has no answer to 1e-2)", v)
     assert len(env.violations) <= max(1, checked_total // 2000), env.violations[:5]
     assert all(max(v[1]["device_vs_fp64"]) <= 5e-4 for v in env.violations), env.violations[:5]
+    assert len(env.ill) <= max(1, checked_total // 2000), env.ill[:5]
     assert checked_pairs > 5000 and checked_poses >= 12
 
 
@@ -2301,11 +2314,14 @@ def test_randomised_aligner_structure(ctx, po):
     checked_total = checked
     for v in env.violations:
         print("OUTSIDE THE ENVELOPE", v)
-    # Fourteen seeds x 420 trials (profiles/r05/fuzz_soak_r05k.log): 3 of 22 535 alignments end outside the envelope -- 1.1e-4, 2.3e-4 and 2.5e-4 m from the fp64 oracle
+    # Eighteen seeds x 420 trials (profiles/r05/fuzz_soak_r05r_*.log): 5 of 28 972 alignments end outside the envelope -- 1.1e-4 ... 2.8e-4 m from the fp64 oracle
     # where the sequential-order evaluations sit within 2e-5 of it: the device's TREE sums pick another pair at a gate, and one pair in a few hundred moves the
     # optimum by that much.  Counted and bounded, not hidden: at most one alignment per two thousand checked (one per run at least), none beyond 5e-4 m / 5e-4 rad.
+    for v in env.ill:
+        print("ILL-CONDITIONED (the reference arithmetic has no answer to 1e-2)", v)
     assert len(env.violations) <= max(1, checked_total // 2000), env.violations[:5]
     assert all(max(v[1]["device_vs_fp64"]) <= 5e-4 for v in env.violations), env.violations[:5]
+    assert len(env.ill) <= max(1, checked_total // 2000), env.ill[:5]
     assert checked >= n_trials // 2 and env.tally["status_differs"] <= max(2, checked // 50)
 
 
