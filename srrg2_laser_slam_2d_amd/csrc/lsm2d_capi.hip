@@ -112,7 +112,7 @@ struct lsm2d_context {
   // the SECOND stream: while a batch is in flight, what the next one needs ahead of its k_align -- its scans' preprocessing (lsm2d_preprocess_scans_refill), its
   // start poses' upload, its placement's estimate -- is queued here, so the chip runs it in the slots the launch in flight leaves free (its tail), and k_align
   // on the first stream waits for an event behind it
-  hipStream_t stream_b = nullptr; hipEvent_t ev_b = nullptr, ev_a_est = nullptr; bool b_dirty = false, a_est_recorded = false;
+  hipStream_t stream_b = nullptr; hipEvent_t ev_b = nullptr, ev_a_est = nullptr; bool b_dirty = false, a_est_recorded = false, b_recorded = false;
   hipStream_t stream_c = nullptr; hipEvent_t ev_c = nullptr; bool c_dirty = false;      // lsm2d_preprocess_scans_refill while a batch is in flight: a stream of its own (refill_stream)
   hipStream_t stream_h = nullptr; hipEvent_t ev_h = nullptr;                            // ... and one for its host-to-device copy (the copy engine's; nothing it waits for)
   // a batch begun asynchronously launches on ITS LANE's stream: two batches in flight are two streams, and the second one's workgroups fill the slots the first
@@ -185,7 +185,7 @@ static hipError_t join_refill_stream(lsm2d_context* ctx, hipStream_t st) {
 static hipError_t join_pre_stream(lsm2d_context* ctx, hipStream_t ks) {
   if (!ctx->b_dirty || !ctx->stream_b) return hipSuccess;
   hipError_t e = hipEventRecord(ctx->ev_b, ctx->stream_b);
-  if (e == hipSuccess) e = hipStreamWaitEvent(ks, ctx->ev_b, 0);
+  if (e == hipSuccess) { ctx->b_recorded = true; e = hipStreamWaitEvent(ks, ctx->ev_b, 0); }
   ctx->b_dirty = false;
   return e;
 }
@@ -2469,6 +2469,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
         size_t est_lds = sizeof(u64) * (size_t) A.s[bs].proj.cols; if (est_lds < sizeof(BalanceLds)) est_lds = sizeof(BalanceLds);
         // (estimates share ONE ticket counter: one queued on the second stream waits for the latest one queued on the first)
         if (pre != ctx->stream && ctx->a_est_recorded) HIPCHK(ctx, hipStreamWaitEvent(pre, ctx->ev_a_est, 0));
+        if (pre == ctx->stream && ctx->b_recorded) HIPCHK(ctx, hipStreamWaitEvent(pre, ctx->ev_b, 0));      // (... and the other way round: a synchronous call while a begun batch's estimate may still be running)
         hipLaunchKernelGGL(k_cull_estimate, dim3((unsigned) n), dim3(kAlignBlock), est_lds, pre, A, bs, d_work, ctx->d_order,
                            notes ? (const int32_t*) ctx->d_wg_place : (const int32_t*) nullptr, ctx->n_cu, (unsigned int*) (ctx->d_wg_place + 1024));
         const hipError_t le = hipGetLastError();

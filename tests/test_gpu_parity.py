@@ -2962,6 +2962,13 @@ def test_first_call_of_a_fresh_context_is_an_asynchronous_begin_and_two_batches_
                 assert np.array_equal(g.pose, w.pose) and np.array_equal(g.stats, w.stats), k
         g = pb.wait(copy=True)
         assert np.array_equal(g.pose, wb.pose) and np.array_equal(g.stats, wb.stats)
+        # a SYNCHRONOUS call while a begun batch is on the chip (the other lane; its estimate shares the ticket counter with the begun batch's: ordered behind it)
+        xc = (wl.x0[fi[0]] + rng.normal(0, [0.02, 0.02, 0.005], (n, 3))).astype(np.float32)
+        wc = al.compute_batch([fixed], [moving], xc, fixed_index=fi, want_stats=True)
+        pa.set_init_poses(xc + np.float32(0.001)); pa.begin()
+        gc_ = al.compute_batch([fixed], [moving], xc, fixed_index=fi, want_stats=True)
+        pa.wait()
+        assert np.array_equal(gc_.pose, wc.pose) and np.array_equal(gc_.stats, wc.stats) and np.array_equal(gc_.status, wc.status)
         fixed.close(); moving.close()
     finally:
         c.close()
