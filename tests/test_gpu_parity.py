@@ -1609,6 +1609,31 @@ def test_preprocessor_bit_exact_batch_and_feeds_aligner(ctx, po):
         assert d[:2].max() < POSE_TOL_M and d[2] < POSE_TOL_RAD
 
 
+def test_preprocessor_batch_form_and_single_scan_form_at_their_capacity_edges(ctx, po):
+    """Round 5: a batch of >= 8 scans of <= 1152 beams runs the preprocessor's small form (512 threads, 34 KB: the sort's keys live where the unprojected points
+    were, and pad to 2048 entries as soon as more than 1024 points carry a normal); anything else the one-beam-per-thread form.  Both against the oracle, bit for bit,
+    on scans built to cross those edges: a smooth room seen with 1081 / 1150 / 1152 / 1153 / 2048 beams (every beam valid, nearly every point gets a normal: more than
+    1024 of them), with and without voxelisation, as batches of 12 (small form where the beams fit) and of 3 (single-scan form)."""
+    world = synth.make_world(4)
+    poses = synth.sample_poses(world, 12, seed=11)
+    for nb in (1081, 1150, 1152, 1153, 2048):
+        a0, a1 = -0.75 * math.pi, 0.75 * math.pi
+        ranges = synth.make_scan_ranges(world, poses, n_beams=nb, angle_min=a0, angle_max=a1, noise_sigma=0.002, seed=nb)
+        for vox in (0.02, 0.0):
+            pre = api.RawDataPreprocessorProjective2D(ctx, range_min=0.1, range_max=40.0, voxelize_resolution=vox, normal_point_distance=0.4)
+            pp = po.Preprocessor(nb, a0, a1, 0.1, 40.0, 0.4, 5, vox)
+            want = [po.preprocess_scan(pp, ranges[i]) for i in range(len(poses))]
+            if vox == 0.0 and nb >= 1150:
+                assert max(len(w) for w in want) > 1024      # (the case the key array must hold 2048 entries for)
+            for lo, hi in ((0, 12), (3, 6)):
+                pre.setRawData(ranges[lo:hi], a0, a1, 0.0, 50.0)
+                meas = pre.compute()
+                for i in range(lo, hi):
+                    assert meas.counts[i - lo] == len(want[i]), (nb, vox, lo, i)
+                    assert np.array_equal(meas.download(i - lo), want[i]), (nb, vox, lo, i)
+                meas.close()
+
+
 def test_preprocessor_reads_pinned_and_device_resident_ranges(ctx, po):
     """lsm2d_preprocess_scans takes its ranges from pageable host memory (staged), pinned host memory (copied from directly) or the
     device (read in place): the same clouds, bit for bit, and the oracle's."""
