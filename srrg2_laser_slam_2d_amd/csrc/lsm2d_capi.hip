@@ -434,9 +434,9 @@ enum : int { kOptBool = 1, kOptEven = 2, kOptResetsNotes = 4, kOptReadOnly = 8, 
 struct OptionDesc { const char* key; int lsm2d_context::* field; long long lo, hi; int flags; };
 struct OptionDescLL { const char* key; long long lsm2d_context::* field; };
 #ifdef LSM2D_EXPERIMENTS
-constexpr int kCullMax = 2, kBuiltWithExperiments = 1;
+constexpr int kCullMax = 2;
 #else
-constexpr int kCullMax = 1, kBuiltWithExperiments = 0;
+constexpr int kCullMax = 1;
 #endif
 const OptionDesc kOptions[] = {
   // ---- public (include/lsm2d.h)
@@ -2087,8 +2087,10 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   const int clock_stride = ctx->clock_stride > 0 ? ctx->clock_stride : (n / 32 > 1 ? n / 32 : 1), n_clock = (n + clock_stride - 1) / clock_stride;
   const size_t o_clock = ctx->kernel_timing ? take(sizeof(unsigned long long) * 4 * (size_t) n_clock) : 0;
   const size_t out_bytes = off - o_pose;      // what travels back to the host
-  const size_t o_work = take(sizeof(int32_t) * (size_t) n), o_order = take(sizeof(int32_t) * (size_t) n);      // balanced placement (device only)
-  const size_t o_resume = take(sizeof(ResumeDev) * (size_t) n);                                                // the state between the two launches of a batch (device only)
+  const size_t o_work = take(sizeof(int32_t) * (size_t) n);                                                     // balanced placement: the estimate's counts (device only)
+#ifdef LSM2D_EXPERIMENTS      // the two-launch form of a batch ("two_stage"): its order and the state between its launches (device only)
+  const size_t o_order = take(sizeof(int32_t) * (size_t) n), o_resume = take(sizeof(ResumeDev) * (size_t) n);
+#endif
   const size_t total_bytes = off;
   int rc = ensure_scratch(ctx, total_bytes); if (rc) return rc;
   rc = ensure_stage(ctx, total_bytes); if (rc) return rc;
@@ -2406,10 +2408,6 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
 #ifdef LSM2D_EXPERIMENTS
   const bool two_stage = !use_split && !use_pair && !zero_copy && A.cull && ctx->balance && ctx->two_stage && n > 256 && n <= 1024 && proj_culled_for_all &&
                          has_proj && !has_nn && !has_dist && !has_kd && ap->max_iterations >= 4;
-#else
-  constexpr bool two_stage = false;
-#endif
-#ifdef LSM2D_EXPERIMENTS
   if (two_stage) {
     int32_t* d_work = (int32_t*) ((char*) ctx->d_scratch + o_work); int32_t* d_order = (int32_t*) ((char*) ctx->d_scratch + o_order);
     const unsigned long long shape = ((unsigned long long) (unsigned) n << 32) ^ ((unsigned long long) lds << 8) ^ 6ull;
