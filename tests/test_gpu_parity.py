@@ -2980,13 +2980,17 @@ def test_first_call_of_a_fresh_context_is_an_asynchronous_begin_and_two_batches_
             assert np.array_equal(g.pose, w.pose) and np.array_equal(g.information, w.information) and np.array_equal(g.status, w.status)
             assert np.array_equal(g.iterations, w.iterations) and np.array_equal(g.stats, w.stats)
         assert (wa.status == 0).all() and not np.array_equal(wa.pose, wb.pose)
-        for k in range(6):                          # a pipeline of them: begin(k) ; wait(k - 1)
-            (pa, pb)[k & 1].begin()
-            if k:
-                g = (pa, pb)[(k - 1) & 1].wait(copy=True); w = (wa, wb)[(k - 1) & 1]
-                assert np.array_equal(g.pose, w.pose) and np.array_equal(g.stats, w.stats), k
-        g = pb.wait(copy=True)
-        assert np.array_equal(g.pose, wb.pose) and np.array_equal(g.stats, wb.stats)
+        for lane_streams in (1, 0):                 # (0: every launch in order on the context's stream, as first built -- a knob of the experiments build)
+            if not xset(c, lane_streams=lane_streams):
+                continue
+            for k in range(6):                      # a pipeline of them: begin(k) ; wait(k - 1)
+                (pa, pb)[k & 1].begin()
+                if k:
+                    g = (pa, pb)[(k - 1) & 1].wait(copy=True); w = (wa, wb)[(k - 1) & 1]
+                    assert np.array_equal(g.pose, w.pose) and np.array_equal(g.stats, w.stats), (lane_streams, k)
+            g = pb.wait(copy=True)
+            assert np.array_equal(g.pose, wb.pose) and np.array_equal(g.stats, wb.stats)
+        xset(c, lane_streams=1)
         # a SYNCHRONOUS call while a begun batch is on the chip (the other lane; its estimate shares the ticket counter with the begun batch's: ordered behind it)
         xc = (wl.x0[fi[0]] + rng.normal(0, [0.02, 0.02, 0.005], (n, 3))).astype(np.float32)
         wc = al.compute_batch([fixed], [moving], xc, fixed_index=fi, want_stats=True)
