@@ -106,8 +106,12 @@ struct lsm2d_context {
     void* h_stage = nullptr; size_t h_stage_bytes = 0; void* h_stage_dev = nullptr; void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
     int32_t* d_order = nullptr; bool order_valid = false; unsigned long long order_key = 0; std::vector<float> order_poses;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr; bool busy = false; int id = 1;
+    std::vector<unsigned char> inputs_shadow; bool inputs_valid = false;
   } parked;
   int lane_id = 0; bool lane_busy = false; hipEvent_t ev_done = nullptr;      // the current lane's id / busy flag / "this batch's last operation has run"
+  // what the lane's device scratch holds as a batch's INPUT block (start poses, index arrays), byte for byte, while nothing else has used the scratch since: a batch
+  // that comes again with the same inputs needs no upload either (ensure_scratch invalidates it: every other user of the scratch comes through there)
+  std::vector<unsigned char> inputs_shadow; bool inputs_valid = false;
   int inflight = 0;                        // batches begun and not yet waited for
   // the SECOND stream: while a batch is in flight, what the next one needs ahead of its k_align -- its scans' preprocessing (lsm2d_preprocess_scans_refill), its
   // start poses' upload, its placement's estimate -- is queued here, so the chip runs it in the slots the launch in flight leaves free (its tail), and k_align
@@ -125,6 +129,7 @@ static void swap_lanes(lsm2d_context* c) {
   std::swap(c->d_scratch, p.d_scratch); std::swap(c->d_scratch_bytes, p.d_scratch_bytes);
   std::swap(c->d_order, p.d_order); std::swap(c->order_valid, p.order_valid); std::swap(c->order_key, p.order_key); c->order_poses.swap(p.order_poses);
   std::swap(c->ev0, p.ev0); std::swap(c->ev1, p.ev1); std::swap(c->ev_done, p.ev_done); std::swap(c->lane_busy, p.busy); std::swap(c->lane_id, p.id);
+  c->inputs_shadow.swap(p.inputs_shadow); std::swap(c->inputs_valid, p.inputs_valid);
 }
 // Side streams, created on first use with the highest priority the device has: what they carry is short, and the launch in flight holds every wave slot of the
 // chip -- the slots that come free at its end should go to the next batches' pre-kernels first, not to the 1000 long-lived workgroups of the launch queued behind it.
@@ -558,6 +563,7 @@ static int stage_device_view(lsm2d_context* ctx, char** out) {
 
 static int ensure_scratch(lsm2d_context* ctx, size_t bytes) {
   if (ctx->lane_busy) return fail(ctx, LSM2D_BAD_ARGUMENT, kBothLanesBusy);
+  ctx->inputs_valid = false;      // (whoever asks is about to write the scratch; lsm2d_align_batch looks at the flag before it asks)
   if (bytes <= ctx->d_scratch_bytes) return LSM2D_SUCCESS;
   if (ctx->d_scratch) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->d_scratch_bytes = 0; }
   size_t cap = bytes + bytes / 2 + 4096;
@@ -2092,6 +2098,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   const size_t o_order = take(sizeof(int32_t) * (size_t) n), o_resume = take(sizeof(ResumeDev) * (size_t) n);
 #endif
   const size_t total_bytes = off;
+  const bool had_inputs = ctx->inputs_valid;      // (the lane's scratch still holds the previous batch's input block: ensure_scratch below clears the flag)
   int rc = ensure_scratch(ctx, total_bytes); if (rc) return rc;
   rc = ensure_stage(ctx, total_bytes); if (rc) return rc;
   char* hs = (char*) ctx->h_stage; char* ds = (char*) ctx->d_scratch;
@@ -2347,7 +2354,16 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     HIPCHK(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(pre, ctx->ev_main, 0));
   }
-  if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, pre));
+  // Round 5: a batch that comes again with the SAME input block (start poses, index arrays; no priors) while nothing else has touched the lane's scratch needs no
+  // upload: the blit and the wait behind it are 8 us of a 0.77 ms step (kernel trace: copy 2.4 us + 5.6 us until k_align starts).  Compared byte for byte against a
+  // host-side shadow of what was uploaded last -- up to 64 KB; a sweep's index arrays beyond that are uploaded as before.
+  const bool same_inputs = !zero_copy && !out_work && !b->prior && had_inputs && in_bytes <= (64u << 10) && ctx->inputs_shadow.size() == in_bytes &&
+                           !memcmp(ctx->inputs_shadow.data(), hs, in_bytes);
+  if (!zero_copy && !same_inputs) {
+    HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, pre));
+    if (!out_work && !b->prior && in_bytes <= (64u << 10)) ctx->inputs_shadow.assign((const unsigned char*) hs, (const unsigned char*) hs + in_bytes); else ctx->inputs_shadow.clear();
+  }
+  ctx->inputs_valid = !zero_copy && !ctx->inputs_shadow.empty();
   A.init_pose = (const float*) (ds + o_pose_in);
   if (xcd_on && !use_split && !use_pair && !zero_copy) {
     const size_t xb = sizeof(uint32_t) * 16 * (size_t) A.xcd_stride;

@@ -3037,6 +3037,30 @@ def test_prepared_batch_equals_compute_batch(ctx, small_workload):
     prep.set_init_poses(x1)
     got = prep.run(); want1 = al.compute_batch([fixed], [moving], x1, want_stats=True)
     assert np.array_equal(got.pose, want1.pose) and np.array_equal(got.stats, want1.stats) and not np.array_equal(want1.pose, want.pose)
+    # round 5: a batch that comes again with the same input block is not uploaded again -- unless something else used the context's scratch in between
+    # (a finder call, another batch), or one start pose differs by one bit
+    n = 300
+    fi = (np.arange(n, dtype=np.int32) % len(wl.x0)).reshape(1, n)
+    xa = wl.x0[fi[0]].astype(np.float32).copy()
+    pa = al.prepare_batch([fixed], [moving], xa, fixed_index=fi, want_stats=True)
+    wa = al.compute_batch([fixed], [moving], xa, fixed_index=fi, want_stats=True)
+    f0 = wl.scan_points[wl.scan_offsets[0]:wl.scan_offsets[1]]
+    finder = api.CorrespondenceFinderProjective2f(ctx, _projector())
+    for k in range(6):
+        if k == 2:                                   # other users of the scratch in between
+            finder.setFixed(f0); finder.setMoving(wl.map_points); finder.setLocalMapInSensor(wl.x0[0]); finder.compute()
+        if k == 4:
+            al.compute_batch([fixed], [moving], wl.x0, want_stats=True)
+        g = pa.run()
+        assert np.array_equal(g.pose, wa.pose) and np.array_equal(g.stats, wa.stats) and np.array_equal(g.status, wa.status), k
+    xb = xa.copy(); xb[7, 2] = np.nextafter(xb[7, 2], np.float32(10.0))
+    pa.set_init_poses(xb)
+    wb = al.compute_batch([fixed], [moving], xb, fixed_index=fi, want_stats=True)
+    g = pa.run()
+    assert np.array_equal(g.pose, wb.pose) and np.array_equal(g.stats, wb.stats)
+    pa.set_init_poses(xa)
+    g = pa.run()
+    assert np.array_equal(g.pose, wa.pose) and np.array_equal(g.stats, wa.stats)
 
 
 def test_two_launches_for_one_batch_change_no_bit(ctx, po):
