@@ -2980,6 +2980,11 @@ def test_first_call_of_a_fresh_context_is_an_asynchronous_begin_and_two_batches_
             assert np.array_equal(g.pose, w.pose) and np.array_equal(g.information, w.information) and np.array_equal(g.status, w.status)
             assert np.array_equal(g.iterations, w.iterations) and np.array_equal(g.stats, w.stats)
         assert (wa.status == 0).all() and not np.array_equal(wa.pose, wb.pose)
+        got = list(api.run_pipelined([pa, pb, pa, pb, pa]))      # the same as a generator over a queue of batches
+        assert len(got) == 5
+        for k, g in enumerate(got):
+            w = (wa, wb)[k & 1]
+            assert np.array_equal(g.pose, w.pose) and np.array_equal(g.stats, w.stats) and np.array_equal(g.status, w.status), k
         for lane_streams in (1, 0):                 # (0: every launch in order on the context's stream, as first built -- a knob of the experiments build)
             if not xset(c, lane_streams=lane_streams):
                 continue
