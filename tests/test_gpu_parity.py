@@ -3026,6 +3026,68 @@ def test_start_poses_that_are_not_numbers_fail_their_alignment_not_the_call(ctx,
     fixed.close(); moving.close()
 
 
+def test_asynchronous_entry_points_reject_what_they_must_and_survive_abandonment(small_workload):
+    """Edge cases of lsm2d_align_batch_begin / _wait / lsm2d_preprocess_scans_refill through the raw ABI: null arguments, an empty batch (begun and waited for: a
+    no-op), wait's outputs missing (the batch is still retired: the lane is free again), a refill into a set of another shape or another context, and a context
+    destroyed while a begun batch was never waited for (its streams are drained, nothing is touched afterwards)."""
+    import ctypes as C
+    from srrg2_laser_slam_2d_amd import _capi
+    wl = small_workload
+    c = api.Context(0)
+    lib = c._lib
+    al = _aligner(c)
+    fixed = api.CloudSet(c, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(c, wl.map_points)
+    pb = al.prepare_batch([fixed], [moving], wl.x0)
+    h = C.c_void_p()
+    assert lib.lsm2d_align_batch_begin(None, C.byref(pb._ap), C.byref(pb._b), 0, C.byref(h)) == _capi.BAD_ARGUMENT
+    assert lib.lsm2d_align_batch_begin(c.handle, C.byref(pb._ap), C.byref(pb._b), 0, None) == _capi.BAD_ARGUMENT
+    assert lib.lsm2d_align_batch_wait(None, None, None, None, None, None) == _capi.BAD_ARGUMENT
+    # an empty batch: begun, waited for, nothing happens
+    pe = al.prepare_batch([fixed], [moving], np.zeros((0, 3), np.float32))
+    pe.begin(); re = pe.wait()
+    assert len(re.pose) == 0
+    # wait without outputs: an error, but the batch is retired -- two more can be begun and give the right answer
+    want = al.compute_batch([fixed], [moving], wl.x0)
+    check_rc = lib.lsm2d_align_batch_begin(c.handle, C.byref(pb._ap), C.byref(pb._b), 0, C.byref(h))
+    assert check_rc == 0 and h.value
+    assert lib.lsm2d_align_batch_wait(h, None, None, None, None, None) == _capi.BAD_ARGUMENT
+    pb2 = al.prepare_batch([fixed], [moving], wl.x0)
+    pb.begin(); pb2.begin()
+    assert np.array_equal(pb.wait().pose, want.pose) and np.array_equal(pb2.wait().pose, want.pose)
+    # refill: the set must come from lsm2d_preprocess_scans with the same number of scans and beams, on this context
+    world = synth.make_world(1); poses = synth.sample_poses(world, 9, seed=2)
+    a0, a1 = -2.0, 2.0
+    rg = synth.make_scan_ranges(world, poses, n_beams=361, angle_min=a0, angle_max=a1, seed=3)
+    pre = api.RawDataPreprocessorProjective2D(c, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+    pre.setRawData(rg, a0, a1, 0.0, 30.0); sset = pre.compute()
+    pre.setRawData(rg[:5], a0, a1, 0.0, 30.0)
+    with pytest.raises(Exception):
+        pre.refill(sset)                                   # 5 scans into a set of 9
+    rg2 = synth.make_scan_ranges(world, poses, n_beams=181, angle_min=a0, angle_max=a1, seed=3)
+    pre.setRawData(rg2, a0, a1, 0.0, 30.0)
+    with pytest.raises(Exception):
+        pre.refill(sset)                                   # other beams
+    with pytest.raises(Exception):
+        pre.setRawData(rg, a0, a1, 0.0, 30.0); pre.refill(fixed)      # a set that no preprocessor made
+    c2 = api.Context(0)
+    pre2 = api.RawDataPreprocessorProjective2D(c2, range_min=0.3, range_max=20.0, voxelize_resolution=0.02)
+    pre2.setRawData(rg, a0, a1, 0.0, 30.0)
+    with pytest.raises(Exception):
+        pre2.refill(sset)                                  # another context's set
+    pre.setRawData(rg, a0, a1, 0.0, 30.0); pre.refill(sset)      # ... and the right one still works
+    assert int(sset.counts.sum()) > 0
+    # a context destroyed with a begun batch that nobody waits for
+    al2 = _aligner(c2)
+    f2 = api.CloudSet(c2, wl.scan_points, wl.scan_offsets); m2 = api.CloudSet(c2, wl.map_points)
+    lost = al2.prepare_batch([f2], [m2], wl.x0)
+    lost.begin()
+    c2.close()
+    # the first context is untouched by all of it
+    got = al.compute_batch([fixed], [moving], wl.x0)
+    assert np.array_equal(got.pose, want.pose)
+    c.close()
+
+
 def test_prepared_batch_equals_compute_batch(ctx, small_workload):
     """MultiAligner2D.prepare_batch: the descriptor and the result arrays built once, lsm2d_align_batch called again and again (what bench.py times) --
     the same results as compute_batch, call after call, also after new start poses were written in place."""
