@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LSM2D_VERSION 150 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
+#define LSM2D_VERSION 160 /* 0.1.1: + lsm2d_preprocess_scan_into, asynchronous clip / merge (NULL size outputs), non-blocking upload;
                              0.1.11: + lsm2d_get_option, align_path 3; 0.1.12: + lsm2d_merge_scenes;
                              0.2.0: + lsm2d_clip_scene_voxelized, lsm2d_sweep_* (multi-device loop-closure sweep), in-kernel clock options;
                              0.2.1: + lsm2d_cloudset_cloud_sizes, pinned / device-resident ranges in lsm2d_preprocess_scans, options
@@ -43,7 +43,9 @@ extern "C" {
                                     lsm2d_pair_hash, lsm2d_estimate_work (work-aware sharding of a candidate sweep);
                              0.5.0: + lsm2d_align_batch_begin / _wait (a batch in flight while the host prepares the next one), lsm2d_preprocess_scans_refill
                                     (fresh scans into an existing set: no allocation, nothing waits); the option keys below are the WHOLE public set (the A/B
-                                    knobs of rounds 1-4 exist only in a -DLSM2D_EXPERIMENTS build); read-only keys "uploads", "last_cull_estimate", "experiments" */
+                                    knobs of rounds 1-4 exist only in a -DLSM2D_EXPERIMENTS build); read-only keys "uploads", "last_cull_estimate", "experiments";
+                             0.6.0: + option "sum_order" (1: H, b and the chi^2 statistics are added pair after pair in the reference's order -- the ONE option
+                                    results depend on: with it the aligner is bitwise the sequential fp32 restatement of nicp_post.m:69-90) */
 
 /* ---- status codes -------------------------------------------------------------------------
  * Replace: std::runtime_error throws of the finders (registration/correspondence_finder_projective_2d.cpp:21-31,
@@ -166,10 +168,22 @@ const char* lsm2d_last_error(const lsm2d_context* ctx);
 /* hip_stream: an existing hipStream_t to launch on (e.g. the caller's torch stream), or NULL to own one */
 int  lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out_ctx);
 /* waits for the stream, frees the context.  Cloud sets still alive on it stay the caller's to destroy (any time), but no call takes them any more. */
+/* (batches begun with lsm2d_align_batch_begin must have been waited for: the call brings every stream of the context to rest before it frees anything, but a
+ * lsm2d_pending that is still outstanding refers to the context and must not be used afterwards) */
 void lsm2d_destroy(lsm2d_context* ctx);
 /* blocks until everything queued on the context's stream has finished */
 int  lsm2d_synchronize(lsm2d_context* ctx);
-/* Options: the WHOLE public set (13 keys; anything else is LSM2D_BAD_ARGUMENT "unknown option").  Results never depend on any of them.
+/* Options: the WHOLE public set (14 keys; anything else is LSM2D_BAD_ARGUMENT "unknown option").  Results never depend on any of them but "sum_order".
+ * "sum_order": 0 (default) = H, b and the chi^2 statistics of an iteration are added in TREES (a thread's pairs, then the 64 lanes of a wave, then the eight
+ *   waves): the fast order.  1 = added PAIR AFTER PAIR in the order of the reference's correspondence vector -- ascending canvas column for the projective
+ *   finder (registration/correspondence_finder_projective_2d.cpp:55-74), ascending moving index for the point-query finders
+ *   (registration/correspondence_finder_kd_tree_2d.cpp:12-27) -- one factor after the other into H and b as octave/solver/nicp_post.m:69-90 does, slice
+ *   totals added in slice order.  Both orders use the same per-pair terms and the same fused operations; they differ in the association of fp32 sums,
+ *   i.e. in the last bits of H and b, which a pair sitting on a gate can turn into another correspondence set a few iterations later (PARITY.md section 0).
+ *   With 1 the aligner (lsm2d_align_batch and its begin / wait / pairs forms, every finder kind, priors, sensor offsets, the split path) and
+ *   lsm2d_linearize equal the sequential fp32 oracle (oracle/: lsmo_align_f, lsmo_linearize_f) BIT FOR BIT.  Cost: the pairs' terms go through LDS (18 KB
+ *   more per workgroup) and eleven lanes add them one after the other: configs[1] (1000 scans vs a 100k-point map) runs at about 0.8 of the default
+ *   order's rate.  Calls the latency kernel would take (align_path 3) run on k_align instead: "last_align_path" reads 1.
  * "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align), 2 = always the split path (k_split_project +
  *   k_split_finish per iteration; projective slices only), 3 = the latency kernel whenever the batch has one or two projective slices
  *   (k_align_pair: 512 threads per slice, two slices' passes side by side in one workgroup; automatic for <= 256 alignments).  All paths return

@@ -66,6 +66,8 @@ struct lsm2d_context {
   int nn_lds_only = 1;         // grid NN with every alignment's tables staged in LDS: the instantiation without the search in global memory (0: the shared one; A/B knob)
   int nn_qcache = 1;           // grid NN over a map-sized fixed cloud: cache every query's cell ranges in LDS between iterations (0: off; A/B knob)
   int cull_block = 0;          // steps per unit of the culled stream (0: automatic, ~1/25 of a chunk; even; tuning knob)
+  int sum_order = 0;           // 0: H, b and the chi^2 sums are formed in trees (a thread's pairs, 64 lanes, 8 waves: the fast order); 1: pair after pair in the reference's order
+                               // (nicp_post.m:69-90: ascending column / moving index) -- bitwise the sequential fp32 CPU restatement the tests check against; k_align_seq, k_split_finish<true>, k_linearize_seq
   int cull = 1;                // k_align, projective slices: exact culling of the moving cloud against the fixed canvas (0: off; results do not depend on it)
   int cull_keep = 1;           // ... the culled stream's unit lists are kept across iterations while the estimate stays within the margins they were built with (0: rebuilt every iteration; A/B knob)
   int cull_margin_um = 10000;  // the translation margin in micrometres (10 mm) and
@@ -210,13 +212,15 @@ static hipError_t stream_sync(lsm2d_context* ctx) {
 // moves as for a stream wait.  A launch that does not report within the spin budget falls back to the real wait (which also
 // surfaces a device error).
 static constexpr int32_t kStatusNotWritten = -1;
-static hipError_t wait_for_statuses(lsm2d_context* ctx, const int32_t* st, int n) {
+// (done != nullptr: the batch was begun asynchronously and launched on its lane's stream -- the fallback waits for the event recorded behind THAT launch;
+// the context's own stream may be idle while the kernel is still writing: round-5 advisor)
+static hipError_t wait_for_statuses(lsm2d_context* ctx, const int32_t* st, int n, hipEvent_t done = nullptr) {
   const auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n; ++i) {
     unsigned spins = 0;
     while (__atomic_load_n(&st[i], __ATOMIC_ACQUIRE) == kStatusNotWritten) {
       __builtin_ia32_pause();
-      if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return stream_sync(ctx);
+      if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return done ? hipEventSynchronize(done) : stream_sync(ctx);
     }
   }
   ++ctx->sync_epoch;
@@ -259,6 +263,7 @@ struct lsm2d_cloudset {
   mutable float4* d_block_bounds = nullptr;     // ... and of every block of every chunk (k_block_bounds): the block-level test of the unit lists
   mutable int32_t block_stride = kCullBlocks;   // blocks per chunk in d_block_bounds: kCullBlocksMax for a set that holds a map-sized cloud (cull_blocks_for)
   mutable float4* d_aos = nullptr;              // (x, y, nx, ny) rows of the whole set (k_aos_rows): one gather per z-buffer winner in k_align's bin walk
+  hipEvent_t ev_stage = nullptr; bool stage_on_side = false;      // behind the set's latest copy OUT of h_upload queued on a side stream (the refill's pageable path): what acquire_upload_stage waits for
   hipEvent_t ev_prep = nullptr;                 // behind the set's latest preprocessing launch on the refill stream: its NEXT refill's copy (another stream) overwrites what that launch reads
   mutable float4* d_tile_bounds = nullptr; mutable int32_t* d_tile_start = nullptr;      // bounding circles of the tiles of 64 points (k_tile_bounds): the point-query finders' culling
   int32_t n_clouds = 0;
@@ -308,6 +313,27 @@ static int fail(lsm2d_context* ctx, int code, const char* msg) {
   if (ctx) ctx->last_error = msg;
   return code;
 }
+
+// ---- the instantiations of k_align a batch can be launched as
+typedef void (*AlignKernel)(const AlignArgs);
+enum : unsigned { kFProj = 1, kFNN = 2, kFDist = 4, kFKd = 8 };
+struct AlignVariant { unsigned finders; int mode; AlignKernel fn; };
+static const AlignVariant kAlignVariants[] = {
+  {kFProj, 5, k_align<true, false, false, false, 5>}, {kFProj, 0, k_align<true, false, false>},
+#ifdef LSM2D_EXPERIMENTS
+  {kFProj, 6, k_align<true, false, false, false, 6>},      // 5 with the XCD lockstep ("xcd_lockstep": measured, 2x slower on configs[4] for 65 % less fabric traffic: DESIGN App. A)
+#endif
+  {kFNN, 1, k_align<false, true, false, false, 1>},   {kFNN, 2, k_align<false, true, false, false, 2>}, {kFNN, 0, k_align<false, true, false>},
+  {kFDist, 0, k_align<false, false, true>},
+  {kFKd, 3, k_align<false, false, false, true, 3>},   {kFKd, 4, k_align<false, false, false, true, 4>}, {kFKd, 0, k_align<false, false, false, true>},
+};
+// ... and with "sum_order" 1 (k_align_seq): one instantiation per finder kind (mode 0: whatever the alignment needs, decided at run time) plus the culled
+// projective stream -- the specialised modes of the table above are speed, not results, and this mode is bought for its bits
+static const AlignVariant kAlignVariantsSeq[] = {
+  {kFProj, 5, k_align_seq<true, false, false, false, 5>}, {kFProj, 0, k_align_seq<true, false, false>},
+  {kFNN, 0, k_align_seq<false, true, false>}, {kFDist, 0, k_align_seq<false, false, true>}, {kFKd, 0, k_align_seq<false, false, false, true>},
+  {kFProj | kFNN | kFDist, 0, k_align_seq<true, true, true>}, {kFProj | kFNN | kFDist | kFKd, 0, k_align_seq<true, true, true, true>},
+};
 
 extern "C" int lsm2d_version(void) { return LSM2D_VERSION; }
 
@@ -364,6 +390,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
 #endif
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  for (const AlignVariant& v : kAlignVariantsSeq) (void) hipFuncSetAttribute((const void*) v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_cull_estimate, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 #ifdef LSM2D_EXPERIMENTS
@@ -390,7 +417,13 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
 extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
+  // every stream the context ever launched on comes to rest BEFORE anything is freed (batches may still be in flight on the lanes' streams; a lsm2d_pending
+  // that has not been waited for is the caller's to delete -- include/lsm2d.h: wait for every begun batch before lsm2d_destroy)
   (void) hipStreamSynchronize(c->stream); ++c->sync_epoch;
+  if (c->stream_b) (void) hipStreamSynchronize(c->stream_b);
+  if (c->stream_c) (void) hipStreamSynchronize(c->stream_c);
+  if (c->stream_h) (void) hipStreamSynchronize(c->stream_h);
+  for (hipStream_t st : c->k_stream) if (st) (void) hipStreamSynchronize(st);
   for (lsm2d_cloudset* cs : c->live_sets) cs->ctx = nullptr;        // still owned by the caller: destroy them any time, use them no more
   if (c->h_stage) (void) hipHostFree(c->h_stage);
   if (c->h_flag) (void) hipHostFree(c->h_flag);
@@ -399,10 +432,6 @@ extern "C" void lsm2d_destroy(lsm2d_context* c) {
   if (c->d_kd_work) (void) hipFree(c->d_kd_work);
   if (c->d_wg_place) (void) hipFree(c->d_wg_place);
   if (c->d_order) (void) hipFree(c->d_order);
-  if (c->stream_b) (void) hipStreamSynchronize(c->stream_b);
-  if (c->stream_c) (void) hipStreamSynchronize(c->stream_c);
-  if (c->stream_h) (void) hipStreamSynchronize(c->stream_h);
-  for (hipStream_t st : c->k_stream) if (st) (void) hipStreamSynchronize(st);
   if (c->parked.h_stage) (void) hipHostFree(c->parked.h_stage);
   if (c->parked.d_scratch) (void) hipFree(c->parked.d_scratch);
   if (c->parked.d_order) (void) hipFree(c->parked.d_order);
@@ -457,6 +486,7 @@ const OptionDesc kOptions[] = {
   {"grid_big_threshold", &lsm2d_context::grid_big_threshold, 1, 0x7fffffff, 0},
   {"distmap_build",      &lsm2d_context::distmap_build,      0, 1,          0},
   {"kd_lds_nodes",       &lsm2d_context::kd_lds_nodes,       0, 4096,       0},
+  {"sum_order",          &lsm2d_context::sum_order,          0, 1,          0},
   // ---- read-only
   {"last_align_path",    &lsm2d_context::last_align_path,    0, 0, kOptReadOnly},
   {"last_query_cull",    &lsm2d_context::last_query_cull,    0, 0, kOptReadOnly},
@@ -530,6 +560,10 @@ extern "C" int lsm2d_last_kernel_ms(lsm2d_context* ctx, float* out_ms) {
   return LSM2D_SUCCESS;
 }
 
+// a timed launch outside the batch entry points recorded the CURRENT lane's events: they are what lsm2d_last_kernel_ms reads next (round-5 advisor: after an
+// asynchronous begin had swapped lanes the call kept answering with the old batch's events)
+static void note_timed(lsm2d_context* ctx, bool timed) { ctx->have_timing = timed; ctx->last_ev0 = ctx->ev0; ctx->last_ev1 = ctx->ev1; }
+
 static bool valid_cloud_index_fwd(const lsm2d_cloudset* cs, int32_t i);
 // what a caller's buffer is to the runtime (entry points that take bulk input accept all three)
 enum class PtrKind { pageable, pinned, device };
@@ -565,6 +599,9 @@ static int ensure_scratch(lsm2d_context* ctx, size_t bytes) {
   if (ctx->lane_busy) return fail(ctx, LSM2D_BAD_ARGUMENT, kBothLanesBusy);
   ctx->inputs_valid = false;      // (whoever asks is about to write the scratch; lsm2d_align_batch looks at the flag before it asks)
   if (bytes <= ctx->d_scratch_bytes) return LSM2D_SUCCESS;
+  // (a NEW allocation holds nobody's input block: the shadow goes with the old one -- round-5 advisor: a batch run again with more outputs, e.g. statistics,
+  // grew the scratch, compared equal against the shadow and skipped the upload into memory that had never seen it)
+  ctx->inputs_shadow.clear();
   if (ctx->d_scratch) { HIPCHK(ctx, stream_sync(ctx)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->d_scratch_bytes = 0; }
   size_t cap = bytes + bytes / 2 + 4096;
   HIPCHK(ctx, hipMalloc(&ctx->d_scratch, cap));
@@ -662,6 +699,7 @@ extern "C" void lsm2d_cloudset_destroy(lsm2d_cloudset* cs) {
   if (cs->d_count) (void) hipFree(cs->d_count);
   if (cs->d_ranges) (void) hipFree(cs->d_ranges);
   if (cs->ev_prep) (void) hipEventDestroy(cs->ev_prep);
+  if (cs->ev_stage) (void) hipEventDestroy(cs->ev_stage);
   for (auto& g : cs->grids) if (g.d_block) (void) hipFree(g.d_block);
   for (auto& d : cs->dists) { if (d.d_meta) (void) hipFree(d.d_meta); if (d.d_parent) (void) hipFree(d.d_parent); }
   for (auto& k : cs->kds) if (k.d_block) (void) hipFree(k.d_block);
@@ -803,6 +841,8 @@ static int acquire_upload_stage(lsm2d_cloudset* cs, size_t need) {
   // free to overwrite once the stream has been waited for since the last staged transfer was queued (the aligner call in between
   // does that); two uploads to the same set back to back wait here
   if (cs->staged_epoch == ctx->sync_epoch) HIPCHK(ctx, stream_sync(ctx));
+  // ... and a copy queued on a side stream (the refill while a batch is in flight) is not covered by the context stream's epoch: its own event
+  if (cs->stage_on_side) { HIPCHK(ctx, hipEventSynchronize(cs->ev_stage)); cs->stage_on_side = false; }
   if (need > cs->h_upload_bytes) {
     if (cs->h_upload) { HIPCHK(ctx, hipHostFree(cs->h_upload)); cs->h_upload = nullptr; cs->h_upload_bytes = 0; }
     const size_t want = cs->capacity > 0 ? sizeof(float) * 4 * (size_t) cs->capacity + 16 : need;
@@ -1472,7 +1512,7 @@ extern "C" int lsm2d_preprocess_scans(lsm2d_context* ctx, const lsm2d_preprocess
   if (e == hipSuccess) e = hipMemcpyAsync(cs->h_count.data(), cs->d_count, sizeof(int32_t) * (size_t) n_scans, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = stream_sync(ctx);
   if (e != hipSuccess) { lsm2d_cloudset_destroy(cs); HIPCHK(ctx, e); }
-  ctx->have_timing = ctx->kernel_timing;
+  note_timed(ctx, ctx->kernel_timing);
   cs->total = 0; for (int c = 0; c < n_scans; ++c) cs->total += cs->h_count[c];
   *out = cs;
   return LSM2D_SUCCESS;
@@ -1522,6 +1562,11 @@ extern "C" int lsm2d_preprocess_scans_refill(lsm2d_context* ctx, const lsm2d_pre
     memcpy(set->h_upload, ranges, rbytes);
     HIPCHK(ctx, hipMemcpyAsync(set->d_ranges, set->h_upload, rbytes, hipMemcpyHostToDevice, cpy));
     set->staged_epoch = ctx->sync_epoch;
+    if (cpy != ctx->stream) {      // (round-5 advisor: the epoch above speaks for the context's stream only)
+      if (!set->ev_stage && hipEventCreateWithFlags(&set->ev_stage, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); set->ev_stage = nullptr; }
+      if (set->ev_stage) { HIPCHK(ctx, hipEventRecord(set->ev_stage, cpy)); set->stage_on_side = true; }
+      else HIPCHK(ctx, hipStreamSynchronize(cpy));
+    }
   }
   else if (kind == PtrKind::pinned) HIPCHK(ctx, hipMemcpyAsync(set->d_ranges, ranges, rbytes, hipMemcpyHostToDevice, cpy));
   if (cpy != pre && kind != PtrKind::device) { HIPCHK(ctx, hipEventRecord(ctx->ev_h, cpy)); HIPCHK(ctx, hipStreamWaitEvent(pre, ctx->ev_h, 0)); }
@@ -1591,7 +1636,7 @@ extern "C" int lsm2d_preprocess_scan_into(lsm2d_context* ctx, const lsm2d_prepro
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   out->staged_epoch = ctx->sync_epoch;                    // the staging buffer is free again once the kernel has run
-  ctx->have_timing = true;
+  note_timed(ctx, true);
   return LSM2D_SUCCESS;
 }
 
@@ -1656,7 +1701,7 @@ static int clip_scene_impl(lsm2d_context* ctx, const lsm2d_projector* pr, const 
     HIPCHK(ctx, hipGetLastError());
   }
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = ctx->kernel_timing;
+  note_timed(ctx, ctx->kernel_timing);
   if (!out_n) {                               // at most one point per column
     clipped->h_count[0] = P.cols; clipped->total = P.cols; clipped->count_pending = true;
     return LSM2D_SUCCESS;
@@ -1745,7 +1790,7 @@ extern "C" int lsm2d_merge_scene(lsm2d_context* ctx, const lsm2d_projector* pr, 
   HIPCHK(ctx, hipGetLastError());
   }
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = ctx->kernel_timing;
+  note_timed(ctx, ctx->kernel_timing);
   if (!out_size) {                            // a merge appends at most one point per column
     scene->h_count[0] = n_scene + P.cols; scene->total = scene->h_count[0]; scene->count_pending = true;
     return LSM2D_SUCCESS;
@@ -1894,7 +1939,7 @@ static int find_correspondences_impl(lsm2d_context* ctx, const lsm2d_slice_param
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->have_timing = ctx->kernel_timing;
+    note_timed(ctx, ctx->kernel_timing);
     if (!direct) HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, stream_sync(ctx));
     const int32_t n = *(const int32_t*) ctx->h_stage;
@@ -1934,7 +1979,7 @@ static int find_correspondences_impl(lsm2d_context* ctx, const lsm2d_slice_param
   hipLaunchKernelGGL(k_find_projective, dim3(1), dim3(kFindBlock), lds, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = ctx->kernel_timing;
+  note_timed(ctx, ctx->kernel_timing);
   HIPCHK(ctx, stream_sync(ctx));
   const int32_t n = *(const int32_t*) ctx->h_stage;
   *out_n = n;
@@ -1985,11 +2030,14 @@ extern "C" int lsm2d_linearize(lsm2d_context* ctx, const lsm2d_slice_params* sp,
   if (direct) *(unsigned long long*) ((char*) ctx->h_stage + dig_off) = 0ull;
   else HIPCHK(ctx, hipMemsetAsync(A.dig, 0, sizeof(unsigned long long), ctx->stream));
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_linearize_partial, dim3(blocks), dim3(256), 0, ctx->stream, A);
-  hipLaunchKernelGGL(k_linearize_final, dim3(1), dim3(64), 0, ctx->stream, (const float*) A.partial, blocks, A.out);
+  if (ctx->sum_order) hipLaunchKernelGGL(k_linearize_seq, dim3(1), dim3(kAlignBlock), 0, ctx->stream, A);      // pair after pair, the order of the vector
+  else {
+    hipLaunchKernelGGL(k_linearize_partial, dim3(blocks), dim3(256), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_linearize_final, dim3(1), dim3(64), 0, ctx->stream, (const float*) A.partial, blocks, A.out);
+  }
   HIPCHK(ctx, hipGetLastError());
   if (ctx->kernel_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = ctx->kernel_timing;
+  note_timed(ctx, ctx->kernel_timing);
   float* h = (float*) ((char*) ctx->h_stage + out_off);
   if (!direct) HIPCHK(ctx, hipMemcpyAsync(h, A.out, sizeof(float) * kAccumWords + sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, stream_sync(ctx));
@@ -2018,20 +2066,6 @@ extern "C" int32_t lsm2d_stats_capacity(const lsm2d_aligner_params* ap) {
   const long long c = (long long) (ap->max_iterations > 0 ? ap->max_iterations : 0) * (ap->enable_inlier_only_runs ? 2 : 1);
   return (int32_t) (c < 1 ? 1 : (c > 0x7fffffff ? 0x7fffffff : c));
 }
-
-// ---- the instantiations of k_align a batch can be launched as
-typedef void (*AlignKernel)(const AlignArgs);
-enum : unsigned { kFProj = 1, kFNN = 2, kFDist = 4, kFKd = 8 };
-struct AlignVariant { unsigned finders; int mode; AlignKernel fn; };
-static const AlignVariant kAlignVariants[] = {
-  {kFProj, 5, k_align<true, false, false, false, 5>}, {kFProj, 0, k_align<true, false, false>},
-#ifdef LSM2D_EXPERIMENTS
-  {kFProj, 6, k_align<true, false, false, false, 6>},      // 5 with the XCD lockstep ("xcd_lockstep": measured, 2x slower on configs[4] for 65 % less fabric traffic: DESIGN App. A)
-#endif
-  {kFNN, 1, k_align<false, true, false, false, 1>},   {kFNN, 2, k_align<false, true, false, false, 2>}, {kFNN, 0, k_align<false, true, false>},
-  {kFDist, 0, k_align<false, false, true>},
-  {kFKd, 3, k_align<false, false, false, true, 3>},   {kFKd, 4, k_align<false, false, false, true, 4>}, {kFKd, 0, k_align<false, false, false, true>},
-};
 
 // What a batch that has been LAUNCHED keeps until its results are asked for (lsm2d_align_batch_begin / _wait; the synchronous calls go through the same two halves)
 struct lsm2d_pending {
@@ -2194,7 +2228,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     if (sp.finder == LSM2D_FINDER_PROJECTIVE) { const int lrc = ensure_lane_layout(ctx, m); if (lrc) return lrc; }
     // k_align's bin walk gathers both z-buffer winners as 16-byte rows of the sets' AoS copies (not for the calls the latency kernel or the split
     // path will take: the live tracker's sets change every step)
-    const bool pair_candidate = ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist && !has_kd && (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0;
+    const bool pair_candidate = !ctx->sum_order && ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist && !has_kd && (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0;
     if (sp.finder == LSM2D_FINDER_PROJECTIVE && !use_split && !pair_candidate && !defer_unpack) {
       int arc = ensure_aos(ctx, f); if (arc) return arc;
       arc = ensure_aos(ctx, m); if (arc) return arc;
@@ -2291,6 +2325,9 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     if ((int) (at + need) + 2048 <= ctx->max_dyn_lds && at + need + 2048 <= 40 * 1024) { A.units_off = (int32_t) at; lds = at + need; }      // four workgroups per CU must still fit (160 KB)
     else proj_culled_for_all = false;
   }
+  // "sum_order" 1: the trip's pair records (lsm2d_device.h), behind everything else -- three workgroups per CU instead of four
+  A.seq_off = 0;
+  if (ctx->sum_order) { lds = (lds + 15) & ~(size_t) 15; A.seq_off = (int32_t) lds; lds += sizeof(float) * kSeqFields * kAlignBlock; }
   // the XCD window (AlignArgs::xcd_sync): a big-map batch of ONE dispatch round -- every workgroup resident from the start (64 VGPRs, <= 40 KB of LDS: four per
   // CU) -- whose position space fits the counters
   A.xcd_sync = nullptr; A.xcd_window = 0; A.xcd_stride = 0; A.xcd_positions = 0;
@@ -2329,7 +2366,8 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   const size_t lds_fix = (size_t) ns * (size_t) max_fixed_rows * sizeof(float4);
   A.pair_fix_cap = max_fixed_rows <= 4096 && (int) (lds_pair0 + (A.pair_mov_cap ? lds_mov : 0) + lds_fix) + 512 <= ctx->max_dyn_lds ? max_fixed_rows : 0;
   const size_t lds_pair = lds_pair0 + (A.pair_mov_cap ? lds_mov : 0) + (A.pair_fix_cap ? lds_fix : 0);
-  const bool use_pair = !use_split && ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist && !has_kd &&
+  // ("sum_order" 1: the latency kernel keeps the tree order -- such calls take k_align_seq, one workgroup per alignment)
+  const bool use_pair = !ctx->sum_order && !use_split && ctx->align_path != 1 && (ns == 1 || ns == 2) && has_proj && !has_nn && !has_dist && !has_kd &&
                         (n <= 256 || ctx->align_path == 3) && ap->max_iterations > 0 && (int) lds_pair + 512 <= ctx->max_dyn_lds;
 
   // ---- inputs
@@ -2543,7 +2581,8 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
     for (int it = 0; it < it_cap; ++it) {      // (alignments that are done leave their launches at once: S.done)
       SA.it = it;
       hipLaunchKernelGGL((k_split_project<false>), dim3((unsigned) mchunks, (unsigned) n, (unsigned) ns), dim3(512), clds, ctx->stream, SA);
-      hipLaunchKernelGGL(k_split_finish, dim3((unsigned) n), dim3(kAlignBlock), 0, ctx->stream, SA);
+      if (ctx->sum_order) hipLaunchKernelGGL(k_split_finish<true>, dim3((unsigned) n), dim3(kAlignBlock), 0, ctx->stream, SA);
+      else hipLaunchKernelGGL(k_split_finish<false>, dim3((unsigned) n), dim3(kAlignBlock), 0, ctx->stream, SA);
     }
   } else {
     const dim3 grid((unsigned) n), block(kAlignBlock);
@@ -2557,6 +2596,12 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
       else if (finders == kFNN) mode = A.nn_lds_points == 0 ? 1 : (nn_lds_for_all ? 2 : 0);                        // tables in global memory / in LDS for every alignment
       else if (finders == kFKd && ns == 1 && ctx->kd_modes) mode = A.kd_lds_points > 0 ? 3 : 4;                    // whole trees in LDS / only their tops
       AlignKernel fn = nullptr;
+      if (ctx->sum_order) {      // the reference's order of summation: k_align_seq, the culled projective stream or the finder kind's general form
+        if (mode != 5) mode = 0;
+        for (const AlignVariant& v : kAlignVariantsSeq) if (v.finders == finders && v.mode == mode) { fn = v.fn; break; }
+        if (!fn) fn = has_kd ? (AlignKernel) k_align_seq<true, true, true, true> : (AlignKernel) k_align_seq<true, true, true>;
+      }
+      else
       for (const AlignVariant& v : kAlignVariants) if (v.finders == finders && v.mode == mode) { fn = v.fn; break; }
       if (!fn) fn = has_kd ? (AlignKernel) k_align<true, true, true, true> : (AlignKernel) k_align<true, true, true>;      // mixed finders
       hipLaunchKernelGGL(fn, grid, block, lds, ks, A);
@@ -2577,7 +2622,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   P.zero_copy = zero_copy; P.want_stats = out_stats != nullptr; P.want_last_pose = out_last_pose != nullptr; P.stamps = stamps; P.timed = ctx->kernel_timing != 0; P.async = async;
   P.xcd_sync = A.xcd_sync; P.xcd_stride = A.xcd_stride; P.xcd_window = A.xcd_window; P.xcd_positions = A.xcd_positions;
   if (async) {
-    if (!zero_copy) HIPCHK(ctx, hipEventRecord(ctx->ev_done, ks));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_done, ks));      // (zero-copy batches too: what their wait falls back to when the statuses do not arrive within the spin budget)
     ctx->lane_busy = true; ++ctx->inflight;
     swap_lanes(ctx);      // whatever is called next works on the other lane
     return LSM2D_SUCCESS;
@@ -2596,7 +2641,7 @@ static int align_batch_finish(lsm2d_pending& P, float* out_pose, float* out_H, i
     // (an event of the batch's own, not a wait for the stream: the NEXT batch may be queued behind it already.  The stream's epoch does not move: work queued
     // after this batch has not necessarily run)
     hipError_t we = hipSuccess;
-    if (zero_copy) { we = wait_for_statuses(ctx, (const int32_t*) (hs + o_status), n); --ctx->sync_epoch; }
+    if (zero_copy) { const unsigned long long epoch = ctx->sync_epoch; we = wait_for_statuses(ctx, (const int32_t*) (hs + o_status), n, P.ev_done); ctx->sync_epoch = epoch; }
     else we = hipEventSynchronize(P.ev_done);
     if (ctx->lane_id == P.lane_id) ctx->lane_busy = false; else if (ctx->parked.id == P.lane_id) ctx->parked.busy = false;
     if (ctx->inflight > 0) --ctx->inflight;

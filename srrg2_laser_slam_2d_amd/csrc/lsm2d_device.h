@@ -575,6 +575,75 @@ LSM2D_DEV float pair_chi(const Iso& T, float2 pf, float2 nf, float2 pm, float2 n
   return __builtin_fmaf(e0, e0, __builtin_fmaf(e1, e1, e2 * e2));
 }
 
+// ---- "sum_order" 1: H, b and the chi^2 statistics added PAIR AFTER PAIR, the reference's order --------------------------------------
+// The reference adds one factor after the other into H and b (octave/solver/nicp_post.m:69-90: H += J'*J; b += J'*e inside the loop over the
+// correspondences; the correspondence vector is in ascending column for the projective finder, correspondence_finder_projective_2d.cpp:55-74, and
+// in ascending moving index for the point-query finders, correspondence_finder_kd_tree_2d.cpp:12-27).  The default kernels add in trees (a thread's
+// pairs, then 64 lanes, then 8 waves): the same terms, another association.  With the option on, every thread that holds a pair writes the pair's
+// TERMS -- accumulate_pair's operations up to the sums, in its order -- as a record of kSeqFields floats into LDS, slot = the pair's position in the
+// reference's order within the current trip of the workgroup (a trip: 512 consecutive columns / moving indices); after the trip's barrier eleven lanes
+// of wave 0 walk the records in ascending slot, lane q adding quantity q with exactly the fused operations the sequential CPU restatement of the factor
+// uses (the tests hold the two against each other bit for bit): h = fma(w a_i, a_j, h), two of them chained for h22 and b2, chi sums by plain adds.  A slot without a pair holds zeros:
+// fma(+0, +0, h) == h and h + 0 == h bit for bit (no sum here is ever -0: they start at +0).  The counts are integers and keep their ballots.
+static constexpr int kSeqFields = 9;      // a0 a1 a2 e0 w dd de chi_in chi_out
+template <bool kInlineLog = false>
+LSM2D_DEV void pair_terms(const Iso& T, float2 pf, float2 nf, float2 pm, float2 nm, bool cauchy, float tau, bool inl_only,
+                          float (&t)[kSeqFields], bool& inlier) {
+  float qx, qy, nqx, nqy;
+  xf_point(T, pm.x, pm.y, qx, qy);
+  xf_normal(T, nm.x, nm.y, nqx, nqy);
+  const float dx = qx - pf.x, dy = qy - pf.y;
+  const float e0 = __builtin_fmaf(nf.x, dx, nf.y * dy);
+  const float e1 = nqx - nf.x, e2 = nqy - nf.y;
+  const float a0 = __builtin_fmaf(T.c, nf.x, T.s * nf.y);
+  const float a1 = __builtin_fmaf(-T.s, nf.x, T.c * nf.y);
+  const float a2 = __builtin_fmaf(a1, pm.x, -(a0 * pm.y));
+  const float d0 = -nqy, d1 = nqx;
+  const float chi = __builtin_fmaf(e0, e0, __builtin_fmaf(e1, e1, e2 * e2));
+  float w = 1.0f, kern = 0.0f;
+  inlier = true;
+  if (cauchy) {
+    const float q = chi / tau;
+    w = 1.0f / (1.0f + q);
+    inlier = chi < tau;
+    if (!inlier) kern = tau * (kInlineLog ? log_fixed_inline(1.0f + q) : log_fixed(1.0f + q));
+    if (inl_only) w = inlier ? 1.0f : 0.0f;
+  }
+  t[0] = a0; t[1] = a1; t[2] = a2; t[3] = e0; t[4] = w;
+  t[5] = __builtin_fmaf(d0, d0, d1 * d1);
+  t[6] = __builtin_fmaf(d0, e1, d1 * e2);
+  t[7] = inlier ? chi : 0.0f;
+  t[8] = inlier ? 0.0f : kern;
+}
+LSM2D_DEV void seq_zero(float (&t)[kSeqFields]) {
+#pragma unroll
+  for (int f = 0; f < kSeqFields; ++f) t[f] = 0.0f;
+}
+// (stride kSeqFields = 9 words: odd, so 64 lanes writing field f of 64 consecutive slots hit 64 different banks)
+LSM2D_DEV void seq_store(float* rec, int slot, const float (&t)[kSeqFields]) {
+#pragma unroll
+  for (int f = 0; f < kSeqFields; ++f) rec[slot * kSeqFields + f] = t[f];
+}
+// Every lane of ONE wave calls (lanes 11..63 walk along and hold nothing of value): `acc` is lane q's running sum of quantity q in the order
+// h00 h01 h02 h11 h12 h22 b0 b1 b2 chi_in chi_out (Accum's).  Records 0 .. n-1 in ascending slot.  All lanes read the same record, 36 bytes: LDS broadcasts.
+LSM2D_DEV float seq_walk(const float* rec, int n, int lane, float acc) {
+  const int q = lane < 11 ? lane : 0;
+  const int i1 = (int) ((0x87210211000ull >> (4 * q)) & 15), j1 = (int) ((0x00333221210ull >> (4 * q)) & 15);      // field of x1's factor, field of y1
+  const bool chi = q >= 9, has2 = q == 5 || q == 8;
+  const int j2 = q == 5 ? 5 : 6;                                                                                 // dd for h22, de for b2
+#pragma unroll 4
+  for (int k = 0; k < n; ++k) {
+    const float* r = rec + k * kSeqFields;
+    const float w = r[4], f1 = r[i1], g1 = r[j1], g2 = r[j2];
+    const float x1 = (chi ? 1.0f : w) * f1;            // w * a_i, the reference's wa_i (1 * chi: exact)
+    const float y1 = chi ? 1.0f : g1;                  // fma(chi, 1, s) == s + chi
+    acc = __builtin_fmaf(x1, y1, acc);
+    const float x2 = has2 ? w : 0.0f, y2 = has2 ? g2 : 0.0f;
+    acc = __builtin_fmaf(x2, y2, acc);                 // h22 += w dd, b2 += w de; elsewhere fma(0, 0, s) == s
+  }
+  return acc;
+}
+
 // ---- wave64 / workgroup reduction: shuffle butterfly, one LDS hop, fixed order => deterministic ----
 static constexpr int kAccumWords = 14;
 

@@ -1305,6 +1305,9 @@ struct AlignArgs {
   // cycles) and s_memrealtime (100 MHz) once at its start and once at its end -- [a / clock_stride][4] = {cycles, 10 ns ticks, start tick, hardware id} of
   // the workgroup's lifetime, from which the host reads the clock the chip held under THIS load (MI355X_MICROARCH.md, DVFS note 6)
   unsigned long long* clock_out; int32_t clock_stride;
+  // "sum_order" 1 (the k_align_seq / k_split_finish<true> instantiations): byte offset in dynamic LDS of the trip's pair records, kAlignBlock x kSeqFields floats
+  // (lsm2d_device.h, "sum_order"); sits in what was padding, so the other fields keep their offsets
+  int32_t seq_off;
   SliceDev s[kMaxSlices];
 };
 
@@ -1410,7 +1413,9 @@ LSM2D_DEV int place_key() {
   const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);      // HW_REG_HW_ID, HW_REG_XCC_ID
   return (int) (((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u));
 }
-template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0, bool kFirstStage = false>
+// kSeq: "sum_order" 1 -- H, b and the chi^2 statistics are added pair after pair in the reference's order (lsm2d_device.h: pair_terms / seq_walk) instead of
+// in trees; instantiations of their own (k_align_seq), so the default kernels do not carry the records' code
+template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0, bool kFirstStage = false, bool kSeq = false>
 LSM2D_DEV void align_body(const AlignArgs& A) {
   __builtin_assume(A.n_slices >= 1 && A.n_slices <= kMaxSlices);      // (the host refuses anything else: the slice loops need no guard -- which, as a flag, was kept in a vector register and spilled)
   constexpr bool kNNGlobal = kNNMode == 1, kNNLds = kNNMode == 2;
@@ -1459,6 +1464,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
   __shared__ int s_nunits[kMaxSlices], s_rebuild[kMaxSlices];      // kProjCulled: entries in a slice's unit list; the list must be rebuilt before it is streamed again
   __shared__ Iso s_list_iso[kMaxSlices];                             // ... and the transform it was built at
   uint16_t* l_units = reinterpret_cast<uint16_t*>(smem + A.units_off);      // [n_slices][kCullBlocks * kAlignBlock]
+  float* l_rec = reinterpret_cast<float*>(smem + (kSeq ? A.seq_off : 0));   // kSeq: [kAlignBlock][kSeqFields], the current trip's pair records
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   // (the alignment's index is wave-uniform: said so, or everything indexed by it would live in vector registers)
@@ -1675,6 +1681,20 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
       const Iso T = s_iso[s];
       const uint32_t salt = (uint32_t) s * 0x632BE5ABu;
       Accum acc; accum_zero(acc);
+      float seq_acc = 0.0f;      // kSeq: lane q < 11 of wave 0 holds the slice's running sum of quantity q (in Accum's order); the counts stay in acc
+      // kSeq: a matched pair becomes a record instead of being added into the thread's partial sums
+      auto seq_pair = [&](float2 pf, float2 nf, float2 pm, float2 nm, float (&t)[kSeqFields]) {
+        bool inl; pair_terms(T, pf, nf, pm, nm, S.cauchy != 0, S.tau, inl_only, t, inl);
+        ++acc.n_corr; acc.n_in += inl ? 1 : 0; acc.n_out += inl ? 0 : 1;
+      };
+      // kSeq: the end of a trip -- every thread's record (zeros: no pair) is in LDS behind the first barrier, wave 0 adds the trip's n_rec records in ascending
+      // slot, and nobody overwrites them before the second
+      auto seq_trip = [&](int slot, bool writer, const float (&t)[kSeqFields], int n_rec) {
+        if (writer) seq_store(l_rec, slot, t);
+        __syncthreads();
+        if (tid < 64) seq_acc = seq_walk(l_rec, n_rec, tid, seq_acc);
+        __syncthreads();
+      };
       LSM2D_PH(2);
       if (kHasProj && ((!kHasNN && !kHasDist && !kHasKd) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
         {
@@ -1787,6 +1807,32 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
 #ifndef LSM2D_BINWALK_BATCHED
 #define LSM2D_BINWALK_BATCHED 1
 #endif
+        if constexpr (kSeq) {
+          // "sum_order" 1: trips of kAlignBlock consecutive columns (every thread takes part in every trip: the barriers), slot = column - first column of the trip
+          for (int col0 = 0; col0 < S.proj.cols; col0 += kAlignBlock) {
+            const int col = col0 + tid;
+            float t[kSeqFields]; seq_zero(t);
+            if (col < S.proj.cols) {
+              const u64 fk = fcs[col], mk = mcan[col];
+              mcan[col] = kEmptyCell;
+              const float fd = __uint_as_float((uint32_t) (fk >> 32)), md = __uint_as_float((uint32_t) (mk >> 32));
+              if (mk != kEmptyCell && fk != kEmptyCell && !(__builtin_fabsf(fd - md) > S.point_distance)) {
+                const int mi = (int) (uint32_t) mk, fi = (int) (uint32_t) fk;
+                float2 nm, pm; float4 f;
+                if (maos) { const float4 m4 = maos[mi]; pm = make_float2(m4.x, m4.y); nm = make_float2(m4.z, m4.w); } else { nm = mn[mi]; pm = mp[mi]; }
+                if (faos) f = faos[fi]; else { const float2 p2 = fpp[fi], n2 = fnr[fi]; f = make_float4(p2.x, p2.y, n2.x, n2.y); }
+                float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+                if (!(__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos)) {
+                  if (want_dig) digest_add(&s_dig, salt, fi, mi);
+                  seq_pair(make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, t);
+                }
+              }
+            }
+            const int left = S.proj.cols - col0;
+            seq_trip(tid, true, t, left < kAlignBlock ? left : kAlignBlock);
+          }
+        }
+        else
         if (LSM2D_BINWALK_BATCHED && kProjCulled && maos && faos) {
           // Round 5: the walk as a two-deep pipeline -- the NEXT column's cells are read and gated (LDS) and its winners' two 16-byte rows asked for BEFORE this
           // column's factor terms are formed; the terms are added in the same column order as before (the sums keep their bits).  A trip used to end in two
@@ -1910,14 +1956,17 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
           const int sub = tid & (group - 1);
           constexpr int per_step = kAlignBlock / group;
           for (int j0 = 0; j0 < nm_pts; j0 += per_step) {
+            bool skip = false;                       // kSeq: a culled tile's wave still takes part in the trip (its records are zeros, the barriers are everybody's)
+            float t[kSeqFields];                     // kSeq: this thread's record of the trip
+            if constexpr (kSeq) seq_zero(t);
             if (group == 1 && pq_cull) {             // this wave's 64 queries of the trip are one tile
               const int tile = (j0 >> 6) + __builtin_amdgcn_readfirstlane(tid >> 6);
               const u64 w = l_keep[tile >> 6];
               const unsigned half = (tile & 32) ? (unsigned) (w >> 32) : (unsigned) w;
-              if (!((__builtin_amdgcn_readfirstlane((int) half) >> (tile & 31)) & 1)) continue;
+              if (!((__builtin_amdgcn_readfirstlane((int) half) >> (tile & 31)) & 1)) { if constexpr (kSeq) skip = true; else continue; }
             }
             const int j = j0 + tid / group;
-            const bool live = j < nm_pts;                    // whole groups are live or not: the shuffles inside stay uniform
+            const bool live = j < nm_pts && !skip;           // whole groups are live or not: the shuffles inside stay uniform
             const float2 pm = live ? mp[j] : make_float2(0.0f, 0.0f);
             float qx, qy; xf_point(T, pm.x, pm.y, qx, qy);
             int best = -1;
@@ -1933,6 +1982,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
                   const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
                   if (!(dot < S.normal_cos)) {
                     if (want_dig) digest_add(&s_dig, salt, S.fixed.kd.leaf_idx[fbase + pos], j);      // the original index: only the digest asks for it
+                    if constexpr (kSeq) seq_pair(bxy, nf, pm, nm, t); else
                     accumulate_pair(T, bxy, nf, pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
                   }
                 }
@@ -1946,6 +1996,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
                 const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
                 if (!(dot < S.normal_cos)) {
                   if (want_dig) digest_add(&s_dig, salt, sidx[pos], j);
+                  if constexpr (kSeq) seq_pair(pf, nf, pm, nm, t); else
                   accumulate_pair(T, pf, nf, pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
                 }
               }
@@ -1963,8 +2014,13 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
               const float dot = __builtin_fmaf(nqx, nf.x, nqy * nf.y);
               if (!(dot < S.normal_cos)) {
                 if (want_dig) digest_add(&s_dig, salt, best, j);
+                if constexpr (kSeq) seq_pair(fp[best], nf, pm, nm, t); else
                 accumulate_pair(T, fp[best], nf, pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
               }
+            }
+            if constexpr (kSeq) {      // "sum_order" 1: the trip's queries are per_step consecutive moving indices, slot = query - first query of the trip
+              const int left = nm_pts - j0;
+              seq_trip(tid / group, sub == 0, t, left < per_step ? left : per_step);
             }
           }
         };
@@ -1986,6 +2042,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
       if (tid < 64) {
         // lanes 0..13 of wave 0 each add one quantity over the waves (wave order) and then into the iteration's sum themselves
         float v; int vi; block_reduce_gather_lane(red, nwaves, tid, v, vi);
+        if constexpr (kSeq) v = seq_acc;      // (the partial sums' floats were never touched: the eleven quantities are the walker's)
         const int n_corr = __builtin_amdgcn_readlane(vi, 13);
         if (tid == 0) s_n_corr += n_corr;
         if (n_corr > S.min_corr) {     // slices with #pairs <= min_num_correspondences are skipped
@@ -2099,6 +2156,12 @@ constexpr int align_min_waves() {
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
 __global__ __launch_bounds__(kAlignBlock, (align_min_waves<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode>())) void k_align(const AlignArgs A) {
   align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false>(A);
+}
+// "sum_order" 1: the same kernel with the reference's order of summation (align_body<.., kSeq = true>).  18 KB of pair records per workgroup beside the canvases:
+// three workgroups per CU at most, so the register budget is that of 6 waves per SIMD (80 VGPRs) -- 4 for the mixed instantiations, as above
+template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
+__global__ __launch_bounds__(kAlignBlock, ((kHasProj && (kHasNN || kHasDist || kHasKd)) ? LSM2D_MIXED_MIN_WAVES : 6)) void k_align_seq(const AlignArgs A) {
+  align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false, true>(A);
 }
 // Round 4 (late): TWO launches for a culled batch of about one dispatch round.  The placement of such a batch decides its tail (the launch lasts as long as
 // the CU with the largest sum of work), and what an alignment will stream is known badly at its START pose -- the estimate of k_cull_estimate left a tail of
@@ -2772,9 +2835,12 @@ __global__ __launch_bounds__(512) void k_split_project(const SplitArgs S) {
   for (int i = tid; i < P.cols; i += 512) { const u64 k = can[i]; if (k != kEmptyCell) atomicMin(&g[i], k); }
 }
 
+// kSeq: "sum_order" 1 -- the sums pair after pair in ascending column (lsm2d_device.h: pair_terms / seq_walk), as k_align_seq forms them
+template <bool kSeq>
 __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S) {
   const AlignArgs& A = S.A;
   __shared__ float red[(kAlignBlock / 64) * kAccumWords];
+  __shared__ float s_rec[kSeq ? kAlignBlock * kSeqFields : 1];
   __shared__ Iso s_iso[kMaxSlices];
   // as in k_align: the iteration's sums are added in LDS by the lanes that gathered them, the matrix is assembled, given its prior and
   // solved where it lies (no private arrays, no scratch on the serial stretch)
@@ -2805,6 +2871,28 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
     const float2* fn = SL.fixed.nrm + fbase; const float2* mn = SL.moving.nrm + mbase;
     const float2* fp = SL.fixed.xy + fbase;  const float2* mp = SL.moving.xy + mbase;
     Accum acc; accum_zero(acc);
+    float seq_acc = 0.0f;
+    if constexpr (kSeq) {
+      for (int col0 = 0; col0 < SL.proj.cols; col0 += kAlignBlock) {      // trips of kAlignBlock consecutive columns, every thread in every trip (barriers)
+        const int col = col0 + tid;
+        float t[kSeqFields]; seq_zero(t);
+        if (col < SL.proj.cols) {
+          const u64 mk = gM[SL.fcan_offset + col];
+          gM[SL.fcan_offset + col] = kEmptyCell;
+          int fi, mi; float2 nf, nm;
+          if (match_bin(gF[SL.fcan_offset + col], mk, SL, T, fn, mn, fi, mi, nf, nm)) {
+            if (want_dig) digest_add(&s_dig, (uint32_t) s * 0x632BE5ABu, fi, mi);
+            bool inl; pair_terms(T, fp[fi], nf, mp[mi], nm, SL.cauchy != 0, SL.tau, inl_only, t, inl);
+            ++acc.n_corr; acc.n_in += inl ? 1 : 0; acc.n_out += inl ? 0 : 1;
+          }
+        }
+        seq_store(s_rec, tid, t);
+        __syncthreads();
+        const int left = SL.proj.cols - col0;
+        if (tid < 64) seq_acc = seq_walk(s_rec, left < kAlignBlock ? left : kAlignBlock, tid, seq_acc);
+        __syncthreads();
+      }
+    } else
     for (int col = tid; col < SL.proj.cols; col += kAlignBlock) {
       const u64 mk = gM[SL.fcan_offset + col];
       gM[SL.fcan_offset + col] = kEmptyCell;                  // ready for the next iteration's projection
@@ -2818,6 +2906,7 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
     __syncthreads();
     if (tid < 64) {
       float v; int vi; block_reduce_gather_lane(red, nwaves, tid, v, vi);
+      if constexpr (kSeq) v = seq_acc;
       const int n_corr = __builtin_amdgcn_readlane(vi, 13);
       if (tid == 0) s_n_corr += n_corr;
       if (n_corr > SL.min_corr) {
@@ -3106,6 +3195,45 @@ __global__ __launch_bounds__(256) void k_linearize_partial(const LinArgs A) {
     float* p = A.partial + (size_t) blockIdx.x * kAccumWords;
     p[0] = t.h00; p[1] = t.h01; p[2] = t.h02; p[3] = t.h11; p[4] = t.h12; p[5] = t.h22; p[6] = t.b0; p[7] = t.b1; p[8] = t.b2;
     p[9] = t.chi_in; p[10] = t.chi_out; p[11] = __int_as_float(t.n_in); p[12] = __int_as_float(t.n_out); p[13] = __int_as_float(t.n_corr);
+  }
+}
+
+// "sum_order" 1: the same factor with the sums formed pair after pair in the order of the correspondence vector (the reference's loop): ONE workgroup,
+// trips of kAlignBlock consecutive pairs, their terms as records in LDS, eleven lanes of wave 0 adding them in ascending position (lsm2d_device.h)
+__global__ __launch_bounds__(kAlignBlock) void k_linearize_seq(const LinArgs A) {
+  __shared__ float s_rec[kAlignBlock * kSeqFields];
+  __shared__ float red[(kAlignBlock / 64) * kAccumWords];
+  __shared__ u64 s_dig;
+  const int tid = threadIdx.x;
+  const int fbase = A.fixed.start[A.fc], mbase = A.moving.start[A.mc];
+  Accum acc; accum_zero(acc);
+  float seq_acc = 0.0f;
+  if (tid == 0) s_dig = 0ull;
+  __syncthreads();
+  u64 dg = 0ull;
+  for (int k0 = 0; k0 < A.n_pairs; k0 += kAlignBlock) {
+    const int k = k0 + tid;
+    float t[kSeqFields]; seq_zero(t);
+    if (k < A.n_pairs) {
+      const int fi = A.pairs[2 * k], mi = A.pairs[2 * k + 1];
+      dg += pair_hash_dev(0u, (uint32_t) fi, (uint32_t) mi);
+      bool inl; pair_terms(A.T, A.fixed.xy[fbase + fi], A.fixed.nrm[fbase + fi], A.moving.xy[mbase + mi], A.moving.nrm[mbase + mi], A.cauchy != 0, A.tau, false, t, inl);
+      ++acc.n_corr; acc.n_in += inl ? 1 : 0; acc.n_out += inl ? 0 : 1;
+    }
+    seq_store(s_rec, tid, t);
+    __syncthreads();
+    const int left = A.n_pairs - k0;
+    if (tid < 64) seq_acc = seq_walk(s_rec, left < kAlignBlock ? left : kAlignBlock, tid, seq_acc);
+    __syncthreads();
+  }
+  if (dg) atomicAdd(reinterpret_cast<unsigned long long*>(&s_dig), (unsigned long long) dg);
+  block_reduce_store(acc, red, tid);
+  __syncthreads();
+  if (tid < 64) {
+    float v; int vi; block_reduce_gather_lane(red, kAlignBlock / 64, tid, v, vi);
+    if (tid < 11) A.out[tid] = seq_acc;
+    else if (tid < kAccumWords) A.out[tid] = __int_as_float(vi);
+    if (tid == 0 && A.dig) *A.dig = (unsigned long long) s_dig;
   }
 }
 

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     bound = {s[0] for s in _capi.SYMBOLS}
     assert set(declared) == bound
     l = _capi.load()
-    assert l.lsm2d_version() == 150
+    assert l.lsm2d_version() == 160
     assert l.lsm2d_status_string(0) == b"Success" and l.lsm2d_status_string(-4) == b"CapacityExceeded"
 
 
