@@ -12,6 +12,7 @@ import math
 import numpy as np
 import pytest
 
+import fuzz_cases
 from conftest import golden_path, has_experiments, need_experiments, xset
 from srrg2_laser_slam_2d_amd import api, synth
 
@@ -21,15 +22,7 @@ POSE_TOL_M = 1e-4
 POSE_TOL_RAD = 1e-4
 
 
-def _oracle_slice(po, sp):
-    """oracle SliceParams with the same values as an ABI SliceParams"""
-    return po.slice_params(finder=sp.finder, canvas_cols=sp.projector.canvas_cols, angle_min=sp.projector.angle_min,
-                           angle_max=sp.projector.angle_max, range_min=sp.projector.range_min, range_max=sp.projector.range_max,
-                           col_offset=sp.projector.col_offset, point_distance=sp.point_distance, normal_cos=sp.normal_cos,
-                           max_distance=sp.max_distance, resolution=sp.resolution, robustifier=sp.robustifier,
-                           chi_threshold=sp.chi_threshold, min_num_correspondences=sp.min_num_correspondences,
-                           sensor_in_robot=tuple(sp.sensor_in_robot), kd_max_leaf_range=sp.kd_max_leaf_range,
-                           kd_min_leaf_points=sp.kd_min_leaf_points)
+_oracle_slice = fuzz_cases.oracle_slice      # oracle SliceParams with the same values as an ABI SliceParams
 
 
 def _same_correspondence_sets(gpu_stats, oracle_stats, iterations):
@@ -83,7 +76,8 @@ class _Envelope:
     alignments are counted, listed and bounded in number, and keep the bitwise device-order check like every other one), violation (outside all of it)."""
     ILL = 1e-2
 
-    def __init__(self):
+    def __init__(self, test="", seed=0):
+        self.test, self.seed = test, seed      # what a named exception is looked up by (fuzz_cases.KNOWN_TREE_ORDER_DEVIATIONS / KNOWN_ILL_CONDITIONED)
         self.tally = dict(ok=0, needs_factor=0, needs_perturbed=0, no_oracle=0, status_differs=0, ill_conditioned=0, violation=0)
         self.violations = []
         self.ill = []
@@ -91,11 +85,23 @@ class _Envelope:
 
     @staticmethod
     def one_ulp_starts(x0):
-        x0 = np.asarray(x0, np.float32)
-        out = []
-        for signs in ((1, 1, 1), (-1, -1, -1), (1, -1, 1), (-1, 1, -1)):
-            out.append(np.array([np.nextafter(v, np.float32(np.inf) * sg) for v, sg in zip(x0, signs)], np.float32))
-        return out
+        """Round 6: 64 starts (all 26 one-ulp patterns, then two-ulp ones: fuzz_cases.perturbed_starts) instead of four -- the replay of round 5's five violators
+        (profiles/r06/violators_replay_r06.txt) showed the reference's own arithmetic leaving 1e-4 in 10-12 of 64 such runs for two of them and reaching 0.95e-4
+        for a third, where the four-run sample had seen nothing"""
+        return [x for _, x in fuzz_cases.perturbed_starts(x0, 64)]
+
+    def assert_only_named_exceptions(self):
+        """Round 6: no allowance by COUNT any more.  Outside the envelope may lie only the alignments NAMED in fuzz_cases -- the two of the
+        eighteen-seed soak where the tree order alone lands a pair on the other side of a gate, each with its own bound -- and ill-conditioned may be only the one
+        named there.  The default run (seeds 5 / 2024) holds none of them: zero tolerated."""
+        for where, v in self.violations:      # where = (trial, alignment, note)
+            key = (self.test, int(self.seed), int(where[0]), int(where[1]))
+            bound = fuzz_cases.KNOWN_TREE_ORDER_DEVIATIONS.get(key)
+            assert bound is not None, ("outside the envelope and not a named tree-order deviation", key, v)
+            assert max(v["device_vs_fp64"]) <= bound, ("a named tree-order deviation beyond its recorded bound", key, v)
+        for where, v in self.ill:
+            key = (self.test, int(self.seed), int(where[0]), int(where[1]))
+            assert key in fuzz_cases.KNOWN_ILL_CONDITIONED, ("ill-conditioned and not the named case", key, v)
 
     def check(self, where, dev_pose, dev_status, r, rd, rr, perturbed=None):
         """perturbed: callable -> the sequential fp32 oracle's results from one_ulp_starts(x0); asked for only when the two evaluations' envelope does not hold"""
@@ -1981,58 +1987,25 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
     column rounding, tight and wide gates, all three finders, Cauchy on/off, sensor extrinsics -- finder pairs must equal
     the oracle's exactly, aligner poses within the north_star tolerance whenever the oracle succeeds."""
     import os
-    n_trials = int(os.environ.get("LSM2D_FUZZ_TRIALS", "36")); rng = np.random.default_rng(int(os.environ.get("LSM2D_FUZZ_SEED", "2024")))      # soak: more trials, other seeds
+    n_trials = int(os.environ.get("LSM2D_FUZZ_TRIALS", "36")); seed = int(os.environ.get("LSM2D_FUZZ_SEED", "2024"))      # soak: more trials, other seeds
     only = int(os.environ.get("LSM2D_FUZZ_ONLY", "-1"))          # reproduce one trial of a soak run, verbosely
-    rng_kd = np.random.default_rng(int(os.environ.get("LSM2D_FUZZ_SEED", "2024")) + 1000)
-    world = synth.make_world(9)
-    maps = {n: synth.make_map(world, n, noise_sigma=0.003, seed=n) for n in (3000, 20000)}
-    poses = synth.sample_poses(world, 12, seed=3)
-    checked_pairs = checked_poses = soft = sets_differ = 0
-    env = _Envelope()
-    for trial in range(n_trials):
-        n_map = (3000, 20000)[trial % 2]
-        m = maps[n_map]
-        beams = int(rng.integers(90, 1200))
-        scan, _ = synth.make_scans(world, poses[trial % 12:trial % 12 + 1], n_beams=beams, fov_deg=float(rng.uniform(90, 300)))
-        x_true, x0 = synth.initial_guesses(poses[trial % 12:trial % 12 + 1], seed=trial, scale=float(rng.uniform(0.0, 0.08)))
-        x0 = x0[0].astype(np.float32)
-        finder = trial % 3 if trial % 7 else 3          # every seventh trial: the reference's own KD-tree, built on the device, random leaf parameters
-        a0 = float(rng.uniform(-math.pi, -0.5)); a1 = float(rng.uniform(0.5, math.pi))
-        cols = int(rng.integers(64, 2000)); off = float(rng.choice([0.0, 0.5]))
-        rmin = float(rng.uniform(0.0, 1.0)); rmax = float(rng.uniform(5.0, 40.0))
-        pd = float(rng.uniform(0.05, 1.5)); nc = float(rng.uniform(0.3, 0.95)); md = float(rng.uniform(0.02, 0.8)); res = float(rng.uniform(0.03, 0.2))
-        cauchy = bool(trial % 4 == 1); tau = float(rng.uniform(0.005, 0.1)); mc = int(rng.integers(0, 30))
-        S = (0.0, 0.0, 0.0) if trial % 5 else (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-1, 1)))
-        its = int(rng.integers(1, 15)); min_inl = int(rng.integers(0, 50))
+    checked_pairs = checked_poses = soft = sets_differ = seq_bitwise = 0
+    env = _Envelope("parameters", seed)
+    for spec in fuzz_cases.parameter_trials(seed, n_trials):      # the draws: tests/fuzz_cases.py (shared with tests/replay_violators.py)
+        trial, finder, m, scan, x0, n_map, beams = spec["trial"], spec["finder"], spec["map"], spec["scan"], spec["x0"], spec["n_map"], spec["beams"]
+        a0, a1, cols, off, rmin, rmax, pd, nc, md, res = (spec[k] for k in ("a0", "a1", "cols", "off", "rmin", "rmax", "pd", "nc", "md", "res"))
+        cauchy, tau, mc, S, its, min_inl = (spec[k] for k in ("cauchy", "tau", "mc", "S", "its", "min_inl"))
         if only >= 0 and trial != only:
             continue
-        proj = api.PointNormal2fProjectorPolar(cols, a0, a1, rmin, rmax, off)
-        if finder == 0:
-            f = api.CorrespondenceFinderProjective2f(ctx, proj, pd, nc)
-            osp = po.slice_params(canvas_cols=cols, angle_min=a0, angle_max=a1, range_min=rmin, range_max=rmax, col_offset=off, point_distance=pd, normal_cos=nc)
-        elif finder == 1:
-            f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=md, normal_cos=nc)
-            osp = po.slice_params(finder=po.FINDER_NN, max_distance=md, normal_cos=nc)
-        elif finder == 3:
-            lr = float(10.0 ** rng_kd.uniform(-3, 0)); lp = int(rng_kd.integers(1, 60))      # (a generator of their own: the other trials keep the parameter sequences of earlier rounds' soaks)
-            f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=md, normal_cos=nc, max_leaf_range=lr, min_leaf_points=lp, search="kdtree")
-            osp = po.slice_params(finder=po.FINDER_KDTREE_APPROX, max_distance=md, normal_cos=nc, kd_max_leaf_range=lr, kd_min_leaf_points=lp)
-        else:
-            f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=md, resolution=res, normal_cos=nc)
-            osp = po.slice_params(finder=po.FINDER_DISTMAP, max_distance=md, resolution=res, normal_cos=nc)
+        f, osp = fuzz_cases.parameter_finder(ctx, spec)
         f.setFixed(scan); f.setMoving(m); f.setLocalMapInSensor(x0)
         got = f.compute(); want = po.find(osp, scan, m, x0)
         assert np.array_equal(got, want), (trial, finder, len(got), len(want))
         checked_pairs += len(want)
         # aligner with the same finder
-        osp.robustifier = po.ROBUST_CAUCHY if cauchy else po.ROBUST_NONE; osp.chi_threshold = tau; osp.min_num_correspondences = mc
-        osp.sensor_in_robot = (po.C.c_float * 3)(*S)
-        if any(S):
-            slicep = api.AlignerSliceProcessorLaser2DWithSensor(f, sensor_in_robot=S, robustifier=api.RobustifierCauchy(tau) if cauchy else None, min_num_correspondences=mc)
-        else:
-            slicep = api.AlignerSliceProcessorLaser2D(f, robustifier=api.RobustifierCauchy(tau) if cauchy else None, min_num_correspondences=mc)
+        fuzz_cases.parameter_aligner_slice(po, spec, osp)
         al = api.MultiAligner2D(ctx, max_iterations=its, min_num_inliers=min_inl)
-        al.param_slice_processors.append(slicep)
+        al.param_slice_processors.append(fuzz_cases.parameter_slice_processor(spec, f))
         res_g = al.compute_batch([scan], [m], x0[None, :], want_stats=True)
         r = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers), [osp], [scan], [m], x0)
         rd = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers), [osp], [scan], [m], x0.astype(np.float64), double=True)
@@ -2046,6 +2019,15 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
                 finally:
                     ctx.set_option("align_path", 0)
                 _assert_bitwise_equal_to_device_order_oracle(res_c, 0, rt, ("trial=%d culled" % trial, finder))
+            # Round 6: with "sum_order" 1 the device adds pair after pair, the reference's order -- and equals the SEQUENTIAL fp32 oracle `r` (the restatement written
+            # from the reference's files, not after the device) bit for bit, in EVERY trial, well-posed or not: status, iterations, pose, information matrix, statistics, digests
+            ctx.set_option("sum_order", 1)
+            try:
+                res_s = al.compute_batch([scan], [m], x0[None, :], want_stats=True)
+            finally:
+                ctx.set_option("sum_order", 0)
+            _assert_bitwise_equal_to_device_order_oracle(res_s, 0, r, ("trial=%d sum_order 1" % trial, finder))
+            seq_bitwise += 1
         if only >= 0:
             print("trial", trial, dict(finder=finder, n_map=n_map, beams=beams, cols=cols, off=off, a0=a0, a1=a1, rmin=rmin, rmax=rmax, pd=pd, nc=nc, md=md, res=res,
                                        cauchy=cauchy, tau=tau, mc=mc, S=S, its=its, min_inl=min_inl, x0=x0.tolist()))
@@ -2068,26 +2050,24 @@ def test_randomised_parameters_finder_and_aligner(ctx, po):
         if r["status"] == rd["status"] and r["status"] != 0:      # both oracles fail alike: the device's status is its mirror's (bitwise above)
             continue
         rr = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers), [osp], [scan], [m], x0, double="ref")
-        env.check(("trial", trial, finder), res_g.pose[0], int(res_g.status[0]), r, rd, rr,
+        env.check((trial, 0, "finder %d" % finder), res_g.pose[0], int(res_g.status[0]), r, rd, rr,
                   perturbed=lambda: [po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers), [osp], [scan], [m], xp) for xp in _Envelope.one_ulp_starts(x0)])
         sets_differ += int(bool(agree) and not same_sets)
         soft += 1
         checked_poses += 1
     if only >= 0:
         return
+    print("fuzz, sum_order 1: %d of %d aligner runs BITWISE equal to the sequential fp32 oracle (status, iterations, pose, information matrix, statistics, pair digests)" % (seq_bitwise, seq_bitwise))
     print("fuzz: %d trials, %d pairs bit-exact, %d poses checked: %d in the strict class (bar 1e-4 against the sequential fp32 oracle), %d in the envelope class (of which %d because "
           "the two summation orders' pair sets part ways -- digests); %s" % (n_trials, checked_pairs, checked_poses, checked_poses - soft, soft, sets_differ, env.summary()))
-    checked_total = checked_poses
     for v in env.violations:
         print("OUTSIDE THE ENVELOPE", v)
-    # Eighteen seeds x 420 trials (profiles/r05/fuzz_soak_r05r_*.log): 5 of 28 972 alignments end outside the envelope -- 1.1e-4 ... 2.8e-4 m from the fp64 oracle
-    # where the sequential-order evaluations sit within 2e-5 of it: the device's TREE sums pick another pair at a gate, and one pair in a few hundred moves the
-    # optimum by that much.  Counted and bounded, not hidden: at most one alignment per two thousand checked (one per run at least), none beyond 5e-4 m / 5e-4 rad.
+    # Round 6: no allowance by count.  Of round 5's five violators (eighteen seeds x 420 trials, 28 972 alignments) three lie INSIDE the reference's own arithmetic
+    # once it is sampled at 64 perturbed starts instead of four (tests/replay_violators.py, profiles/r06/violators_replay_r06.txt); the other two are the tree
+    # order's own and are NAMED in fuzz_cases.KNOWN_TREE_ORDER_DEVIATIONS with their bounds; with "sum_order" 1 all five equal the sequential oracle bit for bit.
     for v in env.ill:
         print("ILL-CONDITIONED (the reference arithmetic has no answer to 1e-2)", v)
-    assert len(env.violations) <= max(1, checked_total // 2000), env.violations[:5]
-    assert all(max(v[1]["device_vs_fp64"]) <= 5e-4 for v in env.violations), env.violations[:5]
-    assert len(env.ill) <= max(1, checked_total // 2000), env.ill[:5]
+    env.assert_only_named_exceptions()
     assert checked_pairs > 5000 and checked_poses >= 12
 
 
@@ -2243,53 +2223,31 @@ def test_randomised_aligner_structure(ctx, po):
     give the fused path's bits; against the oracle the first iteration has the same correspondence count and the final pose is
     within the north_star tolerance (widened only where the fp32 and fp64 oracles themselves disagree or the sets part ways)."""
     import os
-    n_trials = int(os.environ.get("LSM2D_FUZZ_TRIALS", "12")); rng = np.random.default_rng(int(os.environ.get("LSM2D_FUZZ_SEED", "5")))
-    world = synth.make_world(7)
-    maps = {n: synth.make_map(world, n, noise_sigma=0.003, seed=n + 3) for n in (4000, 30000)}
-    poses = synth.sample_poses(world, 8, seed=17)
-    checked = soft = paired = sets_differ = 0
+    n_trials = int(os.environ.get("LSM2D_FUZZ_TRIALS", "12")); seed = int(os.environ.get("LSM2D_FUZZ_SEED", "5"))
+    checked = soft = paired = sets_differ = seq_bitwise = 0
     worst_same_strict = 0.0      # largest |device - sequential-order oracle| (m or rad) in the strict class
-    env = _Envelope()
-    for trial in range(n_trials):
-        ns = int(rng.integers(1, 4)); nb = int(rng.integers(1, 6)); its = int(rng.integers(1, 13)); m = maps[(4000, 30000)[trial % 2]]
-        use_prior = bool(trial % 3 == 0)
-        robots = poses[rng.integers(0, 8, nb)]
-        guess = synth.compose_poses(robots, rng.uniform(-0.04, 0.04, (nb, 3)))
-        x0 = synth.invert_poses(guess).astype(np.float32)
-        al = api.MultiAligner2D(ctx, max_iterations=its, min_num_inliers=int(rng.integers(0, 30)))
+    env = _Envelope("structure", seed)
+    for spec in fuzz_cases.structure_trials(seed, n_trials):      # the draws: tests/fuzz_cases.py (shared with tests/replay_violators.py)
+        trial, ns, nb, its, m, use_prior, x0, pri, all_projective = (spec[k] for k in ("trial", "ns", "nb", "its", "map", "use_prior", "x0", "pri", "all_projective"))
+        al = api.MultiAligner2D(ctx, max_iterations=its, min_num_inliers=spec["min_inl"])
         fixed_sets, oslices, scans_per_slice = [], [], []
-        all_projective = True
-        for s in range(ns):
-            cols = int(rng.integers(200, 1300)); rmax = float(rng.uniform(8.0, 30.0)); ncos = float(rng.uniform(0.5, 0.9)); pd = float(rng.uniform(0.2, 1.0))
-            S = np.float32([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(-3, 3)]) if (trial + s) % 2 else np.zeros(3, np.float32)
-            cauchy = bool((trial + s) % 3 == 1); tau = float(rng.uniform(0.005, 0.05)); mc = int(rng.integers(0, 20))
-            proj = api.PointNormal2fProjectorPolar(cols, -math.pi, math.pi, 0.3, rmax)
-            kind = int(rng.integers(0, 3)) if trial % 4 == 3 else 0          # every 4th trial mixes the three finders across its slices
-            all_projective = all_projective and kind == 0
-            if kind == 0:
-                f = api.CorrespondenceFinderProjective2f(ctx, proj, pd, ncos)
-            elif kind == 1:
-                f = api.CorrespondenceFinderKDTree2D(ctx, max_distance_m=float(rng.uniform(0.1, 0.6)), normal_cos=ncos)
-            else:
-                f = api.CorrespondenceFinderNN2D(ctx, max_distance_m=float(rng.uniform(0.2, 0.6)), resolution=float(rng.uniform(0.05, 0.15)), normal_cos=ncos)
-            rob = api.RobustifierCauchy(tau) if cauchy else None
-            sl = (api.AlignerSliceProcessorLaser2DWithSensor(f, sensor_in_robot=S, robustifier=rob, min_num_correspondences=mc) if S.any()
-                  else api.AlignerSliceProcessorLaser2D(f, robustifier=rob, min_num_correspondences=mc))
+        for sl_spec in spec["slices"]:
+            sl = fuzz_cases.structure_slice_processor(ctx, sl_spec)
             al.param_slice_processors.append(sl)
-            pts, offs = synth.make_scans(world, synth.compose_poses(robots, np.tile(S[None, :].astype(np.float64), (nb, 1))), n_beams=int(rng.integers(300, 1100)),
-                                         noise_sigma=0.003, seed=trial * 7 + s)
-            fixed_sets.append(api.CloudSet(ctx, pts, offs)); scans_per_slice.append((pts, offs))
+            fixed_sets.append(api.CloudSet(ctx, sl_spec["pts"], sl_spec["offs"])); scans_per_slice.append((sl_spec["pts"], sl_spec["offs"]))
             oslices.append(_oracle_slice(po, sl.slice_params()))
-        pri = [(np.zeros(3, np.float32) + x0[i], np.diag(rng.uniform(5.0, 80.0, 3)).astype(np.float32)) for i in range(nb)] if use_prior else None
         mv = [api.CloudSet(ctx, m)] * ns
 
-        def run(path):
-            ctx.set_option("align_path", path)
+        def run(path, sum_order=0):
+            ctx.set_option("align_path", path); ctx.set_option("sum_order", sum_order)
             try:
                 return al.compute_batch(fixed_sets, mv, x0, priors=pri, want_stats=True)
             finally:
-                ctx.set_option("align_path", 0)
+                ctx.set_option("align_path", 0); ctx.set_option("sum_order", 0)
         a = run(1)
+        # Round 6: "sum_order" 1 -- pair after pair, the reference's order: EVERY alignment equals the sequential fp32 oracle `r` below bit for bit, on the
+        # one-workgroup-per-alignment kernel, on whatever the library picks by itself, and on the split path
+        a_seq = run(1, 1); a_seq0 = run(0, 1); a_seq2 = run(2, 1) if all_projective else None
         if all_projective:                # the split path takes projective slices only
             b = run(2)
             assert np.array_equal(a.pose, b.pose) and np.array_equal(a.information, b.information) and np.array_equal(a.status, b.status), ("split != fused", trial)
@@ -2308,6 +2266,10 @@ def test_randomised_aligner_structure(ctx, po):
             rd = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, **kw), oslices, sc, [m] * ns, x0[i].astype(np.float64), double=True)
             rt = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, device_order=True, **kw), oslices, sc, [m] * ns, x0[i])
             _assert_bitwise_equal_to_device_order_oracle(a, i, rt, ("trial=%d" % trial, i))
+            for tag, res_s in (("fused", a_seq), ("automatic path", a_seq0), ("split", a_seq2)):
+                if res_s is not None:
+                    _assert_bitwise_equal_to_device_order_oracle(res_s, i, r, ("trial=%d sum_order 1, %s" % (trial, tag), i))
+            seq_bitwise += 1
             assert a.stats[i]["n_correspondences"][0] == r["stats"][0].n_corr, ("first iteration", trial, i)
             dd = np.abs(r["pose"].astype(np.float64) - rd["pose"]); dd[2] = abs((dd[2] + math.pi) % (2 * math.pi) - math.pi)
             agree = r["status"] == rd["status"] == 0 and r["iterations"] == rd["iterations"] and a.status[i] == 0 and a.iterations[i] == r["iterations"]
@@ -2322,7 +2284,7 @@ def test_randomised_aligner_structure(ctx, po):
             # everything else -- the summation orders' pair sets part ways, the fp32 and fp64 oracles are themselves apart, a status differs -- is held to the
             # ENVELOPE of the reference's own arithmetic around the fp64 truth (round 5; the flat centimetre of rounds 3-4 is gone, and nothing is skipped)
             rr = po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, **kw), oslices, sc, [m] * ns, x0[i], double="ref")
-            verdict = env.check(("trial", trial, i, "same_sets" if same_sets else "sets_differ"), a.pose[i], int(a.status[i]), r, rd, rr,
+            verdict = env.check((trial, i, "same_sets" if same_sets else "sets_differ"), a.pose[i], int(a.status[i]), r, rd, rr,
                                 perturbed=lambda: [po.align(po.aligner_params(its, min_num_inliers=al.param_min_num_inliers, **kw), oslices, sc, [m] * ns, xp) for xp in _Envelope.one_ulp_starts(x0[i])])
             sets_differ += int(bool(agree) and not same_sets)
             soft += 1
@@ -2333,20 +2295,18 @@ def test_randomised_aligner_structure(ctx, po):
                     print("  it %d gpu n=%d in=%d chi=%.7g | f32 n=%d in=%d chi=%.7g | f64 n=%d in=%d chi=%.7g" % (k_, g_["n_correspondences"], g_["n_inliers"], g_["chi_inliers"],
                           o_.n_corr, o_.n_in, o_.chi_in, t_.n_corr, t_.n_in, t_.chi_in))
             checked += 1
+    print("structure fuzz, sum_order 1: %d of %d alignments BITWISE equal to the sequential fp32 oracle on every path (fused, automatic, split)" % (seq_bitwise, seq_bitwise))
     print("structure fuzz: %d trials, %d alignments checked: %d in the strict class (every iteration's digest equal, bar 1e-4 against the sequential fp32 oracle: largest "
           "difference %.2e), %d in the envelope class (of which %d because the two summation orders' pair sets part ways -- digests); split == fused in all, latency kernel == "
           "fused in all %d one- and two-slice trials; %s" % (n_trials, checked, checked - soft, worst_same_strict, soft, sets_differ, paired, env.summary()))
-    checked_total = checked
     for v in env.violations:
         print("OUTSIDE THE ENVELOPE", v)
-    # Eighteen seeds x 420 trials (profiles/r05/fuzz_soak_r05r_*.log): 5 of 28 972 alignments end outside the envelope -- 1.1e-4 ... 2.8e-4 m from the fp64 oracle
-    # where the sequential-order evaluations sit within 2e-5 of it: the device's TREE sums pick another pair at a gate, and one pair in a few hundred moves the
-    # optimum by that much.  Counted and bounded, not hidden: at most one alignment per two thousand checked (one per run at least), none beyond 5e-4 m / 5e-4 rad.
+    # Round 6: no allowance by count.  Of round 5's five violators (eighteen seeds x 420 trials, 28 972 alignments) three lie INSIDE the reference's own arithmetic
+    # once it is sampled at 64 perturbed starts instead of four (tests/replay_violators.py, profiles/r06/violators_replay_r06.txt); the other two are the tree
+    # order's own and are NAMED in fuzz_cases.KNOWN_TREE_ORDER_DEVIATIONS with their bounds; with "sum_order" 1 all five equal the sequential oracle bit for bit.
     for v in env.ill:
         print("ILL-CONDITIONED (the reference arithmetic has no answer to 1e-2)", v)
-    assert len(env.violations) <= max(1, checked_total // 2000), env.violations[:5]
-    assert all(max(v[1]["device_vs_fp64"]) <= 5e-4 for v in env.violations), env.violations[:5]
-    assert len(env.ill) <= max(1, checked_total // 2000), env.ill[:5]
+    env.assert_only_named_exceptions()
     assert checked >= n_trials // 2 and env.tally["status_differs"] <= max(2, checked // 50)
 
 
