@@ -49,8 +49,8 @@ namespace srrg2_laser_slam_2d {
       _fixed_changed_flag = false;
     }
     // moving: behind a CONTENT check (round 5).  The base class has no dirty flag for it as far as the reference's tree shows, and pointer + size say nothing
-    // about contents -- the tracker's clipped scene is one object, cleared and refilled every step, often to the same size -- so the packed floats are hashed
-    // while they are packed: an unchanged cloud (the reference's own aligner loop: twenty compute() calls on one local map) is not copied again, a changed one is.
+    // about contents -- the tracker's clipped scene is one object, cleared and refilled every step, often to the same size -- so the packed floats are compared,
+    // byte for byte, with the ones uploaded last (round 6; a 64-bit hash before): an unchanged cloud (the reference's own aligner loop: twenty compute() calls on one local map) is not copied again, a changed one is.
     _moving_dev.uploadIfChanged(_ctx, *_moving, className());
 
     float pose[3];

@@ -78,10 +78,11 @@ namespace lsm2d_srrg {
     }
     // PointNormal2f -> (x, y, nx, ny).  The preprocessor never emits invalid points
     // (sensor_processing/raw_data_preprocessor_projective_2d.cpp:42-47), so indices are the host cloud's.
-    // uploadIfChanged: the same, unless the device already holds exactly these values -- same object, same size, same 64-bit hash of the packed floats (formed
-    // while they are packed: one pass over the cloud either way).  The reference's own finders re-PROJECT the moving cloud every compute() but never re-copy it
+    // uploadIfChanged: the same, unless the device already holds exactly these values -- same object, same size, and the packed floats compare EQUAL BYTE FOR BYTE
+    // with what was uploaded last (a host-side copy of it is kept; round 5 trusted a 64-bit hash alone: a collision would have matched against a stale cloud, where
+    // the reference re-projects the cloud it is handed every call).  The reference's own finders re-PROJECT the moving cloud every compute() but never re-copy it
     // (registration/correspondence_finder_projective_2d.cpp:37-48); under its aligner loop -- twenty compute() calls on an unchanged local map -- this sibling
-    // now uploads once too (round 4: 1.6 MB over the host link per iteration at 100k points).  A cloud changed IN PLACE has another hash and is uploaded.
+    // uploads once too (1.6 MB over the host link per iteration at 100k points otherwise).  A cloud changed IN PLACE differs and is uploaded.
     // Returns true when an upload was queued.
     bool uploadIfChanged(lsm2d_context* ctx_, const PointNormal2fVectorCloud& cloud_, const char* who_) {
       return uploadImpl(ctx_, cloud_, who_, true);
@@ -95,16 +96,11 @@ namespace lsm2d_srrg {
       const size_t n = cloud_.size();
       _staging.resize(4 * n);
       size_t k       = 0;
-      uint64_t hash  = 0x9E3779B97F4A7C15ull ^ (uint64_t) n;
       for (const auto& p : cloud_) {
-        const float v[4] = {p.coordinates().x(), p.coordinates().y(), p.normal().x(), p.normal().y()};
-        uint64_t w[2];
-        memcpy(w, v, sizeof w);
-        hash = (hash ^ w[0]) * 0xFF51AFD7ED558CCDull; hash ^= hash >> 32;
-        hash = (hash ^ w[1]) * 0xC4CEB9FE1A85EC53ull; hash ^= hash >> 29;
-        _staging[k++] = v[0]; _staging[k++] = v[1]; _staging[k++] = v[2]; _staging[k++] = v[3];
+        _staging[k++] = p.coordinates().x(); _staging[k++] = p.coordinates().y(); _staging[k++] = p.normal().x(); _staging[k++] = p.normal().y();
       }
-      if (skip_if_same_ && _set && _ctx == ctx_ && _host == &cloud_ && _n == n && _hash == hash) {
+      if (skip_if_same_ && _set && _ctx == ctx_ && _host == &cloud_ && _n == n && _uploaded.size() == _staging.size() &&
+          (n == 0 || memcmp(_uploaded.data(), _staging.data(), sizeof(float) * 4 * n) == 0)) {
         return false;
       }
       if (!_set || _ctx != ctx_ || n > _capacity) {
@@ -114,7 +110,8 @@ namespace lsm2d_srrg {
         throwOnError(lsm2d_cloudset_create_reserved(ctx_, (int64_t) _capacity, &_set), std::string(who_) + " reserve", ctx_);
       }
       throwOnError(lsm2d_cloudset_upload(_set, _staging.data(), (int64_t) n), std::string(who_) + " upload", ctx_);
-      _host = &cloud_; _ctx = ctx_; _n = n; _hash = hash;
+      _host = &cloud_; _ctx = ctx_; _n = n;
+      _uploaded.swap(_staging);      // (lsm2d_cloudset_upload copied the values into the set's pinned buffer: the vector is ours again)
       return true;
     }
 
@@ -132,8 +129,7 @@ namespace lsm2d_srrg {
     const PointNormal2fVectorCloud* _host = nullptr;
     const lsm2d_context* _ctx             = nullptr;
     size_t _n                             = 0;
-    uint64_t _hash                        = 0;
-    std::vector<float> _staging;
+    std::vector<float> _staging, _uploaded;      // this call's packed values; what the device holds
   };
 
   inline void fillProjector(const PointNormal2fProjectorPolar& projector_, lsm2d_projector* out_) {

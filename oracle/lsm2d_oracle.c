@@ -4,6 +4,7 @@
  * polynomial atan2 and the pthread batch driver used as bench.py's cpu_baseline ("port").
  * Build: make -C oracle   (gcc -O3 -ffp-contract=off, no fast-math)
  */
+#define _POSIX_C_SOURCE 200809L      /* clock_gettime under -std=c11 */
 #include "lsm2d_oracle.h"
 
 #include <float.h>
@@ -319,45 +320,65 @@ int lsmo_clip_scene_voxelized_f(const lsmo_projector* pr, const lsmo_point* scen
   return n;
 }
 
-/* ---- batch driver (cpu_baseline): static block partition over pthreads ---------------------- */
+/* ---- batch driver (cpu_baseline): pthreads over ONE atomic work counter ------------------------------------------------------------
+ * Every thread takes the next alignment that nobody has taken yet (round 6; a static block partition before: with a CPU quota below the thread count -- the GPU
+ * boxes of this pool give a 256-thread affinity mask and a 16-CPU cgroup quota -- the block of a thread that is descheduled waits for it while others idle).
+ * thread_seconds / thread_jobs (may be NULL, [n_threads]): wall time each worker spent and the alignments it did -- what shows a throttled host. */
+#include <stdatomic.h>
+#include <time.h>
 typedef struct {
   const lsmo_aligner_params* ap; const lsmo_slice_params* sp;
   const lsmo_point* fixed_packed; const int* offs; const lsmo_point* moving; int n_moving;
   const float* x0; float* x_out; float* H_out; int* status; lsmo_iter_stats* last;
-  int begin, end;
+  atomic_int* next; int n; double seconds; int jobs;
 } batch_job;
+
+static double now_seconds(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec; }
 
 static void* batch_worker(void* arg) {
   batch_job* j = (batch_job*) arg;
+  const double t0 = now_seconds();
   lsmo_iter_stats* st = (lsmo_iter_stats*) malloc(sizeof(lsmo_iter_stats) * (size_t) (j->ap->max_iterations > 0 ? j->ap->max_iterations : 1) * 2);
-  for (int i = j->begin; i < j->end; ++i) {
+  for (;;) {
+    const int i = atomic_fetch_add_explicit(j->next, 1, memory_order_relaxed);
+    if (i >= j->n) break;
     const lsmo_point* f = j->fixed_packed + j->offs[i];
     const int nf = j->offs[i + 1] - j->offs[i];
     int its = 0;
     j->status[i] = lsmo_align_f(j->ap, 1, j->sp, &f, &nf, &j->moving, &j->n_moving, j->x0 + 3 * i,
                                 j->x_out + 3 * i, j->H_out + 9 * i, st, &its);
     if (j->last) { if (its > 0) j->last[i] = st[its - 1]; else memset(&j->last[i], 0, sizeof(lsmo_iter_stats)); }
+    ++j->jobs;
   }
   free(st);
+  j->seconds = now_seconds() - t0;
   return NULL;
+}
+
+int lsmo_align_batch_timed_f(const lsmo_aligner_params* ap, const lsmo_slice_params* sp,
+                             const lsmo_point* fixed_packed, const int* fixed_offsets, int n_alignments,
+                             const lsmo_point* moving, int n_moving, const float* x0, float* x_out,
+                             float* H_out, int* status_out, lsmo_iter_stats* last_stats, int n_threads, double* thread_seconds, int* thread_jobs) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > n_alignments) n_threads = n_alignments > 0 ? n_alignments : 1;
+  pthread_t* th = (pthread_t*) malloc(sizeof(pthread_t) * (size_t) n_threads);
+  batch_job* jobs = (batch_job*) malloc(sizeof(batch_job) * (size_t) n_threads);
+  atomic_int next; atomic_init(&next, 0);
+  for (int t = 0; t < n_threads; ++t) {
+    batch_job j = {ap, sp, fixed_packed, fixed_offsets, moving, n_moving, x0, x_out, H_out, status_out, last_stats, &next, n_alignments, 0.0, 0};
+    jobs[t] = j;
+    if (n_threads == 1) batch_worker(&jobs[t]);
+    else pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
+  }
+  if (n_threads > 1) for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+  for (int t = 0; t < n_threads; ++t) { if (thread_seconds) thread_seconds[t] = jobs[t].seconds; if (thread_jobs) thread_jobs[t] = jobs[t].jobs; }
+  free(th); free(jobs);
+  return LSMO_SUCCESS;
 }
 
 int lsmo_align_batch_f(const lsmo_aligner_params* ap, const lsmo_slice_params* sp,
                        const lsmo_point* fixed_packed, const int* fixed_offsets, int n_alignments,
                        const lsmo_point* moving, int n_moving, const float* x0, float* x_out,
                        float* H_out, int* status_out, lsmo_iter_stats* last_stats, int n_threads) {
-  if (n_threads < 1) n_threads = 1;
-  if (n_threads > n_alignments) n_threads = n_alignments > 0 ? n_alignments : 1;
-  pthread_t* th = (pthread_t*) malloc(sizeof(pthread_t) * (size_t) n_threads);
-  batch_job* jobs = (batch_job*) malloc(sizeof(batch_job) * (size_t) n_threads);
-  for (int t = 0; t < n_threads; ++t) {
-    batch_job j = {ap, sp, fixed_packed, fixed_offsets, moving, n_moving, x0, x_out, H_out, status_out, last_stats,
-                   (int) ((long long) n_alignments * t / n_threads), (int) ((long long) n_alignments * (t + 1) / n_threads)};
-    jobs[t] = j;
-    if (n_threads == 1) batch_worker(&jobs[t]);
-    else pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
-  }
-  if (n_threads > 1) for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
-  free(th); free(jobs);
-  return LSMO_SUCCESS;
+  return lsmo_align_batch_timed_f(ap, sp, fixed_packed, fixed_offsets, n_alignments, moving, n_moving, x0, x_out, H_out, status_out, last_stats, n_threads, NULL, NULL);
 }

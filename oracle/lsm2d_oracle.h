@@ -241,6 +241,11 @@ int lsmo_align_batch_f(const lsmo_aligner_params* ap, const lsmo_slice_params* s
                        const lsmo_point* moving, int n_moving,
                        const float* x0 /* [n][3] */, float* x_out /* [n][3] */, float* H_out /* [n][9] */,
                        int* status_out, lsmo_iter_stats* last_stats /* [n] or NULL */, int n_threads);
+/* ... the same with every worker's wall time and number of alignments handed back ([n_threads] each, may be NULL): the workers share one atomic work counter */
+int lsmo_align_batch_timed_f(const lsmo_aligner_params* ap, const lsmo_slice_params* sp,
+                             const lsmo_point* fixed_packed, const int* fixed_offsets, int n_alignments,
+                             const lsmo_point* moving, int n_moving, const float* x0, float* x_out, float* H_out,
+                             int* status_out, lsmo_iter_stats* last_stats, int n_threads, double* thread_seconds, int* thread_jobs);
 
 /* ---- `_r`: the same routines in the reference's own arithmetic (see the header comment) ------------------------------ */
 int lsmo_project_r(const lsmo_projector* pr, const lsmo_point* cloud, int n, const float pose[3],

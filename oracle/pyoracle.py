@@ -278,16 +278,21 @@ def align(ap: AlignerParams, slices, fixed, moving, x0, double=False, want_pairs
                 pairs=[bufs[s_][: npairs[s_]].copy() for s_ in range(n)])
 
 
-def align_batch(ap: AlignerParams, sp: SliceParams, fixed_packed, fixed_offsets, moving, x0, n_threads=1):
-    """fp32 batch over a shared moving cloud (cpu_baseline 'port').  Returns (pose [n,3], H [n,3,3], status [n], last stats)."""
+def align_batch(ap: AlignerParams, sp: SliceParams, fixed_packed, fixed_offsets, moving, x0, n_threads=1, thread_times=None):
+    """fp32 batch over a shared moving cloud (cpu_baseline 'port').  Returns (pose [n,3], H [n,3,3], status [n], last stats).
+    thread_times: a dict that receives every worker's wall seconds and alignment count (the workers share one atomic work counter)."""
     fixed_packed, pf = _pts(fixed_packed); moving, pm = _pts(moving)
     offs = np.ascontiguousarray(fixed_offsets, np.int32); n = len(offs) - 1
     x0 = np.ascontiguousarray(x0, np.float32).reshape(n, 3)
     xo = np.empty((n, 3), np.float32); H = np.empty((n, 9), np.float32); status = np.empty(n, np.int32)
     last = (IterStats * max(n, 1))()
-    lib().lsmo_align_batch_f(C.byref(ap), C.byref(sp), pf, offs.ctypes.data_as(C.c_void_p), n, pm, len(moving),
-                             x0.ctypes.data_as(C.c_void_p), xo.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
-                             status.ctypes.data_as(C.c_void_p), last, int(n_threads))
+    nt = max(1, min(int(n_threads), max(n, 1)))
+    secs = np.zeros(nt, np.float64); jobs = np.zeros(nt, np.int32)
+    lib().lsmo_align_batch_timed_f(C.byref(ap), C.byref(sp), pf, offs.ctypes.data_as(C.c_void_p), n, pm, len(moving),
+                                   x0.ctypes.data_as(C.c_void_p), xo.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
+                                   status.ctypes.data_as(C.c_void_p), last, int(n_threads), secs.ctypes.data_as(C.c_void_p), jobs.ctypes.data_as(C.c_void_p))
+    if thread_times is not None:
+        thread_times.update(seconds=secs, alignments=jobs)
     return xo, H.reshape(n, 3, 3), status, [last[i] for i in range(n)]
 
 

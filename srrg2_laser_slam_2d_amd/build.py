@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblsm2d_hip.so")
 # The same sources with -DLSM2D_EXPERIMENTS: the measured-and-rejected alternatives of DESIGN App. A (second launch form, row-major culled stream, the A/B
-# option keys) compiled in.  NOT the product: only tests/test_gpu_experiments.py and tuning scripts load it, by LSM2D_EXPERIMENTS=1 in the environment.
+# option keys) compiled in.  NOT the product: the GPU suite run with LSM2D_EXPERIMENTS=1 in the environment (its variant tests are skipped otherwise) and tuning scripts load it.
 LIB_PATH_EXPERIMENTS = os.path.join(LIB_DIR, "liblsm2d_hip_experiments.so")
 SOURCES = [os.path.join(CSRC, "lsm2d_capi.hip")]
 HEADERS = [os.path.join(CSRC, "lsm2d_device.h"), os.path.join(CSRC, "lsm2d_kernels.h"),

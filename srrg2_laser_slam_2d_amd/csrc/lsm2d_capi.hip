@@ -496,7 +496,7 @@ const OptionDesc kOptions[] = {
   {"last_xcd_lockstep",  &lsm2d_context::last_xcd_lockstep,  0, 0, kOptReadOnly},
   {"experiments",        &lsm2d_context::experiments,        0, 0, kOptReadOnly},
 #ifdef LSM2D_EXPERIMENTS
-  // ---- A/B knobs of the experiments build (tests/test_gpu_experiments.py; each one's measurement: DESIGN App. A)
+  // ---- A/B knobs of the experiments build (the GPU suite with LSM2D_EXPERIMENTS=1; each one's measurement: DESIGN App. A)
   {"cull_est_um",        &lsm2d_context::cull_est_um,        0, 1000000, kOptExperiment},
   {"cull_est_urad",      &lsm2d_context::cull_est_urad,      0, 1000000, kOptExperiment},
   {"results_to_host",    &lsm2d_context::results_to_host,    0, 1,       kOptExperiment},

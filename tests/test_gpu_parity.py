@@ -123,12 +123,13 @@ class _Envelope:
             more = [o for o in perturbed() if o["status"] == 0]
             if more:
                 pm = max(_pose_diff(o["pose"], rd["pose"])[0] for o in more); pr_ = max(_pose_diff(o["pose"], rd["pose"])[1] for o in more)
-            if dm <= max(POSE_TOL_M, 3.0 * em, 3.0 * pm) and dr <= max(POSE_TOL_RAD, 3.0 * er, 3.0 * pr_):
-                self.tally["needs_perturbed"] += 1; self.worst["needs_perturbed"] = max(self.worst["needs_perturbed"], dm, dr); return "needs_perturbed"
+        # (ill-conditioned is decided BEFORE the perturbed runs are allowed to widen the envelope: with 64 of them, three times a spread of metres would cover anything)
         if max(em, pm) > self.ILL or max(er, pr_) > self.ILL:
             self.tally["ill_conditioned"] += 1
             self.ill.append((where, dict(device_vs_fp64=(dm, dr), oracles_vs_fp64=(em, er), one_ulp_runs_vs_fp64=(pm, pr_))))
             return "ill_conditioned"
+        if perturbed is not None and dm <= max(POSE_TOL_M, 3.0 * em, 3.0 * pm) and dr <= max(POSE_TOL_RAD, 3.0 * er, 3.0 * pr_):
+            self.tally["needs_perturbed"] += 1; self.worst["needs_perturbed"] = max(self.worst["needs_perturbed"], dm, dr); return "needs_perturbed"
         self.tally["violation"] += 1
         self.violations.append((where, dict(device_vs_fp64=(dm, dr), oracles_vs_fp64=(em, er), one_ulp_runs_vs_fp64=(pm, pr_), device=np.asarray(dev_pose).tolist(), fp64=np.asarray(rd["pose"]).tolist())))
         return "violation"
