@@ -2327,7 +2327,7 @@ static int align_batch_impl(lsm2d_context* ctx, const lsm2d_aligner_params* ap, 
   }
   // "sum_order" 1: the trip's pair records (lsm2d_device.h), behind everything else -- three workgroups per CU instead of four
   A.seq_off = 0;
-  if (ctx->sum_order) { lds = (lds + 15) & ~(size_t) 15; A.seq_off = (int32_t) lds; lds += sizeof(float) * kSeqFields * kAlignBlock; }
+  if (ctx->sum_order) { lds = (lds + 15) & ~(size_t) 15; A.seq_off = (int32_t) lds; lds += kSeqLdsBytes; }
   // the XCD window (AlignArgs::xcd_sync): a big-map batch of ONE dispatch round -- every workgroup resident from the start (64 VGPRs, <= 40 KB of LDS: four per
   // CU) -- whose position space fits the counters
   A.xcd_sync = nullptr; A.xcd_window = 0; A.xcd_stride = 0; A.xcd_positions = 0;

@@ -581,11 +581,19 @@ LSM2D_DEV float pair_chi(const Iso& T, float2 pf, float2 nf, float2 pm, float2 n
 // in ascending moving index for the point-query finders, correspondence_finder_kd_tree_2d.cpp:12-27).  The default kernels add in trees (a thread's
 // pairs, then 64 lanes, then 8 waves): the same terms, another association.  With the option on, every thread that holds a pair writes the pair's
 // TERMS -- accumulate_pair's operations up to the sums, in its order -- as a record of kSeqFields floats into LDS, slot = the pair's position in the
-// reference's order within the current trip of the workgroup (a trip: 512 consecutive columns / moving indices); after the trip's barrier eleven lanes
-// of wave 0 walk the records in ascending slot, lane q adding quantity q with exactly the fused operations the sequential CPU restatement of the factor
+// reference's order within the current trip of the workgroup (a trip: 512 consecutive columns / moving indices, handed over in two halves); after the barrier
+// eleven lanes of wave 0 walk the records in ascending slot, lane q adding quantity q with exactly the fused operations the sequential CPU restatement of the factor
 // uses (the tests hold the two against each other bit for bit): h = fma(w a_i, a_j, h), two of them chained for h22 and b2, chi sums by plain adds.  A slot without a pair holds zeros:
 // fma(+0, +0, h) == h and h + 0 == h bit for bit (no sum here is ever -0: they start at +0).  The counts are integers and keep their ballots.
-static constexpr int kSeqFields = 9;      // a0 a1 a2 e0 w dd de chi_in chi_out
+// Record = 14 floats, 56 bytes: a0 a1 a2 e0 | wa0 wa1 wa2 w | dd de chi_in chi_out | 1 0 (wa_i = w * a_i, rounded by the thread that holds the pair: the
+// reference's `wa` temporaries; the two constants travel with every record).  The records of HALF a trip (kSeqHalf = 256) sit in LDS; lane q of the walking wave
+// reads, per record, the four operands of ITS two fused adds straight from LDS -- acc = fma(x1, y1, acc); acc = fma(x2, y2, acc) -- at four per-lane FIELD
+// offsets and one stride for all: an operand that is a constant for this lane (1 for the chi sums' y1; 0, 0 for the second add of the nine quantities that have
+// none) reads the record's constant fields.  So a record costs the walk four LDS reads with immediate offsets (the compiler pairs them: ds_read2_b32) and two
+// dependent FMAs, nothing else.  (Round 6, measured in isolation -- tools/seq_walk_probe.py: a first form that selected and multiplied in the loop and waited for
+// each record's loads 135 cycles per record; per-lane strides for the constants -- sixteen address adds per four records -- 65; this one: see DESIGN section 5.)
+static constexpr int kSeqFields = 14, kSeqHalf = 256;
+static constexpr int kSeqLdsBytes = kSeqHalf * kSeqFields * 4;
 template <bool kInlineLog = false>
 LSM2D_DEV void pair_terms(const Iso& T, float2 pf, float2 nf, float2 pm, float2 nm, bool cauchy, float tau, bool inl_only,
                           float (&t)[kSeqFields], bool& inlier) {
@@ -609,38 +617,61 @@ LSM2D_DEV void pair_terms(const Iso& T, float2 pf, float2 nf, float2 pm, float2 
     if (!inlier) kern = tau * (kInlineLog ? log_fixed_inline(1.0f + q) : log_fixed(1.0f + q));
     if (inl_only) w = inlier ? 1.0f : 0.0f;
   }
-  t[0] = a0; t[1] = a1; t[2] = a2; t[3] = e0; t[4] = w;
-  t[5] = __builtin_fmaf(d0, d0, d1 * d1);
-  t[6] = __builtin_fmaf(d0, e1, d1 * e2);
-  t[7] = inlier ? chi : 0.0f;
-  t[8] = inlier ? 0.0f : kern;
+  t[0] = a0; t[1] = a1; t[2] = a2; t[3] = e0;
+  t[4] = w * a0; t[5] = w * a1; t[6] = w * a2; t[7] = w;
+  t[8] = __builtin_fmaf(d0, d0, d1 * d1);
+  t[9] = __builtin_fmaf(d0, e1, d1 * e2);
+  t[10] = inlier ? chi : 0.0f;
+  t[11] = inlier ? 0.0f : kern;
 }
+// "no pair in this slot": zeros and the constants
 LSM2D_DEV void seq_zero(float (&t)[kSeqFields]) {
 #pragma unroll
-  for (int f = 0; f < kSeqFields; ++f) t[f] = 0.0f;
+  for (int f = 0; f < 12; ++f) t[f] = 0.0f;
+  t[12] = 1.0f; t[13] = 0.0f;
 }
-// (stride kSeqFields = 9 words: odd, so 64 lanes writing field f of 64 consecutive slots hit 64 different banks)
+// `rec`: the region's start; record `slot` (0 .. kSeqHalf - 1) as seven 8-byte stores
 LSM2D_DEV void seq_store(float* rec, int slot, const float (&t)[kSeqFields]) {
+  float2* r = reinterpret_cast<float2*>(rec + slot * kSeqFields);
 #pragma unroll
-  for (int f = 0; f < kSeqFields; ++f) rec[slot * kSeqFields + f] = t[f];
+  for (int f = 0; f < kSeqFields / 2; ++f) r[f] = make_float2(t[2 * f], t[2 * f + 1]);
 }
-// Every lane of ONE wave calls (lanes 11..63 walk along and hold nothing of value): `acc` is lane q's running sum of quantity q in the order
-// h00 h01 h02 h11 h12 h22 b0 b1 b2 chi_in chi_out (Accum's).  Records 0 .. n-1 in ascending slot.  All lanes read the same record, 36 bytes: LDS broadcasts.
+// Every lane of ONE wave calls (lanes 11..63 walk along like lane 0 and hold nothing of value): `acc` is lane q's running sum of quantity q in the order
+// h00 h01 h02 h11 h12 h22 b0 b1 b2 chi_in chi_out (Accum's).  Records 0 .. n-1 of the half-trip in ascending slot.
+#ifndef LSM2D_SEQ_UNROLL
+#define LSM2D_SEQ_UNROLL 2      // records per group; two groups in flight (2 / 3 / 4 / 6: 1.119 / 1.143 / 1.115 / 1.199 ms on configs[1]; 4 and up spill at 64 registers)
+#endif
 LSM2D_DEV float seq_walk(const float* rec, int n, int lane, float acc) {
+  asm volatile("" : "+v"(lane));      // (the lane's field offsets are made HERE, every time: as loop invariants of the iteration loop they are registers held -- and spilled -- across the whole kernel)
   const int q = lane < 11 ? lane : 0;
-  const int i1 = (int) ((0x87210211000ull >> (4 * q)) & 15), j1 = (int) ((0x00333221210ull >> (4 * q)) & 15);      // field of x1's factor, field of y1
   const bool chi = q >= 9, has2 = q == 5 || q == 8;
-  const int j2 = q == 5 ? 5 : 6;                                                                                 // dd for h22, de for b2
-#pragma unroll 4
-  for (int k = 0; k < n; ++k) {
-    const float* r = rec + k * kSeqFields;
-    const float w = r[4], f1 = r[i1], g1 = r[j1], g2 = r[j2];
-    const float x1 = (chi ? 1.0f : w) * f1;            // w * a_i, the reference's wa_i (1 * chi: exact)
-    const float y1 = chi ? 1.0f : g1;                  // fma(chi, 1, s) == s + chi
-    acc = __builtin_fmaf(x1, y1, acc);
-    const float x2 = has2 ? w : 0.0f, y2 = has2 ? g2 : 0.0f;
-    acc = __builtin_fmaf(x2, y2, acc);                 // h22 += w dd, b2 += w de; elsewhere fma(0, 0, s) == s
+  const int fx1 = (int) ((0xBA654655444ull >> (4 * q)) & 15), fy1 = chi ? 12 : (int) ((0x00333221210ull >> (4 * q)) & 15);      // field of x1 (wa_i, or the chi term) and of y1 (a_j, e0, or the constant 1)
+  const int fx2 = has2 ? 7 : 13, fy2 = has2 ? (q == 5 ? 8 : 9) : 13;                                                             // w and dd / de; elsewhere the constant 0 twice
+  const float* px1 = rec + fx1; const float* py1 = rec + fy1; const float* px2 = rec + fx2; const float* py2 = rec + fy2;
+  // two groups of kU records in flight: the NEXT group's loads are issued before this group's dependent adds run
+  constexpr int kU = LSM2D_SEQ_UNROLL;
+  float ax1[kU], ay1[kU], ax2[kU], ay2[kU], bx1[kU], by1[kU], bx2[kU], by2[kU];
+  auto load = [&](int k0, float (&x1)[kU], float (&y1)[kU], float (&x2)[kU], float (&y2)[kU]) {
+#pragma unroll
+    for (int j = 0; j < kU; ++j) { x1[j] = px1[(k0 + j) * kSeqFields]; y1[j] = py1[(k0 + j) * kSeqFields]; x2[j] = px2[(k0 + j) * kSeqFields]; y2[j] = py2[(k0 + j) * kSeqFields]; }
+  };
+  auto add = [&](const float (&x1)[kU], const float (&y1)[kU], const float (&x2)[kU], const float (&y2)[kU]) {
+#pragma unroll
+    for (int j = 0; j < kU; ++j) { acc = __builtin_fmaf(x1[j], y1[j], acc); acc = __builtin_fmaf(x2[j], y2[j], acc); }
+  };
+  int k = 0;
+  if (n >= kU) {
+    load(0, ax1, ay1, ax2, ay2);
+    for (; k + 3 * kU <= n; k += 2 * kU) {      // A holds group k; B <- k + kU; add A; A <- k + 2 kU; add B
+      load(k + kU, bx1, by1, bx2, by2);
+      add(ax1, ay1, ax2, ay2);
+      load(k + 2 * kU, ax1, ay1, ax2, ay2);
+      add(bx1, by1, bx2, by2);
+    }
+    if (k + 2 * kU <= n) { load(k + kU, bx1, by1, bx2, by2); add(ax1, ay1, ax2, ay2); add(bx1, by1, bx2, by2); k += 2 * kU; }
+    else { add(ax1, ay1, ax2, ay2); k += kU; }
   }
+  for (; k < n; ++k) { acc = __builtin_fmaf(px1[k * kSeqFields], py1[k * kSeqFields], acc); acc = __builtin_fmaf(px2[k * kSeqFields], py2[k * kSeqFields], acc); }
   return acc;
 }
 

@@ -1464,7 +1464,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
   __shared__ int s_nunits[kMaxSlices], s_rebuild[kMaxSlices];      // kProjCulled: entries in a slice's unit list; the list must be rebuilt before it is streamed again
   __shared__ Iso s_list_iso[kMaxSlices];                             // ... and the transform it was built at
   uint16_t* l_units = reinterpret_cast<uint16_t*>(smem + A.units_off);      // [n_slices][kCullBlocks * kAlignBlock]
-  float* l_rec = reinterpret_cast<float*>(smem + (kSeq ? A.seq_off : 0));   // kSeq: [kAlignBlock][kSeqFields], the current trip's pair records
+  float* l_rec = reinterpret_cast<float*>(smem + (kSeq ? A.seq_off : 0));   // kSeq: [kSeqHalf][kSeqFields]: half a trip's pair records
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   // (the alignment's index is wave-uniform: said so, or everything indexed by it would live in vector registers)
@@ -1689,11 +1689,15 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
       };
       // kSeq: the end of a trip -- every thread's record (zeros: no pair) is in LDS behind the first barrier, wave 0 adds the trip's n_rec records in ascending
       // slot, and nobody overwrites them before the second
+      // (in halves of kSeqHalf records: 12 KB of LDS instead of 24, three workgroups per CU)
       auto seq_trip = [&](int slot, bool writer, const float (&t)[kSeqFields], int n_rec) {
-        if (writer) seq_store(l_rec, slot, t);
-        __syncthreads();
-        if (tid < 64) seq_acc = seq_walk(l_rec, n_rec, tid, seq_acc);
-        __syncthreads();
+        for (int h0 = 0; h0 < n_rec; h0 += kSeqHalf) {
+          if (writer && slot >= h0 && slot < h0 + kSeqHalf) seq_store(l_rec, slot - h0, t);
+          __syncthreads();
+          const int left = n_rec - h0;
+          if (tid < 64) seq_acc = seq_walk(l_rec, left < kSeqHalf ? left : kSeqHalf, tid, seq_acc);
+          __syncthreads();
+        }
       };
       LSM2D_PH(2);
       if (kHasProj && ((!kHasNN && !kHasDist && !kHasKd) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
@@ -2157,10 +2161,13 @@ template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kN
 __global__ __launch_bounds__(kAlignBlock, (align_min_waves<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode>())) void k_align(const AlignArgs A) {
   align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false>(A);
 }
-// "sum_order" 1: the same kernel with the reference's order of summation (align_body<.., kSeq = true>).  18 KB of pair records per workgroup beside the canvases:
-// three workgroups per CU at most, so the register budget is that of 6 waves per SIMD (80 VGPRs) -- 4 for the mixed instantiations, as above
+// "sum_order" 1: the same kernel with the reference's order of summation (align_body<.., kSeq = true>).  14 KB of pair records per workgroup beside the canvases (four workgroups per CU still fit the headline's shape):
+// the register budget stays that of 8 waves per SIMD -- 4 for the mixed instantiations, as above
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
-__global__ __launch_bounds__(kAlignBlock, ((kHasProj && (kHasNN || kHasDist || kHasKd)) ? LSM2D_MIXED_MIN_WAVES : 6)) void k_align_seq(const AlignArgs A) {
+#ifndef LSM2D_SEQ_MIN_WAVES
+#define LSM2D_SEQ_MIN_WAVES 8
+#endif
+__global__ __launch_bounds__(kAlignBlock, ((kHasProj && (kHasNN || kHasDist || kHasKd)) ? LSM2D_MIXED_MIN_WAVES : LSM2D_SEQ_MIN_WAVES)) void k_align_seq(const AlignArgs A) {
   align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false, true>(A);
 }
 // Round 4 (late): TWO launches for a culled batch of about one dispatch round.  The placement of such a batch decides its tail (the launch lasts as long as
@@ -2840,7 +2847,7 @@ template <bool kSeq>
 __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S) {
   const AlignArgs& A = S.A;
   __shared__ float red[(kAlignBlock / 64) * kAccumWords];
-  __shared__ float s_rec[kSeq ? kAlignBlock * kSeqFields : 1];
+  __shared__ __attribute__((aligned(16))) float s_rec[kSeq ? kSeqHalf * kSeqFields : 4];
   __shared__ Iso s_iso[kMaxSlices];
   // as in k_align: the iteration's sums are added in LDS by the lanes that gathered them, the matrix is assembled, given its prior and
   // solved where it lies (no private arrays, no scratch on the serial stretch)
@@ -2886,11 +2893,14 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
             ++acc.n_corr; acc.n_in += inl ? 1 : 0; acc.n_out += inl ? 0 : 1;
           }
         }
-        seq_store(s_rec, tid, t);
-        __syncthreads();
-        const int left = SL.proj.cols - col0;
-        if (tid < 64) seq_acc = seq_walk(s_rec, left < kAlignBlock ? left : kAlignBlock, tid, seq_acc);
-        __syncthreads();
+        const int n_rec = SL.proj.cols - col0 < kAlignBlock ? SL.proj.cols - col0 : kAlignBlock;
+        for (int h0 = 0; h0 < n_rec; h0 += kSeqHalf) {      // the trip's records in two halves
+          if (tid >= h0 && tid < h0 + kSeqHalf) seq_store(s_rec, tid - h0, t);
+          __syncthreads();
+          const int left = n_rec - h0;
+          if (tid < 64) seq_acc = seq_walk(s_rec, left < kSeqHalf ? left : kSeqHalf, tid, seq_acc);
+          __syncthreads();
+        }
       }
     } else
     for (int col = tid; col < SL.proj.cols; col += kAlignBlock) {
@@ -3201,7 +3211,7 @@ __global__ __launch_bounds__(256) void k_linearize_partial(const LinArgs A) {
 // "sum_order" 1: the same factor with the sums formed pair after pair in the order of the correspondence vector (the reference's loop): ONE workgroup,
 // trips of kAlignBlock consecutive pairs, their terms as records in LDS, eleven lanes of wave 0 adding them in ascending position (lsm2d_device.h)
 __global__ __launch_bounds__(kAlignBlock) void k_linearize_seq(const LinArgs A) {
-  __shared__ float s_rec[kAlignBlock * kSeqFields];
+  __shared__ __attribute__((aligned(16))) float s_rec[kSeqHalf * kSeqFields];
   __shared__ float red[(kAlignBlock / 64) * kAccumWords];
   __shared__ u64 s_dig;
   const int tid = threadIdx.x;
@@ -3220,11 +3230,14 @@ __global__ __launch_bounds__(kAlignBlock) void k_linearize_seq(const LinArgs A) 
       bool inl; pair_terms(A.T, A.fixed.xy[fbase + fi], A.fixed.nrm[fbase + fi], A.moving.xy[mbase + mi], A.moving.nrm[mbase + mi], A.cauchy != 0, A.tau, false, t, inl);
       ++acc.n_corr; acc.n_in += inl ? 1 : 0; acc.n_out += inl ? 0 : 1;
     }
-    seq_store(s_rec, tid, t);
-    __syncthreads();
-    const int left = A.n_pairs - k0;
-    if (tid < 64) seq_acc = seq_walk(s_rec, left < kAlignBlock ? left : kAlignBlock, tid, seq_acc);
-    __syncthreads();
+    const int n_rec = A.n_pairs - k0 < kAlignBlock ? A.n_pairs - k0 : kAlignBlock;
+    for (int h0 = 0; h0 < n_rec; h0 += kSeqHalf) {
+      if (tid >= h0 && tid < h0 + kSeqHalf) seq_store(s_rec, tid - h0, t);
+      __syncthreads();
+      const int left = n_rec - h0;
+      if (tid < 64) seq_acc = seq_walk(s_rec, left < kSeqHalf ? left : kSeqHalf, tid, seq_acc);
+      __syncthreads();
+    }
   }
   if (dg) atomicAdd(reinterpret_cast<unsigned long long*>(&s_dig), (unsigned long long) dg);
   block_reduce_store(acc, red, tid);

@@ -176,5 +176,11 @@ KNOWN_TREE_ORDER_DEVIATIONS = {
     ("structure", 17, 346, 0): 1.2e-4,         # 1.08e-4 m; 15 of 64 perturbed tree-order runs leave 1e-4, none of the reference's
     ("structure", 8675309, 66, 1): 3.0e-4,     # 2.80e-4 m; 64 of 64 tree-order runs, none of the reference's
 }
-# ... and the one alignment where the reference arithmetic itself has no answer (its own 64 runs end metres apart)
-KNOWN_ILL_CONDITIONED = {("parameters", 4711, 219, 0)}
+# ... and the alignments where the reference arithmetic itself has no answer: its own runs from the 64 perturbed starts (or its two evaluations from the logged start)
+# end more than 1e-2 m / 1e-2 rad from the fp64 oracle -- metres, for the first two.  Listed by the eighteen-seed soak (profiles/r06/fuzz_soak_18_seeds_r06i.log);
+# with "sum_order" 1 the device still equals the sequential oracle bit for bit in each of them.
+KNOWN_ILL_CONDITIONED = {
+    ("parameters", 4711, 219, 0),      # one ulp on the start pose moves the sequential oracle by 4 m, the reference arithmetic by 14 m, the tree order by 30 m
+    ("parameters", 7, 25, 0),          # the two fp32 evaluations themselves are 2.2 m from fp64; perturbed runs 17.8 m
+    ("parameters", 42, 30, 0),         # perturbed sequential runs 3.1e-2 m / 3.0e-3 rad, the device 3.1e-2 m: the same spread
+}

@@ -41,6 +41,8 @@ CASES = [
     ("structure", 17, 346, 0, [-19.81760025024414, -4.79147481918335, 0.8986247181892395], "OUTSIDE"),
     ("structure", 8675309, 66, 1, [1.8744546175003052, -18.117185592651367, -0.9545098543167114], "OUTSIDE"),
     ("parameters", 4711, 219, 0, None, "ILL-CONDITIONED"),
+    ("parameters", 7, 25, 0, None, "ILL-CONDITIONED (round 6: decided before the perturbed runs may widen the envelope)"),
+    ("parameters", 42, 30, 0, None, "ILL-CONDITIONED (round 6)"),
 ]
 
 

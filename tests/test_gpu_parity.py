@@ -94,14 +94,20 @@ class _Envelope:
         """Round 6: no allowance by COUNT any more.  Outside the envelope may lie only the alignments NAMED in fuzz_cases -- the two of the
         eighteen-seed soak where the tree order alone lands a pair on the other side of a gate, each with its own bound -- and ill-conditioned may be only the one
         named there.  The default run (seeds 5 / 2024) holds none of them: zero tolerated."""
+        import os
+        collect = bool(os.environ.get("LSM2D_FUZZ_COLLECT"))      # a soak that LISTS what is not named yet instead of stopping at the first (tools/fuzz_soak.sh collect)
         for where, v in self.violations:      # where = (trial, alignment, note)
             key = (self.test, int(self.seed), int(where[0]), int(where[1]))
             bound = fuzz_cases.KNOWN_TREE_ORDER_DEVIATIONS.get(key)
+            if collect and (bound is None or max(v["device_vs_fp64"]) > bound):
+                print("UNNAMED OUTSIDE", key, v); continue
             assert bound is not None, ("outside the envelope and not a named tree-order deviation", key, v)
             assert max(v["device_vs_fp64"]) <= bound, ("a named tree-order deviation beyond its recorded bound", key, v)
         for where, v in self.ill:
             key = (self.test, int(self.seed), int(where[0]), int(where[1]))
-            assert key in fuzz_cases.KNOWN_ILL_CONDITIONED, ("ill-conditioned and not the named case", key, v)
+            if collect and key not in fuzz_cases.KNOWN_ILL_CONDITIONED:
+                print("UNNAMED ILL-CONDITIONED", key, v); continue
+            assert key in fuzz_cases.KNOWN_ILL_CONDITIONED, ("ill-conditioned and not a named case", key, v)
 
     def check(self, where, dev_pose, dev_status, r, rd, rr, perturbed=None):
         """perturbed: callable -> the sequential fp32 oracle's results from one_ulp_starts(x0); asked for only when the two evaluations' envelope does not hold"""
