@@ -19,8 +19,8 @@ LIB_PATH = os.path.join(LIB_DIR, "liblsm2d_hip.so")
 # option keys) compiled in.  NOT the product: the GPU suite run with LSM2D_EXPERIMENTS=1 in the environment (its variant tests are skipped otherwise) and tuning scripts load it.
 LIB_PATH_EXPERIMENTS = os.path.join(LIB_DIR, "liblsm2d_hip_experiments.so")
 SOURCES = [os.path.join(CSRC, "lsm2d_capi.hip")]
-HEADERS = [os.path.join(CSRC, "lsm2d_device.h"), os.path.join(CSRC, "lsm2d_kernels.h"),
-           os.path.join(ROOT, "include", "lsm2d.h")]
+# every header and include part under csrc/ (the kernels by family: lsm2d_k_*.h; the host side's parts: lsm2d_capi_*.inc) + the ABI header
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join(ROOT, "include", "lsm2d.h")]
 
 # -ffp-contract=off: every fused multiply-add in the kernels is explicit, so column indices and
 # z-buffer winners are reproducible bit-for-bit by an IEEE CPU (see csrc/lsm2d_device.h).
