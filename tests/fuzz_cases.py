@@ -1,5 +1,5 @@
 """The randomised aligner cases of the GPU fuzz tests, as DATA: generators that draw every trial's parameters from a seeded stream and hand them over as
-plain dictionaries, so that (i) the GPU tests (tests/test_gpu_parity.py: test_randomised_parameters_finder_and_aligner, test_randomised_aligner_structure)
+plain dictionaries, so that (i) the GPU tests (tests/test_gpu_fuzz.py: test_randomised_parameters_finder_and_aligner, test_randomised_aligner_structure)
 build their api objects from them and (ii) tests/replay_violators.py can re-create ANY trial of ANY seed on the CPU alone -- a soak's violator is named by
 (test, seed, trial, alignment) and nothing else.  The order of the draws is that of rounds 3-5's tests, so the soak logs under profiles/ still name the same cases.
 

@@ -1,7 +1,7 @@
 """Generates tests/golden/tracker_chain.json: ORACLE-GENERATED digests (NOT reference outputs -- the reference cannot be built here,
 SURVEY.md 8c) of an 8-step live-tracker chain: raw ranges -> preprocessed scans -> clipped local map -> pose of the two-slice aligner
 with odometry prior (fp32, the kernels' summation order) -> merged local map.  tests/test_oracle.py holds the oracle to it on the CPU
-box, tests/test_gpu_parity.py the HIP path on the MI355X (no oracle call there).
+box, tests/test_gpu_configs_at_size.py the HIP path on the MI355X (no oracle call there).
 
     python tests/golden/make_tracker_chain.py
 """

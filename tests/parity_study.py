@@ -1,6 +1,6 @@
 """How far is the fixed-polynomial arithmetic of the HIP path from the reference's own arithmetic?  (CPU study, oracle only.)
 
-The HIP kernels are bit-identical to the oracle's fp32 mirror `_f` (proved on the GPU by tests/test_gpu_parity.py); `_f` evaluates
+The HIP kernels are bit-identical to the oracle's fp32 mirror `_f` (proved on the GPU by tests/test_gpu_*.py); `_f` evaluates
 atan2 / sin / cos / log as fixed polynomials and fuses multiply-adds.  The reference calls libm and has no FMA.  This script runs
 both arithmetics (`_f` and the reference-arithmetic mode `_r` of oracle/lsm2d_oracle.h) on every BASELINE.json configuration and
 reports, per configuration:

@@ -441,7 +441,7 @@ def test_fixed_log_accuracy(po):
 def test_tracker_chain_digests(po):
     """tests/golden/tracker_chain.json: an 8-step live-tracker chain (ranges -> preprocess -> clip -> two-slice align with prior, the
     kernels' summation order -> merge) reduced to digests of every intermediate array.  The oracle must reproduce the committed file
-    bit for bit; tests/test_gpu_parity.py holds the HIP path to the same file."""
+    bit for bit; tests/test_gpu_configs_at_size.py holds the HIP path to the same file."""
     import tracker_chain
     g = json.load(open(golden_path("tracker_chain.json")))
     got = tracker_chain.run_oracle(po, len(g["steps"]))
@@ -490,7 +490,7 @@ def test_kdtree_oracle_is_approximate_and_honours_its_parameters(po, small_workl
 
 def test_tracker_replay_1000_digests(po):
     """tests/golden/tracker_replay_1000.json (BASELINE configs[2] at its size: 1 000 steps of the MULTI-parameter tracker chain, digests of
-    every 50th step): the oracle must reproduce the committed file bit for bit; tests/test_gpu_parity.py holds the HIP path to it."""
+    every 50th step): the oracle must reproduce the committed file bit for bit; tests/test_gpu_configs_at_size.py holds the HIP path to it."""
     import tracker_chain
     g = json.load(open(golden_path("tracker_replay_1000.json")))
     got = tracker_chain.run_oracle(po, g["steps_total"], record_every=g["record_every"])

@@ -7,6 +7,6 @@ seeds=${@:-"1 2 3 5 7 11 42 99 123 777 2024 5150 31337 65537 17 4711 271828 8675
 cd $R; : > $out
 for s in $seeds; do
   echo "== seed $s, $trials trials" >> $out
-  LSM2D_FUZZ_TRIALS=$trials LSM2D_FUZZ_SEED=$s timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "randomised" >> $out 2>&1 || { echo "FAILED seed $s" >> $out; tail -30 $out; exit 1; }
+  LSM2D_FUZZ_TRIALS=$trials LSM2D_FUZZ_SEED=$s timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_mapping.py -m gpu -q -s -k "randomised" >> $out 2>&1 || { echo "FAILED seed $s" >> $out; tail -30 $out; exit 1; }
 done
 grep -c "3 passed" $out
