@@ -68,6 +68,8 @@ struct lsm2d_context {
   int cull_block = 0;          // steps per unit of the culled stream (0: automatic, ~1/25 of a chunk; even; tuning knob)
   int sum_order = 0;           // 0: H, b and the chi^2 sums are formed in trees (a thread's pairs, 64 lanes, 8 waves: the fast order); 1: pair after pair in the reference's order
                                // (nicp_post.m:69-90: ascending column / moving index) -- bitwise the sequential fp32 CPU restatement the tests check against; k_align_seq, k_split_finish<true>, k_linearize_seq
+  int align_width = 0;         // threads per workgroup of a culled projective batch: 0 automatic (align_width_for), 512 / 256 forced; results never depend on it
+  int last_align_width = 0;    // what the latest k_align launch used
   int cull = 1;                // k_align, projective slices: exact culling of the moving cloud against the fixed canvas (0: off; results do not depend on it)
   int cull_keep = 1;           // ... the culled stream's unit lists are kept across iterations while the estimate stays within the margins they were built with (0: rebuilt every iteration; A/B knob)
   int cull_margin_um = 10000;  // the translation margin in micrometres (10 mm) and
@@ -391,6 +393,7 @@ extern "C" int lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   for (const AlignVariant& v : kAlignVariantsSeq) (void) hipFuncSetAttribute((const void*) v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
+  (void) hipFuncSetAttribute((const void*) k_align_narrow<256>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_align_pair, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
   (void) hipFuncSetAttribute((const void*) k_cull_estimate, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_dyn_lds);
 #ifdef LSM2D_EXPERIMENTS
@@ -487,8 +490,10 @@ const OptionDesc kOptions[] = {
   {"distmap_build",      &lsm2d_context::distmap_build,      0, 1,          0},
   {"kd_lds_nodes",       &lsm2d_context::kd_lds_nodes,       0, 4096,       0},
   {"sum_order",          &lsm2d_context::sum_order,          0, 1,          0},
+  {"align_width",        &lsm2d_context::align_width,        0, 512,        0},
   // ---- read-only
   {"last_align_path",    &lsm2d_context::last_align_path,    0, 0, kOptReadOnly},
+  {"last_align_width",   &lsm2d_context::last_align_width,   0, 0, kOptReadOnly},
   {"last_query_cull",    &lsm2d_context::last_query_cull,    0, 0, kOptReadOnly},
   {"max_dyn_lds",        &lsm2d_context::max_dyn_lds,        0, 0, kOptReadOnly},      // bytes of LDS one workgroup may ask for
   {"uploads",            &lsm2d_context::uploads,            0, 0, kOptReadOnly},      // host-to-device cloud uploads this context has queued so far (lsm2d_cloudset_create / _upload)

@@ -396,7 +396,8 @@ LSM2D_DEV void xcd_wait(uint32_t* sync, int need, int limit) {
   }
 }
 
-template <bool kGuarded>
+// (kStride: the threads that share the list -- the workgroup's width; nthreads: the chunks of a row of the lane-chunked copy, 512 whatever the width.  0: the same)
+template <bool kGuarded, int kStride = 0>
 LSM2D_DEV void project_cloud_list_t(const float4* __restrict__ lane_xy, int T_steps, const Iso& Tin, const ProjK& Pin, u64* canvas, int tid, int nthreads,
                                     const uint16_t* units, int n_units, int B) {
   const Iso T = Tin; ProjK P = Pin;
@@ -408,7 +409,7 @@ LSM2D_DEV void project_cloud_list_t(const float4* __restrict__ lane_xy, int T_st
   float4* ubase = reinterpret_cast<float4*>(((unsigned long long) pb_hi << 32) | (unsigned long long) pb_lo);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, (short) 0, 0x7fffffff, 0x00020000);
   const int row_bytes = nthreads * (int) sizeof(float4);
-  for (int k = tid; k < n_units; k += nthreads) {
+  for (int k = tid; k < n_units; k += (kStride > 0 ? kStride : nthreads)) {
     const int code = (int) units[k];
     const int g = code & 511, t0 = (code >> 9) * B;
     const int nsteps = T_steps - t0 < B ? T_steps - t0 : B;
@@ -437,10 +438,11 @@ LSM2D_DEV void project_cloud_list_t(const float4* __restrict__ lane_xy, int T_st
     if (t < nsteps) pair(va, idx);
   }
 }
+template <int kStride = 0>
 LSM2D_DEV void project_cloud_list(const float4* __restrict__ lane_xy, int T_steps, const Iso& T, const ProjK& P, u64* canvas, int tid, int nthreads,
                                   const uint16_t* units, int n_units, int B) {
-  if (P.tiny_ok) project_cloud_list_t<false>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
-  else project_cloud_list_t<true>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
+  if (P.tiny_ok) project_cloud_list_t<false, kStride>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
+  else project_cloud_list_t<true, kStride>(lane_xy, T_steps, T, P, canvas, tid, nthreads, units, n_units, B);
 }
 
 #ifdef LSM2D_EXPERIMENTS      // ("cull" 2: measured 3 % slower than the block units, DESIGN App. A; compiled into the experiments build only)

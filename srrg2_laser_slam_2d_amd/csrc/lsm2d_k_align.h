@@ -2,8 +2,15 @@
 // Part of lsm2d_kernels.h (included there, inside namespace lsm2d, in this order); not a translation unit of its own.
 // kSeq: "sum_order" 1 -- H, b and the chi^2 statistics are added pair after pair in the reference's order (lsm2d_device.h: pair_terms / seq_walk) instead of
 // in trees; instantiations of their own (k_align_seq), so the default kernels do not carry the records' code
-template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0, bool kFirstStage = false, bool kSeq = false>
+// kW: threads of the workgroup (round 6).  512 = kAlignBlock everywhere but in the NARROW instantiation of the culled projective stream (k_align_narrow<256>):
+// four waves per workgroup, one per SIMD, so six workgroups fit a CU (the canvases' LDS bounds it: 1536 resident alignments instead of 1024) -- for batches just
+// above a multiple of 1024, whose last alignments would otherwise run a second, nearly empty dispatch round (tools/batch_size_sweep.py: 1100 .. 1536 alignments
+// lost 17-25 % per alignment).  The z-buffer does not care who streams which point; the bin walk and the sums keep the 512 VIRTUAL threads of the wide kernel --
+// thread t plays virtual threads t, t + kW, ... one after the other, each with its own partial sums, its waves' trees written to the same eight rows of `red` --
+// so every result keeps its bits (tests: 256 against 512).
+template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0, bool kFirstStage = false, bool kSeq = false, int kW = kAlignBlock>
 LSM2D_DEV void align_body(const AlignArgs& A) {
+  static_assert(kW == kAlignBlock || (kNNMode == 5 && !kFirstStage && !kSeq && kW % 64 == 0 && kW >= 256 && kW < kAlignBlock), "narrow workgroups: the culled projective stream only");
   __builtin_assume(A.n_slices >= 1 && A.n_slices <= kMaxSlices);      // (the host refuses anything else: the slice loops need no guard -- which, as a flag, was kept in a vector register and spilled)
   constexpr bool kNNGlobal = kNNMode == 1, kNNLds = kNNMode == 2;
   // the same for a pure KD-tree batch: 3 = every alignment's whole tree, leaf arrays included, is in LDS (the tracker's wiring: a tree per scan); 4 = only the
@@ -56,7 +63,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
 
   // (the alignment's index is wave-uniform: said so, or everything indexed by it would live in vector registers)
   const int a = A.order ? __builtin_amdgcn_readfirstlane(A.order[blockIdx.x]) : (int) blockIdx.x, tid = threadIdx.x;
-  constexpr int nwaves = kAlignBlock / 64;
+  constexpr int nwaves = kW / 64;      // physical waves (the rows of `red` stay kAlignBlock / 64: one per VIRTUAL wave)
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
   __shared__ unsigned long long s_clk[2];      // start stamps wait in LDS: no register is held across the kernel for them
 #ifdef LSM2D_PHASE_PROBE      // diagnostics build: thread 0 sums the cycles it spends in the query / projection phase, at the barrier + reduction, and in the solve
@@ -101,10 +108,10 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
   }
 
   if (kHasProj && !kHasNN && !kHasDist && !kHasKd && A.inline_n1)
-    for (int s = 0; s < A.n_slices; ++s) if (A.s[s].unpack_src) unpack_fixed_set(A.s[s], tid, kAlignBlock);      // visible after the barrier below
+    for (int s = 0; s < A.n_slices; ++s) if (A.s[s].unpack_src) unpack_fixed_set(A.s[s], tid, kW);      // visible after the barrier below
   // ---- prologue: fixed canvases, camera at identity (correspondence_finder_projective_2d.cpp:37-44)
-  for (int i = tid; i < A.fcan_total; i += kAlignBlock) fcan[i] = kEmptyCell;
-  for (int i = tid; i < A.cols_max; i += kAlignBlock) mcan[i] = kEmptyCell;      // afterwards the bin walk resets what it reads
+  for (int i = tid; i < A.fcan_total; i += kW) fcan[i] = kEmptyCell;
+  for (int i = tid; i < A.cols_max; i += kW) mcan[i] = kEmptyCell;      // afterwards the bin walk resets what it reads
   // per-iteration set-up by lane 0: X_eff = S^-1 X per slice (AlignerSliceProcessorLaser2DWithSensor), cos/sin once per
   // slice, zeroed sums.  Done here for iteration 0 and at the end of every solve for the next one (no extra barrier).
   auto begin_iteration = [&]() {
@@ -224,7 +231,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
     if (!kHasProj || S.finder != LSM2D_FINDER_PROJECTIVE) continue;
     const int fc = pick_cloud(S.fixed, a);
     // (a set unpacked by this launch: its size comes with the arguments -- the scalar cache may not have seen the count written above)
-    project_cloud(S.fixed.xy + S.fixed.start[fc], (A.inline_n1 && S.unpack_src) ? S.unpack_n : S.fixed.count[fc], ident, S.proj, fcan + S.fcan_offset, tid, kAlignBlock);
+    project_cloud(S.fixed.xy + S.fixed.start[fc], (A.inline_n1 && S.unpack_src) ? S.unpack_n : S.fixed.count[fc], ident, S.proj, fcan + S.fcan_offset, tid, kW);
   }
   __syncthreads();
   if (pq_on) {      // the occupancy bitmap: every thread derives the same cell size and origin from the box, then stamps its points
@@ -308,17 +315,33 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
               const unsigned long long bb = reinterpret_cast<unsigned long long>(S.moving.lane_bounds + (size_t) mc * kAlignBlock);
               float4* bbase = reinterpret_cast<float4*>(((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (bb >> 32)) << 32) |
                                                         (unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) bb));
+              int n_surv = 0;
+              if constexpr (kW == kAlignBlock) {
               const u32x4 bw = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(bbase, (short) 0, kAlignBlock * 16, 0x00020000), tid * 16, 0, 0);
               const bool keep = chunk_may_matter(T, S.proj, make_float4(__uint_as_float(bw.x), __uint_as_float(bw.y), __uint_as_float(bw.z), 0.0f), fcan + S.fcan_offset, S.point_distance, m_t, m_th);
               const u64 bal = __ballot(keep);
               { int wv = tid >> 6; asm volatile("" : "+v"(wv)); if (lane == 0) s_wcnt[wv] = __popcll(bal); }      // (the address made here, not in front of the iteration loop and kept)
               __syncthreads();
-              int before = 0, n_surv = 0;
+              int before = 0;
 #pragma unroll
               for (int w = 0; w < nwaves; ++w) { const int cw = s_wcnt[w]; before += w < wave ? cw : 0; n_surv += cw; }
               n_surv = __builtin_amdgcn_readfirstlane(n_surv);
               if (keep) s_surv[before + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) bal, 0u))] = (uint16_t) tid;
               __syncthreads();
+              } else {      // narrow workgroup: the 512 chunks in rounds of kW, compacted round by round (any order of the survivors serves: the z-buffer's minimum is the same)
+                const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(bbase, (short) 0, kAlignBlock * 16, 0x00020000);
+                int par = 0;
+                for (int v0 = 0; v0 < kAlignBlock; v0 += kW, par ^= 1) {
+                  const int v = v0 + tid; bool keep = false;
+                  if (v < kAlignBlock) {
+                    const u32x4 bw = __builtin_amdgcn_raw_buffer_load_b128(brs, v * 16, 0, 0);
+                    keep = chunk_may_matter(T, S.proj, make_float4(__uint_as_float(bw.x), __uint_as_float(bw.y), __uint_as_float(bw.z), 0.0f), fcan + S.fcan_offset, S.point_distance, m_t, m_th);
+                  }
+                  const int pos = block_compact_pos(keep, s_wcnt, par, n_surv, tid, nwaves);
+                  if (keep) s_surv[pos] = (uint16_t) v;
+                }
+                __syncthreads();
+              }
               // (B) test v = (block v / n_surv, survivor v mod n_surv), v = tid, tid + 512, ...; block_compact_pos: one barrier per round, buffers alternating
               const unsigned long long kb = reinterpret_cast<unsigned long long>(S.moving.block_bounds + (size_t) mc * nbs * kAlignBlock);
               float4* kbase = reinterpret_cast<float4*>(((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (kb >> 32)) << 32) |
@@ -327,7 +350,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
               int n_units = 0, parity = 1, i = tid, blk = 0;
               while (n_surv > 0 && i >= n_surv && blk < nb) { i -= n_surv; ++blk; }
               const int n_tests = nb * n_surv;
-              for (int v0 = 0; v0 < n_tests; v0 += kAlignBlock, parity ^= 1) {
+              for (int v0 = 0; v0 < n_tests; v0 += kW, parity ^= 1) {
                 bool k2 = false; int code = 0;
                 if (blk < nb) {
                   const int g = (int) s_surv[i];
@@ -337,7 +360,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
                 }
                 const int pos = block_compact_pos(k2, s_wcnt, parity, n_units, tid, nwaves);
                 if (k2) units[pos] = (uint16_t) code;
-                i += kAlignBlock;
+                i += kW;
                 while (n_surv > 0 && i >= n_surv && blk < nb) { i -= n_surv; ++blk; }
               }
               if (tid == 0) { s_nunits[s] = n_units; s_list_iso[s] = T; }
@@ -345,7 +368,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
             }
             if (lists_only) continue;
             const int n_units = __builtin_amdgcn_readfirstlane(s_nunits[s]);
-            if (n_units > 0) project_cloud_list(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, units, n_units, B);
+            if (n_units > 0) project_cloud_list<kW>(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, units, n_units, B);
           }
           else if (S.moving.lane_xy && S.moving.lane_bounds && A.cull) {
             // exact culling against the fixed canvas (chunk_may_matter): every thread tests the chunk it would stream, the survivors are
@@ -421,6 +444,31 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
             }
             const int left = S.proj.cols - col0;
             seq_trip(tid, true, t, left < kAlignBlock ? left : kAlignBlock);
+          }
+        }
+        else if constexpr (kW != kAlignBlock) {
+          // narrow workgroup: this thread plays the VIRTUAL threads tid, tid + kW, ... (< 512) of the wide kernel one after the other -- each with its own partial sums
+          // over the wide kernel's columns (vt, vt + 512, ...) in its order, each virtual wave's tree into that wave's row of `red` (kW is a multiple of 64: a
+          // physical wave plays whole virtual waves)
+          const int bits = 32 - __builtin_clz(((S.proj.cols + kAlignBlock - 1) / kAlignBlock) | 1);
+          for (int vt = tid; vt < kAlignBlock; vt += kW) {
+            Accum av; accum_zero(av);
+            for (int col = vt; col < S.proj.cols; col += kAlignBlock) {
+              const u64 fk = fcs[col], mk = mcan[col];
+              mcan[col] = kEmptyCell;
+              if (mk == kEmptyCell || fk == kEmptyCell) continue;
+              const float fd = __uint_as_float((uint32_t) (fk >> 32)), md = __uint_as_float((uint32_t) (mk >> 32));
+              if (__builtin_fabsf(fd - md) > S.point_distance) continue;
+              const int mi = (int) (uint32_t) mk, fi = (int) (uint32_t) fk;
+              float2 nm, pm; float4 f;
+              if (maos) { const float4 m4 = maos[mi]; pm = make_float2(m4.x, m4.y); nm = make_float2(m4.z, m4.w); } else { nm = mn[mi]; pm = mp[mi]; }
+              if (faos) f = faos[fi]; else { const float2 p2 = fpp[fi], n2 = fnr[fi]; f = make_float4(p2.x, p2.y, n2.x, n2.y); }
+              float nqx, nqy; xf_normal(T, nm.x, nm.y, nqx, nqy);
+              if (__builtin_fmaf(nqx, f.z, nqy * f.w) < S.normal_cos) continue;
+              if (want_dig) digest_add(&s_dig, salt, fi, mi);
+              accumulate_pair(T, make_float2(f.x, f.y), make_float2(f.z, f.w), pm, nm, S.cauchy != 0, S.tau, av, inl_only);
+            }
+            block_reduce_store(av, red, vt, bits);
           }
         }
         else
@@ -628,11 +676,12 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
       }
       LSM2D_PH(0);
       // (a projective slice's thread accumulates at most ceil(cols / block) pairs: its counts are a few bits, summed by ballots)
+      if constexpr (kW == kAlignBlock)      // (the narrow workgroups' virtual waves have written their rows in the walk)
       block_reduce_store(acc, red, tid, (kHasProj && !kHasNN && !kHasDist && !kHasKd) ? 32 - __builtin_clz(((S.proj.cols + kAlignBlock - 1) / kAlignBlock) | 1) : 0);
       __syncthreads();
       if (tid < 64) {
         // lanes 0..13 of wave 0 each add one quantity over the waves (wave order) and then into the iteration's sum themselves
-        float v; int vi; block_reduce_gather_lane(red, nwaves, tid, v, vi);
+        float v; int vi; block_reduce_gather_lane(red, kAlignBlock / 64, tid, v, vi);
         if constexpr (kSeq) v = seq_acc;      // (the partial sums' floats were never touched: the eleven quantities are the walker's)
         const int n_corr = __builtin_amdgcn_readlane(vi, 13);
         if (tid == 0) s_n_corr += n_corr;
@@ -747,6 +796,12 @@ constexpr int align_min_waves() {
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
 __global__ __launch_bounds__(kAlignBlock, (align_min_waves<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode>())) void k_align(const AlignArgs A) {
   align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false>(A);
+}
+// The culled projective stream in NARROW workgroups (align_body's kW): 256 threads, six workgroups -- 1536 alignments -- resident per round where the wide kernel
+// holds 1024.  The same results as k_align<1,0,0,0,5>, bit for bit; chosen by the host (align_width_for) for batches just above a multiple of 1024 alignments.
+template <int kW>
+__global__ __launch_bounds__(kW, LSM2D_ALIGN_MIN_WAVES) void k_align_narrow(const AlignArgs A) {
+  align_body<true, false, false, false, 5, false, false, kW>(A);
 }
 // "sum_order" 1: the same kernel with the reference's order of summation (align_body<.., kSeq = true>).  14 KB of pair records per workgroup beside the canvases (four workgroups per CU still fit the headline's shape):
 // the register budget stays that of 8 waves per SIMD -- 4 for the mixed instantiations, as above

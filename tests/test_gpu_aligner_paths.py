@@ -738,3 +738,46 @@ def test_latency_kernel_two_slices_one_empty_fixed_cloud_and_one_beyond_the_lds_
         w = po.align(po.aligner_params(6, min_num_inliers=5, device_order=True), osl, fixed, [m, m], x0[0])
         _assert_bitwise_equal_to_device_order_oracle(c, 0, w, "one empty fixed cloud")
         assert c.status[0] == 0
+
+
+def test_narrow_workgroups_keep_every_bit_and_the_width_rule(ctx, po):
+    """Round 6: the culled projective stream in workgroups of 256 threads (k_align_narrow: six workgroups per CU instead of four, for batches just above a multiple
+    of 1024 alignments).  The bin walk and the sums keep the wide kernel's 512 virtual threads: poses, information matrices, statistics and
+    digests must equal the 512-thread kernel's bit for bit -- one and two slices, Cauchy, a prior, odd canvas sizes; and the automatic rule picks the width the
+    batch-size sweep showed to pay."""
+    wl = synth.make_workload(12, 60000, seed=31, map_noise=0.004, scan_noise=0.004)
+    fixed = api.CloudSet(ctx, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(ctx, wl.map_points)
+    n = 300
+    fi1 = (np.arange(n, dtype=np.int32) % 12).reshape(1, n)
+    x0 = wl.x0[fi1[0]].astype(np.float32).copy(); x0[:, 1] += np.linspace(-0.02, 0.02, n, dtype=np.float32)
+    pri = [(x0[i].copy(), np.diag([20.0, 30.0, 40.0]).astype(np.float32)) for i in range(n)]
+    for ns, cols, rb in ((1, 1081, None), (1, 700, api.RobustifierCauchy(0.02)), (2, 721, api.RobustifierCauchy(0.02))):      # (two slices of 1081 columns do not fit the unit lists beside the canvases: the shared instantiation, one width)
+        al = api.MultiAligner2D(ctx, max_iterations=12, min_num_inliers=10)
+        for s in range(ns):
+            al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector(cols - 180 * s)), min_num_correspondences=10, robustifier=rb))
+        fi = np.tile(fi1, (ns, 1))
+        res = {}
+        for w in (512, 256):
+            ctx.set_option("align_width", w); ctx.set_option("align_path", 1)
+            try:
+                res[w] = al.compute_batch([fixed] * ns, [moving] * ns, x0, fixed_index=fi, priors=pri if ns == 2 else None, want_stats=True)
+                assert ctx.get_option("last_align_width") == w, (w, ctx.get_option("last_align_width"))
+            finally:
+                ctx.set_option("align_width", 0); ctx.set_option("align_path", 0)
+        assert np.all(res[512].status == 0)
+        for w in (256,):
+            assert np.array_equal(res[w].pose, res[512].pose) and np.array_equal(res[w].information, res[512].information), (ns, cols, w)
+            assert np.array_equal(res[w].status, res[512].status) and np.array_equal(res[w].iterations, res[512].iterations) and np.array_equal(res[w].stats, res[512].stats), (ns, cols, w)
+        # ... and the 512-thread kernel is the device-order mirror's, as everywhere
+        osl = [po.slice_params(canvas_cols=cols - 180 * s, robustifier=po.ROBUST_CAUCHY if rb else po.ROBUST_NONE, chi_threshold=0.02 if rb else 0.05) for s in range(ns)]
+        for i in (0, 151, 299):
+            c = int(fi1[0, i]); sc = wl.scan_points[wl.scan_offsets[c]:wl.scan_offsets[c + 1]]
+            kw = dict(prior_z=pri[i][0], prior_omega=pri[i][1]) if ns == 2 else {}
+            rt = po.align(po.aligner_params(12, device_order=True, **kw), osl, [sc] * ns, [wl.map_points] * ns, x0[i])
+            _assert_bitwise_equal_to_device_order_oracle(res[256], i, rt, ("narrow", ns, cols, i))
+    # the automatic rule (one slice, 1081 columns: 25 KB of LDS per workgroup)
+    al = _aligner(ctx)
+    for n_batch, want in ((1000, 512), (1024, 512), (1025, 512), (1040, 256), (1100, 256), (1280, 256), (1400, 256), (1536, 256), (1700, 512), (2048, 512), (2100, 512)):
+        fb = (np.arange(n_batch, dtype=np.int32) % 12).reshape(1, n_batch)
+        al.compute_batch([fixed], [moving], wl.x0[fb[0]], fixed_index=fb)
+        assert ctx.get_option("last_align_width") == want, (n_batch, ctx.get_option("last_align_width"), want)
