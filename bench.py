@@ -843,7 +843,7 @@ def main() -> None:
                     ctx.synchronize()
                 except Exception:
                     pass
-        if world == 1 and n_sets > 1 and not options_set:
+        if world == 1 and n_sets > 1 and not args.no_also and not options_set:
             extra("same_poses_every_step", same_poses_block)
         if world == 1 and default_cfg and not args.no_also and not options_set:
             def sum_order_block():

@@ -94,6 +94,7 @@ struct lsm2d_context {
       0;
 #endif
   int lane_streams = 1;        // asynchronously begun batches launch on their lane's own stream (lane_stream); experiments build: 0 = in order on the context's stream, as first built
+  int order_cluster = 0;       // experiments build: > 0 = big-map batches are dealt to workgroup ids by the sensors' positions and headings (value / 10 = metres per radian of heading): see make_placement
   int estimate_reuse = 1;      // a prepared batch run again with unchanged start poses keeps its placement (no k_cull_estimate launch); experiments build: 0 switches that off
   int last_xcd_lockstep = 0;   // what the latest aligner call ran with (0: free-running)
   int last_cull_estimate = 0;  // what the latest aligner call did about the placement's estimate ("last_cull_estimate")
@@ -521,6 +522,7 @@ const OptionDesc kOptions[] = {
   {"estimate_reuse",     &lsm2d_context::estimate_reuse,     0, 1,       kOptExperiment},
   {"lane_streams",       &lsm2d_context::lane_streams,       0, 1,       kOptExperiment},
   {"xcd_lockstep",       &lsm2d_context::xcd_lockstep,       0, 64,      kOptExperiment},
+  {"order_cluster",      &lsm2d_context::order_cluster,      0, 10000,   kOptExperiment},
 #endif
 };
 const OptionDescLL kOptionsLL[] = {      // read-only, 64-bit

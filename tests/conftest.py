@@ -40,7 +40,7 @@ def ctx():
 # LSM2D_EXPERIMENTS=1 in the environment selects it: srrg2_laser_slam_2d_amd/build.py); value = what the shipped library does.
 EXPERIMENT_DEFAULTS = {"cull_est_um": 0, "cull_est_urad": 40000, "results_to_host": 1, "two_stage": 0, "balance_notes": 1, "cull_keep": 1, "nn_qcache": 1,
                        "nn_lds_only": 1, "kd_modes": 1, "proj_modes": 1, "cull_block": 0, "kd_chain": 1, "grid_big_cells_x10": 50, "kd_scan_max_clouds": 8,
-                       "kd_wide_min_points": 1024, "kd_wg_max_points": 16384, "estimate_reuse": 1, "xcd_lockstep": 0, "lane_streams": 1}
+                       "kd_wide_min_points": 1024, "kd_wg_max_points": 16384, "estimate_reuse": 1, "xcd_lockstep": 0, "lane_streams": 1, "order_cluster": 0}
 
 
 def has_experiments(ctx) -> bool:

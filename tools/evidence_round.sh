@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 evidence pass on the GPU box, in this order (each part appends to gpurun_out/<tag>/): the GPU test suite; the headline's profile round (trace, PMC, probes,
+# Evidence pass (rounds 5-6) on the GPU box, in this order (each part appends to gpurun_out/<tag>/): the GPU test suite; the headline's profile round (trace, PMC, probes,
 # counters.json, bench lines incl. the driver's command); the other modes' counters and lines; the size sweep past the Infinity Cache; the streamed pipeline with its
-# kernel trace.  usage: bash tools/evidence_r05.sh <tag>
+# kernel trace.  usage: bash tools/evidence_round.sh <tag>
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; tag=${1:-r05}; O=$R/gpurun_out/$tag; mkdir -p $O; cd $R
 (timeout -k 10 700 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gpu_tests.log)
 (LSM2D_EXPERIMENTS=1 timeout -k 10 700 python -m pytest tests -m gpu -q > $O/gpu_tests_experiments_build.log 2>&1; echo "gpu tests (experiments build) rc=$?"; tail -3 $O/gpu_tests_experiments_build.log)

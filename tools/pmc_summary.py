@@ -12,7 +12,8 @@ acc = defaultdict(list)
 for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
     per_dispatch = defaultdict(dict)
     for row in csv.DictReader(open(path)):
-        if want not in row["Kernel_Name"]:
+        name = row["Kernel_Name"]      # ("k_align" means the k_align<...> template itself, not k_align_seq / _narrow / _pair: round 6)
+        if not ((want + "<" in name or want + "I" in name) if want == "k_align" else want in name):
             continue
         per_dispatch[row["Dispatch_Id"]][row["Counter_Name"]] = float(row["Counter_Value"])
     for d in per_dispatch.values():
