@@ -525,7 +525,9 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
         // NN finder fused with the factor (correspondence_finder_kd_tree_2d.cpp:12-27): every moving point is
         // transformed, matched to its exact nearest fixed point within max_distance, normal-gated, accumulated
         const int fc = pick_cloud(S.fixed, a), mc = pick_cloud(S.moving, a);
-        const int mbase = S.moving.start[mc], fbase = S.fixed.start[fc];
+        // (the clouds' first indices declared wave-uniform -- they are -- so that the six pointers formed from them live in scalar registers: round 6, k_align<0,1,0,0,1>
+        // 48 B of scratch -> none, role B / exact NN 1.608 -> 1.393 ms on configs[1]; the other point-query modes unchanged: profiles/r06/pq_uniform_bases_ab_r06o.txt)
+        const int mbase = __builtin_amdgcn_readfirstlane(S.moving.start[mc]), fbase = __builtin_amdgcn_readfirstlane(S.fixed.start[fc]);
         const float2* fn = S.fixed.nrm + fbase; const float2* mn = S.moving.nrm + mbase;
         const float2* fp = S.fixed.xy + fbase;  const float2* mp = S.moving.xy + mbase;
         const bool use_grid = kHasNN && ((!kHasDist && !kHasKd) || S.finder == LSM2D_FINDER_NN);

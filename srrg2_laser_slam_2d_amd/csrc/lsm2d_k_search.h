@@ -61,8 +61,27 @@ struct KdDev {
 template <bool kAllLds = false>
 LSM2D_DEV int kd_query_pos(const KdNode* __restrict__ nodes, const float2* __restrict__ lxy, float qx, float qy, float md2, float2& best_xy,
                            const float4* l_plane = nullptr, const int2* l_link = nullptr, int lds_nodes = 0) {
+#ifndef LSM2D_KD_NODE_TOGETHER
+#define LSM2D_KD_NODE_TOGETHER 1
+#endif
   int k = 0;
   int2 L;
+#if LSM2D_KD_NODE_TOGETHER
+  // Round 6: a node's two halves -- its plane and its link, one 32-byte record -- are asked for TOGETHER as soon as the node is known.  (Before: the link first,
+  // and the plane only inside the loop, behind the test of the link: below the levels staged in LDS every level of the descent cost two dependent trips to L2
+  // instead of one.  The leaf's plane is fetched for nothing: the same line.)  The same tests on the same values: the same leaf.
+  float4 P;
+  auto node = [&](int kk) {
+    if (kAllLds || kk < lds_nodes) { P = l_plane[kk]; L = l_link[kk]; }
+    else { P = reinterpret_cast<const float4*>(nodes)[2 * kk]; const int4 w = reinterpret_cast<const int4*>(nodes)[2 * kk + 1]; L = make_int2(w.x, w.y); }
+  };
+  node(0);
+  while (L.x >= 0) {
+    const float t = (qx - P.x) * P.z + (qy - P.y) * P.w;
+    k = L.x + (t < 0.0f ? 0 : 1);
+    node(k);
+  }
+#else
   if (kAllLds || lds_nodes > 0) L = l_link[0]; else { const int4 w = reinterpret_cast<const int4*>(nodes)[1]; L = make_int2(w.x, w.y); }
   while (L.x >= 0) {
     float4 P;
@@ -71,6 +90,7 @@ LSM2D_DEV int kd_query_pos(const KdNode* __restrict__ nodes, const float2* __res
     k = L.x + (t < 0.0f ? 0 : 1);
     if (kAllLds || k < lds_nodes) L = l_link[k]; else { const int4 w = reinterpret_cast<const int4*>(nodes)[2 * k + 1]; L = make_int2(w.x, w.y); }
   }
+#endif
   const int b = -1 - L.x, e = L.y;
   int bestpos = -1; float bd = md2;
   auto consider = [&](int j, float px, float py) {
