@@ -50,12 +50,19 @@ namespace lsm2d_srrg {
   class HipContext : public srrg2_core::Configurable {
   public:
     PARAM(srrg2_core::PropertyInt, device_id, "HIP device ordinal", 0, 0);
+    PARAM(srrg2_core::PropertyInt,
+          sum_order,
+          "0: H, b and the chi2 statistics are added in trees (fast); 1: pair after pair in the reference's order -- the aligner then equals the sequential fp32 "
+          "restatement of the reference's factor loop bit for bit, at about 1.5 x the time (lsm2d.h, option sum_order)",
+          0,
+          0);
     ~HipContext() {
       lsm2d_destroy(_ctx);
     }
     lsm2d_context* handle(const std::string& who_) {
       if (!_ctx) {
         throwOnError(lsm2d_create(param_device_id.value(), nullptr, &_ctx), who_ + " create", nullptr);
+        throwOnError(lsm2d_set_option(_ctx, "sum_order", param_sum_order.value() ? 1 : 0), who_ + " sum_order", _ctx);
       }
       return _ctx;
     }

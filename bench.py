@@ -4,9 +4,14 @@
 Workload (BASELINE.json configs[1]): a batch of 1000 synthetic 1081-beam scans against ONE 100k-point
 local map, 20 Gauss-Newton iterations per alignment, reference role assignment (fixed = scan,
 moving = map, projective finder -- SURVEY.md section 8d "role A / projective").  One step = one pass of the
-batch through lsm2d_align_batch with the clouds already resident in HBM.  With N GPUs every rank
-aligns its own 1000 scans (weak scaling) against the map broadcast from rank 0 over RCCL; there is
-no data-path collective.
+batch through lsm2d_align_batch with the clouds already resident in HBM and NEW START POSES every step
+(--pose-sets sets in rotation: the 12 KB upload and the placement's estimate are inside the step; the
+step with identical poses every time, which the library answers from what it kept, is the labelled
+`same_poses_every_step` block).  With N GPUs every rank aligns its own 1000 scans (weak scaling) against
+the map broadcast from rank 0 over RCCL; there is no data-path collective.
+Blocks beside the headline on the default N=1 line: same_poses_every_step, sum_order_1 (the reference's
+order of summation: bitwise the sequential fp32 oracle), pipelined (two batches in flight), streamed
+(ranges in, poses out), also (configs[4], configs[3]), cpu_baseline (+ all_cores).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -805,7 +810,7 @@ def main() -> None:
                                    % ("configs[1]: " if default_cfg else "", args.scans, args.beams, args.map_points, args.iterations, args.role,
                                       "fixed=scan, moving=map" if args.role == "A" else "fixed=map, moving=scan", args.finder,
                                       ", Cauchy tau %g" % args.cauchy if args.cauchy > 0 else ""),
-                       "unique_scans": n_unique,
+                       "unique_scans": n_unique, "pose_sets": n_sets,
                        "alignments_per_gpu": args.scans, "map_points": args.map_points, "beams": args.beams,
                        "iterations": args.iterations, "parallelism": "alignments sharded, map replicated (RCCL broadcast)"},
             "parity_ok": ok, "max_pose_err_m": float(err[:, :2].max()), "max_pose_err_rad": float(err[:, 2].max()),
