@@ -113,10 +113,12 @@ class _Envelope:
         dm, dr = _pose_diff(dev_pose, rd["pose"])
         if dm <= POSE_TOL_M and dr <= POSE_TOL_RAD:
             self.tally["ok"] += 1; self.worst["ok"] = max(self.worst["ok"], dm, dr); return "ok"
-        if dm <= max(POSE_TOL_M, 3.0 * em) and dr <= max(POSE_TOL_RAD, 3.0 * er):
+        # (an alignment whose two reference-arithmetic evaluations are THEMSELVES a hundred bars from the fp64 oracle is ill-conditioned: decided before their
+        # distance may serve as a yardstick -- round 6; round 5 passed such runaways, up to metres, as "within 3 x the reference arithmetic's own distance")
+        if (em <= self.ILL and er <= self.ILL) and dm <= max(POSE_TOL_M, 3.0 * em) and dr <= max(POSE_TOL_RAD, 3.0 * er):
             self.tally["needs_factor"] += 1; self.worst["needs_factor"] = max(self.worst["needs_factor"], dm, dr); return "needs_factor"
         pm = pr_ = 0.0
-        if perturbed is not None:
+        if perturbed is not None and em <= self.ILL and er <= self.ILL:
             more = [o for o in perturbed() if o["status"] == 0]
             if more:
                 pm = max(_pose_diff(o["pose"], rd["pose"])[0] for o in more); pr_ = max(_pose_diff(o["pose"], rd["pose"])[1] for o in more)
