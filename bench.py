@@ -160,15 +160,16 @@ def working_set_bytes(role: str, finder: str, scans: int, map_points: int, n_sca
     return 32.0 * map_points + 32.0 * scans * n_scan_mean
 
 
-def build_roofline(role, finder, scans, map_points, iterations, beams, cauchy, n_unique, n_scan_mean, k_ms, k_samples, clk, wg_ms):
-    """The roofline block of one measured workload (the headline line and every entry of `also`)."""
+def build_roofline(role, finder, scans, map_points, iterations, beams, cauchy, n_unique, n_scan_mean, k_ms, k_samples, clk, wg_ms, use_counters=True):
+    """The roofline block of one measured workload (the headline line and every entry of `also`).  use_counters False: a workload no PMC pass was taken on (the
+    streamed pipeline's preprocessed scans): launch time, clock and the algorithmic figure only -- the instruction counts of OTHER clouds would price it wrongly."""
     cfg_key = "role%s/%s/scans%d/map%d/it%d/beams%d" % (role, finder, scans, map_points, iterations, beams)
     if cauchy > 0:                       # a robustified run is another instruction stream (the log, the weights): its own counters
         cfg_key += "/cauchy%g" % cauchy
     if n_unique != scans:                # scans shared through the index array: another memory pattern
         cfg_key += "/unique%d" % n_unique
     bytes_per_alignment = algorithmic_bytes_per_alignment(role, finder, map_points, n_scan_mean, beams, iterations)
-    counters, warn = load_counters(cfg_key)
+    counters, warn = load_counters(cfg_key) if use_counters else (None, None)
     effective = bytes_per_alignment * scans / (k_ms * 1e-3) / 1e9
     ws = working_set_bytes(role, finder, n_unique if 0 < n_unique < scans else scans, map_points, n_scan_mean)      # (candidates that share scans through an index array: the distinct scans)
     roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave64-VALU issue slots/s", "frac": None, "traffic": None,
@@ -453,12 +454,12 @@ def run_stream(ctx, api, synth, torch, world_geom, map_set, map_dev, aligner, ar
                       "resident_step_skips_the_estimate": est_skipped, "sustained_over_resident": resident_ms / ms,
                       "note": "resident = the same preprocessed scans already in HBM, lsm2d_align_batch per step (what the default line times); sustained_over_resident = its ms per step / "
                               "the streamed ms per step"},
-           # (the committed counters are the resident line's -- analytic normals; these preprocessed scans are other clouds of the same shape: the instruction counts
-           #  differ by the pairs that survive the gates, a few per cent of the bin walk, which itself is a few per cent of the launch)
+           # (no committed counters for this workload -- the preprocessed scans are other clouds than the resident line's: the PMC-derived fields stay null, without a warning)
            "roofline": build_roofline("A", "projective", n, args.map_points, args.iterations, nb, 0.0, n, data[0]["points"] / float(n), k_ms or float("nan"), len(kernel_ms), clk,
-                                      float(np.median(wg_ms)) if wg_ms else None)}
+                                      float(np.median(wg_ms)) if wg_ms else None, use_counters=False)}
     out["roofline"]["kernel_ms_is"] = "k_align on these scans ONE LAUNCH AT A TIME (40 synchronous launches after the streamed region): streamed launches overlap two at a time"
-    out["roofline"]["counters_note"] = "instruction and traffic counts are the resident line's committed ones (same map, same shape of batch; these scans are preprocessed clouds, not analytic ones): fractions here are indicative"
+    out["roofline"]["counters_note"] = ("no PMC pass was taken on these clouds (preprocessed scans: PCA normals on 2 cm voxels, another survivor set than the resident line's analytic "
+                                        "scans): achieved / frac stay null rather than being priced with the resident line's instruction counts; launch time and clock are measured")
     for s_ in sets:
         s_.close()
     fx.close()
