@@ -173,7 +173,7 @@ int  lsm2d_create(int device_id, void* hip_stream, lsm2d_context** out_ctx);
 void lsm2d_destroy(lsm2d_context* ctx);
 /* blocks until everything queued on the context's stream has finished */
 int  lsm2d_synchronize(lsm2d_context* ctx);
-/* Options: the WHOLE public set (14 keys; anything else is LSM2D_BAD_ARGUMENT "unknown option").  Results never depend on any of them but "sum_order".
+/* Options: the WHOLE public set (15 keys; anything else is LSM2D_BAD_ARGUMENT "unknown option").  Results never depend on any of them but "sum_order".
  * "sum_order": 0 (default) = H, b and the chi^2 statistics of an iteration are added in TREES (a thread's pairs, then the 64 lanes of a wave, then the eight
  *   waves): the fast order.  1 = added PAIR AFTER PAIR in the order of the reference's correspondence vector -- ascending canvas column for the projective
  *   finder (registration/correspondence_finder_projective_2d.cpp:55-74), ascending moving index for the point-query finders
@@ -181,9 +181,12 @@ int  lsm2d_synchronize(lsm2d_context* ctx);
  *   totals added in slice order.  Both orders use the same per-pair terms and the same fused operations; they differ in the association of fp32 sums,
  *   i.e. in the last bits of H and b, which a pair sitting on a gate can turn into another correspondence set a few iterations later (PARITY.md section 0).
  *   With 1 the aligner (lsm2d_align_batch and its begin / wait / pairs forms, every finder kind, priors, sensor offsets, the split path) and
- *   lsm2d_linearize equal the sequential fp32 oracle (oracle/: lsmo_align_f, lsmo_linearize_f) BIT FOR BIT.  Cost: the pairs' terms go through LDS (18 KB
- *   more per workgroup) and eleven lanes add them one after the other: configs[1] (1000 scans vs a 100k-point map) runs at about 0.8 of the default
- *   order's rate.  Calls the latency kernel would take (align_path 3) run on k_align instead: "last_align_path" reads 1.
+ *   lsm2d_linearize equal the sequential fp32 oracle (oracle/: lsmo_align_f, lsmo_linearize_f) BIT FOR BIT.  Cost: the pairs' terms go through LDS (14 KB
+ *   more per workgroup) and eleven lanes add them one after the other: configs[1] (1000 scans vs a 100k-point map) takes 1.46 x the default
+ *   order's step (844 k against 1.23 M alignments/s: DESIGN.md section 5).  Calls the latency kernel would take (align_path 3) run on k_align instead: "last_align_path" reads 1.
+ * "align_width": threads per workgroup of a culled projective batch (k_align): 0 = automatic (default: 512; 256 -- six alignments per CU round instead of four -- for batches
+ *   just above a multiple of 1024 alignments, where the last few would otherwise run a round of their own on an empty chip), 512 / 256 = always that width.  The narrow
+ *   workgroups keep the wide kernel's 512 virtual threads in the bin walk and the sums: bit-identical results (get: "last_align_width").
  * "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align), 2 = always the split path (k_split_project +
  *   k_split_finish per iteration; projective slices only), 3 = the latency kernel whenever the batch has one or two projective slices
  *   (k_align_pair: 512 threads per slice, two slices' passes side by side in one workgroup; automatic for <= 256 alignments).  All paths return
