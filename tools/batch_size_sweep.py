@@ -36,7 +36,7 @@ def main():
     args = ap.parse_args()
     from srrg2_laser_slam_2d_amd import api, synth
     sizes = [int(v) for v in args.sizes.split(",")]
-    wl = synth.make_workload(max(sizes), args.map_points, seed=0, n_beams=args.beams)
+    wl = synth.make_workload(max(8192, max(sizes)), args.map_points, seed=0, n_beams=args.beams)      # (always the same 8192 scans: the sampled poses depend on how many are drawn)
     ctx = api.Context(0, kernel_timing=False)
     opts = {}
     for kv in filter(None, args.options.split(",")):
