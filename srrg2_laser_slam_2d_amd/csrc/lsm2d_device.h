@@ -638,17 +638,85 @@ LSM2D_DEV void seq_store(float* rec, int slot, const float (&t)[kSeqFields]) {
 #pragma unroll
   for (int f = 0; f < kSeqFields / 2; ++f) r[f] = make_float2(t[2 * f], t[2 * f + 1]);
 }
-// Every lane of ONE wave calls (lanes 11..63 walk along like lane 0 and hold nothing of value): `acc` is lane q's running sum of quantity q in the order
-// h00 h01 h02 h11 h12 h22 b0 b1 b2 chi_in chi_out (Accum's).  Records 0 .. n-1 of the half-trip in ascending slot.
-#ifndef LSM2D_SEQ_UNROLL
-#define LSM2D_SEQ_UNROLL 2      // records per group; two groups in flight (2 / 3 / 4 / 6: 1.119 / 1.143 / 1.115 / 1.199 ms on configs[1]; 4 and up spill at 64 registers)
+// The walk, one wave.  The chain of a quantity is serial -- acc = fma(x1, y1, acc); acc = fma(x2, y2, acc), record after record -- and what a single lane walking
+// it pays per record is the LDS round trip of the record's operands as far as nothing covers it: the first form of this round (lane q < 11 walks quantity q, two
+// groups of two records in flight: all the registers the kernel has for it) took 44 cycles per record.  Now a QUAD of lanes walks a quantity: lane j of quad q
+// (lane 4 q + j) holds the operands of records 8 b + 2 j and 8 b + 2 j + 1 of batch b, so ONE pair of LDS reads per operand brings eight records, and the running
+// sum travels round the quad -- quad_perm:[3,0,1,2], one DPP move -- picking up each lane's two records in ascending record order: lane 0 takes it from lane 3
+// (the previous batch's end), adds records 8 b and 8 b + 1, lane 1 takes it from lane 0, ...  Every lane executes every step; the value that counts is in lane s
+// after step s, what the other lanes compute meanwhile is overwritten before it is ever read on the chain.  Per record: two fused adds + half a move = 2.5
+// vector instructions on the chain and an eighth of the LDS reads, the next batch's loads in flight under this batch's twenty instructions.  The same fused operations on
+// the same values in the same order as before: the same bits (the tests hold the kernel against the sequential CPU restatement bit for bit).
+// `acc`: the caller keeps it per lane between calls (zero at first, in all lanes); the running sum of quantity q is lane 4 q + 3's after every call -- seq_total()
+// brings it to lane q.  Records n .. 8 ceil(n / 8) - 1 of the half-trip must hold "no pair" records (every caller's threads write all the slots of a half-trip).
+#ifndef LSM2D_SEQ_WALK_QUADS
+#define LSM2D_SEQ_WALK_QUADS 1      // 0: the single-lane walk (A/B: profiles/r06/sum_order_walker_quads_ab_r06.txt)
 #endif
+// Measured (tools/seq_walk_probe.py: cycles per record in isolation; configs[1] with "sum_order" 1: k_align_seq ms; profiles/r06/sum_order_walker_quads_ab_r06.txt):
+//   single lane 44 / 1.123;  quads, R records per lane and batch, B batches in registers: R 1 B 4: 44 / 1.114;  R 2 B 2 (shipped): 30 / 0.955-0.961;  R 2 B 3: 28 / 0.971;
+//   R 4 B 2: 23 / 0.944 with 48 bytes of scratch in the headline instantiation.  The cost is ~14 cycles for a record's two dependent fused adds + ~30 per move of the
+//   sum to the next lane (a DPP result feeding the chain), i.e. per R records.  Bringing the OPERANDS to the sum instead (quad broadcasts, the x operand as
+//   v_fmac_f32_dpp's own): 33-37 / 1.04-1.06 -- four DPP instructions per record cost more than half a move.  Loads pinned ahead of the chain (sched_barrier): slower.
+#ifndef LSM2D_SEQ_QUAD_R
+#define LSM2D_SEQ_QUAD_R 2
+#endif
+#ifndef LSM2D_SEQ_QUAD_BUFS
+#define LSM2D_SEQ_QUAD_BUFS 2
+#endif
+#ifndef LSM2D_SEQ_UNROLL
+#define LSM2D_SEQ_UNROLL 2      // single-lane walk: records per group; two groups in flight (2 / 3 / 4 / 6: 1.119 / 1.143 / 1.115 / 1.199 ms on configs[1]; 4 and up spill at 64 registers)
+#endif
+LSM2D_DEV float seq_quad_prev(float v) {      // lane 4 q + j <- lane 4 q + (j + 3) % 4
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93 /* quad_perm:[3,0,1,2] */, 0xF, 0xF, true));
+}
 LSM2D_DEV float seq_walk(const float* rec, int n, int lane, float acc) {
   asm volatile("" : "+v"(lane));      // (the lane's field offsets are made HERE, every time: as loop invariants of the iteration loop they are registers held -- and spilled -- across the whole kernel)
+#if LSM2D_SEQ_WALK_QUADS
+  const int q = (lane >> 2) < 11 ? (lane >> 2) : 0, j = lane & 3;      // (quads 11 .. 15 walk along like quad 0 and hold nothing of value)
+#else
   const int q = lane < 11 ? lane : 0;
+#endif
   const bool chi = q >= 9, has2 = q == 5 || q == 8;
   const int fx1 = (int) ((0xBA654655444ull >> (4 * q)) & 15), fy1 = chi ? 12 : (int) ((0x00333221210ull >> (4 * q)) & 15);      // field of x1 (wa_i, or the chi term) and of y1 (a_j, e0, or the constant 1)
   const int fx2 = has2 ? 7 : 13, fy2 = has2 ? (q == 5 ? 8 : 9) : 13;                                                             // w and dd / de; elsewhere the constant 0 twice
+#if LSM2D_SEQ_WALK_QUADS
+  constexpr int kR = LSM2D_SEQ_QUAD_R, kBufs = LSM2D_SEQ_QUAD_BUFS;      // records per lane and batch; batches in registers
+  const float* r0 = rec + kR * j * kSeqFields;      // this lane's first record of batch 0
+  const float* px1 = r0 + fx1; const float* py1 = r0 + fy1; const float* px2 = r0 + fx2; const float* py2 = r0 + fy2;
+  constexpr int kBatch = 4 * kR * kSeqFields;      // floats from one batch to the next
+  struct Ops { float x1[kR], y1[kR], x2[kR], y2[kR]; };
+  auto load = [&](int b) {
+    Ops o; const int off = b * kBatch;
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { o.x1[r] = px1[off + r * kSeqFields]; o.y1[r] = py1[off + r * kSeqFields]; o.x2[r] = px2[off + r * kSeqFields]; o.y2[r] = py2[off + r * kSeqFields]; }
+    return o;
+  };
+  auto chain = [&](const Ops& o) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float t = seq_quad_prev(acc);
+#pragma unroll
+      for (int r = 0; r < kR; ++r) { t = __builtin_fmaf(o.x1[r], o.y1[r], t); t = __builtin_fmaf(o.x2[r], o.y2[r], t); }
+      acc = t;
+    }
+  };
+  const int nb = (n + 4 * kR - 1) / (4 * kR);
+  if (nb <= 0) return acc;
+  Ops buf[kBufs];
+#pragma unroll
+  for (int i = 0; i + 1 < kBufs; ++i) buf[i] = load(i < nb ? i : nb - 1);
+  for (int b = 0; b < nb; b += kBufs) {      // buf[i] holds batch b + i; the free buffer takes batch b + i + kBufs - 1 (past the end: the last batch again, never used)
+#pragma unroll
+    for (int i = 0; i < kBufs; ++i) {
+      if (b + i < nb) {
+        const int nxt = b + i + kBufs - 1;
+        buf[(i + kBufs - 1) % kBufs] = load(nxt < nb ? nxt : nb - 1);
+        chain(buf[i]);
+      }
+    }
+  }
+  return acc;
+#else
   const float* px1 = rec + fx1; const float* py1 = rec + fy1; const float* px2 = rec + fx2; const float* py2 = rec + fy2;
   // two groups of kU records in flight: the NEXT group's loads are issued before this group's dependent adds run
   constexpr int kU = LSM2D_SEQ_UNROLL;
@@ -675,6 +743,16 @@ LSM2D_DEV float seq_walk(const float* rec, int n, int lane, float acc) {
   }
   for (; k < n; ++k) { acc = __builtin_fmaf(px1[k * kSeqFields], py1[k * kSeqFields], acc); acc = __builtin_fmaf(px2[k * kSeqFields], py2[k * kSeqFields], acc); }
   return acc;
+#endif
+}
+// the walk's result for lane q < 11 of the walking wave: the running sum of quantity q (every lane of the wave calls)
+LSM2D_DEV float seq_total(float acc, int lane) {
+#if LSM2D_SEQ_WALK_QUADS
+  const int src = lane < 11 ? 4 * lane + 3 : lane;
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(4 * src, __float_as_int(acc)));
+#else
+  return acc;
+#endif
 }
 
 // ---- wave64 / workgroup reduction: shuffle butterfly, one LDS hop, fixed order => deterministic ----

@@ -275,7 +275,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
       const Iso T = s_iso[s];
       const uint32_t salt = (uint32_t) s * 0x632BE5ABu;
       Accum acc; accum_zero(acc);
-      float seq_acc = 0.0f;      // kSeq: lane q < 11 of wave 0 holds the slice's running sum of quantity q (in Accum's order); the counts stay in acc
+      float seq_acc = 0.0f;      // kSeq: wave 0's lanes carry the slice's eleven running sums (in Accum's order) from trip to trip: seq_walk / seq_total; the counts stay in acc
       // kSeq: a matched pair becomes a record instead of being added into the thread's partial sums
       auto seq_pair = [&](float2 pf, float2 nf, float2 pm, float2 nm, float (&t)[kSeqFields]) {
         bool inl; pair_terms(T, pf, nf, pm, nm, S.cauchy != 0, S.tau, inl_only, t, inl);
@@ -684,7 +684,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
       if (tid < 64) {
         // lanes 0..13 of wave 0 each add one quantity over the waves (wave order) and then into the iteration's sum themselves
         float v; int vi; block_reduce_gather_lane(red, kAlignBlock / 64, tid, v, vi);
-        if constexpr (kSeq) v = seq_acc;      // (the partial sums' floats were never touched: the eleven quantities are the walker's)
+        if constexpr (kSeq) v = seq_total(seq_acc, tid);      // (the partial sums' floats were never touched: the eleven quantities are the walker's)
         const int n_corr = __builtin_amdgcn_readlane(vi, 13);
         if (tid == 0) s_n_corr += n_corr;
         if (n_corr > S.min_corr) {     // slices with #pairs <= min_num_correspondences are skipped

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kAlignBlock) void k_split_finish(const SplitArgs S)
     __syncthreads();
     if (tid < 64) {
       float v; int vi; block_reduce_gather_lane(red, nwaves, tid, v, vi);
-      if constexpr (kSeq) v = seq_acc;
+      if constexpr (kSeq) v = seq_total(seq_acc, tid);
       const int n_corr = __builtin_amdgcn_readlane(vi, 13);
       if (tid == 0) s_n_corr += n_corr;
       if (n_corr > SL.min_corr) {
@@ -452,7 +452,8 @@ __global__ __launch_bounds__(kAlignBlock) void k_linearize_seq(const LinArgs A) 
   __syncthreads();
   if (tid < 64) {
     float v; int vi; block_reduce_gather_lane(red, kAlignBlock / 64, tid, v, vi);
-    if (tid < 11) A.out[tid] = seq_acc;
+    const float tot = seq_total(seq_acc, tid);
+    if (tid < 11) A.out[tid] = tot;
     else if (tid < kAccumWords) A.out[tid] = __int_as_float(vi);
     if (tid == 0 && A.dig) *A.dig = (unsigned long long) s_dig;
   }
