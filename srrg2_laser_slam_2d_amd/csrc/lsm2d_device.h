@@ -669,6 +669,7 @@ LSM2D_DEV void seq_store(float* rec, int slot, const float (&t)[kSeqFields]) {
 LSM2D_DEV float seq_quad_prev(float v) {      // lane 4 q + j <- lane 4 q + (j + 3) % 4
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93 /* quad_perm:[3,0,1,2] */, 0xF, 0xF, true));
 }
+template <bool kTopPriority = false>      // kTopPriority: s_setprio 3 once the walk's addresses are made (k_align_seq: the caller says when it ends)
 LSM2D_DEV float seq_walk(const float* rec, int n, int lane, float acc) {
   asm volatile("" : "+v"(lane));      // (the lane's field offsets are made HERE, every time: as loop invariants of the iteration loop they are registers held -- and spilled -- across the whole kernel)
 #if LSM2D_SEQ_WALK_QUADS
@@ -703,6 +704,7 @@ LSM2D_DEV float seq_walk(const float* rec, int n, int lane, float acc) {
   const int nb = (n + 4 * kR - 1) / (4 * kR);
   if (nb <= 0) return acc;
   Ops buf[kBufs];
+  if constexpr (kTopPriority) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int i = 0; i + 1 < kBufs; ++i) buf[i] = load(i < nb ? i : nb - 1);
   for (int b = 0; b < nb; b += kBufs) {      // buf[i] holds batch b + i; the free buffer takes batch b + i + kBufs - 1 (past the end: the last batch again, never used)

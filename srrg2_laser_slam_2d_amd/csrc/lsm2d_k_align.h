@@ -289,7 +289,11 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
           if (writer && slot >= h0 && slot < h0 + kSeqHalf) seq_store(l_rec, slot - h0, t);
           __syncthreads();
           const int left = n_rec - h0;
-          if (tid < 64) seq_acc = seq_walk(l_rec, left < kSeqHalf ? left : kSeqHalf, tid, seq_acc);
+          if (tid < 64) {
+            // (LSM2D_SEQ_WALK_PRIO: the walking wave ahead of the other workgroups' streams on its SIMD -- its workgroup's other seven waves wait for it, and for the
+            // solve, which is thread 0's: the wave keeps the priority until the next iteration sets the one its progress earns)
+            seq_acc = seq_walk<LSM2D_SEQ_WALK_PRIO != 0>(l_rec, left < kSeqHalf ? left : kSeqHalf, tid, seq_acc);
+          }
           __syncthreads();
         }
       };

@@ -40,6 +40,9 @@ LSM2D_HD int cull_block_steps(int T, int nbs = kCullBlocks) { return 2 * ((T + 2
 // launch), so the last workgroup of a CU ends up alone, with nobody to issue under its barriers, bin walks and solves.  A
 // workgroup that lowers its priority as it advances lets the ones behind it catch up: all of a CU's workgroups finish together.
 // 0 off (1.86 ms on configs[1]), 1 quarters of the iterations (1.69), 2 halving intervals -- 1/2, 3/4, 7/8 (1.65).
+#ifndef LSM2D_SEQ_WALK_PRIO
+#define LSM2D_SEQ_WALK_PRIO 1      // k_align_seq: the walking wave at top priority while it walks (configs[1], "sum_order" 1: 0.954 -> 0.937 ms; profiles/r06/sum_order_walker_quads_ab_r06.txt)
+#endif
 #ifndef LSM2D_PRIO_BY_PROGRESS
 #define LSM2D_PRIO_BY_PROGRESS 2
 #endif
