@@ -69,9 +69,25 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
 #ifdef LSM2D_PHASE_PROBE      // diagnostics build: thread 0 sums the cycles it spends in the query / projection phase, at the barrier + reduction, and in the solve
   __shared__ unsigned long long s_ph[4];
   if (tid == 0) { s_ph[0] = s_ph[1] = s_ph[2] = 0; s_ph[3] = __builtin_amdgcn_s_memtime(); }
-#define LSM2D_PH(k) do { if (tid == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); s_ph[k] += now__ - s_ph[3]; s_ph[3] = now__; } } while (0)
+#define LSM2D_PH_STAMP(k) do { if (tid == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); s_ph[k] += now__ - s_ph[3]; s_ph[3] = now__; } } while (0)
+  // -DLSM2D_PHASE_PROBE=1 (or empty): the three buckets above.  =2: unit lists + stream | bin walk + reduction | solve + the rest.  =3: unit lists | stream | everything else.
+#if LSM2D_PHASE_PROBE + 0 == 2
+#define LSM2D_PH(k) LSM2D_PH_STAMP((k) == 0 ? 1 : (k))
+#define LSM2D_PH_LISTS() do { } while (0)
+#define LSM2D_PH_STREAM() LSM2D_PH_STAMP(0)
+#elif LSM2D_PHASE_PROBE + 0 == 3
+#define LSM2D_PH(k) LSM2D_PH_STAMP(2)
+#define LSM2D_PH_LISTS() LSM2D_PH_STAMP(0)
+#define LSM2D_PH_STREAM() LSM2D_PH_STAMP(1)
+#else
+#define LSM2D_PH(k) LSM2D_PH_STAMP(k)
+#define LSM2D_PH_LISTS() do { } while (0)
+#define LSM2D_PH_STREAM() do { } while (0)
+#endif
 #else
 #define LSM2D_PH(k) do { } while (0)
+#define LSM2D_PH_LISTS() do { } while (0)
+#define LSM2D_PH_STREAM() do { } while (0)
 #endif
   if (A.wg_place && tid == 0) A.wg_place[blockIdx.x] = place_key();
   // the XCD lockstep (AlignArgs::xcd_sync): this workgroup's counters are its XCD's; it counts itself in before anything else
@@ -371,6 +387,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
               __syncthreads();
             }
             if (lists_only) continue;
+            LSM2D_PH_LISTS();
             const int n_units = __builtin_amdgcn_readfirstlane(s_nunits[s]);
             if (n_units > 0) project_cloud_list<kW>(S.moving.lane_xy + S.moving.lane_start[mc], Tm, T, S.proj, mcan, tid, kAlignBlock, units, n_units, B);
           }
@@ -412,6 +429,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
           else project_cloud(S.moving.xy + S.moving.start[mc], S.moving.count[mc], T, S.proj, mcan, tid, kAlignBlock);
         }
         __syncthreads();
+        LSM2D_PH_STREAM();
         if (kXcdWindow && xsync && tid == 0 && it * A.n_slices + s < A.xcd_positions)      // this workgroup's pass (it, s) over the map is behind all its waves
           __hip_atomic_fetch_add(&xsync[16 + it * A.n_slices + s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // bin walk (correspondence_finder_projective_2d.cpp:55-74): the fixed side comes from LDS, the two gathers of the
