@@ -192,4 +192,12 @@ KNOWN_ILL_CONDITIONED = {
     ("parameters", 42, 415, 0),        # 0.87 m (2.0 m)
     ("parameters", 123, 204, 0),       # 1.9e-2 m (the same 1.9e-2 m)
     ("parameters", 8675309, 175, 0),   # 5.6 m (7.6 m)
+    # ... and seven more of the same kind from eighteen FRESH seeds (profiles/r06/fuzz_soak_fresh_seeds_r06I.log; no alignment of those seeds lies outside the envelope)
+    ("parameters", 303, 310, 0),       # oracles 4.4 m / 0.22 rad from fp64 (device 2.4 m / 0.14 rad)
+    ("parameters", 505, 12, 0),        # 11.2 m (12.0 m)
+    ("parameters", 606, 405, 0),       # 214 m (118 m)
+    ("parameters", 808, 219, 0),       # 0.49 m (2.8e-2 m)
+    ("parameters", 1234, 142, 0),      # 2.0 m (2.9 m)
+    ("parameters", 4321, 159, 0),      # 1.3 m (0.32 m)
+    ("parameters", 9999, 243, 0),      # 2.1 m (0.51 m)
 }
