@@ -293,26 +293,39 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
       Accum acc; accum_zero(acc);
       float seq_acc = 0.0f;      // kSeq: wave 0's lanes carry the slice's eleven running sums (in Accum's order) from trip to trip: seq_walk / seq_total; the counts stay in acc
       // kSeq: a matched pair becomes a record instead of being added into the thread's partial sums
+      bool seq_have = false;      // kSeq: this thread holds a pair of the current trip
       auto seq_pair = [&](float2 pf, float2 nf, float2 pm, float2 nm, float (&t)[kSeqFields]) {
         bool inl; pair_terms(T, pf, nf, pm, nm, S.cauchy != 0, S.tau, inl_only, t, inl);
         ++acc.n_corr; acc.n_in += inl ? 1 : 0; acc.n_out += inl ? 0 : 1;
+        seq_have = true;
       };
-      // kSeq: the end of a trip -- every thread's record (zeros: no pair) is in LDS behind the first barrier, wave 0 adds the trip's n_rec records in ascending
-      // slot, and nobody overwrites them before the second
-      // (in halves of kSeqHalf records: 12 KB of LDS instead of 24, three workgroups per CU)
-      auto seq_trip = [&](int slot, bool writer, const float (&t)[kSeqFields], int n_rec) {
-        for (int h0 = 0; h0 < n_rec; h0 += kSeqHalf) {
-          if (writer && slot >= h0 && slot < h0 + kSeqHalf) seq_store(l_rec, slot - h0, t);
-          __syncthreads();
-          const int left = n_rec - h0;
-          if (tid < 64) {
-            // (LSM2D_SEQ_WALK_PRIO: the walking wave ahead of the other workgroups' streams on its SIMD -- its workgroup's other seven waves wait for it, and for the
-            // solve, which is thread 0's: the wave keeps the priority until the next iteration sets the one its progress earns)
-            seq_acc = seq_walk<LSM2D_SEQ_WALK_PRIO != 0>(l_rec, left < kSeqHalf ? left : kSeqHalf, tid, seq_acc);
-          }
-          __syncthreads();
+      // kSeq: the end of a trip.  The trip's PAIRS are compacted in thread order -- ascending column for the projective walk, ascending moving index for the queries: the
+      // reference's order (a slot without a pair would add fma(+0, +0, h) == h: leaving it out changes no bit, and on the tracker's wiring of the point-query finders a
+      // trip of 512 queries holds a handful of pairs) -- and APPENDED to the records in LDS (kSeqHalf of them: 14 KB); wave 0 walks them, in ascending position, whenever
+      // the buffer is full and once more at the end of the slice (seq_flush): a walk costs two barriers, and the queries' 196 trips per iteration on configs[1] fill
+      // the buffer three or four times.  One barrier per trip (the compaction's); the stores of later trips go to other slots than those of earlier ones, and every walk
+      // stands between two barriers of its own.
+      int seq_fill = 0;      // records waiting in LDS (the same in every thread)
+      auto seq_walk_buffer = [&](int n) {      // n records in LDS, "no pair" records up to the next multiple of eight (seq_walk takes eight at a time)
+        if (tid < ((n + 7) & ~7) - n) { float z[kSeqFields]; seq_zero(z); seq_store(l_rec, n + tid, z); }
+        __syncthreads();
+        // (LSM2D_SEQ_WALK_PRIO: the walking wave ahead of the other workgroups' streams on its SIMD -- its workgroup's other seven waves wait for it, and for the
+        // solve, which is thread 0's: the wave keeps the priority until the next iteration sets the one its progress earns)
+        if (tid < 64) seq_acc = seq_walk<LSM2D_SEQ_WALK_PRIO != 0>(l_rec, n, tid, seq_acc);
+        __syncthreads();
+      };
+      auto seq_trip = [&](const float (&t)[kSeqFields], int parity /* 0, 1, 0, ... from trip to trip: s_wcnt's two buffers */) {
+        int n_rec = 0;
+        const int pos = block_compact_pos(seq_have, s_wcnt, parity, n_rec, tid, kAlignBlock / 64);      // (one barrier; n_rec: the trip's pairs, the same in every thread)
+        for (int done = 0; done < n_rec; ) {
+          const int room = kSeqHalf - seq_fill, take = n_rec - done < room ? n_rec - done : room;
+          if (seq_have && pos >= done && pos < done + take) seq_store(l_rec, seq_fill + pos - done, t);
+          seq_fill += take; done += take;
+          if (seq_fill == kSeqHalf) { seq_walk_buffer(kSeqHalf); seq_fill = 0; }
         }
+        seq_have = false;
       };
+      auto seq_flush = [&]() { if (seq_fill > 0) { seq_walk_buffer(seq_fill); seq_fill = 0; } };      // the end of the slice's pairs: what is still waiting
       LSM2D_PH(2);
       if (kHasProj && ((!kHasNN && !kHasDist && !kHasKd) || S.finder == LSM2D_FINDER_PROJECTIVE)) {
         {
@@ -464,8 +477,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
                 }
               }
             }
-            const int left = S.proj.cols - col0;
-            seq_trip(tid, true, t, left < kAlignBlock ? left : kAlignBlock);
+            seq_trip(t, (col0 / kAlignBlock) & 1);
           }
         }
         else if constexpr (kW != kAlignBlock) {
@@ -681,10 +693,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
                 accumulate_pair(T, fp[best], nf, pm, nm, S.cauchy != 0, S.tau, acc, inl_only);
               }
             }
-            if constexpr (kSeq) {      // "sum_order" 1: the trip's queries are per_step consecutive moving indices, slot = query - first query of the trip
-              const int left = nm_pts - j0;
-              seq_trip(tid / group, sub == 0, t, left < per_step ? left : per_step);
-            }
+            if constexpr (kSeq) seq_trip(t, (j0 / per_step) & 1);      // "sum_order" 1: the trip's queries are per_step consecutive moving indices (one lane per query holds its pair: ascending thread = ascending query)
           }
         };
         // (the cooperative search on a scan-sized fixed cloud with its tables in LDS: 2 / 4 / 8 lanes per query take 21 / 41 / 90 ms against
@@ -698,6 +707,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
         if (!kNNLds && coop) query_loop(std::integral_constant<int, kNNGroup>{});
         else query_loop(std::integral_constant<int, 1>{});
       }
+      if constexpr (kSeq) seq_flush();
       LSM2D_PH(0);
       // (a projective slice's thread accumulates at most ceil(cols / block) pairs: its counts are a few bits, summed by ballots)
       if constexpr (kW == kAlignBlock)      // (the narrow workgroups' virtual waves have written their rows in the walk)
