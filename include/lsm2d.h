@@ -183,7 +183,8 @@ int  lsm2d_synchronize(lsm2d_context* ctx);
  *   With 1 the aligner (lsm2d_align_batch and its begin / wait / pairs forms, every finder kind, priors, sensor offsets, the split path) and
  *   lsm2d_linearize equal the sequential fp32 oracle (oracle/: lsmo_align_f, lsmo_linearize_f) BIT FOR BIT.  Cost: the pairs' terms go through LDS (14 KB
  *   more per workgroup) and one wave adds them one after the other (a quad of lanes per quantity): configs[1] (1000 scans vs a 100k-point map) takes
- *   about 1.27 x the default order's step (0.98 M against 1.23 M alignments/s: DESIGN.md section 5).  Calls the latency kernel would take (align_path 3) run on k_align instead: "last_align_path" reads 1.
+ *   about 1.2 x the default order's step (1.03 M against 1.24 M alignments/s: DESIGN.md section 5; the point-query finders in the tracker's wiring, whose 100 000
+ *   queries per iteration all pass a barrier per 512, 3 - 5 x).  Calls the latency kernel would take (align_path 3) run on k_align instead: "last_align_path" reads 1.
  * "align_width": threads per workgroup of a culled projective batch (k_align): 0 = automatic (default: 512; 256 -- six alignments per CU round instead of four -- for batches
  *   just above a multiple of 1024 alignments, where the last few would otherwise run a round of their own on an empty chip), 512 / 256 = always that width.  The narrow
  *   workgroups keep the wide kernel's 512 virtual threads in the bin walk and the sums: bit-identical results (get: "last_align_width").
