@@ -648,7 +648,7 @@ LSM2D_DEV void seq_store(float* rec, int slot, const float (&t)[kSeqFields]) {
 // vector instructions on the chain and an eighth of the LDS reads, the next batch's loads in flight under this batch's twenty instructions.  The same fused operations on
 // the same values in the same order as before: the same bits (the tests hold the kernel against the sequential CPU restatement bit for bit).
 // `acc`: the caller keeps it per lane between calls (zero at first, in all lanes); the running sum of quantity q is lane 4 q + 3's after every call -- seq_total()
-// brings it to lane q.  Records n .. 8 ceil(n / 8) - 1 of the half-trip must hold "no pair" records (every caller's threads write all the slots of a half-trip).
+// brings it to lane q.  Records n .. 8 ceil(n / 8) - 1 of the buffer must hold "no pair" records (k_align_seq, which walks its pairs only, pads them; the split path's kernels write every slot of a half-trip).
 #ifndef LSM2D_SEQ_WALK_QUADS
 #define LSM2D_SEQ_WALK_QUADS 1      // 0: the single-lane walk (A/B: profiles/r06/sum_order_walker_quads_ab_r06.txt)
 #endif
