@@ -185,9 +185,11 @@ int  lsm2d_synchronize(lsm2d_context* ctx);
  *   more per workgroup) and one wave adds them one after the other (a quad of lanes per quantity): configs[1] (1000 scans vs a 100k-point map) takes
  *   about 1.2 x the default order's step (1.03 M against 1.24 M alignments/s: DESIGN.md section 5; the point-query finders in the tracker's wiring, whose 100 000
  *   queries per iteration all pass a barrier per 512, 3 - 5 x).  Calls the latency kernel would take (align_path 3) run on k_align instead: "last_align_path" reads 1.
- * "align_width": threads per workgroup of a culled projective batch (k_align): 0 = automatic (default: 512; 256 -- six alignments per CU round instead of four -- for batches
- *   just above a multiple of 1024 alignments, where the last few would otherwise run a round of their own on an empty chip), 512 / 256 = always that width.  The narrow
- *   workgroups keep the wide kernel's 512 virtual threads in the bin walk and the sums: bit-identical results (get: "last_align_width").
+ * "align_width": the launch form of a culled projective batch (k_align): 0 = automatic (default: workgroups of 512 threads; of 256 -- six alignments per CU round instead
+ *   of four -- for batches just above a multiple of 1024 alignments, where the last few would otherwise run a round of their own on an empty chip; PACKED -- one round
+ *   of 1024 workgroups, the lightest alignments two to a workgroup, one after the other -- for 1025 .. 1048 and 1537 .. 2047 alignments), 512 / 256 = always that
+ *   width, 1024 = packed whenever the batch has 1025 .. 2047 alignments.  The narrow workgroups keep the wide kernel's 512 virtual threads in the bin walk and the
+ *   sums, a packed workgroup runs the same kernel body twice: bit-identical results (get: "last_align_width": 512, 256, or 1024 for a packed launch).
  * "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align), 2 = always the split path (k_split_project +
  *   k_split_finish per iteration; projective slices only), 3 = the latency kernel whenever the batch has one or two projective slices
  *   (k_align_pair: 512 threads per slice, two slices' passes side by side in one workgroup; automatic for <= 256 alignments).  All paths return

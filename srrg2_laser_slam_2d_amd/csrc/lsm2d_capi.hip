@@ -491,7 +491,7 @@ const OptionDesc kOptions[] = {
   {"distmap_build",      &lsm2d_context::distmap_build,      0, 1,          0},
   {"kd_lds_nodes",       &lsm2d_context::kd_lds_nodes,       0, 4096,       0},
   {"sum_order",          &lsm2d_context::sum_order,          0, 1,          0},
-  {"align_width",        &lsm2d_context::align_width,        0, 512,        0},
+  {"align_width",        &lsm2d_context::align_width,        0, 1024,       0},
   // ---- read-only
   {"last_align_path",    &lsm2d_context::last_align_path,    0, 0, kOptReadOnly},
   {"last_align_width",   &lsm2d_context::last_align_width,   0, 0, kOptReadOnly},

@@ -9,7 +9,7 @@
 // thread t plays virtual threads t, t + kW, ... one after the other, each with its own partial sums, its waves' trees written to the same eight rows of `red` --
 // so every result keeps its bits (tests: 256 against 512).
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0, bool kFirstStage = false, bool kSeq = false, int kW = kAlignBlock>
-LSM2D_DEV void align_body(const AlignArgs& A) {
+LSM2D_DEV void align_body(const AlignArgs& A, int a_given = -1) {
   static_assert(kW == kAlignBlock || (kNNMode == 5 && !kFirstStage && !kSeq && kW % 64 == 0 && kW >= 256 && kW < kAlignBlock), "narrow workgroups: the culled projective stream only");
   __builtin_assume(A.n_slices >= 1 && A.n_slices <= kMaxSlices);      // (the host refuses anything else: the slice loops need no guard -- which, as a flag, was kept in a vector register and spilled)
   constexpr bool kNNGlobal = kNNMode == 1, kNNLds = kNNMode == 2;
@@ -62,7 +62,7 @@ LSM2D_DEV void align_body(const AlignArgs& A) {
   __shared__ PriorDev s_prior;      // read once: with zero-copy arguments A.prior is host memory, a PCIe round trip per access
 
   // (the alignment's index is wave-uniform: said so, or everything indexed by it would live in vector registers)
-  const int a = A.order ? __builtin_amdgcn_readfirstlane(A.order[blockIdx.x]) : (int) blockIdx.x, tid = threadIdx.x;
+  const int a = a_given >= 0 ? a_given : (A.order ? __builtin_amdgcn_readfirstlane(A.order[blockIdx.x]) : (int) blockIdx.x), tid = threadIdx.x;
   constexpr int nwaves = kW / 64;      // physical waves (the rows of `red` stay kAlignBlock / 64: one per VIRTUAL wave)
   constexpr int kPriorWords = (int) (sizeof(PriorDev) / sizeof(float));
   __shared__ unsigned long long s_clk[2];      // start stamps wait in LDS: no register is held across the kernel for them
@@ -830,6 +830,15 @@ constexpr int align_min_waves() {
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
 __global__ __launch_bounds__(kAlignBlock, (align_min_waves<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode>())) void k_align(const AlignArgs A) {
   align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false>(A);
+}
+// The culled projective stream with up to TWO alignments per workgroup, one after the other (AlignArgs::order2): the whole body again, from its prologue -- an
+// instantiation of its own (two copies of the body), so that the headline's kernel does not carry a loop around it (in one kernel: 80 bytes of scratch).
+__global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align_two(const AlignArgs A) {
+  align_body<true, false, false, false, 5, false>(A, __builtin_amdgcn_readfirstlane(A.order[blockIdx.x]));
+  const int a2 = __builtin_amdgcn_readfirstlane(A.order2[blockIdx.x]);
+  if (a2 < 0) return;
+  __syncthreads();      // (thread 0 is done with the first one's results before anybody overwrites the state they came from)
+  align_body<true, false, false, false, 5, false>(A, a2);
 }
 // The culled projective stream in NARROW workgroups (align_body's kW): 256 threads, six workgroups -- 1536 alignments -- resident per round where the wide kernel
 // holds 1024.  The same results as k_align<1,0,0,0,5>, bit for bit; chosen by the host (align_width_for) for batches just above a multiple of 1024 alignments.

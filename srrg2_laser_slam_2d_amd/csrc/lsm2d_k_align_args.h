@@ -97,6 +97,8 @@ struct AlignArgs {
   // "sum_order" 1 (the k_align_seq / k_split_finish<true> instantiations): byte offset in dynamic LDS of the trip's pair records, kAlignBlock x kSeqFields floats
   // (lsm2d_device.h, "sum_order"); sits in what was padding, so the other fields keep their offsets
   int32_t seq_off;
+  const int32_t* order2;                    // (round 6, k_align_two) a SECOND alignment for workgroup b to run after its first (-1: none), or nullptr: a batch of a few alignments more than
+                                            // the chip holds packs its lightest ones two to a workgroup instead of starting another dispatch round (balance_order, "packed")
   SliceDev s[kMaxSlices];
 };
 

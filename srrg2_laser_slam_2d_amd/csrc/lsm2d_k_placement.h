@@ -38,7 +38,14 @@ struct BalanceLds {                               // < 40 KB: four workgroups of
   int ngroups, bad;
 };
 static_assert(sizeof(BalanceLds) <= 39 * 1024, "k_cull_estimate: four workgroups per CU");
-LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu, int per_cu, int32_t* __restrict__ order, const int32_t* place, int tid, int nt) {
+// Round 6 (late), PACKED batches: order2 != nullptr and first-round slots < n <= 2 x slots -- the batch runs in ONE dispatch round of `slots` workgroups (k_align_two), its
+// lightest 2 E alignments (E = n - slots) two to a workgroup, one after the other: rank slots - E + j (heaviest-of-the-light) with rank n - 1 - j (lightest).  The
+// deal below then places `slots` ITEMS: item j < E = pair j, item E + r = the single alignment of rank r; an alignment counts as its chunks + kPackConst (the phases
+// outside its stream: with them a pair of light alignments is the heavy item it is -- measured: 1025 alignments 0.835 us each without the constant, 0.734 with).  The
+// pairs' sums are roughly equal and above the singles': the item order is close enough to descending for the level-by-level deal.  order[b] / order2[b]: workgroup
+// b's first and second alignment (-1: none); order + 3 x 1024 is scratch for the seconds (alignment | chunks << 16).
+static constexpr int kPackConst = 150;
+LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu, int per_cu, int32_t* __restrict__ order, const int32_t* place, int tid, int nt, int32_t* __restrict__ order2 = nullptr) {
   for (int i = tid; i < kAlignBlock + 2; i += nt) L.bin[i] = 0;
   for (int i = tid; i < kPlaceKeys / 4; i += nt) L.cnt[i] = 0;
   for (int i = tid; i < kBalMaxGroups; i += nt) L.gproj[i] = INT_MIN;
@@ -67,10 +74,23 @@ LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu
   __syncthreads();
   int first = n < n_cu * per_cu ? n : n_cu * per_cu;      // the ranks that go out in the first dispatch round
   if (first > kBalMaxFirst) first = kBalMaxFirst;
+  const bool packed = order2 != nullptr && n > first && n <= 2 * first && n <= 2048;      // (the host asks for it only then)
+  const int n_pairs = packed ? n - first : 0, n_singles = first - n_pairs;
+  int32_t* seconds = order + 3 * kBalMaxFirst;
   for (int a = tid; a < n; a += nt) {
     const int w = a < 2048 ? (int) L.wall[a] : __hip_atomic_load(&work[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int r = atomicAdd(&L.bin[w], 1);                      // rank among all alignments (ties in any order: placement only)
+    if (packed) {
+      if (r < n_singles) { L.sorted[n_pairs + r] = a; L.sw[n_pairs + r] = (unsigned short) (w + kPackConst); }
+      else if (r < first) { L.sorted[r - n_singles] = a; L.sw[r - n_singles] = (unsigned short) (w + kPackConst); }      // a pair's first
+      else __hip_atomic_store(&seconds[n - 1 - r], a | (w << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // ... and its second
+    }
+    else
     if (r < first) { L.sorted[r] = a; L.sw[r] = (unsigned short) w; } else order[r] = a;      // beyond the first round: the heaviest go first
+  }
+  if (packed) {
+    __syncthreads();
+    for (int j = tid; j < n_pairs; j += nt) L.sw[j] = (unsigned short) ((int) L.sw[j] + (__hip_atomic_load(&seconds[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16) + kPackConst);
   }
   // the groups of the first round's workgroup ids: by the previous launch's notes, or by the round-3 assumption
   for (int b = tid; b < first; b += nt) {
@@ -102,7 +122,7 @@ LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu
   __syncthreads();
   const int G = L.ngroups;
   if (bad || G > kBalMaxGroups) {                // notes this cannot use (more than 8 workgroups on a CU, more than 512 CUs): the plain heaviest-first order
-    for (int r = tid; r < first; r += nt) order[r] = L.sorted[r];
+    for (int r = tid; r < first; r += nt) { order[r] = L.sorted[r]; if (packed) order2[r] = r < n_pairs ? (__hip_atomic_load(&seconds[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFF) : -1; }
     return;
   }
   if (tid == 0) { for (int k = 0; k < kBalMaxLevels; ++k) L.lvl[k + 1] += L.lvl[k]; }      // lvl[k+1] held the groups with a k-th member: now level offsets
@@ -143,11 +163,16 @@ LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu
   // launch gains 1 %, and the rounds cost 17 .. 23 us of the step's 830: dropped.  What decides a CU's end is the sum it carries -- end = const + slope x sum,
   // the constant the same for CUs with three and with four workgroups (tools/balance_probe.py) -- and at equal ESTIMATED sums the sums of the units really
   // streamed still differ by 2.4 .. 3.3 % rms: the tail that is left, ~5 % over 256 CUs, is the estimate's, made at the start pose, not the deal's.)
-  for (int b2 = tid; b2 < first; b2 += nt) order[b2] = L.sorted[L.assign[(int) L.gid[L.wg_key[b2]] * kBalMaxLevels + L.wg_slot[b2]]];
+  for (int b2 = tid; b2 < first; b2 += nt) {
+    const int item = (int) L.assign[(int) L.gid[L.wg_key[b2]] * kBalMaxLevels + L.wg_slot[b2]];
+    order[b2] = L.sorted[item];
+    if (packed) order2[b2] = item < n_pairs ? (__hip_atomic_load(&seconds[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFF) : -1;
+  }
 }
 
 __global__ __launch_bounds__(kAlignBlock) void k_cull_estimate(const AlignArgs A, int slice, int32_t* __restrict__ work,
-                                                               int32_t* __restrict__ order /* or nullptr: counts only */, const int32_t* __restrict__ place, int n_cu, unsigned int* __restrict__ done_counter) {
+                                                               int32_t* __restrict__ order /* or nullptr: counts only */, const int32_t* __restrict__ place, int n_cu, unsigned int* __restrict__ done_counter,
+                                                               int32_t* __restrict__ order2 = nullptr /* packed batch: see balance_order */) {
   extern __shared__ __align__(16) unsigned char smem[];      // the fixed canvas; the last workgroup's BalanceLds afterwards (the host sizes it for both)
   u64* fcan = reinterpret_cast<u64*>(smem);
   __shared__ Iso s_T;
@@ -178,7 +203,7 @@ __global__ __launch_bounds__(kAlignBlock) void k_cull_estimate(const AlignArgs A
   __syncthreads();
   if (!s_last) return;
   // every other workgroup has published its count: this one deals the alignments out
-  balance_order(*reinterpret_cast<BalanceLds*>(smem), work, (int) gridDim.x, n_cu, 4, order, place, tid, kAlignBlock);
+  balance_order(*reinterpret_cast<BalanceLds*>(smem), work, (int) gridDim.x, n_cu, 4, order, place, tid, kAlignBlock, order2);
   if (tid == 0) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next call
 }
 
