@@ -68,6 +68,7 @@ struct lsm2d_context {
   int cull_block = 0;          // steps per unit of the culled stream (0: automatic, ~1/25 of a chunk; even; tuning knob)
   int sum_order = 0;           // 0: H, b and the chi^2 sums are formed in trees (a thread's pairs, 64 lanes, 8 waves: the fast order); 1: pair after pair in the reference's order
                                // (nicp_post.m:69-90: ascending column / moving index) -- bitwise the sequential fp32 CPU restatement the tests check against; k_align_seq, k_split_finish<true>, k_linearize_seq
+  int pack_extra_max = 32;     // packed batches above 2048 alignments: up to this many more than whole rounds hold (experiments build: tuning knob)
   int align_width = 0;         // threads per workgroup of a culled projective batch: 0 automatic (align_width_for), 512 / 256 forced; results never depend on it
   int last_align_width = 0;    // what the latest k_align launch used
   int cull = 1;                // k_align, projective slices: exact culling of the moving cloud against the fixed canvas (0: off; results do not depend on it)
@@ -523,6 +524,7 @@ const OptionDesc kOptions[] = {
   {"lane_streams",       &lsm2d_context::lane_streams,       0, 1,       kOptExperiment},
   {"xcd_lockstep",       &lsm2d_context::xcd_lockstep,       0, 64,      kOptExperiment},
   {"order_cluster",      &lsm2d_context::order_cluster,      0, 10000,   kOptExperiment},
+  {"pack_extra_max",     &lsm2d_context::pack_extra_max,     0, 1024,    kOptExperiment},
 #endif
 };
 const OptionDescLL kOptionsLL[] = {      // read-only, 64-bit

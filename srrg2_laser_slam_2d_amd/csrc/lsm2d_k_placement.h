@@ -43,8 +43,10 @@ static_assert(sizeof(BalanceLds) <= 39 * 1024, "k_cull_estimate: four workgroups
 // deal below then places `slots` ITEMS: item j < E = pair j, item E + r = the single alignment of rank r; an alignment counts as its chunks + kPackConst (the phases
 // outside its stream: with them a pair of light alignments is the heavy item it is -- measured: 1025 alignments 0.835 us each without the constant, 0.734 with).  The
 // pairs' sums are roughly equal and above the singles': the item order is close enough to descending for the level-by-level deal.  order[b] / order2[b]: workgroup
-// b's first and second alignment (-1: none); order + 3 x 1024 is scratch for the seconds (alignment | chunks << 16).
-static constexpr int kPackConst = 150;
+// b's first and second alignment (-1: none); order + kPackSecondsAt is scratch for the seconds (alignment | chunks << 16).  The same for a batch that fills two or
+// three rounds and a little more (n_bins = 2 or 3 x slots workgroups, dispatched round after round): the pairs are the heaviest items and all lie in the first round's deal.
+static constexpr int kPackConst = 150, kPackMaxRounds = 3;
+static constexpr int kOrderInts = 8192, kPackOrder2At = 4096, kPackSecondsAt = 4096 + kPackMaxRounds * 1024;      // lsm2d_context::d_order: [4096] order | [3072] order2 | [1024] seconds
 LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu, int per_cu, int32_t* __restrict__ order, const int32_t* place, int tid, int nt, int32_t* __restrict__ order2 = nullptr) {
   for (int i = tid; i < kAlignBlock + 2; i += nt) L.bin[i] = 0;
   for (int i = tid; i < kPlaceKeys / 4; i += nt) L.cnt[i] = 0;
@@ -74,15 +76,20 @@ LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu
   __syncthreads();
   int first = n < n_cu * per_cu ? n : n_cu * per_cu;      // the ranks that go out in the first dispatch round
   if (first > kBalMaxFirst) first = kBalMaxFirst;
-  const bool packed = order2 != nullptr && n > first && n <= 2 * first && n <= 2048;      // (the host asks for it only then)
-  const int n_pairs = packed ? n - first : 0, n_singles = first - n_pairs;
-  int32_t* seconds = order + 3 * kBalMaxFirst;
+  // (the host asks for it only then: n_bins = the whole rounds the batch fills, at most kPackMaxRounds of them -- the seconds' alignment numbers have 12 bits)
+  const int n_bins = first > 0 ? (n / first) * first : 0;
+  const bool packed = order2 != nullptr && first == n_cu * per_cu && n > n_bins && n_bins >= first && n_bins <= kPackMaxRounds * first && n - n_bins <= first && n < 4096;
+  const int n_pairs = packed ? n - n_bins : 0, n_singles = n_bins - n_pairs;
+  int32_t* seconds = order + kPackSecondsAt;
   for (int a = tid; a < n; a += nt) {
     const int w = a < 2048 ? (int) L.wall[a] : __hip_atomic_load(&work[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int r = atomicAdd(&L.bin[w], 1);                      // rank among all alignments (ties in any order: placement only)
     if (packed) {
-      if (r < n_singles) { L.sorted[n_pairs + r] = a; L.sw[n_pairs + r] = (unsigned short) (w + kPackConst); }
-      else if (r < first) { L.sorted[r - n_singles] = a; L.sw[r - n_singles] = (unsigned short) (w + kPackConst); }      // a pair's first
+      if (r < n_singles) {      // item n_pairs + r: in the first round's deal, or -- beyond it -- in its place of the heaviest-first order
+        const int item = n_pairs + r;
+        if (item < first) { L.sorted[item] = a; L.sw[item] = (unsigned short) (w + kPackConst); } else order[item] = a;
+      }
+      else if (r < n_bins) { L.sorted[r - n_singles] = a; L.sw[r - n_singles] = (unsigned short) (w + kPackConst); }      // a pair's first (n_pairs <= first: every pair is in the deal)
       else __hip_atomic_store(&seconds[n - 1 - r], a | (w << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // ... and its second
     }
     else
@@ -91,6 +98,7 @@ LSM2D_DEV void balance_order(BalanceLds& L, const int32_t* work, int n, int n_cu
   if (packed) {
     __syncthreads();
     for (int j = tid; j < n_pairs; j += nt) L.sw[j] = (unsigned short) ((int) L.sw[j] + (__hip_atomic_load(&seconds[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16) + kPackConst);
+    for (int b2 = first + tid; b2 < n_bins; b2 += nt) order2[b2] = -1;      // (beyond the first round: singles)
   }
   // the groups of the first round's workgroup ids: by the previous launch's notes, or by the round-3 assumption
   for (int b = tid; b < first; b += nt) {
