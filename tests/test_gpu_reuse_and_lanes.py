@@ -84,3 +84,37 @@ def test_last_kernel_ms_follows_the_latest_timed_launch_after_lanes_swapped(smal
         assert find_ms > 0.0 and find_ms < 0.5 * batch_ms, (find_ms, batch_ms)      # one finder pass against twenty iterations of six alignments
     finally:
         c.close()
+
+
+def test_packed_batch_kept_placement_and_asynchronous_begin(small_workload):
+    """Round 6 (late): a PACKED batch (1030 alignments in one dispatch round of 1024 workgroups, the lightest ones two to a workgroup) keeps both halves of its
+    placement -- first and second alignment per workgroup -- for the same batch coming again (no estimate launch), makes them afresh for new start poses, and runs
+    the same way when begun asynchronously, alone or beside another batch in flight (which gets no placement: the plain launch): every result the same bits."""
+    wl = small_workload
+    c = api.Context(0)
+    try:
+        al = _aligner(c, its=8)
+        n = 1030
+        fi = (np.arange(n, dtype=np.int32) % 6).reshape(1, n)
+        x0 = wl.x0[fi[0]].astype(np.float32).copy(); x0[:, 0] += np.linspace(-0.02, 0.02, n, dtype=np.float32)
+        fixed = api.CloudSet(c, wl.scan_points, wl.scan_offsets); moving = api.CloudSet(c, wl.map_points)
+        c.set_option("align_width", 512)
+        ref = al.compute_batch([fixed], [moving], x0, fixed_index=fi)
+        c.set_option("align_width", 0)
+        prep = al.prepare_batch([fixed], [moving], x0, fixed_index=fi)
+        runs = []
+        for k in range(3):      # first: estimate by the round-3 assumption; second: by the first one's notes; third: kept
+            runs.append(prep.run()); assert c.get_option("last_align_width") == 1024
+            assert c.get_option("last_cull_estimate") == (1 if k < 2 else 0), k
+        x1 = x0.copy(); x1[:, 1] += np.float32(0.01)
+        prep.set_init_poses(x1); moved = prep.run()
+        assert c.get_option("last_align_width") == 1024 and c.get_option("last_cull_estimate") == 1
+        prep.set_init_poses(x0); prep.begin(); runs.append(prep.wait(copy=True))
+        assert c.get_option("last_align_width") == 1024
+        prep2 = al.prepare_batch([fixed], [moving], x0, fixed_index=fi)
+        prep.begin(); prep2.begin(); runs.append(prep.wait(copy=True)); runs.append(prep2.wait(copy=True))
+        for r in runs:
+            assert np.array_equal(r.pose, ref.pose) and np.array_equal(r.information, ref.information) and np.array_equal(r.status, ref.status) and np.array_equal(r.iterations, ref.iterations)
+        assert np.all(ref.status == 0) and np.all(moved.status == 0) and np.abs(moved.pose - ref.pose).max() < 1e-4      # (noise-free data: the same answer from the other start, to the bar)
+    finally:
+        c.close()
