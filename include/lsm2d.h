@@ -187,7 +187,7 @@ int  lsm2d_synchronize(lsm2d_context* ctx);
  *   queries per iteration all pass a barrier per 512, 3 - 5 x).  Calls the latency kernel would take (align_path 3) run on k_align instead: "last_align_path" reads 1.
  * "align_width": the launch form of a culled projective batch (k_align): 0 = automatic (default: workgroups of 512 threads; of 256 -- six alignments per CU round instead
  *   of four -- for batches just above a multiple of 1024 alignments, where the last few would otherwise run a round of their own on an empty chip; PACKED -- one round
- *   of 1024 workgroups, the lightest alignments two to a workgroup, one after the other -- for 1025 .. 1048 and 1537 .. 2047 alignments, and for up to 32 more than 2048 or 3072), 512 / 256 = always that
+ *   of 1024 workgroups, the lightest alignments two to a workgroup, one after the other -- for 1025 .. 1048 and 1537 .. 2047 alignments, and for up to 32 more than 2048 or 3072; with "sum_order" 1, which has no narrow form: 1025 .. 1600), 512 / 256 = always that
  *   width, 1024 = packed whenever the batch has more than 1024 and fewer than 4096 alignments and is not a multiple of 1024.  The narrow workgroups keep the wide kernel's 512 virtual threads in the bin walk and the
  *   sums, a packed workgroup runs the same kernel body twice: bit-identical results (get: "last_align_width": 512, 256, or 1024 for a packed launch).
  * "align_path": 0 = automatic (default), 1 = always one workgroup per alignment (k_align), 2 = always the split path (k_split_project +

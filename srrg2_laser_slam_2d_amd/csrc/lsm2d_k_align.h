@@ -831,6 +831,9 @@ template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kN
 __global__ __launch_bounds__(kAlignBlock, (align_min_waves<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode>())) void k_align(const AlignArgs A) {
   align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false>(A);
 }
+#ifndef LSM2D_SEQ_MIN_WAVES
+#define LSM2D_SEQ_MIN_WAVES 8
+#endif
 // The culled projective stream with up to TWO alignments per workgroup, one after the other (AlignArgs::order2): the whole body again, from its prologue -- an
 // instantiation of its own (two copies of the body), so that the headline's kernel does not carry a loop around it (in one kernel: 80 bytes of scratch).
 __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align_two(const AlignArgs A) {
@@ -839,6 +842,14 @@ __global__ __launch_bounds__(kAlignBlock, LSM2D_ALIGN_MIN_WAVES) void k_align_tw
   if (a2 < 0) return;
   __syncthreads();      // (thread 0 is done with the first one's results before anybody overwrites the state they came from)
   align_body<true, false, false, false, 5, false>(A, a2);
+}
+// ... and the same with the reference's order of summation ("sum_order" 1: no narrow form exists for it, so every batch between one and two rounds is packed)
+__global__ __launch_bounds__(kAlignBlock, LSM2D_SEQ_MIN_WAVES) void k_align_seq_two(const AlignArgs A) {
+  align_body<true, false, false, false, 5, false, true>(A, __builtin_amdgcn_readfirstlane(A.order[blockIdx.x]));
+  const int a2 = __builtin_amdgcn_readfirstlane(A.order2[blockIdx.x]);
+  if (a2 < 0) return;
+  __syncthreads();
+  align_body<true, false, false, false, 5, false, true>(A, a2);
 }
 // The culled projective stream in NARROW workgroups (align_body's kW): 256 threads, six workgroups -- 1536 alignments -- resident per round where the wide kernel
 // holds 1024.  The same results as k_align<1,0,0,0,5>, bit for bit; chosen by the host (align_width_for) for batches just above a multiple of 1024 alignments.
@@ -849,9 +860,6 @@ __global__ __launch_bounds__(kW, LSM2D_ALIGN_MIN_WAVES) void k_align_narrow(cons
 // "sum_order" 1: the same kernel with the reference's order of summation (align_body<.., kSeq = true>).  14 KB of pair records per workgroup beside the canvases (four workgroups per CU still fit the headline's shape):
 // the register budget stays that of 8 waves per SIMD -- 4 for the mixed instantiations, as above
 template <bool kHasProj, bool kHasNN, bool kHasDist, bool kHasKd = false, int kNNMode = 0>
-#ifndef LSM2D_SEQ_MIN_WAVES
-#define LSM2D_SEQ_MIN_WAVES 8
-#endif
 __global__ __launch_bounds__(kAlignBlock, ((kHasProj && (kHasNN || kHasDist || kHasKd)) ? LSM2D_MIXED_MIN_WAVES : LSM2D_SEQ_MIN_WAVES)) void k_align_seq(const AlignArgs A) {
   align_body<kHasProj, kHasNN, kHasDist, kHasKd, kNNMode, false, true>(A);
 }

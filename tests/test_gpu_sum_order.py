@@ -87,6 +87,25 @@ def test_projective_aligner_culled_stream_and_small_clouds(seq_ctx, po):
         finally:
             ctx.set_option("cull", 1); ctx.set_option("balance", 1)
         assert np.array_equal(res.pose, res2.pose) and np.array_equal(res.information, res2.information) and np.array_equal(res.stats, res2.stats)
+    # (round 6, late) a PACKED batch in the reference's order: 1040 alignments in one round of 1024 workgroups, the lightest two to a workgroup (k_align_seq_two)
+    al = api.MultiAligner2D(ctx, max_iterations=6, min_num_inliers=10)
+    al.param_slice_processors.append(api.AlignerSliceProcessorLaser2D(api.CorrespondenceFinderProjective2f(ctx, _projector()), min_num_correspondences=10))
+    n = 1040
+    fi = (np.arange(n, dtype=np.int32) % 12).reshape(1, n)
+    x0 = wl.x0[fi[0]].astype(np.float32).copy(); x0[:, 1] += np.linspace(-0.01, 0.01, n, dtype=np.float32)
+    res = al.compute_batch([fixed], [moving], x0, fixed_index=fi, want_stats=True)
+    assert ctx.get_option("last_align_width") == 1024 and ctx.get_option("last_align_path") == 1
+    ctx.set_option("align_width", 512)
+    try:
+        res2 = al.compute_batch([fixed], [moving], x0, fixed_index=fi, want_stats=True)
+        assert ctx.get_option("last_align_width") == 512
+    finally:
+        ctx.set_option("align_width", 0)
+    assert np.array_equal(res.pose, res2.pose) and np.array_equal(res.information, res2.information) and np.array_equal(res.stats, res2.stats) and np.array_equal(res.status, res2.status)
+    for i in (0, 517, 1039):
+        c = int(fi[0, i])
+        ro = po.align(po.aligner_params(6), [po.slice_params()], [wl.scan_points[wl.scan_offsets[c]:wl.scan_offsets[c + 1]]], [wl.map_points], x0[i])
+        assert_bitwise(res, i, ro, ("packed", i))
     # a small moving cloud, canvas smaller and larger than one trip of the workgroup
     small = synth.make_workload(4, 700, seed=12)
     for cols in (300, 512, 513, 1500):
