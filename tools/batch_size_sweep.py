@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput against BATCH SIZE on configs[1]'s geometry (1081-beam scans against one 100k-point map, 20 GN iterations, role A, projective finder), with fresh start
 poses every step -- VERDICT r5 item 2: one workgroup per alignment and 1024 resident workgroup slots mean a batch of 1025 .. 1100 alignments starts a second,
-nearly empty dispatch round; is there a cliff?
+nearly empty dispatch round; is there a cliff?  (Round 6: such batches run in narrow workgroups or PACKED -- `--options align_width=512|256|1024` forces a form.)
 
     python tools/batch_size_sweep.py [--sizes 128,256,...] [--out gpurun_out/batch_size_sweep.jsonl]
 
